@@ -1,0 +1,276 @@
+/*
+ * rxr.h -- C ABI of the MI355X (gfx950) rasterizer back end for Rusterix' tile rasterizer.
+ *
+ * This is the drop-in boundary.  The reference has no FFI of its own; the boundary it exposes is the
+ * Rust call
+ *
+ *     Rasterizer::setup(m2d, view, proj) .. .rasterize(&mut scene, pixels, w, h, tile_size, &assets)
+ *                                                   (reference src/rasterizer.rs:92-152, 185-193)
+ *
+ * The host side (Rust in a real deployment, the C++ mirror under rusterix_amd/csrc/host here) keeps
+ * scene set-up, Scene::project (src/scene.rs:154-200) and the Edges precompute (src/edge.rs:12-24),
+ * flattens what the per-tile loops read into the POD structs below and hands them to the entry
+ * points declared at the bottom of this file.  Everything that `rasterize` does after
+ * `scene.project(..)` (src/rasterizer.rs:256-579) happens behind this ABI on the GPU.
+ *
+ * Conventions
+ *   - plain C, no torch / C++ types; all pointers are HOST pointers unless the name says `dev`.
+ *   - every function returns RXR_OK (0) or a negative rxr_status; nothing throws or aborts.
+ *   - matrices are column-major exactly as vek stores them: m[c*4 + r] == cols[c][r].
+ *   - `usize` indices of the reference are u32 here (the shim asserts < 2^32).
+ *   - structs carry no implicit ownership: the caller keeps every buffer alive until the call
+ *     returns; the library copies what it needs.
+ */
+#ifndef RXR_H
+#define RXR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RXR_ABI_VERSION 1u
+
+typedef enum rxr_status {
+    RXR_OK = 0,
+    RXR_ERR_INVALID = -1,     /* bad argument / index out of range (the reference would panic)   */
+    RXR_ERR_NO_DEVICE = -2,   /* no HIP device, or device id out of range                         */
+    RXR_ERR_HIP = -3,         /* a HIP runtime call failed; see rxr_last_error                    */
+    RXR_ERR_UNSUPPORTED = -4, /* scene uses a feature the device path does not implement (yet)    */
+    RXR_ERR_OOM = -5
+} rxr_status;
+
+/* ---- enums mirrored from the reference ------------------------------------------------------ */
+
+/* SampleMode, src/texture.rs:5-12 */
+enum { RXR_SAMPLE_NEAREST = 0, RXR_SAMPLE_LINEAR = 1 };
+/* RepeatMode, src/texture.rs:14-25 */
+enum { RXR_REPEAT_CLAMP_XY = 0, RXR_REPEAT_REPEAT_XY = 1, RXR_REPEAT_REPEAT_X = 2, RXR_REPEAT_REPEAT_Y = 3 };
+/* PrimitiveMode, src/batch/mod.rs:4-15 */
+enum { RXR_MODE_TRIANGLES = 0, RXR_MODE_LINES = 1, RXR_MODE_LINE_STRIP = 2, RXR_MODE_LINE_LOOP = 3 };
+/* LightType, src/map/light.rs:6-14 */
+enum { RXR_LIGHT_POINT = 0, RXR_LIGHT_AMBIENT = 1, RXR_LIGHT_AMBIENT_DAYLIGHT = 2, RXR_LIGHT_SPOT = 3,
+       RXR_LIGHT_AREA = 4, RXR_LIGHT_DAYLIGHT = 5 };
+/* PixelSource, src/map/pixelsource.rs:23-37.  Only the variants the raster loops distinguish
+ * (src/rasterizer.rs:672-758, 1101-1222); every other variant is RXR_SOURCE_OTHER. */
+enum { RXR_SOURCE_OTHER = 0,         /* Off / TileId / MaterialId / Sequence / Color / ShapeFXGraphId:
+                                        3D texel [0,0,0,255], 2D texel [0,0,0,0]                   */
+       RXR_SOURCE_STATIC_TILE = 1,   /* StaticTileIndex(u16) -> assets.tile_list[index]            */
+       RXR_SOURCE_DYNAMIC_TILE = 2,  /* DynamicTileIndex(u16) -> scene.dynamic_textures[index]     */
+       RXR_SOURCE_PIXEL = 3,         /* Pixel([u8;4])                                              */
+       RXR_SOURCE_TERRAIN = 4,       /* Terrain (chunk terrain texture)                            */
+       RXR_SOURCE_MISSING = 5 };     /* EntityTile/ItemTile whose lookup failed on the host: [0,0,0,0];
+                                        a successful lookup is passed as RXR_SOURCE_DYNAMIC_TILE     */
+/* which Scene list a 3D batch came from; order of the array is submission order
+ * (src/rasterizer.rs:314-405) */
+enum { RXR_LIST_CHUNK_OPACITY = 0, RXR_LIST_CHUNK = 1, RXR_LIST_CHUNK_TERRAIN = 2, RXR_LIST_STATIC = 3,
+       RXR_LIST_DYNAMIC = 4, RXR_LIST_OVERLAY = 5 };
+/* background shader kinds (trait Shader, src/shader/mod.rs:9-33) that the device evaluates itself */
+enum { RXR_BG_NONE = 0, RXR_BG_VGRADIENT = 1 /* src/shader/vgradient.rs:11-15 */,
+       RXR_BG_HOST_PIXELS = 2 /* any other `dyn Shader`, evaluated by the host into background_pixels */ };
+
+/* rxr_frame.flags */
+#define RXR_FLAG_D2_ACTIVE             (1u << 0) /* RenderMode.d2_active, src/rendermode.rs:4-11   */
+#define RXR_FLAG_D3_ACTIVE             (1u << 1) /* RenderMode.d3_active                            */
+#define RXR_FLAG_IGNORE_BG_SHADER      (1u << 2) /* RenderMode.ignore_background_shader             */
+#define RXR_FLAG_PRESERVE_TRANSPARENCY (1u << 3) /* Rasterizer.preserve_transparency, :72           */
+#define RXR_FLAG_HAS_BACKGROUND_COLOR  (1u << 4) /* Rasterizer.background_color.is_some(), :59      */
+#define RXR_FLAG_HAS_AMBIENT           (1u << 5) /* Rasterizer.ambient_color.is_some(), :62         */
+#define RXR_FLAG_HAS_SUN               (1u << 6) /* Rasterizer.sun_dir.is_some(), :86               */
+
+/* ---- PODs ------------------------------------------------------------------------------------ */
+
+/* one Texture (src/texture.rs:46-54): RGBA8 row-major, data[(y*width + x)*4] */
+typedef struct rxr_texture {
+    const uint8_t *rgba;
+    uint32_t width, height;
+} rxr_texture;
+
+/* one Tile (src/map/tile.rs `textures: Vec<Texture>`): the animation frames of a tile; the raster
+ * loops pick textures[animation_frame % len] (src/rasterizer.rs:1104-1105) */
+typedef struct rxr_tile {
+    const rxr_texture *textures;
+    uint32_t n_textures;
+} rxr_tile;
+
+/* CompiledLight, src/map/light.rs:456-477, field for field */
+typedef struct rxr_light {
+    uint32_t light_type;
+    float position[3];
+    float color[3];
+    float intensity;
+    uint32_t emitting;
+    float start_distance, end_distance, flicker;
+    float direction[3];
+    float cone_angle;
+    float normal[3];
+    float width, height;
+    uint32_t from_linedef;
+} rxr_light;
+
+/* Edges, src/edge.rs:2-8.  `Edges` is repr(Rust) with private a/b/c; the shim needs the accessor
+ * shown in INTEGRATION.md to fill this. */
+typedef struct rxr_edges {
+    float a[3], b[3], c[3];
+    uint32_t visible;
+} rxr_edges;
+
+typedef struct rxr_source {
+    uint32_t kind;    /* RXR_SOURCE_*            */
+    uint32_t index;   /* tile index for *_TILE   */
+    uint8_t pixel[4]; /* colour for RXR_SOURCE_PIXEL */
+} rxr_source;
+
+/* Batch3D after clip_and_project (src/batch/batch3d.rs:15-78, outputs of :482-740) */
+typedef struct rxr_batch3d {
+    const float *projected_vertices;  /* [n_vertices][4] = (screen x, screen y, ndc z, clip w), :694-699 */
+    const float *clipped_uvs;         /* [n_vertices][2]                                           */
+    const float *clipped_normals;     /* [n_vertices][3]; NULL iff batch.normals.is_empty() (:1083) */
+    const uint32_t *clipped_indices;  /* [n_triangles][3]                                          */
+    const rxr_edges *edges;           /* [n_triangles]                                             */
+    uint32_t n_vertices, n_triangles;
+    uint32_t has_bounding_box;        /* bounding_box.is_some(); None => batch skipped (:978)      */
+    float bounding_box[4];            /* Rect x, y, width, height (src/rect.rs:5-10)               */
+    uint32_t repeat_mode;
+    rxr_source source;
+    float ambient_color[3];
+    int32_t shader;                   /* Option<usize>: -1 = None                                  */
+    uint32_t has_profile_id, profile_id;
+    uint32_t list;                    /* RXR_LIST_*                                                */
+    int32_t chunk;                    /* index into rxr_frame.chunks, -1 for the scene-level lists */
+} rxr_batch3d;
+
+/* Batch2D after project (src/batch/batch2d.rs:10-52, outputs of :373-425) */
+typedef struct rxr_batch2d {
+    const float *projected_vertices;  /* [n_vertices][2] */
+    const float *uvs;                 /* [n_vertices][2] */
+    const uint32_t *indices;          /* [n_triangles][3]; for Lines only .0/.1 are used (:902)     */
+    const rxr_edges *edges;           /* [n_triangles]   */
+    uint32_t n_vertices, n_triangles;
+    uint32_t has_bounding_box;
+    float bounding_box[4];
+    uint32_t mode;                    /* RXR_MODE_* */
+    uint32_t repeat_mode;
+    rxr_source source;
+    uint32_t receives_light;
+    int32_t shader;
+    int32_t chunk;
+} rxr_batch2d;
+
+/* (BBox, occlusion) entry of MapMini.occluded_sectors / Chunk.occluded_sectors
+ * (src/map/mini.rs:58-66, src/chunk.rs:154-161, src/map/bbox.rs:35-40) */
+typedef struct rxr_occluder {
+    float min[2], max[2];
+    float occlusion;
+} rxr_occluder;
+
+/* CompiledLinedef start/end as used by MapMini::is_visible (src/map/mini.rs:68-95) */
+typedef struct rxr_linedef {
+    float start[2], end[2];
+} rxr_linedef;
+
+/* the per-chunk data the raster loops read (src/chunk.rs); chunks in the host's iteration order */
+typedef struct rxr_chunk {
+    const rxr_occluder *occluders;
+    uint32_t n_occluders;
+} rxr_chunk;
+
+/* everything `rasterize` reads from `self` and `scene` after projection */
+typedef struct rxr_frame {
+    uint32_t abi_version;             /* RXR_ABI_VERSION                                           */
+    uint32_t width, height;           /* framebuffer size in pixels                                */
+    uint32_t tile_size;               /* the caller's tile_size; accepted for API parity only: the
+                                         result does not depend on it   */
+    float inverse_view[16];           /* Rasterizer.inverse_view_matrix, :43, :97                  */
+    float inverse_projection[16];     /* Rasterizer.inverse_projection_matrix, :44, :116           */
+    float camera_pos[3];              /* :98-102                                                   */
+    float translationd2[2];           /* :104-110                                                  */
+    float scaled2;
+    uint32_t hash_anim;               /* hash_u32(animation_frame), :199-208                       */
+    uint64_t animation_frame;         /* scene.animation_frame (usize)                             */
+    uint32_t flags;                   /* RXR_FLAG_*                                                */
+    uint8_t background_color[4];
+    float ambient[4];
+    float sun_dir[3];
+    float day_factor;
+    uint32_t sample_mode;             /* RXR_SAMPLE_*; rasterizer-wide (:1119)                     */
+    float time;
+    uint32_t background_kind;         /* RXR_BG_*; only read when D3 is off or pixel is... see :292 */
+    const uint8_t *background_pixels; /* RXR_BG_HOST_PIXELS: width*height*4                        */
+
+    const rxr_batch3d *batches3d;     /* submission order, src/rasterizer.rs:314-405               */
+    uint32_t n_batches3d;
+    const rxr_batch2d *batches2d;     /* submission order, :503-552                                */
+    uint32_t n_batches2d;
+    const rxr_light *lights;          /* scene.lights followed by scene.dynamic_lights (:1373)     */
+    uint32_t n_lights;
+    const rxr_occluder *occluders;    /* Rasterizer.mapmini.occluded_sectors                       */
+    uint32_t n_occluders;
+    const rxr_linedef *linedefs;      /* Rasterizer.mapmini.linedefs                               */
+    uint32_t n_linedefs;
+    const rxr_chunk *chunks;
+    uint32_t n_chunks;
+    uint32_t n_shader_programs;       /* scene.shaders.len(); a batch whose shader index resolves
+                                         to a program makes the call return RXR_ERR_UNSUPPORTED     */
+} rxr_frame;
+
+/* timings of the last rendered frame (HIP events on the context's stream), microseconds */
+typedef struct rxr_stats {
+    float setup_us;      /* triangle set-up + binning kernels */
+    float raster_us;     /* the tile raster / shade kernel    */
+    float total_us;      /* first kernel start .. last kernel end */
+    uint32_t n_triangles3d, n_triangles2d, n_bin_entries;
+    uint32_t tiles_x, tiles_y;
+} rxr_stats;
+
+typedef struct rxr_ctx rxr_ctx;
+
+/* ---- entry points ----------------------------------------------------------------------------
+ * Each replaces a slice of Rasterizer::rasterize (src/rasterizer.rs:185-580):                     */
+
+/* creates a context on HIP device `device_id` (one process per GPU; no reference counterpart --
+ * the reference uses rayon's global pool, src/rasterizer.rs:273-275) */
+int rxr_create(rxr_ctx **out, int device_id);
+void rxr_destroy(rxr_ctx *ctx);
+/* last error text for this context (or for rxr_create when ctx == NULL) */
+const char *rxr_last_error(const rxr_ctx *ctx);
+/* number of visible HIP devices, 0 if none (never fails) */
+int rxr_device_count(void);
+
+/* uploads assets.tile_list (static) and scene.dynamic_textures (dynamic); replaces the texture
+ * reads at src/rasterizer.rs:1103-1137 / :674-704.  Call again only when the textures change. */
+int rxr_set_textures(rxr_ctx *ctx, const rxr_tile *static_tiles, uint32_t n_static,
+                     const rxr_tile *dynamic_tiles, uint32_t n_dynamic);
+
+/* validates + flattens a projected frame and copies it to HBM (replaces nothing in the reference:
+ * it is the host->device hand-over).  The frame stays resident until the next upload. */
+int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *frame);
+
+/* renders rows [row0,row1) of the resident frame into the context's device framebuffer.
+ * Replaces the tile list + rayon tile loop, src/rasterizer.rs:256-557.  Asynchronous. */
+int rxr_render_rows(rxr_ctx *ctx, uint32_t row0, uint32_t row1);
+/* same, but writes the band into caller-owned DEVICE memory (`dev_pixels` points at row `row0`,
+ * rows are `width*4` bytes apart) on HIP stream `hip_stream` (hipStream_t, NULL = context stream).
+ * Used by the multi-GPU host, which then gathers the bands with RCCL. */
+int rxr_render_rows_to(rxr_ctx *ctx, uint32_t row0, uint32_t row1, void *dev_pixels, void *hip_stream);
+
+/* copies rows [row0,row1) of the context's framebuffer into host `pixels` (full-frame layout:
+ * row r goes to pixels + r*width*4).  Replaces the serial tile->framebuffer copy, :559-579.
+ * Blocks until the bytes have landed. */
+int rxr_download_rows(rxr_ctx *ctx, uint8_t *pixels, uint32_t row0, uint32_t row1);
+
+/* the whole drop-in call: upload + render all rows + download.  `pixels` is width*height*4 bytes
+ * of host memory, fully overwritten, as in the reference (src/rasterizer.rs:185-193). */
+int rxr_rasterize(rxr_ctx *ctx, const rxr_frame *frame, uint8_t *pixels);
+
+int rxr_synchronize(rxr_ctx *ctx);
+int rxr_get_stats(rxr_ctx *ctx, rxr_stats *out);
+/* device pointer of the context framebuffer (width*height*4 bytes of the last uploaded frame) */
+void *rxr_device_framebuffer(rxr_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RXR_H */
