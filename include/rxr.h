@@ -256,6 +256,20 @@ int rxr_render_rows(rxr_ctx *ctx, uint32_t row0, uint32_t row1);
  * Used by the multi-GPU host, which then gathers the bands with RCCL. */
 int rxr_render_rows_to(rxr_ctx *ctx, uint32_t row0, uint32_t row1, void *dev_pixels, void *hip_stream);
 
+/* multi-GPU sharding primitive: renders every `stride`-th stripe of RXR_STRIPE_ROWS pixel rows,
+ * starting at stripe `first`, into a COMPACT caller-owned DEVICE buffer: local stripe j (frame rows
+ * (first + j*stride)*RXR_STRIPE_ROWS ...) lands at dev_pixels + j*RXR_STRIPE_ROWS*width*4.  The
+ * buffer must hold ceil((n_stripes - first) / stride) stripes.  Rank r of N renders (first=r,
+ * stride=N); the compact buffers are then all-gathered (RCCL) and de-interleaved. */
+#define RXR_STRIPE_ROWS 16u
+int rxr_render_stripes_to(rxr_ctx *ctx, uint32_t first, uint32_t stride, void *dev_pixels, void *hip_stream);
+
+/* per-launch kernel timing for the benchmark: after rxr_profile_begin(ctx, n) every render records
+ * HIP events (on the stream it launches on) around its set-up kernels and its raster kernel into a
+ * ring of n slots; rxr_profile_read synchronizes and returns the durations in microseconds. */
+int rxr_profile_begin(rxr_ctx *ctx, uint32_t max_frames);
+int rxr_profile_read(rxr_ctx *ctx, float *setup_us, float *raster_us, uint32_t capacity, uint32_t *n_out);
+
 /* copies rows [row0,row1) of the context's framebuffer into host `pixels` (full-frame layout:
  * row r goes to pixels + r*width*4).  Replaces the serial tile->framebuffer copy, :559-579.
  * Blocks until the bytes have landed. */

@@ -225,6 +225,14 @@ int orc_rasterizer_rasterize(void *r, void *scene, uint8_t *pixels, uint32_t w, 
     return rasterize(rb->r, *(Scene *)scene, pixels, w, h, tile_size, *(Assets *)assets, rb->n_threads);
 }
 
+// host-side projection only (Scene::project with the rasterizer's matrices)
+int orc_scene_project(void *r, void *scene, uint32_t w, uint32_t h) {
+    Rasterizer &x = ((RasterizerBox *)r)->r;
+    return scene_project(*(Scene *)scene, x.has_m2d ? &x.projection_matrix_2d : nullptr, x.view_matrix, x.projection_matrix, (float)w, (float)h)
+               ? 0
+               : RXR_ERR_INVALID;
+}
+
 // ---- introspection of projected batches (after rasterize) --------------------------------------------
 int orc_scene_batch3d_counts(void *s, int list, int chunk, uint32_t i, uint32_t *nv, uint32_t *nt, uint32_t *has_normals) {
     auto *l = list3d((Scene *)s, list, chunk);

@@ -325,6 +325,7 @@ def make_api(lib: C.CDLL, prefix: str, name: str):
         rasterizer_mapmini_add_linedef=fn("rasterizer_mapmini_add_linedef", None, vp, f32, f32, f32, f32),
         rasterizer_get_derived=fn("rasterizer_get_derived", None, vp, pf, pf, pf),
         rasterizer_rasterize=fn("rasterizer_rasterize", i32, vp, vp, pb, u32, u32, u32, vp),
+        scene_project=fn("scene_project", i32, vp, vp, u32, u32),
         scene_batch3d_counts=fn("scene_batch3d_counts", i32, vp, i32, i32, u32, pu, pu, pu),
         scene_batch3d_copy=fn("scene_batch3d_copy", i32, vp, i32, i32, u32, pf, pf, pf, pu, pf, pf),
         camera_orbit=fn("camera_orbit", None, pf, f32, f32, f32, f32, f32, f32, f32, f32, pf, pf),
@@ -668,6 +669,13 @@ def make_api(lib: C.CDLL, prefix: str, name: str):
             iv, ip, cp = np.zeros(16, np.float32), np.zeros(16, np.float32), np.zeros(3, np.float32)
             L.rasterizer_get_derived(self._h, _fp(iv), _fp(ip), _fp(cp))
             return iv, ip, cp
+
+        def project(self, scene, width, height):
+            """Host-side `scene.project(..)` only (reference src/scene.rs:154-200)."""
+            rc = L.scene_project(self._h, scene._h, width, height)
+            if rc != 0:
+                raise RasterizeError(rc, "projection failed (batch without normals panics in the reference)")
+            return self
 
         def rasterize(self, scene, pixels, width, height, tile_size, assets):
             assert pixels.dtype == np.uint8 and pixels.size == width * height * 4 and pixels.flags["C_CONTIGUOUS"]

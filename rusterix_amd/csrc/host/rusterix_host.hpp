@@ -1,0 +1,205 @@
+// rusterix_host.hpp -- C++ mirror of the reference's host-side API for the rasterizer path.
+//
+// In a real deployment this layer is Rusterix itself (Rust): Scene / Batch2D / Batch3D / Assets /
+// Rasterizer with `Rasterizer::setup(..).rasterize(&mut scene, pixels, w, h, tile_size, &assets)`.
+// No Rust toolchain exists in this image, so the same surface is mirrored in C++ with the same
+// names, argument meaning and error behaviour.  What stays on the host is exactly what the
+// north-star keeps there: scene set-up, Scene::project (batch projection + near clipping) and the
+// Edges precompute.  Everything after `scene.project(..)` crosses the C ABI of include/rxr.h.
+//
+// Storage is flat (std::vector<float> / uint32_t / rxr_edges) so that a projected batch can be handed
+// to rxr_batch3d / rxr_batch2d without repacking.
+//
+// All citations are file:line under /root/reference/.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../../include/rusterix_vek.hpp"
+#include "../../../include/rxr.h"
+
+namespace rusterix {
+
+using rvek::Mat3;
+using rvek::Mat4;
+using rvek::Vec2;
+using rvek::Vec3;
+using rvek::Vec4;
+
+using Pixel = uint8_t[4];
+
+enum class CullMode { Off = 0, Front = 1, Back = 2 };  // src/batch/mod.rs:17-26
+
+// src/map/pixelsource.rs:23-37
+struct PixelSource {
+    uint32_t kind = RXR_SOURCE_OTHER;
+    uint32_t index = 0;
+    uint8_t pixel[4] = {0, 0, 0, 0};
+    static PixelSource Off() { return {}; }
+    static PixelSource StaticTileIndex(uint16_t i) { PixelSource s; s.kind = RXR_SOURCE_STATIC_TILE; s.index = i; return s; }
+    static PixelSource DynamicTileIndex(uint16_t i) { PixelSource s; s.kind = RXR_SOURCE_DYNAMIC_TILE; s.index = i; return s; }
+    static PixelSource FromPixel(const uint8_t p[4]) { PixelSource s; s.kind = RXR_SOURCE_PIXEL; for (int i = 0; i < 4; ++i) s.pixel[i] = p[i]; return s; }
+};
+
+// src/texture.rs:46-54
+struct Texture {
+    std::vector<uint8_t> data;
+    uint32_t width = 0, height = 0;
+};
+// src/map/tile.rs
+struct Tile {
+    std::vector<Texture> textures;
+};
+// src/server/assets.rs
+uint64_t next_generation();  // process-wide unique stamps (never reused, unlike addresses)
+struct Assets {
+    std::vector<Tile> tile_list;
+    uint64_t generation = next_generation();  // re-stamped on every mutation; lets the rasterizer skip texture re-uploads
+    Assets &textures(std::vector<Tile> tiles) { tile_list = std::move(tiles); generation = next_generation(); return *this; }
+};
+
+// src/rect.rs
+struct Rect {
+    float x = 0, y = 0, width = 0, height = 0;
+};
+
+using CompiledLight = rxr_light;  // src/map/light.rs:456-477
+
+// src/batch/batch3d.rs:15-78
+class Batch3D {
+public:
+    std::vector<float> vertices;           // [n][4]
+    std::vector<uint32_t> indices;         // [m][3]
+    std::vector<float> uvs;                // [n][2]
+    std::vector<float> normals;            // [n][3] or empty
+    std::vector<float> projected_vertices; // [n'][4]
+    std::vector<uint32_t> clipped_indices; // [m'][3]
+    std::vector<float> clipped_uvs;        // [n'][2]
+    std::vector<float> clipped_normals;    // [n'][3]
+    std::vector<rxr_edges> edges;          // [m']
+    bool has_bounding_box = false;
+    Rect bounding_box;
+    uint32_t repeat_mode_ = RXR_REPEAT_CLAMP_XY;
+    CullMode cull_mode_ = CullMode::Off;
+    PixelSource source_;
+    Mat4 transform_3d = Mat4::identity();
+    bool receives_light_ = true;
+    Vec3 ambient_color_{0, 0, 0};
+    int shader_ = -1;
+    bool has_profile_id = false;
+    uint32_t profile_id_ = 0;
+
+    static Batch3D empty() { return Batch3D(); }
+    static Batch3D make(const float *verts4, size_t nv, const uint32_t *idx3, size_t nt, const float *uvs2);  // Batch3D::new, :109-137
+    static Batch3D from_box(float x, float y, float z, float w, float h, float d);                          // :140-229
+    static Batch3D from_obj(const std::string &text);                                                      // :407-419 + src/wavefront.rs
+    void add(const float *verts4, size_t nv, const uint32_t *idx3, size_t nt, const float *uvs2);          // :238-253
+    void compute_vertex_normals();                                                                          // :771-809
+    // :482-740.  Returns false where the reference panics (normals shorter than vertices, :605-607).
+    bool clip_and_project(const Mat4 &view, const Mat4 &proj, float viewport_width, float viewport_height);
+
+    size_t vertex_count() const { return vertices.size() / 4; }
+    size_t triangle_count() const { return indices.size() / 3; }
+};
+
+// src/batch/batch2d.rs:10-52
+class Batch2D {
+public:
+    uint32_t mode_ = RXR_MODE_TRIANGLES;
+    std::vector<float> vertices;           // [n][2]
+    std::vector<uint32_t> indices;         // [m][3]
+    std::vector<float> uvs;                // [n][2]
+    std::vector<float> projected_vertices; // [n][2]
+    std::vector<rxr_edges> edges;          // [m]
+    bool has_bounding_box = false;
+    Rect bounding_box;
+    uint32_t repeat_mode_ = RXR_REPEAT_CLAMP_XY;
+    PixelSource source_;
+    bool receives_light_ = true;
+    int shader_ = -1;
+
+    static Batch2D make(const float *verts2, size_t nv, const uint32_t *idx3, size_t nt, const float *uvs2);  // :83-106
+    static Batch2D from_rectangle(float x, float y, float w, float h);                                       // :109-127
+    void project(const Mat3 *matrix);                                                                         // :373-425
+};
+
+// src/map/mini.rs (fields the raster loops read)
+struct MapMini {
+    std::vector<rxr_occluder> occluded_sectors;
+    std::vector<rxr_linedef> linedefs;
+};
+
+// src/chunk.rs (fields the raster loops read)
+struct Chunk {
+    std::vector<Batch3D> batches3d_opacity, batches3d;
+    std::vector<Batch2D> batches2d;
+    std::vector<CompiledLight> lights;
+    std::vector<rxr_occluder> occluded_sectors;
+};
+
+// src/scene.rs:8-50
+class Scene {
+public:
+    uint32_t background = RXR_BG_NONE;  // Option<Box<dyn Shader>>: VGrayGradientShader is evaluated on the device
+    std::vector<CompiledLight> lights, dynamic_lights;
+    std::vector<Batch3D> d3_static, d3_dynamic, d3_overlay;
+    std::vector<Batch2D> d2_static, d2_dynamic;
+    std::vector<Tile> dynamic_textures;
+    uint64_t dynamic_textures_generation = next_generation();
+    size_t animation_frame = 1;
+    std::vector<Chunk> chunks;
+
+    // src/scene.rs:154-200.  false where the reference panics.
+    bool project(const Mat3 *m2d, const Mat4 &view, const Mat4 &proj, float width, float height);
+};
+
+// src/rasterizer.rs:35-193
+class Rasterizer {
+public:
+    bool d2_active = true, d3_active = true, ignore_background_shader = false;  // RenderMode
+    bool has_m2d = false;
+    Mat3 projection_matrix_2d = Mat3::identity();
+    Mat4 view_matrix = Mat4::identity(), projection_matrix = Mat4::identity();
+    Mat4 inverse_view_matrix = Mat4::identity(), inverse_projection_matrix = Mat4::identity();
+    float width = 0, height = 0;
+    Vec3 camera_pos;
+    MapMini mapmini;
+    uint32_t sample_mode_ = RXR_SAMPLE_NEAREST;
+    uint32_t hash_anim = 0;
+    bool has_background_color = false;
+    uint8_t background_color[4] = {0, 0, 0, 0};
+    bool has_ambient = false;
+    Vec4 ambient_color;
+    Vec2 translationd2{0, 0};
+    float scaled2 = 1.0f;
+    bool preserve_transparency = false;
+    float time_ = 0.0f;
+    bool has_sun = false;
+    Vec3 sun_dir;
+    float day_factor = 0.0f;
+
+    static Rasterizer setup(const Mat3 *projection_matrix_2d, const Mat4 &view, const Mat4 &proj);  // :92-152
+
+    // :185-580.  Projects the scene on the host, flattens it and renders it on the GPU through the
+    // C ABI.  Returns RXR_OK or a negative rxr_status (the reference panics / has no error path).
+    int rasterize(Scene &scene, uint8_t *pixels, size_t width, size_t height, size_t tile_size, const Assets &assets);
+    // the same up to and including the host->device hand-over (project + flatten + rxr_upload_frame);
+    // callers then drive rxr_render_rows / rxr_render_rows_to themselves (bench, multi-GPU host)
+    int upload(Scene &scene, size_t width, size_t height, size_t tile_size, const Assets &assets);
+};
+
+// the process-wide device context (one process per GPU).  Device index from RXR_DEVICE, else
+// LOCAL_RANK, else 0.
+rxr_ctx *context(std::string *error = nullptr);
+void set_device(int device);
+const std::string &last_error();
+
+// cameras: src/camera/d3orbit.rs:23-56,186-195 and src/camera/d3firstp.rs:17-42
+void orbit_camera(Vec3 center, float distance, float azimuth, float elevation, float fov, float near, float far, float w,
+                  float h, Mat4 &view, Mat4 &proj);
+void firstp_camera(Vec3 position, Vec3 center, float fov, float near, float far, float w, float h, Mat4 &view, Mat4 &proj);
+
+uint32_t hash_u32(uint32_t seed);  // src/rasterizer.rs:199-207
+
+}  // namespace rusterix

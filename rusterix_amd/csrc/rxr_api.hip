@@ -1,0 +1,844 @@
+// rxr_api.hip -- implementation of the C ABI declared in include/rxr.h (host side, compiled by hipcc).
+//
+// One rxr_ctx == one HIP device == one process (multi-GPU hosts run one process per GPU and gather
+// the rendered row bands with RCCL, see rusterix_amd/distributed.py).
+//
+// Frame hand-over: rxr_upload_frame validates the projected frame, packs every per-frame array into
+// ONE pinned staging blob and issues ONE host->device copy; the kernels of rxr_kernels.hip then run
+// entirely out of HBM.  There is no CPU fallback anywhere in this file.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rxr_device.h"
+
+extern "C" void rxr_launch_setup(const RasterParams *P, hipStream_t s);
+extern "C" void rxr_launch_scan(const RasterParams *P, hipStream_t s);
+extern "C" void rxr_launch_fill(const RasterParams *P, hipStream_t s);
+extern "C" void rxr_launch_raster(const RasterParams *P, hipStream_t s);
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+struct TileRange {
+    uint32_t first, n;
+};
+
+struct ProfSlot {
+    hipEvent_t e0, e1, e2;
+};
+
+// one render launch sequence.  Band mode: rows [row0,row1), stride 1.  Stripe mode: every `stride`-th
+// 16-row stripe from `first` into a compact buffer.
+struct RenderSpec {
+    uint32_t row0, row1;
+    uint32_t tile_y0, tile_stride, tiles_y;
+    bool compact, external;
+};
+
+}  // namespace
+
+struct rxr_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // textures
+    DevBuf d_tex, d_texels;
+    std::vector<DevTexDesc> h_tex;
+    std::vector<TileRange> tiles_static, tiles_dynamic;
+
+    // frame blob
+    void *h_stage = nullptr;
+    size_t h_stage_cap = 0;
+    DevBuf d_frame;
+    DevBuf d_tri_setup, d_tri_shade, d_bins, d_list, d_large, d_counters, d_fb;
+    uint32_t *h_counters = nullptr;  // pinned, CNT_WORDS
+    uint32_t list_capacity = 0;
+
+    bool has_frame = false;
+    RasterParams P{};       // template for the resident frame (pointers resolved)
+    uint32_t n_tris2d = 0;
+
+    // last render
+    bool rendered = false;
+    RenderSpec last_spec{};
+    void *last_out = nullptr;
+    hipStream_t last_stream = nullptr;
+    hipStream_t upload_ordered_on = nullptr;  // stream already ordered behind the last upload
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev_upload = nullptr;
+    hipEvent_t last_e0 = nullptr, last_e1 = nullptr, last_e2 = nullptr;
+    std::vector<ProfSlot> prof;  // rxr_profile_begin ring
+    size_t prof_next = 0;
+    rxr_stats stats{};
+};
+
+namespace {
+
+int fail(rxr_ctx *ctx, int code, const std::string &msg) {
+    if (ctx) ctx->err = msg;
+    else g_create_error = msg;
+    return code;
+}
+
+#define HIPCHK(ctx, call)                                                                                  \
+    do {                                                                                                   \
+        hipError_t e_ = (call);                                                                            \
+        if (e_ != hipSuccess)                                                                              \
+            return fail(ctx, RXR_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));              \
+    } while (0)
+
+int ensure(rxr_ctx *ctx, DevBuf &b, size_t bytes) {
+    if (bytes <= b.cap) return RXR_OK;
+    if (b.p) {
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        HIPCHK(ctx, hipFree(b.p));
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    size_t cap = bytes + bytes / 4 + 4096;
+    hipError_t e = hipMalloc(&b.p, cap);
+    if (e != hipSuccess) return fail(ctx, RXR_ERR_OOM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    b.cap = cap;
+    return RXR_OK;
+}
+
+int ensure_stage(rxr_ctx *ctx, size_t bytes) {
+    if (bytes <= ctx->h_stage_cap) return RXR_OK;
+    if (ctx->h_stage) {
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        HIPCHK(ctx, hipHostFree(ctx->h_stage));
+        ctx->h_stage = nullptr;
+        ctx->h_stage_cap = 0;
+    }
+    size_t cap = bytes + bytes / 4 + 4096;
+    hipError_t e = hipHostMalloc(&ctx->h_stage, cap, hipHostMallocDefault);
+    if (e != hipSuccess) return fail(ctx, RXR_ERR_OOM, std::string("hipHostMalloc: ") + hipGetErrorString(e));
+    ctx->h_stage_cap = cap;
+    return RXR_OK;
+}
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+uint32_t pack_px(const uint8_t p[4]) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+
+// Rust `x as isize` narrowed to i32 for the Bresenham end points (rasterizer.rs:1785-1788);
+// coordinates beyond +-2^30 are rejected at upload (the walk would not terminate in a frame's time)
+bool to_isize32(float x, int32_t &out) {
+    if (!(x == x)) {
+        out = 0;
+        return true;
+    }
+    if (x <= -1073741824.0f || x >= 1073741824.0f) return false;
+    out = (int32_t)x;
+    return true;
+}
+
+struct Layout {
+    size_t off_b3, off_base, off_pv, off_uv, off_nrm, off_idx, off_edges, off_lights, off_occ, off_ld, off_chunks, off_b2,
+        off_t2, off_l2, off_items, off_bg, total;
+};
+
+}  // namespace
+
+extern "C" {
+
+int rxr_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char *rxr_last_error(const rxr_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int rxr_create(rxr_ctx **out, int device_id) {
+    if (!out) return fail(nullptr, RXR_ERR_INVALID, "rxr_create: out is NULL");
+    *out = nullptr;
+    int n = rxr_device_count();
+    if (n <= 0) return fail(nullptr, RXR_ERR_NO_DEVICE, "rxr_create: no HIP device visible (there is no CPU fallback)");
+    if (device_id < 0 || device_id >= n) return fail(nullptr, RXR_ERR_NO_DEVICE, "rxr_create: device id out of range");
+    rxr_ctx *ctx = new rxr_ctx();
+    ctx->device = device_id;
+    hipError_t e = hipSetDevice(device_id);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->ev2);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->ev_upload);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_counters, CNT_WORDS * sizeof(uint32_t), hipHostMallocDefault);
+    if (e != hipSuccess) {
+        std::string msg = std::string("rxr_create: ") + hipGetErrorString(e);
+        delete ctx;
+        return fail(nullptr, RXR_ERR_HIP, msg);
+    }
+    memset(ctx->h_counters, 0, CNT_WORDS * sizeof(uint32_t));
+    *out = ctx;
+    return RXR_OK;
+}
+
+void rxr_destroy(rxr_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    DevBuf *bufs[] = {&ctx->d_tex, &ctx->d_texels, &ctx->d_frame, &ctx->d_tri_setup, &ctx->d_tri_shade, &ctx->d_bins,
+                      &ctx->d_list, &ctx->d_large, &ctx->d_counters, &ctx->d_fb};
+    for (DevBuf *b : bufs)
+        if (b->p) (void)hipFree(b->p);
+    if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+    if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->ev2) (void)hipEventDestroy(ctx->ev2);
+    if (ctx->ev_upload) (void)hipEventDestroy(ctx->ev_upload);
+    for (ProfSlot &p : ctx->prof) {
+        (void)hipEventDestroy(p.e0);
+        (void)hipEventDestroy(p.e1);
+        (void)hipEventDestroy(p.e2);
+    }
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int rxr_set_textures(rxr_ctx *ctx, const rxr_tile *static_tiles, uint32_t n_static, const rxr_tile *dynamic_tiles,
+                     uint32_t n_dynamic) {
+    if (!ctx) return RXR_ERR_INVALID;
+    if ((n_static && !static_tiles) || (n_dynamic && !dynamic_tiles)) return fail(ctx, RXR_ERR_INVALID, "rxr_set_textures: NULL tile array");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    ctx->h_tex.clear();
+    ctx->tiles_static.clear();
+    ctx->tiles_dynamic.clear();
+    size_t texels = 0;
+    auto scan = [&](const rxr_tile *tiles, uint32_t n, std::vector<TileRange> &out) -> int {
+        for (uint32_t i = 0; i < n; ++i) {
+            TileRange r{(uint32_t)ctx->h_tex.size(), tiles[i].n_textures};
+            if (tiles[i].n_textures && !tiles[i].textures) return RXR_ERR_INVALID;
+            for (uint32_t k = 0; k < tiles[i].n_textures; ++k) {
+                const rxr_texture &t = tiles[i].textures[k];
+                if (!t.rgba || t.width == 0 || t.height == 0 || t.width > 32768 || t.height > 32768) return RXR_ERR_INVALID;
+                DevTexDesc d{};
+                d.offset = (uint32_t)texels;
+                d.w = t.width;
+                d.h = t.height;
+                bool opaque = true;
+                const uint8_t *p = t.rgba;
+                size_t n_px = (size_t)t.width * t.height;
+                for (size_t q = 0; q < n_px; ++q)
+                    if (p[q * 4 + 3] != 255) {
+                        opaque = false;
+                        break;
+                    }
+                d.all_opaque = opaque ? 1u : 0u;
+                ctx->h_tex.push_back(d);
+                texels += align_up(n_px, 4);
+                if (texels >= (1ull << 32)) return RXR_ERR_INVALID;
+            }
+            out.push_back(r);
+        }
+        return RXR_OK;
+    };
+    if (scan(static_tiles, n_static, ctx->tiles_static) != RXR_OK || scan(dynamic_tiles, n_dynamic, ctx->tiles_dynamic) != RXR_OK)
+        return fail(ctx, RXR_ERR_INVALID, "rxr_set_textures: bad texture (NULL data, zero or oversized extent)");
+
+    size_t desc_bytes = ctx->h_tex.size() * sizeof(DevTexDesc);
+    size_t bytes = texels * 4;
+    int rc;
+    if ((rc = ensure(ctx, ctx->d_tex, desc_bytes ? desc_bytes : 16)) != RXR_OK) return rc;
+    if ((rc = ensure(ctx, ctx->d_texels, bytes ? bytes : 16)) != RXR_OK) return rc;
+    if ((rc = ensure_stage(ctx, bytes + desc_bytes + 64)) != RXR_OK) return rc;
+    // stage texels then descriptors
+    uint8_t *st = (uint8_t *)ctx->h_stage;
+    size_t ti = 0;
+    auto stage = [&](const rxr_tile *tiles, uint32_t n) {
+        for (uint32_t i = 0; i < n; ++i)
+            for (uint32_t k = 0; k < tiles[i].n_textures; ++k) {
+                const rxr_texture &t = tiles[i].textures[k];
+                memcpy(st + (size_t)ctx->h_tex[ti].offset * 4, t.rgba, (size_t)t.width * t.height * 4);
+                ++ti;
+            }
+    };
+    stage(static_tiles, n_static);
+    stage(dynamic_tiles, n_dynamic);
+    if (bytes) HIPCHK(ctx, hipMemcpyAsync(ctx->d_texels.p, st, bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (desc_bytes) {
+        memcpy(st + bytes, ctx->h_tex.data(), desc_bytes);
+        HIPCHK(ctx, hipMemcpyAsync(ctx->d_tex.p, st + bytes, desc_bytes, hipMemcpyHostToDevice, ctx->stream));
+    }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return RXR_OK;
+}
+
+// resolves a PixelSource to (tex index | constant texel); see include/rxr.h RXR_SOURCE_*
+static int resolve_source(rxr_ctx *ctx, const rxr_source &src, bool is_3d, int chunk, uint64_t animation_frame, int32_t &tex,
+                          uint32_t &pixel) {
+    tex = -1;
+    pixel = 0;
+    auto from_tiles = [&](const std::vector<TileRange> &tiles) -> int {
+        if (src.index >= tiles.size()) {
+            if (is_3d) return RXR_ERR_INVALID;  // tile_list[index] panics, rasterizer.rs:1103
+            pixel = 0;                          // 2D uses .get(): [0,0,0,0], :685-687
+            return RXR_OK;
+        }
+        const TileRange &r = tiles[src.index];
+        if (r.n == 0) return RXR_ERR_INVALID;  // `% 0` panics
+        tex = (int32_t)(r.first + (uint32_t)(animation_frame % r.n));
+        return RXR_OK;
+    };
+    switch (src.kind) {
+        case RXR_SOURCE_STATIC_TILE: return from_tiles(ctx->tiles_static);
+        case RXR_SOURCE_DYNAMIC_TILE: return from_tiles(ctx->tiles_dynamic);
+        case RXR_SOURCE_PIXEL: pixel = pack_px(src.pixel); return RXR_OK;
+        case RXR_SOURCE_MISSING: pixel = 0; return RXR_OK;
+        case RXR_SOURCE_TERRAIN:
+            if (chunk >= 0) pixel = 0;                       // chunk without a terrain texture, chunk.rs:150
+            else pixel = is_3d ? 0xFF0000FFu : 0u;           // [255,0,0,255] (:1218) | [0,0,0,0] (:753)
+            return RXR_OK;
+        default: pixel = is_3d ? 0xFF000000u : 0u; return RXR_OK;  // [0,0,0,255] (:1221) | [0,0,0,0] (:757)
+    }
+}
+
+int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
+    if (!ctx) return RXR_ERR_INVALID;
+    if (!f) return fail(ctx, RXR_ERR_INVALID, "rxr_upload_frame: frame is NULL");
+    if (f->abi_version != RXR_ABI_VERSION) return fail(ctx, RXR_ERR_INVALID, "rxr_upload_frame: abi_version mismatch");
+    if (f->width == 0 || f->height == 0 || f->width > 32768 || f->height > 32768)
+        return fail(ctx, RXR_ERR_INVALID, "rxr_upload_frame: width/height must be in 1..32768");
+    if (f->tile_size == 0) return fail(ctx, RXR_ERR_INVALID, "rxr_upload_frame: tile_size 0 (step_by(0) panics in the reference)");
+    if ((f->n_batches3d && !f->batches3d) || (f->n_batches2d && !f->batches2d) || (f->n_lights && !f->lights) ||
+        (f->n_occluders && !f->occluders) || (f->n_linedefs && !f->linedefs) || (f->n_chunks && !f->chunks))
+        return fail(ctx, RXR_ERR_INVALID, "rxr_upload_frame: NULL array with non-zero count");
+    if (f->background_kind == RXR_BG_HOST_PIXELS && !f->background_pixels)
+        return fail(ctx, RXR_ERR_INVALID, "rxr_upload_frame: RXR_BG_HOST_PIXELS without background_pixels");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    ctx->has_frame = false;
+
+    // ---- pass 1: validate + size ---------------------------------------------------------------
+    size_t n_v3 = 0, n_t3 = 0;
+    bool has_opacity = false;
+    for (uint32_t i = 0; i < f->n_batches3d; ++i) {
+        const rxr_batch3d &b = f->batches3d[i];
+        if (b.n_triangles && (!b.clipped_indices || !b.edges)) return fail(ctx, RXR_ERR_INVALID, "batch3d: NULL indices/edges");
+        if (b.n_vertices && (!b.projected_vertices || !b.clipped_uvs)) return fail(ctx, RXR_ERR_INVALID, "batch3d: NULL vertex arrays");
+        if (b.chunk >= (int32_t)f->n_chunks) return fail(ctx, RXR_ERR_INVALID, "batch3d: chunk index out of range");
+        if (b.shader >= 0 && (uint32_t)b.shader < f->n_shader_programs)
+            return fail(ctx, RXR_ERR_UNSUPPORTED, "batch3d uses a Rusteria shader program: not implemented on the device yet");
+        for (uint32_t t = 0; t < b.n_triangles * 3u; ++t)
+            if (b.clipped_indices[t] >= b.n_vertices) return fail(ctx, RXR_ERR_INVALID, "batch3d: vertex index out of range");
+        if (b.list == RXR_LIST_CHUNK_OPACITY) has_opacity = true;
+        n_v3 += b.n_vertices;
+        n_t3 += b.n_triangles;
+    }
+    if (n_v3 >= (1ull << 31) || n_t3 >= (1ull << 31)) return fail(ctx, RXR_ERR_INVALID, "frame too large (>= 2^31 vertices or triangles)");
+    size_t n_t2 = 0, n_l2 = 0, n_items = 0;
+    for (uint32_t i = 0; i < f->n_batches2d; ++i) {
+        const rxr_batch2d &b = f->batches2d[i];
+        if (b.n_triangles && (!b.indices || (b.mode == RXR_MODE_TRIANGLES && !b.edges))) return fail(ctx, RXR_ERR_INVALID, "batch2d: NULL indices/edges");
+        if (b.n_vertices && (!b.projected_vertices || !b.uvs)) return fail(ctx, RXR_ERR_INVALID, "batch2d: NULL vertex arrays");
+        if (b.chunk >= (int32_t)f->n_chunks) return fail(ctx, RXR_ERR_INVALID, "batch2d: chunk index out of range");
+        if (b.mode > RXR_MODE_LINE_LOOP) return fail(ctx, RXR_ERR_INVALID, "batch2d: bad mode");
+        if (b.shader >= 0 && (uint32_t)b.shader < f->n_shader_programs)
+            return fail(ctx, RXR_ERR_UNSUPPORTED, "batch2d uses a Rusteria shader program: not implemented on the device yet");
+        if (b.mode == RXR_MODE_TRIANGLES || b.mode == RXR_MODE_LINES)
+            for (uint32_t t = 0; t < b.n_triangles * 3u; ++t) {
+                if (b.mode == RXR_MODE_LINES && (t % 3u) == 2u) continue;  // only .0/.1 are read, :902
+                if (b.indices[t] >= b.n_vertices) return fail(ctx, RXR_ERR_INVALID, "batch2d: vertex index out of range");
+            }
+        switch (b.mode) {
+            case RXR_MODE_TRIANGLES: n_t2 += b.n_triangles; break;
+            case RXR_MODE_LINES: n_l2 += b.n_triangles; break;
+            case RXR_MODE_LINE_STRIP: n_l2 += b.n_vertices ? b.n_vertices - 1 : 0; break;
+            default: n_l2 += b.n_vertices; break;
+        }
+        n_items += 1;
+    }
+    size_t n_occ_total = f->n_occluders;
+    for (uint32_t c = 0; c < f->n_chunks; ++c) {
+        if (f->chunks[c].n_occluders && !f->chunks[c].occluders) return fail(ctx, RXR_ERR_INVALID, "chunk: NULL occluders");
+        n_occ_total += f->chunks[c].n_occluders;
+    }
+
+    Layout L{};
+    size_t o = 0;
+    auto take = [&](size_t bytes) {
+        size_t at = o;
+        o = align_up(o + (bytes ? bytes : 16), 256);
+        return at;
+    };
+    L.off_b3 = take(f->n_batches3d * sizeof(DevBatch));
+    L.off_base = take((f->n_batches3d + 1) * sizeof(uint32_t));
+    L.off_pv = take(n_v3 * 16);
+    L.off_uv = take(n_v3 * 8);
+    L.off_nrm = take(n_v3 * 12);
+    L.off_idx = take(n_t3 * 12);
+    L.off_edges = take(n_t3 * sizeof(rxr_edges));
+    L.off_lights = take(f->n_lights * sizeof(rxr_light));
+    L.off_occ = take(n_occ_total * sizeof(rxr_occluder));
+    L.off_ld = take(f->n_linedefs * sizeof(rxr_linedef));
+    L.off_chunks = take(f->n_chunks * sizeof(ChunkRange));
+    L.off_b2 = take(f->n_batches2d * sizeof(DevBatch));
+    L.off_t2 = take(n_t2 * sizeof(Tri2D));
+    L.off_l2 = take(n_l2 * sizeof(Line2D));
+    L.off_items = take(n_items * sizeof(Item2D));
+    L.off_bg = take(f->background_kind == RXR_BG_HOST_PIXELS ? (size_t)f->width * f->height * 4 : 0);
+    L.total = o;
+
+    int rc;
+    if ((rc = ensure_stage(ctx, L.total)) != RXR_OK) return rc;
+    if ((rc = ensure(ctx, ctx->d_frame, L.total)) != RXR_OK) return rc;
+    // the staging blob may still be in flight from the previous upload
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    uint8_t *st = (uint8_t *)ctx->h_stage;
+
+    // ---- pass 2: flatten -----------------------------------------------------------------------
+    const float W = (float)f->width, H = (float)f->height;
+    DevBatch *b3 = (DevBatch *)(st + L.off_b3);
+    uint32_t *base = (uint32_t *)(st + L.off_base);
+    size_t vcur = 0, tcur = 0;
+    for (uint32_t i = 0; i < f->n_batches3d; ++i) {
+        const rxr_batch3d &b = f->batches3d[i];
+        DevBatch d{};
+        d.vert_base = (uint32_t)vcur;
+        d.tri_base = (uint32_t)tcur;
+        d.n_tris = b.n_triangles;
+        d.n_verts = b.n_vertices;
+        d.flags = 0;
+        if (b.clipped_normals) d.flags |= DB_HAS_NORMALS;
+        if (b.has_profile_id) d.flags |= DB_HAS_PROFILE;
+        if (b.list == RXR_LIST_CHUNK_OPACITY) d.flags |= DB_OPACITY_LIST;
+        d.profile_id = b.profile_id;
+        d.repeat_mode = b.repeat_mode;
+        d.chunk = b.chunk;
+        memcpy(d.ambient, b.ambient_color, 12);
+        // batch-level box reject, rasterizer.rs:978-983, evaluated against the whole screen
+        bool keep = b.has_bounding_box && b.n_triangles > 0;
+        if (keep) {
+            const float *bb = b.bounding_box;
+            keep = bb[0] < W && (bb[0] + bb[2]) > 0.0f && bb[1] < H && (bb[1] + bb[3]) > 0.0f;
+        }
+        if (keep) {
+            rc = resolve_source(ctx, b.source, true, b.chunk, f->animation_frame, d.tex, d.pixel);
+            if (rc != RXR_OK) return fail(ctx, rc, "batch3d: texture tile index out of range or tile without textures (the reference panics)");
+            if (d.tex >= 0) {
+                if (!ctx->h_tex[d.tex].all_opaque) d.flags |= DB_ALPHA_TEST;
+            } else if ((d.pixel >> 24) != 255u && b.list != RXR_LIST_CHUNK_OPACITY) {
+                keep = false;  // encoded alpha != 255: never written (rasterizer.rs:1408)
+            }
+        }
+        if (!keep) d.flags |= DB_SKIP;
+        b3[i] = d;
+        base[i] = (uint32_t)tcur;
+        if (b.n_vertices) {
+            memcpy(st + L.off_pv + vcur * 16, b.projected_vertices, (size_t)b.n_vertices * 16);
+            memcpy(st + L.off_uv + vcur * 8, b.clipped_uvs, (size_t)b.n_vertices * 8);
+            if (b.clipped_normals) memcpy(st + L.off_nrm + vcur * 12, b.clipped_normals, (size_t)b.n_vertices * 12);
+        }
+        if (b.n_triangles) {
+            memcpy(st + L.off_idx + tcur * 12, b.clipped_indices, (size_t)b.n_triangles * 12);
+            memcpy(st + L.off_edges + tcur * sizeof(rxr_edges), b.edges, (size_t)b.n_triangles * sizeof(rxr_edges));
+        }
+        vcur += b.n_vertices;
+        tcur += b.n_triangles;
+    }
+    base[f->n_batches3d] = (uint32_t)tcur;
+
+    if (f->n_lights) memcpy(st + L.off_lights, f->lights, f->n_lights * sizeof(rxr_light));
+    {
+        rxr_occluder *oc = (rxr_occluder *)(st + L.off_occ);
+        if (f->n_occluders) memcpy(oc, f->occluders, f->n_occluders * sizeof(rxr_occluder));
+        ChunkRange *cr = (ChunkRange *)(st + L.off_chunks);
+        size_t cur = f->n_occluders;
+        for (uint32_t c = 0; c < f->n_chunks; ++c) {
+            cr[c].occ_first = (uint32_t)cur;
+            cr[c].occ_count = f->chunks[c].n_occluders;
+            if (f->chunks[c].n_occluders) memcpy(oc + cur, f->chunks[c].occluders, f->chunks[c].n_occluders * sizeof(rxr_occluder));
+            cur += f->chunks[c].n_occluders;
+        }
+    }
+    if (f->n_linedefs) memcpy(st + L.off_ld, f->linedefs, f->n_linedefs * sizeof(rxr_linedef));
+
+    DevBatch *b2 = (DevBatch *)(st + L.off_b2);
+    Tri2D *t2 = (Tri2D *)(st + L.off_t2);
+    Line2D *l2 = (Line2D *)(st + L.off_l2);
+    Item2D *items = (Item2D *)(st + L.off_items);
+    size_t t2cur = 0, l2cur = 0, icur = 0;
+    for (uint32_t i = 0; i < f->n_batches2d; ++i) {
+        const rxr_batch2d &b = f->batches2d[i];
+        DevBatch d{};
+        d.n_tris = b.n_triangles;
+        d.n_verts = b.n_vertices;
+        d.mode = b.mode;
+        d.repeat_mode = b.repeat_mode;
+        d.chunk = b.chunk;
+        d.flags = b.receives_light ? DB_RECEIVES_LIGHT : 0u;
+        // batch-level box reject with pad 0.5, rasterizer.rs:594-600, against the whole screen
+        bool keep = b.has_bounding_box != 0;
+        if (keep) {
+            const float *bb = b.bounding_box;
+            const float pad = 0.5f;
+            keep = bb[0] < W + pad && (bb[0] + bb[2]) > 0.0f - pad && bb[1] < H + pad && (bb[1] + bb[3]) > 0.0f - pad;
+        }
+        if (keep) {
+            rc = resolve_source(ctx, b.source, false, b.chunk, f->animation_frame, d.tex, d.pixel);
+            if (rc != RXR_OK) return fail(ctx, rc, "batch2d: tile without textures (the reference panics)");
+        } else {
+            d.flags |= DB_SKIP;
+        }
+        b2[i] = d;
+        if (!keep) continue;
+        Item2D it{};
+        it.batch = i;
+        if (b.mode == RXR_MODE_TRIANGLES) {
+            it.first = (uint32_t)t2cur;
+            it.is_lines = 0;
+            for (uint32_t t = 0; t < b.n_triangles; ++t) {
+                const uint32_t *ix = b.indices + 3 * (size_t)t;
+                const rxr_edges &e = b.edges[t];
+                Tri2D T{};
+                memcpy(T.ea, e.a, 12);
+                memcpy(T.eb, e.b, 12);
+                memcpy(T.ec, e.c, 12);
+                T.v0x = b.projected_vertices[2 * ix[0]]; T.v0y = b.projected_vertices[2 * ix[0] + 1];
+                T.v1x = b.projected_vertices[2 * ix[1]]; T.v1y = b.projected_vertices[2 * ix[1] + 1];
+                T.v2x = b.projected_vertices[2 * ix[2]]; T.v2y = b.projected_vertices[2 * ix[2] + 1];
+                T.u0 = b.uvs[2 * ix[0]]; T.v0 = b.uvs[2 * ix[0] + 1];
+                T.u1 = b.uvs[2 * ix[1]]; T.v1 = b.uvs[2 * ix[1] + 1];
+                T.u2 = b.uvs[2 * ix[2]]; T.v2 = b.uvs[2 * ix[2] + 1];
+                T.batch = i;
+                T.visible = e.visible;
+                t2[t2cur++] = T;
+            }
+            it.count = b.n_triangles;
+        } else {
+            it.first = (uint32_t)l2cur;
+            it.is_lines = 1;
+            const uint8_t white[4] = {255, 255, 255, 255};
+            uint32_t color = pack_px(b.source.kind == RXR_SOURCE_PIXEL ? b.source.pixel : white);  // :911-915
+            auto push = [&](uint32_t ia, uint32_t ib) -> bool {
+                Line2D Ln{};
+                if (!to_isize32(b.projected_vertices[2 * ia], Ln.x0) || !to_isize32(b.projected_vertices[2 * ia + 1], Ln.y0) ||
+                    !to_isize32(b.projected_vertices[2 * ib], Ln.x1) || !to_isize32(b.projected_vertices[2 * ib + 1], Ln.y1))
+                    return false;
+                Ln.batch = i;
+                Ln.color = color;
+                l2[l2cur++] = Ln;
+                return true;
+            };
+            bool ok = true;
+            uint32_t before = (uint32_t)l2cur;
+            if (b.mode == RXR_MODE_LINES) {
+                for (uint32_t t = 0; t < b.n_triangles && ok; ++t) ok = push(b.indices[3 * (size_t)t], b.indices[3 * (size_t)t + 1]);
+            } else if (b.mode == RXR_MODE_LINE_STRIP) {
+                for (uint32_t k = 0; k + 1 < b.n_vertices && ok; ++k) ok = push(k, k + 1);
+            } else {
+                for (uint32_t k = 0; k < b.n_vertices && ok; ++k) ok = push(k, (k + 1) % b.n_vertices);
+            }
+            if (!ok) return fail(ctx, RXR_ERR_UNSUPPORTED, "batch2d: line end point beyond +-2^30");
+            it.count = (uint32_t)l2cur - before;
+        }
+        items[icur++] = it;
+    }
+    if (f->background_kind == RXR_BG_HOST_PIXELS) memcpy(st + L.off_bg, f->background_pixels, (size_t)f->width * f->height * 4);
+
+    // ---- device scratch ------------------------------------------------------------------------
+    uint32_t tiles_x = (f->width + RXR_TILE_W - 1) / RXR_TILE_W, tiles_y_all = (f->height + RXR_TILE_H - 1) / RXR_TILE_H;
+    size_t n_bins = (size_t)tiles_x * tiles_y_all;
+    if ((rc = ensure(ctx, ctx->d_tri_setup, (n_t3 ? n_t3 : 1) * sizeof(TriSetup))) != RXR_OK) return rc;
+    if ((rc = ensure(ctx, ctx->d_tri_shade, (n_t3 ? n_t3 : 1) * sizeof(TriShade))) != RXR_OK) return rc;
+    if ((rc = ensure(ctx, ctx->d_bins, (3 * n_bins + 8) * sizeof(uint32_t))) != RXR_OK) return rc;
+    if ((rc = ensure(ctx, ctx->d_large, (n_t3 ? n_t3 : 1) * sizeof(uint32_t))) != RXR_OK) return rc;
+    if ((rc = ensure(ctx, ctx->d_counters, CNT_WORDS * sizeof(uint32_t))) != RXR_OK) return rc;
+    size_t want_list = std::max<size_t>(1u << 20, n_t3 * 4);
+    if (want_list > ctx->list_capacity) {
+        if ((rc = ensure(ctx, ctx->d_list, want_list * sizeof(uint32_t))) != RXR_OK) return rc;
+        ctx->list_capacity = (uint32_t)std::min<size_t>(ctx->d_list.cap / sizeof(uint32_t), 0xFFFFFFF0u);
+    }
+    if ((rc = ensure(ctx, ctx->d_fb, (size_t)f->width * f->height * 4)) != RXR_OK) return rc;
+
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_frame.p, st, L.total, hipMemcpyHostToDevice, ctx->stream));
+
+    // ---- parameter block -----------------------------------------------------------------------
+    RasterParams &P = ctx->P;
+    memset(&P, 0, sizeof(P));
+    P.width = f->width;
+    P.height = f->height;
+    P.tiles_x = tiles_x;
+    P.flags = f->flags;
+    P.fwidth = W;
+    P.fheight = H;
+    memcpy(P.inv_view, f->inverse_view, 64);
+    memcpy(P.inv_proj, f->inverse_projection, 64);
+    memcpy(P.cam, f->camera_pos, 12);
+    memcpy(P.translationd2, f->translationd2, 8);
+    P.scaled2 = f->scaled2;
+    P.hash_anim = f->hash_anim;
+    P.sample_mode = f->sample_mode;
+    P.background_color = pack_px(f->background_color);
+    P.background_kind = f->background_kind;
+    memcpy(P.ambient, f->ambient, 16);
+    memcpy(P.sun_dir, f->sun_dir, 12);
+    P.day_factor = f->day_factor;
+    P.n_tris3d = (uint32_t)n_t3;
+    P.n_batches3d = f->n_batches3d;
+    P.n_lights = f->n_lights;
+    P.n_occluders = f->n_occluders;
+    P.n_linedefs = f->n_linedefs;
+    P.n_items2d = (uint32_t)icur;
+    P.any_lights = f->n_lights ? 1u : 0u;
+    P.has_opacity = has_opacity ? 1u : 0u;
+    P.list_capacity = ctx->list_capacity;
+    uint8_t *d = (uint8_t *)ctx->d_frame.p;
+    P.pv = (const float4 *)(d + L.off_pv);
+    P.uv = (const float2 *)(d + L.off_uv);
+    P.nrm = (const float *)(d + L.off_nrm);
+    P.idx = (const uint32_t *)(d + L.off_idx);
+    P.edges = (const rxr_edges *)(d + L.off_edges);
+    P.batches3d = (const DevBatch *)(d + L.off_b3);
+    P.batch_tri_base = (const uint32_t *)(d + L.off_base);
+    P.tri_setup = (TriSetup *)ctx->d_tri_setup.p;
+    P.tri_shade = (TriShade *)ctx->d_tri_shade.p;
+    P.bin_count = (uint32_t *)ctx->d_bins.p;
+    P.bin_offset = P.bin_count + n_bins + 1;
+    P.bin_cursor = P.bin_offset + n_bins + 1;
+    P.bin_list = (uint32_t *)ctx->d_list.p;
+    P.large_list = (uint32_t *)ctx->d_large.p;
+    P.counters = (uint32_t *)ctx->d_counters.p;
+    P.lights = (const rxr_light *)(d + L.off_lights);
+    P.occluders = (const rxr_occluder *)(d + L.off_occ);
+    P.linedefs = (const rxr_linedef *)(d + L.off_ld);
+    P.chunks = (const ChunkRange *)(d + L.off_chunks);
+    P.batches2d = (const DevBatch *)(d + L.off_b2);
+    P.tri2d = (const Tri2D *)(d + L.off_t2);
+    P.line2d = (const Line2D *)(d + L.off_l2);
+    P.items2d = (const Item2D *)(d + L.off_items);
+    P.tex = (const DevTexDesc *)ctx->d_tex.p;
+    P.texels = (const uint32_t *)ctx->d_texels.p;
+    P.bg_pixels = (const uint32_t *)(d + L.off_bg);
+    ctx->n_tris2d = (uint32_t)t2cur;
+    ctx->has_frame = true;
+    ctx->rendered = false;
+    ctx->upload_ordered_on = nullptr;
+    return RXR_OK;
+}
+
+static int render_impl(rxr_ctx *ctx, const RenderSpec &spec, void *dev_pixels, hipStream_t s) {
+    if (!ctx) return RXR_ERR_INVALID;
+    if (!ctx->has_frame) return fail(ctx, RXR_ERR_INVALID, "render: no frame uploaded");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (!ctx->upload_ordered_on || ctx->upload_ordered_on != s) {
+        if (s != ctx->stream) {
+            // the upload ran on the context stream: order the external stream behind it (once per upload)
+            HIPCHK(ctx, hipEventRecord(ctx->ev_upload, ctx->stream));
+            HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_upload, 0));
+        }
+        ctx->upload_ordered_on = s;
+    }
+    RasterParams P = ctx->P;
+    P.row0 = spec.row0;
+    P.row1 = spec.row1;
+    P.tile_y0 = spec.tile_y0;
+    P.tile_stride = spec.tile_stride;
+    P.tiles_y = spec.tiles_y;
+    P.compact = spec.compact ? 1u : 0u;
+    P.out = (uint32_t *)dev_pixels;
+    P.out_row_stride = P.width;
+    P.out_base_row = (spec.external && !spec.compact) ? (int64_t)spec.row0 : 0;
+    const size_t n_bins = (size_t)P.tiles_x * P.tiles_y;
+
+    hipEvent_t e0 = ctx->ev0, e1 = ctx->ev1, e2 = ctx->ev2;
+    if (!ctx->prof.empty()) {
+        ProfSlot &ps = ctx->prof[ctx->prof_next % ctx->prof.size()];
+        e0 = ps.e0;
+        e1 = ps.e1;
+        e2 = ps.e2;
+        ctx->prof_next++;
+    }
+    ctx->last_e0 = e0;
+    ctx->last_e1 = e1;
+    ctx->last_e2 = e2;
+    HIPCHK(ctx, hipEventRecord(e0, s));
+    if (P.tiles_y && (P.flags & RXR_FLAG_D3_ACTIVE)) {
+        HIPCHK(ctx, hipMemsetAsync(P.counters, 0, CNT_WORDS * sizeof(uint32_t), s));
+        HIPCHK(ctx, hipMemsetAsync(P.bin_count, 0, (n_bins + 1) * sizeof(uint32_t), s));
+        rxr_launch_setup(&P, s);
+        rxr_launch_scan(&P, s);
+        rxr_launch_fill(&P, s);
+    } else if (P.tiles_y) {
+        HIPCHK(ctx, hipMemsetAsync(P.counters, 0, CNT_WORDS * sizeof(uint32_t), s));
+        HIPCHK(ctx, hipMemsetAsync(P.bin_offset, 0, (n_bins + 1) * sizeof(uint32_t), s));
+    }
+    HIPCHK(ctx, hipEventRecord(e1, s));
+    rxr_launch_raster(&P, s);
+    HIPCHK(ctx, hipEventRecord(e2, s));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_counters, P.counters, CNT_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(ctx, hipGetLastError());
+    ctx->rendered = true;
+    ctx->last_spec = spec;
+    ctx->last_out = dev_pixels;
+    ctx->last_stream = s;
+    ctx->stats.tiles_x = P.tiles_x;
+    ctx->stats.tiles_y = P.tiles_y;
+    ctx->stats.n_triangles3d = P.n_tris3d;
+    ctx->stats.n_triangles2d = ctx->n_tris2d;
+    return RXR_OK;
+}
+
+static int band_spec(rxr_ctx *ctx, uint32_t row0, uint32_t row1, bool external, RenderSpec &spec) {
+    if (!ctx->has_frame) return fail(ctx, RXR_ERR_INVALID, "render: no frame uploaded");
+    if (row0 > row1 || row1 > ctx->P.height) return fail(ctx, RXR_ERR_INVALID, "render: bad row range");
+    spec.row0 = row0;
+    spec.row1 = row1;
+    spec.tile_y0 = row0 / RXR_TILE_H;
+    spec.tile_stride = 1;
+    spec.tiles_y = row1 > row0 ? (row1 + RXR_TILE_H - 1) / RXR_TILE_H - spec.tile_y0 : 0;
+    spec.compact = false;
+    spec.external = external;
+    return RXR_OK;
+}
+
+int rxr_render_rows(rxr_ctx *ctx, uint32_t row0, uint32_t row1) {
+    if (!ctx) return RXR_ERR_INVALID;
+    RenderSpec spec{};
+    int rc = band_spec(ctx, row0, row1, false, spec);
+    if (rc != RXR_OK) return rc;
+    return render_impl(ctx, spec, ctx->d_fb.p, ctx->stream);
+}
+
+int rxr_render_rows_to(rxr_ctx *ctx, uint32_t row0, uint32_t row1, void *dev_pixels, void *hip_stream) {
+    if (!ctx) return RXR_ERR_INVALID;
+    if (!dev_pixels) return fail(ctx, RXR_ERR_INVALID, "rxr_render_rows_to: dev_pixels is NULL");
+    RenderSpec spec{};
+    int rc = band_spec(ctx, row0, row1, true, spec);
+    if (rc != RXR_OK) return rc;
+    return render_impl(ctx, spec, dev_pixels, hip_stream ? (hipStream_t)hip_stream : ctx->stream);
+}
+
+int rxr_render_stripes_to(rxr_ctx *ctx, uint32_t first, uint32_t stride, void *dev_pixels, void *hip_stream) {
+    if (!ctx) return RXR_ERR_INVALID;
+    if (!dev_pixels) return fail(ctx, RXR_ERR_INVALID, "rxr_render_stripes_to: dev_pixels is NULL");
+    if (!ctx->has_frame) return fail(ctx, RXR_ERR_INVALID, "render: no frame uploaded");
+    if (stride == 0) return fail(ctx, RXR_ERR_INVALID, "rxr_render_stripes_to: stride 0");
+    const uint32_t n_stripes = (ctx->P.height + RXR_TILE_H - 1) / RXR_TILE_H;
+    RenderSpec spec{};
+    spec.row0 = 0;
+    spec.row1 = ctx->P.height;
+    spec.tile_y0 = first;
+    spec.tile_stride = stride;
+    spec.tiles_y = first < n_stripes ? (n_stripes - first + stride - 1) / stride : 0;
+    spec.compact = true;
+    spec.external = true;
+    return render_impl(ctx, spec, dev_pixels, hip_stream ? (hipStream_t)hip_stream : ctx->stream);
+}
+
+int rxr_profile_begin(rxr_ctx *ctx, uint32_t max_frames) {
+    if (!ctx) return RXR_ERR_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc = rxr_synchronize(ctx);
+    if (rc != RXR_OK) return rc;
+    for (ProfSlot &p : ctx->prof) {
+        (void)hipEventDestroy(p.e0);
+        (void)hipEventDestroy(p.e1);
+        (void)hipEventDestroy(p.e2);
+    }
+    ctx->prof.clear();
+    ctx->prof_next = 0;
+    if (max_frames > 65536) max_frames = 65536;
+    for (uint32_t i = 0; i < max_frames; ++i) {
+        ProfSlot p{};
+        HIPCHK(ctx, hipEventCreate(&p.e0));
+        HIPCHK(ctx, hipEventCreate(&p.e1));
+        HIPCHK(ctx, hipEventCreate(&p.e2));
+        ctx->prof.push_back(p);
+    }
+    return RXR_OK;
+}
+
+int rxr_profile_read(rxr_ctx *ctx, float *setup_us, float *raster_us, uint32_t capacity, uint32_t *n_out) {
+    if (!ctx || !n_out) return RXR_ERR_INVALID;
+    int rc = rxr_synchronize(ctx);
+    if (rc != RXR_OK) return rc;
+    uint32_t n = (uint32_t)std::min<size_t>(std::min<size_t>(ctx->prof_next, ctx->prof.size()), capacity);
+    for (uint32_t i = 0; i < n; ++i) {
+        float a = 0, b = 0;
+        HIPCHK(ctx, hipEventElapsedTime(&a, ctx->prof[i].e0, ctx->prof[i].e1));
+        HIPCHK(ctx, hipEventElapsedTime(&b, ctx->prof[i].e1, ctx->prof[i].e2));
+        if (setup_us) setup_us[i] = a * 1000.0f;
+        if (raster_us) raster_us[i] = b * 1000.0f;
+    }
+    *n_out = n;
+    ctx->prof_next = 0;
+    return RXR_OK;
+}
+
+// waits for the last render and re-renders with a larger bin list if it overflowed
+int rxr_synchronize(rxr_ctx *ctx) {
+    if (!ctx) return RXR_ERR_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    for (int attempt = 0; attempt < 4; ++attempt) {
+        if (ctx->last_stream && ctx->last_stream != ctx->stream) HIPCHK(ctx, hipStreamSynchronize(ctx->last_stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        if (!ctx->rendered) return RXR_OK;
+        ctx->stats.n_bin_entries = ctx->h_counters[CNT_ENTRIES];
+        if (!ctx->h_counters[CNT_OVERFLOW]) {
+            float a = 0, b = 0;
+            if (ctx->last_e0 && hipEventElapsedTime(&a, ctx->last_e0, ctx->last_e1) == hipSuccess &&
+                hipEventElapsedTime(&b, ctx->last_e1, ctx->last_e2) == hipSuccess) {
+                ctx->stats.setup_us = a * 1000.0f;
+                ctx->stats.raster_us = b * 1000.0f;
+                ctx->stats.total_us = (a + b) * 1000.0f;
+            }
+            return RXR_OK;
+        }
+        // bin list overflow: grow and render the same launch again
+        size_t want = (size_t)ctx->h_counters[CNT_ENTRIES] + ctx->h_counters[CNT_ENTRIES] / 2 + 1024;
+        int rc = ensure(ctx, ctx->d_list, want * sizeof(uint32_t));
+        if (rc != RXR_OK) return rc;
+        ctx->list_capacity = (uint32_t)std::min<size_t>(ctx->d_list.cap / sizeof(uint32_t), 0xFFFFFFF0u);
+        ctx->P.bin_list = (uint32_t *)ctx->d_list.p;
+        ctx->P.list_capacity = ctx->list_capacity;
+        rc = render_impl(ctx, ctx->last_spec, ctx->last_out, ctx->last_stream);
+        if (rc != RXR_OK) return rc;
+    }
+    return fail(ctx, RXR_ERR_OOM, "bin list kept overflowing");
+}
+
+int rxr_download_rows(rxr_ctx *ctx, uint8_t *pixels, uint32_t row0, uint32_t row1) {
+    if (!ctx || !pixels) return RXR_ERR_INVALID;
+    if (!ctx->has_frame || row0 > row1 || row1 > ctx->P.height) return fail(ctx, RXR_ERR_INVALID, "rxr_download_rows: bad row range or no frame");
+    int rc = rxr_synchronize(ctx);
+    if (rc != RXR_OK) return rc;
+    size_t off = (size_t)row0 * ctx->P.width * 4, bytes = (size_t)(row1 - row0) * ctx->P.width * 4;
+    if (bytes) {
+        HIPCHK(ctx, hipMemcpyAsync(pixels + off, (uint8_t *)ctx->d_fb.p + off, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return RXR_OK;
+}
+
+int rxr_rasterize(rxr_ctx *ctx, const rxr_frame *frame, uint8_t *pixels) {
+    if (!ctx || !pixels) return RXR_ERR_INVALID;
+    int rc = rxr_upload_frame(ctx, frame);
+    if (rc != RXR_OK) return rc;
+    rc = rxr_render_rows(ctx, 0, frame->height);
+    if (rc != RXR_OK) return rc;
+    return rxr_download_rows(ctx, pixels, 0, frame->height);
+}
+
+int rxr_get_stats(rxr_ctx *ctx, rxr_stats *out) {
+    if (!ctx || !out) return RXR_ERR_INVALID;
+    *out = ctx->stats;
+    return RXR_OK;
+}
+
+void *rxr_device_framebuffer(rxr_ctx *ctx) { return ctx ? ctx->d_fb.p : nullptr; }
+
+}  // extern "C"

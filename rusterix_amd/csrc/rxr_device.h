@@ -1,0 +1,162 @@
+// rxr_device.h -- HBM data layout shared by the C-ABI implementation (rxr_api.hip) and the
+// kernels (rxr_kernels.hip).  See DESIGN.md "Data layout in HBM".
+#pragma once
+#include <stdint.h>
+
+#include "../../include/rxr.h"
+
+// GPU tile = binning granule = one 256-thread workgroup.  16x16 pixels; a wave covers 16x4.
+#define RXR_TILE_W 16
+#define RXR_TILE_H 16
+#define RXR_TILE_THREADS (RXR_TILE_W * RXR_TILE_H)
+// a triangle whose clamped pixel box touches more bins than this goes to the "large" list that
+// every tile scans (with a scalar box reject) instead of being inserted into each bin
+#define RXR_LARGE_BINS 48
+
+// one texture frame; texels live in one RGBA8 pool
+struct DevTexDesc {
+    uint32_t offset;  // in texels (uint32 units) from the pool base
+    uint32_t w, h;
+    uint32_t all_opaque;  // every texel has alpha == 255
+};
+
+enum : uint32_t {
+    DB_HAS_NORMALS = 1u << 0,
+    DB_HAS_PROFILE = 1u << 1,
+    DB_ALPHA_TEST = 1u << 2,  // texel alpha may be != 255: the z-write rule (rasterizer.rs:1408) needs a per-fragment sample
+    DB_SKIP = 1u << 3,        // nothing of this batch can ever be written (no bbox / NaN bbox / constant alpha != 255)
+    DB_RECEIVES_LIGHT = 1u << 4,
+    DB_OPACITY_LIST = 1u << 5,
+};
+
+// flattened Batch3D / Batch2D header.  The texel source is resolved on the host at upload time:
+// tex >= 0 -> sample DevTexDesc[tex]; tex < 0 -> constant texel `pixel`.
+struct DevBatch {
+    uint32_t vert_base;  // into the vertex pools
+    uint32_t tri_base;   // global index of this batch's first triangle (submission order)
+    uint32_t n_tris;
+    uint32_t flags;
+    int32_t tex;
+    uint32_t pixel;  // RGBA8 little endian (r | g<<8 | b<<16 | a<<24)
+    uint32_t repeat_mode;
+    uint32_t profile_id;
+    float ambient[3];
+    int32_t chunk;
+    uint32_t mode;  // 2D: RXR_MODE_*
+    uint32_t n_verts;
+    uint32_t pad[2];
+};  // 64 B
+
+// per-triangle record for the visibility loop (written by k_setup3d).  96 B = 6 x 16 B.
+struct TriSetup {
+    float ea[3], eb[3], ec[3];  // Edges a/b/c (edge.rs:2-8)
+    float v0x, v0y, v1x, v1y, v2x, v2y;
+    float area;               // ac.x*ab.y - ac.y*ab.x (rasterizer.rs:1767)
+    float iz0, iz1, iz2;      // 1.0 / v.z (rasterizer.rs:1054-1055)
+    uint32_t batch;
+    uint32_t bx;              // pixel box: min_x | max_x << 16 (whole screen clamp, exclusive max)
+    uint32_t by;              // min_y | max_y << 16
+    uint32_t pad[2];
+};
+
+// per-triangle record for shading the winning fragment.  80 B = 5 x 16 B.
+struct TriShade {
+    float iw0, iw1, iw2;                     // 1.0 / v.w
+    float u0w, u1w, u2w, v0w, v1w, v2w;      // uv / w (rasterizer.rs:1062-1067)
+    float n0[3], n1[3], n2[3];
+    uint32_t pad[2];
+};
+
+// 2D triangle (flattened on the host at upload; few of them).  96 B.
+struct Tri2D {
+    float ea[3], eb[3], ec[3];
+    float v0x, v0y, v1x, v1y, v2x, v2y;
+    float u0, v0, u1, v1, u2, v2;
+    uint32_t batch;
+    uint32_t visible;
+    uint32_t pad;
+};
+
+// 2D line segment for the Bresenham modes (rasterizer.rs:901-955), endpoints already cast `as isize`
+struct Line2D {
+    int32_t x0, y0, x1, y1;
+    uint32_t batch;
+    uint32_t color;
+    uint32_t pad[2];
+};
+
+// ordered 2D work item: either a triangle range or a line range of one batch
+struct Item2D {
+    uint32_t batch;
+    uint32_t first, count;  // into tri2d[] or line2d[]
+    uint32_t is_lines;
+};
+
+struct ChunkRange {
+    uint32_t occ_first, occ_count;
+};
+
+// device counters (one small buffer, cleared per render)
+enum { CNT_LARGE = 0, CNT_ENTRIES = 1, CNT_OVERFLOW = 2, CNT_WORDS = 4 };
+
+// kernel parameter block (passed by value; lives in the kernarg segment -> scalar loads)
+struct RasterParams {
+    uint32_t width, height;
+    uint32_t row0, row1;           // band of rows this launch renders
+    uint32_t tiles_x, tiles_y;     // tile grid of the band
+    uint32_t tile_y0;              // first tile row of the launch (in whole-frame tile coordinates)
+    uint32_t tile_stride;          // launch tile row l is frame tile row tile_y0 + l*tile_stride (1 = contiguous band)
+    uint32_t compact;              // 1: output row = l*RXR_TILE_H + ly (stripe buffer); 0: frame addressing
+    uint32_t flags;                // RXR_FLAG_*
+    float fwidth, fheight;
+    float inv_view[16], inv_proj[16];
+    float cam[3];
+    float translationd2[2];
+    float scaled2;
+    uint32_t hash_anim;
+    uint32_t sample_mode;
+    uint32_t background_color;     // RGBA8 packed
+    uint32_t background_kind;
+    float ambient[4];
+    float sun_dir[3];
+    float day_factor;
+
+    uint32_t n_tris3d, n_batches3d, n_lights, n_occluders, n_linedefs, n_items2d, any_lights, has_opacity;
+    uint32_t list_capacity;
+
+    // geometry inputs (indexed, as handed over by the host)
+    const float4 *pv;              // projected_vertices
+    const float2 *uv;              // clipped_uvs
+    const float *nrm;              // clipped_normals, 3 floats per vertex
+    const uint32_t *idx;           // clipped_indices, 3 per triangle
+    const rxr_edges *edges;
+    const DevBatch *batches3d;
+    const uint32_t *batch_tri_base;  // n_batches3d + 1 prefix array for the triangle -> batch search
+
+    // set-up outputs
+    TriSetup *tri_setup;
+    TriShade *tri_shade;
+    uint32_t *bin_count;           // tiles_x * tiles_y (+1)
+    uint32_t *bin_offset;          // exclusive scan of bin_count, + total at the end
+    uint32_t *bin_cursor;
+    uint32_t *bin_list;
+    uint32_t *large_list;
+    uint32_t *counters;
+
+    const rxr_light *lights;
+    const rxr_occluder *occluders;     // mapmini occluders first, then the chunks'
+    const rxr_linedef *linedefs;
+    const ChunkRange *chunks;
+
+    const DevBatch *batches2d;
+    const Tri2D *tri2d;
+    const Line2D *line2d;
+    const Item2D *items2d;
+
+    const DevTexDesc *tex;
+    const uint32_t *texels;
+    const uint32_t *bg_pixels;     // RXR_BG_HOST_PIXELS
+    uint32_t *out;                 // framebuffer; row `row0` of the band is at out + out_row0_offset
+    uint64_t out_row_stride;       // in pixels
+    int64_t out_base_row;          // row index that `out` points at (0 for the context framebuffer, row0 for external)
+};

@@ -1,0 +1,896 @@
+// rxr_kernels.hip -- hand-written gfx950 (CDNA4) kernels for the Rusterix tile rasterizer hot path.
+//
+// Compile with -ffp-contract=off and WITHOUT fast-math: the arithmetic below restates the reference's
+// f32 expressions operation for operation (Rust never contracts a*b+c); the only fused operations
+// are the ones the reference itself fuses (vec4_to_pixel's mul_add, vek's Mat*Vec), written fmaf.
+// hipcc's default IEEE-correct division / sqrt expansions are relied on (no -ffast-math, no
+// __fdividef, no rsq shortcuts).
+//
+// Pipeline per frame (all on one stream):
+//   k_setup3d  one thread per 3D triangle: de-indexes the batch arrays into TriSetup / TriShade
+//              records (per-triangle constants of the reference's per-fragment formulas), computes
+//              the triangle's clamped pixel box (rasterizer.rs:998-1017) and counts it into the
+//              16x16-pixel bins it touches (or appends it to the large-triangle list).
+//   k_scan     exclusive scan of the bin counts.
+//   k_fill     writes triangle ids into the bin lists.
+//   k_raster   one 256-thread workgroup per 16x16 tile, one pixel per lane:
+//              visibility (edge functions, barycentrics, depth) over the tile's triangles, then ONE
+//              shading evaluation of the winning fragment, then the 2D pass, then one store.
+//
+// Why visibility-then-shade equals the reference's immediate shading: d3_rasterize writes a
+// fragment iff `z < z_buffer` (strict) and its encoded alpha is 255 (rasterizer.rs:1060, 1408), and
+// a fragment's colour/alpha depend only on (triangle, pixel).  Processing triangles in submission
+// order, the surviving fragment of a pixel is therefore the one with the smallest z among the
+// alpha-255 fragments, ties broken by the smaller submission index -- an order-independent argmin,
+// so the bins need not be sorted and overdraw is never shaded.
+#include <hip/hip_runtime.h>
+
+#include "rxr_device.h"
+
+#ifndef RXR_VEK_FUSED_MATVEC
+#define RXR_VEK_FUSED_MATVEC 1
+#endif
+
+namespace {
+
+struct f3 {
+    float x, y, z;
+};
+__device__ __forceinline__ f3 mk3(float x, float y, float z) { return f3{x, y, z}; }
+__device__ __forceinline__ f3 add3(f3 a, f3 b) { return f3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ f3 sub3(f3 a, f3 b) { return f3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ f3 mul3(f3 a, f3 b) { return f3{a.x * b.x, a.y * b.y, a.z * b.z}; }
+__device__ __forceinline__ f3 scale3(f3 a, float s) { return f3{a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ f3 div3(f3 a, float s) { return f3{a.x / s, a.y / s, a.z / s}; }
+__device__ __forceinline__ f3 neg3(f3 a) { return f3{-a.x, -a.y, -a.z}; }
+// vek: dot = left-to-right sum of products; magnitude = sqrt(dot); normalized = v / magnitude
+__device__ __forceinline__ float dot3(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+__device__ __forceinline__ float mag3(f3 a) { return sqrtf(dot3(a, a)); }
+__device__ __forceinline__ f3 norm3(f3 a) { return div3(a, mag3(a)); }
+
+// Rust f32::clamp keeps NaN
+__device__ __forceinline__ float rclamp(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+__device__ __forceinline__ float madd(float a, float b, float c) {
+#if RXR_VEK_FUSED_MATVEC
+    return fmaf(a, b, c);
+#else
+    return a * b + c;
+#endif
+}
+
+// vek column-major Mat4 * Vec4 (m[c*4+r])
+__device__ __forceinline__ void mat4_mul(const float *m, float x, float y, float z, float w, float &ox, float &oy,
+                                         float &oz, float &ow) {
+    ox = madd(m[12], w, madd(m[8], z, madd(m[4], y, m[0] * x)));
+    oy = madd(m[13], w, madd(m[9], z, madd(m[5], y, m[1] * x)));
+    oz = madd(m[14], w, madd(m[10], z, madd(m[6], y, m[2] * x)));
+    ow = madd(m[15], w, madd(m[11], z, madd(m[7], y, m[3] * x)));
+}
+
+// `x as u8` / `as u32` with Rust semantics (saturate, NaN -> 0)
+__device__ __forceinline__ uint32_t sat_u8(float x) {
+    if (!(x > 0.0f)) return 0u;  // NaN, negatives, zero
+    if (x >= 255.0f) return 255u;
+    return (uint32_t)x;
+}
+__device__ __forceinline__ uint32_t sat_u32(float x) {
+    if (!(x > 0.0f)) return 0u;
+    if (x >= 4294967296.0f) return 0xFFFFFFFFu;
+    return (uint32_t)x;
+}
+// `x as usize` followed by a clamp to [0, hi] (hi < 2^31)
+__device__ __forceinline__ uint32_t sat_index(float x, uint32_t hi) {
+    if (!(x > 0.0f)) return 0u;
+    if (x >= (float)hi) return hi;
+    return (uint32_t)x;
+}
+
+// lib.rs:64-68
+__device__ __forceinline__ uint32_t f32_to_u8_saturated(float x) {
+    float y = fmaf(fminf(fmaxf(x, 0.0f), 1.0f), 255.0f, 0.5f);
+    return (uint32_t)(int)y & 0xFFu;  // y in [0.5, 255.5]
+}
+
+// rasterizer.rs:19-33
+__device__ __forceinline__ float srgb_to_linear_fast(float x) {
+    float x2 = x * x;
+    return (0.6975f * x2 + 0.3025f) * x;
+}
+__device__ __forceinline__ float linear_to_srgb_fast(float x) {
+    float s = sqrtf(x);
+    return 1.055f * s - 0.055f * s * s;
+}
+
+// ---- texture sampling (texture.rs:203-232, 307-323, 414-460) -------------------------------------
+__device__ __forceinline__ uint32_t sample_nearest(const DevTexDesc &d, const uint32_t *texels, float u, float v) {
+    uint32_t tx = sat_index(roundf(u * ((float)d.w - 1.0f)), d.w - 1u);
+    uint32_t ty = sat_index(roundf(v * ((float)d.h - 1.0f)), d.h - 1u);
+    return texels[d.offset + ty * d.w + tx];
+}
+
+__device__ __forceinline__ uint32_t sample_linear(const DevTexDesc &d, const uint32_t *texels, float u, float v) {
+    float x = u * ((float)d.w - 1.0f);
+    float y = v * ((float)d.h - 1.0f);
+    float fx = floorf(x), fy = floorf(y);
+    // `floor() as usize`: u,v are in [0,1] or NaN after the repeat handling, so x0 <= w-1
+    uint32_t x0 = sat_index(fx, d.w - 1u);
+    uint32_t y0 = sat_index(fy, d.h - 1u);
+    uint32_t x1 = min(x0 + 1u, d.w - 1u);
+    uint32_t y1 = min(y0 + 1u, d.h - 1u);
+    float dx = x - fx, dy = y - fy;
+    uint32_t c00 = texels[d.offset + y0 * d.w + x0];
+    uint32_t c10 = texels[d.offset + y0 * d.w + x1];
+    uint32_t c01 = texels[d.offset + y1 * d.w + x0];
+    uint32_t c11 = texels[d.offset + y1 * d.w + x1];
+    uint32_t out = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float v00 = (float)((c00 >> (8 * i)) & 0xFFu);
+        float v10 = (float)((c10 >> (8 * i)) & 0xFFu);
+        float v01 = (float)((c01 >> (8 * i)) & 0xFFu);
+        float v11 = (float)((c11 >> (8 * i)) & 0xFFu);
+        float a = v00 + dx * (v10 - v00);
+        float b = v01 + dx * (v11 - v01);
+        float c = a + dy * (b - a);
+        out |= sat_u8(roundf(c)) << (8 * i);
+    }
+    return out;
+}
+
+__device__ __forceinline__ uint32_t sample_texture(const DevTexDesc &d, const uint32_t *texels, float u, float v,
+                                                   uint32_t sample_mode, uint32_t repeat_mode) {
+    switch (repeat_mode) {
+        case RXR_REPEAT_CLAMP_XY:
+            u = rclamp(u, 0.0f, 1.0f);
+            v = rclamp(v, 0.0f, 1.0f);
+            break;
+        case RXR_REPEAT_REPEAT_XY:
+            u = u - floorf(u);
+            v = v - floorf(v);
+            break;
+        case RXR_REPEAT_REPEAT_X:
+            u = u - floorf(u);
+            v = rclamp(v, 0.0f, 1.0f);
+            break;
+        default:  // RepeatY
+            u = rclamp(u, 0.0f, 1.0f);
+            v = v - floorf(v);
+            break;
+    }
+    return sample_mode == RXR_SAMPLE_NEAREST ? sample_nearest(d, texels, u, v) : sample_linear(d, texels, u, v);
+}
+
+// ---- lights (map/light.rs:491-677) ---------------------------------------------------------------
+__device__ __forceinline__ float smoothstep_rs(float e0, float e1, float x) {
+    float t = rclamp((x - e0) / (e1 - e0), 0.0f, 1.0f);
+    return t * t * (3.0f - 2.0f * t);
+}
+
+__device__ __forceinline__ f3 apply_flicker(const rxr_light &l, float intensity, uint32_t hash) {
+    float ff;
+    if (l.flicker > 0.0f) {
+        uint32_t combined = hash + (sat_u32(l.position[0]) + sat_u32(l.position[1]) + sat_u32(l.position[2])) * 100u;
+        float fv = rclamp((float)combined / 4294967296.0f /* u32::MAX as f32 */, 0.0f, 1.0f);
+        ff = 1.0f - fv * l.flicker;
+    } else {
+        ff = 1.0f;
+    }
+    return mk3(l.color[0] * intensity * ff, l.color[1] * intensity * ff, l.color[2] * intensity * ff);
+}
+
+// CompiledLight::color_at; returns false for None
+__device__ __forceinline__ bool light_color_at(const rxr_light &l, f3 point, uint32_t hash, bool d2, f3 &out) {
+    if (!l.emitting) return false;
+    f3 lp = mk3(l.position[0], l.position[1], l.position[2]);
+    switch (l.light_type) {
+        case RXR_LIGHT_POINT: {
+            float distance = mag3(sub3(point, lp));
+            if (distance >= l.end_distance) return false;
+            if (distance <= l.start_distance) {
+                out = apply_flicker(l, l.intensity, hash);
+                return true;
+            }
+            float att = smoothstep_rs(l.end_distance, l.start_distance, distance);
+            out = apply_flicker(l, l.intensity * att, hash);
+            return true;
+        }
+        case RXR_LIGHT_AMBIENT:
+        case RXR_LIGHT_AMBIENT_DAYLIGHT:
+            out = apply_flicker(l, l.intensity, hash);
+            return true;
+        case RXR_LIGHT_SPOT: {
+            float distance = mag3(sub3(point, lp));
+            if (distance >= l.end_distance) return false;
+            float att = (distance <= l.start_distance)
+                            ? 1.0f
+                            : 1.0f - ((distance - l.start_distance) / (l.end_distance - l.start_distance));
+            f3 dtp = norm3(sub3(point, lp));
+            float angle = acosf(dot3(mk3(l.direction[0], l.direction[1], l.direction[2]), dtp));
+            if (angle > l.cone_angle) return false;
+            out = apply_flicker(l, l.intensity * att, hash);
+            return true;
+        }
+        case RXR_LIGHT_AREA: {
+            f3 to_point = sub3(point, lp);
+            float distance = mag3(to_point);
+            if (distance >= l.end_distance) return false;
+            if (distance < 0.1f) {
+                out = mk3(l.color[0], l.color[1], l.color[2]);
+                return true;
+            }
+            float datt = (distance <= l.start_distance) ? 1.0f : smoothstep_rs(l.end_distance, l.start_distance, distance);
+            float area = l.width * l.height;
+            f3 direction = norm3(to_point);
+            float att;
+            if (l.from_linedef) {
+                att = datt * area * l.intensity;
+            } else if (d2) {
+                float dxn = fabsf(to_point.x / (l.width * 0.5f));
+                float dyn = fabsf(to_point.y / (l.height * 0.5f));
+                float ax = fmaxf(1.0f - dxn, 0.0f);
+                float ay = fmaxf(1.0f - dyn, 0.0f);
+                att = ax * ay * datt * l.intensity;
+            } else {
+                float aa = fmaxf(dot3(mk3(l.normal[0], l.normal[1], l.normal[2]), direction), 0.0f);
+                att = aa * datt * area * l.intensity;
+            }
+            out = mk3(l.color[0] * att, l.color[1] * att, l.color[2] * att);
+            return true;
+        }
+        default: {  // Daylight
+            f3 to_point = sub3(point, lp);
+            float distance = mag3(to_point);
+            if (distance >= l.end_distance) return false;
+            f3 direction = norm3(to_point);
+            float aa = fmaxf(dot3(mk3(l.normal[0], l.normal[1], l.normal[2]), direction), 0.0f);
+            float datt = (distance <= l.start_distance) ? 1.0f : smoothstep_rs(l.end_distance, l.start_distance, distance);
+            float att = aa * datt * l.intensity;
+            out = mk3(l.color[0] * att, l.color[1] * att, l.color[2] * att);
+            return true;
+        }
+    }
+}
+
+// rasterizer.rs:1875-1951 with emissive == 0 at every call site
+__device__ __forceinline__ f3 shade_fast_brdf(f3 base, float roughness, float metallic, f3 n, f3 v, f3 l, f3 radiance) {
+    float n_dot_l = fmaxf(dot3(n, l), 0.0f);
+    if (n_dot_l <= 0.0f) return mk3(0.0f, 0.0f, 0.0f);
+    // Vec3::lerp(0.04, base, metallic) = mul_add(clamp01(t), b - a, a)
+    float tm = rclamp(metallic, 0.0f, 1.0f);
+    f3 f0 = mk3(fmaf(tm, base.x - 0.04f, 0.04f), fmaf(tm, base.y - 0.04f, 0.04f), fmaf(tm, base.z - 0.04f, 0.04f));
+    f3 kd = scale3(base, 1.0f - metallic);
+    kd = scale3(kd, 1.0f - fmaxf(f0.x, fmaxf(f0.y, f0.z)));
+    float a = fmaxf(roughness * roughness, 1e-4f);
+    float shininess = rclamp(2.0f / a - 2.0f, 1.0f, 2048.0f);
+    f3 h = norm3(add3(l, v));
+    float n_dot_h = fmaxf(dot3(n, h), 0.0f);
+    float spec_b = (n_dot_h <= 0.0f) ? 0.0f : exp2f(shininess * log2f(n_dot_h));
+    float n_dot_v = fmaxf(dot3(n, v), 0.0f);
+    float om = 1.0f - rclamp(n_dot_v, 0.0f, 1.0f);
+    float x5 = om * om * om * om * om;
+    f3 f = add3(f0, scale3(sub3(mk3(1.0f, 1.0f, 1.0f), f0), x5));
+    f3 diffuse = scale3(kd, n_dot_l);
+    f3 specular = scale3(scale3(f, spec_b), n_dot_l);
+    return mul3(add3(diffuse, specular), radiance);  // + emissive (0)
+}
+
+// MapMini::get_occlusion / Chunk::get_occlusion (map/mini.rs:58-66, chunk.rs:154-161)
+__device__ __forceinline__ float get_occlusion(const rxr_occluder *occ, uint32_t first, uint32_t count, float x, float y) {
+    for (uint32_t i = 0; i < count; ++i) {
+        const rxr_occluder &o = occ[first + i];
+        if (x >= o.min[0] && x <= o.max[0] && y >= o.min[1] && y <= o.max[1]) return o.occlusion;
+    }
+    return 1.0f;
+}
+
+// MapMini::is_visible (map/mini.rs:68-95)
+__device__ __forceinline__ bool mapmini_is_visible(const rxr_linedef *ld, uint32_t n, float ax, float ay, float bx, float by) {
+    for (uint32_t i = 0; i < n; ++i) {
+        float b1x = ld[i].start[0], b1y = ld[i].start[1], b2x = ld[i].end[0], b2y = ld[i].end[1];
+        float d = (bx - ax) * (b2y - b1y) - (by - ay) * (b2x - b1x);
+        if (d == 0.0f) continue;
+        float u = ((b1x - ax) * (b2y - b1y) - (b1y - ay) * (b2x - b1x)) / d;
+        float v = ((b1x - ax) * (by - ay) - (b1y - ay) * (bx - ax)) / d;
+        if ((u >= 0.0f && u <= 1.0f) && (v >= 0.0f && v <= 1.0f)) return false;
+    }
+    return true;
+}
+
+__device__ __forceinline__ uint32_t pack4(uint32_t r, uint32_t g, uint32_t b, uint32_t a) {
+    return r | (g << 8) | (b << 16) | (a << 24);
+}
+
+// perspective-correct uv of the fragment (rasterizer.rs:1062-1076)
+__device__ __forceinline__ void fragment_uv(const TriShade &S, float alpha, float beta, float gamma, float &u, float &v) {
+    float iu = S.u0w * alpha + S.u1w * beta + S.u2w * gamma;
+    float iv = S.v0w * alpha + S.v1w * beta + S.v2w * gamma;
+    float irw = S.iw0 * alpha + S.iw1 * beta + S.iw2 * gamma;
+    u = iu / irw;
+    v = iv / irw;
+}
+
+__device__ __forceinline__ uint32_t batch_texel(const RasterParams &P, const DevBatch &B, float u, float v) {
+    if (B.tex < 0) return B.pixel;
+    return sample_texture(P.tex[B.tex], P.texels, u, v, P.sample_mode, B.repeat_mode);
+}
+
+// the covered-fragment block of d3_rasterize after the depth test (rasterizer.rs:1062-1404)
+__device__ __forceinline__ uint32_t shade3d(const RasterParams &P, uint32_t t, uint32_t batch_id, float alpha, float beta,
+                                            float z, float fx, float fy) {
+    const TriShade S = P.tri_shade[t];
+    const DevBatch &B = P.batches3d[batch_id];
+    float gamma = 1.0f - alpha - beta;
+    float u, v;
+    fragment_uv(S, alpha, beta, gamma, u, v);
+
+    // screen_to_world (rasterizer.rs:1707-1727)
+    float x_ndc = 2.0f * (fx / P.fwidth) - 1.0f;
+    float y_ndc = 1.0f - 2.0f * (fy / P.fheight);
+    float vx, vy, vz, vw;
+    mat4_mul(P.inv_proj, x_ndc, y_ndc, z, 1.0f, vx, vy, vz, vw);
+    vx = vx / vw;
+    vy = vy / vw;
+    vz = vz / vw;
+    vw = vw / vw;
+    float wx, wy, wz, ww;
+    mat4_mul(P.inv_view, vx, vy, vz, vw, wx, wy, wz, ww);
+    f3 world = mk3(wx, wy, wz);
+    f3 cam = mk3(P.cam[0], P.cam[1], P.cam[2]);
+    f3 view_dir = norm3(sub3(cam, world));
+
+    f3 normal;
+    if (B.flags & DB_HAS_NORMALS) {  // :1083-1099
+        f3 n0 = mk3(S.n0[0], S.n0[1], S.n0[2]), n1 = mk3(S.n1[0], S.n1[1], S.n1[2]), n2 = mk3(S.n2[0], S.n2[1], S.n2[2]);
+        normal = norm3(add3(add3(scale3(n0, alpha), scale3(n1, beta)), scale3(n2, gamma)));
+        if (dot3(normal, view_dir) < 0.0f) normal = neg3(normal);
+    } else {
+        normal = mk3(0.0f, 0.0f, 0.0f);
+    }
+
+    uint32_t texel = batch_texel(P, B, u, v);
+    const float INV_255 = 1.0f / 255.0f;  // lib.rs:52
+    f3 base = mk3(srgb_to_linear_fast((float)(texel & 0xFFu) * INV_255), srgb_to_linear_fast((float)((texel >> 8) & 0xFFu) * INV_255),
+                  srgb_to_linear_fast((float)((texel >> 16) & 0xFFu) * INV_255));
+    float opacity = (float)(texel >> 24) / 255.0f;  // :1313
+
+    normal = norm3(normal);  // :1320
+    const float rough = 0.5f, metal = 0.0f;
+
+    f3 lit = mk3(0.0f, 0.0f, 0.0f);
+    float occlusion;
+    if (B.chunk >= 0) {
+        ChunkRange cr = P.chunks[B.chunk];
+        occlusion = get_occlusion(P.occluders, cr.occ_first, cr.occ_count, world.x, world.z);
+    } else {
+        occlusion = get_occlusion(P.occluders, 0, P.n_occluders, world.x, world.z);
+    }
+    float hemi = 0.5f * (normal.y + 1.0f);
+    f3 kd = scale3(scale3(base, 1.0f - metal), 1.0f - 0.04f);
+    if (occlusion > 0.0f) {  // :1334-1365
+        if (P.flags & RXR_FLAG_HAS_AMBIENT) {
+            lit = add3(lit, scale3(mul3(mk3(P.ambient[0], P.ambient[1], P.ambient[2]), kd), hemi));
+        }
+        if ((P.flags & RXR_FLAG_HAS_SUN) && P.day_factor > 0.0f) {
+            f3 ldir = norm3(neg3(mk3(P.sun_dir[0], P.sun_dir[1], P.sun_dir[2])));
+            float df = fmaxf(P.day_factor, 0.0f);
+            lit = add3(lit, shade_fast_brdf(base, rough, metal, normal, view_dir, ldir, mk3(df, df, df)));
+        }
+        lit = scale3(lit, occlusion);
+    }
+    lit = add3(lit, scale3(mul3(mk3(B.ambient[0], B.ambient[1], B.ambient[2]), kd), hemi));  // :1368-1370
+
+    for (uint32_t li = 0; li < P.n_lights; ++li) {  // :1373-1391
+        const rxr_light &L = P.lights[li];
+        f3 incoming;
+        if (!light_color_at(L, world, P.hash_anim, false, incoming)) continue;
+        f3 ldir = norm3(sub3(mk3(L.position[0], L.position[1], L.position[2]), world));
+        f3 radiance;
+        if (L.light_type == RXR_LIGHT_AMBIENT || L.light_type == RXR_LIGHT_AMBIENT_DAYLIGHT || L.light_type == RXR_LIGHT_DAYLIGHT) {
+            radiance = incoming;
+        } else {
+            float lambert = fmaxf(dot3(normal, ldir), 0.0f);  // radiance_at, light.rs:529-532
+            radiance = scale3(incoming, lambert);
+        }
+        lit = add3(lit, shade_fast_brdf(base, rough, metal, normal, view_dir, ldir, radiance));
+    }
+    // + mat_emissive (0)
+
+    return pack4(f32_to_u8_saturated(linear_to_srgb_fast(lit.x)), f32_to_u8_saturated(linear_to_srgb_fast(lit.y)),
+                 f32_to_u8_saturated(linear_to_srgb_fast(lit.z)), f32_to_u8_saturated(opacity));
+}
+
+// the covered-fragment block of d3_rasterize_opacity (rasterizer.rs:1497-1682, no shader)
+__device__ __forceinline__ uint32_t shade3d_opacity(const RasterParams &P, uint32_t t, uint32_t batch_id, float alpha, float beta) {
+    const TriShade S = P.tri_shade[t];
+    const DevBatch &B = P.batches3d[batch_id];
+    float gamma = 1.0f - alpha - beta;
+    float u, v;
+    fragment_uv(S, alpha, beta, gamma, u, v);
+    uint32_t texel = batch_texel(P, B, u, v);
+    const float INV_255 = 1.0f / 255.0f;
+    float r = srgb_to_linear_fast((float)(texel & 0xFFu) * INV_255);
+    float g = srgb_to_linear_fast((float)((texel >> 8) & 0xFFu) * INV_255);
+    float b = srgb_to_linear_fast((float)((texel >> 16) & 0xFFu) * INV_255);
+    float opacity = (float)(texel >> 24) / 255.0f;
+    return pack4(f32_to_u8_saturated(linear_to_srgb_fast(r)), f32_to_u8_saturated(linear_to_srgb_fast(g)),
+                 f32_to_u8_saturated(linear_to_srgb_fast(b)), f32_to_u8_saturated(opacity));
+}
+
+// one 2D fragment (rasterizer.rs:656-895); returns the new pixel
+__device__ __forceinline__ uint32_t fragment2d(const RasterParams &P, const Tri2D &T, const DevBatch &B, uint32_t px, uint32_t py,
+                                               float fx, float fy, uint32_t dst) {
+    // barycentric_weights_2d (rasterizer.rs:1731-1750)
+    float acx = T.v2x - T.v0x, acy = T.v2y - T.v0y;
+    float abx = T.v1x - T.v0x, aby = T.v1y - T.v0y;
+    float apx = fx - T.v0x, apy = fy - T.v0y;
+    float pcx = T.v2x - fx, pcy = T.v2y - fy;
+    float pbx = T.v1x - fx, pby = T.v1y - fy;
+    float area = acx * aby - acy * abx;
+    float w0 = (pcx * pby - pcy * pbx) / area;
+    float w1 = (acx * apy - acy * apx) / area;
+    float w2 = 1.0f - w0 - w1;
+    float u = T.u0 * w0 + T.u1 * w1 + T.u2 * w2;
+    float v = T.v0 * w0 + T.v1 * w1 + T.v2 * w2;
+
+    // :664-670
+    float gx = ((float)px - P.fwidth / 2.0f) - (P.translationd2[0] - P.fwidth / 2.0f);
+    float gy = ((float)py - P.fheight / 2.0f) - (P.translationd2[1] - P.fheight / 2.0f);
+    float wx = gx / P.scaled2, wy = gy / P.scaled2;
+
+    uint32_t texel = batch_texel(P, B, u, v);
+    uint32_t tr = texel & 0xFFu, tg = (texel >> 8) & 0xFFu, tb = (texel >> 16) & 0xFFu, ta = texel >> 24;
+
+    // :799-873 -- note the reference's precedence: (receives_light && any lights) || ambient
+    if (((B.flags & DB_RECEIVES_LIGHT) && P.any_lights) || (P.flags & RXR_FLAG_HAS_AMBIENT)) {
+        float acc0 = 0.0f, acc1 = 0.0f, acc2 = 0.0f;
+        uint32_t occ_first = 0, occ_count = P.n_occluders;
+        if (B.chunk >= 0) {
+            ChunkRange cr = P.chunks[B.chunk];
+            occ_first = cr.occ_first;
+            occ_count = cr.occ_count;
+        }
+        if (P.flags & RXR_FLAG_HAS_AMBIENT) {
+            float occlusion = get_occlusion(P.occluders, occ_first, occ_count, wx, wy);
+            acc0 += P.ambient[0] * occlusion;
+            acc1 += P.ambient[1] * occlusion;
+            acc2 += P.ambient[2] * occlusion;
+        }
+        for (uint32_t li = 0; li < P.n_lights; ++li) {
+            const rxr_light &L = P.lights[li];
+            f3 lc;
+            if (!light_color_at(L, mk3(wx, 0.0f, wy), P.hash_anim, true, lc)) continue;
+            bool visible = true;
+            if (L.light_type == RXR_LIGHT_AMBIENT_DAYLIGHT) {
+                float occlusion = get_occlusion(P.occluders, occ_first, occ_count, wx, wy);
+                lc = scale3(lc, occlusion);
+            }
+            if (L.light_type != RXR_LIGHT_AMBIENT && L.light_type != RXR_LIGHT_AMBIENT_DAYLIGHT &&
+                !mapmini_is_visible(P.linedefs, P.n_linedefs, wx, wy, L.position[0], L.position[2]))
+                visible = false;
+            if (visible) {
+                acc0 += lc.x;
+                acc1 += lc.y;
+                acc2 += lc.z;
+            }
+        }
+        acc0 = rclamp(acc0, 0.0f, 1.0f);
+        acc1 = rclamp(acc1, 0.0f, 1.0f);
+        acc2 = rclamp(acc2, 0.0f, 1.0f);
+        tr = sat_u8(rclamp(((float)tr / 255.0f) * acc0 * 255.0f, 0.0f, 255.0f));
+        tg = sat_u8(rclamp(((float)tg / 255.0f) * acc1 * 255.0f, 0.0f, 255.0f));
+        tb = sat_u8(rclamp(((float)tb / 255.0f) * acc2 * 255.0f, 0.0f, 255.0f));
+    }
+
+    if (ta == 255u) return pack4(tr, tg, tb, ta);  // :878-879
+    float src_alpha = (float)ta / 255.0f;
+    float dst_alpha = 1.0f - src_alpha;
+    uint32_t dr = dst & 0xFFu, dg = (dst >> 8) & 0xFFu, db = (dst >> 16) & 0xFFu, da = dst >> 24;
+    uint32_t orr = sat_u8(((float)tr * src_alpha) + ((float)dr * dst_alpha));
+    uint32_t og = sat_u8(((float)tg * src_alpha) + ((float)dg * dst_alpha));
+    uint32_t ob = sat_u8(((float)tb * src_alpha) + ((float)db * dst_alpha));
+    uint32_t oa = (P.flags & RXR_FLAG_PRESERVE_TRANSPARENCY) ? max(da, ta) : 255u;
+    return pack4(orr, og, ob, oa);
+}
+
+// bins (launch-local tile rows l0..l1, tile columns bx0..bx1) touched by a clamped pixel box
+__device__ __forceinline__ bool bin_range(const RasterParams &P, uint32_t min_x, uint32_t max_x, uint32_t min_y, uint32_t max_y,
+                                          uint32_t &bx0, uint32_t &bx1, uint32_t &l0, uint32_t &l1) {
+    if (!(min_x < max_x && min_y < max_y) || P.tiles_y == 0) return false;
+    bx0 = min_x / RXR_TILE_W;
+    bx1 = (max_x - 1) / RXR_TILE_W;
+    uint32_t g0 = min_y / RXR_TILE_H, g1 = (max_y - 1) / RXR_TILE_H;  // frame tile rows
+    if (g1 < P.tile_y0) return false;
+    l0 = g0 <= P.tile_y0 ? 0u : (g0 - P.tile_y0 + P.tile_stride - 1u) / P.tile_stride;
+    l1 = (g1 - P.tile_y0) / P.tile_stride;
+    if (l1 >= P.tiles_y) l1 = P.tiles_y - 1u;
+    return l0 <= l1;
+}
+
+}  // namespace
+
+// =================================================================================================
+// k_setup3d: triangle set-up + bin counting.  One thread per triangle.
+// Replaces the per-tile re-derivation of per-triangle constants in rasterizer.rs:989-1017, 1054-1072.
+// =================================================================================================
+extern "C" __global__ void __launch_bounds__(256) k_setup3d(RasterParams P) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= P.n_tris3d) return;
+
+    // triangle -> batch: largest b with base[b] <= t
+    uint32_t lo = 0, hi = P.n_batches3d;
+    while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (P.batch_tri_base[mid] <= t) lo = mid;
+        else hi = mid;
+    }
+    const DevBatch B = P.batches3d[lo];
+
+    uint32_t i0 = P.idx[3 * t + 0] + B.vert_base, i1 = P.idx[3 * t + 1] + B.vert_base, i2 = P.idx[3 * t + 2] + B.vert_base;
+    float4 v0 = P.pv[i0], v1 = P.pv[i1], v2 = P.pv[i2];
+    const rxr_edges E = P.edges[t];
+
+    TriSetup S;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        S.ea[k] = E.a[k];
+        S.eb[k] = E.b[k];
+        S.ec[k] = E.c[k];
+    }
+    S.v0x = v0.x; S.v0y = v0.y; S.v1x = v1.x; S.v1y = v1.y; S.v2x = v2.x; S.v2y = v2.y;
+    {
+        float acx = v2.x - v0.x, acy = v2.y - v0.y, abx = v1.x - v0.x, aby = v1.y - v0.y;
+        S.area = acx * aby - acy * abx;
+    }
+    S.iz0 = 1.0f / v0.z;
+    S.iz1 = 1.0f / v1.z;
+    S.iz2 = 1.0f / v2.z;
+    S.batch = lo;
+    S.pad[0] = S.pad[1] = 0;
+
+    TriShade H;
+    H.iw0 = 1.0f / v0.w;
+    H.iw1 = 1.0f / v1.w;
+    H.iw2 = 1.0f / v2.w;
+    float2 uv0 = P.uv[i0], uv1 = P.uv[i1], uv2 = P.uv[i2];
+    H.u0w = uv0.x / v0.w; H.u1w = uv1.x / v1.w; H.u2w = uv2.x / v2.w;
+    H.v0w = uv0.y / v0.w; H.v1w = uv1.y / v1.w; H.v2w = uv2.y / v2.w;
+    if (B.flags & DB_HAS_NORMALS) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            H.n0[k] = P.nrm[3 * (size_t)i0 + k];
+            H.n1[k] = P.nrm[3 * (size_t)i1 + k];
+            H.n2[k] = P.nrm[3 * (size_t)i2 + k];
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) H.n0[k] = H.n1[k] = H.n2[k] = 0.0f;
+    }
+    H.pad[0] = H.pad[1] = 0;
+    P.tri_shade[t] = H;
+
+    // clamped pixel box, rasterizer.rs:998-1017 with the tile replaced by (whole width) x (row band)
+    float min_xf = fminf(v0.x, fminf(v1.x, v2.x)), max_xf = fmaxf(v0.x, fmaxf(v1.x, v2.x));
+    float min_yf = fminf(v0.y, fminf(v1.y, v2.y)), max_yf = fmaxf(v0.y, fmaxf(v1.y, v2.y));
+    uint32_t min_x = sat_index(fmaxf(floorf(min_xf), 0.0f), 0xFFFFu);
+    uint32_t max_x = sat_index(fminf(ceilf(max_xf), (float)P.width), 0xFFFFu);
+    uint32_t min_y = sat_index(fmaxf(floorf(min_yf), (float)P.row0), 0xFFFFu);
+    uint32_t max_y = sat_index(fminf(ceilf(max_yf), (float)P.row1), 0xFFFFu);
+
+    bool live = E.visible && !(B.flags & DB_SKIP) && min_x < max_x && min_y < max_y;
+    if (!live) {
+        S.bx = 0;
+        S.by = 0;
+        P.tri_setup[t] = S;
+        return;
+    }
+    S.bx = min_x | (max_x << 16);
+    S.by = min_y | (max_y << 16);
+    P.tri_setup[t] = S;
+
+    uint32_t bx0, bx1, by0, by1;
+    if (!bin_range(P, min_x, max_x, min_y, max_y, bx0, bx1, by0, by1)) return;
+    uint32_t nb = (bx1 - bx0 + 1) * (by1 - by0 + 1);
+    if (nb > RXR_LARGE_BINS) {
+        uint32_t slot = atomicAdd(&P.counters[CNT_LARGE], 1u);
+        P.large_list[slot] = t;
+    } else {
+        for (uint32_t by = by0; by <= by1; ++by)
+            for (uint32_t bx = bx0; bx <= bx1; ++bx) atomicAdd(&P.bin_count[by * P.tiles_x + bx], 1u);
+    }
+}
+
+// =================================================================================================
+// k_scan: exclusive scan of bin_count -> bin_offset (one 1024-thread workgroup, 8 bins per thread)
+// =================================================================================================
+extern "C" __global__ void __launch_bounds__(1024) k_scan(RasterParams P) {
+    __shared__ uint32_t wave_tot[16];
+    __shared__ uint32_t carry_s;
+    const uint32_t n = P.tiles_x * P.tiles_y;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    constexpr uint32_t PER = 8;
+    for (uint32_t base = 0; base < n; base += 1024 * PER) {
+        uint32_t i0 = base + tid * PER;
+        uint32_t v[PER];
+        uint32_t sum = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < PER; ++k) {
+            uint32_t i = i0 + k;
+            v[k] = (i < n) ? P.bin_count[i] : 0u;
+            sum += v[k];
+        }
+        // inclusive scan of `sum` across the wave
+        uint32_t inc = sum;
+#pragma unroll
+        for (uint32_t d = 1; d < 64; d <<= 1) {
+            uint32_t o = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += o;
+        }
+        if (lane == 63) wave_tot[wave] = inc;
+        __syncthreads();
+        uint32_t wave_off = 0;
+        for (uint32_t w = 0; w < wave; ++w) wave_off += wave_tot[w];
+        uint32_t carry = carry_s;
+        uint32_t run = carry + wave_off + (inc - sum);
+#pragma unroll
+        for (uint32_t k = 0; k < PER; ++k) {
+            uint32_t i = i0 + k;
+            if (i < n) {
+                P.bin_offset[i] = run;
+                P.bin_cursor[i] = 0u;
+            }
+            run += v[k];
+        }
+        __syncthreads();
+        if (tid == 1023) carry_s = run;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        P.bin_offset[n] = carry_s;
+        P.counters[CNT_ENTRIES] = carry_s;
+        if (carry_s > P.list_capacity) P.counters[CNT_OVERFLOW] = 1u;
+    }
+}
+
+// =================================================================================================
+// k_fill: scatter triangle ids into the bin lists (order inside a bin is irrelevant, see header)
+// =================================================================================================
+extern "C" __global__ void __launch_bounds__(256) k_fill(RasterParams P) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= P.n_tris3d) return;
+    uint32_t bxw = P.tri_setup[t].bx, byw = P.tri_setup[t].by;
+    uint32_t min_x = bxw & 0xFFFFu, max_x = bxw >> 16, min_y = byw & 0xFFFFu, max_y = byw >> 16;
+    uint32_t bx0, bx1, by0, by1;
+    if (!bin_range(P, min_x, max_x, min_y, max_y, bx0, bx1, by0, by1)) return;
+    uint32_t nb = (bx1 - bx0 + 1) * (by1 - by0 + 1);
+    if (nb > RXR_LARGE_BINS) return;
+    for (uint32_t by = by0; by <= by1; ++by)
+        for (uint32_t bx = bx0; bx <= bx1; ++bx) {
+            uint32_t bin = by * P.tiles_x + bx;
+            uint32_t pos = P.bin_offset[bin] + atomicAdd(&P.bin_cursor[bin], 1u);
+            if (pos < P.list_capacity) P.bin_list[pos] = t;
+        }
+}
+
+// =================================================================================================
+// k_raster: the tile kernel.  One workgroup per 16x16 tile, one pixel per lane.
+// Replaces the rayon tile closure, rasterizer.rs:275-556, and the tile->framebuffer copy, :559-579.
+// =================================================================================================
+namespace {
+
+struct Vis {
+    float zmin;
+    int best;  // global triangle id of the winner, -1 = none
+    float alpha, beta;
+};
+
+// one candidate triangle against this lane's pixel (rasterizer.rs:1020-1060 + the :1408 alpha rule)
+template <bool OPACITY>
+__device__ __forceinline__ void visit(const RasterParams &P, const TriSetup &S, uint32_t t, uint32_t px, uint32_t py, float fx,
+                                      float fy, Vis &vis, int surf_profile) {
+    uint32_t min_x = S.bx & 0xFFFFu, max_x = S.bx >> 16, min_y = S.by & 0xFFFFu, max_y = S.by >> 16;
+    bool in = px >= min_x && px < max_x && py >= min_y && py < max_y;
+    // Edges::evaluate (edge.rs:28-36): reject iff a*px + b*py + c < 0 (NaN passes)
+    float r0 = S.ea[0] * fx + S.eb[0] * fy + S.ec[0];
+    float r1 = S.ea[1] * fx + S.eb[1] * fy + S.ec[1];
+    float r2 = S.ea[2] * fx + S.eb[2] * fy + S.ec[2];
+    in = in && !(r0 < 0.0f) && !(r1 < 0.0f) && !(r2 < 0.0f);
+    if (!in) return;
+    const DevBatch &B = P.batches3d[S.batch];
+    const bool is_opacity = (B.flags & DB_OPACITY_LIST) != 0;
+    if (is_opacity != OPACITY) return;
+    if (!OPACITY) {
+        // surface_id[idx].is_some() && surface_id[idx] == batch.profile_id  (:1044-1048)
+        if (surf_profile >= 0 && (B.flags & DB_HAS_PROFILE) && (uint32_t)surf_profile == B.profile_id) return;
+    }
+    // barycentric_weights_3d (:1754-1773)
+    float pcx = S.v2x - fx, pcy = S.v2y - fy;
+    float pbx = S.v1x - fx, pby = S.v1y - fy;
+    float apx = fx - S.v0x, apy = fy - S.v0y;
+    float acx = S.v2x - S.v0x, acy = S.v2y - S.v0y;
+    float abx = S.v1x - S.v0x, aby = S.v1y - S.v0y;
+    float alpha = (pcx * pby - pcy * pbx) / S.area;
+    float beta = (acx * apy - acy * apx) / S.area;
+    float gamma = 1.0f - alpha - beta;
+    float one_over_z = S.iz0 * alpha + S.iz1 * beta + S.iz2 * gamma;
+    float z = 1.0f / one_over_z;
+    bool closer = z < vis.zmin || (z == vis.zmin && vis.best >= 0 && (int)t < vis.best);
+    if (!closer) return;
+    if (!OPACITY && (B.flags & DB_ALPHA_TEST)) {
+        // the fragment is only written when its encoded alpha is 255 (:1408): sample it now
+        const TriShade H = P.tri_shade[t];
+        float u, v;
+        fragment_uv(H, alpha, beta, gamma, u, v);
+        uint32_t texel = batch_texel(P, B, u, v);
+        if ((texel >> 24) != 255u) return;
+    }
+    vis.zmin = z;
+    vis.best = (int)t;
+    vis.alpha = alpha;
+    vis.beta = beta;
+}
+
+template <bool OPACITY>
+__device__ __forceinline__ void scan_lists(const RasterParams &P, uint32_t bin, uint32_t tile_x0, uint32_t tile_y0px, uint32_t px,
+                                           uint32_t py, float fx, float fy, Vis &vis, int surf_profile) {
+    // large triangles: every tile walks the list, scalar reject against the tile rectangle
+    const uint32_t n_large = P.counters[CNT_LARGE];
+    for (uint32_t i = 0; i < n_large; ++i) {
+        uint32_t t = P.large_list[i];
+        const TriSetup &S = P.tri_setup[t];
+        uint32_t min_x = S.bx & 0xFFFFu, max_x = S.bx >> 16, min_y = S.by & 0xFFFFu, max_y = S.by >> 16;
+        if (min_x >= tile_x0 + RXR_TILE_W || max_x <= tile_x0 || min_y >= tile_y0px + RXR_TILE_H || max_y <= tile_y0px) continue;
+        visit<OPACITY>(P, S, t, px, py, fx, fy, vis, surf_profile);
+    }
+    const uint32_t b0 = P.bin_offset[bin], b1 = P.bin_offset[bin + 1];
+    for (uint32_t i = b0; i < b1; ++i) {
+        uint32_t t = P.bin_list[i];
+        visit<OPACITY>(P, P.tri_setup[t], t, px, py, fx, fy, vis, surf_profile);
+    }
+}
+
+// Bresenham walk of one segment (rasterizer.rs:1777-1821): does the walk plot pixel (px,py)?
+// Every lane runs the same uniform loop; cost O(segment length) per tile that the segment's box touches.
+__device__ __forceinline__ bool bresenham_hits(const Line2D &Ln, int px, int py) {
+    int x0 = Ln.x0, y0 = Ln.y0, x1 = Ln.x1, y1 = Ln.y1;
+    int dx = abs(x1 - x0), dy = abs(y1 - y0);
+    int sx = x0 < x1 ? 1 : -1, sy = y0 < y1 ? 1 : -1;
+    int err = dx - dy;
+    int x = x0, y = y0;
+    bool hit = false;
+    while (x != x1 || y != y1) {
+        hit = hit || (x == px && y == py);
+        int e2 = err * 2;
+        if (e2 > -dy) {
+            err -= dy;
+            x += sx;
+        }
+        if (e2 < dx) {
+            err += dx;
+            y += sy;
+        }
+    }
+    return hit;
+}
+
+}  // namespace
+
+extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS) k_raster(RasterParams P) {
+    const uint32_t bin = blockIdx.x;
+    const uint32_t tx = bin % P.tiles_x, ty = bin / P.tiles_x;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t tile_x0 = tx * RXR_TILE_W, tile_y0px = (P.tile_y0 + ty * P.tile_stride) * RXR_TILE_H;
+    const uint32_t px = tile_x0 + (tid & (RXR_TILE_W - 1));
+    const uint32_t py = tile_y0px + (tid / RXR_TILE_W);
+    const float fx = (float)px + 0.5f, fy = (float)py + 0.5f;  // rasterizer.rs:1022
+    const bool in_frame = px < P.width && py >= P.row0 && py < P.row1;
+
+    // tile initial colour: zeros | background colour | background shader (rasterizer.rs:277-308)
+    uint32_t color = 0u;
+    if (P.flags & RXR_FLAG_HAS_BACKGROUND_COLOR) color = P.background_color;
+    if (!(P.flags & RXR_FLAG_IGNORE_BG_SHADER)) {
+        if (P.background_kind == RXR_BG_VGRADIENT) {
+            uint32_t i = sat_u8(rclamp(((float)py / P.fheight) * 128.0f, 0.0f, 128.0f));  // shader/vgradient.rs:11-15
+            color = pack4(i, i, i, 255u);
+        } else if (P.background_kind == RXR_BG_HOST_PIXELS && in_frame) {
+            color = P.bg_pixels[(size_t)py * P.width + px];
+        }
+    }
+
+    if (P.flags & RXR_FLAG_D3_ACTIVE) {
+        int surf_profile = -1;
+        Vis op;
+        op.zmin = 1.0f; op.best = -1; op.alpha = 0.0f; op.beta = 0.0f;
+        if (P.has_opacity) {
+            scan_lists<true>(P, bin, tile_x0, tile_y0px, px, py, fx, fy, op, -1);
+            if (op.best >= 0) {
+                const DevBatch &OB = P.batches3d[P.tri_setup[op.best].batch];
+                surf_profile = (OB.flags & DB_HAS_PROFILE) ? (int)OB.profile_id : -1;
+            }
+        }
+        Vis vis;
+        vis.zmin = 1.0f; vis.best = -1; vis.alpha = 0.0f; vis.beta = 0.0f;
+        scan_lists<false>(P, bin, tile_x0, tile_y0px, px, py, fx, fy, vis, surf_profile);
+
+        // resolve (rasterizer.rs:409-497): hit -> shaded colour; miss -> [0,0,0,255]
+        if (vis.best >= 0) {
+            color = shade3d(P, (uint32_t)vis.best, P.tri_setup[vis.best].batch, vis.alpha, vis.beta, vis.zmin, fx, fy);
+        } else {
+            color = pack4(0u, 0u, 0u, 255u);
+        }
+        if (op.best >= 0 && op.zmin < 1.0f && vis.zmin > op.zmin) {  // :464-495
+            uint32_t src = shade3d_opacity(P, (uint32_t)op.best, P.tri_setup[op.best].batch, op.alpha, op.beta);
+            float src_r = (float)(src & 0xFFu), src_g = (float)((src >> 8) & 0xFFu), src_b = (float)((src >> 16) & 0xFFu);
+            float src_a = (float)(src >> 24) / 255.0f;
+            float dst_r = (float)(color & 0xFFu), dst_g = (float)((color >> 8) & 0xFFu), dst_b = (float)((color >> 16) & 0xFFu);
+            float dst_a = (float)(color >> 24) / 255.0f;
+            float inv_a = 1.0f - src_a;
+            float out_r = src_r * src_a + dst_r * inv_a;
+            float out_g = src_g * src_a + dst_g * inv_a;
+            float out_b = src_b * src_a + dst_b * inv_a;
+            float out_a = !(P.flags & RXR_FLAG_PRESERVE_TRANSPARENCY) ? 1.0f : rclamp(src_a + dst_a * inv_a, 0.0f, 1.0f);
+            color = pack4(sat_u8(rclamp(out_r, 0.0f, 255.0f)), sat_u8(rclamp(out_g, 0.0f, 255.0f)), sat_u8(rclamp(out_b, 0.0f, 255.0f)),
+                          sat_u8(rclamp(out_a * 255.0f, 0.0f, 255.0f)));
+        }
+    }
+
+    if (P.flags & RXR_FLAG_D2_ACTIVE) {  // rasterizer.rs:501-553, strictly in submission order
+        for (uint32_t it = 0; it < P.n_items2d; ++it) {
+            const Item2D I = P.items2d[it];
+            const DevBatch &B = P.batches2d[I.batch];
+            if (!I.is_lines) {
+                for (uint32_t k = 0; k < I.count; ++k) {
+                    const Tri2D &T = P.tri2d[I.first + k];
+                    // clamped box (rasterizer.rs:615-634)
+                    float min_xf = fminf(T.v0x, fminf(T.v1x, T.v2x)), max_xf = fmaxf(T.v0x, fmaxf(T.v1x, T.v2x));
+                    float min_yf = fminf(T.v0y, fminf(T.v1y, T.v2y)), max_yf = fmaxf(T.v0y, fmaxf(T.v1y, T.v2y));
+                    uint32_t min_x = sat_index(fmaxf(floorf(min_xf), 0.0f), 0xFFFFu);
+                    uint32_t max_x = sat_index(fminf(ceilf(max_xf), (float)P.width), 0xFFFFu);
+                    uint32_t min_y = sat_index(fmaxf(floorf(min_yf), 0.0f), 0xFFFFu);
+                    uint32_t max_y = sat_index(fminf(ceilf(max_yf), (float)P.height), 0xFFFFu);
+                    if (min_x >= tile_x0 + RXR_TILE_W || max_x <= tile_x0 || min_y >= tile_y0px + RXR_TILE_H || max_y <= tile_y0px)
+                        continue;  // uniform
+                    bool in = px >= min_x && px < max_x && py >= min_y && py < max_y && T.visible;
+                    float r0 = T.ea[0] * fx + T.eb[0] * fy + T.ec[0];
+                    float r1 = T.ea[1] * fx + T.eb[1] * fy + T.ec[1];
+                    float r2 = T.ea[2] * fx + T.eb[2] * fy + T.ec[2];
+                    in = in && !(r0 < 0.0f) && !(r1 < 0.0f) && !(r2 < 0.0f);
+                    if (in) color = fragment2d(P, T, B, px, py, fx, fy, color);
+                }
+            } else {
+                for (uint32_t k = 0; k < I.count; ++k) {
+                    const Line2D &Ln = P.line2d[I.first + k];
+                    int lx0 = min(Ln.x0, Ln.x1), lx1 = max(Ln.x0, Ln.x1), ly0 = min(Ln.y0, Ln.y1), ly1 = max(Ln.y0, Ln.y1);
+                    if (lx0 >= (int)(tile_x0 + RXR_TILE_W) || lx1 < (int)tile_x0 || ly0 >= (int)(tile_y0px + RXR_TILE_H) || ly1 < (int)tile_y0px)
+                        continue;  // uniform: the walk never leaves the endpoint box
+                    if (bresenham_hits(Ln, (int)px, (int)py)) color = Ln.color;
+                }
+            }
+        }
+    }
+
+    if (in_frame) {
+        const int64_t row = P.compact ? (int64_t)(ty * RXR_TILE_H + tid / RXR_TILE_W) : (int64_t)py - P.out_base_row;
+        P.out[(size_t)row * P.out_row_stride + px] = color;
+    }
+}
+
+// ---- host-callable launchers (used by rxr_api.hip) ------------------------------------------------
+extern "C" void rxr_launch_setup(const RasterParams *P, hipStream_t s) {
+    if (P->n_tris3d == 0) return;
+    uint32_t blocks = (P->n_tris3d + 255u) / 256u;
+    hipLaunchKernelGGL(k_setup3d, dim3(blocks), dim3(256), 0, s, *P);
+}
+extern "C" void rxr_launch_scan(const RasterParams *P, hipStream_t s) { hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, *P); }
+extern "C" void rxr_launch_fill(const RasterParams *P, hipStream_t s) {
+    if (P->n_tris3d == 0) return;
+    uint32_t blocks = (P->n_tris3d + 255u) / 256u;
+    hipLaunchKernelGGL(k_fill, dim3(blocks), dim3(256), 0, s, *P);
+}
+extern "C" void rxr_launch_raster(const RasterParams *P, hipStream_t s) {
+    uint32_t tiles = P->tiles_x * P->tiles_y;
+    if (tiles == 0) return;
+    hipLaunchKernelGGL(k_raster, dim3(tiles), dim3(RXR_TILE_THREADS), 0, s, *P);
+}

@@ -1,0 +1,342 @@
+"""GPU parity: the HIP path (through the C ABI of include/rxr.h) against the CPU oracle on the same
+scene descriptions.
+
+Bars (BASELINE.json north_star):
+  * bit-exact for Nearest sampling on integer-coordinate 2D batches and for everything that involves
+    no transcendental (coverage, depth, texel selection with unlit shading);
+  * within 1 per 8-bit channel for the float-interpolated, lit 3D paths.  The only arithmetic that is
+    not bit-reproducible between glibc and OCML is log2f/exp2f in pow32_fast (rasterizer.rs:1895-1901)
+    and acosf in the spot light; everything else is IEEE-exact on both sides, so a +-1 step can only
+    come from there.  TOLERANCE = 1.
+"""
+import zlib
+
+import numpy as np
+import pytest
+
+from rusterix_amd import binding as B
+from rusterix_amd import scenes
+
+pytestmark = pytest.mark.gpu
+
+TOLERANCE = 1  # per 8-bit channel, lit 3D only
+
+
+def both(oracle, product, builder, **kw):
+    got = scenes.render(builder(product, **kw))
+    ref = scenes.render(builder(oracle, **kw))
+    return got, ref
+
+
+def assert_exact(got, ref, what):
+    if not np.array_equal(got, ref):
+        d = np.argwhere((got != ref).any(axis=2))
+        y, x = d[0]
+        raise AssertionError(f"{what}: {len(d)} pixels differ; first at (x={x}, y={y}): gpu={got[y, x]} oracle={ref[y, x]}")
+
+
+def assert_close(got, ref, what, tol=TOLERANCE, max_outliers=0):
+    diff = np.abs(got.astype(np.int16) - ref.astype(np.int16)).max(axis=2)
+    bad = np.argwhere(diff > tol)
+    if len(bad) > max_outliers:
+        y, x = bad[0]
+        raise AssertionError(f"{what}: {len(bad)} pixels differ by more than {tol}; first at (x={x}, y={y}): "
+                             f"gpu={got[y, x]} oracle={ref[y, x]}")
+    return int((diff > 0).sum())
+
+
+# ---- 2D: bit-exact ------------------------------------------------------------------------------------
+def scene_2d(api, width=256, height=160, alpha=128, background=None, ambient=None, preserve=False, lights=False,
+             linedef=False, vgradient=True):
+    rects = [
+        api.Batch2D.from_rectangle(0.0, 0.0, 200.0, 120.0).source(B.PixelSource.Pixel((200, 40, 90, alpha))),
+        api.Batch2D.from_rectangle(30.0, 20.0, 100.0, 100.0).source(B.PixelSource.StaticTileIndex(0)),
+        api.Batch2D.from_rectangle(90.0, 60.0, 150.0, 90.0).source(B.PixelSource.StaticTileIndex(1)).repeat_mode(B.REPEAT_REPEAT_XY),
+        api.Batch2D.from_rectangle(10.0, 100.0, 60.0, 40.0).source(B.PixelSource.StaticTileIndex(7)),  # missing tile -> transparent
+    ]
+    scene = api.Scene.from_static(rects, [])
+    if vgradient:
+        scene.background(api.VGrayGradientShader())
+    if lights:
+        scene.lights([B.Light(B.LIGHT_POINT).with_position((100.0, 0.0, 80.0)).with_color((1.0, 0.9, 0.6)).with_intensity(1.0)
+                      .with_start_distance(20.0).with_end_distance(120.0).compile(),
+                      B.Light(B.LIGHT_AMBIENT).with_color((0.2, 0.2, 0.3)).with_intensity(0.5).compile()])
+    assets = api.Assets.default().textures([B.Tile.from_texture(scenes.logo_texture(1, 64)), B.Tile.from_texture(scenes.fence_texture(6))])
+
+    def setup():
+        cam = api.D3OrbitCamera.new()
+        v, p = cam.matrices(float(width), float(height))
+        r = api.Rasterizer.setup(None, v, p).render_mode(B.RenderMode.render_2d())
+        if background is not None:
+            r.background(background)
+        if ambient is not None:
+            r.ambient(ambient)
+        if preserve:
+            r.preserve_transparency(True)
+        if linedef:
+            r.mapmini_add_linedef((60.0, 0.0), (60.0, 200.0))
+            r.mapmini_add_occluder((120.0, 0.0), (400.0, 60.0), 0.5)
+        return r
+
+    return scenes._result(api, scene, assets, setup, width, height, 40, "2d")
+
+
+@pytest.mark.parametrize("kw", [
+    dict(),
+    dict(alpha=255),
+    dict(background=(10, 20, 30, 0), vgradient=False, preserve=True),
+    dict(ambient=(0.7, 0.8, 0.9, 1.0)),
+    dict(ambient=(0.5, 0.5, 0.5, 1.0), lights=True, linedef=True),
+    dict(lights=True),
+    dict(width=203, height=77),
+])
+def test_2d_batches_bit_exact(oracle, product, kw):
+    got, ref = both(oracle, product, scene_2d, **kw)
+    assert_exact(got, ref, f"2D scene {kw}")
+
+
+def test_2d_diagonal_blended_twice(oracle, product):
+    """SURVEY section 8c pin 1: the rectangle's diagonal is covered by both triangles and blended twice."""
+    got, ref = both(oracle, product, scene_2d, alpha=128, background=(0, 0, 0, 255), vgradient=False)
+    assert_exact(got, ref, "2D diagonal")
+    # the 200x120 rectangle's diagonal passes through the centre of pixel (x=2, y=1): 2.5 * 0.6 == 1.5
+    assert tuple(got[1, 3]) == (100, 20, 45, 255)   # one blend of (200,40,90,128) over black, truncated
+    assert tuple(got[1, 2]) == (150, 30, 67, 255)   # blended by both triangles (edge.rs:31 is inclusive)
+
+
+def lines_scene(api, width=200, height=120):
+    v = np.array([[10.2, 10.7], [150.9, 30.1], [90.0, 110.5], [20.0, 90.0], [-5.5, 40.0], [199.0, 119.0]], np.float32)
+    uv = np.zeros_like(v)
+    tris = np.array([[0, 1, 0], [1, 2, 0], [2, 3, 0], [4, 5, 0]], np.uint32)
+    lines = api.Batch2D.new(v, tris, uv).mode(B.MODE_LINES).source(B.PixelSource.Pixel((255, 200, 0, 255)))
+    strip = api.Batch2D.new(v[:4] + np.float32(7.0), tris[:1], uv[:4]).mode(B.MODE_LINE_STRIP)
+    loop = api.Batch2D.new(v[:4] * np.float32(0.5), tris[:1], uv[:4]).mode(B.MODE_LINE_LOOP).source(B.PixelSource.Pixel((0, 255, 255, 255)))
+    rect = api.Batch2D.from_rectangle(40.0, 40.0, 60.0, 30.0).source(B.PixelSource.Pixel((80, 80, 200, 100)))
+    scene = api.Scene.from_static([lines, rect, strip, loop], [])
+    assets = api.Assets.default()
+
+    def setup():
+        v_, p_ = api.D3OrbitCamera.new().matrices(float(width), float(height))
+        return api.Rasterizer.setup(None, v_, p_).render_mode(B.RenderMode.render_2d()).background((5, 5, 5, 255))
+
+    return scenes._result(api, scene, assets, setup, width, height, 40, "lines")
+
+
+def test_bresenham_lines_bit_exact(oracle, product):
+    got, ref = both(oracle, product, lines_scene)
+    assert_exact(got, ref, "Bresenham line modes")
+    assert (got[..., 0] == 255).any()
+
+
+def test_2d_matrix_projection(oracle, product):
+    def build(api):
+        cfg = scene_2d(api)
+        m = B.Mat3.from_rows([[1.5, 0.0, 12.0], [0.0, 1.5, -8.0], [0.0, 0.0, 1.0]])
+        base = cfg.setup
+
+        def setup():
+            r0 = base()
+            v, p = api.D3OrbitCamera.new().matrices(float(cfg.width), float(cfg.height))
+            r = api.Rasterizer.setup(m, v, p).render_mode(B.RenderMode.render_2d()).ambient((1.0, 1.0, 1.0, 1.0))
+            del r0
+            return r
+
+        cfg.setup = setup
+        return cfg
+
+    got, ref = scenes.render(build(product)), scenes.render(build(oracle))
+    assert_exact(got, ref, "2D with Mat3 projection")
+
+
+# ---- 3D -------------------------------------------------------------------------------------------------
+def test_empty_scene_3d_is_black(oracle, product):
+    """SURVEY section 8c pin 3: in 3D mode every non-hit pixel is [0,0,0,255] regardless of the background."""
+    def build(api):
+        scene = api.Scene.empty().background(api.VGrayGradientShader())
+        v, p = api.D3OrbitCamera.new().matrices(64.0, 48.0)
+        return scenes._result(api, scene, api.Assets.default(), lambda: api.Rasterizer.setup(None, v, p).background((9, 9, 9, 9)), 64, 48, 16, "empty")
+
+    got = scenes.render(build(product))
+    assert (got == np.array([0, 0, 0, 255], np.uint8)).all()
+    assert_exact(got, scenes.render(build(oracle)), "empty scene")
+
+
+@pytest.mark.parametrize("kw", [
+    dict(width=320, height=200, distance=3.0, textured=True, logo_size=128),
+    dict(width=320, height=200, distance=3.0, textured=False),
+    dict(width=333, height=211, distance=1.2, textured=True, logo_size=128),   # near plane clipping + odd size
+    dict(width=320, height=200, distance=3.0, textured=True, logo_size=128, sample_mode=B.SAMPLE_LINEAR),
+])
+def test_cube_unlit_bit_exact(oracle, product, kw):
+    """C1: no lights, no ambient -> lit == 0 -> the colour path has no transcendental: bit-exact."""
+    got, ref = both(oracle, product, scenes.cube_scene, **kw)
+    assert_exact(got, ref, f"cube {kw}")
+
+
+def test_teapot_ambient(oracle, product):
+    """C2 (stand-in mesh): ambient only, no transcendental -> bit-exact; also exercises the bin lists."""
+    got, ref = both(oracle, product, scenes.teapot_scene, width=480, height=270, logo_size=256)
+    assert_exact(got, ref, "teapot ambient")
+    assert (got[..., :3].max(axis=2) > 0).mean() > 0.05
+
+
+def test_teapot_lit(oracle, product):
+    got, ref = both(oracle, product, scenes.teapot_scene, width=480, height=270, logo_size=256, with_light=True)
+    n = assert_close(got, ref, "teapot lit")
+    assert n <= got.shape[0] * got.shape[1] // 50, f"{n} pixels differ by 1 -- more than log2/exp2 rounding explains"
+
+
+@pytest.mark.parametrize("n_lights", [1, 16])
+def test_map_scene(oracle, product, n_lights):
+    """C3 / C4 at reduced resolution: lit 3D + cut-out fence + 2D logo on top."""
+    kw = dict(width=640, height=360, logo_size=128, n_lights=n_lights)
+    got, ref = both(oracle, product, scenes.map_scene, **kw)
+    n = assert_close(got, ref, f"map {n_lights} lights")
+    assert n <= got.shape[0] * got.shape[1] // 50
+    assert_exact(got[:200, :200], ref[:200, :200], "2D logo rectangle over the 3D frame")  # bit-exact part
+
+
+def test_map_scene_linear_sampling(oracle, product):
+    kw = dict(width=400, height=240, logo_size=128, n_lights=4, sample_mode=B.SAMPLE_LINEAR)
+    got, ref = both(oracle, product, scenes.map_scene, **kw)
+    assert_close(got, ref, "map linear")
+
+
+def test_box_grid(oracle, product):
+    """C5 in miniature: many small triangles through the bins, Linear sampling, ambient only -> exact."""
+    kw = dict(n=24, width=512, height=288)
+    got, ref = both(oracle, product, scenes.box_grid_scene, **kw)
+    assert_exact(got, ref, "box grid")
+    assert (got[..., :3].max(axis=2) > 0).mean() > 0.1
+
+
+def test_all_light_types_and_sun(oracle, product):
+    def build(api):
+        cfg = scenes.map_scene(api, width=320, height=180, logo_size=64, n_lights=1)
+        sc = cfg.scene
+        sc.lights([
+            B.Light(B.LIGHT_AMBIENT).with_color((0.1, 0.2, 0.1)).with_intensity(0.5).compile(),
+            B.Light(B.LIGHT_AMBIENT_DAYLIGHT).with_color((0.1, 0.1, 0.2)).with_intensity(0.4).with_flicker(0.3).compile(),
+            _light(B.LIGHT_SPOT, (7.0, 1.8, 8.0), direction=(0.0, -1.0, 0.3), cone_angle=0.7, end=9.0, start=1.0, intensity=2.0),
+            _light(B.LIGHT_AREA, (3.0, 1.0, 12.0), normal=(0.0, 0.0, -1.0), end=6.0, start=1.0, intensity=1.5, width=2.0, height=1.0),
+            _light(B.LIGHT_AREA, (12.0, 1.0, 12.0), normal=(-1.0, 0.0, 0.0), end=6.0, start=1.0, intensity=0.7, width=2.0, height=1.0, from_linedef=True),
+            _light(B.LIGHT_DAYLIGHT, (7.0, 3.0, 10.0), normal=(0.0, -1.0, 0.0), end=12.0, start=2.0, intensity=0.8),
+        ])
+        sc.add_dynamic_light(B.Light(B.LIGHT_POINT).with_position((2.0, 1.0, 6.0)).with_color((0.9, 0.3, 0.2)).with_intensity(1.2)
+                             .with_start_distance(1.0).with_end_distance(5.0).with_flicker(0.5).compile())
+        base = cfg.setup
+
+        def setup():
+            return base().sun((0.3, -1.0, 0.2), 0.6).mapmini_add_occluder((0.0, 9.0), (6.0, 15.0), 0.35)
+
+        cfg.setup = setup
+        return cfg
+
+    got, ref = scenes.render(build(product)), scenes.render(build(oracle))
+    # acosf decides cone membership: allow a handful of cone-edge pixels to flip
+    assert_close(got, ref, "all light types", max_outliers=got.shape[0] * got.shape[1] // 2000)
+
+
+def _light(kind, pos, direction=(0.0, 0.0, -1.0), cone_angle=0.785, normal=(0.0, 1.0, 0.0), start=1.0, end=2.0, intensity=1.0,
+           width=1.0, height=1.0, from_linedef=False):
+    l = B.Light(kind).with_position(pos).with_intensity(intensity).with_start_distance(start).with_end_distance(end)
+    l.direction, l.cone_angle, l.normal, l.width, l.height, l.from_linedef = direction, cone_angle, normal, width, height, from_linedef
+    return l.compile()
+
+
+def test_chunks_opacity_and_profile_ids(oracle, product):
+    """Rows R4/R5: chunk opacity batches, src-over resolve, surface-id skip, chunk occlusion + chunk lights."""
+    def build(api):
+        scene = api.Scene.empty()
+        ch = scene.add_chunk()
+        wall = api.Batch3D.from_box(-1.0, -1.0, -0.2, 2.0, 2.0, 0.2).source(B.PixelSource.StaticTileIndex(0)).with_computed_normals().profile_id(7)
+        other = api.Batch3D.from_box(-2.5, -0.5, -1.5, 1.0, 1.0, 1.0).source(B.PixelSource.Pixel((40, 200, 90, 255))).with_computed_normals().profile_id(9)
+        glass = api.Batch3D.from_box(-0.8, -0.8, 0.6, 1.6, 1.6, 0.05).source(B.PixelSource.Pixel((200, 220, 255, 110))).with_computed_normals().profile_id(7)
+        glass2 = api.Batch3D.from_box(-2.6, -0.6, 0.4, 1.2, 1.2, 0.05).source(B.PixelSource.StaticTileIndex(1)).with_computed_normals()
+        ch.add_batch3d(wall).add_batch3d(other).add_batch3d_opacity(glass).add_batch3d_opacity(glass2)
+        ch.add_occluder((-3.0, -3.0), (-1.2, 3.0), 0.4)
+        ch.add_light(B.Light(B.LIGHT_POINT).with_position((0.0, 1.5, 2.0)).with_intensity(2.0).with_start_distance(1.0).with_end_distance(8.0).compile())
+        scene.add_d3_static(api.Batch3D.from_box(1.3, -0.5, -0.5, 0.8, 0.8, 0.8).source(B.PixelSource.Pixel((220, 60, 60, 255))).with_computed_normals())
+        assets = api.Assets.default().textures([B.Tile.from_texture(scenes.brick_texture(2)), B.Tile.from_texture(scenes.fence_texture(6))])
+        cam = api.D3OrbitCamera.new()
+        cam.set_parameter_f32("distance", 4.5)
+        v, p = cam.matrices(320.0, 200.0)
+        return scenes._result(api, scene, assets, lambda: api.Rasterizer.setup(None, v, p).ambient((0.6, 0.6, 0.6, 1.0)), 320, 200, 40, "chunks")
+
+    got, ref = scenes.render(build(product)), scenes.render(build(oracle))
+    assert_close(got, ref, "chunk opacity scene")
+
+
+# ---- properties -------------------------------------------------------------------------------------------
+def test_row_bands_equal_full_frame(product):
+    """Multi-GPU sharding invariant: rendering row bands separately gives the same bytes as one launch."""
+    import ctypes as C
+
+    cfg = scenes.map_scene(product, width=640, height=360, logo_size=64, n_lights=4)
+    full = scenes.render(cfg).copy()
+    lib = product.lib
+    rxr = C.CDLL(__import__("rusterix_amd").lib_paths()["rxr"])
+    lib.rxh_context.restype = C.c_void_p
+    lib.rxh_rasterizer_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+    rxr.rxr_render_rows.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+    rxr.rxr_download_rows.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), C.c_uint32, C.c_uint32]
+    r = cfg.setup()
+    assert lib.rxh_rasterizer_upload(r._h, cfg.scene._h, cfg.width, cfg.height, cfg.tile_size, cfg.assets._h) == 0
+    ctx = lib.rxh_context()
+    out = np.zeros((cfg.height, cfg.width, 4), np.uint8)
+    for (a, b) in [(0, 45), (45, 90), (90, 203), (203, 360)]:  # deliberately not tile aligned
+        assert rxr.rxr_render_rows(ctx, a, b) == 0
+        assert rxr.rxr_download_rows(ctx, out.ctypes.data_as(C.POINTER(C.c_uint8)), a, b) == 0
+    assert_exact(out, full, "row bands vs full frame")
+
+
+def test_tile_size_invariance(oracle, product):
+    """R9: the oracle's output does not depend on tile_size, and equals the GPU's (which ignores it)."""
+    frames = []
+    for ts in (16, 40, 200):
+        cfg = scenes.cube_scene(oracle, width=256, height=160, tile_size=ts, textured=True, distance=3.0, logo_size=64)
+        frames.append(scenes.render(cfg).copy())
+    assert_exact(frames[0], frames[1], "oracle tile 16 vs 40")
+    assert_exact(frames[0], frames[2], "oracle tile 16 vs 200")
+    got = scenes.render(scenes.cube_scene(product, width=256, height=160, tile_size=40, textured=True, distance=3.0, logo_size=64))
+    assert_exact(got, frames[0], "gpu vs oracle")
+
+
+def test_repeatability(product):
+    cfg = scenes.map_scene(product, width=320, height=180, logo_size=64, n_lights=16)
+    a = scenes.render(cfg).copy()
+    b = scenes.render(cfg).copy()
+    assert_exact(a, b, "same frame twice")
+
+
+def test_full_size_frame_properties(product):
+    """BASELINE config C4 at full size (3840x2160, 16 lights): size-independent properties only."""
+    cfg = scenes.map_scene(product, width=3840, height=2160, n_lights=16)
+    img = scenes.render(cfg)
+    assert (img[..., 3] == 255).all()                       # every pixel resolved (rasterizer.rs:420-461)
+    assert (img[: 2160 // 3, 300:] == np.array([0, 0, 0, 255], np.uint8)).all(axis=2).mean() > 0.5   # sky is black
+    assert img[1500:, :, :3].max() > 60                      # lit floor
+    # band invariance at full size through a checksum of checksums
+    rows = [zlib.crc32(img[y].tobytes()) for y in range(0, 2160, 135)]
+    img2 = scenes.render(cfg)
+    assert rows == [zlib.crc32(img2[y].tobytes()) for y in range(0, 2160, 135)]
+
+
+# ---- error behaviour ---------------------------------------------------------------------------------------
+def test_errors_are_reported_not_thrown(product):
+    scene = product.Scene.from_static([], [product.Batch3D.from_box(-0.5, -0.5, -0.5, 1, 1, 1)])  # no normals: reference panics
+    v, p = product.D3OrbitCamera.new().matrices(64.0, 64.0)
+    out = np.zeros(64 * 64 * 4, np.uint8)
+    with pytest.raises(B.RasterizeError) as e:
+        product.Rasterizer.setup(None, v, p).rasterize(scene, out, 64, 64, 16, product.Assets.default())
+    assert e.value.code == B.RXR_ERR_INVALID
+    scene = product.Scene.from_static([], [product.Batch3D.from_box(-0.5, -0.5, -0.5, 1, 1, 1).with_computed_normals()
+                                           .source(B.PixelSource.StaticTileIndex(3))])  # tile_list[3] panics
+    cam = product.D3OrbitCamera.new()
+    cam.set_parameter_f32("distance", 3.0)
+    v, p = cam.matrices(64.0, 64.0)
+    with pytest.raises(B.RasterizeError) as e:
+        product.Rasterizer.setup(None, v, p).rasterize(scene, out, 64, 64, 16, product.Assets.default())
+    assert e.value.code == B.RXR_ERR_INVALID
+    with pytest.raises(B.RasterizeError):
+        product.Rasterizer.setup(None, v, p).rasterize(product.Scene.empty(), out, 64, 64, 0, product.Assets.default())
