@@ -63,9 +63,12 @@ struct rxr_ctx {
     void *h_stage = nullptr;
     size_t h_stage_cap = 0;
     DevBuf d_frame;
-    DevBuf d_tri_setup, d_tri_shade, d_bins, d_list, d_large, d_counters, d_fb;
-    uint32_t *h_counters = nullptr;  // pinned, CNT_WORDS
+    DevBuf d_tri_setup, d_tri_shade, d_bin_count, d_bins, d_list, d_large, d_counters, d_fb;
+    uint32_t *h_counters = nullptr;  // pinned, CNT_WORDS; written by k_scan through d_host_status
+    uint32_t *d_host_status = nullptr;
     uint32_t list_capacity = 0;
+    uint32_t parity = 0;             // counter set of the next launch
+    bool scratch_dirty = false;      // a pre-pass was queued without its raster launch
 
     bool has_frame = false;
     RasterParams P{};       // template for the resident frame (pointers resolved)
@@ -183,6 +186,7 @@ int rxr_create(rxr_ctx **out, int device_id) {
         return fail(nullptr, RXR_ERR_HIP, msg);
     }
     memset(ctx->h_counters, 0, CNT_WORDS * sizeof(uint32_t));
+    if (hipHostGetDevicePointer((void **)&ctx->d_host_status, ctx->h_counters, 0) != hipSuccess) ctx->d_host_status = ctx->h_counters;
     *out = ctx;
     return RXR_OK;
 }
@@ -191,7 +195,7 @@ void rxr_destroy(rxr_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    DevBuf *bufs[] = {&ctx->d_tex, &ctx->d_texels, &ctx->d_frame, &ctx->d_tri_setup, &ctx->d_tri_shade, &ctx->d_bins,
+    DevBuf *bufs[] = {&ctx->d_tex, &ctx->d_texels, &ctx->d_frame, &ctx->d_tri_setup, &ctx->d_tri_shade, &ctx->d_bin_count, &ctx->d_bins,
                       &ctx->d_list, &ctx->d_large, &ctx->d_counters, &ctx->d_fb};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
@@ -554,9 +558,21 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
     size_t n_bins = (size_t)tiles_x * tiles_y_all;
     if ((rc = ensure(ctx, ctx->d_tri_setup, (n_t3 ? n_t3 : 1) * sizeof(TriSetup))) != RXR_OK) return rc;
     if ((rc = ensure(ctx, ctx->d_tri_shade, (n_t3 ? n_t3 : 1) * sizeof(TriShade))) != RXR_OK) return rc;
-    if ((rc = ensure(ctx, ctx->d_bins, (3 * n_bins + 8) * sizeof(uint32_t))) != RXR_OK) return rc;
+    const size_t n_chunks = (n_bins + RXR_SCAN_CHUNK - 1) / RXR_SCAN_CHUNK + 1;
+    {
+        // bin_count lives in its OWN buffer: the invariant "all-zero between launches" (k_raster hands every
+        // bin back cleared) must hold for whatever frame size comes next, so nothing else may share it
+        void *before = ctx->d_bin_count.p;
+        if ((rc = ensure(ctx, ctx->d_bin_count, (n_bins + 1) * sizeof(uint32_t))) != RXR_OK) return rc;
+        if (ctx->d_bin_count.p != before) HIPCHK(ctx, hipMemsetAsync(ctx->d_bin_count.p, 0, ctx->d_bin_count.cap, ctx->stream));
+    }
+    if ((rc = ensure(ctx, ctx->d_bins, (2 * (n_bins + 1) + 2 * n_chunks + 8) * sizeof(uint32_t))) != RXR_OK) return rc;
     if ((rc = ensure(ctx, ctx->d_large, (n_t3 ? n_t3 : 1) * sizeof(uint32_t))) != RXR_OK) return rc;
-    if ((rc = ensure(ctx, ctx->d_counters, CNT_WORDS * sizeof(uint32_t))) != RXR_OK) return rc;
+    {
+        void *before = ctx->d_counters.p;
+        if ((rc = ensure(ctx, ctx->d_counters, 2 * CNT_WORDS * sizeof(uint32_t))) != RXR_OK) return rc;
+        if (ctx->d_counters.p != before) HIPCHK(ctx, hipMemsetAsync(ctx->d_counters.p, 0, ctx->d_counters.cap, ctx->stream));
+    }
     size_t want_list = std::max<size_t>(1u << 20, n_t3 * 4);
     if (want_list > ctx->list_capacity) {
         if ((rc = ensure(ctx, ctx->d_list, want_list * sizeof(uint32_t))) != RXR_OK) return rc;
@@ -606,9 +622,12 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
     P.batch_tri_base = (const uint32_t *)(d + L.off_base);
     P.tri_setup = (TriSetup *)ctx->d_tri_setup.p;
     P.tri_shade = (TriShade *)ctx->d_tri_shade.p;
-    P.bin_count = (uint32_t *)ctx->d_bins.p;
-    P.bin_offset = P.bin_count + n_bins + 1;
+    P.bin_count = (uint32_t *)ctx->d_bin_count.p;
+    P.bin_offset = (uint32_t *)ctx->d_bins.p;
     P.bin_cursor = P.bin_offset + n_bins + 1;
+    P.chunk_tot = P.bin_cursor + n_bins + 1;
+    P.chunk_base = P.chunk_tot + n_chunks;
+    P.host_status = ctx->d_host_status;
     P.bin_list = (uint32_t *)ctx->d_list.p;
     P.large_list = (uint32_t *)ctx->d_large.p;
     P.counters = (uint32_t *)ctx->d_counters.p;
@@ -666,21 +685,32 @@ static int render_impl(rxr_ctx *ctx, const RenderSpec &spec, void *dev_pixels, h
     ctx->last_e1 = e1;
     ctx->last_e2 = e2;
     HIPCHK(ctx, hipEventRecord(e0, s));
-    if (P.tiles_y && (P.flags & RXR_FLAG_D3_ACTIVE)) {
-        HIPCHK(ctx, hipMemsetAsync(P.counters, 0, CNT_WORDS * sizeof(uint32_t), s));
-        HIPCHK(ctx, hipMemsetAsync(P.bin_count, 0, (n_bins + 1) * sizeof(uint32_t), s));
+    const bool prepass = P.tiles_y && (P.flags & RXR_FLAG_D3_ACTIVE);
+    if (prepass && ctx->scratch_dirty) {
+        // a previous launch sequence was cut short: restore the all-zero invariants explicitly
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_bin_count.p, 0, ctx->d_bin_count.cap, s));
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_counters.p, 0, ctx->d_counters.cap, s));
+    }
+    if (prepass) {
+        ctx->scratch_dirty = true;
+        // counter set `parity` is clean (cleared by the previous launch's k_scan); this launch's k_scan
+        // clears the other set.  bin_count is clean because k_raster hands every bin back zeroed.
+        P.counters = (uint32_t *)ctx->d_counters.p + (size_t)ctx->parity * CNT_WORDS;
+        P.counters_next = (uint32_t *)ctx->d_counters.p + (size_t)(ctx->parity ^ 1u) * CNT_WORDS;
+        ctx->parity ^= 1u;
         rxr_launch_setup(&P, s);
         rxr_launch_scan(&P, s);
         rxr_launch_fill(&P, s);
-    } else if (P.tiles_y) {
-        HIPCHK(ctx, hipMemsetAsync(P.counters, 0, CNT_WORDS * sizeof(uint32_t), s));
-        HIPCHK(ctx, hipMemsetAsync(P.bin_offset, 0, (n_bins + 1) * sizeof(uint32_t), s));
+    } else {
+        ctx->h_counters[CNT_ENTRIES] = 0;
+        ctx->h_counters[CNT_OVERFLOW] = 0;
     }
+    (void)n_bins;
     HIPCHK(ctx, hipEventRecord(e1, s));
     rxr_launch_raster(&P, s);
     HIPCHK(ctx, hipEventRecord(e2, s));
-    HIPCHK(ctx, hipMemcpyAsync(ctx->h_counters, P.counters, CNT_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIPCHK(ctx, hipGetLastError());
+    ctx->scratch_dirty = false;  // the raster launch that hands the bins back is queued
     ctx->rendered = true;
     ctx->last_spec = spec;
     ctx->last_out = dev_pixels;

@@ -56,8 +56,12 @@ struct TriSetup {
     uint32_t batch;
     uint32_t bx;              // pixel box: min_x | max_x << 16 (whole screen clamp, exclusive max)
     uint32_t by;              // min_y | max_y << 16
-    uint32_t pad[2];
+    uint32_t bflags;          // copy of the batch's DevBatch.flags (saves a dependent load per candidate)
+    uint32_t profile_id;      // copy of the batch's profile id
 };
+static_assert(sizeof(TriSetup) == 96, "TriSetup is staged through LDS as 6 x 16 B");
+// candidates staged per round in k_raster (LDS: RXR_STAGE_TRIS * 96 B)
+#define RXR_STAGE_TRIS 128
 
 // per-triangle record for shading the winning fragment.  80 B = 5 x 16 B.
 struct TriShade {
@@ -96,8 +100,11 @@ struct ChunkRange {
     uint32_t occ_first, occ_count;
 };
 
-// device counters (one small buffer, cleared per render)
-enum { CNT_LARGE = 0, CNT_ENTRIES = 1, CNT_OVERFLOW = 2, CNT_WORDS = 4 };
+// device counters.  Two sets: launch i uses set i&1 and k_scan's last block clears the other one for
+// launch i+1, so no per-frame memset is needed.
+enum { CNT_LARGE = 0, CNT_ENTRIES = 1, CNT_OVERFLOW = 2, CNT_TICKET = 3, CNT_WORDS = 4 };
+// bins per k_scan workgroup (256 threads x 8)
+#define RXR_SCAN_CHUNK 2048u
 
 // kernel parameter block (passed by value; lives in the kernarg segment -> scalar loads)
 struct RasterParams {
@@ -136,9 +143,13 @@ struct RasterParams {
     // set-up outputs
     TriSetup *tri_setup;
     TriShade *tri_shade;
-    uint32_t *bin_count;           // tiles_x * tiles_y (+1)
-    uint32_t *bin_offset;          // exclusive scan of bin_count, + total at the end
+    uint32_t *bin_count;           // tiles_x * tiles_y; all-zero between launches (k_raster clears its own bin)
+    uint32_t *bin_offset;          // chunk-local exclusive scan of bin_count; add chunk_base[bin / RXR_SCAN_CHUNK]
     uint32_t *bin_cursor;
+    uint32_t *chunk_tot;           // per k_scan workgroup: number of list entries of its chunk
+    uint32_t *chunk_base;          // exclusive scan of chunk_tot (written by the last k_scan workgroup)
+    uint32_t *counters_next;       // the other counter set, cleared for the next launch
+    uint32_t *host_status;         // pinned host words (device-visible), indexed like the counters: [CNT_ENTRIES], [CNT_OVERFLOW]
     uint32_t *bin_list;
     uint32_t *large_list;
     uint32_t *counters;

@@ -315,9 +315,16 @@ __device__ __forceinline__ uint32_t batch_texel(const RasterParams &P, const Dev
     return sample_texture(P.tex[B.tex], P.texels, u, v, P.sample_mode, B.repeat_mode);
 }
 
-// the covered-fragment block of d3_rasterize after the depth test (rasterizer.rs:1062-1404)
-__device__ __forceinline__ uint32_t shade3d(const RasterParams &P, uint32_t t, uint32_t batch_id, float alpha, float beta,
-                                            float z, float fx, float fy) {
+// ---- the covered-fragment block of d3_rasterize after the depth test (rasterizer.rs:1062-1404) ----
+// Split in three so that the light loop runs in wave-uniform control flow (see shade3d_lights).
+struct Frag {
+    f3 world, normal, view_dir, base, lit;
+    float opacity;
+};
+
+// everything before the light loop: uv, world position, normal, texel, ambient terms (:1062-1370)
+__device__ __forceinline__ void shade3d_begin(const RasterParams &P, uint32_t t, uint32_t batch_id, float alpha, float beta,
+                                              float z, float fx, float fy, Frag &F) {
     const TriShade S = P.tri_shade[t];
     const DevBatch &B = P.batches3d[batch_id];
     float gamma = 1.0f - alpha - beta;
@@ -352,10 +359,10 @@ __device__ __forceinline__ uint32_t shade3d(const RasterParams &P, uint32_t t, u
     const float INV_255 = 1.0f / 255.0f;  // lib.rs:52
     f3 base = mk3(srgb_to_linear_fast((float)(texel & 0xFFu) * INV_255), srgb_to_linear_fast((float)((texel >> 8) & 0xFFu) * INV_255),
                   srgb_to_linear_fast((float)((texel >> 16) & 0xFFu) * INV_255));
-    float opacity = (float)(texel >> 24) / 255.0f;  // :1313
+    F.opacity = (float)(texel >> 24) / 255.0f;  // :1313
 
     normal = norm3(normal);  // :1320
-    const float rough = 0.5f, metal = 0.0f;
+    const float rough = 0.5f, metal = 0.0f;  // :1315-1316 (no-shader branch)
 
     f3 lit = mk3(0.0f, 0.0f, 0.0f);
     float occlusion;
@@ -379,25 +386,88 @@ __device__ __forceinline__ uint32_t shade3d(const RasterParams &P, uint32_t t, u
         lit = scale3(lit, occlusion);
     }
     lit = add3(lit, scale3(mul3(mk3(B.ambient[0], B.ambient[1], B.ambient[2]), kd), hemi));  // :1368-1370
+    F.world = world;
+    F.normal = normal;
+    F.view_dir = view_dir;
+    F.base = base;
+    F.lit = lit;
+}
 
-    for (uint32_t li = 0; li < P.n_lights; ++li) {  // :1373-1391
-        const rxr_light &L = P.lights[li];
-        f3 incoming;
-        if (!light_color_at(L, world, P.hash_anim, false, incoming)) continue;
-        f3 ldir = norm3(sub3(mk3(L.position[0], L.position[1], L.position[2]), world));
-        f3 radiance;
-        if (L.light_type == RXR_LIGHT_AMBIENT || L.light_type == RXR_LIGHT_AMBIENT_DAYLIGHT || L.light_type == RXR_LIGHT_DAYLIGHT) {
-            radiance = incoming;
-        } else {
-            float lambert = fmaxf(dot3(normal, ldir), 0.0f);  // radiance_at, light.rs:529-532
-            radiance = scale3(incoming, lambert);
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d, 64));
+    return v;
+}
+
+// The direct-light loop (:1373-1391).  Must be called by EVERY lane of the wave (`hit` marks the lanes
+// that own a fragment).  Lights are first culled per WAVE, one light per lane: a light whose range
+// sphere cannot reach the bounding sphere of the wave's fragments is one for which every lane's
+// `distance >= end_distance` test (light.rs:539, 561, 586, 636) would return None, so skipping it
+// changes nothing; the surviving lights are then evaluated in their original order.
+__device__ __forceinline__ void shade3d_lights(const RasterParams &P, bool hit, Frag &F) {
+    const unsigned long long hitmask = __ballot(hit);
+    if (hitmask == 0ull) return;
+    const int lane = (int)(threadIdx.x & 63u);
+    const int src = __ffsll((long long)hitmask) - 1;
+    const f3 c = mk3(__shfl(F.world.x, src, 64), __shfl(F.world.y, src, 64), __shfl(F.world.z, src, 64));
+    const float r = hit ? mag3(sub3(F.world, c)) : 0.0f;
+    // NaN / inf world positions are not bounded by the sphere: no culling for this wave then
+    const bool can_cull = __ballot(hit && !(r < INFINITY)) == 0ull;
+    const float rmax = wave_max(r);
+    const float rough = 0.5f, metal = 0.0f;
+
+    for (uint32_t base_i = 0; base_i < P.n_lights; base_i += 64u) {
+        const uint32_t mine = base_i + (uint32_t)lane;
+        bool cand = mine < P.n_lights;
+        if (cand && can_cull) {
+            const rxr_light &L = P.lights[mine];
+            if (L.light_type == RXR_LIGHT_POINT || L.light_type == RXR_LIGHT_SPOT || L.light_type == RXR_LIGHT_AREA ||
+                L.light_type == RXR_LIGHT_DAYLIGHT) {
+                float dcl = mag3(sub3(c, mk3(L.position[0], L.position[1], L.position[2])));
+                // every fragment p of the wave has |p - L| >= dcl - rmax; the margin covers rounding
+                float margin = 1e-3f * (dcl + rmax + fabsf(L.end_distance)) + 1e-6f;
+                if (dcl - rmax > L.end_distance + margin) cand = false;
+            }
         }
-        lit = add3(lit, shade_fast_brdf(base, rough, metal, normal, view_dir, ldir, radiance));
+        unsigned long long todo = __ballot(cand);
+        while (todo) {
+            const uint32_t li = base_i + (uint32_t)(__ffsll((long long)todo) - 1);
+            todo &= todo - 1ull;
+            if (!hit) continue;
+            const rxr_light &L = P.lights[li];
+            const f3 lp = mk3(L.position[0], L.position[1], L.position[2]);
+            f3 incoming, ldir;
+            if (L.light_type == RXR_LIGHT_POINT) {
+                // calculate_point_light (light.rs:535-552) sharing d = lp - world with the caller's
+                // (lp - world).normalized(): |world - lp| and |lp - world| are the same float
+                if (!L.emitting) continue;
+                f3 d = sub3(lp, F.world);
+                float distance = mag3(d);
+                if (distance >= L.end_distance) continue;
+                float intensity = L.intensity;
+                if (!(distance <= L.start_distance)) intensity = L.intensity * smoothstep_rs(L.end_distance, L.start_distance, distance);
+                incoming = apply_flicker(L, intensity, P.hash_anim);
+                ldir = div3(d, distance);
+            } else {
+                if (!light_color_at(L, F.world, P.hash_anim, false, incoming)) continue;
+                ldir = norm3(sub3(lp, F.world));
+            }
+            f3 radiance;
+            if (L.light_type == RXR_LIGHT_AMBIENT || L.light_type == RXR_LIGHT_AMBIENT_DAYLIGHT || L.light_type == RXR_LIGHT_DAYLIGHT) {
+                radiance = incoming;
+            } else {
+                float lambert = fmaxf(dot3(F.normal, ldir), 0.0f);  // radiance_at, light.rs:529-532
+                radiance = scale3(incoming, lambert);
+            }
+            F.lit = add3(F.lit, shade_fast_brdf(F.base, rough, metal, F.normal, F.view_dir, ldir, radiance));
+        }
     }
-    // + mat_emissive (0)
+}
 
-    return pack4(f32_to_u8_saturated(linear_to_srgb_fast(lit.x)), f32_to_u8_saturated(linear_to_srgb_fast(lit.y)),
-                 f32_to_u8_saturated(linear_to_srgb_fast(lit.z)), f32_to_u8_saturated(opacity));
+// encode (:1394-1404); + mat_emissive is + 0
+__device__ __forceinline__ uint32_t shade3d_end(const Frag &F) {
+    return pack4(f32_to_u8_saturated(linear_to_srgb_fast(F.lit.x)), f32_to_u8_saturated(linear_to_srgb_fast(F.lit.y)),
+                 f32_to_u8_saturated(linear_to_srgb_fast(F.lit.z)), f32_to_u8_saturated(F.opacity));
 }
 
 // the covered-fragment block of d3_rasterize_opacity (rasterizer.rs:1497-1682, no shader)
@@ -546,7 +616,8 @@ extern "C" __global__ void __launch_bounds__(256) k_setup3d(RasterParams P) {
     S.iz1 = 1.0f / v1.z;
     S.iz2 = 1.0f / v2.z;
     S.batch = lo;
-    S.pad[0] = S.pad[1] = 0;
+    S.bflags = B.flags;
+    S.profile_id = B.profile_id;
 
     TriShade H;
     H.iw0 = 1.0f / v0.w;
@@ -593,7 +664,7 @@ extern "C" __global__ void __launch_bounds__(256) k_setup3d(RasterParams P) {
     uint32_t nb = (bx1 - bx0 + 1) * (by1 - by0 + 1);
     if (nb > RXR_LARGE_BINS) {
         uint32_t slot = atomicAdd(&P.counters[CNT_LARGE], 1u);
-        P.large_list[slot] = t;
+        if (slot < P.n_tris3d) P.large_list[slot] = t;  // (always true while the counter invariant holds)
     } else {
         for (uint32_t by = by0; by <= by1; ++by)
             for (uint32_t bx = bx0; bx <= bx1; ++bx) atomicAdd(&P.bin_count[by * P.tiles_x + bx], 1u);
@@ -601,57 +672,81 @@ extern "C" __global__ void __launch_bounds__(256) k_setup3d(RasterParams P) {
 }
 
 // =================================================================================================
-// k_scan: exclusive scan of bin_count -> bin_offset (one 1024-thread workgroup, 8 bins per thread)
+// k_scan: exclusive scan of bin_count.  One 256-thread workgroup per chunk of 2048 bins writes
+// chunk-local offsets; the workgroup that finishes last (ticket counter) scans the chunk totals,
+// publishes the totals to the host-visible status words and clears the other counter set.
 // =================================================================================================
-extern "C" __global__ void __launch_bounds__(1024) k_scan(RasterParams P) {
-    __shared__ uint32_t wave_tot[16];
-    __shared__ uint32_t carry_s;
+extern "C" __global__ void __launch_bounds__(256) k_scan(RasterParams P) {
+    __shared__ uint32_t wave_tot[4];
+    __shared__ uint32_t s_last;
     const uint32_t n = P.tiles_x * P.tiles_y;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    if (tid == 0) carry_s = 0;
+    constexpr uint32_t PER = RXR_SCAN_CHUNK / 256u;
+    const uint32_t i0 = blockIdx.x * RXR_SCAN_CHUNK + tid * PER;
+    uint32_t v[PER];
+    uint32_t sum = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < PER; ++k) {
+        uint32_t i = i0 + k;
+        v[k] = (i < n) ? P.bin_count[i] : 0u;
+        sum += v[k];
+    }
+    uint32_t inc = sum;
+#pragma unroll
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+        uint32_t o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) wave_tot[wave] = inc;
     __syncthreads();
-    constexpr uint32_t PER = 8;
-    for (uint32_t base = 0; base < n; base += 1024 * PER) {
-        uint32_t i0 = base + tid * PER;
-        uint32_t v[PER];
-        uint32_t sum = 0;
+    uint32_t wave_off = 0, total = 0;
 #pragma unroll
-        for (uint32_t k = 0; k < PER; ++k) {
-            uint32_t i = i0 + k;
-            v[k] = (i < n) ? P.bin_count[i] : 0u;
-            sum += v[k];
-        }
-        // inclusive scan of `sum` across the wave
-        uint32_t inc = sum;
+    for (uint32_t w = 0; w < 4; ++w) {
+        uint32_t wt = wave_tot[w];
+        if (w < wave) wave_off += wt;
+        total += wt;
+    }
+    uint32_t run = wave_off + (inc - sum);
 #pragma unroll
-        for (uint32_t d = 1; d < 64; d <<= 1) {
-            uint32_t o = __shfl_up(inc, d, 64);
-            if (lane >= d) inc += o;
+    for (uint32_t k = 0; k < PER; ++k) {
+        uint32_t i = i0 + k;
+        if (i < n) {
+            P.bin_offset[i] = run;
+            P.bin_cursor[i] = 0u;
         }
-        if (lane == 63) wave_tot[wave] = inc;
-        __syncthreads();
-        uint32_t wave_off = 0;
-        for (uint32_t w = 0; w < wave; ++w) wave_off += wave_tot[w];
-        uint32_t carry = carry_s;
-        uint32_t run = carry + wave_off + (inc - sum);
-#pragma unroll
-        for (uint32_t k = 0; k < PER; ++k) {
-            uint32_t i = i0 + k;
-            if (i < n) {
-                P.bin_offset[i] = run;
-                P.bin_cursor[i] = 0u;
-            }
-            run += v[k];
-        }
-        __syncthreads();
-        if (tid == 1023) carry_s = run;
-        __syncthreads();
+        run += v[k];
     }
     if (tid == 0) {
-        P.bin_offset[n] = carry_s;
-        P.counters[CNT_ENTRIES] = carry_s;
-        if (carry_s > P.list_capacity) P.counters[CNT_OVERFLOW] = 1u;
+        __hip_atomic_store(&P.chunk_tot[blockIdx.x], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        uint32_t ticket = atomicAdd(&P.counters[CNT_TICKET], 1u);
+        s_last = (ticket == gridDim.x - 1u) ? 1u : 0u;
     }
+    __syncthreads();
+    if (!s_last || wave != 0) return;
+    // last workgroup, wave 0: scan the chunk totals
+    __threadfence();
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < gridDim.x; base += 64u) {
+        uint32_t c = base + lane;
+        uint32_t t = (c < gridDim.x) ? __hip_atomic_load(&P.chunk_tot[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        uint32_t ic = t;
+#pragma unroll
+        for (uint32_t d = 1; d < 64; d <<= 1) {
+            uint32_t o = __shfl_up(ic, d, 64);
+            if (lane >= d) ic += o;
+        }
+        if (c < gridDim.x) P.chunk_base[c] = carry + ic - t;
+        carry += __shfl(ic, 63, 64);
+    }
+    if (lane == 0) {
+        const uint32_t overflow = carry > P.list_capacity ? 1u : 0u;
+        P.counters[CNT_ENTRIES] = carry;
+        P.counters[CNT_OVERFLOW] = overflow;
+        P.host_status[CNT_ENTRIES] = carry;
+        P.host_status[CNT_OVERFLOW] = overflow;
+    }
+    if (lane < CNT_WORDS) P.counters_next[lane] = 0u;
 }
 
 // =================================================================================================
@@ -669,7 +764,7 @@ extern "C" __global__ void __launch_bounds__(256) k_fill(RasterParams P) {
     for (uint32_t by = by0; by <= by1; ++by)
         for (uint32_t bx = bx0; bx <= bx1; ++bx) {
             uint32_t bin = by * P.tiles_x + bx;
-            uint32_t pos = P.bin_offset[bin] + atomicAdd(&P.bin_cursor[bin], 1u);
+            uint32_t pos = P.chunk_base[bin / RXR_SCAN_CHUNK] + P.bin_offset[bin] + atomicAdd(&P.bin_cursor[bin], 1u);
             if (pos < P.list_capacity) P.bin_list[pos] = t;
         }
 }
@@ -698,19 +793,17 @@ __device__ __forceinline__ void visit(const RasterParams &P, const TriSetup &S, 
     float r2 = S.ea[2] * fx + S.eb[2] * fy + S.ec[2];
     in = in && !(r0 < 0.0f) && !(r1 < 0.0f) && !(r2 < 0.0f);
     if (!in) return;
-    const DevBatch &B = P.batches3d[S.batch];
-    const bool is_opacity = (B.flags & DB_OPACITY_LIST) != 0;
+    const bool is_opacity = (S.bflags & DB_OPACITY_LIST) != 0;
     if (is_opacity != OPACITY) return;
     if (!OPACITY) {
         // surface_id[idx].is_some() && surface_id[idx] == batch.profile_id  (:1044-1048)
-        if (surf_profile >= 0 && (B.flags & DB_HAS_PROFILE) && (uint32_t)surf_profile == B.profile_id) return;
+        if (surf_profile >= 0 && (S.bflags & DB_HAS_PROFILE) && (uint32_t)surf_profile == S.profile_id) return;
     }
     // barycentric_weights_3d (:1754-1773)
     float pcx = S.v2x - fx, pcy = S.v2y - fy;
     float pbx = S.v1x - fx, pby = S.v1y - fy;
     float apx = fx - S.v0x, apy = fy - S.v0y;
     float acx = S.v2x - S.v0x, acy = S.v2y - S.v0y;
-    float abx = S.v1x - S.v0x, aby = S.v1y - S.v0y;
     float alpha = (pcx * pby - pcy * pbx) / S.area;
     float beta = (acx * apy - acy * apx) / S.area;
     float gamma = 1.0f - alpha - beta;
@@ -718,8 +811,9 @@ __device__ __forceinline__ void visit(const RasterParams &P, const TriSetup &S, 
     float z = 1.0f / one_over_z;
     bool closer = z < vis.zmin || (z == vis.zmin && vis.best >= 0 && (int)t < vis.best);
     if (!closer) return;
-    if (!OPACITY && (B.flags & DB_ALPHA_TEST)) {
+    if (!OPACITY && (S.bflags & DB_ALPHA_TEST)) {
         // the fragment is only written when its encoded alpha is 255 (:1408): sample it now
+        const DevBatch &B = P.batches3d[S.batch];
         const TriShade H = P.tri_shade[t];
         float u, v;
         fragment_uv(H, alpha, beta, gamma, u, v);
@@ -732,22 +826,76 @@ __device__ __forceinline__ void visit(const RasterParams &P, const TriSetup &S, 
     vis.beta = beta;
 }
 
+// LDS staging area of one workgroup: candidate triangle records of the current round
+struct Stage {
+    float4 tri[RXR_STAGE_TRIS * 6];  // TriSetup records, 6 x 16 B each
+    uint32_t ids[RXR_STAGE_TRIS];
+    uint32_t wave_cnt[RXR_TILE_THREADS / 64];
+};
+
+// Visibility pass over the tile's candidate triangles = [large-triangle list, filtered against the
+// tile rectangle] ++ [this tile's bin list].  Per round of RXR_STAGE_TRIS list entries:
+//   1. the first RXR_STAGE_TRIS threads fetch one entry each (large entries also fetch their pixel
+//      box and test it against the tile),
+//   2. survivors are compacted with a wave ballot + popcount prefix sum (+ a 4-entry cross-wave sum),
+//   3. all 256 threads copy the survivors' 96-byte TriSetup records into LDS with coalesced 16-byte
+//      loads,
+//   4. every lane walks the staged records (uniform LDS addresses -> broadcast reads).
 template <bool OPACITY>
-__device__ __forceinline__ void scan_lists(const RasterParams &P, uint32_t bin, uint32_t tile_x0, uint32_t tile_y0px, uint32_t px,
-                                           uint32_t py, float fx, float fy, Vis &vis, int surf_profile) {
-    // large triangles: every tile walks the list, scalar reject against the tile rectangle
-    const uint32_t n_large = P.counters[CNT_LARGE];
-    for (uint32_t i = 0; i < n_large; ++i) {
-        uint32_t t = P.large_list[i];
-        const TriSetup &S = P.tri_setup[t];
-        uint32_t min_x = S.bx & 0xFFFFu, max_x = S.bx >> 16, min_y = S.by & 0xFFFFu, max_y = S.by >> 16;
-        if (min_x >= tile_x0 + RXR_TILE_W || max_x <= tile_x0 || min_y >= tile_y0px + RXR_TILE_H || max_y <= tile_y0px) continue;
-        visit<OPACITY>(P, S, t, px, py, fx, fy, vis, surf_profile);
-    }
-    const uint32_t b0 = P.bin_offset[bin], b1 = P.bin_offset[bin + 1];
-    for (uint32_t i = b0; i < b1; ++i) {
-        uint32_t t = P.bin_list[i];
-        visit<OPACITY>(P, P.tri_setup[t], t, px, py, fx, fy, vis, surf_profile);
+__device__ __forceinline__ void scan_lists(const RasterParams &P, Stage &st, uint32_t b0, uint32_t b1, uint32_t tile_x0,
+                                           uint32_t tile_y0px, uint32_t px, uint32_t py, float fx, float fy, Vis &vis,
+                                           int surf_profile) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t n_large = min(P.counters[CNT_LARGE], P.n_tris3d);
+    const uint32_t total = n_large + (b1 - b0);
+    const float4 *g4 = reinterpret_cast<const float4 *>(P.tri_setup);
+    for (uint32_t base = 0; base < total; base += RXR_STAGE_TRIS) {
+        // 1. fetch + test
+        uint32_t id = 0;
+        bool keep = false;
+        const uint32_t e = base + tid;
+        if (tid < RXR_STAGE_TRIS && e < total) {
+            if (e < n_large) {
+                id = min(P.large_list[e], P.n_tris3d - 1u);
+                const uint2 box = *reinterpret_cast<const uint2 *>(&P.tri_setup[id].bx);
+                uint32_t min_x = box.x & 0xFFFFu, max_x = box.x >> 16, min_y = box.y & 0xFFFFu, max_y = box.y >> 16;
+                keep = !(min_x >= tile_x0 + RXR_TILE_W || max_x <= tile_x0 || min_y >= tile_y0px + RXR_TILE_H || max_y <= tile_y0px);
+            } else {
+                id = P.bin_list[b0 + (e - n_large)];
+                keep = true;
+            }
+            // defensive: never follow an id outside this frame's triangle records
+            if (id >= P.n_tris3d) {
+                keep = false;
+                id = 0;
+            }
+        }
+        // 2. compaction
+        const unsigned long long m = __ballot(keep);
+        const uint32_t before = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) st.wave_cnt[wave] = (uint32_t)__popcll(m);
+        __syncthreads();
+        uint32_t off = 0, n = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < RXR_TILE_THREADS / 64; ++w) {
+            uint32_t c = st.wave_cnt[w];
+            if (w < wave) off += c;
+            n += c;
+        }
+        if (keep) st.ids[off + before] = id;
+        __syncthreads();
+        // 3. stage the records
+        for (uint32_t f = tid; f < n * 6u; f += RXR_TILE_THREADS) {
+            uint32_t k = f / 6u, j = f - k * 6u;
+            st.tri[f] = g4[(size_t)st.ids[k] * 6u + j];
+        }
+        __syncthreads();
+        // 4. walk
+        for (uint32_t k = 0; k < n; ++k) {
+            const TriSetup &S = *reinterpret_cast<const TriSetup *>(&st.tri[k * 6u]);
+            visit<OPACITY>(P, S, st.ids[k], px, py, fx, fy, vis, surf_profile);
+        }
+        __syncthreads();  // the stage is reused by the next round
     }
 }
 
@@ -800,11 +948,23 @@ extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS) k_raster(RasterPa
     }
 
     if (P.flags & RXR_FLAG_D3_ACTIVE) {
+        // this tile's bin list; the bin count is handed back zeroed for the next launch
+        __shared__ uint32_t s_bin[2];
+        __shared__ Stage stage;
+        if (tid == 0) {
+            uint32_t cnt = P.bin_count[bin];
+            uint32_t start = P.chunk_base[bin / RXR_SCAN_CHUNK] + P.bin_offset[bin];
+            s_bin[0] = min(start, P.list_capacity);
+            s_bin[1] = min(start + cnt, P.list_capacity);  // on overflow the frame is re-rendered (rxr_synchronize)
+            if (cnt) P.bin_count[bin] = 0u;
+        }
+        __syncthreads();
+        const uint32_t b0 = s_bin[0], b1 = s_bin[1];
         int surf_profile = -1;
         Vis op;
         op.zmin = 1.0f; op.best = -1; op.alpha = 0.0f; op.beta = 0.0f;
         if (P.has_opacity) {
-            scan_lists<true>(P, bin, tile_x0, tile_y0px, px, py, fx, fy, op, -1);
+            scan_lists<true>(P, stage, b0, b1, tile_x0, tile_y0px, px, py, fx, fy, op, -1);
             if (op.best >= 0) {
                 const DevBatch &OB = P.batches3d[P.tri_setup[op.best].batch];
                 surf_profile = (OB.flags & DB_HAS_PROFILE) ? (int)OB.profile_id : -1;
@@ -812,14 +972,16 @@ extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS) k_raster(RasterPa
         }
         Vis vis;
         vis.zmin = 1.0f; vis.best = -1; vis.alpha = 0.0f; vis.beta = 0.0f;
-        scan_lists<false>(P, bin, tile_x0, tile_y0px, px, py, fx, fy, vis, surf_profile);
+        scan_lists<false>(P, stage, b0, b1, tile_x0, tile_y0px, px, py, fx, fy, vis, surf_profile);
 
         // resolve (rasterizer.rs:409-497): hit -> shaded colour; miss -> [0,0,0,255]
-        if (vis.best >= 0) {
-            color = shade3d(P, (uint32_t)vis.best, P.tri_setup[vis.best].batch, vis.alpha, vis.beta, vis.zmin, fx, fy);
-        } else {
-            color = pack4(0u, 0u, 0u, 255u);
-        }
+        const bool hit = vis.best >= 0;
+        Frag F;
+        F.world = F.normal = F.view_dir = F.base = F.lit = mk3(0.0f, 0.0f, 0.0f);
+        F.opacity = 0.0f;
+        if (hit) shade3d_begin(P, (uint32_t)vis.best, P.tri_setup[vis.best].batch, vis.alpha, vis.beta, vis.zmin, fx, fy, F);
+        if (P.n_lights) shade3d_lights(P, hit, F);  // wave-uniform call
+        color = hit ? shade3d_end(F) : pack4(0u, 0u, 0u, 255u);
         if (op.best >= 0 && op.zmin < 1.0f && vis.zmin > op.zmin) {  // :464-495
             uint32_t src = shade3d_opacity(P, (uint32_t)op.best, P.tri_setup[op.best].batch, op.alpha, op.beta);
             float src_r = (float)(src & 0xFFu), src_g = (float)((src >> 8) & 0xFFu), src_b = (float)((src >> 16) & 0xFFu);
@@ -883,7 +1045,12 @@ extern "C" void rxr_launch_setup(const RasterParams *P, hipStream_t s) {
     uint32_t blocks = (P->n_tris3d + 255u) / 256u;
     hipLaunchKernelGGL(k_setup3d, dim3(blocks), dim3(256), 0, s, *P);
 }
-extern "C" void rxr_launch_scan(const RasterParams *P, hipStream_t s) { hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, *P); }
+extern "C" void rxr_launch_scan(const RasterParams *P, hipStream_t s) {
+    uint32_t n = P->tiles_x * P->tiles_y;
+    uint32_t chunks = (n + RXR_SCAN_CHUNK - 1u) / RXR_SCAN_CHUNK;
+    if (chunks == 0) chunks = 1;
+    hipLaunchKernelGGL(k_scan, dim3(chunks), dim3(256), 0, s, *P);
+}
 extern "C" void rxr_launch_fill(const RasterParams *P, hipStream_t s) {
     if (P->n_tris3d == 0) return;
     uint32_t blocks = (P->n_tris3d + 255u) / 256u;

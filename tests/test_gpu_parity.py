@@ -302,6 +302,16 @@ def test_tile_size_invariance(oracle, product):
     assert_exact(got, frames[0], "gpu vs oracle")
 
 
+def test_frame_size_sequence(oracle, product):
+    """Regression: the per-context scratch (bin counters handed back zeroed by the raster kernel) must
+    stay consistent when frame sizes shrink and grow without a reallocation in between."""
+    for (w, h) in [(640, 360), (160, 96), (480, 270), (96, 64), (640, 360), (333, 211)]:
+        got, ref = both(oracle, product, scenes.teapot_scene, width=w, height=h, logo_size=64)
+        assert_exact(got, ref, f"teapot {w}x{h} in a size sequence")
+        got, ref = both(oracle, product, scenes.box_grid_scene, n=12, width=w, height=h)
+        assert_exact(got, ref, f"box grid {w}x{h} in a size sequence")
+
+
 def test_repeatability(product):
     cfg = scenes.map_scene(product, width=320, height=180, logo_size=64, n_lights=16)
     a = scenes.render(cfg).copy()
