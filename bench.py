@@ -101,18 +101,17 @@ def main():
     if world == 1:
         frames = [torch.empty((H, W, 4), dtype=torch.uint8, device="cuda") for _ in range(NBUF)]
     else:
-        bands = [torch.empty((stripe_rows, W, 4), dtype=torch.uint8, device="cuda") for _ in range(NBUF)]
-        gathered = [torch.empty((world * stripe_rows, W, 4), dtype=torch.uint8, device="cuda") for _ in range(NBUF)]
-        frames = [torch.empty((spr * world * D.TILE_H, W, 4), dtype=torch.uint8, device="cuda") for _ in range(NBUF)]
+        gather = D.StripeGather(H, W, world, rank, device="cuda", nbuf=NBUF)
+        frames = gather.frames
 
     def step(i):
         b = i % NBUF
         if world == 1:
             check(rxr.rxr_render_rows_to(ctx, 0, H, C.c_void_p(frames[b].data_ptr()), sptr))
         else:
-            check(rxr.rxr_render_stripes_to(ctx, rank, world, C.c_void_p(bands[b].data_ptr()), sptr))
-            dist.all_gather_into_tensor(gathered[b], bands[b])
-            D.assemble_torch(gathered[b], H, W, world, out=frames[b])
+            # this rank's stripes -> compact band -> RCCL all-gather over xGMI -> de-interleave
+            check(rxr.rxr_render_stripes_to(ctx, rank, world, C.c_void_p(gather.band(i).data_ptr()), sptr))
+            gather.exchange(i)
 
     def fence():
         torch.cuda.synchronize()

@@ -48,3 +48,44 @@ def assemble_torch(gathered, height: int, width: int, world: int, out=None):
         return g.reshape(spr * world * TILE_H, width, 4)[:height]
     out.view(spr, world, TILE_H, width, 4).copy_(g)
     return out.view(spr * world * TILE_H, width, 4)[:height]
+
+
+def extract_stripes(frame: np.ndarray, world: int, rank: int) -> np.ndarray:
+    """CPU model of rxr_render_stripes_to: the compact [stripes_per_rank*16, W, 4] buffer rank `rank` owns."""
+    height, width = frame.shape[0], frame.shape[1]
+    spr = stripes_per_rank(height, world)
+    out = np.zeros((spr * TILE_H, width, 4), np.uint8)
+    for j, (a, b) in enumerate(stripe_rows(height, world, rank)):
+        out[j * TILE_H:j * TILE_H + (b - a)] = frame[a:b]
+    return out
+
+
+class StripeGather:
+    """Owns the per-rank stripe buffer(s) and the gathered / assembled frame buffers (double-buffered)
+    and performs the exchange step: all_gather_into_tensor (RCCL on GPUs, gloo in the CPU tests) followed
+    by the de-interleave copy."""
+
+    def __init__(self, height: int, width: int, world: int, rank: int, device, nbuf: int = 2):
+        import torch
+
+        self.h, self.w, self.world, self.rank = height, width, world, rank
+        self.spr = stripes_per_rank(height, world)
+        rows = self.spr * TILE_H
+        self.bands = [torch.zeros((rows, width, 4), dtype=torch.uint8, device=device) for _ in range(nbuf)]
+        self.gathered = [torch.zeros((world * rows, width, 4), dtype=torch.uint8, device=device) for _ in range(nbuf)]
+        self.frames = [torch.zeros((self.spr * world * TILE_H, width, 4), dtype=torch.uint8, device=device) for _ in range(nbuf)]
+        self.nbuf = nbuf
+
+    def band(self, i):
+        return self.bands[i % self.nbuf]
+
+    def exchange(self, i):
+        """Gathers band(i) from every rank and returns the assembled frame (height x width x 4)."""
+        import torch.distributed as dist
+
+        b = i % self.nbuf
+        if self.world > 1:
+            dist.all_gather_into_tensor(self.gathered[b], self.bands[b])
+        else:
+            self.gathered[b].copy_(self.bands[b])
+        return assemble_torch(self.gathered[b], self.h, self.w, self.world, out=self.frames[b])

@@ -290,6 +290,40 @@ def test_row_bands_equal_full_frame(product):
     assert_exact(out, full, "row bands vs full frame")
 
 
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_stripes_equal_full_frame(product, world):
+    """The multi-GPU sharding primitive on ONE GPU: every rank's interleaved stripes rendered in turn
+    (rxr_render_stripes_to), assembled like the all-gather does, must equal the single-launch frame
+    byte for byte (1 GPU == N GPU)."""
+    import ctypes as C
+
+    import torch
+
+    from rusterix_amd import distributed as D
+
+    cfg = scenes.map_scene(product, width=400, height=250, logo_size=64, n_lights=3)   # 250 rows: ragged last stripe
+    full = scenes.render(cfg).copy()
+    lib = product.lib
+    rxr = C.CDLL(__import__("rusterix_amd").lib_paths()["rxr"])
+    lib.rxh_context.restype = C.c_void_p
+    lib.rxh_rasterizer_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+    rxr.rxr_render_stripes_to.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+    rxr.rxr_synchronize.argtypes = [C.c_void_p]
+    r = cfg.setup()
+    assert lib.rxh_rasterizer_upload(r._h, cfg.scene._h, cfg.width, cfg.height, cfg.tile_size, cfg.assets._h) == 0
+    ctx = lib.rxh_context()
+    spr = D.stripes_per_rank(cfg.height, world)
+    parts = []
+    for rank in range(world):
+        band = torch.full((spr * D.TILE_H, cfg.width, 4), 77, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        assert rxr.rxr_render_stripes_to(ctx, rank, world, C.c_void_p(band.data_ptr()), None) == 0
+        assert rxr.rxr_synchronize(ctx) == 0
+        parts.append(band.cpu().numpy())
+    frame = D.assemble_numpy(np.concatenate(parts, axis=0), cfg.height, cfg.width, world)
+    assert_exact(frame, full, f"{world}-way stripes vs full frame")
+
+
 def test_tile_size_invariance(oracle, product):
     """R9: the oracle's output does not depend on tile_size, and equals the GPU's (which ignores it)."""
     frames = []

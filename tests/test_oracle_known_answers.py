@@ -1,0 +1,293 @@
+"""Pins for the CPU oracle.  The reference ships NO tests, golden images or known-answer vectors for
+the rasterizer path, and no Rust toolchain exists here, so "parity unpinned" by the
+reference's own tests.  What pins the oracle instead are the analytic known answers derivable from
+the reference source text, each checked below with the file:line it
+follows, plus the committed golden frames of tests/test_golden_frames.py.
+"""
+import numpy as np
+import pytest
+
+from rusterix_amd import binding as B
+from rusterix_amd import scenes
+
+
+def render(api, scene, w, h, setup, tile=40, assets=None):
+    assets = assets or api.Assets.default()
+    out = np.zeros(w * h * 4, np.uint8)
+    setup().rasterize(scene, out, w, h, tile, assets)
+    return out.reshape(h, w, 4)
+
+
+def cam(api, w, h):
+    return api.D3OrbitCamera.new().matrices(float(w), float(h))
+
+
+# 1. Edges: rectangle coverage and the doubly covered diagonal (batch2d.rs:109-127, edge.rs:17-31)
+def test_rectangle_coverage_and_diagonal(oracle):
+    o = oracle
+    w, h = 256, 256
+    v, p = cam(o, w, h)
+    rect = o.Batch2D.from_rectangle(0.0, 0.0, 200.0, 200.0).source(B.PixelSource.Pixel((255, 255, 255, 128)))
+    scene = o.Scene.from_static([rect], [])
+    img = render(o, scene, w, h, lambda: o.Rasterizer.setup(None, v, p).render_mode(B.RenderMode.render_2d()).background((0, 0, 0, 255)))
+    covered = img[..., 0] > 0
+    assert covered.sum() == 40000                       # exactly x,y in [0,199]
+    assert covered[:200, :200].all() and not covered[200:, :].any() and not covered[:, 200:].any()
+    once = int(255 * (128 / 255.0))                     # one blend over black, truncated (rasterizer.rs:885-887)
+    a = np.float32(128) / np.float32(255)
+    twice = int(np.float32(255) * a + np.float32(once) * (np.float32(1) - a))
+    diag = np.array([img[i, i, 0] for i in range(200)])
+    off = img[10, 50, 0]
+    assert off == once == 128
+    assert (diag == twice).all() and twice == 191      # 200 diagonal pixels are blended by both triangles
+    assert (img[:200, :200, 0] == twice).sum() == 200
+
+
+# 2. VGrayGradientShader rows (shader/vgradient.rs:11-15) in render_2d mode
+def test_vgradient_rows(oracle):
+    o = oracle
+    w, h = 8, 1080
+    v, p = cam(o, w, h)
+    scene = o.Scene.empty().background(o.VGrayGradientShader())
+    img = render(o, scene, w, h, lambda: o.Rasterizer.setup(None, v, p).render_mode(B.RenderMode.render_2d()))
+    for row, grey in [(0, 0), (1, 0), (539, 63), (540, 64), (1079, 127)]:
+        assert tuple(img[row, 3]) == (grey, grey, grey, 255), row
+    ignore = render(o, scene, w, h, lambda: o.Rasterizer.setup(None, v, p).render_mode(
+        B.RenderMode.render_2d().ignore_background_shader(True)).background((1, 2, 3, 4)))
+    assert (ignore == np.array([1, 2, 3, 4], np.uint8)).all()
+
+
+# 3. 3D mode, empty scene: every pixel [0,0,0,255] regardless of the background (rasterizer.rs:420-461)
+def test_empty_3d_scene_is_black(oracle):
+    o = oracle
+    v, p = cam(o, 64, 48)
+    scene = o.Scene.empty().background(o.VGrayGradientShader())
+    img = render(o, scene, 64, 48, lambda: o.Rasterizer.setup(None, v, p).background((9, 9, 9, 9)))
+    assert (img == np.array([0, 0, 0, 255], np.uint8)).all()
+
+
+# 4. sample_nearest: round half away from zero (texture.rs:307-323)
+def test_sample_nearest_rounding(oracle):
+    o = oracle
+    wtex = 64
+    ramp = np.zeros((1, wtex, 4), np.uint8)
+    ramp[0, :, 0] = np.arange(wtex)
+    ramp[..., 3] = 255
+    tex = B.Texture(ramp.reshape(-1), wtex, 1)
+    for k in range(wtex):
+        u = float(np.float32(k) / np.float32(wtex - 1))
+        assert o.texture_sample(tex, u, 0.0, B.SAMPLE_NEAREST, B.REPEAT_CLAMP_XY)[0] == k
+    assert o.texture_sample(tex, 0.5, 0.0, B.SAMPLE_NEAREST, B.REPEAT_CLAMP_XY)[0] == 32             # round(31.5) = 32
+    u = float(np.float32(30.5) / np.float32(63.0))
+    x = np.float32(u) * np.float32(63.0)
+    expect = 31 if x >= np.float32(30.5) else 30                                                      # half AWAY from zero, not to even
+    assert o.texture_sample(tex, u, 0.0, B.SAMPLE_NEAREST, B.REPEAT_CLAMP_XY)[0] == expect
+    assert o.texture_sample(tex, float("nan"), 0.0, B.SAMPLE_NEAREST, B.REPEAT_CLAMP_XY)[0] == 0      # NaN as usize = 0
+    assert o.texture_sample(tex, 7.25, 0.0, B.SAMPLE_NEAREST, B.REPEAT_REPEAT_XY)[0] == 16            # 0.25*63 = 15.75 -> 16
+    assert o.texture_sample(tex, -3.0, 0.0, B.SAMPLE_NEAREST, B.REPEAT_CLAMP_XY)[0] == 0
+    assert o.texture_sample(tex, 3.0, 0.0, B.SAMPLE_NEAREST, B.REPEAT_CLAMP_XY)[0] == 63
+
+
+def test_sample_linear(oracle):
+    o = oracle
+    t = np.zeros((2, 2, 4), np.uint8)
+    t[0, 0] = (0, 0, 0, 255)
+    t[0, 1] = (100, 0, 0, 255)
+    t[1, 0] = (0, 200, 0, 255)
+    t[1, 1] = (100, 200, 0, 255)
+    tex = B.Texture(t.reshape(-1), 2, 2)
+    assert tuple(o.texture_sample(tex, 0.5, 0.5, B.SAMPLE_LINEAR, B.REPEAT_CLAMP_XY)) == (50, 100, 0, 255)
+    assert tuple(o.texture_sample(tex, 0.0, 0.0, B.SAMPLE_LINEAR, B.REPEAT_CLAMP_XY)) == (0, 0, 0, 255)
+    assert tuple(o.texture_sample(tex, 1.0, 1.0, B.SAMPLE_LINEAR, B.REPEAT_CLAMP_XY)) == (100, 200, 0, 255)
+    assert tuple(o.texture_sample(tex, 0.25, 0.0, B.SAMPLE_LINEAR, B.REPEAT_CLAMP_XY)) == (25, 0, 0, 255)
+    assert tuple(o.texture_sample(tex, float("nan"), 0.0, B.SAMPLE_LINEAR, B.REPEAT_CLAMP_XY)) == (0, 0, 0, 0)  # NaN.round() as u8
+
+
+# 5. vec4_to_pixel(pixel_to_vec4(p)) == p for all 256 values (lib.rs:55-79)
+def test_pixel_roundtrip(oracle):
+    o = oracle
+    for v in range(256):
+        px = np.array([v, 255 - v, (v * 7) % 256, 255], np.uint8)
+        assert (o.vec4_to_pixel(o.pixel_to_vec4(px)) == px).all()
+    assert tuple(o.vec4_to_pixel([float("nan"), -1.0, 2.0, 0.5])) == (0, 0, 255, 128)  # NaN -> 0, saturate, fma(0.5,255,0.5)=128
+    assert np.float32(255) * (np.float32(1.0) / np.float32(255.0)) == np.float32(1.0)
+
+
+# 6. hash_u32 (rasterizer.rs:199-207)
+def test_hash_u32(oracle):
+    assert oracle.hash_u32(0) == 0xC0A9496A
+    assert oracle.hash_u32(1) == 0x27922C9D
+    assert oracle.hash_u32(2) == 0xC6793575
+    assert oracle.hash_u32(1000) == 0x9E417152
+
+
+# 7. point light falloff (light.rs:535-552, 674-677)
+def test_point_light_falloff(oracle):
+    o = oracle
+    l = B.Light(B.LIGHT_POINT).with_position((0.0, 0.0, 0.0)).with_color((1.0, 0.5, 0.25)).with_intensity(2.0) \
+        .with_start_distance(2.0).with_end_distance(6.0).compile()
+    assert np.allclose(o.light_color_at(l, (1.0, 0.0, 0.0), 0), (2.0, 1.0, 0.5))       # d <= start: colour * intensity
+    assert np.allclose(o.light_color_at(l, (2.0, 0.0, 0.0), 0), (2.0, 1.0, 0.5))
+    assert o.light_color_at(l, (6.0, 0.0, 0.0), 0) is None                              # d >= end: None
+    assert o.light_color_at(l, (7.0, 0.0, 0.0), 0) is None
+    assert np.allclose(o.light_color_at(l, (4.0, 0.0, 0.0), 0), (1.0, 0.5, 0.25))       # midpoint: smoothstep = 0.5
+    t = np.float32(0.25)                                                                 # d = 5: t = (5-6)/(2-6)
+    att = t * t * (np.float32(3.0) - np.float32(2.0) * t)
+    assert np.allclose(o.light_color_at(l, (5.0, 0.0, 0.0), 0), np.array((2.0, 1.0, 0.5)) * att, rtol=1e-6)
+    # radiance_at multiplies by Lambert (light.rs:529-532)
+    rad = o.light_radiance_at(l, (1.0, 0.0, 0.0), (-1.0, 0.0, 0.0), 0)
+    assert np.allclose(rad, (2.0, 1.0, 0.5))
+    rad = o.light_radiance_at(l, (1.0, 0.0, 0.0), (1.0, 0.0, 0.0), 0)
+    assert np.allclose(rad, (0.0, 0.0, 0.0))
+    l.emitting = 0
+    assert o.light_color_at(l, (1.0, 0.0, 0.0), 0) is None
+
+
+def test_flicker(oracle):
+    o = oracle
+    l = B.Light(B.LIGHT_AMBIENT).with_position((3.7, 1.2, 9.9)).with_intensity(1.0).with_flicker(0.5).compile()
+    h = o.hash_u32(1)
+    combined = (h + (3 + 1 + 9) * 100) & 0xFFFFFFFF
+    fv = np.float32(combined) / np.float32(4294967295.0)
+    expect = np.float32(1.0) - fv * np.float32(0.5)
+    assert np.allclose(o.light_color_at(l, (0.0, 0.0, 0.0), h), (expect,) * 3, rtol=1e-6)
+
+
+# 8. fence cut-out: texel alpha < 255 keeps what was behind and leaves z unchanged (rasterizer.rs:1408)
+def test_cutout_keeps_background(oracle):
+    o = oracle
+    w, h = 160, 120
+    camo = o.D3OrbitCamera.new()
+    camo.set_parameter_f32("distance", 3.0)
+    camo.elevation = 0.0                                       # head-on: the green box sits right behind the hole
+    v, p = camo.matrices(float(w), float(h))
+    holes = np.zeros((4, 4, 4), np.uint8)
+    holes[..., :3] = 200
+    holes[..., 3] = 255
+    holes[1:3, 1:3, 3] = 0                                     # a transparent hole in the middle
+    assets = o.Assets.default().textures([B.Tile.from_texture(B.Texture(holes.reshape(-1), 4, 4))])
+    front = o.Batch3D.from_box(-0.5, -0.5, 0.4, 1.0, 1.0, 0.01).source(B.PixelSource.StaticTileIndex(0)).with_computed_normals()
+    back = o.Batch3D.from_box(-0.5, -0.5, -0.6, 1.0, 1.0, 0.01).source(B.PixelSource.Pixel((10, 250, 10, 255))).with_computed_normals()
+    half = o.Batch3D.from_box(-0.5, -0.5, 0.7, 1.0, 1.0, 0.01).source(B.PixelSource.Pixel((250, 10, 10, 254))).with_computed_normals()
+    for order in ([front, back], [back, front], [half, back, front]):
+        scene = o.Scene.from_static([], order)
+        img = render(o, scene, w, h, lambda: o.Rasterizer.setup(None, v, p).ambient((1.0, 1.0, 1.0, 1.0)), assets=assets)
+        centre = img[h // 2, w // 2]
+        assert centre[1] > centre[0] + 50, "the hole must show the green box behind"
+        rgb = img[..., :3].astype(int)
+        grey = (np.abs(rgb[..., 0] - rgb[..., 1]) < 5) & (np.abs(rgb[..., 1] - rgb[..., 2]) < 5) & (rgb[..., 0] > 50)
+        assert grey.sum() > 200, "opaque texels of the front box are grey"
+        assert not (rgb[..., 0] > rgb[..., 1] + 100).any(), "alpha-254 fragments must never be written"
+        assert (img[..., 3] == 255).all()                      # alpha 254 fragments are never written
+
+
+# 9. properties: tile-size invariance (R9) and determinism
+@pytest.mark.parametrize("builder,kw", [
+    (scenes.cube_scene, dict(width=200, height=160, textured=True, distance=3.0, logo_size=64)),
+    (scenes.map_scene, dict(width=240, height=136, logo_size=64, n_lights=3)),
+])
+def test_tile_size_invariance(oracle, builder, kw):
+    frames = []
+    for ts in (16, 40, 60, 200):
+        frames.append(scenes.render(builder(oracle, tile_size=ts, **kw)).copy())
+    for f in frames[1:]:
+        assert np.array_equal(frames[0], f)
+
+
+def test_thread_count_invariance(oracle):
+    cfg = scenes.map_scene(oracle, width=200, height=120, logo_size=64, n_lights=2)
+    out = []
+    for n in (1, 3, 8):
+        r = oracle.set_threads(cfg.setup(), n)
+        img = np.zeros(200 * 120 * 4, np.uint8)
+        r.rasterize(cfg.scene, img, 200, 120, 40, cfg.assets)
+        out.append(img)
+    assert np.array_equal(out[0], out[1]) and np.array_equal(out[0], out[2])
+
+
+# leaf functions
+def test_edges_inclusive(oracle):
+    o = oracle
+    e = o.edges_new([[0, 0], [0, 10], [10, 10]], [[0, 10], [10, 10], [0, 0]])
+    assert np.allclose(e[:3], (10, 0, -10)) and np.allclose(e[3:6], (0, -10, 10)) and np.allclose(e[6:], (0, 100, 0))
+    assert o.edges_evaluate(e, 2.5, 5.5)         # inside
+    assert o.edges_evaluate(e, 5.5, 5.5)         # on the diagonal: inclusive (edge.rs:31)
+    assert not o.edges_evaluate(e, 6.5, 5.5)
+    assert o.edges_evaluate(e, float("nan"), 1.0)  # NaN < 0 is false: passes
+
+
+def test_srgb_approximations(oracle):
+    o = oracle
+    assert o.srgb_to_linear_fast(1.0) == pytest.approx(1.0)
+    assert o.srgb_to_linear_fast(0.0) == 0.0
+    x = np.float32(0.5)
+    assert np.float32(o.srgb_to_linear_fast(0.5)) == (np.float32(0.6975) * (x * x) + np.float32(0.3025)) * x
+    s = np.sqrt(np.float32(0.25), dtype=np.float32)
+    assert np.float32(o.linear_to_srgb_fast(0.25)) == np.float32(1.055) * s - np.float32(0.055) * s * s
+    assert np.isnan(o.linear_to_srgb_fast(-1.0))
+
+
+def test_camera_and_inverse_consistency(oracle):
+    """vek restatement self-consistency: inverse view gives back the eye; NDC round trip."""
+    o = oracle
+    c = o.D3OrbitCamera.new()
+    c.set_parameter_f32("distance", 20.0)
+    v, p = c.matrices(800.0, 600.0)
+    iv = o.mat4_inverted(v)
+    eye = np.array([20 * np.cos(np.pi / 2) * np.cos(0.698), 20 * np.sin(0.698), 20 * np.sin(np.pi / 2) * np.cos(0.698)])
+    assert np.allclose(iv[12:15], eye, atol=1e-4)
+    ident = np.array([o.mat4_mul_vec4(v, o.mat4_mul_vec4(iv, e)) for e in np.eye(4, dtype=np.float32)])
+    assert np.allclose(ident, np.eye(4), atol=1e-5)
+    clip = o.mat4_mul_vec4(p, [0.0, 0.0, -0.01, 1.0])   # a point on the near plane -> ndc z = 0 (zero-to-one depth)
+    assert abs(clip[2] / clip[3]) < 1e-6
+    clip = o.mat4_mul_vec4(p, [0.0, 0.0, -100.0, 1.0])  # far plane -> ndc z = 1
+    assert clip[2] / clip[3] == pytest.approx(1.0, abs=1e-5)
+    h = 1.0 / np.tan(np.radians(75.0) / 2)
+    assert p[5] == pytest.approx(h, rel=1e-6) and p[0] == pytest.approx(h * 600 / 800, rel=1e-6)
+
+
+def test_cube_is_centred_and_lit_faces_visible(oracle):
+    cfg = scenes.cube_scene(oracle, width=200, height=150, textured=True, distance=3.0, logo_size=64)
+    img = scenes.render(cfg)
+    ys, xs = np.nonzero(img[40:, :, :3].max(axis=2) > 0)      # skip the 2D logo rows on the left
+    assert abs(xs.mean() - 100) < 8
+
+
+def test_near_plane_clipping_appends_triangles(oracle):
+    o = oracle
+    camo = o.D3OrbitCamera.new()
+    camo.set_parameter_f32("distance", 0.7)     # eye 0.04 in front of the +z face: faces cross z = -0.1
+    v, p = camo.matrices(160.0, 120.0)
+    box = o.Batch3D.from_box(-0.5, -0.5, -0.5, 1.0, 1.0, 1.0).with_computed_normals()
+    scene = o.Scene.from_static([], [box])
+    o.Rasterizer.setup(None, v, p).project(scene, 160, 120)
+    b = scene.projected_batch3d(B.LIST_STATIC, 0)
+    assert b["clipped_indices"].shape[0] > 12               # fan triangles appended after the 12 originals
+    assert b["projected_vertices"].shape[0] > 24
+    vis = b["edges"][:, 9]
+    assert (vis[:12] == 0).any() and (vis[12:] == 1).all()  # clipped originals are hidden, the fans are visible
+    assert b["clipped_indices"][12:].min() >= 24            # the fans index the appended vertices only
+
+
+def test_reference_panics_become_errors(oracle):
+    o = oracle
+    v, p = cam(o, 32, 32)
+    out = np.zeros(32 * 32 * 4, np.uint8)
+    scene = o.Scene.from_static([], [o.Batch3D.from_box(-0.5, -0.5, -0.5, 1, 1, 1)])     # no normals (batch3d.rs:605)
+    with pytest.raises(B.RasterizeError):
+        o.Rasterizer.setup(None, v, p).rasterize(scene, out, 32, 32, 16, o.Assets.default())
+    with pytest.raises(B.RasterizeError):
+        o.Rasterizer.setup(None, v, p).rasterize(o.Scene.empty(), out, 32, 32, 0, o.Assets.default())  # step_by(0)
+
+
+def test_chunk_lights_are_appended_every_call(oracle):
+    """rasterizer.rs:219-223: chunk lights are pushed onto scene.dynamic_lights on every call."""
+    o = oracle
+    scene = o.Scene.empty()
+    ch = scene.add_chunk()
+    ch.add_light(B.Light(B.LIGHT_POINT).compile())
+    v, p = cam(o, 16, 16)
+    out = np.zeros(16 * 16 * 4, np.uint8)
+    for n in (1, 2, 3):
+        o.Rasterizer.setup(None, v, p).rasterize(scene, out, 16, 16, 16, o.Assets.default())
+        assert scene.num_dynamic_lights() == n
