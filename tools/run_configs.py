@@ -1,0 +1,125 @@
+#!/usr/bin/env python3
+"""Runs the BASELINE.json configurations at full size on one GPU: kernel-only and end-to-end timings
+through the C ABI, plus a full-size comparison with the CPU oracle (the checker; never the thing
+measured).  Writes one JSON line per configuration; used to fill the table in BASELINE.md.
+
+    python tools/run_configs.py [--configs C2,C3,C4,C5] [--frames 30] [--oracle C2,C3,C4]
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import rusterix_amd  # noqa: E402
+from rusterix_amd import binding as B  # noqa: E402
+from rusterix_amd import scenes  # noqa: E402
+
+
+def config(api, name):
+    if name == "C1":
+        return scenes.cube_scene(api, width=800, height=600, tile_size=200, textured=True, distance=3.0)
+    if name == "C2":
+        return scenes.teapot_scene(api, width=1920, height=1080)
+    if name == "C3":
+        return scenes.map_scene(api, width=1920, height=1080, n_lights=1)
+    if name == "C4":
+        return scenes.map_scene(api, width=3840, height=2160, n_lights=16)
+    if name == "C5":
+        return scenes.box_grid_scene(api, n=289, width=7680, height=4320)
+    if name == "C5s":  # reduced C5 for a full oracle comparison
+        return scenes.box_grid_scene(api, n=96, width=1920, height=1080)
+    raise SystemExit(f"unknown config {name}")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--configs", default="C2,C3,C4,C5s,C5")
+    ap.add_argument("--frames", type=int, default=30)
+    ap.add_argument("--oracle", default="C2,C3,C4,C5s")
+    ap.add_argument("--threads", type=int, default=0)
+    args = ap.parse_args()
+
+    prod = rusterix_amd.load()
+    host = prod.lib
+    rxr = C.CDLL(rusterix_amd.lib_paths()["rxr"])
+    host.rxh_context.restype = C.c_void_p
+    host.rxh_last_error.restype = C.c_char_p
+    host.rxh_rasterizer_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+    rxr.rxr_render_rows.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+    rxr.rxr_synchronize.argtypes = [C.c_void_p]
+    rxr.rxr_download_rows.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), C.c_uint32, C.c_uint32]
+    rxr.rxr_profile_begin.argtypes = [C.c_void_p, C.c_uint32]
+    rxr.rxr_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_uint32)]
+
+    class Stats(C.Structure):
+        _fields_ = [("setup_us", C.c_float), ("raster_us", C.c_float), ("total_us", C.c_float), ("n_triangles3d", C.c_uint32),
+                    ("n_triangles2d", C.c_uint32), ("n_bin_entries", C.c_uint32), ("tiles_x", C.c_uint32), ("tiles_y", C.c_uint32)]
+
+    rxr.rxr_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+
+    for name in args.configs.split(","):
+        t0 = time.perf_counter()
+        cfg = config(prod, name)
+        t_build = time.perf_counter() - t0
+        W, H = cfg.width, cfg.height
+        out = np.zeros((H, W, 4), np.uint8)
+        # end-to-end: Rasterizer::setup(..).rasterize(..) = host projection + upload + kernels + download
+        scenes.render(cfg, out.reshape(-1))  # warm-up (also uploads the textures)
+        e2e = []
+        for _ in range(max(3, args.frames // 5)):
+            t0 = time.perf_counter()
+            scenes.render(cfg, out.reshape(-1))
+            e2e.append(time.perf_counter() - t0)
+        # device-resident: upload once, then kernels only
+        r = cfg.setup()
+        t0 = time.perf_counter()
+        rc = host.rxh_rasterizer_upload(r._h, cfg.scene._h, W, H, cfg.tile_size, cfg.assets._h)
+        t_upload = time.perf_counter() - t0
+        assert rc == 0, host.rxh_last_error()
+        ctx = host.rxh_context()
+        for _ in range(3):
+            rxr.rxr_render_rows(ctx, 0, H)
+        rxr.rxr_synchronize(ctx)
+        rxr.rxr_profile_begin(ctx, args.frames)
+        t0 = time.perf_counter()
+        for _ in range(args.frames):
+            rxr.rxr_render_rows(ctx, 0, H)
+        rxr.rxr_synchronize(ctx)
+        t_loop = (time.perf_counter() - t0) / args.frames
+        su = (C.c_float * args.frames)()
+        ru = (C.c_float * args.frames)()
+        n = C.c_uint32()
+        rxr.rxr_profile_read(ctx, su, ru, args.frames, C.byref(n))
+        st = Stats()
+        rxr.rxr_get_stats(ctx, C.byref(st))
+        rec = dict(config=name, scene=cfg.name, resolution=[W, H], triangles_3d=st.n_triangles3d, bin_entries=st.n_bin_entries,
+                   scene_build_s=round(t_build, 2), upload_ms=round(t_upload * 1e3, 2),
+                   setup_kernels_us=round(float(np.median(su[: n.value])), 1), raster_kernel_us=round(float(np.median(ru[: n.value])), 1),
+                   frame_ms_device_resident=round(t_loop * 1e3, 4), mpix_per_s_device_resident=round(W * H / t_loop / 1e6, 1),
+                   frame_ms_end_to_end=round(float(np.median(e2e)) * 1e3, 3), mpix_per_s_end_to_end=round(W * H / float(np.median(e2e)) / 1e6, 1))
+        if name in args.oracle.split(","):
+            from tests.oracle_api import load_oracle
+
+            orc = load_oracle()
+            ocfg = config(orc, name)
+            ref = np.zeros((H, W, 4), np.uint8)
+            threads = args.threads or os.cpu_count()
+            t0 = time.perf_counter()
+            orc.set_threads(ocfg.setup(), threads).rasterize(ocfg.scene, ref.reshape(-1), W, H, ocfg.tile_size, ocfg.assets)
+            t_cpu = time.perf_counter() - t0
+            diff = np.abs(out.astype(np.int16) - ref.astype(np.int16)).max(axis=2)
+            rec.update(cpu_port_ms=round(t_cpu * 1e3, 1), cpu_port_mpix_per_s=round(W * H / t_cpu / 1e6, 2), cpu_threads=threads,
+                       parity=dict(pixels=int(W * H), differing=int((diff > 0).sum()), off_by_more_than_1=int((diff > 1).sum()),
+                                   max_abs_diff=int(diff.max())))
+        print(json.dumps(rec), flush=True)
+
+
+if __name__ == "__main__":
+    main()
