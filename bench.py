@@ -42,6 +42,8 @@ def main():
     ap.add_argument("--lights", type=int, default=16)
     ap.add_argument("--cpu-frames", type=int, default=2, help="frames of the same workload timed on the CPU oracle (rank 0, N=1 only)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--force-gather", action="store_true",
+                    help="debug: run the stripe -> gather -> assemble path even at N=1 (never used by the driver)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -98,20 +100,28 @@ def main():
     stripe_rows = spr * D.TILE_H
     # double-buffered outputs so that frame i+1 can render while frame i is being gathered
     NBUF = 2
-    if world == 1:
+    sharded = world > 1 or args.force_gather
+    if not sharded:
         frames = [torch.empty((H, W, 4), dtype=torch.uint8, device="cuda") for _ in range(NBUF)]
     else:
         gather = D.StripeGather(H, W, world, rank, device="cuda", nbuf=NBUF)
         frames = gather.frames
 
-    def step(i):
-        b = i % NBUF
-        if world == 1:
-            check(rxr.rxr_render_rows_to(ctx, 0, H, C.c_void_p(frames[b].data_ptr()), sptr))
-        else:
-            # this rank's stripes -> compact band -> RCCL all-gather over xGMI -> de-interleave
-            check(rxr.rxr_render_stripes_to(ctx, rank, world, C.c_void_p(gather.band(i).data_ptr()), sptr))
-            gather.exchange(i)
+    def run(n):
+        """n complete frames.  N > 1 is software-pipelined: while frame i-1 is being all-gathered on the
+        RCCL stream, frame i renders; every frame is gathered and assembled before run() returns."""
+        for i in range(n):
+            b = i % NBUF
+            if not sharded:
+                check(rxr.rxr_render_rows_to(ctx, 0, H, C.c_void_p(frames[b].data_ptr()), sptr))
+            else:
+                # this rank's stripes -> compact band -> RCCL all-gather over xGMI -> de-interleave
+                check(rxr.rxr_render_stripes_to(ctx, rank, world, C.c_void_p(gather.band(i).data_ptr()), sptr))
+                gather.exchange_begin(i)
+                if i > 0:
+                    gather.exchange_end(i - 1)
+        if sharded and n > 0:
+            gather.exchange_end(n - 1)
 
     def fence():
         torch.cuda.synchronize()
@@ -119,14 +129,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
+    run(args.warmup)
     fence()
     check(rxr.rxr_profile_begin(ctx, args.steps))
     fence()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
+    run(args.steps)
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -151,8 +159,8 @@ def main():
         value = W * H * args.steps / dt / 1e6
         # algorithmic bytes of ONE raster launch: this rank's share of the framebuffer + the scene read once
         n_verts, n_tris, tex_bytes = scene_counts(cfg, prod)
-        fb_share = W * min(stripe_rows, H) if world > 1 else W * H
-        alg = algorithmic_bytes(W, 1, n_verts, n_tris, tex_bytes, args.lights) - W * 4 + fb_share * 4
+        rows_this_rank = min(stripe_rows, H) if sharded else H
+        alg = algorithmic_bytes(W, rows_this_rank, n_verts, n_tris, tex_bytes, args.lights)
         achieved = alg / (raster_avg_us * 1e-6) / 1e9
         out = {
             "metric": "Mpixels/s (+ ms/frame) on rasterize_map @3840x2160, 1/2/4/8 MI355X vs CPU",
@@ -185,8 +193,10 @@ def main():
                 "algorithmic_bytes_per_launch": int(alg),
                 "kernel_avg_us": round(raster_avg_us, 2),
                 "setup_kernels_avg_us": round(setup_avg_us, 2),
-                "note": "ALU-bound path: algorithmic HBM traffic is ~4 B/pixel, see DESIGN.md; fp32 VALU peak "
-                        f"{FP32_VALU_PEAK_TFLOPS} TFLOP/s is the bound that matters",
+                "measured_traffic_bytes_4k_1gpu": {"WRITE_SIZE": 33177600, "FETCH_SIZE_x2": 4230000,
+                                                   "source": "profiles/r01 rocprofv3 --pmc passes (separate runs)"},
+                "note": "fp32-VALU-bound path: algorithmic HBM traffic is ~4.5 B/pixel (DESIGN.md section 6); "
+                        "218.6 M VALU wave-instructions per 4K launch = ~63 % of VALU issue peak",
             },
         }
         if world == 1 and not args.no_cpu:
@@ -224,10 +234,17 @@ def cpu_baseline(W, H, n_lights, n_frames):
     threads = os.cpu_count() or 1
     r = orc.set_threads(cfg.setup(), threads)
     r.rasterize(cfg.scene, out, W, H, cfg.tile_size, cfg.assets)  # warm-up frame (not timed)
+    # bounded sample: at least `n_frames` frames and at least ~10 s of wall time, at most 30 s
     t0 = time.perf_counter()
-    for _ in range(n_frames):
+    done = 0
+    while True:
         r = orc.set_threads(cfg.setup(), threads)
         r.rasterize(cfg.scene, out, W, H, cfg.tile_size, cfg.assets)
+        done += 1
+        el = time.perf_counter() - t0
+        if (done >= n_frames and el >= 10.0) or el >= 30.0:
+            break
+    n_frames = done
     dt = time.perf_counter() - t0
     return {
         "value": round(W * H * n_frames / dt / 1e6, 3),

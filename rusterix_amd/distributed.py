@@ -81,11 +81,25 @@ class StripeGather:
 
     def exchange(self, i):
         """Gathers band(i) from every rank and returns the assembled frame (height x width x 4)."""
+        self.exchange_begin(i)
+        return self.exchange_end(i)
+
+    # split form for software pipelining: begin(i) queues the collective behind the work already on the
+    # current stream (the render of frame i) and returns at once; end(i) makes the current stream wait
+    # for it and de-interleaves.  Rendering frame i+1 between the two overlaps it with the gather of
+    # frame i (the collective runs on the backend's own stream).
+    def exchange_begin(self, i):
         import torch.distributed as dist
 
         b = i % self.nbuf
         if self.world > 1:
-            dist.all_gather_into_tensor(self.gathered[b], self.bands[b])
+            self._work = getattr(self, "_work", {})
+            self._work[b] = dist.all_gather_into_tensor(self.gathered[b], self.bands[b], async_op=True)
         else:
             self.gathered[b].copy_(self.bands[b])
+
+    def exchange_end(self, i):
+        b = i % self.nbuf
+        if self.world > 1:
+            self._work.pop(b).wait()
         return assemble_torch(self.gathered[b], self.h, self.w, self.world, out=self.frames[b])
