@@ -252,7 +252,8 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *frame);
  * Replaces the tile list + rayon tile loop, src/rasterizer.rs:256-557.  Asynchronous. */
 int rxr_render_rows(rxr_ctx *ctx, uint32_t row0, uint32_t row1);
 /* same, but writes the band into caller-owned DEVICE memory (`dev_pixels` points at row `row0`,
- * rows are `width*4` bytes apart) on HIP stream `hip_stream` (hipStream_t, NULL = context stream).
+ * rows are `width*4` bytes apart) on HIP stream `hip_stream` (hipStream_t; NULL means the context's own
+ * non-blocking stream, NOT the legacy default stream -- pass an explicit stream to order with other work).
  * Used by the multi-GPU host, which then gathers the bands with RCCL. */
 int rxr_render_rows_to(rxr_ctx *ctx, uint32_t row0, uint32_t row1, void *dev_pixels, void *hip_stream);
 

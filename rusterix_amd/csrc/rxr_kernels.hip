@@ -925,13 +925,28 @@ __device__ __forceinline__ bool bresenham_hits(const Line2D &Ln, int px, int py)
 
 }  // namespace
 
-extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS) k_raster(RasterParams P) {
+// tuning knobs: occupancy bound of k_raster and the pixel footprint of a wave
+#ifndef RXR_RASTER_WAVES_PER_SIMD
+#define RXR_RASTER_WAVES_PER_SIMD 1
+#endif
+#ifndef RXR_WAVE_8X8
+#define RXR_WAVE_8X8 0
+#endif
+
+extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_RASTER_WAVES_PER_SIMD) k_raster(RasterParams P) {
     const uint32_t bin = blockIdx.x;
     const uint32_t tx = bin % P.tiles_x, ty = bin / P.tiles_x;
     const uint32_t tid = threadIdx.x;
     const uint32_t tile_x0 = tx * RXR_TILE_W, tile_y0px = (P.tile_y0 + ty * P.tile_stride) * RXR_TILE_H;
-    const uint32_t px = tile_x0 + (tid & (RXR_TILE_W - 1));
-    const uint32_t py = tile_y0px + (tid / RXR_TILE_W);
+#if RXR_WAVE_8X8
+    // wave w owns the 8x8 quadrant (w & 1, w >> 1) of the tile
+    const uint32_t lx = ((tid >> 6) & 1u) * 8u + (tid & 7u), ly = (tid >> 7) * 8u + ((tid >> 3) & 7u);
+#else
+    // wave w owns rows 4w .. 4w+3 of the tile (16 x 4 pixels: 64-byte row segments on the store)
+    const uint32_t lx = tid & (RXR_TILE_W - 1), ly = tid / RXR_TILE_W;
+#endif
+    const uint32_t px = tile_x0 + lx;
+    const uint32_t py = tile_y0px + ly;
     const float fx = (float)px + 0.5f, fy = (float)py + 0.5f;  // rasterizer.rs:1022
     const bool in_frame = px < P.width && py >= P.row0 && py < P.row1;
 
@@ -1034,7 +1049,7 @@ extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS) k_raster(RasterPa
     }
 
     if (in_frame) {
-        const int64_t row = P.compact ? (int64_t)(ty * RXR_TILE_H + tid / RXR_TILE_W) : (int64_t)py - P.out_base_row;
+        const int64_t row = P.compact ? (int64_t)(ty * RXR_TILE_H + ly) : (int64_t)py - P.out_base_row;
         P.out[(size_t)row * P.out_row_stride + px] = color;
     }
 }

@@ -1,14 +1,17 @@
 """Multi-GPU host for the rasterizer path: one process per GPU, framebuffer sharded by tile rows,
-assembled with one RCCL all-gather over xGMI (torch.distributed backend "nccl" == RCCL on ROCm).
+assembled on rank 0 with one RCCL gather over xGMI (torch.distributed backend "nccl" == RCCL on ROCm).
 
 The reference has no distributed code; what it does have is the observation this module builds on:
 tiles are rendered independently and only concatenated at the end
 (reference src/rasterizer.rs:273-275, 559-579).
 
-Sharding: the frame is cut into stripes of RXR_TILE_H (16) rows; stripe s belongs to rank s % world
-(interleaved, so that the expensive bottom-of-frame stripes and the cheap sky stripes are spread over
-all ranks).  Every rank renders its stripes into a compact [stripes_per_rank*16, W] buffer, the
-buffers are all-gathered, and one strided copy puts the stripes back in frame order.
+Sharding: the frame is cut into stripes of RXR_STRIPE_ROWS (16) rows; stripe s belongs to rank
+s % world (interleaved, so that the expensive bottom-of-frame stripes and the cheap sky stripes are
+spread over all ranks).  Every rank renders its stripes into a compact [stripes_per_rank*16, W]
+buffer (rxr_render_stripes_to); the buffers are gathered to rank 0 -- on a fully connected xGMI node
+the N-1 transfers run concurrently, one per link -- and one strided copy on rank 0 puts the stripes
+back in frame order.  The exchange is split into begin/end so that the caller can render frame i+1
+while frame i is in flight.
 """
 from __future__ import annotations
 
@@ -32,8 +35,8 @@ def stripe_rows(height: int, world: int, rank: int):
 
 
 def assemble_numpy(gathered: np.ndarray, height: int, width: int, world: int) -> np.ndarray:
-    """gathered: [world, stripes_per_rank*16, width, 4] -> frame [height, width, 4] (CPU reference
-    of the device-side de-interleave; used by the gloo tests)."""
+    """gathered: [world, stripes_per_rank*16, width, 4] -> frame [height, width, 4] (CPU model of the
+    device-side de-interleave; used by the tests)."""
     spr = stripes_per_rank(height, world)
     g = gathered.reshape(world, spr, TILE_H, width, 4)
     frame = np.ascontiguousarray(g.transpose(1, 0, 2, 3, 4)).reshape(spr * world * TILE_H, width, 4)
@@ -41,7 +44,7 @@ def assemble_numpy(gathered: np.ndarray, height: int, width: int, world: int) ->
 
 
 def assemble_torch(gathered, height: int, width: int, world: int, out=None):
-    """Device-side de-interleave of the all-gathered stripes (one strided copy)."""
+    """Device-side de-interleave of the gathered stripes (one strided copy)."""
     spr = stripes_per_rank(height, world)
     g = gathered.view(world, spr, TILE_H, width, 4).permute(1, 0, 2, 3, 4)
     if out is None:
@@ -61,45 +64,60 @@ def extract_stripes(frame: np.ndarray, world: int, rank: int) -> np.ndarray:
 
 
 class StripeGather:
-    """Owns the per-rank stripe buffer(s) and the gathered / assembled frame buffers (double-buffered)
-    and performs the exchange step: all_gather_into_tensor (RCCL on GPUs, gloo in the CPU tests) followed
-    by the de-interleave copy."""
+    """Owns the per-rank stripe buffers and, on the root, the gathered / assembled frame buffers
+    (all double-buffered) and performs the exchange step.
 
-    def __init__(self, height: int, width: int, world: int, rank: int, device, nbuf: int = 2):
+    mode "gather"    : dist.gather to `root` (default; only the root assembles and owns the frame)
+    mode "allgather" : dist.all_gather_into_tensor (every rank assembles the frame)
+    """
+
+    def __init__(self, height: int, width: int, world: int, rank: int, device, nbuf: int = 2, mode: str = "gather", root: int = 0):
         import torch
 
-        self.h, self.w, self.world, self.rank = height, width, world, rank
+        assert mode in ("gather", "allgather")
+        self.h, self.w, self.world, self.rank, self.mode, self.root = height, width, world, rank, mode, root
         self.spr = stripes_per_rank(height, world)
         rows = self.spr * TILE_H
-        self.bands = [torch.zeros((rows, width, 4), dtype=torch.uint8, device=device) for _ in range(nbuf)]
-        self.gathered = [torch.zeros((world * rows, width, 4), dtype=torch.uint8, device=device) for _ in range(nbuf)]
-        self.frames = [torch.zeros((self.spr * world * TILE_H, width, 4), dtype=torch.uint8, device=device) for _ in range(nbuf)]
         self.nbuf = nbuf
+        self.bands = [torch.zeros((rows, width, 4), dtype=torch.uint8, device=device) for _ in range(nbuf)]
+        self.owns_frame = mode == "allgather" or rank == root or world == 1
+        if self.owns_frame:
+            self.gathered = [torch.zeros((world * rows, width, 4), dtype=torch.uint8, device=device) for _ in range(nbuf)]
+            self.frames = [torch.zeros((self.spr * world * TILE_H, width, 4), dtype=torch.uint8, device=device) for _ in range(nbuf)]
+            # per-source views of the gather target (rank r's stripes land at rows [r*rows, (r+1)*rows))
+            self.slots = [[g[r * rows:(r + 1) * rows] for r in range(world)] for g in self.gathered]
+        else:
+            self.gathered, self.frames, self.slots = None, None, None
+        self._work = {}
 
     def band(self, i):
         return self.bands[i % self.nbuf]
 
     def exchange(self, i):
-        """Gathers band(i) from every rank and returns the assembled frame (height x width x 4)."""
+        """Blocking form: returns the assembled frame (height x width x 4) on ranks that own it, else None."""
         self.exchange_begin(i)
         return self.exchange_end(i)
 
     # split form for software pipelining: begin(i) queues the collective behind the work already on the
     # current stream (the render of frame i) and returns at once; end(i) makes the current stream wait
-    # for it and de-interleaves.  Rendering frame i+1 between the two overlaps it with the gather of
+    # for it and de-interleaves.  Rendering frame i+1 between the two overlaps it with the transfer of
     # frame i (the collective runs on the backend's own stream).
     def exchange_begin(self, i):
         import torch.distributed as dist
 
         b = i % self.nbuf
-        if self.world > 1:
-            self._work = getattr(self, "_work", {})
+        if self.world == 1:
+            self.gathered[b].copy_(self.bands[b])
+        elif self.mode == "allgather":
             self._work[b] = dist.all_gather_into_tensor(self.gathered[b], self.bands[b], async_op=True)
         else:
-            self.gathered[b].copy_(self.bands[b])
+            self._work[b] = dist.gather(self.bands[b], self.slots[b] if self.rank == self.root else None, dst=self.root, async_op=True)
 
     def exchange_end(self, i):
         b = i % self.nbuf
-        if self.world > 1:
-            self._work.pop(b).wait()
+        w = self._work.pop(b, None)
+        if w is not None:
+            w.wait()
+        if not self.owns_frame:
+            return None
         return assemble_torch(self.gathered[b], self.h, self.w, self.world, out=self.frames[b])

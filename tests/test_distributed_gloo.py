@@ -1,6 +1,7 @@
 """The N>1 path on CPU: world_size-2 (and 3) gloo process groups exercise the stripe partition, the
-all-gather exchange and the de-interleave exactly as bench.py runs them over RCCL; the per-rank render
-is modelled by slicing a frame rendered by the CPU oracle (tests only)."""
+exchange (gather to rank 0, and the all-gather variant) and the de-interleave exactly as bench.py
+runs them over RCCL -- including the begin/end software pipelining; the per-rank render is modelled by
+slicing a frame rendered by the CPU oracle (tests only)."""
 import os
 import socket
 
@@ -21,34 +22,56 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, frame, result_dir):
+def _worker(rank, world, port, frame, result_dir, mode):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         h, w = frame.shape[0], frame.shape[1]
-        g = D.StripeGather(h, w, world, rank, device="cpu")
+        g = D.StripeGather(h, w, world, rank, device="cpu", mode=mode)
         ok = True
-        for i in range(3):  # several frames through the double buffers
-            shifted = np.roll(frame, i * 5, axis=1)
-            g.band(i).copy_(torch.from_numpy(D.extract_stripes(shifted, world, rank)))
-            out = g.exchange(i)
-            ok &= np.array_equal(out.numpy(), shifted)
-        np.save(os.path.join(result_dir, f"ok{rank}.npy"), np.array([ok]))
+        n = 5
+
+        def want(i):
+            return np.roll(frame, i * 5, axis=1)
+
+        def check(i, out):
+            nonlocal ok
+            if g.owns_frame:
+                ok &= out is not None and np.array_equal(out.numpy(), want(i))
+            else:
+                ok &= out is None
+
+        # the same pipelined loop bench.py runs: render(i); begin(i); end(i-1)
+        for i in range(n):
+            g.band(i).copy_(torch.from_numpy(D.extract_stripes(want(i), world, rank)))
+            g.exchange_begin(i)
+            if i > 0:
+                check(i - 1, g.exchange_end(i - 1))
+        check(n - 1, g.exchange_end(n - 1))
+        # and the blocking form
+        g.band(0).copy_(torch.from_numpy(D.extract_stripes(frame, world, rank)))
+        check(0, g.exchange(0))
+        np.save(os.path.join(result_dir, f"ok{rank}.npy"), np.array([ok, g.owns_frame]))
     finally:
         dist.barrier()
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,size", [(2, (360, 640)), (3, (203, 77)), (2, (16, 32))])
-def test_stripe_allgather_roundtrip(tmp_path, oracle, world, size):
+@pytest.mark.parametrize("world,size,mode", [(2, (360, 640), "gather"), (3, (203, 77), "gather"), (2, (16, 32), "gather"),
+                                             (2, (100, 64), "allgather")])
+def test_stripe_exchange_roundtrip(tmp_path, oracle, world, size, mode):
     from rusterix_amd import scenes
 
     h, w = size
     frame = scenes.render(scenes.map_scene(oracle, width=w, height=h, logo_size=16, n_lights=1)).copy()
-    mp.spawn(_worker, args=(world, _free_port(), frame, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), frame, str(tmp_path), mode), nprocs=world, join=True)
+    owners = 0
     for r in range(world):
-        assert np.load(tmp_path / f"ok{r}.npy")[0], f"rank {r} assembled a wrong frame"
+        ok, owns = np.load(tmp_path / f"ok{r}.npy")
+        assert ok, f"rank {r} assembled a wrong frame"
+        owners += int(owns)
+    assert owners == (world if mode == "allgather" else 1)
 
 
 def test_partition_covers_every_row_once():
@@ -73,3 +96,10 @@ def test_assemble_numpy_matches_torch():
     out = torch.zeros((D.stripes_per_rank(h, world) * world * D.TILE_H, w, 4), dtype=torch.uint8)
     c = D.assemble_torch(torch.from_numpy(parts), h, w, world, out=out).numpy()
     assert np.array_equal(a, frame) and np.array_equal(b, frame) and np.array_equal(c, frame)
+
+
+def test_single_process_world_one():
+    frame = np.random.default_rng(2).integers(0, 256, (50, 20, 4), dtype=np.uint8)
+    g = D.StripeGather(50, 20, 1, 0, device="cpu")
+    g.band(0).copy_(torch.from_numpy(D.extract_stripes(frame, 1, 0)))
+    assert np.array_equal(g.exchange(0).numpy(), frame)
