@@ -142,6 +142,32 @@ typedef struct rxr_batch3d {
     int32_t chunk;                    /* index into rxr_frame.chunks, -1 for the scene-level lists */
 } rxr_batch3d;
 
+/* CullMode, src/batch/mod.rs:17-26 */
+enum { RXR_CULL_OFF = 0, RXR_CULL_FRONT = 1, RXR_CULL_BACK = 2 };
+
+/* Batch3D BEFORE projection: the inputs of Batch3D::clip_and_project (src/batch/batch3d.rs:482-740).
+ * Used by the device-side projection path (rxr_set_meshes + rxr_frame.use_meshes): the geometry is
+ * uploaded once and every frame sends only matrices; the device then performs the view transform,
+ * the near-plane clip (z < -0.1) with its appended fan triangles, the screen mapping (:689-700),
+ * Edges::new with the cull-mode rule (:706-739, src/edge.rs:12-24) and the bounding box (:749-768). */
+typedef struct rxr_mesh3d {
+    const float *vertices;            /* [n_vertices][4]                                            */
+    const uint32_t *indices;          /* [n_triangles][3]                                           */
+    const float *uvs;                 /* [n_vertices][2]                                            */
+    const float *normals;             /* [n_vertices][3]; required when n_triangles > 0 (the
+                                         reference indexes self.normals unconditionally, :605-607)   */
+    uint32_t n_vertices, n_triangles;
+    float transform_3d[16];           /* Batch3D.transform_3d, column-major                         */
+    uint32_t cull_mode;               /* RXR_CULL_*                                                 */
+    uint32_t repeat_mode;
+    rxr_source source;
+    float ambient_color[3];
+    int32_t shader;
+    uint32_t has_profile_id, profile_id;
+    uint32_t list;                    /* RXR_LIST_*                                                 */
+    int32_t chunk;
+} rxr_mesh3d;
+
 /* Batch2D after project (src/batch/batch2d.rs:10-52, outputs of :373-425) */
 typedef struct rxr_batch2d {
     const float *projected_vertices;  /* [n_vertices][2] */
@@ -214,6 +240,15 @@ typedef struct rxr_frame {
     uint32_t n_chunks;
     uint32_t n_shader_programs;       /* scene.shaders.len(); a batch whose shader index resolves
                                          to a program makes the call return RXR_ERR_UNSUPPORTED     */
+    /* device-side projection: when use_meshes != 0 the 3D batches are the meshes
+     * registered with rxr_set_meshes (batches3d must then be empty) and are projected on the device
+     * with these matrices, replacing Scene::project's 3D half (src/scene.rs:189-199) */
+    uint32_t use_meshes;
+    float view[16];                   /* Rasterizer.view_matrix, :40                               */
+    float projection[16];             /* Rasterizer.projection_matrix, :41                         */
+    const float *mesh_transforms;     /* optional [n_meshes][16]: this frame's Batch3D.transform_3d of
+                                         every registered mesh (moving objects need no re-registration);
+                                         NULL = the transforms given to rxr_set_meshes                */
 } rxr_frame;
 
 /* timings of the last rendered frame (HIP events on the context's stream), microseconds */
@@ -243,6 +278,18 @@ int rxr_device_count(void);
  * reads at src/rasterizer.rs:1103-1137 / :674-704.  Call again only when the textures change. */
 int rxr_set_textures(rxr_ctx *ctx, const rxr_tile *static_tiles, uint32_t n_static,
                      const rxr_tile *dynamic_tiles, uint32_t n_dynamic);
+
+/* registers the object-space 3D batches of a scene for device-side projection (submission order).
+ * Replaces nothing per frame: it is the one-time hand-over of what Batch3D::clip_and_project reads
+ * from `self` (src/batch/batch3d.rs:482-740).  Call again only when geometry or materials change. */
+int rxr_set_meshes(rxr_ctx *ctx, const rxr_mesh3d *meshes, uint32_t n_meshes);
+
+/* debugging / tests: copies the device-projected arrays of mesh `index` (as produced for the last
+ * rendered frame) back to the host in the layout of rxr_batch3d.  Any pointer may be NULL.
+ * counts[0] = vertices (originals + appended), counts[1] = triangles (originals + appended). */
+int rxr_read_projected_mesh(rxr_ctx *ctx, uint32_t index, uint32_t counts[2], float *projected_vertices, float *clipped_uvs,
+                            float *clipped_normals, uint32_t *clipped_indices, rxr_edges *edges, float bounding_box[5],
+                            uint32_t capacity_vertices, uint32_t capacity_triangles);
 
 /* validates + flattens a projected frame and copies it to HBM (replaces nothing in the reference:
  * it is the host->device hand-over).  The frame stays resident until the next upload. */

@@ -50,6 +50,9 @@ void rxh_set_device(int device) { set_device(device); }
 // the process-wide rxr_ctx (NULL + rxh_last_error() when no GPU): lets callers drive the split-phase
 // ABI (rxr_render_rows_to / rxr_get_stats) after rxh_rasterizer_upload
 void *rxh_context() { return context(); }
+// device-side projection on/off (rusterix::set_device_projection)
+void rxh_set_device_projection(int on) { set_device_projection(on != 0); }
+int rxh_get_device_projection() { return device_projection() ? 1 : 0; }
 
 // ---- scene ----------------------------------------------------------------------------------------
 void *rxh_scene_new() { return new Scene(); }

@@ -389,6 +389,13 @@ bool Scene::project(const Mat3 *m2d, const Mat4 &view, const Mat4 &proj, float w
     return ok;
 }
 
+void Scene::project_2d(const Mat3 *m2d) {
+    for (Chunk &c : chunks)
+        for (Batch2D &b : c.batches2d) b.project(m2d);
+    for (Batch2D &b : d2_static) b.project(m2d);
+    for (Batch2D &b : d2_dynamic) b.project(m2d);
+}
+
 // ---- device context -----------------------------------------------------------------------------
 namespace {
 std::mutex g_mu;
@@ -396,7 +403,12 @@ rxr_ctx *g_ctx = nullptr;
 int g_device = -1;
 std::string g_error;
 uint64_t g_tex_static_gen = 0, g_tex_dynamic_gen = 0;
+bool g_device_projection = false;
+uint64_t g_mesh_fingerprint = 0;
 }  // namespace
+
+void set_device_projection(bool on) { g_device_projection = on; }
+bool device_projection() { return g_device_projection; }
 
 const std::string &last_error() { return g_error; }
 
@@ -405,6 +417,7 @@ void set_device(int device) {
     if (g_ctx && device != g_device) {
         rxr_destroy(g_ctx);
         g_ctx = nullptr;
+        g_mesh_fingerprint = 0;
         g_tex_static_gen = g_tex_dynamic_gen = 0;
     }
     g_device = device;
@@ -525,7 +538,10 @@ int Rasterizer::upload(Scene &scene, size_t w, size_t h, size_t tile_size, const
     height = (float)h;
     hash_anim = hash_u32((uint32_t)scene.animation_frame);  // :208
 
-    if (!scene.project(has_m2d ? &projection_matrix_2d : nullptr, view_matrix, projection_matrix, width, height)) {  // :210
+    const bool on_device = g_device_projection;
+    if (on_device) {
+        scene.project_2d(has_m2d ? &projection_matrix_2d : nullptr);  // the 3D half runs on the GPU
+    } else if (!scene.project(has_m2d ? &projection_matrix_2d : nullptr, view_matrix, projection_matrix, width, height)) {  // :210
         g_error = "clip_and_project: batch without normals (the reference panics at batch3d.rs:605)";
         return RXR_ERR_INVALID;
     }
@@ -561,6 +577,85 @@ int Rasterizer::upload(Scene &scene, size_t w, size_t h, size_t tile_size, const
     for (const Batch3D &b : scene.d3_static) b3.push_back(view3d(b, RXR_LIST_STATIC, -1));
     for (const Batch3D &b : scene.d3_dynamic) b3.push_back(view3d(b, RXR_LIST_DYNAMIC, -1));
     for (const Batch3D &b : scene.d3_overlay) b3.push_back(view3d(b, RXR_LIST_OVERLAY, -1));
+
+    // device-side projection: the same batches in the same order, as object-space meshes
+    std::vector<rxr_mesh3d> meshes;
+    std::vector<float> mesh_transforms;
+    if (on_device) {
+        uint64_t fp = 1469598103934665603ull;  // FNV-1a over what rxr_set_meshes copies (transforms travel per frame)
+        auto mix = [&](const void *p, size_t n) {
+            const uint8_t *q = (const uint8_t *)p;
+            for (size_t i = 0; i < n; ++i) fp = (fp ^ q[i]) * 1099511628211ull;
+        };
+        auto add = [&](const Batch3D &b, uint32_t list, int chunk) -> bool {
+            if (!b.indices.empty() && b.normals.size() / 3 < b.vertex_count()) return false;  // batch3d.rs:605 panics
+            rxr_mesh3d m{};
+            m.vertices = b.vertices.data();
+            m.indices = b.indices.data();
+            m.uvs = b.uvs.data();
+            m.normals = b.normals.empty() ? nullptr : b.normals.data();
+            m.n_vertices = (uint32_t)b.vertex_count();
+            m.n_triangles = (uint32_t)b.triangle_count();
+            memcpy(m.transform_3d, b.transform_3d.m, 64);
+            m.cull_mode = (uint32_t)b.cull_mode_;
+            m.repeat_mode = b.repeat_mode_;
+            m.source.kind = b.source_.kind;
+            m.source.index = b.source_.index;
+            memcpy(m.source.pixel, b.source_.pixel, 4);
+            m.ambient_color[0] = b.ambient_color_.x; m.ambient_color[1] = b.ambient_color_.y; m.ambient_color[2] = b.ambient_color_.z;
+            m.shader = b.shader_;
+            m.has_profile_id = b.has_profile_id ? 1u : 0u;
+            m.profile_id = b.profile_id_;
+            m.list = list;
+            m.chunk = chunk;
+            meshes.push_back(m);
+            mesh_transforms.insert(mesh_transforms.end(), b.transform_3d.m, b.transform_3d.m + 16);
+            const void *ptrs[4] = {m.vertices, m.indices, m.uvs, m.normals};
+            mix(ptrs, sizeof(ptrs));
+            const uint32_t meta[12] = {m.n_vertices, m.n_triangles, m.cull_mode, m.repeat_mode, m.source.kind, m.source.index,
+                                       (uint32_t)m.shader, m.has_profile_id, m.profile_id, m.list, (uint32_t)m.chunk,
+                                       (uint32_t)b.normals.size()};
+            mix(meta, sizeof(meta));
+            mix(m.source.pixel, 4);
+            mix(m.ambient_color, 12);
+            // content stamp (addresses get reused): small meshes are hashed whole, large ones sampled
+            const size_t vb = (size_t)m.n_vertices * 16, ib = (size_t)m.n_triangles * 12;
+            if (vb + ib <= (1u << 20)) {
+                mix(m.vertices, vb);
+                mix(m.indices, ib);
+                mix(m.uvs, (size_t)m.n_vertices * 8);
+                if (m.normals) mix(m.normals, (size_t)m.n_vertices * 12);
+            } else {
+                for (size_t v = 0; v < m.n_vertices; v += 1021) mix(m.vertices + 4 * v, 16);
+                for (size_t t = 0; t < m.n_triangles; t += 1021) mix(m.indices + 3 * t, 12);
+                mix(m.vertices + 4 * (size_t)(m.n_vertices - 1), 16);
+                mix(m.indices + 3 * (size_t)(m.n_triangles - 1), 12);
+            }
+            return true;
+        };
+        bool ok = true;
+        for (size_t c = 0; c < scene.chunks.size(); ++c) {
+            for (const Batch3D &b : scene.chunks[c].batches3d_opacity) ok = ok && add(b, RXR_LIST_CHUNK_OPACITY, (int)c);
+            for (const Batch3D &b : scene.chunks[c].batches3d) ok = ok && add(b, RXR_LIST_CHUNK, (int)c);
+        }
+        for (const Batch3D &b : scene.d3_static) ok = ok && add(b, RXR_LIST_STATIC, -1);
+        for (const Batch3D &b : scene.d3_dynamic) ok = ok && add(b, RXR_LIST_DYNAMIC, -1);
+        for (const Batch3D &b : scene.d3_overlay) ok = ok && add(b, RXR_LIST_OVERLAY, -1);
+        if (!ok) {
+            g_error = "clip_and_project: batch without normals (the reference panics at batch3d.rs:605)";
+            return RXR_ERR_INVALID;
+        }
+        if (fp != g_mesh_fingerprint) {
+            int rc = rxr_set_meshes(ctx, meshes.data(), (uint32_t)meshes.size());
+            if (rc != RXR_OK) {
+                g_error = rxr_last_error(ctx);
+                g_mesh_fingerprint = 0;
+                return rc;
+            }
+            g_mesh_fingerprint = fp;
+        }
+        b3.clear();
+    }
     for (const Batch2D &b : scene.d2_static) b2.push_back(view2d(b, -1));
     for (const Batch2D &b : scene.d2_dynamic) b2.push_back(view2d(b, -1));
 
@@ -604,6 +699,12 @@ int Rasterizer::upload(Scene &scene, size_t w, size_t h, size_t tile_size, const
     f.chunks = chunks.data();
     f.n_chunks = (uint32_t)chunks.size();
     f.n_shader_programs = 0;
+    if (on_device) {
+        f.use_meshes = 1;
+        memcpy(f.view, view_matrix.m, 64);
+        memcpy(f.projection, projection_matrix.m, 64);
+        f.mesh_transforms = mesh_transforms.empty() ? nullptr : mesh_transforms.data();
+    }
 
     int rc = rxr_upload_frame(ctx, &f);
     if (rc != RXR_OK) g_error = rxr_last_error(ctx);

@@ -152,6 +152,8 @@ public:
 
     // src/scene.rs:154-200.  false where the reference panics.
     bool project(const Mat3 *m2d, const Mat4 &view, const Mat4 &proj, float width, float height);
+    // the 2D half only (src/scene.rs:163-187); used when the 3D half runs on the device
+    void project_2d(const Mat3 *m2d);
 };
 
 // src/rasterizer.rs:35-193
@@ -192,6 +194,11 @@ public:
 // the process-wide device context (one process per GPU).  Device index from RXR_DEVICE, else
 // LOCAL_RANK, else 0.
 rxr_ctx *context(std::string *error = nullptr);
+// device-side projection: when on, Rasterizer::upload registers the object-space
+// batches once (rxr_set_meshes) and each frame sends matrices only; Scene::project's 3D half
+// (clip_and_project, Edges::new, bounding boxes) then runs on the GPU.  Off by default.
+void set_device_projection(bool on);
+bool device_projection();
 void set_device(int device);
 const std::string &last_error();
 

@@ -15,8 +15,12 @@
 #include <string>
 #include <vector>
 
+#include "../../include/rusterix_vek.hpp"  // host-side Mat4 products for the device-projection path
 #include "rxr_device.h"
+#include "rxr_project.h"
 
+extern "C" void rxr_launch_proj_static(const ProjectParams *P, hipStream_t s);
+extern "C" void rxr_launch_project(const ProjectParams *P, hipStream_t s);
 extern "C" void rxr_launch_setup(const RasterParams *P, hipStream_t s);
 extern "C" void rxr_launch_scan(const RasterParams *P, hipStream_t s);
 extern "C" void rxr_launch_fill(const RasterParams *P, hipStream_t s);
@@ -33,6 +37,20 @@ struct DevBuf {
 
 struct TileRange {
     uint32_t first, n;
+};
+
+// host-side record of one registered mesh (rxr_set_meshes)
+struct HostMesh {
+    DevMesh dev;              // static part (bases, counts, cull mode); view_model / rejected are per frame
+    float transform[16];
+    float aabb_lo[3], aabb_hi[3];
+    bool has_vertices;
+    uint32_t repeat_mode;
+    rxr_source source;
+    float ambient[3];
+    int32_t shader;
+    uint32_t has_profile_id, profile_id, list;
+    int32_t chunk;
 };
 
 struct ProfSlot {
@@ -69,6 +87,14 @@ struct rxr_ctx {
     uint32_t list_capacity = 0;
     uint32_t parity = 0;             // counter set of the next launch
     bool scratch_dirty = false;      // a pre-pass was queued without its raster launch
+
+    // device-side projection (rxr_set_meshes)
+    std::vector<HostMesh> meshes;
+    DevBuf d_obj, d_proj_out, d_proj_misc;
+    ProjectParams PP{};
+    size_t mesh_verts_out = 0, mesh_tris_out = 0;
+    size_t pp_off_meshes = 0;  // byte offset of the per-frame DevMesh array inside d_proj_misc
+    bool frame_uses_meshes = false;
 
     bool has_frame = false;
     RasterParams P{};       // template for the resident frame (pointers resolved)
@@ -195,7 +221,7 @@ void rxr_destroy(rxr_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    DevBuf *bufs[] = {&ctx->d_tex, &ctx->d_texels, &ctx->d_frame, &ctx->d_tri_setup, &ctx->d_tri_shade, &ctx->d_bin_count, &ctx->d_bins,
+    DevBuf *bufs[] = {&ctx->d_obj, &ctx->d_proj_out, &ctx->d_proj_misc, &ctx->d_tex, &ctx->d_texels, &ctx->d_frame, &ctx->d_tri_setup, &ctx->d_tri_shade, &ctx->d_bin_count, &ctx->d_bins,
                       &ctx->d_list, &ctx->d_large, &ctx->d_counters, &ctx->d_fb};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
@@ -282,6 +308,200 @@ int rxr_set_textures(rxr_ctx *ctx, const rxr_tile *static_tiles, uint32_t n_stat
     return RXR_OK;
 }
 
+int rxr_set_meshes(rxr_ctx *ctx, const rxr_mesh3d *meshes, uint32_t n_meshes) {
+    if (!ctx) return RXR_ERR_INVALID;
+    if (n_meshes && !meshes) return fail(ctx, RXR_ERR_INVALID, "rxr_set_meshes: NULL mesh array");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->meshes.clear();
+    ctx->has_frame = false;
+    size_t vin = 0, tin = 0, vout = 0, tout = 0;
+    for (uint32_t i = 0; i < n_meshes; ++i) {
+        const rxr_mesh3d &m = meshes[i];
+        if (m.n_vertices && (!m.vertices || !m.uvs)) return fail(ctx, RXR_ERR_INVALID, "mesh: NULL vertex arrays");
+        if (m.n_triangles && !m.indices) return fail(ctx, RXR_ERR_INVALID, "mesh: NULL indices");
+        if (m.n_triangles && !m.normals)
+            return fail(ctx, RXR_ERR_INVALID, "mesh without normals (clip_and_project panics at batch3d.rs:605)");
+        if (m.cull_mode > RXR_CULL_BACK) return fail(ctx, RXR_ERR_INVALID, "mesh: bad cull mode");
+        for (uint32_t t = 0; t < m.n_triangles * 3u; ++t)
+            if (m.indices[t] >= m.n_vertices) return fail(ctx, RXR_ERR_INVALID, "mesh: vertex index out of range");
+        HostMesh h{};
+        h.dev.vin_base = (uint32_t)vin;
+        h.dev.tin_base = (uint32_t)tin;
+        h.dev.n_verts = m.n_vertices;
+        h.dev.n_tris = m.n_triangles;
+        h.dev.vout_base = (uint32_t)vout;
+        h.dev.tout_base = (uint32_t)tout;
+        h.dev.cull_mode = m.cull_mode;
+        memcpy(h.transform, m.transform_3d, 64);
+        // object-space AABB with f32::min / f32::max semantics (batch3d.rs:494-507)
+        for (int k = 0; k < 3; ++k) {
+            h.aabb_lo[k] = INFINITY;
+            h.aabb_hi[k] = -INFINITY;
+        }
+        for (uint32_t v = 0; v < m.n_vertices; ++v)
+            for (int k = 0; k < 3; ++k) {
+                h.aabb_lo[k] = std::fmin(h.aabb_lo[k], m.vertices[4 * (size_t)v + k]);
+                h.aabb_hi[k] = std::fmax(h.aabb_hi[k], m.vertices[4 * (size_t)v + k]);
+            }
+        h.has_vertices = m.n_vertices > 0;
+        h.repeat_mode = m.repeat_mode;
+        h.source = m.source;
+        memcpy(h.ambient, m.ambient_color, 12);
+        h.shader = m.shader;
+        h.has_profile_id = m.has_profile_id;
+        h.profile_id = m.profile_id;
+        h.list = m.list;
+        h.chunk = m.chunk;
+        ctx->meshes.push_back(h);
+        vin += m.n_vertices;
+        tin += m.n_triangles;
+        vout += (size_t)m.n_vertices + 4 * (size_t)m.n_triangles;
+        tout += 3 * (size_t)m.n_triangles;
+    }
+    if (vout >= (1ull << 31) || tout >= (1ull << 31)) return fail(ctx, RXR_ERR_INVALID, "meshes too large (>= 2^31 output slots)");
+    ctx->mesh_verts_out = vout;
+    ctx->mesh_tris_out = tout;
+
+    // ---- object-space pools + static prefix arrays: one staging blob, one copy ----
+    size_t o = 0;
+    auto take = [&](size_t bytes) {
+        size_t at = o;
+        o = align_up(o + (bytes ? bytes : 16), 256);
+        return at;
+    };
+    const size_t off_v = take(vin * 16), off_i = take(tin * 12), off_uv = take(vin * 8), off_n = take(vin * 12);
+    const size_t off_pv = take((n_meshes + 1) * 4), off_pt = take((n_meshes + 1) * 4), off_po = take((n_meshes + 1) * 4);
+    const size_t off_dm = take((size_t)n_meshes * sizeof(DevMesh));
+    const size_t obj_total = o;
+    int rc;
+    if ((rc = ensure_stage(ctx, obj_total)) != RXR_OK) return rc;
+    if ((rc = ensure(ctx, ctx->d_obj, obj_total)) != RXR_OK) return rc;
+    uint8_t *st = (uint8_t *)ctx->h_stage;
+    uint32_t *pv = (uint32_t *)(st + off_pv), *pt = (uint32_t *)(st + off_pt), *po = (uint32_t *)(st + off_po);
+    DevMesh *dm = (DevMesh *)(st + off_dm);
+    for (uint32_t i = 0; i < n_meshes; ++i) {
+        const rxr_mesh3d &m = meshes[i];
+        const HostMesh &h = ctx->meshes[i];
+        pv[i] = h.dev.vin_base;
+        pt[i] = h.dev.tin_base;
+        po[i] = h.dev.tout_base;
+        dm[i] = h.dev;
+        if (m.n_vertices) {
+            memcpy(st + off_v + (size_t)h.dev.vin_base * 16, m.vertices, (size_t)m.n_vertices * 16);
+            memcpy(st + off_uv + (size_t)h.dev.vin_base * 8, m.uvs, (size_t)m.n_vertices * 8);
+            if (m.normals) memcpy(st + off_n + (size_t)h.dev.vin_base * 12, m.normals, (size_t)m.n_vertices * 12);
+            else memset(st + off_n + (size_t)h.dev.vin_base * 12, 0, (size_t)m.n_vertices * 12);
+        }
+        if (m.n_triangles) memcpy(st + off_i + (size_t)h.dev.tin_base * 12, m.indices, (size_t)m.n_triangles * 12);
+    }
+    pv[n_meshes] = (uint32_t)vin;
+    pt[n_meshes] = (uint32_t)tin;
+    po[n_meshes] = (uint32_t)tout;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_obj.p, st, obj_total, hipMemcpyHostToDevice, ctx->stream));
+
+    // ---- output pools (the arrays k_setup3d reads) + scratch ----
+    o = 0;
+    const size_t q_vs = take(vout * 16), q_pv = take(vout * 16), q_uv = take(vout * 8), q_nrm = take(vout * 12);
+    const size_t q_idx = take(tout * 12), q_edges = take(tout * sizeof(rxr_edges));
+    const size_t out_total = o;
+    if ((rc = ensure(ctx, ctx->d_proj_out, out_total)) != RXR_OK) return rc;
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_proj_out.p, 0, out_total, ctx->stream));  // indices 0 / edges invisible until written
+    o = 0;
+    const size_t n_chunks = (tin + 1 + RXR_PROJ_SCAN_CHUNK - 1) / RXR_PROJ_SCAN_CHUNK + 1;
+    const size_t m_evis = take(tin + 1), m_app = take((tin + 1) * 8), m_ct = take(n_chunks * 8), m_cb = take(n_chunks * 8);
+    const size_t m_ticket = take(16), m_bbox = take((size_t)n_meshes * sizeof(DevBBox));
+    const size_t m_dm = take((size_t)n_meshes * sizeof(DevMesh));
+    if ((rc = ensure(ctx, ctx->d_proj_misc, o)) != RXR_OK) return rc;
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_proj_misc.p, 0, o, ctx->stream));
+    ctx->pp_off_meshes = m_dm;
+
+    ProjectParams &PP = ctx->PP;
+    memset(&PP, 0, sizeof(PP));
+    PP.n_meshes = n_meshes;
+    PP.n_verts_in = (uint32_t)vin;
+    PP.n_tris_in = (uint32_t)tin;
+    PP.n_tris_out = (uint32_t)tout;
+    uint8_t *d = (uint8_t *)ctx->d_obj.p, *q = (uint8_t *)ctx->d_proj_out.p, *mm = (uint8_t *)ctx->d_proj_misc.p;
+    PP.meshes = (const DevMesh *)(d + off_dm);  // static copy; replaced by the per-frame array at render time
+    PP.vin_prefix = (const uint32_t *)(d + off_pv);
+    PP.tin_prefix = (const uint32_t *)(d + off_pt);
+    PP.tout_prefix = (const uint32_t *)(d + off_po);
+    PP.obj_verts = (const float4 *)(d + off_v);
+    PP.obj_idx = (const uint32_t *)(d + off_i);
+    PP.obj_uvs = (const float2 *)(d + off_uv);
+    PP.obj_normals = (const float *)(d + off_n);
+    PP.view_verts = (float4 *)(q + q_vs);
+    PP.pv = (float4 *)(q + q_pv);
+    PP.uv = (float2 *)(q + q_uv);
+    PP.nrm = (float *)(q + q_nrm);
+    PP.idx = (uint32_t *)(q + q_idx);
+    PP.edges = (rxr_edges *)(q + q_edges);
+    PP.edge_vis = (uint8_t *)(mm + m_evis);
+    PP.append = (AppendCount *)(mm + m_app);
+    PP.chunk_tot = (AppendCount *)(mm + m_ct);
+    PP.chunk_base = (AppendCount *)(mm + m_cb);
+    PP.ticket = (uint32_t *)(mm + m_ticket);
+    PP.bbox = (DevBBox *)(mm + m_bbox);
+    rxr_launch_proj_static(&PP, ctx->stream);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return RXR_OK;
+}
+
+int rxr_read_projected_mesh(rxr_ctx *ctx, uint32_t index, uint32_t counts[2], float *projected_vertices, float *clipped_uvs,
+                            float *clipped_normals, uint32_t *clipped_indices, rxr_edges *edges, float bounding_box[5],
+                            uint32_t capacity_vertices, uint32_t capacity_triangles) {
+    if (!ctx || !counts) return RXR_ERR_INVALID;
+    if (index >= ctx->meshes.size()) return fail(ctx, RXR_ERR_INVALID, "rxr_read_projected_mesh: no such mesh");
+    int rc = rxr_synchronize(ctx);
+    if (rc != RXR_OK) return rc;
+    const DevMesh &M = ctx->meshes[index].dev;
+    const ProjectParams &PP = ctx->PP;
+    // appended counts of this mesh = prefix(end) - prefix(start)
+    auto prefix_at = [&](uint32_t i, AppendCount &out) -> int {
+        AppendCount a = 0, b = 0;
+        HIPCHK(ctx, hipMemcpy(&a, PP.append + i, 8, hipMemcpyDeviceToHost));
+        HIPCHK(ctx, hipMemcpy(&b, PP.chunk_base + i / RXR_PROJ_SCAN_CHUNK, 8, hipMemcpyDeviceToHost));
+        out = a + b;
+        return RXR_OK;
+    };
+    AppendCount p0 = 0, p1 = 0;
+    DevMesh frame_mesh{};
+    HIPCHK(ctx, hipMemcpy(&frame_mesh, (uint8_t *)ctx->d_proj_misc.p + ctx->pp_off_meshes + (size_t)index * sizeof(DevMesh), sizeof(DevMesh), hipMemcpyDeviceToHost));
+    uint32_t nv = 0, nt = 0;
+    if (!frame_mesh.rejected) {
+        if ((rc = prefix_at(M.tin_base, p0)) != RXR_OK || (rc = prefix_at(M.tin_base + M.n_tris, p1)) != RXR_OK) return rc;
+        AppendCount tot = p1 - p0;
+        nv = M.n_verts + (uint32_t)(tot & 0xFFFFFFFFull);
+        nt = M.n_tris + (uint32_t)(tot >> 32);
+    }
+    counts[0] = nv;
+    counts[1] = nt;
+    if (nv > capacity_vertices || nt > capacity_triangles) return fail(ctx, RXR_ERR_INVALID, "rxr_read_projected_mesh: capacity too small");
+    if (projected_vertices && nv) HIPCHK(ctx, hipMemcpy(projected_vertices, PP.pv + M.vout_base, (size_t)nv * 16, hipMemcpyDeviceToHost));
+    if (clipped_uvs && nv) HIPCHK(ctx, hipMemcpy(clipped_uvs, PP.uv + M.vout_base, (size_t)nv * 8, hipMemcpyDeviceToHost));
+    if (clipped_normals && nv) HIPCHK(ctx, hipMemcpy(clipped_normals, PP.nrm + 3 * (size_t)M.vout_base, (size_t)nv * 12, hipMemcpyDeviceToHost));
+    if (clipped_indices && nt) HIPCHK(ctx, hipMemcpy(clipped_indices, PP.idx + 3 * (size_t)M.tout_base, (size_t)nt * 12, hipMemcpyDeviceToHost));
+    if (edges && nt) HIPCHK(ctx, hipMemcpy(edges, PP.edges + M.tout_base, (size_t)nt * sizeof(rxr_edges), hipMemcpyDeviceToHost));
+    if (bounding_box) {
+        DevBBox bb{};
+        HIPCHK(ctx, hipMemcpy(&bb, PP.bbox + index, sizeof(bb), hipMemcpyDeviceToHost));
+        auto dec = [](uint32_t e) {
+            uint32_t u = (e & 0x80000000u) ? (e ^ 0x80000000u) : ~e;
+            float f;
+            memcpy(&f, &u, 4);
+            return f;
+        };
+        bounding_box[0] = frame_mesh.rejected ? 0.0f : 1.0f;
+        bounding_box[1] = dec(bb.min_x);
+        bounding_box[2] = dec(bb.min_y);
+        bounding_box[3] = dec(bb.max_x) - dec(bb.min_x);
+        bounding_box[4] = dec(bb.max_y) - dec(bb.min_y);
+    }
+    return RXR_OK;
+}
+
 // resolves a PixelSource to (tex index | constant texel); see include/rxr.h RXR_SOURCE_*
 static int resolve_source(rxr_ctx *ctx, const rxr_source &src, bool is_3d, int chunk, uint64_t animation_frame, int32_t &tex,
                           uint32_t &pixel) {
@@ -329,6 +549,16 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
     // ---- pass 1: validate + size ---------------------------------------------------------------
     size_t n_v3 = 0, n_t3 = 0;
     bool has_opacity = false;
+    const bool use_meshes = f->use_meshes != 0;
+    if (use_meshes && f->n_batches3d) return fail(ctx, RXR_ERR_INVALID, "rxr_upload_frame: use_meshes with batches3d");
+    const uint32_t n_b3 = use_meshes ? (uint32_t)ctx->meshes.size() : f->n_batches3d;
+    if (use_meshes)
+        for (const HostMesh &h : ctx->meshes) {
+            if (h.chunk >= (int32_t)f->n_chunks) return fail(ctx, RXR_ERR_INVALID, "mesh: chunk index out of range");
+            if (h.shader >= 0 && (uint32_t)h.shader < f->n_shader_programs)
+                return fail(ctx, RXR_ERR_UNSUPPORTED, "mesh uses a Rusteria shader program: not implemented on the device yet");
+            if (h.list == RXR_LIST_CHUNK_OPACITY) has_opacity = true;
+        }
     for (uint32_t i = 0; i < f->n_batches3d; ++i) {
         const rxr_batch3d &b = f->batches3d[i];
         if (b.n_triangles && (!b.clipped_indices || !b.edges)) return fail(ctx, RXR_ERR_INVALID, "batch3d: NULL indices/edges");
@@ -378,8 +608,8 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
         o = align_up(o + (bytes ? bytes : 16), 256);
         return at;
     };
-    L.off_b3 = take(f->n_batches3d * sizeof(DevBatch));
-    L.off_base = take((f->n_batches3d + 1) * sizeof(uint32_t));
+    L.off_b3 = take(n_b3 * sizeof(DevBatch));
+    L.off_base = take((n_b3 + 1) * sizeof(uint32_t));
     L.off_pv = take(n_v3 * 16);
     L.off_uv = take(n_v3 * 8);
     L.off_nrm = take(n_v3 * 12);
@@ -454,6 +684,74 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
         tcur += b.n_triangles;
     }
     base[f->n_batches3d] = (uint32_t)tcur;
+
+    if (use_meshes) {
+        // headers of the device-projected batches + the per-frame half of DevMesh (view * model, frustum reject)
+        rvek::Mat4 view{}, proj{};
+        memcpy(view.m, f->view, 64);
+        memcpy(proj.m, f->projection, 64);
+        const rvek::Mat4 pv_m = proj * view;
+        std::vector<DevMesh> dm(ctx->meshes.size());
+        for (uint32_t i = 0; i < n_b3; ++i) {
+            const HostMesh &h = ctx->meshes[i];
+            rvek::Mat4 model{};
+            memcpy(model.m, f->mesh_transforms ? f->mesh_transforms + 16 * (size_t)i : h.transform, 64);
+            const rvek::Mat4 mvp = pv_m * model;             // batch3d.rs:490
+            const rvek::Mat4 view_model = view * model;      // :555
+            bool rejected = false;
+            if (h.has_vertices) {                            // :493-552
+                bool out_l = true, out_r = true, out_b = true, out_t = true, out_n = true, out_f = true;
+                for (int c = 0; c < 8; ++c) {
+                    rvek::Vec4 corner{(c & 4) ? h.aabb_hi[0] : h.aabb_lo[0], (c & 2) ? h.aabb_hi[1] : h.aabb_lo[1],
+                                      (c & 1) ? h.aabb_hi[2] : h.aabb_lo[2], 1.0f};
+                    rvek::Vec4 v = mvp * corner;
+                    const float w = v.w;
+                    out_l &= v.x < -w;
+                    out_r &= v.x > w;
+                    out_b &= v.y < -w;
+                    out_t &= v.y > w;
+                    out_n &= v.z < -w;
+                    out_f &= v.z > w;
+                }
+                rejected = out_l || out_r || out_b || out_t || out_n || out_f;
+            }
+            dm[i] = h.dev;
+            dm[i].rejected = rejected ? 1u : 0u;
+            memcpy(dm[i].view_model, view_model.m, 64);
+
+            DevBatch d{};
+            d.vert_base = h.dev.vout_base;
+            d.tri_base = h.dev.tout_base;
+            d.n_tris = 3u * h.dev.n_tris;
+            d.n_verts = h.dev.n_verts + 4u * h.dev.n_tris;
+            d.flags = DB_HAS_NORMALS;  // meshes with triangles must carry normals (batch3d.rs:605)
+            if (h.has_profile_id) d.flags |= DB_HAS_PROFILE;
+            if (h.list == RXR_LIST_CHUNK_OPACITY) d.flags |= DB_OPACITY_LIST;
+            d.profile_id = h.profile_id;
+            d.repeat_mode = h.repeat_mode;
+            d.chunk = h.chunk;
+            memcpy(d.ambient, h.ambient, 12);
+            bool keep = !rejected && h.dev.n_tris > 0;       // the box reject itself happens on the device (dev_bbox)
+            if (keep) {
+                rc = resolve_source(ctx, h.source, true, h.chunk, f->animation_frame, d.tex, d.pixel);
+                if (rc != RXR_OK) return fail(ctx, rc, "mesh: texture tile index out of range or tile without textures (the reference panics)");
+                if (d.tex >= 0) {
+                    if (!ctx->h_tex[d.tex].all_opaque) d.flags |= DB_ALPHA_TEST;
+                } else if ((d.pixel >> 24) != 255u && h.list != RXR_LIST_CHUNK_OPACITY) {
+                    keep = false;
+                }
+            }
+            if (!keep) d.flags |= DB_SKIP;
+            b3[i] = d;
+            base[i] = h.dev.tout_base;
+        }
+        base[n_b3] = (uint32_t)ctx->mesh_tris_out;
+        n_t3 = ctx->mesh_tris_out;
+        // the per-frame DevMesh array goes straight into the projection scratch (tiny: 96 B per mesh)
+        if (n_b3) HIPCHK(ctx, hipMemcpyAsync((uint8_t *)ctx->d_proj_misc.p + ctx->pp_off_meshes, dm.data(), dm.size() * sizeof(DevMesh),
+                                             hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // `dm` is a stack-lifetime source
+    }
 
     if (f->n_lights) memcpy(st + L.off_lights, f->lights, f->n_lights * sizeof(rxr_light));
     {
@@ -604,7 +902,7 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
     memcpy(P.sun_dir, f->sun_dir, 12);
     P.day_factor = f->day_factor;
     P.n_tris3d = (uint32_t)n_t3;
-    P.n_batches3d = f->n_batches3d;
+    P.n_batches3d = n_b3;
     P.n_lights = f->n_lights;
     P.n_occluders = f->n_occluders;
     P.n_linedefs = f->n_linedefs;
@@ -642,6 +940,21 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
     P.tex = (const DevTexDesc *)ctx->d_tex.p;
     P.texels = (const uint32_t *)ctx->d_texels.p;
     P.bg_pixels = (const uint32_t *)(d + L.off_bg);
+    ctx->frame_uses_meshes = use_meshes;
+    if (use_meshes) {
+        // the raster pre-pass reads the pools the projection kernels write
+        ProjectParams &PP = ctx->PP;
+        memcpy(PP.projection, f->projection, 64);
+        PP.width = W;
+        PP.height = H;
+        PP.meshes = (const DevMesh *)((uint8_t *)ctx->d_proj_misc.p + ctx->pp_off_meshes);
+        P.pv = PP.pv;
+        P.uv = PP.uv;
+        P.nrm = PP.nrm;
+        P.idx = PP.idx;
+        P.edges = PP.edges;
+        P.dev_bbox = PP.bbox;
+    }
     ctx->n_tris2d = (uint32_t)t2cur;
     ctx->has_frame = true;
     ctx->rendered = false;
@@ -698,6 +1011,7 @@ static int render_impl(rxr_ctx *ctx, const RenderSpec &spec, void *dev_pixels, h
         P.counters = (uint32_t *)ctx->d_counters.p + (size_t)ctx->parity * CNT_WORDS;
         P.counters_next = (uint32_t *)ctx->d_counters.p + (size_t)(ctx->parity ^ 1u) * CNT_WORDS;
         ctx->parity ^= 1u;
+        if (ctx->frame_uses_meshes) rxr_launch_project(&ctx->PP, s);  // clip_and_project + Edges + boxes on the device
         rxr_launch_setup(&P, s);
         rxr_launch_scan(&P, s);
         rxr_launch_fill(&P, s);

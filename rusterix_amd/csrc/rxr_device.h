@@ -139,6 +139,7 @@ struct RasterParams {
     const rxr_edges *edges;
     const DevBatch *batches3d;
     const uint32_t *batch_tri_base;  // n_batches3d + 1 prefix array for the triangle -> batch search
+    const struct DevBBox *dev_bbox;  // device-projection path: per-batch boxes accumulated on the device (else NULL)
 
     // set-up outputs
     TriSetup *tri_setup;

@@ -26,6 +26,7 @@
 #include <hip/hip_runtime.h>
 
 #include "rxr_device.h"
+#include "rxr_project.h"
 
 #ifndef RXR_VEK_FUSED_MATVEC
 #define RXR_VEK_FUSED_MATVEC 1
@@ -648,7 +649,17 @@ extern "C" __global__ void __launch_bounds__(256) k_setup3d(RasterParams P) {
     uint32_t min_y = sat_index(fmaxf(floorf(min_yf), (float)P.row0), 0xFFFFu);
     uint32_t max_y = sat_index(fminf(ceilf(max_yf), (float)P.row1), 0xFFFFu);
 
-    bool live = E.visible && !(B.flags & DB_SKIP) && min_x < max_x && min_y < max_y;
+    bool skip = (B.flags & DB_SKIP) != 0;
+    if (P.dev_bbox) {
+        // device-projection path: the batch-level box reject (rasterizer.rs:978-983, whole screen) on the
+        // box accumulated by rxr_project.hip; Rect {x, y, width = max - min, height} as batch3d.rs:762-767
+        const DevBBox bb = P.dev_bbox[lo];
+        auto dec = [](uint32_t e) { return __uint_as_float((e & 0x80000000u) ? (e ^ 0x80000000u) : ~e); };
+        float bx = dec(bb.min_x), by = dec(bb.min_y), bw = dec(bb.max_x) - bx, bh = dec(bb.max_y) - by;
+        bool keep = bx < (float)P.width && (bx + bw) > 0.0f && by < (float)P.height && (by + bh) > 0.0f;
+        skip = skip || !keep;
+    }
+    bool live = E.visible && !skip && min_x < max_x && min_y < max_y;
     if (!live) {
         S.bx = 0;
         S.by = 0;

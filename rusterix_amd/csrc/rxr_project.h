@@ -1,0 +1,62 @@
+// rxr_project.h -- data layout of the device-side projection path:
+// Batch3D::clip_and_project + Edges::new + bounding box on the GPU.  See rxr_project.hip.
+#pragma once
+#include <stdint.h>
+
+#include "../../include/rxr.h"
+
+// Output layout per mesh (capacity based, so that triangle ids keep the reference's submission order
+// without a cross-mesh compaction): vertices [vout_base, vout_base + n_verts + 4*n_tris),
+// triangles [tout_base, tout_base + 3*n_tris).  The first n_verts / n_tris slots are the originals
+// (copied by clip_and_project at batch3d.rs:566-574), the rest receives what near-plane clipping
+// appends (:627-686) -- at most 4 vertices and 2 fan triangles per clipped triangle.
+struct DevMesh {
+    uint32_t vin_base, tin_base;    // into the object-space pools
+    uint32_t n_verts, n_tris;
+    uint32_t vout_base, tout_base;  // into the projected pools (the pools k_setup3d reads)
+    uint32_t cull_mode;
+    uint32_t rejected;              // per frame: the AABB frustum test dropped the batch (:493-552)
+    float view_model[16];           // per frame: view * transform_3d (:555)
+};  // 96 B
+
+// bounding boxes are accumulated with integer atomics on an order-preserving encoding of f32
+struct DevBBox {
+    uint32_t min_x, min_y, max_x, max_y;
+};
+
+// prefix entry of the append scan: low 32 bits = vertices emitted before this triangle, high 32 bits =
+// fan triangles emitted before it (both counted over ALL meshes; per-mesh offsets subtract the value
+// at the mesh's first triangle)
+typedef unsigned long long AppendCount;
+
+#define RXR_PROJ_SCAN_CHUNK 2048u
+
+struct ProjectParams {
+    uint32_t n_meshes, n_verts_in, n_tris_in;  // totals over all meshes (object space)
+    uint32_t n_tris_out;                       // total triangle capacity (sum of 3 * n_tris)
+    float projection[16];
+    float width, height;
+
+    const DevMesh *meshes;
+    const uint32_t *vin_prefix;   // n_meshes + 1: first object-space vertex of each mesh
+    const uint32_t *tin_prefix;   // n_meshes + 1
+    const uint32_t *tout_prefix;  // n_meshes + 1 (== the raster path's batch_tri_base)
+
+    const float4 *obj_verts;
+    const uint32_t *obj_idx;      // 3 per triangle, mesh-local
+    const float2 *obj_uvs;
+    const float *obj_normals;     // 3 per vertex
+
+    float4 *view_verts;           // view space, indexed like the projected pool
+    float4 *pv;                   // projected_vertices pool (output layout)
+    float2 *uv;                   // clipped_uvs pool
+    float *nrm;                   // clipped_normals pool
+    uint32_t *idx;                // clipped_indices pool, 3 per triangle slot, mesh-local
+    rxr_edges *edges;             // Edges pool, one per triangle slot
+    uint8_t *edge_vis;            // per original triangle: edge_visibility (:582-618)
+    AppendCount *append;          // per original triangle: this triangle's (verts, tris) then, after the scan, the exclusive prefix
+    AppendCount *chunk_tot;       // scan scratch
+    AppendCount *chunk_base;
+    uint32_t *ticket;             // scan last-block ticket (cleared by the last block)
+    DevBBox *bbox;                // per mesh
+};

@@ -1,0 +1,395 @@
+// rxr_project.hip -- device-side Batch3D::clip_and_project + Edges::new + bounding box
+// (reference src/batch/batch3d.rs:482-768, src/edge.rs:12-24).
+//
+// Same exactness rules as rxr_kernels.hip: -ffp-contract=off, IEEE division, fmaf only where vek's
+// Mat4 * Vec4 fuses.  The host half that remains per frame is two Mat4 * Mat4 products and the 8-corner
+// AABB frustum test per mesh (rxr_api.hip); everything per vertex / per triangle happens here.
+//
+// Ordering: the reference appends the vertices / fan triangles created by near-plane clipping after
+// the originals, in the order of the original triangles (:627-686).  Triangle order is the tie-break
+// of the depth test, so it is reproduced exactly: k_clip_count counts what each triangle emits, an
+// exclusive scan turns the counts into append offsets, k_clip_emit writes at those offsets.
+#include <hip/hip_runtime.h>
+
+#include "rxr_project.h"
+
+#ifndef RXR_VEK_FUSED_MATVEC
+#define RXR_VEK_FUSED_MATVEC 1
+#endif
+
+namespace {
+
+__device__ __forceinline__ float madd(float a, float b, float c) {
+#if RXR_VEK_FUSED_MATVEC
+    return fmaf(a, b, c);
+#else
+    return a * b + c;
+#endif
+}
+
+// vek column-major Mat4 * Vec4 (m[c*4+r])
+__device__ __forceinline__ float4 mat4_mul(const float *m, float4 v) {
+    float4 o;
+    o.x = madd(m[12], v.w, madd(m[8], v.z, madd(m[4], v.y, m[0] * v.x)));
+    o.y = madd(m[13], v.w, madd(m[9], v.z, madd(m[5], v.y, m[1] * v.x)));
+    o.z = madd(m[14], v.w, madd(m[10], v.z, madd(m[6], v.y, m[2] * v.x)));
+    o.w = madd(m[15], v.w, madd(m[11], v.z, madd(m[7], v.y, m[3] * v.x)));
+    return o;
+}
+
+// order-preserving f32 -> u32 (so that integer atomicMin/Max implement f32 min/max)
+__device__ __forceinline__ uint32_t enc(float f) {
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// largest b in [0, n) with prefix[b] <= i  (prefix has n + 1 entries, meshes may be empty)
+__device__ __forceinline__ uint32_t find_mesh(const uint32_t *prefix, uint32_t n, uint32_t i) {
+    uint32_t lo = 0, hi = n;
+    while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (prefix[mid] <= i) lo = mid;
+        else hi = mid;
+    }
+    return lo;
+}
+
+// projection to the screen, batch3d.rs:689-700
+__device__ __forceinline__ float4 to_screen(const ProjectParams &P, float4 vs) {
+    float4 r = mat4_mul(P.projection, vs);
+    float w = r.w;
+    float4 o;
+    o.x = ((r.x / w) * 0.5f + 0.5f) * P.width;
+    o.y = ((-r.y / w) * 0.5f + 0.5f) * P.height;
+    o.z = r.z / w;
+    o.w = w;
+    return o;
+}
+
+// f32::min / f32::max drop NaN (batch3d.rs:755-760): a NaN coordinate does not contribute
+__device__ __forceinline__ void bbox_add(DevBBox *bb, float x, float y) {
+    if (x == x) {
+        atomicMin(&bb->min_x, enc(x));
+        atomicMax(&bb->max_x, enc(x));
+    }
+    if (y == y) {
+        atomicMin(&bb->min_y, enc(y));
+        atomicMax(&bb->max_y, enc(y));
+    }
+}
+
+struct Clip {
+    int nv;            // emitted vertices (0, 3 or 4)
+    bool edge_vis;     // edge_visibility[triangle] (:582-618)
+};
+
+// classification of one original triangle, batch3d.rs:586-623.  z0..z2 are view-space z.
+__device__ __forceinline__ Clip classify(const DevMesh &M, float4 v0, float4 v1, float4 v2) {
+    Clip c;
+    c.nv = 0;
+    c.edge_vis = true;
+    if (M.cull_mode != RXR_CULL_OFF) {  // :592-600 -- skips the clip step, leaves edge_visibility true
+        float orient = (v1.x - v0.x) * (v2.y - v0.y) - (v1.y - v0.y) * (v2.x - v0.x);
+        bool is_front = orient > 0.0f;
+        if (M.cull_mode == RXR_CULL_BACK && is_front) return c;
+        if (M.cull_mode == RXR_CULL_FRONT && !is_front) return c;
+    }
+    const float near_plane = 0.1f;
+    bool in0 = v0.z < -near_plane, in1 = v1.z < -near_plane, in2 = v2.z < -near_plane;
+    if (in0 && in1 && in2) return c;
+    c.edge_vis = false;
+    if (!in0 && !in1 && !in2) return c;
+    // :630-669: one vertex per inside corner plus one per edge that crosses the plane
+    c.nv = (int)in0 + (int)in1 + (int)in2 + (int)(in0 != in1) + (int)(in1 != in2) + (int)(in2 != in0);
+    return c;
+}
+
+}  // namespace
+
+// one-time (per rxr_set_meshes): originals of clipped_indices / clipped_uvs / clipped_normals
+// (batch3d.rs:566-574) at their fixed slots, appended slots zeroed
+extern "C" __global__ void __launch_bounds__(256) k_proj_static(ProjectParams P) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < P.n_verts_in) {
+        uint32_t b = find_mesh(P.vin_prefix, P.n_meshes, i);
+        const DevMesh &M = P.meshes[b];
+        uint32_t o = M.vout_base + (i - M.vin_base);
+        P.uv[o] = P.obj_uvs[i];
+        P.nrm[3 * (size_t)o + 0] = P.obj_normals[3 * (size_t)i + 0];
+        P.nrm[3 * (size_t)o + 1] = P.obj_normals[3 * (size_t)i + 1];
+        P.nrm[3 * (size_t)o + 2] = P.obj_normals[3 * (size_t)i + 2];
+    }
+    if (i < P.n_tris_in) {
+        uint32_t b = find_mesh(P.tin_prefix, P.n_meshes, i);
+        const DevMesh &M = P.meshes[b];
+        uint32_t o = M.tout_base + (i - M.tin_base);
+        P.idx[3 * (size_t)o + 0] = P.obj_idx[3 * (size_t)i + 0];
+        P.idx[3 * (size_t)o + 1] = P.obj_idx[3 * (size_t)i + 1];
+        P.idx[3 * (size_t)o + 2] = P.obj_idx[3 * (size_t)i + 2];
+    }
+}
+
+// per frame: reset the per-mesh boxes to (+inf, +inf, -inf, -inf), batch3d.rs:750-753
+extern "C" __global__ void __launch_bounds__(256) k_proj_init(ProjectParams P) {
+    uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= P.n_meshes) return;
+    DevBBox bb;
+    bb.min_x = bb.min_y = enc(INFINITY);
+    bb.max_x = bb.max_y = enc(-INFINITY);
+    P.bbox[b] = bb;
+}
+
+// per frame: view transform (:555-560) and screen projection (:689-700) of the ORIGINAL vertices
+extern "C" __global__ void __launch_bounds__(256) k_proj_vertices(ProjectParams P) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.n_verts_in) return;
+    uint32_t b = find_mesh(P.vin_prefix, P.n_meshes, i);
+    const DevMesh &M = P.meshes[b];
+    if (M.rejected) return;
+    uint32_t o = M.vout_base + (i - M.vin_base);
+    float4 vs = mat4_mul(M.view_model, P.obj_verts[i]);
+    P.view_verts[o] = vs;
+    float4 s = to_screen(P, vs);
+    P.pv[o] = s;
+    bbox_add(&P.bbox[b], s.x, s.y);
+}
+
+// per frame: what each original triangle appends (:586-681)
+extern "C" __global__ void __launch_bounds__(256) k_clip_count(ProjectParams P) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t > P.n_tris_in) return;
+    if (t == P.n_tris_in) {  // sentinel: after the scan it holds the grand total
+        P.append[t] = 0ull;
+        return;
+    }
+    uint32_t b = find_mesh(P.tin_prefix, P.n_meshes, t);
+    const DevMesh &M = P.meshes[b];
+    if (M.rejected) {
+        P.append[t] = 0ull;
+        P.edge_vis[t] = 0;
+        return;
+    }
+    const uint32_t *ix = P.obj_idx + 3 * (size_t)t;
+    float4 v0 = P.view_verts[M.vout_base + ix[0]], v1 = P.view_verts[M.vout_base + ix[1]], v2 = P.view_verts[M.vout_base + ix[2]];
+    Clip c = classify(M, v0, v1, v2);
+    P.edge_vis[t] = c.edge_vis ? 1 : 0;
+    uint32_t nt = c.nv >= 3 ? (uint32_t)(c.nv - 2) : 0u;
+    P.append[t] = (AppendCount)(uint32_t)c.nv | ((AppendCount)nt << 32);
+}
+
+// exclusive scan of P.append[0 .. n_tris_in] (n_tris_in + 1 entries) in place: chunk-local prefixes,
+// chunk bases written by the workgroup that finishes last (same scheme as k_scan in rxr_kernels.hip)
+extern "C" __global__ void __launch_bounds__(256) k_proj_scan(ProjectParams P) {
+    __shared__ AppendCount wave_tot[4];
+    __shared__ uint32_t s_last;
+    const uint32_t n = P.n_tris_in + 1u;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    constexpr uint32_t PER = RXR_PROJ_SCAN_CHUNK / 256u;
+    const uint32_t i0 = blockIdx.x * RXR_PROJ_SCAN_CHUNK + tid * PER;
+    AppendCount v[PER];
+    AppendCount sum = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < PER; ++k) {
+        uint32_t i = i0 + k;
+        v[k] = (i < n) ? P.append[i] : 0ull;
+        sum += v[k];
+    }
+    AppendCount inc = sum;
+#pragma unroll
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+        AppendCount o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) wave_tot[wave] = inc;
+    __syncthreads();
+    AppendCount wave_off = 0, total = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < 4; ++w) {
+        AppendCount wt = wave_tot[w];
+        if (w < wave) wave_off += wt;
+        total += wt;
+    }
+    AppendCount run = wave_off + (inc - sum);
+#pragma unroll
+    for (uint32_t k = 0; k < PER; ++k) {
+        uint32_t i = i0 + k;
+        if (i < n) P.append[i] = run;
+        run += v[k];
+    }
+    if (tid == 0) {
+        __hip_atomic_store(&P.chunk_tot[blockIdx.x], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        uint32_t ticket = atomicAdd(P.ticket, 1u);
+        s_last = (ticket == gridDim.x - 1u) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_last || wave != 0) return;
+    __threadfence();
+    AppendCount carry = 0;
+    for (uint32_t base = 0; base < gridDim.x; base += 64u) {
+        uint32_t c = base + lane;
+        AppendCount t = (c < gridDim.x) ? __hip_atomic_load(&P.chunk_tot[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        AppendCount ic = t;
+#pragma unroll
+        for (uint32_t d = 1; d < 64; d <<= 1) {
+            AppendCount o = __shfl_up(ic, d, 64);
+            if (lane >= d) ic += o;
+        }
+        if (c < gridDim.x) P.chunk_base[c] = carry + ic - t;
+        carry += __shfl(ic, 63, 64);
+    }
+    if (lane == 0) *P.ticket = 0u;  // ready for the next frame
+}
+
+namespace {
+__device__ __forceinline__ AppendCount prefix_at(const ProjectParams &P, uint32_t i) {
+    return P.chunk_base[i / RXR_PROJ_SCAN_CHUNK] + P.append[i];
+}
+}  // namespace
+
+// per frame: Sutherland-Hodgman against z = -0.1 for the mixed triangles, appended vertices and fan
+// triangles written at their scanned offsets (:626-686), new vertices projected (:689-700)
+extern "C" __global__ void __launch_bounds__(256) k_clip_emit(ProjectParams P) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= P.n_tris_in) return;
+    uint32_t b = find_mesh(P.tin_prefix, P.n_meshes, t);
+    const DevMesh &M = P.meshes[b];
+    if (M.rejected) return;
+    const uint32_t *ix = P.obj_idx + 3 * (size_t)t;
+    const uint32_t gi[3] = {M.vout_base + ix[0], M.vout_base + ix[1], M.vout_base + ix[2]};
+    float4 v[3] = {P.view_verts[gi[0]], P.view_verts[gi[1]], P.view_verts[gi[2]]};
+    Clip c = classify(M, v[0], v[1], v[2]);
+    if (c.nv < 3) return;
+
+    AppendCount rel = prefix_at(P, t) - prefix_at(P, M.tin_base);  // no borrow: both halves are monotone
+    uint32_t voff = (uint32_t)(rel & 0xFFFFFFFFull), toff = (uint32_t)(rel >> 32);
+    const uint32_t first_local = M.n_verts + voff;               // mesh-local index of the first emitted vertex
+    uint32_t out = M.vout_base + first_local;
+
+    const float near_plane = 0.1f;
+    int k = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int j = (i + 1) % 3;
+        const float4 cur = v[i], nxt = v[j];
+        const float2 uvc = P.uv[gi[i]], uvn = P.uv[gi[j]];
+        const float *ncp = P.nrm + 3 * (size_t)gi[i], *nnp = P.nrm + 3 * (size_t)gi[j];
+        const float nc[3] = {ncp[0], ncp[1], ncp[2]}, nn[3] = {nnp[0], nnp[1], nnp[2]};
+        if (cur.z < -near_plane) {  // :640-646
+            float4 s = to_screen(P, cur);
+            P.pv[out + k] = s;
+            P.uv[out + k] = uvc;
+            P.nrm[3 * (size_t)(out + k) + 0] = nc[0];
+            P.nrm[3 * (size_t)(out + k) + 1] = nc[1];
+            P.nrm[3 * (size_t)(out + k) + 2] = nc[2];
+            bbox_add(&P.bbox[b], s.x, s.y);
+            ++k;
+        }
+        if ((cur.z < -near_plane) != (nxt.z < -near_plane)) {  // :648-668
+            float tt = (-near_plane - cur.z) / (nxt.z - cur.z);
+            float4 isect;
+            isect.x = cur.x + tt * (nxt.x - cur.x);
+            isect.y = cur.y + tt * (nxt.y - cur.y);
+            isect.z = cur.z + tt * (nxt.z - cur.z);
+            isect.w = cur.w + tt * (nxt.w - cur.w);
+            float2 iuv;
+            iuv.x = uvc.x + tt * (uvn.x - uvc.x);
+            iuv.y = uvc.y + tt * (uvn.y - uvc.y);
+            // (n_current * (1.0 - t) + n_next * t).normalized()
+            float omt = 1.0f - tt;
+            float nx = nc[0] * omt + nn[0] * tt, ny = nc[1] * omt + nn[1] * tt, nz = nc[2] * omt + nn[2] * tt;
+            float mag = sqrtf((nx * nx + ny * ny) + nz * nz);
+            float4 s = to_screen(P, isect);
+            P.pv[out + k] = s;
+            P.uv[out + k] = iuv;
+            P.nrm[3 * (size_t)(out + k) + 0] = nx / mag;
+            P.nrm[3 * (size_t)(out + k) + 1] = ny / mag;
+            P.nrm[3 * (size_t)(out + k) + 2] = nz / mag;
+            bbox_add(&P.bbox[b], s.x, s.y);
+            ++k;
+        }
+    }
+    // fan, :672-678 (mesh-local indices, as the reference stores them)
+    uint32_t ts = M.tout_base + M.n_tris + toff;
+    for (int i = 1; i + 1 < k; ++i) {
+        P.idx[3 * (size_t)ts + 0] = first_local;
+        P.idx[3 * (size_t)ts + 1] = first_local + (uint32_t)i;
+        P.idx[3 * (size_t)ts + 2] = first_local + (uint32_t)i + 1u;
+        ++ts;
+    }
+}
+
+// per frame: Edges for every triangle slot (:706-739 + edge.rs:12-24); unused slots become invisible
+extern "C" __global__ void __launch_bounds__(256) k_proj_edges(ProjectParams P) {
+    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= P.n_tris_out) return;
+    uint32_t b = find_mesh(P.tout_prefix, P.n_meshes, s);
+    const DevMesh &M = P.meshes[b];
+    uint32_t local = s - M.tout_base;
+    rxr_edges E;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) E.a[i] = E.b[i] = E.c[i] = 0.0f;
+    E.visible = 0;
+    bool used = false, evis = true;
+    if (!M.rejected) {
+        if (local < M.n_tris) {
+            used = true;
+            evis = P.edge_vis[M.tin_base + local] != 0;
+        } else {
+            AppendCount tot = prefix_at(P, M.tin_base + M.n_tris) - prefix_at(P, M.tin_base);
+            used = (local - M.n_tris) < (uint32_t)(tot >> 32);  // appended fans: edge_visibility defaults to true (:731-732)
+        }
+    }
+    if (!used) {
+        P.edges[s] = E;
+        return;
+    }
+    const uint32_t *ix = P.idx + 3 * (size_t)s;
+    float4 v0 = P.pv[M.vout_base + ix[0]], v1 = P.pv[M.vout_base + ix[1]], v2 = P.pv[M.vout_base + ix[2]];
+    // is_front_facing, :742-746
+    bool front = ((v1.x - v0.x) * (v2.y - v0.y) - (v1.y - v0.y) * (v2.x - v0.x)) > 0.0f;
+    bool visible, swap;
+    if (M.cull_mode == RXR_CULL_OFF) {
+        swap = front;
+        visible = true;
+    } else if (M.cull_mode == RXR_CULL_FRONT) {
+        swap = false;
+        visible = !front;
+    } else {
+        swap = front;
+        visible = front;
+    }
+    if (swap) {
+        float4 tmp = v1;
+        v1 = v2;
+        v2 = tmp;
+    }
+    // Edges::new([v0,v1,v2], [v1,v2,v0]): a = y1 - y0, b = x0 - x1, c = x1*y0 - y1*x0
+    const float px[3] = {v0.x, v1.x, v2.x}, py[3] = {v0.y, v1.y, v2.y};
+    const float qx[3] = {v1.x, v2.x, v0.x}, qy[3] = {v1.y, v2.y, v0.y};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        E.a[i] = qy[i] - py[i];
+        E.b[i] = px[i] - qx[i];
+        E.c[i] = qx[i] * py[i] - qy[i] * px[i];
+    }
+    E.visible = (evis && visible) ? 1u : 0u;
+    P.edges[s] = E;
+}
+
+// ---- host-callable launchers ------------------------------------------------------------------------
+extern "C" void rxr_launch_proj_static(const ProjectParams *P, hipStream_t s) {
+    uint32_t n = P->n_verts_in > P->n_tris_in ? P->n_verts_in : P->n_tris_in;
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_proj_static, dim3((n + 255u) / 256u), dim3(256), 0, s, *P);
+}
+extern "C" void rxr_launch_project(const ProjectParams *P, hipStream_t s) {
+    if (P->n_meshes == 0) return;
+    hipLaunchKernelGGL(k_proj_init, dim3((P->n_meshes + 255u) / 256u), dim3(256), 0, s, *P);
+    if (P->n_verts_in) hipLaunchKernelGGL(k_proj_vertices, dim3((P->n_verts_in + 255u) / 256u), dim3(256), 0, s, *P);
+    uint32_t nt1 = P->n_tris_in + 1u;
+    hipLaunchKernelGGL(k_clip_count, dim3((nt1 + 255u) / 256u), dim3(256), 0, s, *P);
+    hipLaunchKernelGGL(k_proj_scan, dim3((nt1 + RXR_PROJ_SCAN_CHUNK - 1u) / RXR_PROJ_SCAN_CHUNK), dim3(256), 0, s, *P);
+    if (P->n_tris_in) hipLaunchKernelGGL(k_clip_emit, dim3((P->n_tris_in + 255u) / 256u), dim3(256), 0, s, *P);
+    if (P->n_tris_out) hipLaunchKernelGGL(k_proj_edges, dim3((P->n_tris_out + 255u) / 256u), dim3(256), 0, s, *P);
+}

@@ -1,0 +1,153 @@
+"""Batch3D::clip_and_project + Edges::new + bounding box on the device.
+
+The device-projected path must be indistinguishable from the host-projected one: the projected
+arrays read back from the GPU equal the C++ host mirror's (which the CPU tests pin bit-for-bit to the
+oracle), and the rendered frames are byte-identical -- including the lit ones, because both paths feed
+the same raster kernels."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import rusterix_amd
+from rusterix_amd import binding as B
+from rusterix_amd import scenes
+
+pytestmark = pytest.mark.gpu
+
+
+class RxrEdges(C.Structure):
+    _fields_ = [("a", C.c_float * 3), ("b", C.c_float * 3), ("c", C.c_float * 3), ("visible", C.c_uint32)]
+
+
+@pytest.fixture()
+def devproj(product):
+    lib = product.lib
+    lib.rxh_set_device_projection.argtypes = [C.c_int]
+    lib.rxh_context.restype = C.c_void_p
+    rxr = C.CDLL(rusterix_amd.lib_paths()["rxr"])
+    rxr.rxr_read_projected_mesh.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                            C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.POINTER(RxrEdges), C.POINTER(C.c_float),
+                                            C.c_uint32, C.c_uint32]
+
+    def read_mesh(index, cap_v, cap_t):
+        counts = (C.c_uint32 * 2)()
+        pv = np.zeros((cap_v, 4), np.float32)
+        uv = np.zeros((cap_v, 2), np.float32)
+        nr = np.zeros((cap_v, 3), np.float32)
+        idx = np.zeros((cap_t, 3), np.uint32)
+        ed = (RxrEdges * cap_t)()
+        bb = np.zeros(5, np.float32)
+        fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+        rc = rxr.rxr_read_projected_mesh(lib.rxh_context(), index, counts, fp(pv), fp(uv), fp(nr), idx.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                         ed, fp(bb), cap_v, cap_t)
+        assert rc == 0
+        nv, nt = counts[0], counts[1]
+        edges = np.array([[*e.a, *e.b, *e.c, float(e.visible)] for e in ed[:nt]], np.float32).reshape(nt, 10)
+        return dict(projected_vertices=pv[:nv], clipped_uvs=uv[:nv], clipped_normals=nr[:nv], clipped_indices=idx[:nt], edges=edges,
+                    bounding_box=bb)
+
+    class Ctl:
+        def on(self):
+            lib.rxh_set_device_projection(1)
+
+        def off(self):
+            lib.rxh_set_device_projection(0)
+
+        read = staticmethod(read_mesh)
+
+    ctl = Ctl()
+    yield ctl
+    ctl.off()
+
+
+SCENES = [
+    ("cube", scenes.cube_scene, dict(width=320, height=200, distance=3.0, textured=True, logo_size=64)),
+    ("cube_near_clip", scenes.cube_scene, dict(width=333, height=211, distance=0.7, textured=True, logo_size=64)),
+    ("cube_inside", scenes.cube_scene, dict(width=256, height=160, distance=0.3, textured=True, logo_size=64)),
+    ("teapot_lit", scenes.teapot_scene, dict(width=480, height=270, logo_size=64, with_light=True)),
+    ("map16", scenes.map_scene, dict(width=640, height=360, logo_size=64, n_lights=16)),
+    ("box_grid", scenes.box_grid_scene, dict(n=24, width=512, height=288)),
+]
+
+
+@pytest.mark.parametrize("name,builder,kw", SCENES, ids=[s[0] for s in SCENES])
+def test_frames_identical_to_host_projection(product, devproj, name, builder, kw):
+    devproj.off()
+    want = scenes.render(builder(product, **kw)).copy()
+    devproj.on()
+    cfg = builder(product, **kw)
+    got = scenes.render(cfg).copy()
+    assert np.array_equal(got, want), f"{name}: {(got != want).any(axis=2).sum()} pixels differ"
+    again = scenes.render(cfg)          # second frame of the same scene: meshes stay registered, only matrices travel
+    assert np.array_equal(again, want)
+
+
+@pytest.mark.parametrize("name,builder,kw", SCENES[:4] + SCENES[5:], ids=[s[0] for s in SCENES[:4] + SCENES[5:]])
+def test_projected_arrays_match_host_mirror(product, devproj, name, builder, kw):
+    # host mirror projection (bit-identical to the oracle: tests/test_host_and_abi.py)
+    devproj.off()
+    ref_cfg = builder(product, **kw)
+    ref_cfg.setup().project(ref_cfg.scene, ref_cfg.width, ref_cfg.height)
+    devproj.on()
+    cfg = builder(product, **kw)
+    scenes.render(cfg)
+    i = 0
+    while True:
+        try:
+            ref = ref_cfg.scene.projected_batch3d(B.LIST_STATIC, i)
+        except IndexError:
+            break
+        nv, nt = ref["projected_vertices"].shape[0], ref["clipped_indices"].shape[0]
+        if ref["bounding_box"][0] == 0.0:      # frustum-rejected batch: everything cleared on both sides
+            got = devproj.read(i, 8, 8)
+            assert got["bounding_box"][0] == 0.0 and got["projected_vertices"].shape[0] == 0
+        else:
+            got = devproj.read(i, nv + 16, nt + 16)
+            for key in ("projected_vertices", "clipped_uvs", "clipped_normals", "clipped_indices", "edges", "bounding_box"):
+                assert got[key].shape == ref[key].shape, (name, i, key, got[key].shape, ref[key].shape)
+                assert got[key].tobytes() == ref[key].tobytes(), (name, i, key)
+        i += 1
+    assert i > 0
+
+
+@pytest.mark.parametrize("cull", [B.CULL_OFF, B.CULL_FRONT, B.CULL_BACK])
+def test_cull_modes_and_moving_transform(product, devproj, cull):
+    def build(api, angle):
+        cam = api.D3OrbitCamera.new()
+        cam.set_parameter_f32("distance", 1.1)
+        v, p = cam.matrices(256.0, 192.0)
+        c, s = np.float32(np.cos(angle)), np.float32(np.sin(angle))
+        rot = B.Mat4.from_rows([[c, 0, s, 0.1], [0, 1, 0, -0.05], [-s, 0, c, 0.2], [0, 0, 0, 1]])
+        box = (api.Batch3D.from_box(-0.5, -0.5, -0.5, 1.0, 1.0, 1.0).cull_mode(cull).source(B.PixelSource.StaticTileIndex(0))
+               .transform(rot).with_computed_normals())
+        far = api.Batch3D.from_box(40.0, 40.0, 40.0, 1.0, 1.0, 1.0).source(B.PixelSource.Pixel((9, 9, 9, 255))).with_computed_normals()  # frustum-rejected
+        scene = api.Scene.from_static([], [box, far])
+        assets = api.Assets.default().textures([B.Tile.from_texture(scenes.brick_texture(2))])
+        return scenes._result(api, scene, assets, lambda: api.Rasterizer.setup(None, v, p).ambient((0.9, 0.9, 0.9, 1.0)), 256, 192, 40, "cull")
+
+    for angle in (0.0, 0.4, 1.3):
+        devproj.off()
+        want = scenes.render(build(product, angle)).copy()
+        devproj.on()
+        got = scenes.render(build(product, angle)).copy()
+        assert np.array_equal(got, want), (cull, angle)
+        assert (got[..., :3].max(axis=2) > 0).any()
+
+
+def test_device_projection_vs_oracle(oracle, product, devproj):
+    devproj.on()
+    kw = dict(width=400, height=240, logo_size=64, distance=0.7, textured=True)
+    got = scenes.render(scenes.cube_scene(product, **kw))
+    ref = scenes.render(scenes.cube_scene(oracle, **kw))
+    assert np.array_equal(got, ref)
+
+
+def test_missing_normals_is_an_error(product, devproj):
+    devproj.on()
+    scene = product.Scene.from_static([], [product.Batch3D.from_box(-0.5, -0.5, -0.5, 1, 1, 1)])
+    v, p = product.D3OrbitCamera.new().matrices(64.0, 64.0)
+    out = np.zeros(64 * 64 * 4, np.uint8)
+    with pytest.raises(B.RasterizeError) as e:
+        product.Rasterizer.setup(None, v, p).rasterize(scene, out, 64, 64, 16, product.Assets.default())
+    assert e.value.code == B.RXR_ERR_INVALID
