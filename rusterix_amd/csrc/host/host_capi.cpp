@@ -87,7 +87,10 @@ void rxh_batch3d_free(void *b) { delete (Batch3D *)b; }
 void rxh_batch3d_add(void *b, const float *v4, uint32_t nv, const uint32_t *idx, uint32_t nt, const float *uv2) {
     ((Batch3D *)b)->add(v4, nv, idx, nt, uv2);
 }
-void rxh_batch3d_set_normals(void *b, const float *n3, uint32_t n) { ((Batch3D *)b)->normals.assign(n3, n3 + (size_t)n * 3); }
+void rxh_batch3d_set_normals(void *b, const float *n3, uint32_t n) {
+    ((Batch3D *)b)->normals.assign(n3, n3 + (size_t)n * 3);
+    ((Batch3D *)b)->touch();
+}
 void rxh_batch3d_compute_vertex_normals(void *b) { ((Batch3D *)b)->compute_vertex_normals(); }
 void rxh_batch3d_set_source(void *b, uint32_t kind, uint32_t index, const uint8_t *pixel) { set_source(((Batch3D *)b)->source_, kind, index, pixel); }
 void rxh_batch3d_set_repeat_mode(void *b, int m) { ((Batch3D *)b)->repeat_mode_ = (uint32_t)m; }

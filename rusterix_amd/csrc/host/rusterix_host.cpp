@@ -77,6 +77,7 @@ void Batch3D::add(const float *verts4, size_t nv, const uint32_t *idx3, size_t n
     uvs.insert(uvs.end(), uvs2, uvs2 + nv * 2);
     indices.reserve(indices.size() + nt * 3);
     for (size_t i = 0; i < nt * 3; ++i) indices.push_back(idx3[i] + base_index);
+    touch();
 }
 
 Batch3D Batch3D::from_box(float x, float y, float z, float w, float h, float d) {
@@ -172,6 +173,7 @@ void Batch3D::compute_vertex_normals() {
         normals[3 * i + 1] = n.y;
         normals[3 * i + 2] = n.z;
     }
+    touch();
 }
 
 bool Batch3D::clip_and_project(const Mat4 &view_matrix, const Mat4 &projection_matrix, float viewport_width,
@@ -610,27 +612,13 @@ int Rasterizer::upload(Scene &scene, size_t w, size_t h, size_t tile_size, const
             m.chunk = chunk;
             meshes.push_back(m);
             mesh_transforms.insert(mesh_transforms.end(), b.transform_3d.m, b.transform_3d.m + 16);
-            const void *ptrs[4] = {m.vertices, m.indices, m.uvs, m.normals};
-            mix(ptrs, sizeof(ptrs));
             const uint32_t meta[12] = {m.n_vertices, m.n_triangles, m.cull_mode, m.repeat_mode, m.source.kind, m.source.index,
                                        (uint32_t)m.shader, m.has_profile_id, m.profile_id, m.list, (uint32_t)m.chunk,
                                        (uint32_t)b.normals.size()};
             mix(meta, sizeof(meta));
             mix(m.source.pixel, 4);
             mix(m.ambient_color, 12);
-            // content stamp (addresses get reused): small meshes are hashed whole, large ones sampled
-            const size_t vb = (size_t)m.n_vertices * 16, ib = (size_t)m.n_triangles * 12;
-            if (vb + ib <= (1u << 20)) {
-                mix(m.vertices, vb);
-                mix(m.indices, ib);
-                mix(m.uvs, (size_t)m.n_vertices * 8);
-                if (m.normals) mix(m.normals, (size_t)m.n_vertices * 12);
-            } else {
-                for (size_t v = 0; v < m.n_vertices; v += 1021) mix(m.vertices + 4 * v, 16);
-                for (size_t t = 0; t < m.n_triangles; t += 1021) mix(m.indices + 3 * t, 12);
-                mix(m.vertices + 4 * (size_t)(m.n_vertices - 1), 16);
-                mix(m.indices + 3 * (size_t)(m.n_triangles - 1), 12);
-            }
+            mix(&b.geometry_stamp, 8);  // geometry identity (Batch3D::touch)
             return true;
         };
         bool ok = true;

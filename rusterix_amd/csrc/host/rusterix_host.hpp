@@ -89,6 +89,10 @@ public:
     int shader_ = -1;
     bool has_profile_id = false;
     uint32_t profile_id_ = 0;
+    // geometry stamp for the device-projection cache: re-stamped by every mutator below; code that edits the
+    // public vectors directly calls touch().  Copies keep the stamp (same content).
+    uint64_t geometry_stamp = next_generation();
+    void touch() { geometry_stamp = next_generation(); }
 
     static Batch3D empty() { return Batch3D(); }
     static Batch3D make(const float *verts4, size_t nv, const uint32_t *idx3, size_t nt, const float *uvs2);  // Batch3D::new, :109-137

@@ -78,6 +78,36 @@ __device__ __forceinline__ void bbox_add(DevBBox *bb, float x, float y) {
     }
 }
 
+// Wave-cooperative form for kernels where a wave's lanes almost always belong to one mesh: reduce the
+// encoded min / max across the wave (integer min/max of the order-preserving encoding == f32 min/max,
+// NaN lanes contribute the neutral element) and let one lane issue the four atomics.  Must be called
+// by every lane of the wave; `active` marks lanes that carry a vertex of mesh `b`.
+__device__ __forceinline__ void bbox_add_wave(DevBBox *boxes, uint32_t b, bool active, float x, float y) {
+    const uint32_t b0 = __shfl(b, __ffsll((long long)__ballot(active)) - 1, 64);
+    const bool uniform = __ballot(active && b != b0) == 0ull;
+    if (!uniform) {  // a mesh boundary inside the wave: plain per-lane atomics
+        if (active) bbox_add(&boxes[b], x, y);
+        return;
+    }
+    uint32_t mnx = (active && x == x) ? enc(x) : 0xFFFFFFFFu, mxx = (active && x == x) ? enc(x) : 0u;
+    uint32_t mny = (active && y == y) ? enc(y) : 0xFFFFFFFFu, mxy = (active && y == y) ? enc(y) : 0u;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        mnx = min(mnx, (uint32_t)__shfl_xor((int)mnx, d, 64));
+        mxx = max(mxx, (uint32_t)__shfl_xor((int)mxx, d, 64));
+        mny = min(mny, (uint32_t)__shfl_xor((int)mny, d, 64));
+        mxy = max(mxy, (uint32_t)__shfl_xor((int)mxy, d, 64));
+    }
+    if ((threadIdx.x & 63u) == 0u) {
+        DevBBox *bb = &boxes[b0];
+        // neutral values mean "no finite-or-infinite coordinate seen": skip them (the box keeps +-inf)
+        if (mnx != 0xFFFFFFFFu) atomicMin(&bb->min_x, mnx);
+        if (mxx != 0u) atomicMax(&bb->max_x, mxx);
+        if (mny != 0xFFFFFFFFu) atomicMin(&bb->min_y, mny);
+        if (mxy != 0u) atomicMax(&bb->max_y, mxy);
+    }
+}
+
 struct Clip {
     int nv;            // emitted vertices (0, 3 or 4)
     bool edge_vis;     // edge_visibility[triangle] (:582-618)
@@ -142,16 +172,22 @@ extern "C" __global__ void __launch_bounds__(256) k_proj_init(ProjectParams P) {
 // per frame: view transform (:555-560) and screen projection (:689-700) of the ORIGINAL vertices
 extern "C" __global__ void __launch_bounds__(256) k_proj_vertices(ProjectParams P) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P.n_verts_in) return;
-    uint32_t b = find_mesh(P.vin_prefix, P.n_meshes, i);
-    const DevMesh &M = P.meshes[b];
-    if (M.rejected) return;
-    uint32_t o = M.vout_base + (i - M.vin_base);
-    float4 vs = mat4_mul(M.view_model, P.obj_verts[i]);
-    P.view_verts[o] = vs;
-    float4 s = to_screen(P, vs);
-    P.pv[o] = s;
-    bbox_add(&P.bbox[b], s.x, s.y);
+    bool active = i < P.n_verts_in;
+    uint32_t b = 0;
+    float4 s = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (active) {
+        b = find_mesh(P.vin_prefix, P.n_meshes, i);
+        const DevMesh &M = P.meshes[b];
+        active = !M.rejected;
+        if (active) {
+            uint32_t o = M.vout_base + (i - M.vin_base);
+            float4 vs = mat4_mul(M.view_model, P.obj_verts[i]);
+            P.view_verts[o] = vs;
+            s = to_screen(P, vs);
+            P.pv[o] = s;
+        }
+    }
+    if (__ballot(active) != 0ull) bbox_add_wave(P.bbox, b, active, s.x, s.y);  // wave-uniform call
 }
 
 // per frame: what each original triangle appends (:586-681)

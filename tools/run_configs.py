@@ -44,6 +44,8 @@ def main():
     ap.add_argument("--frames", type=int, default=30)
     ap.add_argument("--oracle", default="C2,C3,C4,C5s")
     ap.add_argument("--threads", type=int, default=0)
+    ap.add_argument("--device-projection", action="store_true",
+                    help="N1: clip_and_project + Edges on the GPU (geometry registered once, matrices per frame)")
     args = ap.parse_args()
 
     prod = rusterix_amd.load()
@@ -63,6 +65,8 @@ def main():
                     ("n_triangles2d", C.c_uint32), ("n_bin_entries", C.c_uint32), ("tiles_x", C.c_uint32), ("tiles_y", C.c_uint32)]
 
     rxr.rxr_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+    host.rxh_set_device_projection.argtypes = [C.c_int]
+    host.rxh_set_device_projection(1 if args.device_projection else 0)
 
     for name in args.configs.split(","):
         t0 = time.perf_counter()
@@ -99,7 +103,7 @@ def main():
         rxr.rxr_profile_read(ctx, su, ru, args.frames, C.byref(n))
         st = Stats()
         rxr.rxr_get_stats(ctx, C.byref(st))
-        rec = dict(config=name, scene=cfg.name, resolution=[W, H], triangles_3d=st.n_triangles3d, bin_entries=st.n_bin_entries,
+        rec = dict(config=name, scene=cfg.name, device_projection=bool(args.device_projection), resolution=[W, H], triangles_3d=st.n_triangles3d, bin_entries=st.n_bin_entries,
                    scene_build_s=round(t_build, 2), upload_ms=round(t_upload * 1e3, 2),
                    setup_kernels_us=round(float(np.median(su[: n.value])), 1), raster_kernel_us=round(float(np.median(ru[: n.value])), 1),
                    frame_ms_device_resident=round(t_loop * 1e3, 4), mpix_per_s_device_resident=round(W * H / t_loop / 1e6, 1),
