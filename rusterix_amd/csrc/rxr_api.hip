@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -87,6 +88,8 @@ struct rxr_ctx {
     uint32_t list_capacity = 0;
     uint32_t parity = 0;             // counter set of the next launch
     bool scratch_dirty = false;      // a pre-pass was queued without its raster launch
+    uint32_t small_mode = 2;         // RasterParams.fused_small for frames with <= RXR_STAGE_TRIS triangles;
+                                     // RXR_SMALL_MODE=0|1|2 overrides it (tests / A-B runs)
 
     // device-side projection (rxr_set_meshes)
     std::vector<HostMesh> meshes;
@@ -212,6 +215,9 @@ int rxr_create(rxr_ctx **out, int device_id) {
         return fail(nullptr, RXR_ERR_HIP, msg);
     }
     memset(ctx->h_counters, 0, CNT_WORDS * sizeof(uint32_t));
+    if (const char *sm = getenv("RXR_SMALL_MODE")) {
+        if (sm[0] >= '0' && sm[0] <= '2') ctx->small_mode = (uint32_t)(sm[0] - '0');
+    }
     if (hipHostGetDevicePointer((void **)&ctx->d_host_status, ctx->h_counters, 0) != hipSuccess) ctx->d_host_status = ctx->h_counters;
     *out = ctx;
     return RXR_OK;
@@ -998,7 +1004,14 @@ static int render_impl(rxr_ctx *ctx, const RenderSpec &spec, void *dev_pixels, h
     ctx->last_e1 = e1;
     ctx->last_e2 = e2;
     HIPCHK(ctx, hipEventRecord(e0, s));
-    const bool prepass = P.tiles_y && (P.flags & RXR_FLAG_D3_ACTIVE);
+    // small scenes: one staging round of k_raster holds every triangle -> no set-up / binning launches at all
+    const bool d3 = P.tiles_y && (P.flags & RXR_FLAG_D3_ACTIVE);
+    P.fused_small = (d3 && P.n_tris3d <= RXR_STAGE_TRIS) ? ctx->small_mode : 0u;
+    if (d3 && P.fused_small) {
+        if (ctx->frame_uses_meshes) rxr_launch_project(&ctx->PP, s);
+        if (P.fused_small == 2u) rxr_launch_setup(&P, s);  // records only; no counters, bins or lists are touched
+    }
+    const bool prepass = d3 && !P.fused_small;
     if (prepass && ctx->scratch_dirty) {
         // a previous launch sequence was cut short: restore the all-zero invariants explicitly
         HIPCHK(ctx, hipMemsetAsync(ctx->d_bin_count.p, 0, ctx->d_bin_count.cap, s));

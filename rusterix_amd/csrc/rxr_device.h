@@ -130,6 +130,9 @@ struct RasterParams {
 
     uint32_t n_tris3d, n_batches3d, n_lights, n_occluders, n_linedefs, n_items2d, any_lights, has_opacity;
     uint32_t list_capacity;
+    uint32_t fused_small;          // small-scene mode (whole frame <= RXR_STAGE_TRIS triangles): 0 = binned pipeline,
+                                   // 1 = fully fused (k_raster_fused builds the records itself, no pre-pass launch),
+                                   // 2 = implicit list (k_setup3d writes the records, no scan / fill / bins; default)
 
     // geometry inputs (indexed, as handed over by the host)
     const float4 *pv;              // projected_vertices

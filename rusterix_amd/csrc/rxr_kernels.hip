@@ -324,9 +324,8 @@ struct Frag {
 };
 
 // everything before the light loop: uv, world position, normal, texel, ambient terms (:1062-1370)
-__device__ __forceinline__ void shade3d_begin(const RasterParams &P, uint32_t t, uint32_t batch_id, float alpha, float beta,
+__device__ __forceinline__ void shade3d_begin(const RasterParams &P, const TriShade &S, uint32_t batch_id, float alpha, float beta,
                                               float z, float fx, float fy, Frag &F) {
-    const TriShade S = P.tri_shade[t];
     const DevBatch &B = P.batches3d[batch_id];
     float gamma = 1.0f - alpha - beta;
     float u, v;
@@ -472,8 +471,7 @@ __device__ __forceinline__ uint32_t shade3d_end(const Frag &F) {
 }
 
 // the covered-fragment block of d3_rasterize_opacity (rasterizer.rs:1497-1682, no shader)
-__device__ __forceinline__ uint32_t shade3d_opacity(const RasterParams &P, uint32_t t, uint32_t batch_id, float alpha, float beta) {
-    const TriShade S = P.tri_shade[t];
+__device__ __forceinline__ uint32_t shade3d_opacity(const RasterParams &P, const TriShade &S, uint32_t batch_id, float alpha, float beta) {
     const DevBatch &B = P.batches3d[batch_id];
     float gamma = 1.0f - alpha - beta;
     float u, v;
@@ -578,16 +576,12 @@ __device__ __forceinline__ bool bin_range(const RasterParams &P, uint32_t min_x,
     return l0 <= l1;
 }
 
-}  // namespace
-
-// =================================================================================================
-// k_setup3d: triangle set-up + bin counting.  One thread per triangle.
-// Replaces the per-tile re-derivation of per-triangle constants in rasterizer.rs:989-1017, 1054-1072.
-// =================================================================================================
-extern "C" __global__ void __launch_bounds__(256) k_setup3d(RasterParams P) {
-    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= P.n_tris3d) return;
-
+// Per-triangle set-up shared by k_setup3d and the fused small-scene path of k_raster: de-indexes the
+// batch arrays into the TriSetup / TriShade records (per-triangle constants of the reference's
+// per-fragment formulas, rasterizer.rs:989-995, 1054-1072, 1754-1767) and computes the clamped pixel
+// box (:998-1017, tile = whole width x row band).  Returns false when no pixel can be produced
+// (invisible edge, skipped batch, empty box); the records are valid either way.
+__device__ __forceinline__ bool make_setup(const RasterParams &P, uint32_t t, TriSetup &S, TriShade &H) {
     // triangle -> batch: largest b with base[b] <= t
     uint32_t lo = 0, hi = P.n_batches3d;
     while (hi - lo > 1) {
@@ -597,11 +591,10 @@ extern "C" __global__ void __launch_bounds__(256) k_setup3d(RasterParams P) {
     }
     const DevBatch B = P.batches3d[lo];
 
-    uint32_t i0 = P.idx[3 * t + 0] + B.vert_base, i1 = P.idx[3 * t + 1] + B.vert_base, i2 = P.idx[3 * t + 2] + B.vert_base;
+    uint32_t i0 = P.idx[3 * (size_t)t + 0] + B.vert_base, i1 = P.idx[3 * (size_t)t + 1] + B.vert_base, i2 = P.idx[3 * (size_t)t + 2] + B.vert_base;
     float4 v0 = P.pv[i0], v1 = P.pv[i1], v2 = P.pv[i2];
     const rxr_edges E = P.edges[t];
 
-    TriSetup S;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         S.ea[k] = E.a[k];
@@ -620,7 +613,6 @@ extern "C" __global__ void __launch_bounds__(256) k_setup3d(RasterParams P) {
     S.bflags = B.flags;
     S.profile_id = B.profile_id;
 
-    TriShade H;
     H.iw0 = 1.0f / v0.w;
     H.iw1 = 1.0f / v1.w;
     H.iw2 = 1.0f / v2.w;
@@ -639,7 +631,6 @@ extern "C" __global__ void __launch_bounds__(256) k_setup3d(RasterParams P) {
         for (int k = 0; k < 3; ++k) H.n0[k] = H.n1[k] = H.n2[k] = 0.0f;
     }
     H.pad[0] = H.pad[1] = 0;
-    P.tri_shade[t] = H;
 
     // clamped pixel box, rasterizer.rs:998-1017 with the tile replaced by (whole width) x (row band)
     float min_xf = fminf(v0.x, fminf(v1.x, v2.x)), max_xf = fmaxf(v0.x, fmaxf(v1.x, v2.x));
@@ -660,15 +651,27 @@ extern "C" __global__ void __launch_bounds__(256) k_setup3d(RasterParams P) {
         skip = skip || !keep;
     }
     bool live = E.visible && !skip && min_x < max_x && min_y < max_y;
-    if (!live) {
-        S.bx = 0;
-        S.by = 0;
-        P.tri_setup[t] = S;
-        return;
-    }
-    S.bx = min_x | (max_x << 16);
-    S.by = min_y | (max_y << 16);
+    S.bx = live ? (min_x | (max_x << 16)) : 0u;
+    S.by = live ? (min_y | (max_y << 16)) : 0u;
+    return live;
+}
+
+}  // namespace
+
+// =================================================================================================
+// k_setup3d: triangle set-up + bin counting.  One thread per triangle.
+// Replaces the per-tile re-derivation of per-triangle constants in rasterizer.rs:989-1017, 1054-1072.
+// =================================================================================================
+extern "C" __global__ void __launch_bounds__(256) k_setup3d(RasterParams P) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= P.n_tris3d) return;
+    TriSetup S;
+    TriShade H;
+    const bool live = make_setup(P, t, S, H);
+    P.tri_shade[t] = H;
     P.tri_setup[t] = S;
+    if (!live || P.fused_small) return;  // small scenes are not binned (see scan_lists, implicit list)
+    const uint32_t min_x = S.bx & 0xFFFFu, max_x = S.bx >> 16, min_y = S.by & 0xFFFFu, max_y = S.by >> 16;
 
     uint32_t bx0, bx1, by0, by1;
     if (!bin_range(P, min_x, max_x, min_y, max_y, bx0, bx1, by0, by1)) return;
@@ -788,14 +791,16 @@ namespace {
 
 struct Vis {
     float zmin;
-    int best;  // global triangle id of the winner, -1 = none
+    int best;        // global triangle id of the winner, -1 = none
     float alpha, beta;
+    uint32_t slot;   // staged slot of the winner (fused small-scene path: its TriShade lives in LDS)
+    uint32_t batch;  // batch of the winner
 };
 
 // one candidate triangle against this lane's pixel (rasterizer.rs:1020-1060 + the :1408 alpha rule)
 template <bool OPACITY>
-__device__ __forceinline__ void visit(const RasterParams &P, const TriSetup &S, uint32_t t, uint32_t px, uint32_t py, float fx,
-                                      float fy, Vis &vis, int surf_profile) {
+__device__ __forceinline__ void visit(const RasterParams &P, const TriSetup &S, const TriShade *shade, uint32_t t, uint32_t slot,
+                                      uint32_t px, uint32_t py, float fx, float fy, Vis &vis, int surf_profile) {
     uint32_t min_x = S.bx & 0xFFFFu, max_x = S.bx >> 16, min_y = S.by & 0xFFFFu, max_y = S.by >> 16;
     bool in = px >= min_x && px < max_x && py >= min_y && py < max_y;
     // Edges::evaluate (edge.rs:28-36): reject iff a*px + b*py + c < 0 (NaN passes)
@@ -825,7 +830,7 @@ __device__ __forceinline__ void visit(const RasterParams &P, const TriSetup &S, 
     if (!OPACITY && (S.bflags & DB_ALPHA_TEST)) {
         // the fragment is only written when its encoded alpha is 255 (:1408): sample it now
         const DevBatch &B = P.batches3d[S.batch];
-        const TriShade H = P.tri_shade[t];
+        const TriShade H = *shade;
         float u, v;
         fragment_uv(H, alpha, beta, gamma, u, v);
         uint32_t texel = batch_texel(P, B, u, v);
@@ -835,6 +840,25 @@ __device__ __forceinline__ void visit(const RasterParams &P, const TriSetup &S, 
     vis.best = (int)t;
     vis.alpha = alpha;
     vis.beta = beta;
+    vis.slot = slot;
+    vis.batch = S.batch;
+}
+
+// Exact trivial reject of a triangle for a whole tile: Edges::evaluate computes r = (a*x + b*y) + c per
+// pixel centre and rejects r < 0.  Rounded multiplication and addition are monotone, so over the tile's
+// pixel centres r is largest at the corner that maximises a*x and b*y separately; if even that corner
+// is rejected, every pixel of the tile is.  (NaN coefficients compare false and never reject.)
+__device__ __forceinline__ bool tile_outside_edges(const float *ea, const float *eb, const float *ec, uint32_t tile_x0, uint32_t tile_y0px) {
+    const float x_lo = (float)tile_x0 + 0.5f, x_hi = (float)(tile_x0 + RXR_TILE_W - 1u) + 0.5f;
+    const float y_lo = (float)tile_y0px + 0.5f, y_hi = (float)(tile_y0px + RXR_TILE_H - 1u) + 0.5f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float xm = ea[i] >= 0.0f ? x_hi : x_lo;
+        const float ym = eb[i] >= 0.0f ? y_hi : y_lo;
+        const float r = ea[i] * xm + eb[i] * ym + ec[i];
+        if (r < 0.0f) return true;
+    }
+    return false;
 }
 
 // LDS staging area of one workgroup: candidate triangle records of the current round
@@ -842,6 +866,7 @@ struct Stage {
     float4 tri[RXR_STAGE_TRIS * 6];  // TriSetup records, 6 x 16 B each
     uint32_t ids[RXR_STAGE_TRIS];
     uint32_t wave_cnt[RXR_TILE_THREADS / 64];
+    TriShade shade[RXR_STAGE_TRIS];  // fused small-scene path only: shading records of the staged triangles
 };
 
 // Visibility pass over the tile's candidate triangles = [large-triangle list, filtered against the
@@ -857,7 +882,9 @@ __device__ __forceinline__ void scan_lists(const RasterParams &P, Stage &st, uin
                                            uint32_t tile_y0px, uint32_t px, uint32_t py, float fx, float fy, Vis &vis,
                                            int surf_profile) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t n_large = min(P.counters[CNT_LARGE], P.n_tris3d);
+    // small_mode 2 ("implicit list"): every triangle of the frame is a candidate, ids 0..n-1, no counters / lists
+    const bool implicit = P.fused_small == 2u;
+    const uint32_t n_large = implicit ? P.n_tris3d : min(P.counters[CNT_LARGE], P.n_tris3d);
     const uint32_t total = n_large + (b1 - b0);
     const float4 *g4 = reinterpret_cast<const float4 *>(P.tri_setup);
     for (uint32_t base = 0; base < total; base += RXR_STAGE_TRIS) {
@@ -867,7 +894,7 @@ __device__ __forceinline__ void scan_lists(const RasterParams &P, Stage &st, uin
         const uint32_t e = base + tid;
         if (tid < RXR_STAGE_TRIS && e < total) {
             if (e < n_large) {
-                id = min(P.large_list[e], P.n_tris3d - 1u);
+                id = implicit ? e : min(P.large_list[e], P.n_tris3d - 1u);
                 const uint2 box = *reinterpret_cast<const uint2 *>(&P.tri_setup[id].bx);
                 uint32_t min_x = box.x & 0xFFFFu, max_x = box.x >> 16, min_y = box.y & 0xFFFFu, max_y = box.y >> 16;
                 keep = !(min_x >= tile_x0 + RXR_TILE_W || max_x <= tile_x0 || min_y >= tile_y0px + RXR_TILE_H || max_y <= tile_y0px);
@@ -879,6 +906,10 @@ __device__ __forceinline__ void scan_lists(const RasterParams &P, Stage &st, uin
             if (id >= P.n_tris3d) {
                 keep = false;
                 id = 0;
+            }
+            if (keep) {
+                const TriSetup &R = P.tri_setup[id];
+                if (tile_outside_edges(R.ea, R.eb, R.ec, tile_x0, tile_y0px)) keep = false;
             }
         }
         // 2. compaction
@@ -904,10 +935,54 @@ __device__ __forceinline__ void scan_lists(const RasterParams &P, Stage &st, uin
         // 4. walk
         for (uint32_t k = 0; k < n; ++k) {
             const TriSetup &S = *reinterpret_cast<const TriSetup *>(&st.tri[k * 6u]);
-            visit<OPACITY>(P, S, st.ids[k], px, py, fx, fy, vis, surf_profile);
+            const uint32_t t = st.ids[k];
+            visit<OPACITY>(P, S, &P.tri_shade[t], t, k, px, py, fx, fy, vis, surf_profile);
         }
         __syncthreads();  // the stage is reused by the next round
     }
+}
+
+// Fused small-scene path (P.fused_small: the whole frame has <= RXR_STAGE_TRIS triangles, so one
+// staging round holds them all): no k_setup3d / k_scan / k_fill launches and no records in HBM --
+// thread t builds triangle t's TriSetup / TriShade itself (make_setup), tests its pixel box against
+// the tile, survivors are ballot-compacted straight into LDS, then every lane walks them.
+template <bool OPACITY>
+__device__ __forceinline__ void scan_fused(const RasterParams &P, Stage &st, uint32_t tile_x0, uint32_t tile_y0px, uint32_t px,
+                                           uint32_t py, float fx, float fy, Vis &vis, int surf_profile) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    bool keep = false;
+    TriSetup S;
+    TriShade H;
+    if (tid < RXR_STAGE_TRIS && tid < P.n_tris3d) {
+        if (make_setup(P, tid, S, H)) {
+            uint32_t min_x = S.bx & 0xFFFFu, max_x = S.bx >> 16, min_y = S.by & 0xFFFFu, max_y = S.by >> 16;
+            keep = !(min_x >= tile_x0 + RXR_TILE_W || max_x <= tile_x0 || min_y >= tile_y0px + RXR_TILE_H || max_y <= tile_y0px);
+            if (keep && tile_outside_edges(S.ea, S.eb, S.ec, tile_x0, tile_y0px)) keep = false;
+        }
+    }
+    const unsigned long long m = __ballot(keep);
+    const uint32_t before = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) st.wave_cnt[wave] = (uint32_t)__popcll(m);
+    __syncthreads();
+    uint32_t off = 0, n = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < RXR_TILE_THREADS / 64; ++w) {
+        uint32_t c = st.wave_cnt[w];
+        if (w < wave) off += c;
+        n += c;
+    }
+    if (keep) {
+        const uint32_t slot = off + before;
+        st.ids[slot] = tid;
+        *reinterpret_cast<TriSetup *>(&st.tri[slot * 6u]) = S;
+        st.shade[slot] = H;
+    }
+    __syncthreads();
+    for (uint32_t k = 0; k < n; ++k) {
+        const TriSetup &SK = *reinterpret_cast<const TriSetup *>(&st.tri[k * 6u]);
+        visit<OPACITY>(P, SK, &st.shade[k], st.ids[k], k, px, py, fx, fy, vis, surf_profile);
+    }
+    __syncthreads();  // a second pass (opacity, then opaque) rebuilds the stage
 }
 
 // Bresenham walk of one segment (rasterizer.rs:1777-1821): does the walk plot pixel (px,py)?
@@ -944,7 +1019,8 @@ __device__ __forceinline__ bool bresenham_hits(const Line2D &Ln, int px, int py)
 #define RXR_WAVE_8X8 0
 #endif
 
-extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_RASTER_WAVES_PER_SIMD) k_raster(RasterParams P) {
+template <bool FUSED>
+__device__ __forceinline__ void raster_tile(const RasterParams &P) {
     const uint32_t bin = blockIdx.x;
     const uint32_t tx = bin % P.tiles_x, ty = bin / P.tiles_x;
     const uint32_t tid = threadIdx.x;
@@ -974,42 +1050,60 @@ extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_RASTER_WAVES_
     }
 
     if (P.flags & RXR_FLAG_D3_ACTIVE) {
-        // this tile's bin list; the bin count is handed back zeroed for the next launch
         __shared__ uint32_t s_bin[2];
         __shared__ Stage stage;
-        if (tid == 0) {
-            uint32_t cnt = P.bin_count[bin];
-            uint32_t start = P.chunk_base[bin / RXR_SCAN_CHUNK] + P.bin_offset[bin];
-            s_bin[0] = min(start, P.list_capacity);
-            s_bin[1] = min(start + cnt, P.list_capacity);  // on overflow the frame is re-rendered (rxr_synchronize)
-            if (cnt) P.bin_count[bin] = 0u;
+        constexpr bool fused = FUSED;
+        uint32_t b0 = 0, b1 = 0;
+        if (!fused && P.fused_small == 0u) {
+            // this tile's bin list; the bin count is handed back zeroed for the next launch
+            if (tid == 0) {
+                uint32_t cnt = P.bin_count[bin];
+                uint32_t start = P.chunk_base[bin / RXR_SCAN_CHUNK] + P.bin_offset[bin];
+                s_bin[0] = min(start, P.list_capacity);
+                s_bin[1] = min(start + cnt, P.list_capacity);  // on overflow the frame is re-rendered (rxr_synchronize)
+                if (cnt) P.bin_count[bin] = 0u;
+            }
+            __syncthreads();
+            b0 = s_bin[0];
+            b1 = s_bin[1];
         }
-        __syncthreads();
-        const uint32_t b0 = s_bin[0], b1 = s_bin[1];
         int surf_profile = -1;
         Vis op;
-        op.zmin = 1.0f; op.best = -1; op.alpha = 0.0f; op.beta = 0.0f;
+        op.zmin = 1.0f; op.best = -1; op.alpha = 0.0f; op.beta = 0.0f; op.slot = 0; op.batch = 0;
+        uint32_t op_color = 0u;  // the opacity winner is shaded at once: the opaque pass rebuilds the stage
         if (P.has_opacity) {
-            scan_lists<true>(P, stage, b0, b1, tile_x0, tile_y0px, px, py, fx, fy, op, -1);
+            if (fused) scan_fused<true>(P, stage, tile_x0, tile_y0px, px, py, fx, fy, op, -1);
+            else scan_lists<true>(P, stage, b0, b1, tile_x0, tile_y0px, px, py, fx, fy, op, -1);
             if (op.best >= 0) {
-                const DevBatch &OB = P.batches3d[P.tri_setup[op.best].batch];
+                const DevBatch &OB = P.batches3d[op.batch];
                 surf_profile = (OB.flags & DB_HAS_PROFILE) ? (int)OB.profile_id : -1;
+                TriShade OS;
+                if (fused) OS = stage.shade[op.slot];
+                else OS = P.tri_shade[op.best];
+                op_color = shade3d_opacity(P, OS, op.batch, op.alpha, op.beta);
             }
+            __syncthreads();  // everyone has copied its record before the stage is rebuilt
         }
         Vis vis;
-        vis.zmin = 1.0f; vis.best = -1; vis.alpha = 0.0f; vis.beta = 0.0f;
-        scan_lists<false>(P, stage, b0, b1, tile_x0, tile_y0px, px, py, fx, fy, vis, surf_profile);
+        vis.zmin = 1.0f; vis.best = -1; vis.alpha = 0.0f; vis.beta = 0.0f; vis.slot = 0; vis.batch = 0;
+        if (fused) scan_fused<false>(P, stage, tile_x0, tile_y0px, px, py, fx, fy, vis, surf_profile);
+        else scan_lists<false>(P, stage, b0, b1, tile_x0, tile_y0px, px, py, fx, fy, vis, surf_profile);
 
         // resolve (rasterizer.rs:409-497): hit -> shaded colour; miss -> [0,0,0,255]
         const bool hit = vis.best >= 0;
         Frag F;
         F.world = F.normal = F.view_dir = F.base = F.lit = mk3(0.0f, 0.0f, 0.0f);
         F.opacity = 0.0f;
-        if (hit) shade3d_begin(P, (uint32_t)vis.best, P.tri_setup[vis.best].batch, vis.alpha, vis.beta, vis.zmin, fx, fy, F);
+        if (hit) {
+            TriShade HS;
+            if (fused) HS = stage.shade[vis.slot];
+            else HS = P.tri_shade[vis.best];
+            shade3d_begin(P, HS, vis.batch, vis.alpha, vis.beta, vis.zmin, fx, fy, F);
+        }
         if (P.n_lights) shade3d_lights(P, hit, F);  // wave-uniform call
         color = hit ? shade3d_end(F) : pack4(0u, 0u, 0u, 255u);
         if (op.best >= 0 && op.zmin < 1.0f && vis.zmin > op.zmin) {  // :464-495
-            uint32_t src = shade3d_opacity(P, (uint32_t)op.best, P.tri_setup[op.best].batch, op.alpha, op.beta);
+            uint32_t src = op_color;
             float src_r = (float)(src & 0xFFu), src_g = (float)((src >> 8) & 0xFFu), src_b = (float)((src >> 16) & 0xFFu);
             float src_a = (float)(src >> 24) / 255.0f;
             float dst_r = (float)(color & 0xFFu), dst_g = (float)((color >> 8) & 0xFFu), dst_b = (float)((color >> 16) & 0xFFu);
@@ -1065,6 +1159,10 @@ extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_RASTER_WAVES_
     }
 }
 
+// two instantiations so that each path gets its own register allocation
+extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_RASTER_WAVES_PER_SIMD) k_raster(RasterParams P) { raster_tile<false>(P); }
+extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_RASTER_WAVES_PER_SIMD) k_raster_fused(RasterParams P) { raster_tile<true>(P); }
+
 // ---- host-callable launchers (used by rxr_api.hip) ------------------------------------------------
 extern "C" void rxr_launch_setup(const RasterParams *P, hipStream_t s) {
     if (P->n_tris3d == 0) return;
@@ -1085,5 +1183,6 @@ extern "C" void rxr_launch_fill(const RasterParams *P, hipStream_t s) {
 extern "C" void rxr_launch_raster(const RasterParams *P, hipStream_t s) {
     uint32_t tiles = P->tiles_x * P->tiles_y;
     if (tiles == 0) return;
-    hipLaunchKernelGGL(k_raster, dim3(tiles), dim3(RXR_TILE_THREADS), 0, s, *P);
+    if (P->fused_small == 1u) hipLaunchKernelGGL(k_raster_fused, dim3(tiles), dim3(RXR_TILE_THREADS), 0, s, *P);
+    else hipLaunchKernelGGL(k_raster, dim3(tiles), dim3(RXR_TILE_THREADS), 0, s, *P);
 }
