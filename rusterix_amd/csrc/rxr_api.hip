@@ -23,7 +23,9 @@
 extern "C" void rxr_launch_proj_static(const ProjectParams *P, hipStream_t s);
 extern "C" void rxr_launch_project(const ProjectParams *P, hipStream_t s);
 extern "C" void rxr_launch_setup(const RasterParams *P, hipStream_t s);
-extern "C" void rxr_launch_scan(const RasterParams *P, hipStream_t s);
+extern "C" void rxr_launch_scan(const ScanArgs *A, hipStream_t s);
+extern "C" void rxr_launch_bin2d_count(const RasterParams *P, hipStream_t s);
+extern "C" void rxr_launch_bin2d_fill(const RasterParams *P, hipStream_t s);
 extern "C" void rxr_launch_fill(const RasterParams *P, hipStream_t s);
 extern "C" void rxr_launch_raster(const RasterParams *P, hipStream_t s);
 
@@ -83,11 +85,14 @@ struct rxr_ctx {
     size_t h_stage_cap = 0;
     DevBuf d_frame;
     DevBuf d_tri_setup, d_tri_shade, d_bin_count, d_bins, d_list, d_large, d_counters, d_fb;
+    DevBuf d_bin2d_count, d_bins2d, d_list2d, d_large2d;
+    uint32_t list2d_capacity = 0, parity2d = 0;
     uint32_t *h_counters = nullptr;  // pinned, CNT_WORDS; written by k_scan through d_host_status
     uint32_t *d_host_status = nullptr;
     uint32_t list_capacity = 0;
     uint32_t parity = 0;             // counter set of the next launch
     bool scratch_dirty = false;      // a pre-pass was queued without its raster launch
+    bool scratch2d_dirty = false;
     uint32_t small_mode = 2;         // RasterParams.fused_small for frames with <= RXR_STAGE_TRIS triangles;
                                      // RXR_SMALL_MODE=0|1|2 overrides it (tests / A-B runs)
 
@@ -179,7 +184,7 @@ bool to_isize32(float x, int32_t &out) {
 
 struct Layout {
     size_t off_b3, off_base, off_pv, off_uv, off_nrm, off_idx, off_edges, off_lights, off_occ, off_ld, off_chunks, off_b2,
-        off_t2, off_l2, off_items, off_bg, total;
+        off_p2, off_bg, total;
 };
 
 }  // namespace
@@ -208,13 +213,13 @@ int rxr_create(rxr_ctx **out, int device_id) {
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev2);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev_upload);
-    if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_counters, CNT_WORDS * sizeof(uint32_t), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_counters, 2 * CNT_WORDS * sizeof(uint32_t), hipHostMallocDefault);
     if (e != hipSuccess) {
         std::string msg = std::string("rxr_create: ") + hipGetErrorString(e);
         delete ctx;
         return fail(nullptr, RXR_ERR_HIP, msg);
     }
-    memset(ctx->h_counters, 0, CNT_WORDS * sizeof(uint32_t));
+    memset(ctx->h_counters, 0, 2 * CNT_WORDS * sizeof(uint32_t));
     if (const char *sm = getenv("RXR_SMALL_MODE")) {
         if (sm[0] >= '0' && sm[0] <= '2') ctx->small_mode = (uint32_t)(sm[0] - '0');
     }
@@ -227,7 +232,8 @@ void rxr_destroy(rxr_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    DevBuf *bufs[] = {&ctx->d_obj, &ctx->d_proj_out, &ctx->d_proj_misc, &ctx->d_tex, &ctx->d_texels, &ctx->d_frame, &ctx->d_tri_setup, &ctx->d_tri_shade, &ctx->d_bin_count, &ctx->d_bins,
+    DevBuf *bufs[] = {&ctx->d_obj, &ctx->d_proj_out, &ctx->d_proj_misc, &ctx->d_tex, &ctx->d_texels, &ctx->d_frame, &ctx->d_tri_setup, &ctx->d_tri_shade, &ctx->d_bin_count, &ctx->d_bins, &ctx->d_bin2d_count, &ctx->d_bins2d,
+                      &ctx->d_list2d, &ctx->d_large2d,
                       &ctx->d_list, &ctx->d_large, &ctx->d_counters, &ctx->d_fb};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
@@ -626,9 +632,8 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
     L.off_ld = take(f->n_linedefs * sizeof(rxr_linedef));
     L.off_chunks = take(f->n_chunks * sizeof(ChunkRange));
     L.off_b2 = take(f->n_batches2d * sizeof(DevBatch));
-    L.off_t2 = take(n_t2 * sizeof(Tri2D));
-    L.off_l2 = take(n_l2 * sizeof(Line2D));
-    L.off_items = take(n_items * sizeof(Item2D));
+    L.off_p2 = take((n_t2 + n_l2) * sizeof(Prim2D));
+    (void)n_items;
     L.off_bg = take(f->background_kind == RXR_BG_HOST_PIXELS ? (size_t)f->width * f->height * 4 : 0);
     L.total = o;
 
@@ -775,10 +780,14 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
     if (f->n_linedefs) memcpy(st + L.off_ld, f->linedefs, f->n_linedefs * sizeof(rxr_linedef));
 
     DevBatch *b2 = (DevBatch *)(st + L.off_b2);
-    Tri2D *t2 = (Tri2D *)(st + L.off_t2);
-    Line2D *l2 = (Line2D *)(st + L.off_l2);
-    Item2D *items = (Item2D *)(st + L.off_items);
-    size_t t2cur = 0, l2cur = 0, icur = 0;
+    Prim2D *p2 = (Prim2D *)(st + L.off_p2);
+    size_t p2cur = 0, t2cur = 0;
+    // `x as usize` after the clamp against the screen, as the device's sat_index (rasterizer.rs:631-634)
+    auto sat_px = [](float x, uint32_t hi) -> uint32_t {
+        if (!(x > 0.0f)) return 0u;
+        if (x >= (float)hi) return hi;
+        return (uint32_t)x;
+    };
     for (uint32_t i = 0; i < f->n_batches2d; ++i) {
         const rxr_batch2d &b = f->batches2d[i];
         DevBatch d{};
@@ -803,15 +812,11 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
         }
         b2[i] = d;
         if (!keep) continue;
-        Item2D it{};
-        it.batch = i;
         if (b.mode == RXR_MODE_TRIANGLES) {
-            it.first = (uint32_t)t2cur;
-            it.is_lines = 0;
             for (uint32_t t = 0; t < b.n_triangles; ++t) {
                 const uint32_t *ix = b.indices + 3 * (size_t)t;
                 const rxr_edges &e = b.edges[t];
-                Tri2D T{};
+                Prim2D T{};
                 memcpy(T.ea, e.a, 12);
                 memcpy(T.eb, e.b, 12);
                 memcpy(T.ec, e.c, 12);
@@ -821,28 +826,45 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
                 T.u0 = b.uvs[2 * ix[0]]; T.v0 = b.uvs[2 * ix[0] + 1];
                 T.u1 = b.uvs[2 * ix[1]]; T.v1 = b.uvs[2 * ix[1] + 1];
                 T.u2 = b.uvs[2 * ix[2]]; T.v2 = b.uvs[2 * ix[2] + 1];
-                T.batch = i;
-                T.visible = e.visible;
-                t2[t2cur++] = T;
+                T.batch_kind = (i << 2) | (e.visible ? 1u : 0u);
+                // clamped pixel box of the triangle, rasterizer.rs:615-634 with tile = whole screen
+                float min_xf = std::fmin(T.v0x, std::fmin(T.v1x, T.v2x)), max_xf = std::fmax(T.v0x, std::fmax(T.v1x, T.v2x));
+                float min_yf = std::fmin(T.v0y, std::fmin(T.v1y, T.v2y)), max_yf = std::fmax(T.v0y, std::fmax(T.v1y, T.v2y));
+                uint32_t min_x = sat_px(std::fmax(std::floor(min_xf), 0.0f), 0xFFFFu), max_x = sat_px(std::fmin(std::ceil(max_xf), W), 0xFFFFu);
+                uint32_t min_y = sat_px(std::fmax(std::floor(min_yf), 0.0f), 0xFFFFu), max_y = sat_px(std::fmin(std::ceil(max_yf), H), 0xFFFFu);
+                if (!(min_x < max_x && min_y < max_y) || !e.visible) min_x = max_x = min_y = max_y = 0;
+                T.bx = min_x | (max_x << 16);
+                T.by = min_y | (max_y << 16);
+                p2[p2cur++] = T;
+                ++t2cur;
             }
-            it.count = b.n_triangles;
         } else {
-            it.first = (uint32_t)l2cur;
-            it.is_lines = 1;
             const uint8_t white[4] = {255, 255, 255, 255};
             uint32_t color = pack_px(b.source.kind == RXR_SOURCE_PIXEL ? b.source.pixel : white);  // :911-915
             auto push = [&](uint32_t ia, uint32_t ib) -> bool {
-                Line2D Ln{};
-                if (!to_isize32(b.projected_vertices[2 * ia], Ln.x0) || !to_isize32(b.projected_vertices[2 * ia + 1], Ln.y0) ||
-                    !to_isize32(b.projected_vertices[2 * ib], Ln.x1) || !to_isize32(b.projected_vertices[2 * ib + 1], Ln.y1))
+                int32_t x0, y0, x1, y1;
+                if (!to_isize32(b.projected_vertices[2 * ia], x0) || !to_isize32(b.projected_vertices[2 * ia + 1], y0) ||
+                    !to_isize32(b.projected_vertices[2 * ib], x1) || !to_isize32(b.projected_vertices[2 * ib + 1], y1))
                     return false;
-                Ln.batch = i;
-                Ln.color = color;
-                l2[l2cur++] = Ln;
+                Prim2D Ln{};
+                memcpy(&Ln.v0x, &x0, 4);
+                memcpy(&Ln.v0y, &y0, 4);
+                memcpy(&Ln.v1x, &x1, 4);
+                memcpy(&Ln.v1y, &y1, 4);
+                memcpy(&Ln.v2x, &color, 4);
+                Ln.batch_kind = (i << 2) | 2u | 1u;
+                // the walk never leaves the end-point box (the last point is not plotted, :1800)
+                int64_t lx0 = std::min(x0, x1), lx1 = (int64_t)std::max(x0, x1) + 1, ly0 = std::min(y0, y1), ly1 = (int64_t)std::max(y0, y1) + 1;
+                auto cl = [](int64_t v, int64_t hi) { return (uint32_t)std::min<int64_t>(std::max<int64_t>(v, 0), hi); };
+                uint32_t min_x = cl(lx0, (int64_t)f->width), max_x = cl(lx1, (int64_t)f->width);
+                uint32_t min_y = cl(ly0, (int64_t)f->height), max_y = cl(ly1, (int64_t)f->height);
+                if (!(min_x < max_x && min_y < max_y)) min_x = max_x = min_y = max_y = 0;
+                Ln.bx = min_x | (max_x << 16);
+                Ln.by = min_y | (max_y << 16);
+                p2[p2cur++] = Ln;
                 return true;
             };
             bool ok = true;
-            uint32_t before = (uint32_t)l2cur;
             if (b.mode == RXR_MODE_LINES) {
                 for (uint32_t t = 0; t < b.n_triangles && ok; ++t) ok = push(b.indices[3 * (size_t)t], b.indices[3 * (size_t)t + 1]);
             } else if (b.mode == RXR_MODE_LINE_STRIP) {
@@ -851,9 +873,7 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
                 for (uint32_t k = 0; k < b.n_vertices && ok; ++k) ok = push(k, (k + 1) % b.n_vertices);
             }
             if (!ok) return fail(ctx, RXR_ERR_UNSUPPORTED, "batch2d: line end point beyond +-2^30");
-            it.count = (uint32_t)l2cur - before;
         }
-        items[icur++] = it;
     }
     if (f->background_kind == RXR_BG_HOST_PIXELS) memcpy(st + L.off_bg, f->background_pixels, (size_t)f->width * f->height * 4);
 
@@ -872,9 +892,23 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
     }
     if ((rc = ensure(ctx, ctx->d_bins, (2 * (n_bins + 1) + 2 * n_chunks + 8) * sizeof(uint32_t))) != RXR_OK) return rc;
     if ((rc = ensure(ctx, ctx->d_large, (n_t3 ? n_t3 : 1) * sizeof(uint32_t))) != RXR_OK) return rc;
+    // 2D binning scratch (used only when the frame has more than RXR_STAGE_TRIS 2D primitives)
+    const bool binned2d = p2cur > RXR_STAGE_TRIS;
+    if (binned2d) {
+        void *before = ctx->d_bin2d_count.p;
+        if ((rc = ensure(ctx, ctx->d_bin2d_count, (n_bins + 1) * sizeof(uint32_t))) != RXR_OK) return rc;
+        if (ctx->d_bin2d_count.p != before) HIPCHK(ctx, hipMemsetAsync(ctx->d_bin2d_count.p, 0, ctx->d_bin2d_count.cap, ctx->stream));
+        if ((rc = ensure(ctx, ctx->d_bins2d, (2 * (n_bins + 1) + 2 * n_chunks + 8) * sizeof(uint32_t))) != RXR_OK) return rc;
+        if ((rc = ensure(ctx, ctx->d_large2d, p2cur * sizeof(uint32_t))) != RXR_OK) return rc;
+        size_t want2d = std::max<size_t>(1u << 18, p2cur * 8);
+        if (want2d > ctx->list2d_capacity) {
+            if ((rc = ensure(ctx, ctx->d_list2d, want2d * sizeof(uint32_t))) != RXR_OK) return rc;
+            ctx->list2d_capacity = (uint32_t)std::min<size_t>(ctx->d_list2d.cap / sizeof(uint32_t), 0xFFFFFFF0u);
+        }
+    }
     {
         void *before = ctx->d_counters.p;
-        if ((rc = ensure(ctx, ctx->d_counters, 2 * CNT_WORDS * sizeof(uint32_t))) != RXR_OK) return rc;
+        if ((rc = ensure(ctx, ctx->d_counters, 4 * CNT_WORDS * sizeof(uint32_t))) != RXR_OK) return rc;  // 2 sets for 3D, 2 for 2D
         if (ctx->d_counters.p != before) HIPCHK(ctx, hipMemsetAsync(ctx->d_counters.p, 0, ctx->d_counters.cap, ctx->stream));
     }
     size_t want_list = std::max<size_t>(1u << 20, n_t3 * 4);
@@ -912,7 +946,9 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
     P.n_lights = f->n_lights;
     P.n_occluders = f->n_occluders;
     P.n_linedefs = f->n_linedefs;
-    P.n_items2d = (uint32_t)icur;
+    P.n_prims2d = (uint32_t)p2cur;
+    P.binned2d = binned2d ? 1u : 0u;
+    P.list2d_capacity = ctx->list2d_capacity;
     P.any_lights = f->n_lights ? 1u : 0u;
     P.has_opacity = has_opacity ? 1u : 0u;
     P.list_capacity = ctx->list_capacity;
@@ -940,9 +976,17 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
     P.linedefs = (const rxr_linedef *)(d + L.off_ld);
     P.chunks = (const ChunkRange *)(d + L.off_chunks);
     P.batches2d = (const DevBatch *)(d + L.off_b2);
-    P.tri2d = (const Tri2D *)(d + L.off_t2);
-    P.line2d = (const Line2D *)(d + L.off_l2);
-    P.items2d = (const Item2D *)(d + L.off_items);
+    P.prim2d = (const Prim2D *)(d + L.off_p2);
+    if (binned2d) {
+        P.bin2d_count = (uint32_t *)ctx->d_bin2d_count.p;
+        P.bin2d_offset = (uint32_t *)ctx->d_bins2d.p;
+        P.bin2d_cursor = P.bin2d_offset + n_bins + 1;
+        P.chunk2d_tot = P.bin2d_cursor + n_bins + 1;
+        P.chunk2d_base = P.chunk2d_tot + n_chunks;
+        P.bin2d_list = (uint32_t *)ctx->d_list2d.p;
+        P.large2d_list = (uint32_t *)ctx->d_large2d.p;
+        P.host_status2d = ctx->d_host_status + CNT_WORDS;
+    }
     P.tex = (const DevTexDesc *)ctx->d_tex.p;
     P.texels = (const uint32_t *)ctx->d_texels.p;
     P.bg_pixels = (const uint32_t *)(d + L.off_bg);
@@ -1026,18 +1070,59 @@ static int render_impl(rxr_ctx *ctx, const RenderSpec &spec, void *dev_pixels, h
         ctx->parity ^= 1u;
         if (ctx->frame_uses_meshes) rxr_launch_project(&ctx->PP, s);  // clip_and_project + Edges + boxes on the device
         rxr_launch_setup(&P, s);
-        rxr_launch_scan(&P, s);
+        ScanArgs A{};
+        A.n = P.tiles_x * P.tiles_y;
+        A.list_capacity = P.list_capacity;
+        A.count = P.bin_count;
+        A.offset = P.bin_offset;
+        A.cursor = P.bin_cursor;
+        A.chunk_tot = P.chunk_tot;
+        A.chunk_base = P.chunk_base;
+        A.counters = P.counters;
+        A.counters_next = P.counters_next;
+        A.host_status = P.host_status;
+        rxr_launch_scan(&A, s);
         rxr_launch_fill(&P, s);
     } else {
         ctx->h_counters[CNT_ENTRIES] = 0;
         ctx->h_counters[CNT_OVERFLOW] = 0;
     }
     (void)n_bins;
+    // 2D binning pre-pass (many 2D primitives): count -> scan -> fill; k_raster sorts each tile's list
+    const bool prepass2d = P.tiles_y && (P.flags & RXR_FLAG_D2_ACTIVE) && P.binned2d;
+    if (prepass2d) {
+        if (ctx->scratch2d_dirty) {
+            HIPCHK(ctx, hipMemsetAsync(ctx->d_bin2d_count.p, 0, ctx->d_bin2d_count.cap, s));
+            HIPCHK(ctx, hipMemsetAsync((uint32_t *)ctx->d_counters.p + 2 * CNT_WORDS, 0, 2 * CNT_WORDS * sizeof(uint32_t), s));
+        }
+        ctx->scratch2d_dirty = true;
+        P.counters2d = (uint32_t *)ctx->d_counters.p + (size_t)(2u + ctx->parity2d) * CNT_WORDS;
+        P.counters2d_next = (uint32_t *)ctx->d_counters.p + (size_t)(2u + (ctx->parity2d ^ 1u)) * CNT_WORDS;
+        ctx->parity2d ^= 1u;
+        rxr_launch_bin2d_count(&P, s);
+        ScanArgs A{};
+        A.n = P.tiles_x * P.tiles_y;
+        A.list_capacity = P.list2d_capacity;
+        A.count = P.bin2d_count;
+        A.offset = P.bin2d_offset;
+        A.cursor = P.bin2d_cursor;
+        A.chunk_tot = P.chunk2d_tot;
+        A.chunk_base = P.chunk2d_base;
+        A.counters = P.counters2d;
+        A.counters_next = P.counters2d_next;
+        A.host_status = P.host_status2d;
+        rxr_launch_scan(&A, s);
+        rxr_launch_bin2d_fill(&P, s);
+    } else {
+        ctx->h_counters[CNT_WORDS + CNT_ENTRIES] = 0;
+        ctx->h_counters[CNT_WORDS + CNT_OVERFLOW] = 0;
+    }
     HIPCHK(ctx, hipEventRecord(e1, s));
     rxr_launch_raster(&P, s);
     HIPCHK(ctx, hipEventRecord(e2, s));
     HIPCHK(ctx, hipGetLastError());
     ctx->scratch_dirty = false;  // the raster launch that hands the bins back is queued
+    ctx->scratch2d_dirty = false;
     ctx->rendered = true;
     ctx->last_spec = spec;
     ctx->last_out = dev_pixels;
@@ -1145,6 +1230,19 @@ int rxr_synchronize(rxr_ctx *ctx) {
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         if (!ctx->rendered) return RXR_OK;
         ctx->stats.n_bin_entries = ctx->h_counters[CNT_ENTRIES];
+        if (ctx->h_counters[CNT_WORDS + CNT_OVERFLOW]) {
+            // 2D bin list overflow: grow and render the same launch again
+            size_t want = (size_t)ctx->h_counters[CNT_WORDS + CNT_ENTRIES] + ctx->h_counters[CNT_WORDS + CNT_ENTRIES] / 2 + 1024;
+            int rc = ensure(ctx, ctx->d_list2d, want * sizeof(uint32_t));
+            if (rc != RXR_OK) return rc;
+            ctx->list2d_capacity = (uint32_t)std::min<size_t>(ctx->d_list2d.cap / sizeof(uint32_t), 0xFFFFFFF0u);
+            ctx->P.bin2d_list = (uint32_t *)ctx->d_list2d.p;
+            ctx->P.list2d_capacity = ctx->list2d_capacity;
+            ctx->h_counters[CNT_WORDS + CNT_OVERFLOW] = 0;
+            rc = render_impl(ctx, ctx->last_spec, ctx->last_out, ctx->last_stream);
+            if (rc != RXR_OK) return rc;
+            continue;
+        }
         if (!ctx->h_counters[CNT_OVERFLOW]) {
             float a = 0, b = 0;
             if (ctx->last_e0 && hipEventElapsedTime(&a, ctx->last_e0, ctx->last_e1) == hipSuccess &&

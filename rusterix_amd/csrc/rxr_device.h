@@ -71,29 +71,28 @@ struct TriShade {
     uint32_t pad[2];
 };
 
-// 2D triangle (flattened on the host at upload; few of them).  96 B.
-struct Tri2D {
-    float ea[3], eb[3], ec[3];
-    float v0x, v0y, v1x, v1y, v2x, v2y;
-    float u0, v0, u1, v1, u2, v2;
-    uint32_t batch;
-    uint32_t visible;
-    uint32_t pad;
+// 2D primitive in submission order (flattened on the host at upload): a triangle of a Triangles batch
+// or one Bresenham segment of a Lines / LineStrip / LineLoop batch (rasterizer.rs:602-955).  96 B, staged
+// through LDS like TriSetup.  Order matters (alpha blending, :876-895), so the per-tile lists are sorted
+// by primitive index before they are walked.
+struct Prim2D {
+    float ea[3], eb[3], ec[3];               // triangle: Edges a/b/c
+    float v0x, v0y, v1x, v1y, v2x, v2y;      // triangle: vertices;  line: x0, y0, x1, y1 as int bits (`as isize`, :1785-1788), colour in v2x
+    float u0, v0, u1, v1, u2, v2;            // triangle: uvs
+    uint32_t batch_kind;                     // batch index << 2 | is_line << 1 | visible
+    uint32_t bx, by;                         // pixel box (whole screen clamp, exclusive max), as TriSetup
 };
+static_assert(sizeof(Prim2D) == 96, "Prim2D is staged through LDS as 6 x 16 B");
+// most primitives a tile may list before k_raster falls back to walking all of them (LDS sort capacity)
+#define RXR_SORT2D_MAX 1024
 
-// 2D line segment for the Bresenham modes (rasterizer.rs:901-955), endpoints already cast `as isize`
-struct Line2D {
-    int32_t x0, y0, x1, y1;
-    uint32_t batch;
-    uint32_t color;
-    uint32_t pad[2];
-};
-
-// ordered 2D work item: either a triangle range or a line range of one batch
-struct Item2D {
-    uint32_t batch;
-    uint32_t first, count;  // into tri2d[] or line2d[]
-    uint32_t is_lines;
+// what one k_scan launch works on (the 3D bins and the 2D bins use the same kernel)
+struct ScanArgs {
+    uint32_t n;                 // number of bins
+    uint32_t list_capacity;
+    const uint32_t *count;
+    uint32_t *offset, *cursor, *chunk_tot, *chunk_base;
+    uint32_t *counters, *counters_next, *host_status;
 };
 
 struct ChunkRange {
@@ -128,7 +127,9 @@ struct RasterParams {
     float sun_dir[3];
     float day_factor;
 
-    uint32_t n_tris3d, n_batches3d, n_lights, n_occluders, n_linedefs, n_items2d, any_lights, has_opacity;
+    uint32_t n_tris3d, n_batches3d, n_lights, n_occluders, n_linedefs, n_prims2d, any_lights, has_opacity;
+    uint32_t binned2d;             // 1: the 2D primitives were binned (n_prims2d > RXR_STAGE_TRIS); 0: implicit ordered list
+    uint32_t list2d_capacity;
     uint32_t list_capacity;
     uint32_t fused_small;          // small-scene mode (whole frame <= RXR_STAGE_TRIS triangles): 0 = binned pipeline,
                                    // 1 = fully fused (k_raster_fused builds the records itself, no pre-pass launch),
@@ -164,9 +165,12 @@ struct RasterParams {
     const ChunkRange *chunks;
 
     const DevBatch *batches2d;
-    const Tri2D *tri2d;
-    const Line2D *line2d;
-    const Item2D *items2d;
+    const Prim2D *prim2d;
+    uint32_t *bin2d_count;         // own zero-invariant buffer, like bin_count
+    uint32_t *bin2d_offset, *bin2d_cursor, *chunk2d_tot, *chunk2d_base;
+    uint32_t *bin2d_list, *large2d_list;
+    uint32_t *counters2d, *counters2d_next;
+    uint32_t *host_status2d;
 
     const DevTexDesc *tex;
     const uint32_t *texels;

@@ -487,7 +487,7 @@ __device__ __forceinline__ uint32_t shade3d_opacity(const RasterParams &P, const
 }
 
 // one 2D fragment (rasterizer.rs:656-895); returns the new pixel
-__device__ __forceinline__ uint32_t fragment2d(const RasterParams &P, const Tri2D &T, const DevBatch &B, uint32_t px, uint32_t py,
+__device__ __forceinline__ uint32_t fragment2d(const RasterParams &P, const Prim2D &T, const DevBatch &B, uint32_t px, uint32_t py,
                                                float fx, float fy, uint32_t dst) {
     // barycentric_weights_2d (rasterizer.rs:1731-1750)
     float acx = T.v2x - T.v0x, acy = T.v2y - T.v0y;
@@ -690,10 +690,10 @@ extern "C" __global__ void __launch_bounds__(256) k_setup3d(RasterParams P) {
 // chunk-local offsets; the workgroup that finishes last (ticket counter) scans the chunk totals,
 // publishes the totals to the host-visible status words and clears the other counter set.
 // =================================================================================================
-extern "C" __global__ void __launch_bounds__(256) k_scan(RasterParams P) {
+extern "C" __global__ void __launch_bounds__(256) k_scan(ScanArgs A) {
     __shared__ uint32_t wave_tot[4];
     __shared__ uint32_t s_last;
-    const uint32_t n = P.tiles_x * P.tiles_y;
+    const uint32_t n = A.n;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     constexpr uint32_t PER = RXR_SCAN_CHUNK / 256u;
     const uint32_t i0 = blockIdx.x * RXR_SCAN_CHUNK + tid * PER;
@@ -702,7 +702,7 @@ extern "C" __global__ void __launch_bounds__(256) k_scan(RasterParams P) {
 #pragma unroll
     for (uint32_t k = 0; k < PER; ++k) {
         uint32_t i = i0 + k;
-        v[k] = (i < n) ? P.bin_count[i] : 0u;
+        v[k] = (i < n) ? A.count[i] : 0u;
         sum += v[k];
     }
     uint32_t inc = sum;
@@ -725,15 +725,15 @@ extern "C" __global__ void __launch_bounds__(256) k_scan(RasterParams P) {
     for (uint32_t k = 0; k < PER; ++k) {
         uint32_t i = i0 + k;
         if (i < n) {
-            P.bin_offset[i] = run;
-            P.bin_cursor[i] = 0u;
+            A.offset[i] = run;
+            A.cursor[i] = 0u;
         }
         run += v[k];
     }
     if (tid == 0) {
-        __hip_atomic_store(&P.chunk_tot[blockIdx.x], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&A.chunk_tot[blockIdx.x], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __threadfence();
-        uint32_t ticket = atomicAdd(&P.counters[CNT_TICKET], 1u);
+        uint32_t ticket = atomicAdd(&A.counters[CNT_TICKET], 1u);
         s_last = (ticket == gridDim.x - 1u) ? 1u : 0u;
     }
     __syncthreads();
@@ -743,24 +743,24 @@ extern "C" __global__ void __launch_bounds__(256) k_scan(RasterParams P) {
     uint32_t carry = 0;
     for (uint32_t base = 0; base < gridDim.x; base += 64u) {
         uint32_t c = base + lane;
-        uint32_t t = (c < gridDim.x) ? __hip_atomic_load(&P.chunk_tot[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        uint32_t t = (c < gridDim.x) ? __hip_atomic_load(&A.chunk_tot[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
         uint32_t ic = t;
 #pragma unroll
         for (uint32_t d = 1; d < 64; d <<= 1) {
             uint32_t o = __shfl_up(ic, d, 64);
             if (lane >= d) ic += o;
         }
-        if (c < gridDim.x) P.chunk_base[c] = carry + ic - t;
+        if (c < gridDim.x) A.chunk_base[c] = carry + ic - t;
         carry += __shfl(ic, 63, 64);
     }
     if (lane == 0) {
-        const uint32_t overflow = carry > P.list_capacity ? 1u : 0u;
-        P.counters[CNT_ENTRIES] = carry;
-        P.counters[CNT_OVERFLOW] = overflow;
-        P.host_status[CNT_ENTRIES] = carry;
-        P.host_status[CNT_OVERFLOW] = overflow;
+        const uint32_t overflow = carry > A.list_capacity ? 1u : 0u;
+        A.counters[CNT_ENTRIES] = carry;
+        A.counters[CNT_OVERFLOW] = overflow;
+        A.host_status[CNT_ENTRIES] = carry;
+        A.host_status[CNT_OVERFLOW] = overflow;
     }
-    if (lane < CNT_WORDS) P.counters_next[lane] = 0u;
+    if (lane < CNT_WORDS) A.counters_next[lane] = 0u;
 }
 
 // =================================================================================================
@@ -780,6 +780,50 @@ extern "C" __global__ void __launch_bounds__(256) k_fill(RasterParams P) {
             uint32_t bin = by * P.tiles_x + bx;
             uint32_t pos = P.chunk_base[bin / RXR_SCAN_CHUNK] + P.bin_offset[bin] + atomicAdd(&P.bin_cursor[bin], 1u);
             if (pos < P.list_capacity) P.bin_list[pos] = t;
+        }
+}
+
+// =================================================================================================
+// 2D binning (only when the frame has more than RXR_STAGE_TRIS 2D primitives): count / fill of the
+// primitives' pixel boxes, same scheme as the 3D bins; the lists are sorted per tile in k_raster.
+// =================================================================================================
+namespace {
+__device__ __forceinline__ bool prim2d_bins(const RasterParams &P, const Prim2D &R, uint32_t &bx0, uint32_t &bx1, uint32_t &l0, uint32_t &l1) {
+    uint32_t min_x = R.bx & 0xFFFFu, max_x = R.bx >> 16, min_y = R.by & 0xFFFFu, max_y = R.by >> 16;
+    // clamp the box to the rows of this launch (bands / stripes)
+    if (min_y < P.row0) min_y = P.row0;
+    if (max_y > P.row1) max_y = P.row1;
+    return bin_range(P, min_x, max_x, min_y, max_y, bx0, bx1, l0, l1);
+}
+}  // namespace
+
+extern "C" __global__ void __launch_bounds__(256) k_bin2d_count(RasterParams P) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= P.n_prims2d) return;
+    uint32_t bx0, bx1, by0, by1;
+    if (!prim2d_bins(P, P.prim2d[t], bx0, bx1, by0, by1)) return;
+    uint32_t nb = (bx1 - bx0 + 1) * (by1 - by0 + 1);
+    if (nb > RXR_LARGE_BINS) {
+        uint32_t slot = atomicAdd(&P.counters2d[CNT_LARGE], 1u);
+        if (slot < P.n_prims2d) P.large2d_list[slot] = t;
+    } else {
+        for (uint32_t by = by0; by <= by1; ++by)
+            for (uint32_t bx = bx0; bx <= bx1; ++bx) atomicAdd(&P.bin2d_count[by * P.tiles_x + bx], 1u);
+    }
+}
+
+extern "C" __global__ void __launch_bounds__(256) k_bin2d_fill(RasterParams P) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= P.n_prims2d) return;
+    uint32_t bx0, bx1, by0, by1;
+    if (!prim2d_bins(P, P.prim2d[t], bx0, bx1, by0, by1)) return;
+    uint32_t nb = (bx1 - bx0 + 1) * (by1 - by0 + 1);
+    if (nb > RXR_LARGE_BINS) return;
+    for (uint32_t by = by0; by <= by1; ++by)
+        for (uint32_t bx = bx0; bx <= bx1; ++bx) {
+            uint32_t bin = by * P.tiles_x + bx;
+            uint32_t pos = P.chunk2d_base[bin / RXR_SCAN_CHUNK] + P.bin2d_offset[bin] + atomicAdd(&P.bin2d_cursor[bin], 1u);
+            if (pos < P.list2d_capacity) P.bin2d_list[pos] = t;
         }
 }
 
@@ -863,10 +907,13 @@ __device__ __forceinline__ bool tile_outside_edges(const float *ea, const float 
 
 // LDS staging area of one workgroup: candidate triangle records of the current round
 struct Stage {
-    float4 tri[RXR_STAGE_TRIS * 6];  // TriSetup records, 6 x 16 B each
+    float4 tri[RXR_STAGE_TRIS * 6];  // TriSetup / Prim2D records, 6 x 16 B each
     uint32_t ids[RXR_STAGE_TRIS];
     uint32_t wave_cnt[RXR_TILE_THREADS / 64];
-    TriShade shade[RXR_STAGE_TRIS];  // fused small-scene path only: shading records of the staged triangles
+};
+// fused small-scene path only: shading records of the staged triangles
+struct StageShade {
+    TriShade shade[RXR_STAGE_TRIS];
 };
 
 // Visibility pass over the tile's candidate triangles = [large-triangle list, filtered against the
@@ -947,7 +994,7 @@ __device__ __forceinline__ void scan_lists(const RasterParams &P, Stage &st, uin
 // thread t builds triangle t's TriSetup / TriShade itself (make_setup), tests its pixel box against
 // the tile, survivors are ballot-compacted straight into LDS, then every lane walks them.
 template <bool OPACITY>
-__device__ __forceinline__ void scan_fused(const RasterParams &P, Stage &st, uint32_t tile_x0, uint32_t tile_y0px, uint32_t px,
+__device__ __forceinline__ void scan_fused(const RasterParams &P, Stage &st, StageShade &sh, uint32_t tile_x0, uint32_t tile_y0px, uint32_t px,
                                            uint32_t py, float fx, float fy, Vis &vis, int surf_profile) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     bool keep = false;
@@ -975,38 +1022,78 @@ __device__ __forceinline__ void scan_fused(const RasterParams &P, Stage &st, uin
         const uint32_t slot = off + before;
         st.ids[slot] = tid;
         *reinterpret_cast<TriSetup *>(&st.tri[slot * 6u]) = S;
-        st.shade[slot] = H;
+        sh.shade[slot] = H;
     }
     __syncthreads();
     for (uint32_t k = 0; k < n; ++k) {
         const TriSetup &SK = *reinterpret_cast<const TriSetup *>(&st.tri[k * 6u]);
-        visit<OPACITY>(P, SK, &st.shade[k], st.ids[k], k, px, py, fx, fy, vis, surf_profile);
+        visit<OPACITY>(P, SK, &sh.shade[k], st.ids[k], k, px, py, fx, fy, vis, surf_profile);
     }
     __syncthreads();  // a second pass (opacity, then opaque) rebuilds the stage
 }
 
-// Bresenham walk of one segment (rasterizer.rs:1777-1821): does the walk plot pixel (px,py)?
-// Every lane runs the same uniform loop; cost O(segment length) per tile that the segment's box touches.
-__device__ __forceinline__ bool bresenham_hits(const Line2D &Ln, int px, int py) {
-    int x0 = Ln.x0, y0 = Ln.y0, x1 = Ln.x1, y1 = Ln.y1;
-    int dx = abs(x1 - x0), dy = abs(y1 - y0);
-    int sx = x0 < x1 ? 1 : -1, sy = y0 < y1 ? 1 : -1;
-    int err = dx - dy;
-    int x = x0, y = y0;
-    bool hit = false;
-    while (x != x1 || y != y1) {
-        hit = hit || (x == px && y == py);
-        int e2 = err * 2;
-        if (e2 > -dy) {
-            err -= dy;
-            x += sx;
-        }
-        if (e2 < dx) {
-            err += dx;
-            y += sy;
-        }
+// Does the Bresenham walk of one segment (rasterizer.rs:1777-1821) plot pixel (px, py)?  Closed form of
+// the reference's loop (err = dx - dy; x steps when 2*err > -dy, y steps when 2*err < dx; the end point
+// is not plotted): on an x-major segment (dx >= dy) x advances in every iteration, so iteration
+// k = |px - x0| is the only one that can plot column px, and the number of y steps taken before it is
+// max(0, ceil((2*k*dy - dx) / (2*dx))); y-major segments are the mirror image.  O(1) per pixel instead
+// of one walk per tile; verified exhaustively against the sequential walk (tests/test_bresenham_closed_form.py).
+__device__ __forceinline__ bool bresenham_hits(const Prim2D &Ln, int px, int py) {
+    const long long x0 = __float_as_int(Ln.v0x), y0 = __float_as_int(Ln.v0y), x1 = __float_as_int(Ln.v1x), y1 = __float_as_int(Ln.v1y);
+    const long long dx = x1 > x0 ? x1 - x0 : x0 - x1, dy = y1 > y0 ? y1 - y0 : y0 - y1;
+    const long long sx = x0 < x1 ? 1 : -1, sy = y0 < y1 ? 1 : -1;
+    if (dx >= dy) {
+        const long long k = ((long long)px - x0) * sx;
+        if (k < 0 || k >= dx) return false;
+        const long long a = 2 * k * dy - dx;
+        const long long j = a <= 0 ? 0 : (a + 2 * dx - 1) / (2 * dx);
+        return (long long)py == y0 + sy * j;
     }
-    return hit;
+    const long long k = ((long long)py - y0) * sy;
+    if (k < 0 || k >= dy) return false;
+    const long long a = 2 * k * dx - dy;
+    const long long i = a <= 0 ? 0 : (a + 2 * dy - 1) / (2 * dy);
+    return (long long)px == x0 + sx * i;
+}
+
+// one 2D primitive against this lane's pixel (rasterizer.rs:636-655 coverage, then fragment2d / the line colour)
+__device__ __forceinline__ uint32_t prim2d_pixel(const RasterParams &P, const Prim2D &T, uint32_t px, uint32_t py, float fx, float fy,
+                                                 uint32_t color) {
+    const uint32_t min_x = T.bx & 0xFFFFu, max_x = T.bx >> 16, min_y = T.by & 0xFFFFu, max_y = T.by >> 16;
+    if (T.batch_kind & 2u) {  // Bresenham segment
+        if (bresenham_hits(T, (int)px, (int)py)) color = __float_as_uint(T.v2x);
+        return color;
+    }
+    bool in = px >= min_x && px < max_x && py >= min_y && py < max_y && (T.batch_kind & 1u);
+    float r0 = T.ea[0] * fx + T.eb[0] * fy + T.ec[0];
+    float r1 = T.ea[1] * fx + T.eb[1] * fy + T.ec[1];
+    float r2 = T.ea[2] * fx + T.eb[2] * fy + T.ec[2];
+    in = in && !(r0 < 0.0f) && !(r1 < 0.0f) && !(r2 < 0.0f);
+    if (in) color = fragment2d(P, T, P.batches2d[T.batch_kind >> 2], px, py, fx, fy, color);
+    return color;
+}
+
+// stages the Prim2D records of `n` primitive ids (st.ids-like array `ids`, already in submission order)
+// through LDS in rounds of RXR_STAGE_TRIS and applies them to this lane's pixel in order
+__device__ __forceinline__ uint32_t walk_prims2d(const RasterParams &P, Stage &st, const uint32_t *ids, uint32_t n, bool implicit_ids,
+                                                 uint32_t px, uint32_t py, float fx, float fy, uint32_t color) {
+    const uint32_t tid = threadIdx.x;
+    const float4 *g4 = reinterpret_cast<const float4 *>(P.prim2d);
+    for (uint32_t base = 0; base < n; base += RXR_STAGE_TRIS) {
+        const uint32_t m = min(n - base, (uint32_t)RXR_STAGE_TRIS);
+        for (uint32_t f = tid; f < m * 6u; f += RXR_TILE_THREADS) {
+            uint32_t k = f / 6u, j = f - k * 6u;
+            uint32_t id = implicit_ids ? base + k : ids[base + k];
+            st.tri[f] = g4[(size_t)id * 6u + j];
+        }
+        __syncthreads();
+        for (uint32_t k = 0; k < m; ++k) {
+            const Prim2D &T = *reinterpret_cast<const Prim2D *>(&st.tri[k * 6u]);
+            color = prim2d_pixel(P, T, px, py, fx, fy, color);
+        }
+        __syncthreads();
+    }
+    return color;
 }
 
 }  // namespace
@@ -1019,8 +1106,19 @@ __device__ __forceinline__ bool bresenham_hits(const Line2D &Ln, int px, int py)
 #define RXR_WAVE_8X8 0
 #endif
 
+// LDS of the fused instantiation only
+template <bool F>
+struct ShadeStore {
+    StageShade s;
+};
+template <>
+struct ShadeStore<false> {};
+
 template <bool FUSED>
 __device__ __forceinline__ void raster_tile(const RasterParams &P) {
+    __shared__ Stage stage;
+    __shared__ uint32_t s_bin[4];
+    __shared__ ShadeStore<FUSED> shade_store;
     const uint32_t bin = blockIdx.x;
     const uint32_t tx = bin % P.tiles_x, ty = bin / P.tiles_x;
     const uint32_t tid = threadIdx.x;
@@ -1050,11 +1148,9 @@ __device__ __forceinline__ void raster_tile(const RasterParams &P) {
     }
 
     if (P.flags & RXR_FLAG_D3_ACTIVE) {
-        __shared__ uint32_t s_bin[2];
-        __shared__ Stage stage;
         constexpr bool fused = FUSED;
         uint32_t b0 = 0, b1 = 0;
-        if (!fused && P.fused_small == 0u) {
+        if (!fused && P.fused_small == 0u) {  // (s_bin[0..1]: this tile's 3D list)
             // this tile's bin list; the bin count is handed back zeroed for the next launch
             if (tid == 0) {
                 uint32_t cnt = P.bin_count[bin];
@@ -1072,13 +1168,13 @@ __device__ __forceinline__ void raster_tile(const RasterParams &P) {
         op.zmin = 1.0f; op.best = -1; op.alpha = 0.0f; op.beta = 0.0f; op.slot = 0; op.batch = 0;
         uint32_t op_color = 0u;  // the opacity winner is shaded at once: the opaque pass rebuilds the stage
         if (P.has_opacity) {
-            if (fused) scan_fused<true>(P, stage, tile_x0, tile_y0px, px, py, fx, fy, op, -1);
+            if constexpr (FUSED) scan_fused<true>(P, stage, shade_store.s, tile_x0, tile_y0px, px, py, fx, fy, op, -1);
             else scan_lists<true>(P, stage, b0, b1, tile_x0, tile_y0px, px, py, fx, fy, op, -1);
             if (op.best >= 0) {
                 const DevBatch &OB = P.batches3d[op.batch];
                 surf_profile = (OB.flags & DB_HAS_PROFILE) ? (int)OB.profile_id : -1;
                 TriShade OS;
-                if (fused) OS = stage.shade[op.slot];
+                if constexpr (FUSED) OS = shade_store.s.shade[op.slot];
                 else OS = P.tri_shade[op.best];
                 op_color = shade3d_opacity(P, OS, op.batch, op.alpha, op.beta);
             }
@@ -1086,7 +1182,7 @@ __device__ __forceinline__ void raster_tile(const RasterParams &P) {
         }
         Vis vis;
         vis.zmin = 1.0f; vis.best = -1; vis.alpha = 0.0f; vis.beta = 0.0f; vis.slot = 0; vis.batch = 0;
-        if (fused) scan_fused<false>(P, stage, tile_x0, tile_y0px, px, py, fx, fy, vis, surf_profile);
+        if constexpr (FUSED) scan_fused<false>(P, stage, shade_store.s, tile_x0, tile_y0px, px, py, fx, fy, vis, surf_profile);
         else scan_lists<false>(P, stage, b0, b1, tile_x0, tile_y0px, px, py, fx, fy, vis, surf_profile);
 
         // resolve (rasterizer.rs:409-497): hit -> shaded colour; miss -> [0,0,0,255]
@@ -1096,7 +1192,7 @@ __device__ __forceinline__ void raster_tile(const RasterParams &P) {
         F.opacity = 0.0f;
         if (hit) {
             TriShade HS;
-            if (fused) HS = stage.shade[vis.slot];
+            if constexpr (FUSED) HS = shade_store.s.shade[vis.slot];
             else HS = P.tri_shade[vis.best];
             shade3d_begin(P, HS, vis.batch, vis.alpha, vis.beta, vis.zmin, fx, fy, F);
         }
@@ -1118,37 +1214,86 @@ __device__ __forceinline__ void raster_tile(const RasterParams &P) {
         }
     }
 
-    if (P.flags & RXR_FLAG_D2_ACTIVE) {  // rasterizer.rs:501-553, strictly in submission order
-        for (uint32_t it = 0; it < P.n_items2d; ++it) {
-            const Item2D I = P.items2d[it];
-            const DevBatch &B = P.batches2d[I.batch];
-            if (!I.is_lines) {
-                for (uint32_t k = 0; k < I.count; ++k) {
-                    const Tri2D &T = P.tri2d[I.first + k];
-                    // clamped box (rasterizer.rs:615-634)
-                    float min_xf = fminf(T.v0x, fminf(T.v1x, T.v2x)), max_xf = fmaxf(T.v0x, fmaxf(T.v1x, T.v2x));
-                    float min_yf = fminf(T.v0y, fminf(T.v1y, T.v2y)), max_yf = fmaxf(T.v0y, fmaxf(T.v1y, T.v2y));
-                    uint32_t min_x = sat_index(fmaxf(floorf(min_xf), 0.0f), 0xFFFFu);
-                    uint32_t max_x = sat_index(fminf(ceilf(max_xf), (float)P.width), 0xFFFFu);
-                    uint32_t min_y = sat_index(fmaxf(floorf(min_yf), 0.0f), 0xFFFFu);
-                    uint32_t max_y = sat_index(fminf(ceilf(max_yf), (float)P.height), 0xFFFFu);
-                    if (min_x >= tile_x0 + RXR_TILE_W || max_x <= tile_x0 || min_y >= tile_y0px + RXR_TILE_H || max_y <= tile_y0px)
-                        continue;  // uniform
-                    bool in = px >= min_x && px < max_x && py >= min_y && py < max_y && T.visible;
-                    float r0 = T.ea[0] * fx + T.eb[0] * fy + T.ec[0];
-                    float r1 = T.ea[1] * fx + T.eb[1] * fy + T.ec[1];
-                    float r2 = T.ea[2] * fx + T.eb[2] * fy + T.ec[2];
-                    in = in && !(r0 < 0.0f) && !(r1 < 0.0f) && !(r2 < 0.0f);
-                    if (in) color = fragment2d(P, T, B, px, py, fx, fy, color);
+    if ((P.flags & RXR_FLAG_D2_ACTIVE) && P.n_prims2d) {  // rasterizer.rs:501-553, strictly in submission order
+        __syncthreads();  // the 3D pass is done with the stage
+        if (!P.binned2d) {
+            // few primitives: the implicit ordered list 0..n-1 (every primitive carries its own pixel box)
+            color = walk_prims2d(P, stage, nullptr, P.n_prims2d, true, px, py, fx, fy, color);
+        } else {
+            // candidates = [large 2D primitives whose box touches the tile] ++ [this tile's bin list], gathered
+            // into LDS, sorted by primitive index (submission order), then staged and applied in order
+            __shared__ uint32_t s_sort[RXR_SORT2D_MAX];
+            const uint32_t lane = tid & 63u, wave = tid >> 6;
+            if (tid == 0) {
+                uint32_t cnt = P.bin2d_count[bin];
+                uint32_t start = P.chunk2d_base[bin / RXR_SCAN_CHUNK] + P.bin2d_offset[bin];
+                s_bin[0] = min(start, P.list2d_capacity);
+                s_bin[1] = min(start + cnt, P.list2d_capacity);
+                s_bin[2] = 0u;  // number of gathered candidates
+                if (cnt) P.bin2d_count[bin] = 0u;
+            }
+            __syncthreads();
+            const uint32_t c0 = s_bin[0], c1 = s_bin[1];
+            const uint32_t n_large = min(P.counters2d[CNT_LARGE], P.n_prims2d);
+            const uint32_t total = n_large + (c1 - c0);
+            for (uint32_t base = 0; base < total; base += RXR_TILE_THREADS) {
+                const uint32_t e = base + tid;
+                uint32_t id = 0;
+                bool keep = false;
+                if (e < total) {
+                    if (e < n_large) {
+                        id = min(P.large2d_list[e], P.n_prims2d - 1u);
+                        const uint2 box = *reinterpret_cast<const uint2 *>(&P.prim2d[id].bx);
+                        uint32_t min_x = box.x & 0xFFFFu, max_x = box.x >> 16, min_y = box.y & 0xFFFFu, max_y = box.y >> 16;
+                        keep = !(min_x >= tile_x0 + RXR_TILE_W || max_x <= tile_x0 || min_y >= tile_y0px + RXR_TILE_H || max_y <= tile_y0px);
+                    } else {
+                        id = P.bin2d_list[c0 + (e - n_large)];
+                        keep = id < P.n_prims2d;
+                    }
                 }
+                const unsigned long long m = __ballot(keep);
+                const uint32_t before = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                if (lane == 0) stage.wave_cnt[wave] = (uint32_t)__popcll(m);
+                __syncthreads();
+                uint32_t off = s_bin[2], n = 0;
+#pragma unroll
+                for (uint32_t w = 0; w < RXR_TILE_THREADS / 64; ++w) {
+                    uint32_t c = stage.wave_cnt[w];
+                    if (w < wave) off += c;
+                    n += c;
+                }
+                if (keep && off + before < RXR_SORT2D_MAX) s_sort[off + before] = id;
+                __syncthreads();
+                if (tid == 0) s_bin[2] = min(s_bin[2] + n, (uint32_t)RXR_SORT2D_MAX + 1u);  // MAX + 1 flags "too many"
+                __syncthreads();
+            }
+            const uint32_t n_cand = s_bin[2];
+            if (n_cand > RXR_SORT2D_MAX) {
+                // more candidates than the LDS sort holds: walk every primitive in order (correct, slow)
+                color = walk_prims2d(P, stage, nullptr, P.n_prims2d, true, px, py, fx, fy, color);
             } else {
-                for (uint32_t k = 0; k < I.count; ++k) {
-                    const Line2D &Ln = P.line2d[I.first + k];
-                    int lx0 = min(Ln.x0, Ln.x1), lx1 = max(Ln.x0, Ln.x1), ly0 = min(Ln.y0, Ln.y1), ly1 = max(Ln.y0, Ln.y1);
-                    if (lx0 >= (int)(tile_x0 + RXR_TILE_W) || lx1 < (int)tile_x0 || ly0 >= (int)(tile_y0px + RXR_TILE_H) || ly1 < (int)tile_y0px)
-                        continue;  // uniform: the walk never leaves the endpoint box
-                    if (bresenham_hits(Ln, (int)px, (int)py)) color = Ln.color;
+                // bitonic sort of s_sort[0 .. n_cand) padded to the next power of two with 0xFFFFFFFF
+                uint32_t n2 = 1;
+                while (n2 < n_cand) n2 <<= 1;
+                for (uint32_t i2 = n_cand + tid; i2 < n2; i2 += RXR_TILE_THREADS) s_sort[i2] = 0xFFFFFFFFu;
+                __syncthreads();
+                for (uint32_t k2 = 2; k2 <= n2; k2 <<= 1) {
+                    for (uint32_t j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
+                        for (uint32_t i2 = tid; i2 < n2; i2 += RXR_TILE_THREADS) {
+                            uint32_t l2 = i2 ^ j2;
+                            if (l2 > i2) {
+                                uint32_t a = s_sort[i2], b = s_sort[l2];
+                                bool up = (i2 & k2) == 0;
+                                if ((a > b) == up) {
+                                    s_sort[i2] = b;
+                                    s_sort[l2] = a;
+                                }
+                            }
+                        }
+                        __syncthreads();
+                    }
                 }
+                color = walk_prims2d(P, stage, s_sort, n_cand, false, px, py, fx, fy, color);
             }
         }
     }
@@ -1169,11 +1314,18 @@ extern "C" void rxr_launch_setup(const RasterParams *P, hipStream_t s) {
     uint32_t blocks = (P->n_tris3d + 255u) / 256u;
     hipLaunchKernelGGL(k_setup3d, dim3(blocks), dim3(256), 0, s, *P);
 }
-extern "C" void rxr_launch_scan(const RasterParams *P, hipStream_t s) {
-    uint32_t n = P->tiles_x * P->tiles_y;
-    uint32_t chunks = (n + RXR_SCAN_CHUNK - 1u) / RXR_SCAN_CHUNK;
+extern "C" void rxr_launch_scan(const ScanArgs *A, hipStream_t s) {
+    uint32_t chunks = (A->n + RXR_SCAN_CHUNK - 1u) / RXR_SCAN_CHUNK;
     if (chunks == 0) chunks = 1;
-    hipLaunchKernelGGL(k_scan, dim3(chunks), dim3(256), 0, s, *P);
+    hipLaunchKernelGGL(k_scan, dim3(chunks), dim3(256), 0, s, *A);
+}
+extern "C" void rxr_launch_bin2d_count(const RasterParams *P, hipStream_t s) {
+    if (P->n_prims2d == 0) return;
+    hipLaunchKernelGGL(k_bin2d_count, dim3((P->n_prims2d + 255u) / 256u), dim3(256), 0, s, *P);
+}
+extern "C" void rxr_launch_bin2d_fill(const RasterParams *P, hipStream_t s) {
+    if (P->n_prims2d == 0) return;
+    hipLaunchKernelGGL(k_bin2d_fill, dim3((P->n_prims2d + 255u) / 256u), dim3(256), 0, s, *P);
 }
 extern "C" void rxr_launch_fill(const RasterParams *P, hipStream_t s) {
     if (P->n_tris3d == 0) return;

@@ -311,6 +311,50 @@ def box_grid_scene(api, n=289, width=7680, height=4320, tile_size=40, sample_mod
     return _result(api, scene, assets, setup, width, height, tile_size, f"C5-boxgrid-{n}")
 
 
+def tile_map_2d_scene(api, width=640, height=400, nx=30, ny=20, stacked=0, lines=True, lights=True):
+    """A 2D "tile map": nx*ny textured / translucent rectangles with overlaps, a few screen-sized
+    translucent overlays (large primitives), optional `stacked` rectangles piled on one spot (more
+    candidates in one tile than the LDS sort holds) and Bresenham line batches in between."""
+    rng = np.random.default_rng([0x52585231, 77, nx, ny, stacked])
+    rects = []
+    cw, ch = width / nx, height / ny
+    for j in range(ny):
+        for i in range(nx):
+            r = api.Batch2D.from_rectangle(float(np.float32(i * cw - 1.0)), float(np.float32(j * ch - 1.0)), float(np.float32(cw + 3.0)), float(np.float32(ch + 3.0)))
+            k = (i + 2 * j) % 4
+            if k == 0:
+                r.source(B.PixelSource.StaticTileIndex(int(rng.integers(0, 3)))).repeat_mode(B.REPEAT_REPEAT_XY)
+            elif k == 1:
+                r.source(B.PixelSource.Pixel(tuple(int(x) for x in rng.integers(0, 256, 3)) + (int(rng.integers(40, 255)),)))
+            elif k == 2:
+                r.source(B.PixelSource.StaticTileIndex(2))
+            else:
+                r.source(B.PixelSource.Pixel(tuple(int(x) for x in rng.integers(0, 256, 3)) + (255,)))
+            r.receives_light(bool((i + j) % 3))
+            rects.append(r)
+        if lines and j % 5 == 2:
+            v = np.array([[5.5, j * ch + 3.2], [width - 7.0, j * ch + ch * 0.8], [width * 0.5, j * ch - 4.0], [40.0, j * ch + 30.0]], np.float32)
+            rects.append(api.Batch2D.new(v, np.array([[0, 1, 0], [1, 2, 0], [2, 3, 0]], np.uint32), np.zeros_like(v)).mode(B.MODE_LINES)
+                         .source(B.PixelSource.Pixel((255, 255, 0, 255))))
+    rects.append(api.Batch2D.from_rectangle(20.0, 15.0, float(width - 60), float(height - 50)).source(B.PixelSource.Pixel((30, 60, 200, 90))))
+    for _ in range(stacked):
+        rects.append(api.Batch2D.from_rectangle(100.0, 100.0, 24.0, 24.0).source(B.PixelSource.Pixel(tuple(int(x) for x in rng.integers(0, 256, 3)) + (40,))))
+    rects.append(api.Batch2D.from_rectangle(0.0, 0.0, float(width), float(height)).source(B.PixelSource.Pixel((255, 255, 255, 20))))
+    scene = api.Scene.from_static(rects, [])
+    if lights:
+        scene.lights([B.Light(B.LIGHT_POINT).with_position((width * 0.5, 0.0, height * 0.5)).with_color((1.0, 0.9, 0.7)).with_intensity(1.0)
+                      .with_start_distance(50.0).with_end_distance(400.0).compile()])
+    assets = api.Assets.default().textures([B.Tile.from_texture(brick_texture(2)), B.Tile.from_texture(fence_texture(6)),
+                                            B.Tile.from_texture(logo_texture(1, 64))])
+
+    def setup():
+        v, p = api.D3OrbitCamera.new().matrices(float(width), float(height))
+        return (api.Rasterizer.setup(None, v, p).render_mode(B.RenderMode.render_2d()).background((12, 12, 12, 255))
+                .ambient((0.4, 0.4, 0.4, 1.0)).mapmini_add_linedef((200.0, 0.0), (200.0, 150.0)))
+
+    return _result(api, scene, assets, setup, width, height, 40, "rects")
+
+
 def render(cfg, out=None):
     """One `Rasterizer::setup(..).rasterize(scene, pixels, w, h, tile, assets)` call."""
     if out is None:

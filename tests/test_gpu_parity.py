@@ -384,3 +384,34 @@ def test_errors_are_reported_not_thrown(product):
     assert e.value.code == B.RXR_ERR_INVALID
     with pytest.raises(B.RasterizeError):
         product.Rasterizer.setup(None, v, p).rasterize(product.Scene.empty(), out, 64, 64, 0, product.Assets.default())
+
+
+# ---- 2D at scale: binned + per-tile sorted primitive lists ------------------------------------------------
+many_rects_scene = scenes.tile_map_2d_scene
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(width=333, height=211, nx=17, ny=11), dict(stacked=600, nx=12, ny=8), dict(lights=False, lines=False)])
+def test_2d_many_rectangles_bit_exact(oracle, product, kw):
+    got, ref = both(oracle, product, many_rects_scene, **kw)
+    assert_exact(got, ref, f"2D tile map {kw}")
+    assert len(np.unique(got.reshape(-1, 4), axis=0)) > 100
+
+
+def test_2d_many_rectangles_over_3d(oracle, product):
+    """2D primitives binned + sorted on top of a lit 3D frame (both pre-passes in one frame)."""
+    def build(api):
+        cfg = scenes.map_scene(api, width=480, height=300, logo_size=64, n_lights=3)
+        over = many_rects_scene(api, width=480, height=300, nx=16, ny=10, lights=False)
+        # move the rectangles of `over` into the map scene as dynamic 2D batches: rebuild them here
+        rng = np.random.default_rng(5)
+        for j in range(10):
+            for i in range(16):
+                if (i + j) % 2:
+                    continue
+                cfg.scene.add_d2_dynamic(api.Batch2D.from_rectangle(i * 30.0 + 2.0, j * 30.0 + 1.0, 33.0, 33.0)
+                                         .source(B.PixelSource.Pixel(tuple(int(x) for x in rng.integers(0, 256, 3)) + (int(rng.integers(30, 256)),))))
+        del over
+        return cfg
+
+    got, ref = scenes.render(build(product)), scenes.render(build(oracle))
+    assert_close(got, ref, "2D tile map over 3D")
