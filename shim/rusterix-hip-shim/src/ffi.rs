@@ -108,6 +108,28 @@ pub struct rxr_batch3d {
     pub chunk: i32,
 }
 
+/// Object-space Batch3D for device-side projection (rxr_set_meshes).
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct rxr_mesh3d {
+    pub vertices: *const f32,
+    pub indices: *const u32,
+    pub uvs: *const f32,
+    pub normals: *const f32,
+    pub n_vertices: u32,
+    pub n_triangles: u32,
+    pub transform_3d: [f32; 16],
+    pub cull_mode: u32,
+    pub repeat_mode: u32,
+    pub source: rxr_source,
+    pub ambient_color: [f32; 3],
+    pub shader: i32,
+    pub has_profile_id: u32,
+    pub profile_id: u32,
+    pub list: u32,
+    pub chunk: i32,
+}
+
 #[repr(C)]
 #[derive(Clone, Copy)]
 pub struct rxr_batch2d {
@@ -184,6 +206,10 @@ pub struct rxr_frame {
     pub chunks: *const rxr_chunk,
     pub n_chunks: u32,
     pub n_shader_programs: u32,
+    pub use_meshes: u32,
+    pub view: [f32; 16],
+    pub projection: [f32; 16],
+    pub mesh_transforms: *const f32,
 }
 
 extern "C" {
@@ -192,6 +218,7 @@ extern "C" {
     pub fn rxr_last_error(ctx: *const rxr_ctx) -> *const c_char;
     pub fn rxr_device_count() -> c_int;
     pub fn rxr_set_textures(ctx: *mut rxr_ctx, s: *const rxr_tile, ns: u32, d: *const rxr_tile, nd: u32) -> c_int;
+    pub fn rxr_set_meshes(ctx: *mut rxr_ctx, meshes: *const rxr_mesh3d, n: u32) -> c_int;
     pub fn rxr_upload_frame(ctx: *mut rxr_ctx, frame: *const rxr_frame) -> c_int;
     pub fn rxr_render_rows(ctx: *mut rxr_ctx, row0: u32, row1: u32) -> c_int;
     pub fn rxr_render_rows_to(ctx: *mut rxr_ctx, row0: u32, row1: u32, dev: *mut c_void, stream: *mut c_void) -> c_int;
