@@ -332,6 +332,15 @@ int rxr_get_stats(rxr_ctx *ctx, rxr_stats *out);
 /* device pointer of the context framebuffer (width*height*4 bytes of the last uploaded frame) */
 void *rxr_device_framebuffer(rxr_ctx *ctx);
 
+/* diagnostics: the raster kernel replaces hipcc's expansions of f32 division, sqrtf and exp2f(k*log2f(x))
+ * by shorter instruction sequences that are bit-identical (rusterix_amd/csrc/rxr_exact_math.h).  This
+ * runs both over `n_tuples` seeded operand tuples per operation kind on the device (rounded up to whole
+ * workgroups) and returns the number of tuples whose results differ in mismatches[0..RXR_MATH_KINDS-1]:
+ * 0 div2, 1 div3, 2 div3_self, 3 normalize3, 4 sqrt, 5 pow, 6 div1, 7 pixel-centre/size and byte/255.
+ * Blocking.  Nothing in the reference corresponds to it. */
+#define RXR_MATH_KINDS 8
+int rxr_selftest_math(rxr_ctx *ctx, uint64_t n_tuples, uint64_t seed, uint64_t mismatches[RXR_MATH_KINDS]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -28,6 +28,7 @@ extern "C" void rxr_launch_bin2d_count(const RasterParams *P, hipStream_t s);
 extern "C" void rxr_launch_bin2d_fill(const RasterParams *P, hipStream_t s);
 extern "C" void rxr_launch_fill(const RasterParams *P, hipStream_t s);
 extern "C" void rxr_launch_raster(const RasterParams *P, hipStream_t s);
+extern "C" void rxr_launch_selftest_math(uint64_t seed, uint32_t blocks, uint32_t iters, unsigned long long *mismatch, hipStream_t s);
 
 namespace {
 
@@ -1295,5 +1296,29 @@ int rxr_get_stats(rxr_ctx *ctx, rxr_stats *out) {
 }
 
 void *rxr_device_framebuffer(rxr_ctx *ctx) { return ctx ? ctx->d_fb.p : nullptr; }
+
+int rxr_selftest_math(rxr_ctx *ctx, uint64_t n_tuples, uint64_t seed, uint64_t mismatches[RXR_MATH_KINDS]) {
+    if (!ctx || !mismatches) return fail(ctx, RXR_ERR_INVALID, "rxr_selftest_math: NULL argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const uint32_t iters = 256;
+    uint64_t per_block = 256ull * iters;
+    uint64_t blocks64 = (n_tuples + per_block - 1) / per_block;
+    if (blocks64 == 0) blocks64 = 1;
+    if (blocks64 > (1ull << 22)) return fail(ctx, RXR_ERR_INVALID, "rxr_selftest_math: n_tuples too large (max 2^38)");
+    unsigned long long *d = nullptr;
+    HIPCHK(ctx, hipMalloc(&d, RXR_MATH_KINDS * sizeof(unsigned long long)));
+    hipError_t e = hipMemsetAsync(d, 0, RXR_MATH_KINDS * sizeof(unsigned long long), ctx->stream);
+    if (e == hipSuccess) {
+        rxr_launch_selftest_math(seed, (uint32_t)blocks64, iters, d, ctx->stream);
+        e = hipGetLastError();
+    }
+    unsigned long long h[RXR_MATH_KINDS] = {0};
+    if (e == hipSuccess) e = hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(ctx, RXR_ERR_HIP, std::string("rxr_selftest_math: ") + hipGetErrorString(e));
+    for (int k = 0; k < RXR_MATH_KINDS; ++k) mismatches[k] = h[k];
+    return RXR_OK;
+}
 
 }  // extern "C"

@@ -1,0 +1,187 @@
+// rxr_exact_math.h -- cheaper instruction sequences for IEEE-correct f32 division, square root and
+// log2/exp2 on gfx950 that are BIT-IDENTICAL to what hipcc emits for `/`, sqrtf, log2f and exp2f.
+//
+// Why: the raster kernel is fp32-VALU bound and (measured, tools/microbench/valu_rates.hip) a
+// correctly rounded division costs 36 SIMD cycles per wave (2 v_div_scale + v_rcp + 6 fma/mul +
+// v_div_fmas + v_div_fixup), a square root 56, log2f/exp2f 26 each -- together about 40 % of the
+// kernel's VALU time.  hipcc's expansions are written for every possible operand; most of their
+// instructions only deal with operands near the ends of the exponent range:
+//   * v_div_scale_f32 returns its operand unchanged and leaves VCC clear unless the denominator, its
+//     reciprocal, the numerator or the quotient comes near the denormal range or the quotient near
+//     FLT_MAX; v_div_fmas_f32 is then a plain fma and v_div_fixup_f32 returns its first operand
+//     for finite non-zero operands.  What remains is rcp + 2 fma (functions of the denominator only)
+//     and mul + 4 fma per numerator -- so divisions that share a denominator (normalisation, the
+//     perspective divide) also share the reciprocal.
+//   * sqrtf: v_sqrt_f32 followed by two one-ulp correction probes; the rest scales arguments below
+//     2^-96 and passes 0 / inf through.
+//   * log2f / exp2f: v_log_f32 / v_exp_f32 plus scaling for arguments below 2^-126 / -126.
+// Every helper here tests, for the whole wave, that all active lanes' operands are inside a window in
+// which those extra instructions are provably no-ops, runs the short sequence if so and the
+// compiler's own expansion otherwise (wave-uniform branch).  In the window the short sequence IS the
+// compiler's sequence with the no-op instructions removed, so the result is the same float; outside
+// the window it is the compiler's code.  tests/test_gpu_exact_math.py checks bit equality over
+// billions of operand pairs, including the window edges and every special value.
+//
+// RXR_EXACT_FAST=0 compiles the plain operators instead (A/B measurements).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#ifndef RXR_EXACT_FAST
+#define RXR_EXACT_FAST 1
+#endif
+
+namespace rxm {
+
+// operand window for divisions: with 2^-40 <= |n|, |d| <= 2^40 the quotient lies in [2^-80, 2^80],
+// no v_div_scale_f32 case applies (exponent difference < 96, nothing denormal, numerator exponent > 23)
+// and every intermediate of the chain (the smallest is the residual, >= 2^-24 * 2^-40 * 2^-24) is a
+// normal number.
+constexpr float WIN_LO = 0x1p-40f;
+constexpr float WIN_HI = 0x1p40f;
+
+__device__ __forceinline__ bool wave_all(bool ok) { return __builtin_amdgcn_ballot_w64(!ok) == 0ull; }
+
+__device__ __forceinline__ bool in_window(float x) {
+    float a = __builtin_fabsf(x);
+    return a >= WIN_LO && a <= WIN_HI;  // false for NaN
+}
+
+// squares of window values, for magnitudes: 2^-80 <= x <= 2^80 by one unsigned compare on the bits
+// (negative, NaN and inf fail)
+__device__ __forceinline__ bool sq_in_window(float x) {
+    return (__float_as_uint(x) - 0x17800000u /* 2^-80 */) <= (0x67800000u /* 2^80 */ - 0x17800000u);
+}
+
+// rcp + one Newton step: the part of the division chain that depends on the denominator only
+__device__ __forceinline__ float rcp_refined(float d) {
+    float r0 = __builtin_amdgcn_rcpf(d);
+    float e0 = fmaf(-d, r0, 1.0f);
+    return fmaf(e0, r0, r0);
+}
+// the per-numerator part: q0, residual, correction, residual, correction (= v_div_fmas with VCC clear)
+__device__ __forceinline__ float div_chain(float n, float d, float r) {
+    float q0 = n * r;
+    float e1 = fmaf(-d, q0, n);
+    float q1 = fmaf(e1, r, q0);
+    float e2 = fmaf(-d, q1, n);
+    return fmaf(e2, r, q1);
+}
+
+// sqrt core: v_sqrt_f32 and the two one-ulp probes of hipcc's expansion, valid for 2^-96 <= x < inf
+__device__ __forceinline__ float sqrt_core(float x) {
+    float s = __builtin_amdgcn_sqrtf(x);
+    float s_dn = __uint_as_float(__float_as_uint(s) - 1u);
+    float s_up = __uint_as_float(__float_as_uint(s) + 1u);
+    float r_dn = fmaf(-s_dn, s, x);
+    float r_up = fmaf(-s_up, s, x);
+    float t = (r_dn <= 0.0f) ? s_dn : s;
+    return (r_up > 0.0f) ? s_up : t;
+}
+
+// ---- public helpers (same value as the plain operator for EVERY input) --------------------------
+
+// n / d for one numerator.  Only cheaper than `/` when the window test is cheap for the caller, so it
+// takes the caller's knowledge: `ok` must imply in_window(n) && in_window(d) for this lane.
+__device__ __forceinline__ float div1_known(float n, float d, bool ok) {
+#if RXR_EXACT_FAST
+    if (wave_all(ok)) return div_chain(n, d, rcp_refined(d));
+#endif
+    return n / d;
+}
+
+__device__ __forceinline__ void div2(float n0, float n1, float d, float &q0, float &q1) {
+#if RXR_EXACT_FAST
+    float lo = fminf(__builtin_fabsf(n0), __builtin_fabsf(n1)), hi = fmaxf(__builtin_fabsf(n0), __builtin_fabsf(n1));
+    if (wave_all(in_window(d) && lo >= WIN_LO && hi <= WIN_HI)) {
+        float r = rcp_refined(d);
+        q0 = div_chain(n0, d, r);
+        q1 = div_chain(n1, d, r);
+        return;
+    }
+#endif
+    q0 = n0 / d;
+    q1 = n1 / d;
+}
+
+__device__ __forceinline__ void div3(float n0, float n1, float n2, float d, float &q0, float &q1, float &q2) {
+#if RXR_EXACT_FAST
+    float lo = __builtin_fminf(__builtin_fminf(__builtin_fabsf(n0), __builtin_fabsf(n1)), __builtin_fabsf(n2));
+    float hi = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(n0), __builtin_fabsf(n1)), __builtin_fabsf(n2));
+    if (wave_all(in_window(d) && lo >= WIN_LO && hi <= WIN_HI)) {
+        float r = rcp_refined(d);
+        q0 = div_chain(n0, d, r);
+        q1 = div_chain(n1, d, r);
+        q2 = div_chain(n2, d, r);
+        return;
+    }
+#endif
+    q0 = n0 / d;
+    q1 = n1 / d;
+    q2 = n2 / d;
+}
+
+// (n0, n1, n2, d) / d: the perspective divide of a Vec4 by its own w (d / d is exactly 1 in the window)
+__device__ __forceinline__ void div3_self(float n0, float n1, float n2, float d, float &q0, float &q1, float &q2, float &qd) {
+#if RXR_EXACT_FAST
+    float lo = __builtin_fminf(__builtin_fminf(__builtin_fabsf(n0), __builtin_fabsf(n1)), __builtin_fabsf(n2));
+    float hi = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(n0), __builtin_fabsf(n1)), __builtin_fabsf(n2));
+    if (wave_all(in_window(d) && lo >= WIN_LO && hi <= WIN_HI)) {
+        float r = rcp_refined(d);
+        q0 = div_chain(n0, d, r);
+        q1 = div_chain(n1, d, r);
+        q2 = div_chain(n2, d, r);
+        qd = 1.0f;
+        return;
+    }
+#endif
+    q0 = n0 / d;
+    q1 = n1 / d;
+    q2 = n2 / d;
+    qd = d / d;
+}
+
+__device__ __forceinline__ float sqrt_exact(float x) {
+#if RXR_EXACT_FAST
+    // 2^-96 <= x < inf  (bits in [0x0f800000, 0x7f800000))
+    if (wave_all((__float_as_uint(x) - 0x0f800000u) < (0x7f800000u - 0x0f800000u))) return sqrt_core(x);
+#endif
+    return sqrtf(x);
+}
+
+// v / |v| with |v| = sqrt((x*x + y*y) + z*z), vek's `normalized`; also returns the magnitude.
+// One window test on the squared magnitude covers the square root and the denominator
+// (2^-80 <= m2 <= 2^80  =>  2^-40 <= m <= 2^40); the numerators satisfy |n| <= m by monotonicity of
+// rounding, so only their lower bound is tested.
+__device__ __forceinline__ void normalize3(float x, float y, float z, float &ox, float &oy, float &oz, float &mag) {
+    float m2 = (x * x + y * y) + z * z;
+#if RXR_EXACT_FAST
+    float lo = __builtin_fminf(__builtin_fminf(__builtin_fabsf(x), __builtin_fabsf(y)), __builtin_fabsf(z));
+    if (wave_all(sq_in_window(m2) && lo >= WIN_LO)) {
+        float m = sqrt_core(m2);
+        float r = rcp_refined(m);
+        ox = div_chain(x, m, r);
+        oy = div_chain(y, m, r);
+        oz = div_chain(z, m, r);
+        mag = m;
+        return;
+    }
+#endif
+    float m = sqrtf(m2);
+    ox = x / m;
+    oy = y / m;
+    oz = z / m;
+    mag = m;
+}
+
+// exp2f(k * log2f(x)) as the reference's pow32_fast computes it (rasterizer.rs:1895-1901)
+__device__ __forceinline__ float pow_exp2_log2(float x, float k) {
+#if RXR_EXACT_FAST
+    // log2f scales arguments below 2^-126, exp2f arguments below -126; NaN takes neither branch
+    float lg = __builtin_amdgcn_logf(x);
+    float y = k * lg;
+    if (wave_all(!(x < 0x1p-126f) && !(y < -126.0f))) return __builtin_amdgcn_exp2f(y);
+#endif
+    return exp2f(k * log2f(x));
+}
+
+}  // namespace rxm

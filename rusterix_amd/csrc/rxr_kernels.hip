@@ -26,6 +26,7 @@
 #include <hip/hip_runtime.h>
 
 #include "rxr_device.h"
+#include "rxr_exact_math.h"
 #include "rxr_project.h"
 
 #ifndef RXR_VEK_FUSED_MATVEC
@@ -48,6 +49,17 @@ __device__ __forceinline__ f3 neg3(f3 a) { return f3{-a.x, -a.y, -a.z}; }
 __device__ __forceinline__ float dot3(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 __device__ __forceinline__ float mag3(f3 a) { return sqrtf(dot3(a, a)); }
 __device__ __forceinline__ f3 norm3(f3 a) { return div3(a, mag3(a)); }
+// same values through the shared-reciprocal sequences of rxr_exact_math.h (bit-identical; cheaper
+// unless a component is exactly zero, which sends the wave down the plain path)
+__device__ __forceinline__ f3 norm3_fast(f3 a, float &mag) {
+    f3 o;
+    rxm::normalize3(a.x, a.y, a.z, o.x, o.y, o.z, mag);
+    return o;
+}
+__device__ __forceinline__ f3 norm3_fast(f3 a) {
+    float m;
+    return norm3_fast(a, m);
+}
 
 // Rust f32::clamp keeps NaN
 __device__ __forceinline__ float rclamp(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
@@ -99,7 +111,7 @@ __device__ __forceinline__ float srgb_to_linear_fast(float x) {
     return (0.6975f * x2 + 0.3025f) * x;
 }
 __device__ __forceinline__ float linear_to_srgb_fast(float x) {
-    float s = sqrtf(x);
+    float s = rxm::sqrt_exact(x);
     return 1.055f * s - 0.055f * s * s;
 }
 
@@ -264,9 +276,9 @@ __device__ __forceinline__ f3 shade_fast_brdf(f3 base, float roughness, float me
     kd = scale3(kd, 1.0f - fmaxf(f0.x, fmaxf(f0.y, f0.z)));
     float a = fmaxf(roughness * roughness, 1e-4f);
     float shininess = rclamp(2.0f / a - 2.0f, 1.0f, 2048.0f);
-    f3 h = norm3(add3(l, v));
+    f3 h = norm3_fast(add3(l, v));
     float n_dot_h = fmaxf(dot3(n, h), 0.0f);
-    float spec_b = (n_dot_h <= 0.0f) ? 0.0f : exp2f(shininess * log2f(n_dot_h));
+    float spec_b = (n_dot_h <= 0.0f) ? 0.0f : rxm::pow_exp2_log2(n_dot_h, shininess);
     float n_dot_v = fmaxf(dot3(n, v), 0.0f);
     float om = 1.0f - rclamp(n_dot_v, 0.0f, 1.0f);
     float x5 = om * om * om * om * om;
@@ -307,8 +319,7 @@ __device__ __forceinline__ void fragment_uv(const TriShade &S, float alpha, floa
     float iu = S.u0w * alpha + S.u1w * beta + S.u2w * gamma;
     float iv = S.v0w * alpha + S.v1w * beta + S.v2w * gamma;
     float irw = S.iw0 * alpha + S.iw1 * beta + S.iw2 * gamma;
-    u = iu / irw;
-    v = iv / irw;
+    rxm::div2(iu, iv, irw, u, v);
 }
 
 __device__ __forceinline__ uint32_t batch_texel(const RasterParams &P, const DevBatch &B, float u, float v) {
@@ -332,19 +343,18 @@ __device__ __forceinline__ void shade3d_begin(const RasterParams &P, const TriSh
     fragment_uv(S, alpha, beta, gamma, u, v);
 
     // screen_to_world (rasterizer.rs:1707-1727)
-    float x_ndc = 2.0f * (fx / P.fwidth) - 1.0f;
-    float y_ndc = 1.0f - 2.0f * (fy / P.fheight);
+    // fx, fy are pixel centres (0.5 .. 2^15) and the frame size is validated by rxr_upload_frame
+    // (1 .. 32768): always inside the division window
+    float x_ndc = 2.0f * rxm::div1_known(fx, P.fwidth, true) - 1.0f;
+    float y_ndc = 1.0f - 2.0f * rxm::div1_known(fy, P.fheight, true);
     float vx, vy, vz, vw;
     mat4_mul(P.inv_proj, x_ndc, y_ndc, z, 1.0f, vx, vy, vz, vw);
-    vx = vx / vw;
-    vy = vy / vw;
-    vz = vz / vw;
-    vw = vw / vw;
+    rxm::div3_self(vx, vy, vz, vw, vx, vy, vz, vw);
     float wx, wy, wz, ww;
     mat4_mul(P.inv_view, vx, vy, vz, vw, wx, wy, wz, ww);
     f3 world = mk3(wx, wy, wz);
     f3 cam = mk3(P.cam[0], P.cam[1], P.cam[2]);
-    f3 view_dir = norm3(sub3(cam, world));
+    f3 view_dir = norm3_fast(sub3(cam, world));
 
     f3 normal;
     if (B.flags & DB_HAS_NORMALS) {  // :1083-1099
@@ -442,15 +452,15 @@ __device__ __forceinline__ void shade3d_lights(const RasterParams &P, bool hit, 
                 // (lp - world).normalized(): |world - lp| and |lp - world| are the same float
                 if (!L.emitting) continue;
                 f3 d = sub3(lp, F.world);
-                float distance = mag3(d);
+                float distance;
+                ldir = norm3_fast(d, distance);
                 if (distance >= L.end_distance) continue;
                 float intensity = L.intensity;
                 if (!(distance <= L.start_distance)) intensity = L.intensity * smoothstep_rs(L.end_distance, L.start_distance, distance);
                 incoming = apply_flicker(L, intensity, P.hash_anim);
-                ldir = div3(d, distance);
             } else {
                 if (!light_color_at(L, F.world, P.hash_anim, false, incoming)) continue;
-                ldir = norm3(sub3(lp, F.world));
+                ldir = norm3_fast(sub3(lp, F.world));
             }
             f3 radiance;
             if (L.light_type == RXR_LIGHT_AMBIENT || L.light_type == RXR_LIGHT_AMBIENT_DAYLIGHT || L.light_type == RXR_LIGHT_DAYLIGHT) {
