@@ -949,6 +949,17 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
     P.n_linedefs = f->n_linedefs;
     P.n_prims2d = (uint32_t)p2cur;
     P.binned2d = binned2d ? 1u : 0u;
+    {
+        // tiles outside the union of the 2D pixel boxes skip the 2D pass without touching memory
+        uint32_t bx0 = 0xFFFFu, bx1 = 0, by0 = 0xFFFFu, by1 = 0;
+        for (size_t i = 0; i < p2cur; ++i) {
+            uint32_t a = p2[i].bx & 0xFFFFu, b = p2[i].bx >> 16, c = p2[i].by & 0xFFFFu, d = p2[i].by >> 16;
+            if (a < b && c < d) {
+                bx0 = std::min(bx0, a); bx1 = std::max(bx1, b); by0 = std::min(by0, c); by1 = std::max(by1, d);
+            }
+        }
+        P.d2_box[0] = bx0; P.d2_box[1] = bx1; P.d2_box[2] = by0; P.d2_box[3] = by1;
+    }
     P.list2d_capacity = ctx->list2d_capacity;
     P.any_lights = f->n_lights ? 1u : 0u;
     P.has_opacity = has_opacity ? 1u : 0u;

@@ -25,12 +25,42 @@
 // so the bins need not be sorted and overdraw is never shaded.
 #include <hip/hip_runtime.h>
 
+#include <cstring>
+
 #include "rxr_device.h"
 #include "rxr_exact_math.h"
 #include "rxr_project.h"
 
 #ifndef RXR_VEK_FUSED_MATVEC
 #define RXR_VEK_FUSED_MATVEC 1
+#endif
+
+// -DRXR_PHASE_TIMING=1 (tuning builds only): per-phase wave-cycle totals of the raster kernel, read with
+// rxr_debug_phase_read; see tools/phase_timing.py
+#ifndef RXR_PHASE_TIMING
+#define RXR_PHASE_TIMING 0
+#endif
+#if RXR_PHASE_TIMING
+__device__ unsigned long long g_phase[1024][16];  // spread over 1024 slots: same-address atomics would serialise
+#define PHASE_DECL unsigned long long ph_t = __builtin_readcyclecounter(), ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define PHASE_MARK(k)                                          \
+    do {                                                       \
+        unsigned long long now_ = __builtin_readcyclecounter(); \
+        ph_acc[k] += now_ - ph_t;                              \
+        ph_t = now_;                                           \
+    } while (0)
+#define PHASE_FLUSH                                                              \
+    do {                                                                         \
+        if ((threadIdx.x & 63u) == 0) {                                          \
+            unsigned slot_ = (blockIdx.x * 4u + (threadIdx.x >> 6)) & 1023u;                   \
+            for (int k_ = 0; k_ < 8; ++k_) atomicAdd(&g_phase[slot_][k_], ph_acc[k_]);   \
+            atomicAdd(&g_phase[slot_][8], 1ull);                                        \
+        }                                                                        \
+    } while (0)
+#else
+#define PHASE_DECL
+#define PHASE_MARK(k)
+#define PHASE_FLUSH
 #endif
 
 namespace {
@@ -939,9 +969,7 @@ __device__ __forceinline__ void scan_lists(const RasterParams &P, Stage &st, uin
                                            uint32_t tile_y0px, uint32_t px, uint32_t py, float fx, float fy, Vis &vis,
                                            int surf_profile) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    // small_mode 2 ("implicit list"): every triangle of the frame is a candidate, ids 0..n-1, no counters / lists
-    const bool implicit = P.fused_small == 2u;
-    const uint32_t n_large = implicit ? P.n_tris3d : min(P.counters[CNT_LARGE], P.n_tris3d);
+    const uint32_t n_large = min(P.counters[CNT_LARGE], P.n_tris3d);
     const uint32_t total = n_large + (b1 - b0);
     const float4 *g4 = reinterpret_cast<const float4 *>(P.tri_setup);
     for (uint32_t base = 0; base < total; base += RXR_STAGE_TRIS) {
@@ -951,7 +979,7 @@ __device__ __forceinline__ void scan_lists(const RasterParams &P, Stage &st, uin
         const uint32_t e = base + tid;
         if (tid < RXR_STAGE_TRIS && e < total) {
             if (e < n_large) {
-                id = implicit ? e : min(P.large_list[e], P.n_tris3d - 1u);
+                id = min(P.large_list[e], P.n_tris3d - 1u);
                 const uint2 box = *reinterpret_cast<const uint2 *>(&P.tri_setup[id].bx);
                 uint32_t min_x = box.x & 0xFFFFu, max_x = box.x >> 16, min_y = box.y & 0xFFFFu, max_y = box.y >> 16;
                 keep = !(min_x >= tile_x0 + RXR_TILE_W || max_x <= tile_x0 || min_y >= tile_y0px + RXR_TILE_H || max_y <= tile_y0px);
@@ -997,6 +1025,46 @@ __device__ __forceinline__ void scan_lists(const RasterParams &P, Stage &st, uin
         }
         __syncthreads();  // the stage is reused by the next round
     }
+}
+
+// Small-scene mode 2 ("implicit list": the whole frame has <= RXR_STAGE_TRIS triangles and k_setup3d has
+// written their records): no lists at all.  All records are copied to LDS with one round of coalesced
+// loads, THEN thread t tests record t against the tile from LDS and the survivors' indices are
+// ballot-compacted -- one global-memory latency per tile instead of three dependent ones.
+template <bool OPACITY>
+__device__ __forceinline__ void scan_implicit(const RasterParams &P, Stage &st, uint32_t tile_x0, uint32_t tile_y0px, uint32_t px, uint32_t py,
+                                              float fx, float fy, Vis &vis, int surf_profile) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t n_all = min(P.n_tris3d, (uint32_t)RXR_STAGE_TRIS);
+    const float4 *g4 = reinterpret_cast<const float4 *>(P.tri_setup);
+    for (uint32_t f = tid; f < n_all * 6u; f += RXR_TILE_THREADS) st.tri[f] = g4[f];
+    __syncthreads();
+    bool keep = false;
+    if (tid < n_all) {
+        const TriSetup &R = *reinterpret_cast<const TriSetup *>(&st.tri[tid * 6u]);
+        uint32_t min_x = R.bx & 0xFFFFu, max_x = R.bx >> 16, min_y = R.by & 0xFFFFu, max_y = R.by >> 16;
+        keep = !(min_x >= tile_x0 + RXR_TILE_W || max_x <= tile_x0 || min_y >= tile_y0px + RXR_TILE_H || max_y <= tile_y0px);
+        if (keep && tile_outside_edges(R.ea, R.eb, R.ec, tile_x0, tile_y0px)) keep = false;
+    }
+    const unsigned long long m = __ballot(keep);
+    const uint32_t before = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) st.wave_cnt[wave] = (uint32_t)__popcll(m);
+    __syncthreads();
+    uint32_t off = 0, n = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < RXR_TILE_THREADS / 64; ++w) {
+        uint32_t c = st.wave_cnt[w];
+        if (w < wave) off += c;
+        n += c;
+    }
+    if (keep) st.ids[off + before] = tid;
+    __syncthreads();
+    for (uint32_t k = 0; k < n; ++k) {
+        const uint32_t t = st.ids[k];
+        const TriSetup &S = *reinterpret_cast<const TriSetup *>(&st.tri[t * 6u]);
+        visit<OPACITY>(P, S, &P.tri_shade[t], t, t, px, py, fx, fy, vis, surf_profile);
+    }
+    __syncthreads();  // the stage is reused (second pass, 2D pass)
 }
 
 // Fused small-scene path (P.fused_small: the whole frame has <= RXR_STAGE_TRIS triangles, so one
@@ -1144,6 +1212,7 @@ __device__ __forceinline__ void raster_tile(const RasterParams &P) {
     const uint32_t py = tile_y0px + ly;
     const float fx = (float)px + 0.5f, fy = (float)py + 0.5f;  // rasterizer.rs:1022
     const bool in_frame = px < P.width && py >= P.row0 && py < P.row1;
+    PHASE_DECL;
 
     // tile initial colour: zeros | background colour | background shader (rasterizer.rs:277-308)
     uint32_t color = 0u;
@@ -1179,6 +1248,7 @@ __device__ __forceinline__ void raster_tile(const RasterParams &P) {
         uint32_t op_color = 0u;  // the opacity winner is shaded at once: the opaque pass rebuilds the stage
         if (P.has_opacity) {
             if constexpr (FUSED) scan_fused<true>(P, stage, shade_store.s, tile_x0, tile_y0px, px, py, fx, fy, op, -1);
+            else if (P.fused_small == 2u) scan_implicit<true>(P, stage, tile_x0, tile_y0px, px, py, fx, fy, op, -1);
             else scan_lists<true>(P, stage, b0, b1, tile_x0, tile_y0px, px, py, fx, fy, op, -1);
             if (op.best >= 0) {
                 const DevBatch &OB = P.batches3d[op.batch];
@@ -1192,9 +1262,12 @@ __device__ __forceinline__ void raster_tile(const RasterParams &P) {
         }
         Vis vis;
         vis.zmin = 1.0f; vis.best = -1; vis.alpha = 0.0f; vis.beta = 0.0f; vis.slot = 0; vis.batch = 0;
+        PHASE_MARK(0);
         if constexpr (FUSED) scan_fused<false>(P, stage, shade_store.s, tile_x0, tile_y0px, px, py, fx, fy, vis, surf_profile);
+        else if (P.fused_small == 2u) scan_implicit<false>(P, stage, tile_x0, tile_y0px, px, py, fx, fy, vis, surf_profile);
         else scan_lists<false>(P, stage, b0, b1, tile_x0, tile_y0px, px, py, fx, fy, vis, surf_profile);
 
+        PHASE_MARK(1);
         // resolve (rasterizer.rs:409-497): hit -> shaded colour; miss -> [0,0,0,255]
         const bool hit = vis.best >= 0;
         Frag F;
@@ -1206,8 +1279,11 @@ __device__ __forceinline__ void raster_tile(const RasterParams &P) {
             else HS = P.tri_shade[vis.best];
             shade3d_begin(P, HS, vis.batch, vis.alpha, vis.beta, vis.zmin, fx, fy, F);
         }
+        PHASE_MARK(2);
         if (P.n_lights) shade3d_lights(P, hit, F);  // wave-uniform call
+        PHASE_MARK(3);
         color = hit ? shade3d_end(F) : pack4(0u, 0u, 0u, 255u);
+        PHASE_MARK(4);
         if (op.best >= 0 && op.zmin < 1.0f && vis.zmin > op.zmin) {  // :464-495
             uint32_t src = op_color;
             float src_r = (float)(src & 0xFFu), src_g = (float)((src >> 8) & 0xFFu), src_b = (float)((src >> 16) & 0xFFu);
@@ -1224,11 +1300,36 @@ __device__ __forceinline__ void raster_tile(const RasterParams &P) {
         }
     }
 
-    if ((P.flags & RXR_FLAG_D2_ACTIVE) && P.n_prims2d) {  // rasterizer.rs:501-553, strictly in submission order
+    // rasterizer.rs:501-553, strictly in submission order.  Tiles that no 2D pixel box reaches skip the pass
+    // (a primitive only ever writes inside its box: :636-655, :1777-1821)
+    const bool d2_here = (P.flags & RXR_FLAG_D2_ACTIVE) && P.n_prims2d && tile_x0 < P.d2_box[1] && tile_x0 + RXR_TILE_W > P.d2_box[0] &&
+                         tile_y0px < P.d2_box[3] && tile_y0px + RXR_TILE_H > P.d2_box[2];
+    if (d2_here) {
         __syncthreads();  // the 3D pass is done with the stage
         if (!P.binned2d) {
-            // few primitives: the implicit ordered list 0..n-1 (every primitive carries its own pixel box)
-            color = walk_prims2d(P, stage, nullptr, P.n_prims2d, true, px, py, fx, fy, color);
+            // few primitives (<= RXR_STAGE_TRIS): thread t tests primitive t's pixel box against the tile, the
+            // survivors are ballot-compacted (which keeps submission order) and only they are staged
+            const uint32_t lane = tid & 63u, wave = tid >> 6;
+            bool keep = false;
+            if (tid < P.n_prims2d) {
+                const uint2 box = *reinterpret_cast<const uint2 *>(&P.prim2d[tid].bx);
+                uint32_t min_x = box.x & 0xFFFFu, max_x = box.x >> 16, min_y = box.y & 0xFFFFu, max_y = box.y >> 16;
+                keep = !(min_x >= tile_x0 + RXR_TILE_W || max_x <= tile_x0 || min_y >= tile_y0px + RXR_TILE_H || max_y <= tile_y0px);
+            }
+            const unsigned long long m = __ballot(keep);
+            const uint32_t before = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            if (lane == 0) stage.wave_cnt[wave] = (uint32_t)__popcll(m);
+            __syncthreads();
+            uint32_t off = 0, n = 0;
+#pragma unroll
+            for (uint32_t w = 0; w < RXR_TILE_THREADS / 64; ++w) {
+                uint32_t c = stage.wave_cnt[w];
+                if (w < wave) off += c;
+                n += c;
+            }
+            if (keep) stage.ids[off + before] = tid;
+            __syncthreads();
+            if (n) color = walk_prims2d(P, stage, stage.ids, n, false, px, py, fx, fy, color);
         } else {
             // candidates = [large 2D primitives whose box touches the tile] ++ [this tile's bin list], gathered
             // into LDS, sorted by primitive index (submission order), then staged and applied in order
@@ -1308,15 +1409,34 @@ __device__ __forceinline__ void raster_tile(const RasterParams &P) {
         }
     }
 
+    PHASE_MARK(5);
     if (in_frame) {
         const int64_t row = P.compact ? (int64_t)(ty * RXR_TILE_H + ly) : (int64_t)py - P.out_base_row;
         P.out[(size_t)row * P.out_row_stride + px] = color;
     }
+    PHASE_MARK(6);
+    PHASE_FLUSH;
 }
 
 // two instantiations so that each path gets its own register allocation
 extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_RASTER_WAVES_PER_SIMD) k_raster(RasterParams P) { raster_tile<false>(P); }
 extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_RASTER_WAVES_PER_SIMD) k_raster_fused(RasterParams P) { raster_tile<true>(P); }
+
+#if RXR_PHASE_TIMING
+extern "C" int rxr_debug_phase_read(unsigned long long *out16, int reset) {
+    static unsigned long long h[1024][16];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase), sizeof(h)) != hipSuccess) return -1;
+    for (int k = 0; k < 16; ++k) {
+        out16[k] = 0;
+        for (int i = 0; i < 1024; ++i) out16[k] += h[i][k];
+    }
+    if (reset) {
+        memset(h, 0, sizeof(h));
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase), h, sizeof(h)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 // ---- host-callable launchers (used by rxr_api.hip) ------------------------------------------------
 extern "C" void rxr_launch_setup(const RasterParams *P, hipStream_t s) {

@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Per-phase wave-cycle breakdown of the raster kernel.  Needs a library built with -DRXR_PHASE_TIMING=1
+(tuning build, see tools/try_variants.sh); renders the bench frame a few times and prints the share of
+wave lifetime spent in each phase (s_memtime deltas summed over waves)."""
+import argparse
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import rusterix_amd  # noqa: E402
+from rusterix_amd import scenes  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--lights", type=int, default=16)
+ap.add_argument("--width", type=int, default=3840)
+ap.add_argument("--height", type=int, default=2160)
+ap.add_argument("--frames", type=int, default=5)
+a = ap.parse_args()
+prod = rusterix_amd.load()
+rxr = C.CDLL(rusterix_amd.lib_paths()["rxr"])
+cfg = scenes.map_scene(prod, width=a.width, height=a.height, n_lights=a.lights)
+scenes.render(cfg)
+out = (C.c_ulonglong * 16)()
+assert rxr.rxr_debug_phase_read(out, 1) == 0, "library was not built with -DRXR_PHASE_TIMING=1"
+import time
+t0 = time.time()
+for _ in range(a.frames):
+    scenes.render(cfg)
+print(f"wall per frame incl. host work: {(time.time() - t0) / a.frames * 1e3:.2f} ms")
+assert rxr.rxr_debug_phase_read(out, 1) == 0
+names = ["prologue", "visibility (lists+walk)", "shade begin", "lights", "shade end", "2D pass", "store", "-"]
+tot = sum(out[k] for k in range(8))
+waves = out[8]
+print(f"lights={a.lights} waves={waves} cycles/wave={tot / max(waves, 1):.0f}")
+for k in range(7):
+    print(f"  {names[k]:26s} {out[k] / max(waves, 1):9.0f} cyc/wave  {100.0 * out[k] / max(tot, 1):5.1f} %")
