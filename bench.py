@@ -176,6 +176,7 @@ def main():
         rows_this_rank = min(stripe_rows, H) if sharded else H
         alg = algorithmic_bytes(W, rows_this_rank, n_verts, n_tris, tex_bytes, args.lights)
         achieved = alg / (raster_avg_us * 1e-6) / 1e9
+        default_workload = (W, H, args.lights, world) == (3840, 2160, 16, 1)
         out = {
             "metric": "Mpixels/s (+ ms/frame) on rasterize_map @3840x2160, 1/2/4/8 MI355X vs CPU",
             "value": round(value, 2),
@@ -204,14 +205,21 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6),
-                "traffic": None,
+                # HBM bytes of one launch from the rocprofv3 PMC passes of this same command (FETCH_SIZE with the
+                # gfx950 x2 correction + WRITE_SIZE; profiles/r01/e_bench_pmc_summary.json); only known for the
+                # default workload
+                "traffic": MEASURED_TRAFFIC_4K["fetch_x2"] + MEASURED_TRAFFIC_4K["write"] if default_workload else None,
                 "algorithmic_bytes_per_launch": int(alg),
                 "kernel_avg_us": round(raster_avg_us, 2),
                 "setup_kernels_avg_us": round(setup_avg_us, 2),
-                "measured_traffic_bytes_4k_1gpu": {"WRITE_SIZE": 33177600, "FETCH_SIZE_x2": 4230000,
-                                                   "source": "profiles/r01 rocprofv3 --pmc passes (separate runs)"},
-                "note": "fp32-VALU-bound path: algorithmic HBM traffic is ~4.5 B/pixel (DESIGN.md section 6); "
-                        "218.6 M VALU wave-instructions per 4K launch = ~63 % of VALU issue peak",
+                "measured_traffic_bytes_4k_1gpu": MEASURED_TRAFFIC_4K,
+                "valu": {
+                    "note": "the kernel is fp32-VALU bound, not HBM bound: algorithmic HBM traffic is ~4.5 B/pixel "
+                            "(DESIGN.md section 6)",
+                    "wave_instructions_per_launch_4k": MEASURED_VALU_4K,
+                    "issue_cycles_per_launch_4k": VALU_ISSUE_CYCLES_4K,
+                    "frac_of_simd_cycles": round(VALU_ISSUE_CYCLES_4K / (1024 * 2.4e3 * raster_avg_us), 3) if default_workload else None,
+                },
             },
         }
         if world == 1 and not args.no_cpu:
@@ -221,6 +229,15 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+# rocprofv3 PMC passes of `python3 bench.py` (3840x2160, 16 lights, 1 GPU), per k_raster launch:
+# profiles/r01/e_bench_pmc_summary.json
+MEASURED_TRAFFIC_4K = {"write": 33177600, "fetch_x2": 2241053, "source": "profiles/r01/e_bench_pmc_summary.json"}
+MEASURED_VALU_4K = 155934525
+# the same instructions priced with the measured issue costs of tools/microbench/valu_rates.hip
+# (fma/mul/add 2 cycles, compares / selects / conversions / min / max 4, rcp / sqrt / log / exp 8 per wave64)
+VALU_ISSUE_CYCLES_4K = int(71.6e6 * 2 + 5.78e6 * 8 + (155.93e6 - 71.6e6 - 5.78e6) * 3.3)
 
 
 def scene_counts(cfg, api):
