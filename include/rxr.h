@@ -251,6 +251,68 @@ typedef struct rxr_frame {
                                          NULL = the transforms given to rxr_set_meshes                */
 } rxr_frame;
 
+/* ---- Rusteria shader programs -------------------------------------
+ * A program is handed over as the reference's NodeOp tree (rusteria/src/node/nodeop.rs:12-103),
+ * serialised depth-first into 32-bit words; opcodes are the NodeOp variants in declaration order:
+ *   node := opcode [payload]
+ *   LoadGlobal / StoreGlobal / LoadLocal / StoreLocal : index
+ *   GetComponents / SetComponents                     : n, then n component indices (one per word)
+ *   If                                                : then_len, has_else, else_len, then-block, else-block
+ *   For                                               : init_len, cond_len, incr_len, body_len, the four blocks
+ *   Push                                              : the f32 bits of x, y, z
+ *   FunctionCall                                      : arity, total_locals, function index
+ *   every other variant                               : no payload
+ * (block lengths in words).  The library flattens the tree into jump code for the device. */
+enum {
+    RXR_NODE_LOAD_GLOBAL = 0, RXR_NODE_STORE_GLOBAL, RXR_NODE_LOAD_LOCAL, RXR_NODE_STORE_LOCAL, RXR_NODE_SWAP,
+    RXR_NODE_GET_COMPONENTS, RXR_NODE_SET_COMPONENTS, RXR_NODE_IF, RXR_NODE_FOR, RXR_NODE_PUSH, RXR_NODE_FUNCTION_CALL,
+    RXR_NODE_RETURN, RXR_NODE_DUP, RXR_NODE_CLEAR, RXR_NODE_PACK2, RXR_NODE_PACK3, RXR_NODE_ADD, RXR_NODE_SUB, RXR_NODE_MUL,
+    RXR_NODE_DIV, RXR_NODE_LENGTH, RXR_NODE_LENGTH2, RXR_NODE_LENGTH3, RXR_NODE_ABS, RXR_NODE_SIN, RXR_NODE_SIN1,
+    RXR_NODE_SIN2, RXR_NODE_COS, RXR_NODE_COS1, RXR_NODE_COS2, RXR_NODE_TAN, RXR_NODE_ATAN, RXR_NODE_ATAN2,
+    RXR_NODE_ROTATE2D, RXR_NODE_DOT, RXR_NODE_DOT2, RXR_NODE_DOT3, RXR_NODE_CROSS, RXR_NODE_NORMALIZE, RXR_NODE_FLOOR,
+    RXR_NODE_CEIL, RXR_NODE_ROUND, RXR_NODE_FRACT, RXR_NODE_MOD, RXR_NODE_DEGREES, RXR_NODE_RADIANS, RXR_NODE_MIN,
+    RXR_NODE_MAX, RXR_NODE_MIX, RXR_NODE_SMOOTHSTEP, RXR_NODE_STEP, RXR_NODE_CLAMP, RXR_NODE_SQRT, RXR_NODE_POW,
+    RXR_NODE_LOG, RXR_NODE_PRINT, RXR_NODE_EQ, RXR_NODE_NE, RXR_NODE_LT, RXR_NODE_LE, RXR_NODE_GT, RXR_NODE_GE,
+    RXR_NODE_AND, RXR_NODE_OR, RXR_NODE_NOT, RXR_NODE_NEG, RXR_NODE_UV, RXR_NODE_SET_UV, RXR_NODE_NORMAL,
+    RXR_NODE_SET_NORMAL, RXR_NODE_HITPOINT, RXR_NODE_TIME, RXR_NODE_SAMPLE, RXR_NODE_SAMPLE_NORMAL, RXR_NODE_COLOR,
+    RXR_NODE_SET_COLOR, RXR_NODE_ROUGHNESS, RXR_NODE_SET_ROUGHNESS, RXR_NODE_METALLIC, RXR_NODE_SET_METALLIC,
+    RXR_NODE_EMISSIVE, RXR_NODE_SET_EMISSIVE, RXR_NODE_OPACITY, RXR_NODE_SET_OPACITY, RXR_NODE_BUMP, RXR_NODE_SET_BUMP,
+    RXR_NODE_ALLOC, RXR_NODE_ITERATE, RXR_NODE_SAVE, RXR_NODE_PALETTE_INDEX, RXR_NODE_COUNT
+};
+
+/* one user function: Arc<[NodeOp]> (rusteria/src/node/program.rs:15) */
+typedef struct rxr_function {
+    const uint32_t *words;
+    uint32_t n_words;
+} rxr_function;
+
+/* rusteria::Program (rusteria/src/node/program.rs:7-29); `body` and `strings` are not read by the raster path */
+typedef struct rxr_program {
+    uint32_t n_globals;               /* Program.globals                                            */
+    int32_t shade_index;              /* Program.shade_index; -1 = None (the batch then shades as if it had no shader) */
+    uint32_t shade_locals;            /* Program.shade_locals                                       */
+    const rxr_function *functions;    /* Program.user_functions                                     */
+    uint32_t n_functions;
+} rxr_program;
+
+/* TexStorage of the global pattern bank (rusteria/src/textures/mod.rs:10-15): width*height RGB f32 */
+typedef struct rxr_pattern {
+    const float *rgb;
+    uint32_t width, height;
+} rxr_pattern;
+
+typedef struct rxr_shader_set {
+    const rxr_program *programs;      /* scene.shaders (src/scene.rs:43), indexed by rxr_batch*.shader */
+    uint32_t n_programs;
+    const rxr_pattern *patterns;      /* rusteria::textures::patterns::patterns(), read by NodeOp::Sample */
+    uint32_t n_patterns;
+    const rxr_pattern *normal_patterns; /* patterns_normal(), read by NodeOp::SampleNormal          */
+    uint32_t n_normal_patterns;
+    const float *palette_rgb;         /* assets.palette.colors as [n][3] (TheColor::to_vec3)        */
+    const uint8_t *palette_present;   /* [n]: 0 where the palette slot is None                      */
+    uint32_t n_palette;
+} rxr_shader_set;
+
 /* timings of the last rendered frame (HIP events on the context's stream), microseconds */
 typedef struct rxr_stats {
     float setup_us;      /* triangle set-up + binning kernels */
@@ -290,6 +352,14 @@ int rxr_set_meshes(rxr_ctx *ctx, const rxr_mesh3d *meshes, uint32_t n_meshes);
 int rxr_read_projected_mesh(rxr_ctx *ctx, uint32_t index, uint32_t counts[2], float *projected_vertices, float *clipped_uvs,
                             float *clipped_normals, uint32_t *clipped_indices, rxr_edges *edges, float bounding_box[5],
                             uint32_t capacity_vertices, uint32_t capacity_triangles);
+
+/* replaces the context's shader programs, pattern bank and palette (stay resident until the next call;
+ * NULL or an empty set removes them).  Programs are restricted to what a per-fragment evaluation can
+ * reproduce: RXR_ERR_UNSUPPORTED for Alloc / Iterate / Save, for SetEmissive (the
+ * reference leaks it into every later fragment of the tile), for a global read before it is written in
+ * the same invocation and for Return inside For (the reference unwinds that incorrectly).
+ * Replaces: Execution::shade per fragment, src/rasterizer.rs:760-800, :1283-1304, :1642-1667. */
+int rxr_set_shaders(rxr_ctx *ctx, const rxr_shader_set *set);
 
 /* validates + flattens a projected frame and copies it to HBM (replaces nothing in the reference:
  * it is the host->device hand-over).  The frame stays resident until the next upload. */

@@ -71,6 +71,28 @@ void orc_chunk_add_occluder(void *s, int chunk, float minx, float miny, float ma
     ((Scene *)s)->chunks[chunk].occluded_sectors.push_back(Occluder{{minx, miny}, {maxx, maxy}, occ});
 }
 void orc_chunk_add_light(void *s, int chunk, const rxr_light *l) { ((Scene *)s)->chunks[chunk].lights.push_back(*l); }
+// scene.add_shader (src/scene.rs:104-134) minus the parser / compiler: the program arrives as NodeOp trees
+// in the word serialisation of include/rxr.h.  chunk < 0: scene.shaders, else that chunk's shaders.
+int orc_scene_add_program(void *s, int chunk, uint32_t n_globals, int32_t shade_index, uint32_t shade_locals,
+                          const uint32_t *const *fn_words, const uint32_t *fn_lens, uint32_t n_functions) {
+    Scene *sc = (Scene *)s;
+    vm::Program p;
+    p.globals = n_globals;
+    p.shade_index = shade_index;
+    p.shade_locals = shade_locals;
+    for (uint32_t i = 0; i < n_functions; ++i) {
+        std::vector<vm::NodeOp> code;
+        if (!vm::parse_block(fn_words[i], fn_lens[i], code)) return RXR_ERR_INVALID;
+        p.user_functions.push_back(std::move(code));
+    }
+    std::vector<vm::Program> *dst = &sc->shaders;
+    if (chunk >= 0) {
+        if ((size_t)chunk >= sc->chunks.size()) return RXR_ERR_INVALID;
+        dst = &sc->chunks[chunk].shaders;
+    }
+    dst->push_back(std::move(p));
+    return (int)dst->size() - 1;
+}
 uint32_t orc_scene_num_dynamic_lights(void *s) { return (uint32_t)((Scene *)s)->dynamic_lights.size(); }
 
 // ---- Batch3D --------------------------------------------------------------------------------------
@@ -168,6 +190,52 @@ void *orc_assets_new() { return new Assets(); }
 void orc_assets_free(void *a) { delete (Assets *)a; }
 void orc_assets_add_tile(void *a, const uint8_t *const *frames, const uint32_t *ws, const uint32_t *hs, uint32_t n) {
     ((Assets *)a)->tile_list.push_back(make_tile(frames, ws, hs, n));
+}
+
+// rusteria's global pattern banks (textures/patterns.rs) and assets.palette, as data
+void orc_assets_set_patterns(void *a, int normal, const float *const *rgb, const uint32_t *ws, const uint32_t *hs, uint32_t n) {
+    std::vector<vm::TexStorage> &dst = normal ? ((Assets *)a)->vm_env.patterns_normal : ((Assets *)a)->vm_env.patterns;
+    dst.clear();
+    for (uint32_t i = 0; i < n; ++i) {
+        vm::TexStorage t;
+        t.width = ws[i];
+        t.height = hs[i];
+        t.data.resize((size_t)ws[i] * hs[i]);
+        for (size_t k = 0; k < t.data.size(); ++k) t.data[k] = Vec3{rgb[i][3 * k], rgb[i][3 * k + 1], rgb[i][3 * k + 2]};
+        dst.push_back(std::move(t));
+    }
+}
+void orc_assets_set_palette(void *a, const float *rgb3, const uint8_t *present, uint32_t n) {
+    vm::Env &e = ((Assets *)a)->vm_env;
+    e.palette_rgb.clear();
+    e.palette_present.clear();
+    for (uint32_t i = 0; i < n; ++i) {
+        e.palette_rgb.push_back(Vec3{rgb3[3 * i], rgb3[3 * i + 1], rgb3[3 * i + 2]});
+        e.palette_present.push_back(present ? present[i] : 1);
+    }
+}
+// one invocation of Execution::shade on a fresh Execution with the given inputs (tests/test_oracle_vm.py):
+// in/out = uv, color, roughness, metallic, emissive, opacity, bump, normal, hitpoint, time (10 x 3 floats)
+int orc_vm_shade(void *s, void *a, int program, float *fields30) {
+    Scene *sc = (Scene *)s;
+    if (program < 0 || (size_t)program >= sc->shaders.size()) return RXR_ERR_INVALID;
+    const vm::Program &p = sc->shaders[program];
+    if (p.shade_index < 0) return RXR_ERR_INVALID;
+    vm::Execution ex(0);
+    Vec3 *f[10] = {&ex.uv, &ex.color, &ex.roughness, &ex.metallic, &ex.emissive, &ex.opacity, &ex.bump, &ex.normal, &ex.hitpoint, &ex.time};
+    for (int i = 0; i < 10; ++i) *f[i] = Vec3{fields30[3 * i], fields30[3 * i + 1], fields30[3 * i + 2]};
+    ex.reset(p.globals);
+    try {
+        ex.shade((size_t)p.shade_index, p, ((Assets *)a)->vm_env);
+    } catch (const vm::Fault &) {
+        return RXR_ERR_INVALID;
+    }
+    for (int i = 0; i < 10; ++i) {
+        fields30[3 * i] = f[i]->x;
+        fields30[3 * i + 1] = f[i]->y;
+        fields30[3 * i + 2] = f[i]->z;
+    }
+    return 0;
 }
 
 // ---- Rasterizer -----------------------------------------------------------------------------------

@@ -679,12 +679,10 @@ struct TileRect {  // src/rasterizer.rs:2013-2019
     size_t x, y, width, height;
 };
 
-// rusteria Execution fields the no-shader path routes material values through
-// (rusteria/src/node/execution.rs:8-107; src/rasterizer.rs:1305-1323).  One per tile (:310).
-struct Execution {
-    Vec3 color{0, 0, 0}, normal{0, 0, 0}, emissive{0, 0, 0};
-    float roughness_x = 0, metallic_x = 0, opacity_x = 0;
-};
+// One rusteria Execution per tile (:310), shared by every fragment of the tile: state a shader leaves
+// behind (emissive, globals, the components the raster loops do not overwrite) leaks into the following
+// fragments exactly as in the reference.
+using vm::Execution;
 
 struct FrameCtx {
     const Rasterizer *r;
@@ -889,20 +887,39 @@ static int d3_rasterize(const FrameCtx &fc, uint8_t *buffer, float *z_buffer, co
                 float color[4];
                 pixel_to_vec4(texel, color);
 
-                // no-shader branch :1305-1317 (a shader index that resolves to no program behaves the same, :1268-1304)
+                // :1226-1317.  chunk.shader_textures (baked shader textures) are not modelled: with None the
+                // reference takes the branch below
                 color[0] = srgb_to_linear_fast(color[0]);
                 color[1] = srgb_to_linear_fast(color[1]);
                 color[2] = srgb_to_linear_fast(color[2]);
                 execution.color = Vec3{color[0], color[1], color[2]};
-                execution.opacity_x = (float)texel[3] / 255.0f;
+                execution.opacity.x = (float)texel[3] / 255.0f;
                 execution.normal = normal;
-                execution.roughness_x = 0.5f;
-                execution.metallic_x = 0.0f;
+                execution.roughness.x = 0.5f;
+                execution.metallic.x = 0.0f;
+                if (batch.shader >= 0) {  // :1283-1304
+                    const std::vector<vm::Program> &progs = chunk ? chunk->shaders : fc.scene->shaders;
+                    if ((size_t)batch.shader < progs.size()) {
+                        const vm::Program &program = progs[(size_t)batch.shader];
+                        if (program.shade_index >= 0) {
+                            execution.uv.x = interpolated_u / 4.0f;
+                            execution.uv.y = interpolated_v / 4.0f;
+                            execution.hitpoint = world;
+                            execution.time = Vec3{r.time, r.time, r.time};
+                            execution.reset(program.globals);
+                            try {
+                                execution.shade((size_t)program.shade_index, program, fc.assets->vm_env);
+                            } catch (const vm::Fault &) {
+                                return RXR_ERR_INVALID;
+                            }
+                        }
+                    }
+                }
 
                 Vec3 mat_base = execution.color;  // :1319-1323
                 normal = rvek::normalized(execution.normal);
-                float mat_roughness = rclamp(execution.roughness_x, 0.0f, 1.0f);
-                float mat_metallic = rclamp(execution.metallic_x, 0.0f, 1.0f);
+                float mat_roughness = rclamp(execution.roughness.x, 0.0f, 1.0f);
+                float mat_metallic = rclamp(execution.metallic.x, 0.0f, 1.0f);
                 Vec3 mat_emissive = execution.emissive;
 
                 Vec3 lit{0, 0, 0};
@@ -948,7 +965,7 @@ static int d3_rasterize(const FrameCtx &fc, uint8_t *buffer, float *z_buffer, co
                 color[0] = linear_to_srgb_fast(lit.x);
                 color[1] = linear_to_srgb_fast(lit.y);
                 color[2] = linear_to_srgb_fast(lit.z);
-                color[3] = execution.opacity_x;
+                color[3] = execution.opacity.x;
                 vec4_to_pixel(color, texel);
 
                 if (texel[3] == 255) {  // :1408-1412
@@ -1014,12 +1031,35 @@ static int d3_rasterize_opacity(const FrameCtx &fc, uint8_t *buffer, float *z_bu
                 color[1] = srgb_to_linear_fast(color[1]);
                 color[2] = srgb_to_linear_fast(color[2]);
                 execution.color = Vec3{color[0], color[1], color[2]};
-                execution.opacity_x = (float)texel[3] / 255.0f;
+                execution.opacity.x = (float)texel[3] / 255.0f;
+
+                if (batch.shader >= 0) {  // :1642-1667
+                    const std::vector<vm::Program> &progs = chunk ? chunk->shaders : fc.scene->shaders;
+                    if ((size_t)batch.shader < progs.size()) {
+                        const vm::Program &program = progs[(size_t)batch.shader];
+                        if (program.shade_index >= 0) {
+                            Vec3 world = screen_to_world(*fc.r, p[0], p[1], z);  // :1515
+                            execution.normal = Vec3{0, 0, 0};
+                            execution.uv.x = interpolated_u / 4.0f;
+                            execution.uv.y = interpolated_v / 4.0f;
+                            execution.hitpoint = world;
+                            execution.time = Vec3{fc.r->time, fc.r->time, fc.r->time};
+                            execution.roughness.x = 0.5f;
+                            execution.metallic.x = 0.0f;
+                            execution.reset(program.globals);
+                            try {
+                                execution.shade((size_t)program.shade_index, program, fc.assets->vm_env);
+                            } catch (const vm::Fault &) {
+                                return RXR_ERR_INVALID;
+                            }
+                        }
+                    }
+                }
 
                 color[0] = linear_to_srgb_fast(execution.color.x);  // :1670-1674
                 color[1] = linear_to_srgb_fast(execution.color.y);
                 color[2] = linear_to_srgb_fast(execution.color.z);
-                color[3] = execution.opacity_x;
+                color[3] = execution.opacity.x;
                 vec4_to_pixel(color, texel);
 
                 memcpy(buffer + zidx * 4, texel, 4);  // :1678-1682
@@ -1061,7 +1101,7 @@ static void rasterize_line_bresenham(const float p0[2], const float p1[2], uint8
 
 // ---- src/rasterizer.rs:584-959 ---------------------------------------------------------------
 static int d2_rasterize(const FrameCtx &fc, uint8_t *buffer, const TileRect &tile, const Batch2D &batch,
-                        const Chunk *chunk) {
+                        const Chunk *chunk, Execution &execution) {
     const Rasterizer &r = *fc.r;
     if (!batch.has_bounding_box) return 0;
     const Rect &bbox = batch.bounding_box;
@@ -1114,6 +1154,36 @@ static int d2_rasterize(const FrameCtx &fc, uint8_t *buffer, const TileRect &til
                         uint8_t texel[4];
                         if (!fetch_texel(fc, batch.source, batch.repeat_mode, u, v, false, chunk != nullptr, texel))
                             return RXR_ERR_INVALID;
+
+                        if (batch.shader >= 0) {  // :760-797
+                            const std::vector<vm::Program> &progs = chunk ? chunk->shaders : fc.scene->shaders;
+                            if ((size_t)batch.shader < progs.size()) {
+                                const vm::Program &program = progs[(size_t)batch.shader];
+                                if (program.shade_index >= 0) {
+                                    float color[4];
+                                    pixel_to_vec4(texel, color);
+                                    execution.uv.x = u / 4.0f;
+                                    execution.uv.y = v / 4.0f;
+                                    execution.color = Vec3{color[0], color[1], color[2]};
+                                    execution.hitpoint.x = world.x;
+                                    execution.hitpoint.y = world.y;
+                                    execution.time = Vec3{r.time, r.time, r.time};
+                                    execution.roughness.x = 0.5f;
+                                    execution.metallic.x = 0.0f;
+                                    execution.reset(program.globals);
+                                    try {
+                                        execution.shade((size_t)program.shade_index, program, fc.assets->vm_env);
+                                    } catch (const vm::Fault &) {
+                                        return RXR_ERR_INVALID;
+                                    }
+                                    color[0] = execution.color.x;
+                                    color[1] = execution.color.y;
+                                    color[2] = execution.color.z;
+                                    color[3] = 1.0f;
+                                    vec4_to_pixel(color, texel);
+                                }
+                            }
+                        }
 
                         // :799-803 (operator precedence: `a && b || c`)
                         if ((batch.receives_light && fc.any_lights) || r.has_ambient) {
@@ -1272,11 +1342,11 @@ static int raster_tile(const FrameCtx &fc, const TileRect &tile, std::vector<uin
     if (r.d2_active) {  // :501-553
         for (const Chunk &chunk : scene.chunks)
             for (const Batch2D &b : chunk.batches2d)
-                if ((rc = d2_rasterize(fc, buffer.data(), tile, b, &chunk))) return rc;
+                if ((rc = d2_rasterize(fc, buffer.data(), tile, b, &chunk, execution))) return rc;
         for (const Batch2D &b : scene.d2_static)
-            if ((rc = d2_rasterize(fc, buffer.data(), tile, b, nullptr))) return rc;
+            if ((rc = d2_rasterize(fc, buffer.data(), tile, b, nullptr, execution))) return rc;
         for (const Batch2D &b : scene.d2_dynamic)
-            if ((rc = d2_rasterize(fc, buffer.data(), tile, b, nullptr))) return rc;
+            if ((rc = d2_rasterize(fc, buffer.data(), tile, b, nullptr, execution))) return rc;
     }
     return 0;
 }

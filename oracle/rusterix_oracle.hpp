@@ -22,6 +22,7 @@
 
 #include "../include/rusterix_vek.hpp"
 #include "../include/rxr.h"  // enum values + rxr_light POD (data layout only)
+#include "rusteria_vm.hpp"
 
 namespace orc {
 
@@ -107,9 +108,11 @@ struct Texture {
 struct Tile {
     std::vector<Texture> textures;
 };
-// src/server/assets.rs (only `tile_list`)
+// src/server/assets.rs (only `tile_list` and `palette`); `vm_env` also carries rusteria's process-global
+// pattern banks (rusteria/src/textures/patterns.rs) so that tests can supply their own
 struct Assets {
     std::vector<Tile> tile_list;
+    vm::Env vm_env;
 };
 
 enum CullMode { CullOff = 0, CullFront = 1, CullBack = 2 };  // src/batch/mod.rs:17-26
@@ -178,6 +181,7 @@ struct Chunk {
     std::vector<Batch2D> batches2d;
     std::vector<CompiledLight> lights;
     std::vector<Occluder> occluded_sectors;
+    std::vector<vm::Program> shaders;  // src/chunk.rs:51
 };
 
 // src/scene.rs:8-50
@@ -190,6 +194,7 @@ struct Scene {
     std::vector<Tile> dynamic_textures;
     size_t animation_frame = 1;  // src/scene.rs:72
     std::vector<Chunk> chunks;   // FxHashMap in the reference; here: the host's iteration order
+    std::vector<vm::Program> shaders;  // src/scene.rs:43
 };
 
 // src/rasterizer.rs:35-88

@@ -258,6 +258,71 @@ class VGrayGradientShader:
     kind = BG_VGRADIENT
 
 
+# ---- Rusteria programs (reference rusteria/src/node/{nodeop,program}.rs) -------------------------------
+# NodeOp variants in declaration order = the RXR_NODE_* opcodes of include/rxr.h
+NODE_OPS = [
+    "LoadGlobal", "StoreGlobal", "LoadLocal", "StoreLocal", "Swap", "GetComponents", "SetComponents", "If", "For", "Push",
+    "FunctionCall", "Return", "Dup", "Clear", "Pack2", "Pack3", "Add", "Sub", "Mul", "Div", "Length", "Length2", "Length3",
+    "Abs", "Sin", "Sin1", "Sin2", "Cos", "Cos1", "Cos2", "Tan", "Atan", "Atan2", "Rotate2D", "Dot", "Dot2", "Dot3", "Cross",
+    "Normalize", "Floor", "Ceil", "Round", "Fract", "Mod", "Degrees", "Radians", "Min", "Max", "Mix", "Smoothstep", "Step",
+    "Clamp", "Sqrt", "Pow", "Log", "Print", "Eq", "Ne", "Lt", "Le", "Gt", "Ge", "And", "Or", "Not", "Neg", "UV", "SetUV",
+    "Normal", "SetNormal", "Hitpoint", "Time", "Sample", "SampleNormal", "Color", "SetColor", "Roughness", "SetRoughness",
+    "Metallic", "SetMetallic", "Emissive", "SetEmissive", "Opacity", "SetOpacity", "Bump", "SetBump", "Alloc", "Iterate",
+    "Save", "PaletteIndex",
+]
+NODE_OPCODE = {n: i for i, n in enumerate(NODE_OPS)}
+
+
+def assemble(ops):
+    """NodeOp tree -> the word serialisation of include/rxr.h.  An op is a name ("Add") or a tuple:
+    ("Push", x, y, z) | ("Push", x) (splat) | ("LoadLocal", i) | ("GetComponents", [0, 1]) |
+    ("If", then_ops, else_ops_or_None) | ("For", init, cond, incr, body) | ("FunctionCall", arity, total_locals, index)."""
+    out = []
+    for op in ops:
+        if isinstance(op, str):
+            op = (op,)
+        name, args = op[0], op[1:]
+        code = NODE_OPCODE[name]
+        out.append(code)
+        if name in ("LoadGlobal", "StoreGlobal", "LoadLocal", "StoreLocal"):
+            out.append(int(args[0]))
+        elif name in ("GetComponents", "SetComponents"):
+            out.append(len(args[0]))
+            out.extend(int(c) for c in args[0])
+        elif name == "If":
+            t = assemble(args[0])
+            e = assemble(args[1]) if len(args) > 1 and args[1] is not None else []
+            out.extend([len(t), 1 if (len(args) > 1 and args[1] is not None) else 0, len(e)])
+            out.extend(t)
+            out.extend(e)
+        elif name == "For":
+            blocks = [assemble(b) for b in args]
+            assert len(blocks) == 4
+            out.extend(len(b) for b in blocks)
+            for b in blocks:
+                out.extend(b)
+        elif name == "Push":
+            v = args if len(args) == 3 else (args[0],) * 3
+            out.extend(int(x) for x in np.asarray(v, np.float32).view(np.uint32))
+        elif name == "FunctionCall":
+            out.extend(int(a) for a in args)
+        else:
+            assert not args, f"{name} takes no payload"
+    return out
+
+
+class Program:
+    """reference rusteria/src/node/program.rs:7-29: user functions (NodeOp trees), the index of `shade`, its
+    local count and the number of globals.  There is no parser / compiler here (out of scope): programs are
+    given as op lists, see `assemble`."""
+
+    def __init__(self, functions, shade_index=0, shade_locals=0, globals=0):
+        self.functions = [assemble(f) for f in functions]
+        self.shade_index = -1 if shade_index is None else int(shade_index)
+        self.shade_locals = int(shade_locals)
+        self.globals = int(globals)
+
+
 def make_api(lib: C.CDLL, prefix: str, name: str):
     """Build Scene/Batch3D/... classes bound to `lib`'s `<prefix>*` entry points."""
 
@@ -282,6 +347,9 @@ def make_api(lib: C.CDLL, prefix: str, name: str):
         chunk_add_occluder=fn("chunk_add_occluder", None, vp, i32, f32, f32, f32, f32, f32),
         chunk_add_light=fn("chunk_add_light", None, vp, i32, C.POINTER(RxrLight)),
         scene_num_dynamic_lights=fn("scene_num_dynamic_lights", u32, vp),
+        scene_add_program=fn("scene_add_program", i32, vp, i32, u32, i32, u32, C.POINTER(pu), pu, u32),
+        assets_set_patterns=fn("assets_set_patterns", None, vp, i32, C.POINTER(pf), pu, pu, u32),
+        assets_set_palette=fn("assets_set_palette", None, vp, pf, pb, u32),
         batch3d_new=fn("batch3d_new", vp, pf, u32, pu, u32, pf),
         batch3d_from_box=fn("batch3d_from_box", vp, f32, f32, f32, f32, f32, f32),
         batch3d_from_obj=fn("batch3d_from_obj", vp, C.c_char_p),
@@ -568,6 +636,17 @@ def make_api(lib: C.CDLL, prefix: str, name: str):
         def add_chunk(self):
             return Chunk(self, L.scene_add_chunk(self._h))
 
+        def add_program(self, program: Program, chunk=-1):
+            """scene.add_shader (reference src/scene.rs:104-134) without the compiler; returns the shader index"""
+            n = len(program.functions)
+            arrs = [np.asarray(f, np.uint32) if len(f) else np.zeros(1, np.uint32) for f in program.functions]
+            ptrs = (pu * max(n, 1))(*[_up(a) for a in arrs])
+            lens = (C.c_uint32 * max(n, 1))(*[len(f) for f in program.functions])
+            idx = L.scene_add_program(self._h, chunk, program.globals, program.shade_index, program.shade_locals, ptrs, lens, n)
+            if idx < 0:
+                raise RasterizeError(f"add_program failed ({idx})")
+            return idx
+
         def num_dynamic_lights(self):
             return L.scene_num_dynamic_lights(self._h)
 
@@ -606,6 +685,29 @@ def make_api(lib: C.CDLL, prefix: str, name: str):
             for t in tiles:
                 frames, ws, hs, n = tile_args(t)
                 L.assets_add_tile(self._h, frames, ws, hs, n)
+            return self
+
+        def patterns(self, textures, normal=False):
+            """rusteria's global pattern bank (rusteria/src/textures/patterns.rs) as data: a list of float32
+            arrays of shape (h, w, 3); `normal=True` sets the bank NodeOp::SampleNormal reads"""
+            arrs = [_f32(t, (-1,)) for t in textures]
+            shapes = [np.asarray(t).shape for t in textures]
+            n = len(arrs)
+            ptrs = (pf * max(n, 1))(*[_fp(a) for a in arrs])
+            ws = (C.c_uint32 * max(n, 1))(*[sh[1] for sh in shapes])
+            hs = (C.c_uint32 * max(n, 1))(*[sh[0] for sh in shapes])
+            L.assets_set_patterns(self._h, 1 if normal else 0, ptrs, ws, hs, n)
+            return self
+
+        def palette(self, colors):
+            """assets.palette.colors: a list of (r, g, b) floats or None (empty slot)"""
+            rgb = np.zeros((max(len(colors), 1), 3), np.float32)
+            present = np.zeros(max(len(colors), 1), np.uint8)
+            for i, c in enumerate(colors):
+                if c is not None:
+                    rgb[i] = c
+                    present[i] = 1
+            L.assets_set_palette(self._h, _fp(rgb), _bp(present), len(colors))
             return self
 
     class Rasterizer:
@@ -751,5 +853,5 @@ def make_api(lib: C.CDLL, prefix: str, name: str):
         D3OrbitCamera=D3OrbitCamera, D3FirstPCamera=D3FirstPCamera,
         # shared value types
         Texture=Texture, Tile=Tile, Light=Light, PixelSource=PixelSource, RenderMode=RenderMode,
-        VGrayGradientShader=VGrayGradientShader, Mat4=Mat4, Mat3=Mat3,
+        VGrayGradientShader=VGrayGradientShader, Mat4=Mat4, Mat3=Mat3, Program=Program,
     )

@@ -19,7 +19,7 @@ def build_oracle():
 def load_oracle():
     global _cached
     if _cached is None:
-        srcs = [os.path.join(ORACLE_DIR, f) for f in ("rusterix_oracle.cpp", "oracle_capi.cpp", "rusterix_oracle.hpp")]
+        srcs = [os.path.join(ORACLE_DIR, f) for f in ("rusterix_oracle.cpp", "oracle_capi.cpp", "rusterix_oracle.hpp", "rusteria_vm.hpp")]
         if not os.path.exists(ORACLE_SO) or any(os.path.getmtime(s) > os.path.getmtime(ORACLE_SO) for s in srcs):
             build_oracle()
         lib = ctypes.CDLL(ORACLE_SO)
@@ -55,6 +55,23 @@ def _bind_leaf_functions(api, lib):
     lib.orc_edges_evaluate.argtypes = [pf, C.c_float, C.c_float]
     lib.orc_mat4_inverted.argtypes = [pf, pf]
     lib.orc_mat4_mul_vec4.argtypes = [pf, pf, pf]
+    lib.orc_vm_shade.restype = C.c_int
+    lib.orc_vm_shade.argtypes = [C.c_void_p, C.c_void_p, C.c_int, pf]
+
+    FIELDS = ["uv", "color", "roughness", "metallic", "emissive", "opacity", "bump", "normal", "hitpoint", "time"]
+
+    def vm_shade(scene, assets, program_index, **inputs):
+        """one Execution::shade on a fresh Execution; returns dict field -> (x, y, z), or None on a fault"""
+        f = np.zeros((10, 3), np.float32)
+        f[2] = 0.5  # Execution::new: roughness = broadcast(0.5)
+        for k, v in inputs.items():
+            f[FIELDS.index(k)] = v
+        rc = lib.orc_vm_shade(scene._h, assets._h, program_index, f.ctypes.data_as(pf))
+        if rc != 0:
+            return None
+        return {k: tuple(float(x) for x in f[i]) for i, k in enumerate(FIELDS)}
+
+    api.vm_shade = vm_shade
     lib.orc_rasterizer_set_threads.argtypes = [C.c_void_p, C.c_int]
     lib.orc_rasterizer_get_threads.restype = C.c_int
     lib.orc_rasterizer_get_threads.argtypes = [C.c_void_p]
