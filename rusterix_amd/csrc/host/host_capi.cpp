@@ -75,6 +75,22 @@ void rxh_chunk_add_occluder(void *s, int chunk, float minx, float miny, float ma
     ((Scene *)s)->chunks[chunk].occluded_sectors.push_back(rxr_occluder{{minx, miny}, {maxx, maxy}, occ});
 }
 void rxh_chunk_add_light(void *s, int chunk, const rxr_light *l) { ((Scene *)s)->chunks[chunk].lights.push_back(*l); }
+// scene.add_shader (src/scene.rs:104-134) minus the parser / compiler; chunk >= 0: that chunk's shaders
+int rxh_scene_add_program(void *s, int chunk, uint32_t n_globals, int32_t shade_index, uint32_t shade_locals,
+                          const uint32_t *const *fn_words, const uint32_t *fn_lens, uint32_t n_functions) {
+    Scene *sc = (Scene *)s;
+    Program p;
+    p.globals = n_globals;
+    p.shade_index = shade_index;
+    p.shade_locals = shade_locals;
+    for (uint32_t i = 0; i < n_functions; ++i) p.user_functions.emplace_back(fn_words[i], fn_words[i] + fn_lens[i]);
+    if (chunk >= 0) {
+        if ((size_t)chunk >= sc->chunks.size()) return RXR_ERR_INVALID;
+        sc->chunks[chunk].shaders.push_back(std::move(p));
+        return (int)sc->chunks[chunk].shaders.size() - 1;
+    }
+    return (int)sc->add_program(std::move(p));
+}
 uint32_t rxh_scene_num_dynamic_lights(void *s) { return (uint32_t)((Scene *)s)->dynamic_lights.size(); }
 
 // ---- Batch3D --------------------------------------------------------------------------------------
@@ -150,6 +166,27 @@ void rxh_assets_add_tile(void *a, const uint8_t *const *frames, const uint32_t *
     Assets *as = (Assets *)a;
     as->tile_list.push_back(make_tile(frames, ws, hs, n));
     as->generation = next_generation();
+}
+
+void rxh_assets_set_patterns(void *a, int normal, const float *const *rgb, const uint32_t *ws, const uint32_t *hs, uint32_t n) {
+    Assets *as = (Assets *)a;
+    std::vector<Pattern> &dst = normal ? as->patterns_normal : as->patterns;
+    dst.clear();
+    for (uint32_t i = 0; i < n; ++i) {
+        Pattern t;
+        t.width = ws[i];
+        t.height = hs[i];
+        t.rgb.assign(rgb[i], rgb[i] + (size_t)3 * ws[i] * hs[i]);
+        dst.push_back(std::move(t));
+    }
+    as->shader_env_generation = next_generation();
+}
+void rxh_assets_set_palette(void *a, const float *rgb3, const uint8_t *present, uint32_t n) {
+    Assets *as = (Assets *)a;
+    as->palette_rgb.assign(rgb3, rgb3 + (size_t)3 * n);
+    as->palette_present.assign(n, 1);
+    if (present) as->palette_present.assign(present, present + n);
+    as->shader_env_generation = next_generation();
 }
 
 // ---- Rasterizer -----------------------------------------------------------------------------------

@@ -405,6 +405,7 @@ rxr_ctx *g_ctx = nullptr;
 int g_device = -1;
 std::string g_error;
 uint64_t g_tex_static_gen = 0, g_tex_dynamic_gen = 0;
+uint64_t g_shaders_gen = 0, g_shader_env_gen = 0;
 bool g_device_projection = false;
 uint64_t g_mesh_fingerprint = 0;
 }  // namespace
@@ -421,6 +422,7 @@ void set_device(int device) {
         g_ctx = nullptr;
         g_mesh_fingerprint = 0;
         g_tex_static_gen = g_tex_dynamic_gen = 0;
+        g_shaders_gen = g_shader_env_gen = 0;
     }
     g_device = device;
 }
@@ -565,6 +567,46 @@ int Rasterizer::upload(Scene &scene, size_t w, size_t h, size_t tile_size, const
         g_tex_dynamic_gen = scene.dynamic_textures_generation;
     }
 
+    // Rusteria programs, patterns, palette: re-sent only when they changed
+    for (const Chunk &c : scene.chunks)
+        if (!c.shaders.empty()) {
+            g_error = "chunk-level shader programs (chunk.shaders / shader_textures) are not supported on the device yet";
+            return RXR_ERR_UNSUPPORTED;
+        }
+    if (g_shaders_gen != scene.shaders_generation || g_shader_env_gen != assets.shader_env_generation) {
+        std::vector<std::vector<rxr_function>> fns(scene.shaders.size());
+        std::vector<rxr_program> progs(scene.shaders.size());
+        for (size_t i = 0; i < scene.shaders.size(); ++i) {
+            const Program &p = scene.shaders[i];
+            for (const auto &f : p.user_functions) fns[i].push_back(rxr_function{f.data(), (uint32_t)f.size()});
+            progs[i] = rxr_program{p.globals, p.shade_index, p.shade_locals, fns[i].data(), (uint32_t)fns[i].size()};
+        }
+        auto views = [](const std::vector<Pattern> &src) {
+            std::vector<rxr_pattern> v;
+            for (const Pattern &t : src) v.push_back(rxr_pattern{t.rgb.data(), t.width, t.height});
+            return v;
+        };
+        std::vector<rxr_pattern> pv = views(assets.patterns), pn = views(assets.patterns_normal);
+        rxr_shader_set set{};
+        set.programs = progs.data();
+        set.n_programs = (uint32_t)progs.size();
+        set.patterns = pv.data();
+        set.n_patterns = (uint32_t)pv.size();
+        set.normal_patterns = pn.data();
+        set.n_normal_patterns = (uint32_t)pn.size();
+        set.palette_rgb = assets.palette_rgb.data();
+        set.palette_present = assets.palette_present.data();
+        set.n_palette = (uint32_t)assets.palette_present.size();
+        int rc = rxr_set_shaders(ctx, &set);
+        if (rc != RXR_OK) {
+            g_error = rxr_last_error(ctx);
+            g_shaders_gen = 0;
+            return rc;
+        }
+        g_shaders_gen = scene.shaders_generation;
+        g_shader_env_gen = assets.shader_env_generation;
+    }
+
     // flatten in submission order (:314-405, :503-552)
     std::vector<rxr_batch3d> b3;
     std::vector<rxr_batch2d> b2;
@@ -686,7 +728,7 @@ int Rasterizer::upload(Scene &scene, size_t w, size_t h, size_t tile_size, const
     f.n_linedefs = (uint32_t)mapmini.linedefs.size();
     f.chunks = chunks.data();
     f.n_chunks = (uint32_t)chunks.size();
-    f.n_shader_programs = 0;
+    f.n_shader_programs = (uint32_t)scene.shaders.size();
     if (on_device) {
         f.use_meshes = 1;
         memcpy(f.view, view_matrix.m, 64);

@@ -53,10 +53,31 @@ struct Tile {
 };
 // src/server/assets.rs
 uint64_t next_generation();  // process-wide unique stamps (never reused, unlike addresses)
+// rusteria TexStorage (rusteria/src/textures/mod.rs:10-15): width * height RGB f32
+struct Pattern {
+    uint32_t width = 0, height = 0;
+    std::vector<float> rgb;
+};
+
 struct Assets {
     std::vector<Tile> tile_list;
     uint64_t generation = next_generation();  // re-stamped on every mutation; lets the rasterizer skip texture re-uploads
     Assets &textures(std::vector<Tile> tiles) { tile_list = std::move(tiles); generation = next_generation(); return *this; }
+    // what a Rusteria program reads besides its own code: assets.palette (ThePalette.colors) and rusteria's
+    // process-global pattern banks (rusteria/src/textures/patterns.rs), which the caller hands over as data
+    std::vector<Pattern> patterns, patterns_normal;
+    std::vector<float> palette_rgb;        // [n][3]
+    std::vector<uint8_t> palette_present;  // [n]
+    uint64_t shader_env_generation = next_generation();
+};
+
+// rusteria::Program (rusteria/src/node/program.rs:7-29): user functions as NodeOp trees in the word
+// serialisation of include/rxr.h (there is no Rusteria parser / compiler on this side)
+struct Program {
+    uint32_t globals = 0;
+    int32_t shade_index = -1;
+    uint32_t shade_locals = 0;
+    std::vector<std::vector<uint32_t>> user_functions;
 };
 
 // src/rect.rs
@@ -140,6 +161,7 @@ struct Chunk {
     std::vector<Batch2D> batches2d;
     std::vector<CompiledLight> lights;
     std::vector<rxr_occluder> occluded_sectors;
+    std::vector<Program> shaders;  // src/chunk.rs:51 -- not supported on the device yet: rasterize returns RXR_ERR_UNSUPPORTED
 };
 
 // src/scene.rs:8-50
@@ -153,6 +175,10 @@ public:
     uint64_t dynamic_textures_generation = next_generation();
     size_t animation_frame = 1;
     std::vector<Chunk> chunks;
+    std::vector<Program> shaders;  // src/scene.rs:43
+    uint64_t shaders_generation = next_generation();
+    // scene.add_shader (src/scene.rs:104-134) minus parse + compile; returns the shader index
+    size_t add_program(Program p) { shaders.push_back(std::move(p)); shaders_generation = next_generation(); return shaders.size() - 1; }
 
     // src/scene.rs:154-200.  false where the reference panics.
     bool project(const Mat3 *m2d, const Mat4 &view, const Mat4 &proj, float width, float height);

@@ -105,6 +105,12 @@ struct rxr_ctx {
     size_t pp_off_meshes = 0;  // byte offset of the per-frame DevMesh array inside d_proj_misc
     bool frame_uses_meshes = false;
 
+    // Rusteria programs (rxr_set_shaders)
+    DevBuf d_vm_code, d_programs, d_patterns, d_pattern_data, d_palette;
+    std::vector<DevProgram> programs;
+    uint32_t n_patterns = 0, n_normal_patterns = 0, n_palette = 0;
+    bool frame_uses_programs = false;
+
     bool has_frame = false;
     RasterParams P{};       // template for the resident frame (pointers resolved)
     uint32_t n_tris2d = 0;
@@ -214,13 +220,13 @@ int rxr_create(rxr_ctx **out, int device_id) {
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev2);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev_upload);
-    if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_counters, 2 * CNT_WORDS * sizeof(uint32_t), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_counters, (2 * CNT_WORDS + 4) * sizeof(uint32_t), hipHostMallocDefault);
     if (e != hipSuccess) {
         std::string msg = std::string("rxr_create: ") + hipGetErrorString(e);
         delete ctx;
         return fail(nullptr, RXR_ERR_HIP, msg);
     }
-    memset(ctx->h_counters, 0, 2 * CNT_WORDS * sizeof(uint32_t));
+    memset(ctx->h_counters, 0, (2 * CNT_WORDS + 4) * sizeof(uint32_t));
     if (const char *sm = getenv("RXR_SMALL_MODE")) {
         if (sm[0] >= '0' && sm[0] <= '2') ctx->small_mode = (uint32_t)(sm[0] - '0');
     }
@@ -235,7 +241,8 @@ void rxr_destroy(rxr_ctx *ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&ctx->d_obj, &ctx->d_proj_out, &ctx->d_proj_misc, &ctx->d_tex, &ctx->d_texels, &ctx->d_frame, &ctx->d_tri_setup, &ctx->d_tri_shade, &ctx->d_bin_count, &ctx->d_bins, &ctx->d_bin2d_count, &ctx->d_bins2d,
                       &ctx->d_list2d, &ctx->d_large2d,
-                      &ctx->d_list, &ctx->d_large, &ctx->d_counters, &ctx->d_fb};
+                      &ctx->d_list, &ctx->d_large, &ctx->d_counters, &ctx->d_fb,
+                      &ctx->d_vm_code, &ctx->d_programs, &ctx->d_patterns, &ctx->d_pattern_data, &ctx->d_palette};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
@@ -560,6 +567,15 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
     ctx->has_frame = false;
 
     // ---- pass 1: validate + size ---------------------------------------------------------------
+    if (f->n_shader_programs > ctx->programs.size())
+        return fail(ctx, RXR_ERR_INVALID, "rxr_upload_frame: n_shader_programs exceeds the programs set with rxr_set_shaders");
+    // batch.shader -> program (scene.shaders.get(index), src/rasterizer.rs:1287); chunk batches look in chunk.shaders,
+    // which this ABI does not carry: they resolve to no program
+    auto program_of = [&](int32_t shader, int32_t chunk) -> uint32_t {
+        if (shader < 0 || chunk >= 0 || (uint32_t)shader >= f->n_shader_programs) return 0u;
+        return (uint32_t)shader + 1u;
+    };
+    bool uses_programs = false;
     size_t n_v3 = 0, n_t3 = 0;
     bool has_opacity = false;
     const bool use_meshes = f->use_meshes != 0;
@@ -568,8 +584,6 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
     if (use_meshes)
         for (const HostMesh &h : ctx->meshes) {
             if (h.chunk >= (int32_t)f->n_chunks) return fail(ctx, RXR_ERR_INVALID, "mesh: chunk index out of range");
-            if (h.shader >= 0 && (uint32_t)h.shader < f->n_shader_programs)
-                return fail(ctx, RXR_ERR_UNSUPPORTED, "mesh uses a Rusteria shader program: not implemented on the device yet");
             if (h.list == RXR_LIST_CHUNK_OPACITY) has_opacity = true;
         }
     for (uint32_t i = 0; i < f->n_batches3d; ++i) {
@@ -577,8 +591,6 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
         if (b.n_triangles && (!b.clipped_indices || !b.edges)) return fail(ctx, RXR_ERR_INVALID, "batch3d: NULL indices/edges");
         if (b.n_vertices && (!b.projected_vertices || !b.clipped_uvs)) return fail(ctx, RXR_ERR_INVALID, "batch3d: NULL vertex arrays");
         if (b.chunk >= (int32_t)f->n_chunks) return fail(ctx, RXR_ERR_INVALID, "batch3d: chunk index out of range");
-        if (b.shader >= 0 && (uint32_t)b.shader < f->n_shader_programs)
-            return fail(ctx, RXR_ERR_UNSUPPORTED, "batch3d uses a Rusteria shader program: not implemented on the device yet");
         for (uint32_t t = 0; t < b.n_triangles * 3u; ++t)
             if (b.clipped_indices[t] >= b.n_vertices) return fail(ctx, RXR_ERR_INVALID, "batch3d: vertex index out of range");
         if (b.list == RXR_LIST_CHUNK_OPACITY) has_opacity = true;
@@ -593,8 +605,6 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
         if (b.n_vertices && (!b.projected_vertices || !b.uvs)) return fail(ctx, RXR_ERR_INVALID, "batch2d: NULL vertex arrays");
         if (b.chunk >= (int32_t)f->n_chunks) return fail(ctx, RXR_ERR_INVALID, "batch2d: chunk index out of range");
         if (b.mode > RXR_MODE_LINE_LOOP) return fail(ctx, RXR_ERR_INVALID, "batch2d: bad mode");
-        if (b.shader >= 0 && (uint32_t)b.shader < f->n_shader_programs)
-            return fail(ctx, RXR_ERR_UNSUPPORTED, "batch2d uses a Rusteria shader program: not implemented on the device yet");
         if (b.mode == RXR_MODE_TRIANGLES || b.mode == RXR_MODE_LINES)
             for (uint32_t t = 0; t < b.n_triangles * 3u; ++t) {
                 if (b.mode == RXR_MODE_LINES && (t % 3u) == 2u) continue;  // only .0/.1 are read, :902
@@ -661,6 +671,12 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
         if (b.clipped_normals) d.flags |= DB_HAS_NORMALS;
         if (b.has_profile_id) d.flags |= DB_HAS_PROFILE;
         if (b.list == RXR_LIST_CHUNK_OPACITY) d.flags |= DB_OPACITY_LIST;
+        d.program_plus1 = program_of(b.shader, b.chunk);
+        const bool prog_runs = d.program_plus1 && ctx->programs[d.program_plus1 - 1].shade_entry != 0xFFFFFFFFu;
+        const bool prog_opacity = prog_runs && (ctx->programs[d.program_plus1 - 1].flags & 1u);
+        if (!prog_runs) d.program_plus1 = 0;
+        if (prog_runs) d.flags |= DB_HAS_PROGRAM;
+        if (prog_opacity) d.flags |= DB_PROGRAM_OPACITY;
         d.profile_id = b.profile_id;
         d.repeat_mode = b.repeat_mode;
         d.chunk = b.chunk;
@@ -676,11 +692,12 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
             if (rc != RXR_OK) return fail(ctx, rc, "batch3d: texture tile index out of range or tile without textures (the reference panics)");
             if (d.tex >= 0) {
                 if (!ctx->h_tex[d.tex].all_opaque) d.flags |= DB_ALPHA_TEST;
-            } else if ((d.pixel >> 24) != 255u && b.list != RXR_LIST_CHUNK_OPACITY) {
+            } else if ((d.pixel >> 24) != 255u && b.list != RXR_LIST_CHUNK_OPACITY && !prog_opacity) {
                 keep = false;  // encoded alpha != 255: never written (rasterizer.rs:1408)
             }
         }
         if (!keep) d.flags |= DB_SKIP;
+        else if (prog_runs) uses_programs = true;
         b3[i] = d;
         base[i] = (uint32_t)tcur;
         if (b.n_vertices) {
@@ -739,6 +756,12 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
             d.flags = DB_HAS_NORMALS;  // meshes with triangles must carry normals (batch3d.rs:605)
             if (h.has_profile_id) d.flags |= DB_HAS_PROFILE;
             if (h.list == RXR_LIST_CHUNK_OPACITY) d.flags |= DB_OPACITY_LIST;
+            d.program_plus1 = program_of(h.shader, h.chunk);
+            const bool prog_runs = d.program_plus1 && ctx->programs[d.program_plus1 - 1].shade_entry != 0xFFFFFFFFu;
+            const bool prog_opacity = prog_runs && (ctx->programs[d.program_plus1 - 1].flags & 1u);
+            if (!prog_runs) d.program_plus1 = 0;
+            if (prog_runs) d.flags |= DB_HAS_PROGRAM;
+            if (prog_opacity) d.flags |= DB_PROGRAM_OPACITY;
             d.profile_id = h.profile_id;
             d.repeat_mode = h.repeat_mode;
             d.chunk = h.chunk;
@@ -749,11 +772,12 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
                 if (rc != RXR_OK) return fail(ctx, rc, "mesh: texture tile index out of range or tile without textures (the reference panics)");
                 if (d.tex >= 0) {
                     if (!ctx->h_tex[d.tex].all_opaque) d.flags |= DB_ALPHA_TEST;
-                } else if ((d.pixel >> 24) != 255u && h.list != RXR_LIST_CHUNK_OPACITY) {
+                } else if ((d.pixel >> 24) != 255u && h.list != RXR_LIST_CHUNK_OPACITY && !prog_opacity) {
                     keep = false;
                 }
             }
             if (!keep) d.flags |= DB_SKIP;
+            else if (prog_runs) uses_programs = true;
             b3[i] = d;
             base[i] = h.dev.tout_base;
         }
@@ -798,6 +822,12 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
         d.repeat_mode = b.repeat_mode;
         d.chunk = b.chunk;
         d.flags = b.receives_light ? DB_RECEIVES_LIGHT : 0u;
+        d.program_plus1 = program_of(b.shader, b.chunk);
+        if (d.program_plus1 && ctx->programs[d.program_plus1 - 1].shade_entry == 0xFFFFFFFFu) d.program_plus1 = 0;
+        if (d.program_plus1) {
+            d.flags |= DB_HAS_PROGRAM;
+            uses_programs = true;
+        }
         // batch-level box reject with pad 0.5, rasterizer.rs:594-600, against the whole screen
         bool keep = b.has_bounding_box != 0;
         if (keep) {
@@ -949,6 +979,18 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
     P.n_linedefs = f->n_linedefs;
     P.n_prims2d = (uint32_t)p2cur;
     P.binned2d = binned2d ? 1u : 0u;
+    ctx->frame_uses_programs = uses_programs;
+    P.vm_code = uses_programs ? (const uint32_t *)ctx->d_vm_code.p : nullptr;
+    P.programs = (const DevProgram *)ctx->d_programs.p;
+    P.patterns = (const DevPattern *)ctx->d_patterns.p;
+    P.pattern_data = (const float *)ctx->d_pattern_data.p;
+    P.palette = (const float *)ctx->d_palette.p;
+    P.n_programs = (uint32_t)ctx->programs.size();
+    P.n_patterns = ctx->n_patterns;
+    P.n_normal_patterns = ctx->n_normal_patterns;
+    P.n_palette = ctx->n_palette;
+    P.vm_fault = ctx->d_host_status + 2 * CNT_WORDS;
+    P.time = f->time;
     {
         // tiles outside the union of the 2D pixel boxes skip the 2D pass without touching memory
         uint32_t bx0 = 0xFFFFu, bx1 = 0, by0 = 0xFFFFu, by1 = 0;
@@ -1063,6 +1105,7 @@ static int render_impl(rxr_ctx *ctx, const RenderSpec &spec, void *dev_pixels, h
     // small scenes: one staging round of k_raster holds every triangle -> no set-up / binning launches at all
     const bool d3 = P.tiles_y && (P.flags & RXR_FLAG_D3_ACTIVE);
     P.fused_small = (d3 && P.n_tris3d <= RXR_STAGE_TRIS) ? ctx->small_mode : 0u;
+    if (P.vm_code && P.fused_small == 1u) P.fused_small = 2u;  // k_raster_vm reads the records k_setup3d writes
     if (d3 && P.fused_small) {
         if (ctx->frame_uses_meshes) rxr_launch_project(&ctx->PP, s);
         if (P.fused_small == 2u) rxr_launch_setup(&P, s);  // records only; no counters, bins or lists are touched
@@ -1241,6 +1284,15 @@ int rxr_synchronize(rxr_ctx *ctx) {
         if (ctx->last_stream && ctx->last_stream != ctx->stream) HIPCHK(ctx, hipStreamSynchronize(ctx->last_stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         if (!ctx->rendered) return RXR_OK;
+        if (ctx->h_counters[2 * CNT_WORDS]) {
+            // a fragment's program did what makes the reference panic (rxr_vm.h, VMF_*)
+            static const char *const what[] = {"", "stack underflow", "stack overflow", "local index out of range", "global index out of range",
+                                               "call depth", "loop depth", "instruction limit (runaway loop)", "clamp with min > max",
+                                               "call of a missing function", "bad opcode", "too many locals"};
+            uint32_t code = ctx->h_counters[2 * CNT_WORDS];
+            ctx->h_counters[2 * CNT_WORDS] = 0;
+            return fail(ctx, RXR_ERR_INVALID, std::string("shader program fault: ") + (code < sizeof(what) / sizeof(what[0]) ? what[code] : "?"));
+        }
         ctx->stats.n_bin_entries = ctx->h_counters[CNT_ENTRIES];
         if (ctx->h_counters[CNT_WORDS + CNT_OVERFLOW]) {
             // 2D bin list overflow: grow and render the same launch again
@@ -1307,6 +1359,346 @@ int rxr_get_stats(rxr_ctx *ctx, rxr_stats *out) {
 }
 
 void *rxr_device_framebuffer(rxr_ctx *ctx) { return ctx ? ctx->d_fb.p : nullptr; }
+
+// ---- Rusteria programs: NodeOp tree (include/rxr.h) -> jump code (rxr_device.h) ------------------
+namespace {
+
+struct Flattener {
+    std::vector<uint32_t> code;
+    std::vector<std::pair<size_t, uint32_t>> call_patches;  // (position of the target word, function index)
+    std::vector<size_t> return_patches;                     // positions to fill with the current function's ENDFN address
+    uint32_t n_functions = 0;
+    bool writes_opacity = false;
+    std::string err;
+    int status = RXR_OK;
+
+    bool bad(int st, const std::string &m) {
+        if (status == RXR_OK) {
+            status = st;
+            err = m;
+        }
+        return false;
+    }
+
+    // one block of the serialised tree; for_depth > 0 inside a For
+    bool block(const uint32_t *w, size_t n, int for_depth, int depth) {
+        if (depth > 64) return bad(RXR_ERR_INVALID, "program nested too deeply");
+        size_t i = 0;
+        auto need = [&](size_t k) { return i + k <= n; };
+        while (i < n) {
+            const uint32_t op = w[i++];
+            if (op >= RXR_NODE_COUNT) return bad(RXR_ERR_INVALID, "unknown NodeOp opcode");
+            switch (op) {
+                case RXR_NODE_LOAD_GLOBAL:
+                case RXR_NODE_STORE_GLOBAL:
+                case RXR_NODE_LOAD_LOCAL:
+                case RXR_NODE_STORE_LOCAL:
+                    if (!need(1)) return bad(RXR_ERR_INVALID, "truncated program");
+                    code.push_back(op);
+                    code.push_back(w[i++]);
+                    break;
+                case RXR_NODE_GET_COMPONENTS:
+                case RXR_NODE_SET_COMPONENTS: {
+                    if (!need(1)) return bad(RXR_ERR_INVALID, "truncated program");
+                    uint32_t k = w[i++];
+                    if (!need(k)) return bad(RXR_ERR_INVALID, "truncated program");
+                    if (k > 12) return bad(RXR_ERR_UNSUPPORTED, "swizzle with more than 12 components");
+                    uint32_t enc = k;
+                    for (uint32_t j = 0; j < k; ++j) enc |= (w[i + j] > 2u ? 3u : w[i + j]) << (4u + 2u * j);
+                    i += k;
+                    code.push_back(op == RXR_NODE_GET_COMPONENTS ? (uint32_t)VM_GETC : (uint32_t)VM_SETC);
+                    code.push_back(enc);
+                    break;
+                }
+                case RXR_NODE_IF: {
+                    if (!need(3)) return bad(RXR_ERR_INVALID, "truncated program");
+                    const uint32_t tl = w[i], he = w[i + 1], el = w[i + 2];
+                    i += 3;
+                    if (!need((size_t)tl + el)) return bad(RXR_ERR_INVALID, "truncated program");
+                    code.push_back(VM_JZ);
+                    const size_t jz = code.size();
+                    code.push_back(0);
+                    if (!block(w + i, tl, for_depth, depth + 1)) return false;
+                    i += tl;
+                    if (he) {
+                        code.push_back(VM_JMP);
+                        const size_t jend = code.size();
+                        code.push_back(0);
+                        code[jz] = (uint32_t)code.size();
+                        if (!block(w + i, el, for_depth, depth + 1)) return false;
+                        code[jend] = (uint32_t)code.size();
+                    } else {
+                        code[jz] = (uint32_t)code.size();
+                    }
+                    i += el;
+                    break;
+                }
+                case RXR_NODE_FOR: {  // execution.rs:251-278
+                    if (!need(4)) return bad(RXR_ERR_INVALID, "truncated program");
+                    const uint32_t l[4] = {w[i], w[i + 1], w[i + 2], w[i + 3]};
+                    i += 4;
+                    if (!need((size_t)l[0] + l[1] + l[2] + l[3])) return bad(RXR_ERR_INVALID, "truncated program");
+                    const uint32_t *init = w + i, *cond = init + l[0], *incr = cond + l[1], *body = incr + l[2];
+                    i += (size_t)l[0] + l[1] + l[2] + l[3];
+                    code.push_back(VM_FOR_ENTER);
+                    if (!block(init, l[0], for_depth + 1, depth + 1)) return false;
+                    code.push_back(VM_FOR_TRUNC);
+                    const uint32_t top = (uint32_t)code.size();
+                    if (!block(cond, l[1], for_depth + 1, depth + 1)) return false;
+                    code.push_back(VM_FOR_COND);
+                    const size_t jexit = code.size();
+                    code.push_back(0);
+                    code.push_back(VM_FOR_TRUNC);
+                    if (!block(body, l[3], for_depth + 1, depth + 1)) return false;
+                    code.push_back(VM_FOR_TRUNC);
+                    if (!block(incr, l[2], for_depth + 1, depth + 1)) return false;
+                    code.push_back(VM_FOR_TRUNC);
+                    code.push_back(VM_JMP);
+                    code.push_back(top);
+                    code[jexit] = (uint32_t)code.size();
+                    code.push_back(VM_FOR_EXIT);
+                    break;
+                }
+                case RXR_NODE_PUSH:
+                    if (!need(3)) return bad(RXR_ERR_INVALID, "truncated program");
+                    code.push_back(op);
+                    code.push_back(w[i]);
+                    code.push_back(w[i + 1]);
+                    code.push_back(w[i + 2]);
+                    i += 3;
+                    break;
+                case RXR_NODE_FUNCTION_CALL: {
+                    if (!need(3)) return bad(RXR_ERR_INVALID, "truncated program");
+                    const uint32_t arity = w[i], total = w[i + 1], index = w[i + 2];
+                    i += 3;
+                    if (index >= n_functions) {  // program.user_functions[index] panics when reached
+                        code.push_back(VM_FAULT);
+                        code.push_back(VMF_BAD_CALL);
+                        break;
+                    }
+                    if (total > RXR_VM_LOCALS) return bad(RXR_ERR_UNSUPPORTED, "function with more locals than the device VM holds");
+                    code.push_back(VM_CALL);
+                    code.push_back(arity);
+                    code.push_back(total);
+                    call_patches.emplace_back(code.size(), index);
+                    code.push_back(0);
+                    break;
+                }
+                case RXR_NODE_RETURN:
+                    // the reference's For keeps iterating after a Return unwound its body (execution.rs:258-277):
+                    // it pops the ENCLOSING frame's values as loop conditions
+                    if (for_depth > 0) return bad(RXR_ERR_UNSUPPORTED, "Return inside For (the reference unwinds it incorrectly)");
+                    code.push_back(VM_RETURN);
+                    return_patches.push_back(code.size());
+                    code.push_back(0);
+                    break;
+                case RXR_NODE_ALLOC:
+                case RXR_NODE_ITERATE:
+                case RXR_NODE_SAVE:
+                    return bad(RXR_ERR_UNSUPPORTED, "Alloc / Iterate / Save (texture baking) are not part of per-fragment shading");
+                case RXR_NODE_SET_EMISSIVE:
+                    return bad(RXR_ERR_UNSUPPORTED, "SetEmissive: the reference leaks emissive into every later fragment of its tile");
+                case RXR_NODE_SET_OPACITY:
+                    writes_opacity = true;
+                    code.push_back(op);
+                    break;
+                default: code.push_back(op); break;
+            }
+        }
+        return true;
+    }
+};
+
+// conservative purity check for globals: a LoadGlobal is accepted only if the same global was stored by a
+// top-level operation of `shade` earlier in the same invocation (the reference's globals otherwise carry
+// the previous fragment's values)
+void collect_global_loads(const rxr_program &p, const uint32_t *w, size_t n, std::vector<uint32_t> &loads, std::vector<char> &visiting, int depth) {
+    size_t i = 0;
+    while (i < n && depth < 64) {
+        uint32_t op = w[i++];
+        switch (op) {
+            case RXR_NODE_LOAD_GLOBAL: loads.push_back(w[i]); i += 1; break;
+            case RXR_NODE_STORE_GLOBAL:
+            case RXR_NODE_LOAD_LOCAL:
+            case RXR_NODE_STORE_LOCAL: i += 1; break;
+            case RXR_NODE_GET_COMPONENTS:
+            case RXR_NODE_SET_COMPONENTS: i += 1 + w[i]; break;
+            case RXR_NODE_PUSH: i += 3; break;
+            case RXR_NODE_IF: {
+                uint32_t tl = w[i], el = w[i + 2];
+                i += 3;
+                collect_global_loads(p, w + i, tl, loads, visiting, depth + 1);
+                collect_global_loads(p, w + i + tl, el, loads, visiting, depth + 1);
+                i += (size_t)tl + el;
+                break;
+            }
+            case RXR_NODE_FOR: {
+                size_t tot = (size_t)w[i] + w[i + 1] + w[i + 2] + w[i + 3];
+                i += 4;
+                collect_global_loads(p, w + i, tot, loads, visiting, depth + 1);  // the four blocks are contiguous
+                i += tot;
+                break;
+            }
+            case RXR_NODE_FUNCTION_CALL: {
+                uint32_t index = w[i + 2];
+                i += 3;
+                if (index < p.n_functions && !visiting[index]) {
+                    visiting[index] = 1;
+                    collect_global_loads(p, p.functions[index].words, p.functions[index].n_words, loads, visiting, depth + 1);
+                    visiting[index] = 0;
+                }
+                break;
+            }
+            default: break;
+        }
+    }
+}
+
+bool globals_are_pure(const rxr_program &p) {
+    if (p.shade_index < 0 || (uint32_t)p.shade_index >= p.n_functions) return true;
+    const uint32_t *w = p.functions[p.shade_index].words;
+    const size_t n = p.functions[p.shade_index].n_words;
+    std::vector<char> stored(p.n_globals + 1, 0), visiting(p.n_functions, 0);
+    visiting[p.shade_index] = 1;
+    size_t i = 0;
+    while (i < n) {
+        const size_t at = i;
+        uint32_t op = w[i++];
+        size_t len = 0;
+        switch (op) {
+            case RXR_NODE_STORE_GLOBAL:
+                if (w[i] < p.n_globals) stored[w[i]] = 1;
+                len = 1;
+                break;
+            case RXR_NODE_LOAD_GLOBAL:
+            case RXR_NODE_LOAD_LOCAL:
+            case RXR_NODE_STORE_LOCAL: len = 1; break;
+            case RXR_NODE_GET_COMPONENTS:
+            case RXR_NODE_SET_COMPONENTS: len = 1 + w[i]; break;
+            case RXR_NODE_PUSH: len = 3; break;
+            case RXR_NODE_IF: len = 3 + (size_t)w[i] + w[i + 2]; break;
+            case RXR_NODE_FOR: len = 4 + (size_t)w[i] + w[i + 1] + w[i + 2] + w[i + 3]; break;
+            case RXR_NODE_FUNCTION_CALL: len = 3; break;
+            default: break;
+        }
+        std::vector<uint32_t> loads;
+        collect_global_loads(p, w + at, 1 + len, loads, visiting, 0);
+        for (uint32_t g : loads)
+            if (g >= p.n_globals || !stored[g]) return false;
+        i += len;
+    }
+    return true;
+}
+
+}  // namespace
+
+int rxr_set_shaders(rxr_ctx *ctx, const rxr_shader_set *set) {
+    if (!ctx) return RXR_ERR_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    ctx->has_frame = false;  // the resident frame's batch headers refer to the old programs
+    ctx->programs.clear();
+    ctx->n_patterns = ctx->n_normal_patterns = ctx->n_palette = 0;
+    if (!set) return RXR_OK;
+    if ((set->n_programs && !set->programs) || (set->n_patterns && !set->patterns) || (set->n_normal_patterns && !set->normal_patterns) ||
+        (set->n_palette && !set->palette_rgb))
+        return fail(ctx, RXR_ERR_INVALID, "rxr_set_shaders: NULL array");
+
+    // ---- validate + flatten every program into one code stream
+    Flattener fl;
+    std::vector<DevProgram> progs;
+    for (uint32_t pi = 0; pi < set->n_programs; ++pi) {
+        const rxr_program &p = set->programs[pi];
+        if (p.n_functions && !p.functions) return fail(ctx, RXR_ERR_INVALID, "rxr_set_shaders: NULL function array");
+        for (uint32_t k = 0; k < p.n_functions; ++k)
+            if (p.functions[k].n_words && !p.functions[k].words) return fail(ctx, RXR_ERR_INVALID, "rxr_set_shaders: NULL function body");
+        DevProgram d{};
+        d.shade_entry = 0xFFFFFFFFu;
+        d.shade_locals = p.shade_locals;
+        d.n_globals = p.n_globals;
+        if (p.shade_index >= 0) {
+            if ((uint32_t)p.shade_index >= p.n_functions)  // program.user_functions[index] would panic on the first fragment
+                return fail(ctx, RXR_ERR_INVALID, "rxr_set_shaders: shade_index out of range");
+            if (p.n_globals > RXR_VM_GLOBALS) return fail(ctx, RXR_ERR_UNSUPPORTED, "rxr_set_shaders: more globals than the device VM holds");
+            if (p.shade_locals > RXR_VM_LOCALS) return fail(ctx, RXR_ERR_UNSUPPORTED, "rxr_set_shaders: more locals than the device VM holds");
+            // structural check first (lengths), so that the purity walk below cannot run off the arrays
+            fl.n_functions = p.n_functions;
+            fl.writes_opacity = false;
+            fl.call_patches.clear();
+            std::vector<uint32_t> entries(p.n_functions);
+            for (uint32_t k = 0; k < p.n_functions; ++k) {
+                entries[k] = (uint32_t)fl.code.size();
+                fl.return_patches.clear();
+                if (!fl.block(p.functions[k].words, p.functions[k].n_words, 0, 0)) return fail(ctx, fl.status, "rxr_set_shaders: " + fl.err);
+                const uint32_t endfn = (uint32_t)fl.code.size();
+                fl.code.push_back(VM_ENDFN);
+                for (size_t pos : fl.return_patches) fl.code[pos] = endfn;
+            }
+            for (auto &cp : fl.call_patches) fl.code[cp.first] = entries[cp.second];
+            if (!globals_are_pure(p))
+                return fail(ctx, RXR_ERR_UNSUPPORTED, "rxr_set_shaders: a global is read before this invocation wrote it (the reference would read the previous fragment's value)");
+            d.shade_entry = entries[p.shade_index];
+            d.flags = fl.writes_opacity ? 1u : 0u;
+        }
+        progs.push_back(d);
+    }
+    if (fl.code.size() >= (1ull << 31)) return fail(ctx, RXR_ERR_INVALID, "rxr_set_shaders: programs too large");
+
+    // ---- patterns + palette
+    std::vector<DevPattern> pats;
+    size_t n_floats = 0;
+    auto add_patterns = [&](const rxr_pattern *src, uint32_t n) -> int {
+        for (uint32_t i = 0; i < n; ++i) {
+            if (!src[i].rgb || src[i].width == 0 || src[i].height == 0 || src[i].width > 32768 || src[i].height > 32768) return RXR_ERR_INVALID;
+            DevPattern d{};
+            d.offset = (uint32_t)n_floats;
+            d.w = src[i].width;
+            d.h = src[i].height;
+            pats.push_back(d);
+            n_floats += (size_t)3 * d.w * d.h;
+            if (n_floats >= (1ull << 31)) return RXR_ERR_INVALID;
+        }
+        return RXR_OK;
+    };
+    int rc;
+    if ((rc = add_patterns(set->patterns, set->n_patterns)) != RXR_OK) return fail(ctx, rc, "rxr_set_shaders: bad pattern");
+    if ((rc = add_patterns(set->normal_patterns, set->n_normal_patterns)) != RXR_OK) return fail(ctx, rc, "rxr_set_shaders: bad normal pattern");
+
+    auto up = [&](DevBuf &b, const void *src, size_t bytes) -> int {
+        int r = ensure(ctx, b, bytes ? bytes : 16);
+        if (r != RXR_OK) return r;
+        if (bytes) HIPCHK(ctx, hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        return RXR_OK;
+    };
+    if ((rc = up(ctx->d_vm_code, fl.code.data(), fl.code.size() * 4)) != RXR_OK) return rc;
+    if ((rc = up(ctx->d_programs, progs.data(), progs.size() * sizeof(DevProgram))) != RXR_OK) return rc;
+    if ((rc = up(ctx->d_patterns, pats.data(), pats.size() * sizeof(DevPattern))) != RXR_OK) return rc;
+    if ((rc = ensure(ctx, ctx->d_pattern_data, n_floats ? n_floats * 4 : 16)) != RXR_OK) return rc;
+    {
+        size_t k = 0;
+        auto copy_pats = [&](const rxr_pattern *src, uint32_t n) -> int {
+            for (uint32_t i = 0; i < n; ++i, ++k)
+                HIPCHK(ctx, hipMemcpyAsync((float *)ctx->d_pattern_data.p + pats[k].offset, src[i].rgb, (size_t)12 * pats[k].w * pats[k].h,
+                                           hipMemcpyHostToDevice, ctx->stream));
+            return RXR_OK;
+        };
+        if ((rc = copy_pats(set->patterns, set->n_patterns)) != RXR_OK) return rc;
+        if ((rc = copy_pats(set->normal_patterns, set->n_normal_patterns)) != RXR_OK) return rc;
+    }
+    std::vector<float> pal((size_t)set->n_palette * 4);
+    for (uint32_t i = 0; i < set->n_palette; ++i) {
+        pal[4 * i] = set->palette_rgb[3 * i];
+        pal[4 * i + 1] = set->palette_rgb[3 * i + 1];
+        pal[4 * i + 2] = set->palette_rgb[3 * i + 2];
+        pal[4 * i + 3] = (!set->palette_present || set->palette_present[i]) ? 1.0f : 0.0f;
+    }
+    if ((rc = up(ctx->d_palette, pal.data(), pal.size() * 4)) != RXR_OK) return rc;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // the staging vectors die here
+    ctx->programs = std::move(progs);
+    ctx->n_patterns = set->n_patterns;
+    ctx->n_normal_patterns = set->n_normal_patterns;
+    ctx->n_palette = set->n_palette;
+    return RXR_OK;
+}
 
 int rxr_selftest_math(rxr_ctx *ctx, uint64_t n_tuples, uint64_t seed, uint64_t mismatches[RXR_MATH_KINDS]) {
     if (!ctx || !mismatches) return fail(ctx, RXR_ERR_INVALID, "rxr_selftest_math: NULL argument");

@@ -27,6 +27,8 @@ enum : uint32_t {
     DB_SKIP = 1u << 3,        // nothing of this batch can ever be written (no bbox / NaN bbox / constant alpha != 255)
     DB_RECEIVES_LIGHT = 1u << 4,
     DB_OPACITY_LIST = 1u << 5,
+    DB_HAS_PROGRAM = 1u << 6,     // the batch runs a Rusteria program per fragment (DevBatch.program_plus1)
+    DB_PROGRAM_OPACITY = 1u << 7, // ... which may write `opacity`: the z-write rule needs the program's result per candidate
 };
 
 // flattened Batch3D / Batch2D header.  The texel source is resolved on the host at upload time:
@@ -44,7 +46,8 @@ struct DevBatch {
     int32_t chunk;
     uint32_t mode;  // 2D: RXR_MODE_*
     uint32_t n_verts;
-    uint32_t pad[2];
+    uint32_t program_plus1;  // 0: no program; else 1 + index into RasterParams.programs
+    uint32_t pad;
 };  // 64 B
 
 // per-triangle record for the visibility loop (written by k_setup3d).  96 B = 6 x 16 B.
@@ -97,6 +100,46 @@ struct ScanArgs {
 
 struct ChunkRange {
     uint32_t occ_first, occ_count;
+};
+
+// ---- Rusteria programs on the device (rxr_vm.h) --------------------------------------------------
+// The NodeOp trees are flattened by rxr_set_shaders into one word stream of jump code.  A word's low 8
+// bits are the opcode: the RXR_NODE_* value for data operations, one of the VM_* control opcodes below
+// otherwise; immediates follow in the next words.
+enum : uint32_t {
+    VM_JMP = 128,        // target
+    VM_JZ = 129,         // target: pop; jump if x == 0.0 (NodeOp::If; NaN takes the then-branch)
+    VM_FOR_ENTER = 130,  // push the current stack height on the loop stack (execution.rs:252)
+    VM_FOR_TRUNC = 131,  // stack.truncate(base)
+    VM_FOR_COND = 132,   // exit target: pop z; if z.x == 0.0 leave the loop
+    VM_FOR_EXIT = 133,   // pop the loop stack
+    VM_CALL = 134,       // arity, total_locals, target (NodeOp::FunctionCall)
+    VM_ENDFN = 135,      // end of a function body: return to the caller, or halt for `shade`
+    VM_RETURN = 136,     // address of the enclosing function's VM_ENDFN (NodeOp::Return)
+    VM_FAULT = 137,      // statically known panic (e.g. a call of a function that does not exist)
+    VM_GETC = 138,       // GetComponents: next word = n | idx0 << 4 | idx1 << 6 ... (2 bits each, 3 = "not x/y/z")
+    VM_SETC = 139,       // SetComponents, same encoding
+};
+#define RXR_VM_STACK 32
+#define RXR_VM_LOCALS 48
+#define RXR_VM_GLOBALS 16
+#define RXR_VM_FRAMES 8
+#define RXR_VM_LOOPS 8
+#define RXR_VM_MAX_STEPS (1u << 20)
+// fault codes (what the reference answers with a panic)
+enum : uint32_t {
+    VMF_STACK_UNDERFLOW = 1, VMF_STACK_OVERFLOW, VMF_LOCAL_INDEX, VMF_GLOBAL_INDEX, VMF_CALL_DEPTH, VMF_LOOP_DEPTH,
+    VMF_STEP_LIMIT, VMF_CLAMP_BOUNDS, VMF_BAD_CALL, VMF_BAD_OPCODE, VMF_LOCALS_OVERFLOW,
+};
+struct DevProgram {
+    uint32_t shade_entry;   // word offset of the shade function in vm_code; 0xFFFFFFFF: shade_index is None
+    uint32_t shade_locals;
+    uint32_t n_globals;
+    uint32_t flags;         // bit 0: writes opacity
+};
+struct DevPattern {
+    uint32_t offset;        // in floats from pattern_data
+    uint32_t w, h, pad;
 };
 
 // device counters.  Two sets: launch i uses set i&1 and k_scan's last block clears the other one for
@@ -172,6 +215,16 @@ struct RasterParams {
     uint32_t *bin2d_list, *large2d_list;
     uint32_t *counters2d, *counters2d_next;
     uint32_t *host_status2d;
+
+    // Rusteria programs (rxr_set_shaders); vm_code == NULL when the frame uses none
+    const uint32_t *vm_code;
+    const DevProgram *programs;
+    const DevPattern *patterns;        // n_patterns colour patterns, then n_normal_patterns normal patterns
+    const float *pattern_data;
+    const float *palette;              // n_palette x 4: r, g, b, present (0 / 1)
+    uint32_t n_programs, n_patterns, n_normal_patterns, n_palette;
+    uint32_t *vm_fault;                // pinned host word: a non-zero VMF_* code if any fragment's program faulted
+    float time;                        // Rasterizer.time
 
     const DevTexDesc *tex;
     const uint32_t *texels;

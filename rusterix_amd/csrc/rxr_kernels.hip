@@ -30,6 +30,7 @@
 #include "rxr_device.h"
 #include "rxr_exact_math.h"
 #include "rxr_project.h"
+#include "rxr_vm.h"
 
 #ifndef RXR_VEK_FUSED_MATVEC
 #define RXR_VEK_FUSED_MATVEC 1
@@ -362,9 +363,11 @@ __device__ __forceinline__ uint32_t batch_texel(const RasterParams &P, const Dev
 struct Frag {
     f3 world, normal, view_dir, base, lit;
     float opacity;
+    float rough, metal;  // mat_roughness / mat_metallic (:1321-1322): 0.5 / 0 unless a program ran
 };
 
 // everything before the light loop: uv, world position, normal, texel, ambient terms (:1062-1370)
+template <bool VM>
 __device__ __forceinline__ void shade3d_begin(const RasterParams &P, const TriShade &S, uint32_t batch_id, float alpha, float beta,
                                               float z, float fx, float fy, Frag &F) {
     const DevBatch &B = P.batches3d[batch_id];
@@ -400,9 +403,30 @@ __device__ __forceinline__ void shade3d_begin(const RasterParams &P, const TriSh
     f3 base = mk3(srgb_to_linear_fast((float)(texel & 0xFFu) * INV_255), srgb_to_linear_fast((float)((texel >> 8) & 0xFFu) * INV_255),
                   srgb_to_linear_fast((float)((texel >> 16) & 0xFFu) * INV_255));
     F.opacity = (float)(texel >> 24) / 255.0f;  // :1313
+    float rough = 0.5f, metal = 0.0f;  // :1315-1316 (no-shader branch)
+    if constexpr (VM) {
+        if (B.program_plus1) {  // :1283-1304
+            rxvm::IO io;
+            rxvm::io_defaults(io);
+            io.color = rxvm::mk(base.x, base.y, base.z);
+            io.opacity.x = F.opacity;
+            io.normal = rxvm::mk(normal.x, normal.y, normal.z);
+            io.roughness.x = 0.5f;
+            io.metallic.x = 0.0f;
+            io.uv.x = u / 4.0f;
+            io.uv.y = v / 4.0f;
+            io.hitpoint = rxvm::mk(world.x, world.y, world.z);
+            io.time = rxvm::splat(P.time);
+            rxvm::shade(P, B.program_plus1 - 1u, io);
+            base = mk3(io.color.x, io.color.y, io.color.z);  // :1319-1323
+            normal = mk3(io.normal.x, io.normal.y, io.normal.z);
+            rough = rclamp(io.roughness.x, 0.0f, 1.0f);
+            metal = rclamp(io.metallic.x, 0.0f, 1.0f);
+            F.opacity = io.opacity.x;  // :1403
+        }
+    }
 
     normal = norm3(normal);  // :1320
-    const float rough = 0.5f, metal = 0.0f;  // :1315-1316 (no-shader branch)
 
     f3 lit = mk3(0.0f, 0.0f, 0.0f);
     float occlusion;
@@ -431,6 +455,8 @@ __device__ __forceinline__ void shade3d_begin(const RasterParams &P, const TriSh
     F.view_dir = view_dir;
     F.base = base;
     F.lit = lit;
+    F.rough = rough;
+    F.metal = metal;
 }
 
 __device__ __forceinline__ float wave_max(float v) {
@@ -444,6 +470,7 @@ __device__ __forceinline__ float wave_max(float v) {
 // sphere cannot reach the bounding sphere of the wave's fragments is one for which every lane's
 // `distance >= end_distance` test (light.rs:539, 561, 586, 636) would return None, so skipping it
 // changes nothing; the surviving lights are then evaluated in their original order.
+template <bool VM>
 __device__ __forceinline__ void shade3d_lights(const RasterParams &P, bool hit, Frag &F) {
     const unsigned long long hitmask = __ballot(hit);
     if (hitmask == 0ull) return;
@@ -454,7 +481,7 @@ __device__ __forceinline__ void shade3d_lights(const RasterParams &P, bool hit, 
     // NaN / inf world positions are not bounded by the sphere: no culling for this wave then
     const bool can_cull = __ballot(hit && !(r < INFINITY)) == 0ull;
     const float rmax = wave_max(r);
-    const float rough = 0.5f, metal = 0.0f;
+    const float rough = VM ? F.rough : 0.5f, metal = VM ? F.metal : 0.0f;
 
     for (uint32_t base_i = 0; base_i < P.n_lights; base_i += 64u) {
         const uint32_t mine = base_i + (uint32_t)lane;
@@ -511,7 +538,9 @@ __device__ __forceinline__ uint32_t shade3d_end(const Frag &F) {
 }
 
 // the covered-fragment block of d3_rasterize_opacity (rasterizer.rs:1497-1682, no shader)
-__device__ __forceinline__ uint32_t shade3d_opacity(const RasterParams &P, const TriShade &S, uint32_t batch_id, float alpha, float beta) {
+template <bool VM>
+__device__ __forceinline__ uint32_t shade3d_opacity(const RasterParams &P, const TriShade &S, uint32_t batch_id, float alpha, float beta,
+                                                    float z, float fx, float fy) {
     const DevBatch &B = P.batches3d[batch_id];
     float gamma = 1.0f - alpha - beta;
     float u, v;
@@ -522,11 +551,41 @@ __device__ __forceinline__ uint32_t shade3d_opacity(const RasterParams &P, const
     float g = srgb_to_linear_fast((float)((texel >> 8) & 0xFFu) * INV_255);
     float b = srgb_to_linear_fast((float)((texel >> 16) & 0xFFu) * INV_255);
     float opacity = (float)(texel >> 24) / 255.0f;
+    if constexpr (VM) {
+        if (B.program_plus1) {  // :1642-1667
+            // screen_to_world (:1515, :1707-1727)
+            float x_ndc = 2.0f * (fx / P.fwidth) - 1.0f;
+            float y_ndc = 1.0f - 2.0f * (fy / P.fheight);
+            float vx, vy, vz, vw, wx, wy, wz, ww;
+            mat4_mul(P.inv_proj, x_ndc, y_ndc, z, 1.0f, vx, vy, vz, vw);
+            vx = vx / vw;
+            vy = vy / vw;
+            vz = vz / vw;
+            vw = vw / vw;
+            mat4_mul(P.inv_view, vx, vy, vz, vw, wx, wy, wz, ww);
+            rxvm::IO io;
+            rxvm::io_defaults(io);
+            io.color = rxvm::mk(r, g, b);
+            io.opacity.x = opacity;
+            io.uv.x = u / 4.0f;
+            io.uv.y = v / 4.0f;
+            io.hitpoint = rxvm::mk(wx, wy, wz);
+            io.time = rxvm::splat(P.time);
+            io.roughness.x = 0.5f;
+            io.metallic.x = 0.0f;
+            rxvm::shade(P, B.program_plus1 - 1u, io);
+            r = io.color.x;
+            g = io.color.y;
+            b = io.color.z;
+            opacity = io.opacity.x;
+        }
+    }
     return pack4(f32_to_u8_saturated(linear_to_srgb_fast(r)), f32_to_u8_saturated(linear_to_srgb_fast(g)),
                  f32_to_u8_saturated(linear_to_srgb_fast(b)), f32_to_u8_saturated(opacity));
 }
 
 // one 2D fragment (rasterizer.rs:656-895); returns the new pixel
+template <bool VM>
 __device__ __forceinline__ uint32_t fragment2d(const RasterParams &P, const Prim2D &T, const DevBatch &B, uint32_t px, uint32_t py,
                                                float fx, float fy, uint32_t dst) {
     // barycentric_weights_2d (rasterizer.rs:1731-1750)
@@ -548,6 +607,23 @@ __device__ __forceinline__ uint32_t fragment2d(const RasterParams &P, const Prim
     float wx = gx / P.scaled2, wy = gy / P.scaled2;
 
     uint32_t texel = batch_texel(P, B, u, v);
+    if constexpr (VM) {
+        if (B.program_plus1 && P.programs[B.program_plus1 - 1u].shade_entry != 0xFFFFFFFFu) {  // :760-797
+            const float INV_255 = 1.0f / 255.0f;  // pixel_to_vec4, lib.rs:52-62
+            rxvm::IO io;
+            rxvm::io_defaults(io);
+            io.uv.x = u / 4.0f;
+            io.uv.y = v / 4.0f;
+            io.color = rxvm::mk((float)(texel & 0xFFu) * INV_255, (float)((texel >> 8) & 0xFFu) * INV_255, (float)((texel >> 16) & 0xFFu) * INV_255);
+            io.hitpoint.x = wx;
+            io.hitpoint.y = wy;
+            io.time = rxvm::splat(P.time);
+            io.roughness.x = 0.5f;
+            io.metallic.x = 0.0f;
+            rxvm::shade(P, B.program_plus1 - 1u, io);
+            texel = pack4(f32_to_u8_saturated(io.color.x), f32_to_u8_saturated(io.color.y), f32_to_u8_saturated(io.color.z), 255u);
+        }
+    }
     uint32_t tr = texel & 0xFFu, tg = (texel >> 8) & 0xFFu, tb = (texel >> 16) & 0xFFu, ta = texel >> 24;
 
     // :799-873 -- note the reference's precedence: (receives_light && any lights) || ambient
@@ -882,7 +958,17 @@ struct Vis {
 };
 
 // one candidate triangle against this lane's pixel (rasterizer.rs:1020-1060 + the :1408 alpha rule)
-template <bool OPACITY>
+// the encoded alpha of an opaque-pass fragment whose program may write `opacity` (:1403-1408): the whole
+// front half of the fragment block has to run to know whether the fragment is written at all
+__device__ __noinline__ bool fragment_alpha_is_255_vm(const RasterParams &P, const TriShade *shade, uint32_t batch, float alpha, float beta,
+                                                      float z, float fx, float fy) {
+    const TriShade H = *shade;
+    Frag F;
+    shade3d_begin<true>(P, H, batch, alpha, beta, z, fx, fy, F);
+    return f32_to_u8_saturated(F.opacity) == 255u;
+}
+
+template <bool OPACITY, bool VM>
 __device__ __forceinline__ void visit(const RasterParams &P, const TriSetup &S, const TriShade *shade, uint32_t t, uint32_t slot,
                                       uint32_t px, uint32_t py, float fx, float fy, Vis &vis, int surf_profile) {
     uint32_t min_x = S.bx & 0xFFFFu, max_x = S.bx >> 16, min_y = S.by & 0xFFFFu, max_y = S.by >> 16;
@@ -911,7 +997,9 @@ __device__ __forceinline__ void visit(const RasterParams &P, const TriSetup &S, 
     float z = 1.0f / one_over_z;
     bool closer = z < vis.zmin || (z == vis.zmin && vis.best >= 0 && (int)t < vis.best);
     if (!closer) return;
-    if (!OPACITY && (S.bflags & DB_ALPHA_TEST)) {
+    if (VM && !OPACITY && (S.bflags & DB_PROGRAM_OPACITY)) {
+        if (!fragment_alpha_is_255_vm(P, shade, S.batch, alpha, beta, z, fx, fy)) return;
+    } else if (!OPACITY && (S.bflags & DB_ALPHA_TEST)) {
         // the fragment is only written when its encoded alpha is 255 (:1408): sample it now
         const DevBatch &B = P.batches3d[S.batch];
         const TriShade H = *shade;
@@ -964,7 +1052,7 @@ struct StageShade {
 //   3. all 256 threads copy the survivors' 96-byte TriSetup records into LDS with coalesced 16-byte
 //      loads,
 //   4. every lane walks the staged records (uniform LDS addresses -> broadcast reads).
-template <bool OPACITY>
+template <bool OPACITY, bool VM>
 __device__ __forceinline__ void scan_lists(const RasterParams &P, Stage &st, uint32_t b0, uint32_t b1, uint32_t tile_x0,
                                            uint32_t tile_y0px, uint32_t px, uint32_t py, float fx, float fy, Vis &vis,
                                            int surf_profile) {
@@ -1021,7 +1109,7 @@ __device__ __forceinline__ void scan_lists(const RasterParams &P, Stage &st, uin
         for (uint32_t k = 0; k < n; ++k) {
             const TriSetup &S = *reinterpret_cast<const TriSetup *>(&st.tri[k * 6u]);
             const uint32_t t = st.ids[k];
-            visit<OPACITY>(P, S, &P.tri_shade[t], t, k, px, py, fx, fy, vis, surf_profile);
+            visit<OPACITY, VM>(P, S, &P.tri_shade[t], t, k, px, py, fx, fy, vis, surf_profile);
         }
         __syncthreads();  // the stage is reused by the next round
     }
@@ -1031,7 +1119,7 @@ __device__ __forceinline__ void scan_lists(const RasterParams &P, Stage &st, uin
 // written their records): no lists at all.  All records are copied to LDS with one round of coalesced
 // loads, THEN thread t tests record t against the tile from LDS and the survivors' indices are
 // ballot-compacted -- one global-memory latency per tile instead of three dependent ones.
-template <bool OPACITY>
+template <bool OPACITY, bool VM>
 __device__ __forceinline__ void scan_implicit(const RasterParams &P, Stage &st, uint32_t tile_x0, uint32_t tile_y0px, uint32_t px, uint32_t py,
                                               float fx, float fy, Vis &vis, int surf_profile) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -1062,7 +1150,7 @@ __device__ __forceinline__ void scan_implicit(const RasterParams &P, Stage &st, 
     for (uint32_t k = 0; k < n; ++k) {
         const uint32_t t = st.ids[k];
         const TriSetup &S = *reinterpret_cast<const TriSetup *>(&st.tri[t * 6u]);
-        visit<OPACITY>(P, S, &P.tri_shade[t], t, t, px, py, fx, fy, vis, surf_profile);
+        visit<OPACITY, VM>(P, S, &P.tri_shade[t], t, t, px, py, fx, fy, vis, surf_profile);
     }
     __syncthreads();  // the stage is reused (second pass, 2D pass)
 }
@@ -1071,7 +1159,7 @@ __device__ __forceinline__ void scan_implicit(const RasterParams &P, Stage &st, 
 // staging round holds them all): no k_setup3d / k_scan / k_fill launches and no records in HBM --
 // thread t builds triangle t's TriSetup / TriShade itself (make_setup), tests its pixel box against
 // the tile, survivors are ballot-compacted straight into LDS, then every lane walks them.
-template <bool OPACITY>
+template <bool OPACITY, bool VM>
 __device__ __forceinline__ void scan_fused(const RasterParams &P, Stage &st, StageShade &sh, uint32_t tile_x0, uint32_t tile_y0px, uint32_t px,
                                            uint32_t py, float fx, float fy, Vis &vis, int surf_profile) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -1105,7 +1193,7 @@ __device__ __forceinline__ void scan_fused(const RasterParams &P, Stage &st, Sta
     __syncthreads();
     for (uint32_t k = 0; k < n; ++k) {
         const TriSetup &SK = *reinterpret_cast<const TriSetup *>(&st.tri[k * 6u]);
-        visit<OPACITY>(P, SK, &sh.shade[k], st.ids[k], k, px, py, fx, fy, vis, surf_profile);
+        visit<OPACITY, VM>(P, SK, &sh.shade[k], st.ids[k], k, px, py, fx, fy, vis, surf_profile);
     }
     __syncthreads();  // a second pass (opacity, then opaque) rebuilds the stage
 }
@@ -1135,6 +1223,7 @@ __device__ __forceinline__ bool bresenham_hits(const Prim2D &Ln, int px, int py)
 }
 
 // one 2D primitive against this lane's pixel (rasterizer.rs:636-655 coverage, then fragment2d / the line colour)
+template <bool VM>
 __device__ __forceinline__ uint32_t prim2d_pixel(const RasterParams &P, const Prim2D &T, uint32_t px, uint32_t py, float fx, float fy,
                                                  uint32_t color) {
     const uint32_t min_x = T.bx & 0xFFFFu, max_x = T.bx >> 16, min_y = T.by & 0xFFFFu, max_y = T.by >> 16;
@@ -1147,12 +1236,13 @@ __device__ __forceinline__ uint32_t prim2d_pixel(const RasterParams &P, const Pr
     float r1 = T.ea[1] * fx + T.eb[1] * fy + T.ec[1];
     float r2 = T.ea[2] * fx + T.eb[2] * fy + T.ec[2];
     in = in && !(r0 < 0.0f) && !(r1 < 0.0f) && !(r2 < 0.0f);
-    if (in) color = fragment2d(P, T, P.batches2d[T.batch_kind >> 2], px, py, fx, fy, color);
+    if (in) color = fragment2d<VM>(P, T, P.batches2d[T.batch_kind >> 2], px, py, fx, fy, color);
     return color;
 }
 
 // stages the Prim2D records of `n` primitive ids (st.ids-like array `ids`, already in submission order)
 // through LDS in rounds of RXR_STAGE_TRIS and applies them to this lane's pixel in order
+template <bool VM>
 __device__ __forceinline__ uint32_t walk_prims2d(const RasterParams &P, Stage &st, const uint32_t *ids, uint32_t n, bool implicit_ids,
                                                  uint32_t px, uint32_t py, float fx, float fy, uint32_t color) {
     const uint32_t tid = threadIdx.x;
@@ -1167,7 +1257,7 @@ __device__ __forceinline__ uint32_t walk_prims2d(const RasterParams &P, Stage &s
         __syncthreads();
         for (uint32_t k = 0; k < m; ++k) {
             const Prim2D &T = *reinterpret_cast<const Prim2D *>(&st.tri[k * 6u]);
-            color = prim2d_pixel(P, T, px, py, fx, fy, color);
+            color = prim2d_pixel<VM>(P, T, px, py, fx, fy, color);
         }
         __syncthreads();
     }
@@ -1192,7 +1282,7 @@ struct ShadeStore {
 template <>
 struct ShadeStore<false> {};
 
-template <bool FUSED>
+template <bool FUSED, bool VM>
 __device__ __forceinline__ void raster_tile(const RasterParams &P) {
     __shared__ Stage stage;
     __shared__ uint32_t s_bin[4];
@@ -1247,25 +1337,25 @@ __device__ __forceinline__ void raster_tile(const RasterParams &P) {
         op.zmin = 1.0f; op.best = -1; op.alpha = 0.0f; op.beta = 0.0f; op.slot = 0; op.batch = 0;
         uint32_t op_color = 0u;  // the opacity winner is shaded at once: the opaque pass rebuilds the stage
         if (P.has_opacity) {
-            if constexpr (FUSED) scan_fused<true>(P, stage, shade_store.s, tile_x0, tile_y0px, px, py, fx, fy, op, -1);
-            else if (P.fused_small == 2u) scan_implicit<true>(P, stage, tile_x0, tile_y0px, px, py, fx, fy, op, -1);
-            else scan_lists<true>(P, stage, b0, b1, tile_x0, tile_y0px, px, py, fx, fy, op, -1);
+            if constexpr (FUSED) scan_fused<true, VM>(P, stage, shade_store.s, tile_x0, tile_y0px, px, py, fx, fy, op, -1);
+            else if (P.fused_small == 2u) scan_implicit<true, VM>(P, stage, tile_x0, tile_y0px, px, py, fx, fy, op, -1);
+            else scan_lists<true, VM>(P, stage, b0, b1, tile_x0, tile_y0px, px, py, fx, fy, op, -1);
             if (op.best >= 0) {
                 const DevBatch &OB = P.batches3d[op.batch];
                 surf_profile = (OB.flags & DB_HAS_PROFILE) ? (int)OB.profile_id : -1;
                 TriShade OS;
                 if constexpr (FUSED) OS = shade_store.s.shade[op.slot];
                 else OS = P.tri_shade[op.best];
-                op_color = shade3d_opacity(P, OS, op.batch, op.alpha, op.beta);
+                op_color = shade3d_opacity<VM>(P, OS, op.batch, op.alpha, op.beta, op.zmin, fx, fy);
             }
             __syncthreads();  // everyone has copied its record before the stage is rebuilt
         }
         Vis vis;
         vis.zmin = 1.0f; vis.best = -1; vis.alpha = 0.0f; vis.beta = 0.0f; vis.slot = 0; vis.batch = 0;
         PHASE_MARK(0);
-        if constexpr (FUSED) scan_fused<false>(P, stage, shade_store.s, tile_x0, tile_y0px, px, py, fx, fy, vis, surf_profile);
-        else if (P.fused_small == 2u) scan_implicit<false>(P, stage, tile_x0, tile_y0px, px, py, fx, fy, vis, surf_profile);
-        else scan_lists<false>(P, stage, b0, b1, tile_x0, tile_y0px, px, py, fx, fy, vis, surf_profile);
+        if constexpr (FUSED) scan_fused<false, VM>(P, stage, shade_store.s, tile_x0, tile_y0px, px, py, fx, fy, vis, surf_profile);
+        else if (P.fused_small == 2u) scan_implicit<false, VM>(P, stage, tile_x0, tile_y0px, px, py, fx, fy, vis, surf_profile);
+        else scan_lists<false, VM>(P, stage, b0, b1, tile_x0, tile_y0px, px, py, fx, fy, vis, surf_profile);
 
         PHASE_MARK(1);
         // resolve (rasterizer.rs:409-497): hit -> shaded colour; miss -> [0,0,0,255]
@@ -1273,14 +1363,16 @@ __device__ __forceinline__ void raster_tile(const RasterParams &P) {
         Frag F;
         F.world = F.normal = F.view_dir = F.base = F.lit = mk3(0.0f, 0.0f, 0.0f);
         F.opacity = 0.0f;
+        F.rough = 0.5f;
+        F.metal = 0.0f;
         if (hit) {
             TriShade HS;
             if constexpr (FUSED) HS = shade_store.s.shade[vis.slot];
             else HS = P.tri_shade[vis.best];
-            shade3d_begin(P, HS, vis.batch, vis.alpha, vis.beta, vis.zmin, fx, fy, F);
+            shade3d_begin<VM>(P, HS, vis.batch, vis.alpha, vis.beta, vis.zmin, fx, fy, F);
         }
         PHASE_MARK(2);
-        if (P.n_lights) shade3d_lights(P, hit, F);  // wave-uniform call
+        if (P.n_lights) shade3d_lights<VM>(P, hit, F);  // wave-uniform call
         PHASE_MARK(3);
         color = hit ? shade3d_end(F) : pack4(0u, 0u, 0u, 255u);
         PHASE_MARK(4);
@@ -1329,7 +1421,7 @@ __device__ __forceinline__ void raster_tile(const RasterParams &P) {
             }
             if (keep) stage.ids[off + before] = tid;
             __syncthreads();
-            if (n) color = walk_prims2d(P, stage, stage.ids, n, false, px, py, fx, fy, color);
+            if (n) color = walk_prims2d<VM>(P, stage, stage.ids, n, false, px, py, fx, fy, color);
         } else {
             // candidates = [large 2D primitives whose box touches the tile] ++ [this tile's bin list], gathered
             // into LDS, sorted by primitive index (submission order), then staged and applied in order
@@ -1381,7 +1473,7 @@ __device__ __forceinline__ void raster_tile(const RasterParams &P) {
             const uint32_t n_cand = s_bin[2];
             if (n_cand > RXR_SORT2D_MAX) {
                 // more candidates than the LDS sort holds: walk every primitive in order (correct, slow)
-                color = walk_prims2d(P, stage, nullptr, P.n_prims2d, true, px, py, fx, fy, color);
+                color = walk_prims2d<VM>(P, stage, nullptr, P.n_prims2d, true, px, py, fx, fy, color);
             } else {
                 // bitonic sort of s_sort[0 .. n_cand) padded to the next power of two with 0xFFFFFFFF
                 uint32_t n2 = 1;
@@ -1404,7 +1496,7 @@ __device__ __forceinline__ void raster_tile(const RasterParams &P) {
                         __syncthreads();
                     }
                 }
-                color = walk_prims2d(P, stage, s_sort, n_cand, false, px, py, fx, fy, color);
+                color = walk_prims2d<VM>(P, stage, s_sort, n_cand, false, px, py, fx, fy, color);
             }
         }
     }
@@ -1419,8 +1511,11 @@ __device__ __forceinline__ void raster_tile(const RasterParams &P) {
 }
 
 // two instantiations so that each path gets its own register allocation
-extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_RASTER_WAVES_PER_SIMD) k_raster(RasterParams P) { raster_tile<false>(P); }
-extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_RASTER_WAVES_PER_SIMD) k_raster_fused(RasterParams P) { raster_tile<true>(P); }
+extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_RASTER_WAVES_PER_SIMD) k_raster(RasterParams P) { raster_tile<false, false>(P); }
+extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_RASTER_WAVES_PER_SIMD) k_raster_fused(RasterParams P) { raster_tile<true, false>(P); }
+// frames in which a batch runs a Rusteria program: the interpreter (rxr_vm.h) keeps its state in scratch memory,
+// so it gets its own instantiation and the kernels above stay as they are
+extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS) k_raster_vm(RasterParams P) { raster_tile<false, true>(P); }
 
 #if RXR_PHASE_TIMING
 extern "C" int rxr_debug_phase_read(unsigned long long *out16, int reset) {
@@ -1465,6 +1560,7 @@ extern "C" void rxr_launch_fill(const RasterParams *P, hipStream_t s) {
 extern "C" void rxr_launch_raster(const RasterParams *P, hipStream_t s) {
     uint32_t tiles = P->tiles_x * P->tiles_y;
     if (tiles == 0) return;
-    if (P->fused_small == 1u) hipLaunchKernelGGL(k_raster_fused, dim3(tiles), dim3(RXR_TILE_THREADS), 0, s, *P);
+    if (P->vm_code) hipLaunchKernelGGL(k_raster_vm, dim3(tiles), dim3(RXR_TILE_THREADS), 0, s, *P);
+    else if (P->fused_small == 1u) hipLaunchKernelGGL(k_raster_fused, dim3(tiles), dim3(RXR_TILE_THREADS), 0, s, *P);
     else hipLaunchKernelGGL(k_raster, dim3(tiles), dim3(RXR_TILE_THREADS), 0, s, *P);
 }

@@ -1,0 +1,238 @@
+"""Rusteria programs: the device VM (flattened jump code, rusterix_amd/csrc/rxr_vm.h)
+against the oracle's tree interpreter (oracle/rusteria_vm.hpp) on the same scenes, through the C ABI.
+
+Programs that only use exact arithmetic must match bit for bit; sin / cos / tan / atan / atan2 / pow / ln come
+from different math libraries (OCML vs glibc) and are compared at +-1 per 8-bit channel (TOLERANCE).  All
+programs here are "pure" in the sense of include/rxr.h, so the reference's per-tile Execution gives the same
+result as a per-fragment one."""
+import numpy as np
+import pytest
+
+from rusterix_amd import binding as B
+from rusterix_amd import scenes
+from rusterix_amd.binding import Program
+
+pytestmark = pytest.mark.gpu
+
+TOLERANCE = 1
+W, H = 192, 128
+
+
+def patterns():
+    rng = np.random.default_rng([0x52585231, 77])
+    return [rng.random((16, 32, 3), dtype=np.float32), rng.random((8, 8, 3), dtype=np.float32)]
+
+
+def rect_scene(api, program, textured=True, time=0.0, lights=False):
+    """a 2D rectangle over the whole frame whose batch runs `program` (src/rasterizer.rs:760-797)"""
+    scene = api.Scene.empty()
+    idx = scene.add_program(program)
+    rect = api.Batch2D.from_rectangle(0.0, 0.0, float(W), float(H))
+    rect.source(B.PixelSource.StaticTileIndex(0) if textured else B.PixelSource.Pixel((200, 100, 50, 255)))
+    rect.shader(idx)
+    scene.add_d2_static(rect)
+    if lights:
+        scene.lights([B.Light(B.LIGHT_POINT).with_position((60.0, 0.0, 40.0)).with_color((1.0, 0.9, 0.8)).with_intensity(1.5)
+                      .with_start_distance(10.0).with_end_distance(120.0).compile()])
+    assets = api.Assets.default().textures([B.Tile.from_texture(scenes.noise_texture(5, 32, 32))])
+    assets.patterns(patterns()).patterns(patterns()[::-1], normal=True).palette([(0.9, 0.1, 0.2), None, (0.2, 0.3, 0.9)])
+
+    def setup():
+        return api.Rasterizer.setup(None, B.Mat4.identity(), B.Mat4.identity()).time(time)
+
+    return scenes._result(api, scene, assets, setup, W, H, 40, "shader-rect")
+
+
+def cube_scene(api, program, opacity_list=False, behind=True):
+    """textured cube with lights whose batch runs `program` (src/rasterizer.rs:1283-1304 / :1642-1667)"""
+    scene = api.Scene.empty()
+    idx = scene.add_program(program)
+    box = api.Batch3D.from_box(-0.5, -0.5, -0.5, 1.0, 1.0, 1.0).cull_mode(B.CULL_OFF).with_computed_normals()
+    box.source(B.PixelSource.StaticTileIndex(0)).repeat_mode(B.REPEAT_REPEAT_XY).shader(idx)
+    if behind:
+        back = api.Batch3D.from_box(-1.2, -1.2, -2.0, 2.4, 2.4, 0.2).with_computed_normals().source(B.PixelSource.Pixel((30, 160, 60, 255)))
+        scene.add_d3_static(back)
+    if opacity_list:
+        chunk = scene.add_chunk()
+        chunk.add_batch3d_opacity(box)
+    else:
+        scene.add_d3_static(box)
+    scene.lights([B.Light(B.LIGHT_POINT).with_position((1.5, 1.0, 2.0)).with_color((1.0, 0.95, 0.8)).with_intensity(2.0)
+                  .with_start_distance(1.0).with_end_distance(8.0).compile()])
+    assets = api.Assets.default().textures([B.Tile.from_texture(scenes.noise_texture(6, 32, 32))])
+    assets.patterns(patterns())
+    cam = api.D3OrbitCamera.new()
+    cam.set_parameter_f32("distance", 2.5)
+    cam.azimuth = 1.0
+    cam.elevation = 0.5
+
+    def setup():
+        v, p = cam.matrices(float(W), float(H))
+        return api.Rasterizer.setup(None, v, p).ambient((0.3, 0.3, 0.35, 1.0)).time(1.25)
+
+    return scenes._result(api, scene, assets, setup, W, H, 40, "shader-cube")
+
+
+def compare(oracle, product, build, tol=0):
+    got = scenes.render(build(product))
+    ref = scenes.render(build(oracle))
+    diff = np.abs(got.astype(np.int16) - ref.astype(np.int16)).max(axis=2)
+    assert int(diff.max()) <= tol, f"{(diff > tol).sum()} pixels differ by more than {tol} (max {diff.max()}); first at {np.argwhere(diff > tol)[:3].tolist()}"
+    return got
+
+
+# per-pixel varying operands: A = (u*4 - 2, v*4 - 2, u*v) and B = (v + 0.25, u - 0.5, 1.5 - u)
+A = ["UV", ("GetComponents", [0]), ("Push", 16.0), "Mul", ("Push", 2.0), "Sub",
+     "UV", ("GetComponents", [1]), ("Push", 16.0), "Mul", ("Push", 2.0), "Sub",
+     "UV", ("GetComponents", [0]), "UV", ("GetComponents", [1]), "Mul", ("Push", 16.0), "Mul", "Pack3"]
+Bv = ["UV", ("GetComponents", [1]), ("Push", 4.0), "Mul", ("Push", 0.25), "Add",
+      "UV", ("GetComponents", [0]), ("Push", 4.0), "Mul", ("Push", 0.5), "Sub",
+      ("Push", 1.5), "UV", ("GetComponents", [0]), ("Push", 4.0), "Mul", "Sub", "Pack3"]
+TO_COLOR = [("Push", 0.25), "Mul", ("Push", 0.5), "Add", "SetColor"]
+
+EXACT_UNARY = ["Abs", "Neg", "Floor", "Ceil", "Round", "Fract", "Length", "Length2", "Length3", "Normalize", "Sqrt", "Radians", "Degrees", "Not"]
+EXACT_BINARY = ["Add", "Sub", "Mul", "Div", "Min", "Max", "Mod", "Step", "Dot", "Dot2", "Dot3", "Cross", "Eq", "Ne", "Lt", "Le", "Gt", "Ge", "And", "Or"]
+LIBM_UNARY = ["Sin", "Sin1", "Sin2", "Cos", "Cos1", "Cos2", "Tan", "Atan", "Log"]
+LIBM_BINARY = ["Atan2", "Pow", "Rotate2D"]
+
+
+@pytest.mark.parametrize("op", EXACT_UNARY)
+def test_exact_unary_ops(oracle, product, op):
+    compare(oracle, product, lambda api: rect_scene(api, Program([A + [op] + TO_COLOR])))
+
+
+@pytest.mark.parametrize("op", EXACT_BINARY)
+def test_exact_binary_ops(oracle, product, op):
+    compare(oracle, product, lambda api: rect_scene(api, Program([A + Bv + [op] + TO_COLOR])))
+
+
+@pytest.mark.parametrize("op", LIBM_UNARY)
+def test_libm_unary_ops(oracle, product, op):
+    compare(oracle, product, lambda api: rect_scene(api, Program([A + [op] + TO_COLOR])), tol=TOLERANCE)
+
+
+@pytest.mark.parametrize("op", LIBM_BINARY)
+def test_libm_binary_ops(oracle, product, op):
+    args = A + [("Push", 37.0)] if op == "Rotate2D" else A + Bv
+    compare(oracle, product, lambda api: rect_scene(api, Program([args + [op] + TO_COLOR])), tol=TOLERANCE)
+
+
+def test_ternary_ops_swizzles_and_fields(oracle, product):
+    prog = Program([A + Bv + [("Push", 0.3, 0.6, 0.9), "Mix",                      # mix(A, B, t)
+                              ("Push", -1.0), ("Push", 1.0), "Clamp",
+                              ("Push", 0.0), ("Push", 1.0), "UV", ("GetComponents", [0]), ("Push", 4.0), "Mul", "Smoothstep", "Mul",
+                              "Color", "Add",                                      # + the texel (pixel_to_vec4, not linearised in 2D)
+                              "Hitpoint", ("Push", 0.001), "Mul", "Add",
+                              "Time", ("Push", 0.1), "Mul", "Add",
+                              "Dup", ("GetComponents", [2, 0]), ("SetComponents", [1, 2]),
+                              ("Push", 0.5), "Mul", "SetColor"]])
+    compare(oracle, product, lambda api: rect_scene(api, prog, time=0.75, lights=True))
+
+
+def test_patterns_and_palette(oracle, product):
+    prog = Program([["UV", ("Push", 8.0), "Mul", ("Push", 0.0), "Sample",
+                     "UV", ("Push", 5.0), "Mul", ("Push", 1.0), "SampleNormal", ("Push", 0.25), "Mul", "Add",
+                     # slot 1 is empty: PaletteIndex then pushes nothing and the Add below consumes the sample instead
+                     ("Push", 0.1, 0.1, 0.1), "UV", ("GetComponents", [0]), ("Push", 12.0), "Mul", "PaletteIndex", "Add",
+                     "UV", ("Push", 3.0), "Mul", ("Push", 9.0), "Sample", "Add",                                          # no such pattern
+                     "SetColor"]])
+    got = compare(oracle, product, lambda api: rect_scene(api, prog))
+    assert len(np.unique(got.reshape(-1, 4), axis=0)) > 50
+
+
+def test_control_flow(oracle, product):
+    # per-pixel trip count, nested If, a helper function with a Return inside an If, recursion
+    helper = [("LoadLocal", 0), ("Push", 0.5), "Gt", ("If", [("LoadLocal", 0), ("Push", 0.5), "Sub", "Return"], None), ("LoadLocal", 0), "Return"]
+    fact = [("LoadLocal", 0), ("Push", 1.0), "Le", ("If", [("Push", 1.0), "Return"], None),
+            ("LoadLocal", 0), ("LoadLocal", 0), ("Push", 1.0), "Sub", ("FunctionCall", 1, 1, 2), "Mul", "Return"]
+    shade = [("Push", 0.0), ("StoreLocal", 0),
+             "UV", ("GetComponents", [0]), ("Push", 40.0), "Mul", "Floor", ("StoreLocal", 2),          # 0..9 iterations
+             ("For", [("Push", 0.0), ("StoreLocal", 1)], [("LoadLocal", 1), ("LoadLocal", 2), "Lt"],
+              [("LoadLocal", 1), ("Push", 1.0), "Add", ("StoreLocal", 1)],
+              [("LoadLocal", 1), ("Push", 2.0), "Mod", ("Push", 0.0), "Eq",
+               ("If", [("LoadLocal", 0), ("Push", 0.07), "Add", ("StoreLocal", 0)], [("LoadLocal", 0), ("Push", 0.02), "Add", ("StoreLocal", 0)]),
+               ("Push", 5.0)]),                                                                          # a temporary the loop truncates
+             ("LoadLocal", 0), "UV", ("GetComponents", [1]), ("Push", 4.0), "Mul", ("FunctionCall", 1, 1, 1),
+             "UV", ("GetComponents", [0]), ("Push", 16.0), "Mul", "Floor", ("FunctionCall", 1, 1, 2), ("Push", 0.04), "Mul", "Pack3", "SetColor"]
+    got = compare(oracle, product, lambda api: rect_scene(api, Program([shade, helper, fact], shade_locals=3), textured=False))
+    assert len(np.unique(got[..., 0])) > 5 and len(np.unique(got[..., 2])) >= 3
+
+
+def test_globals_written_before_read(oracle, product):
+    prog = Program([["UV", ("StoreGlobal", 1), ("LoadGlobal", 1), ("Push", 4.0), "Mul", ("FunctionCall", 0, 0, 1), "Add", "SetColor"],
+                    [("LoadGlobal", 1), ("Push", 1.0), "Mul"]], globals=2)
+    compare(oracle, product, lambda api: rect_scene(api, prog))
+
+
+def test_cube_material_program(oracle, product):
+    """the 3D opaque pass: colour, roughness, metallic and normal come back from the program and feed the lighting"""
+    prog = Program([["Color", "UV", ("Push", 6.0), "Mul", ("Push", 0.0), "Sample", "Mul", ("Push", 1.5), "Mul", "SetColor",
+                     "UV", ("GetComponents", [0]), ("Push", 4.0), "Mul", "Fract", "SetRoughness",
+                     "UV", ("GetComponents", [1]), ("Push", 4.0), "Mul", "Fract", "SetMetallic",
+                     "Normal", "Hitpoint", ("Push", 0.15), "Mul", "Add", "SetNormal"]])
+    got = compare(oracle, product, lambda api: cube_scene(api, prog), tol=TOLERANCE)
+    assert len(np.unique(got.reshape(-1, 4), axis=0)) > 200
+
+
+def test_cube_program_without_shade_function_is_ignored(oracle, product):
+    compare(oracle, product, lambda api: cube_scene(api, Program([[("Push", 1.0), "SetColor"]], shade_index=None)), tol=TOLERANCE)
+
+
+def test_program_opacity_decides_visibility(oracle, product):
+    """a program that writes opacity: fragments whose encoded alpha is not 255 are not written (src/rasterizer.rs:1403-1412),
+    so the wall behind shows through the holes and the depth of the holes is the wall's"""
+    prog = Program([["UV", ("Push", 12.0), "Mul", "Fract", ("GetComponents", [0]), ("Push", 0.5), "Gt",
+                     ("If", [("Push", 1.0), "SetOpacity"], [("Push", 0.4), "SetOpacity"]),
+                     "Color", ("Push", 1.2), "Mul", "SetColor"]])
+    got = compare(oracle, product, lambda api: cube_scene(api, prog), tol=TOLERANCE)
+    green = (got[..., 1] > got[..., 0] + 40) & (got[..., 1] > got[..., 2] + 40)
+    centre = green[H // 2 - 20:H // 2 + 20, W // 2 - 20:W // 2 + 20]
+    assert 0.2 < centre.mean() < 0.8, "the cut-outs should expose the wall behind the cube"
+
+
+def test_opacity_pass_program(oracle, product):
+    """chunk.batches3d_opacity with a program (src/rasterizer.rs:1642-1673): colour and opacity come from the program"""
+    prog = Program([["Color", "Hitpoint", ("Push", 0.5), "Mul", "Abs", "Add", "SetColor",
+                     "UV", ("GetComponents", [1]), ("Push", 4.0), "Mul", "Fract", "SetOpacity", "Normal", "Length", ("Push", 0.0), "Eq",
+                     ("If", [], [("Push", 0.0), "SetColor"])]])    # the opacity pass hands the program a zero normal
+    got = compare(oracle, product, lambda api: cube_scene(api, prog, opacity_list=True), tol=TOLERANCE)
+    assert len(np.unique(got.reshape(-1, 4), axis=0)) > 100
+
+
+def test_tile_size_does_not_matter_for_pure_programs(oracle):
+    prog = Program([["Color", "UV", "Add", "SetColor", "UV", ("GetComponents", [0]), ("Push", 4.0), "Mul", "SetRoughness"]])
+    cfg = cube_scene(oracle, prog)
+    a = scenes.render(cfg).copy()
+    cfg.tile_size = 16
+    assert np.array_equal(a, scenes.render(cfg))
+
+
+# ---- what the device refuses or reports --------------------------------------------------------------------
+@pytest.mark.parametrize("ops, why", [
+    ([("Push", 0.5), "SetEmissive"], "emissive leaks"),
+    ([("LoadGlobal", 0), "SetColor"], "global read before written"),
+    ([("For", [], [("Push", 0.0)], [], ["Return"])], "Return inside For"),
+    ([("Push", 4.0), ("Push", 4.0), "Alloc"], "texture baking"),
+])
+def test_unsupported_programs_are_refused(product, ops, why):
+    cfg = rect_scene(product, Program([ops], globals=1))
+    with pytest.raises(B.RasterizeError) as e:
+        scenes.render(cfg)
+    assert e.value.code == B.RXR_ERR_UNSUPPORTED, why
+
+
+@pytest.mark.parametrize("ops, locals_", [
+    (["Add"], 0),                                            # pop().unwrap() on an empty stack
+    ([("LoadLocal", 5)], 1),                                 # locals[5]
+    ([("FunctionCall", 0, 0, 9)], 0),                        # user_functions[9]
+    ([("Push", 1.0), ("Push", 2.0), ("Push", 1.0), "Clamp"], 0),
+    ([("For", [], [("Push", 1.0)], [], [])], 0),             # endless loop: the reference panics after 10 M iterations
+])
+def test_program_faults_are_reported(oracle, product, ops, locals_):
+    """where the reference panics both sides return an error instead of a frame"""
+    for api in (product,):
+        with pytest.raises(B.RasterizeError) as e:
+            scenes.render(rect_scene(api, Program([ops], shade_locals=locals_), textured=False))
+        assert e.value.code == B.RXR_ERR_INVALID
+    # and the context is usable afterwards
+    compare(oracle, product, lambda api: rect_scene(api, Program([["UV", "SetColor"]])))
