@@ -212,6 +212,44 @@ pub struct rxr_frame {
     pub mesh_transforms: *const f32,
 }
 
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct rxr_function {
+    pub words: *const u32,
+    pub n_words: u32,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct rxr_program {
+    pub n_globals: u32,
+    pub shade_index: i32,
+    pub shade_locals: u32,
+    pub functions: *const rxr_function,
+    pub n_functions: u32,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct rxr_pattern {
+    pub rgb: *const f32,
+    pub width: u32,
+    pub height: u32,
+}
+
+#[repr(C)]
+pub struct rxr_shader_set {
+    pub programs: *const rxr_program,
+    pub n_programs: u32,
+    pub patterns: *const rxr_pattern,
+    pub n_patterns: u32,
+    pub normal_patterns: *const rxr_pattern,
+    pub n_normal_patterns: u32,
+    pub palette_rgb: *const f32,
+    pub palette_present: *const u8,
+    pub n_palette: u32,
+}
+
 extern "C" {
     pub fn rxr_create(out: *mut *mut rxr_ctx, device_id: c_int) -> c_int;
     pub fn rxr_destroy(ctx: *mut rxr_ctx);
@@ -219,6 +257,7 @@ extern "C" {
     pub fn rxr_device_count() -> c_int;
     pub fn rxr_set_textures(ctx: *mut rxr_ctx, s: *const rxr_tile, ns: u32, d: *const rxr_tile, nd: u32) -> c_int;
     pub fn rxr_set_meshes(ctx: *mut rxr_ctx, meshes: *const rxr_mesh3d, n: u32) -> c_int;
+    pub fn rxr_set_shaders(ctx: *mut rxr_ctx, set: *const rxr_shader_set) -> c_int;
     pub fn rxr_upload_frame(ctx: *mut rxr_ctx, frame: *const rxr_frame) -> c_int;
     pub fn rxr_render_rows(ctx: *mut rxr_ctx, row0: u32, row1: u32) -> c_int;
     pub fn rxr_render_rows_to(ctx: *mut rxr_ctx, row0: u32, row1: u32, dev: *mut c_void, stream: *mut c_void) -> c_int;
