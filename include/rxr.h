@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define RXR_ABI_VERSION 1u
+#define RXR_ABI_VERSION 2u
 
 typedef enum rxr_status {
     RXR_OK = 0,
@@ -199,8 +199,21 @@ typedef struct rxr_linedef {
 
 /* the per-chunk data the raster loops read (src/chunk.rs); chunks in the host's iteration order */
 typedef struct rxr_chunk {
-    const rxr_occluder *occluders;
+    const rxr_occluder *occluders;    /* chunk.occluded_sectors (src/chunk.rs:42)                  */
     uint32_t n_occluders;
+    /* chunk.shaders (src/chunk.rs:51): programs[program_base .. program_base + n_programs) of the set given to
+     * rxr_set_shaders; a chunk batch's `shader` indexes this range (src/rasterizer.rs:763, :1285, :1645) */
+    uint32_t program_base, n_programs;
+    /* chunk.shader_textures (src/chunk.rs:53): the baked texture of shader i replaces the texel of a 3D
+     * opaque-pass batch whose shader == i, and the program does not run (src/rasterizer.rs:1226-1267);
+     * rgba == NULL for None */
+    const rxr_texture *shader_textures;
+    uint32_t n_shader_textures;
+    /* chunk.terrain_texture (NULL = None), chunk.origin, chunk.size: what PixelSource::Terrain batches of
+     * this chunk sample by world position (src/chunk.rs:133-151) */
+    const rxr_texture *terrain_texture;
+    int32_t origin[2];
+    int32_t size;
 } rxr_chunk;
 
 /* everything `rasterize` reads from `self` and `scene` after projection */

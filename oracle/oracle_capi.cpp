@@ -41,6 +41,7 @@ std::vector<Batch3D> *list3d(Scene *s, int list, int chunk) {
     switch (list) {
         case RXR_LIST_CHUNK_OPACITY: return (chunk >= 0 && (size_t)chunk < s->chunks.size()) ? &s->chunks[chunk].batches3d_opacity : nullptr;
         case RXR_LIST_CHUNK: return (chunk >= 0 && (size_t)chunk < s->chunks.size()) ? &s->chunks[chunk].batches3d : nullptr;
+        case RXR_LIST_CHUNK_TERRAIN: return (chunk >= 0 && (size_t)chunk < s->chunks.size()) ? &s->chunks[chunk].terrain_batch3d : nullptr;
         case RXR_LIST_STATIC: return &s->d3_static;
         case RXR_LIST_DYNAMIC: return &s->d3_dynamic;
         case RXR_LIST_OVERLAY: return &s->d3_overlay;
@@ -69,6 +70,36 @@ int orc_scene_add_chunk(void *s) {
 }
 void orc_chunk_add_occluder(void *s, int chunk, float minx, float miny, float maxx, float maxy, float occ) {
     ((Scene *)s)->chunks[chunk].occluded_sectors.push_back(Occluder{{minx, miny}, {maxx, maxy}, occ});
+}
+// chunk.terrain_texture / origin / size (src/chunk.rs:25-36); rgba == NULL: no texture
+void orc_chunk_set_terrain(void *s, int chunk, const uint8_t *rgba, uint32_t w, uint32_t h, int ox, int oy, int size) {
+    Chunk &c = ((Scene *)s)->chunks[chunk];
+    c.origin[0] = ox;
+    c.origin[1] = oy;
+    c.size = size;
+    c.has_terrain_texture = rgba != nullptr;
+    if (rgba) {
+        c.terrain_texture.width = w;
+        c.terrain_texture.height = h;
+        c.terrain_texture.data.assign(rgba, rgba + (size_t)w * h * 4);
+    }
+}
+void orc_chunk_set_terrain_batch2d(void *s, int chunk, void *b) {
+    Chunk &c = ((Scene *)s)->chunks[chunk];
+    c.terrain_batch2d.clear();
+    c.terrain_batch2d.push_back(*(Batch2D *)b);
+}
+// chunk.shader_textures.push(texture) (src/chunk.rs:129); rgba == NULL pushes None
+void orc_chunk_add_shader_texture(void *s, int chunk, const uint8_t *rgba, uint32_t w, uint32_t h) {
+    Chunk &c = ((Scene *)s)->chunks[chunk];
+    Texture t;
+    if (rgba) {
+        t.width = w;
+        t.height = h;
+        t.data.assign(rgba, rgba + (size_t)w * h * 4);
+    }
+    c.shader_textures.push_back(std::move(t));
+    c.shader_texture_present.push_back(rgba ? 1 : 0);
 }
 void orc_chunk_add_light(void *s, int chunk, const rxr_light *l) { ((Scene *)s)->chunks[chunk].lights.push_back(*l); }
 // scene.add_shader (src/scene.rs:104-134) minus the parser / compiler: the program arrives as NodeOp trees
@@ -148,6 +179,7 @@ uint32_t orc_batch3d_num_normals(void *b) { return (uint32_t)((Batch3D *)b)->nor
 int orc_scene_push_batch3d(void *s, void *b, int list, int chunk) {
     auto *l = list3d((Scene *)s, list, chunk);
     if (!l) return RXR_ERR_INVALID;
+    if (list == RXR_LIST_CHUNK_TERRAIN) l->clear();  // Option<Batch3D>: the latest one wins
     l->push_back(*(Batch3D *)b);
     return 0;
 }

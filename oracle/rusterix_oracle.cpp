@@ -641,8 +641,10 @@ bool scene_project(Scene &s, const Mat3 *m2d, const Mat4 &view, const Mat4 &proj
     bool ok = true;
     for (Chunk &c : s.chunks) {
         for (auto &b : c.batches2d) batch2d_project(b, m2d);
+        for (auto &b : c.terrain_batch2d) batch2d_project(b, m2d);
         for (auto &b : c.batches3d_opacity) ok &= batch3d_clip_and_project(b, view, proj, w, h);
         for (auto &b : c.batches3d) ok &= batch3d_clip_and_project(b, view, proj, w, h);
+        for (auto &b : c.terrain_batch3d) ok &= batch3d_clip_and_project(b, view, proj, w, h);
     }
     for (auto &b : s.d2_static) batch2d_project(b, m2d);
     for (auto &b : s.d2_dynamic) batch2d_project(b, m2d);
@@ -748,7 +750,8 @@ static inline Vec3 shade_fast_brdf(Vec3 base_color, float roughness, float metal
 // 3D: src/rasterizer.rs:1101-1222 (unknown -> [0,0,0,255]); 2D: :672-758 (unknown -> [0,0,0,0]).
 // Returns false where the reference would panic (3D tile_list[index] unchecked, :1103).
 static inline bool fetch_texel(const FrameCtx &fc, const Source &src, int repeat_mode, float u, float v, bool is_3d,
-                               bool in_chunk, uint8_t texel[4]) {
+                               const Chunk *chunk, Vec2 terrain_pos, uint8_t texel[4]) {
+    const bool in_chunk = chunk != nullptr;
     const Rasterizer &r = *fc.r;
     auto zero = [&]() { texel[0] = texel[1] = texel[2] = texel[3] = 0; };
     switch (src.kind) {
@@ -784,7 +787,8 @@ static inline bool fetch_texel(const FrameCtx &fc, const Source &src, int repeat
             return true;
         case RXR_SOURCE_TERRAIN:
             if (in_chunk) {
-                zero();  // chunk.sample_terrain_texture with no terrain texture, src/chunk.rs:150
+                // 3D: chunk.sample_terrain_texture(world_2d, Vec2::one()), :1191; 2D: (world, Vec2::one()), :751
+                if (!chunk_sample_terrain_texture(*chunk, terrain_pos, Vec2{1.0f, 1.0f}, texel)) return false;
             } else if (is_3d) {
                 texel[0] = 255; texel[1] = 0; texel[2] = 0; texel[3] = 255;  // :1218
             } else {
@@ -813,6 +817,29 @@ static inline void tri_bounds(const float *v0, const float *v1, const float *v2,
     max_x = (size_t)sat_usize(rmin(std::ceil(max_xf), (float)(tile.x + tile.width)));
     min_y = (size_t)sat_usize(rmax(std::floor(min_yf), (float)tile.y));
     max_y = (size_t)sat_usize(rmin(std::ceil(max_yf), (float)(tile.y + tile.height)));
+}
+
+// ---- src/chunk.rs:133-151 ----------------------------------------------------------------------
+bool chunk_sample_terrain_texture(const Chunk &c, Vec2 world_pos, Vec2 scale, uint8_t out[4]) {
+    float local_x = (world_pos.x / scale.x) - (float)c.origin[0];
+    float local_y = (world_pos.y / scale.y) - (float)c.origin[1];
+    if (c.has_terrain_texture) {
+        const Texture &texture = c.terrain_texture;
+        if (c.size == 0) return false;  // `texture.width as i32 / self.size` panics
+        if ((int32_t)texture.width == INT32_MIN && c.size == -1) return false;
+        int pixels_per_tile = (int)(int32_t)texture.width / c.size;
+        float pixel_x = local_x * (float)pixels_per_tile;
+        float pixel_y = local_y * (float)pixels_per_tile;
+        // f32::clamp(0.0, w - 1.0) with w >= 1 never panics; `as u32` saturates, NaN -> 0
+        uint32_t px = sat_u32(rclamp(std::floor(pixel_x), 0.0f, (float)texture.width - 1.0f));
+        uint32_t py = sat_u32(rclamp(std::floor(pixel_y), 0.0f, (float)texture.height - 1.0f));
+        // Texture::get_pixel, src/texture.rs:527-538
+        size_t x = std::min<size_t>(px, texture.width - 1), y = std::min<size_t>(py, texture.height - 1);
+        memcpy(out, &texture.data[(y * texture.width + x) * 4], 4);
+        return true;
+    }
+    out[0] = out[1] = out[2] = out[3] = 0;
+    return true;
 }
 
 // ---- src/rasterizer.rs:964-1420 --------------------------------------------------------------
@@ -881,7 +908,7 @@ static int d3_rasterize(const FrameCtx &fc, uint8_t *buffer, float *z_buffer, co
                 }
 
                 uint8_t texel[4];
-                if (!fetch_texel(fc, batch.source, batch.repeat_mode, interpolated_u, interpolated_v, true, chunk != nullptr, texel))
+                if (!fetch_texel(fc, batch.source, batch.repeat_mode, interpolated_u, interpolated_v, true, chunk, world_2d, texel))
                     return RXR_ERR_INVALID;
 
                 float color[4];
@@ -897,7 +924,22 @@ static int d3_rasterize(const FrameCtx &fc, uint8_t *buffer, float *z_buffer, co
                 execution.normal = normal;
                 execution.roughness.x = 0.5f;
                 execution.metallic.x = 0.0f;
-                if (batch.shader >= 0) {  // :1283-1304
+                const Texture *baked = nullptr;  // chunk.shader_textures.get(shader_index), :1226-1237
+                if (batch.shader >= 0 && chunk && (size_t)batch.shader < chunk->shader_textures.size() &&
+                    chunk->shader_texture_present[(size_t)batch.shader])
+                    baked = &chunk->shader_textures[(size_t)batch.shader];
+                if (baked) {  // :1239-1267: the baked shader texture replaces the texel; the program does not run
+                    texture_sample(*baked, interpolated_u, interpolated_v, r.sample_mode, batch.repeat_mode, texel);
+                    pixel_to_vec4(texel, color);
+                    color[0] = srgb_to_linear_fast(color[0]);
+                    color[1] = srgb_to_linear_fast(color[1]);
+                    color[2] = srgb_to_linear_fast(color[2]);
+                    execution.color = Vec3{color[0], color[1], color[2]};
+                    execution.opacity.x = color[3];
+                    execution.roughness.x = 0.5f;
+                    execution.metallic.x = 0.0f;
+                    execution.normal = normal;
+                } else if (batch.shader >= 0) {  // :1283-1304
                     const std::vector<vm::Program> &progs = chunk ? chunk->shaders : fc.scene->shaders;
                     if ((size_t)batch.shader < progs.size()) {
                         const vm::Program &program = progs[(size_t)batch.shader];
@@ -1021,8 +1063,11 @@ static int d3_rasterize_opacity(const FrameCtx &fc, uint8_t *buffer, float *z_bu
                 interpolated_u /= interpolated_reciprocal_w;
                 interpolated_v /= interpolated_reciprocal_w;
 
+                Vec3 world = screen_to_world(*fc.r, p[0], p[1], z);  // :1515
+                Vec2 world_2d{world.x, world.z};
+
                 uint8_t texel[4];
-                if (!fetch_texel(fc, batch.source, batch.repeat_mode, interpolated_u, interpolated_v, true, chunk != nullptr, texel))
+                if (!fetch_texel(fc, batch.source, batch.repeat_mode, interpolated_u, interpolated_v, true, chunk, world_2d, texel))
                     return RXR_ERR_INVALID;
 
                 float color[4];
@@ -1038,7 +1083,6 @@ static int d3_rasterize_opacity(const FrameCtx &fc, uint8_t *buffer, float *z_bu
                     if ((size_t)batch.shader < progs.size()) {
                         const vm::Program &program = progs[(size_t)batch.shader];
                         if (program.shade_index >= 0) {
-                            Vec3 world = screen_to_world(*fc.r, p[0], p[1], z);  // :1515
                             execution.normal = Vec3{0, 0, 0};
                             execution.uv.x = interpolated_u / 4.0f;
                             execution.uv.y = interpolated_v / 4.0f;
@@ -1152,7 +1196,7 @@ static int d2_rasterize(const FrameCtx &fc, uint8_t *buffer, const TileRect &til
                         Vec2 world = grid_space_pos / r.scaled2;
 
                         uint8_t texel[4];
-                        if (!fetch_texel(fc, batch.source, batch.repeat_mode, u, v, false, chunk != nullptr, texel))
+                        if (!fetch_texel(fc, batch.source, batch.repeat_mode, u, v, false, chunk, world, texel))
                             return RXR_ERR_INVALID;
 
                         if (batch.shader >= 0) {  // :760-797
@@ -1300,6 +1344,8 @@ static int raster_tile(const FrameCtx &fc, const TileRect &tile, std::vector<uin
                 if ((rc = d3_rasterize_opacity(fc, buffer_opacity.data(), z_buffer_opacity.data(), surface_id.data(), tile, b, &chunk, execution))) return rc;
             for (const Batch3D &b : chunk.batches3d)
                 if ((rc = d3_rasterize(fc, buffer.data(), z_buffer.data(), surface_id.data(), tile, b, &chunk, execution))) return rc;
+            for (const Batch3D &b : chunk.terrain_batch3d)  // :343-356
+                if ((rc = d3_rasterize(fc, buffer.data(), z_buffer.data(), surface_id.data(), tile, b, &chunk, execution))) return rc;
         }
         for (const Batch3D &b : scene.d3_static)
             if ((rc = d3_rasterize(fc, buffer.data(), z_buffer.data(), surface_id.data(), tile, b, nullptr, execution))) return rc;
@@ -1340,9 +1386,12 @@ static int raster_tile(const FrameCtx &fc, const TileRect &tile, std::vector<uin
     }
 
     if (r.d2_active) {  // :501-553
-        for (const Chunk &chunk : scene.chunks)
+        for (const Chunk &chunk : scene.chunks) {
             for (const Batch2D &b : chunk.batches2d)
                 if ((rc = d2_rasterize(fc, buffer.data(), tile, b, &chunk, execution))) return rc;
+            for (const Batch2D &b : chunk.terrain_batch2d)  // :515-525
+                if ((rc = d2_rasterize(fc, buffer.data(), tile, b, &chunk, execution))) return rc;
+        }
         for (const Batch2D &b : scene.d2_static)
             if ((rc = d2_rasterize(fc, buffer.data(), tile, b, nullptr, execution))) return rc;
         for (const Batch2D &b : scene.d2_dynamic)

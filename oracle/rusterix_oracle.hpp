@@ -182,7 +182,18 @@ struct Chunk {
     std::vector<CompiledLight> lights;
     std::vector<Occluder> occluded_sectors;
     std::vector<vm::Program> shaders;  // src/chunk.rs:51
+    // Option<..> fields as 0- or 1-element vectors / presence flags
+    std::vector<Batch2D> terrain_batch2d;        // src/chunk.rs:34
+    std::vector<Batch3D> terrain_batch3d;        // :35
+    bool has_terrain_texture = false;            // :36
+    Texture terrain_texture;
+    int origin[2] = {0, 0};                      // :25
+    int size = 1;                                // :26
+    std::vector<Texture> shader_textures;        // :53: Vec<Option<Texture>>
+    std::vector<uint8_t> shader_texture_present;
 };
+// src/chunk.rs:133-151; false where the reference panics (size == 0: integer division by zero)
+bool chunk_sample_terrain_texture(const Chunk &c, Vec2 world_pos, Vec2 scale, uint8_t out[4]);
 
 // src/scene.rs:8-50
 struct Scene {

@@ -346,6 +346,9 @@ def make_api(lib: C.CDLL, prefix: str, name: str):
         scene_add_chunk=fn("scene_add_chunk", i32, vp),
         chunk_add_occluder=fn("chunk_add_occluder", None, vp, i32, f32, f32, f32, f32, f32),
         chunk_add_light=fn("chunk_add_light", None, vp, i32, C.POINTER(RxrLight)),
+        chunk_set_terrain=fn("chunk_set_terrain", None, vp, i32, pb, u32, u32, i32, i32, i32),
+        chunk_set_terrain_batch2d=fn("chunk_set_terrain_batch2d", None, vp, i32, vp),
+        chunk_add_shader_texture=fn("chunk_add_shader_texture", None, vp, i32, pb, u32, u32),
         scene_num_dynamic_lights=fn("scene_num_dynamic_lights", u32, vp),
         scene_add_program=fn("scene_add_program", i32, vp, i32, u32, i32, u32, C.POINTER(pu), pu, u32),
         assets_set_patterns=fn("assets_set_patterns", None, vp, i32, C.POINTER(pf), pu, pu, u32),
@@ -557,6 +560,32 @@ def make_api(lib: C.CDLL, prefix: str, name: str):
         def add_batch2d(self, b):
             assert L.scene_push_batch2d(self._scene._h, b._h, 0, self.index) == 0
             return self
+
+        def terrain(self, texture, origin=(0, 0), size=1):
+            """chunk.terrain_texture (a Texture or None), chunk.origin, chunk.size (reference src/chunk.rs:25-36)"""
+            if texture is None:
+                L.chunk_set_terrain(self._scene._h, self.index, None, 0, 0, origin[0], origin[1], size)
+            else:
+                L.chunk_set_terrain(self._scene._h, self.index, _bp(texture.data), texture.width, texture.height, origin[0], origin[1], size)
+            return self
+
+        def terrain_batch3d(self, b):
+            assert L.scene_push_batch3d(self._scene._h, b._h, LIST_CHUNK_TERRAIN, self.index) == 0
+            return self
+
+        def terrain_batch2d(self, b):
+            L.chunk_set_terrain_batch2d(self._scene._h, self.index, b._h)
+            return self
+
+        def add_shader(self, program: Program, baked_texture=None):
+            """chunk.add_shader (reference src/chunk.rs:84-131) without the compiler and the 64x64 bake: the program and
+            the texture the reference would have baked from it (or None) are given directly; returns the shader index"""
+            idx = self._scene.add_program(program, chunk=self.index)
+            if baked_texture is None:
+                L.chunk_add_shader_texture(self._scene._h, self.index, None, 0, 0)
+            else:
+                L.chunk_add_shader_texture(self._scene._h, self.index, _bp(baked_texture.data), baked_texture.width, baked_texture.height)
+            return idx
 
         def add_occluder(self, mn, mx, occlusion):
             L.chunk_add_occluder(self._scene._h, self.index, mn[0], mn[1], mx[0], mx[1], occlusion)

@@ -380,8 +380,10 @@ bool Scene::project(const Mat3 *m2d, const Mat4 &view, const Mat4 &proj, float w
     bool ok = true;
     for (Chunk &c : chunks) {
         for (Batch2D &b : c.batches2d) b.project(m2d);
+        for (Batch2D &b : c.terrain_batch2d) b.project(m2d);
         for (Batch3D &b : c.batches3d_opacity) ok &= b.clip_and_project(view, proj, w, h);
         for (Batch3D &b : c.batches3d) ok &= b.clip_and_project(view, proj, w, h);
+        for (Batch3D &b : c.terrain_batch3d) ok &= b.clip_and_project(view, proj, w, h);
     }
     for (Batch2D &b : d2_static) b.project(m2d);
     for (Batch2D &b : d2_dynamic) b.project(m2d);
@@ -392,8 +394,10 @@ bool Scene::project(const Mat3 *m2d, const Mat4 &view, const Mat4 &proj, float w
 }
 
 void Scene::project_2d(const Mat3 *m2d) {
-    for (Chunk &c : chunks)
+    for (Chunk &c : chunks) {
         for (Batch2D &b : c.batches2d) b.project(m2d);
+        for (Batch2D &b : c.terrain_batch2d) b.project(m2d);
+    }
     for (Batch2D &b : d2_static) b.project(m2d);
     for (Batch2D &b : d2_dynamic) b.project(m2d);
 }
@@ -568,16 +572,19 @@ int Rasterizer::upload(Scene &scene, size_t w, size_t h, size_t tile_size, const
     }
 
     // Rusteria programs, patterns, palette: re-sent only when they changed
-    for (const Chunk &c : scene.chunks)
-        if (!c.shaders.empty()) {
-            g_error = "chunk-level shader programs (chunk.shaders / shader_textures) are not supported on the device yet";
-            return RXR_ERR_UNSUPPORTED;
-        }
+    // one table: scene.shaders first, then every chunk's shaders (rxr_chunk.program_base points into it)
+    std::vector<const Program *> all_programs;
+    for (const Program &p : scene.shaders) all_programs.push_back(&p);
+    std::vector<uint32_t> chunk_program_base(scene.chunks.size(), 0);
+    for (size_t c = 0; c < scene.chunks.size(); ++c) {
+        chunk_program_base[c] = (uint32_t)all_programs.size();
+        for (const Program &p : scene.chunks[c].shaders) all_programs.push_back(&p);
+    }
     if (g_shaders_gen != scene.shaders_generation || g_shader_env_gen != assets.shader_env_generation) {
-        std::vector<std::vector<rxr_function>> fns(scene.shaders.size());
-        std::vector<rxr_program> progs(scene.shaders.size());
-        for (size_t i = 0; i < scene.shaders.size(); ++i) {
-            const Program &p = scene.shaders[i];
+        std::vector<std::vector<rxr_function>> fns(all_programs.size());
+        std::vector<rxr_program> progs(all_programs.size());
+        for (size_t i = 0; i < all_programs.size(); ++i) {
+            const Program &p = *all_programs[i];
             for (const auto &f : p.user_functions) fns[i].push_back(rxr_function{f.data(), (uint32_t)f.size()});
             progs[i] = rxr_program{p.globals, p.shade_index, p.shade_locals, fns[i].data(), (uint32_t)fns[i].size()};
         }
@@ -611,12 +618,34 @@ int Rasterizer::upload(Scene &scene, size_t w, size_t h, size_t tile_size, const
     std::vector<rxr_batch3d> b3;
     std::vector<rxr_batch2d> b2;
     std::vector<rxr_chunk> chunks;
+    std::vector<std::vector<rxr_texture>> chunk_shader_textures(scene.chunks.size());
+    std::vector<rxr_texture> chunk_terrain_textures(scene.chunks.size());
     for (size_t c = 0; c < scene.chunks.size(); ++c) {
         const Chunk &ch = scene.chunks[c];
         for (const Batch3D &b : ch.batches3d_opacity) b3.push_back(view3d(b, RXR_LIST_CHUNK_OPACITY, (int)c));
         for (const Batch3D &b : ch.batches3d) b3.push_back(view3d(b, RXR_LIST_CHUNK, (int)c));
+        for (const Batch3D &b : ch.terrain_batch3d) b3.push_back(view3d(b, RXR_LIST_CHUNK_TERRAIN, (int)c));  // :343-356
         for (const Batch2D &b : ch.batches2d) b2.push_back(view2d(b, (int)c));
-        chunks.push_back(rxr_chunk{ch.occluded_sectors.data(), (uint32_t)ch.occluded_sectors.size()});
+        for (const Batch2D &b : ch.terrain_batch2d) b2.push_back(view2d(b, (int)c));  // :515-525
+        rxr_chunk rc{};
+        rc.occluders = ch.occluded_sectors.data();
+        rc.n_occluders = (uint32_t)ch.occluded_sectors.size();
+        rc.program_base = chunk_program_base[c];
+        rc.n_programs = (uint32_t)ch.shaders.size();
+        for (size_t k = 0; k < ch.shader_textures.size(); ++k) {
+            const Texture &t = ch.shader_textures[k];
+            chunk_shader_textures[c].push_back(rxr_texture{ch.shader_texture_present[k] ? t.data.data() : nullptr, (uint32_t)t.width, (uint32_t)t.height});
+        }
+        rc.shader_textures = chunk_shader_textures[c].data();
+        rc.n_shader_textures = (uint32_t)chunk_shader_textures[c].size();
+        if (ch.has_terrain_texture) {
+            chunk_terrain_textures[c] = rxr_texture{ch.terrain_texture.data.data(), (uint32_t)ch.terrain_texture.width, (uint32_t)ch.terrain_texture.height};
+            rc.terrain_texture = &chunk_terrain_textures[c];
+        }
+        rc.origin[0] = ch.origin[0];
+        rc.origin[1] = ch.origin[1];
+        rc.size = ch.size;
+        chunks.push_back(rc);
     }
     for (const Batch3D &b : scene.d3_static) b3.push_back(view3d(b, RXR_LIST_STATIC, -1));
     for (const Batch3D &b : scene.d3_dynamic) b3.push_back(view3d(b, RXR_LIST_DYNAMIC, -1));
@@ -667,6 +696,7 @@ int Rasterizer::upload(Scene &scene, size_t w, size_t h, size_t tile_size, const
         for (size_t c = 0; c < scene.chunks.size(); ++c) {
             for (const Batch3D &b : scene.chunks[c].batches3d_opacity) ok = ok && add(b, RXR_LIST_CHUNK_OPACITY, (int)c);
             for (const Batch3D &b : scene.chunks[c].batches3d) ok = ok && add(b, RXR_LIST_CHUNK, (int)c);
+            for (const Batch3D &b : scene.chunks[c].terrain_batch3d) ok = ok && add(b, RXR_LIST_CHUNK_TERRAIN, (int)c);
         }
         for (const Batch3D &b : scene.d3_static) ok = ok && add(b, RXR_LIST_STATIC, -1);
         for (const Batch3D &b : scene.d3_dynamic) ok = ok && add(b, RXR_LIST_DYNAMIC, -1);

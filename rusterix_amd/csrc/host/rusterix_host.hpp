@@ -161,7 +161,16 @@ struct Chunk {
     std::vector<Batch2D> batches2d;
     std::vector<CompiledLight> lights;
     std::vector<rxr_occluder> occluded_sectors;
-    std::vector<Program> shaders;  // src/chunk.rs:51 -- not supported on the device yet: rasterize returns RXR_ERR_UNSUPPORTED
+    std::vector<Program> shaders;  // src/chunk.rs:51
+    // Option<..> fields as 0- or 1-element vectors / presence flags
+    std::vector<Batch2D> terrain_batch2d;           // src/chunk.rs:34
+    std::vector<Batch3D> terrain_batch3d;           // :35
+    bool has_terrain_texture = false;               // :36
+    Texture terrain_texture;
+    int32_t origin[2] = {0, 0};                     // :25
+    int32_t size = 1;                               // :26
+    std::vector<Texture> shader_textures;           // :53, Vec<Option<Texture>>
+    std::vector<uint8_t> shader_texture_present;
 };
 
 // src/scene.rs:8-50

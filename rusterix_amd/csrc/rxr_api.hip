@@ -190,8 +190,8 @@ bool to_isize32(float x, int32_t &out) {
 }
 
 struct Layout {
-    size_t off_b3, off_base, off_pv, off_uv, off_nrm, off_idx, off_edges, off_lights, off_occ, off_ld, off_chunks, off_b2,
-        off_p2, off_bg, total;
+    size_t off_b3, off_base, off_pv, off_uv, off_nrm, off_idx, off_edges, off_lights, off_occ, off_ld, off_chunks, off_tdesc,
+        off_ltex, off_b2, off_p2, off_bg, total;
 };
 
 }  // namespace
@@ -569,13 +569,17 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
     // ---- pass 1: validate + size ---------------------------------------------------------------
     if (f->n_shader_programs > ctx->programs.size())
         return fail(ctx, RXR_ERR_INVALID, "rxr_upload_frame: n_shader_programs exceeds the programs set with rxr_set_shaders");
-    // batch.shader -> program (scene.shaders.get(index), src/rasterizer.rs:1287); chunk batches look in chunk.shaders,
-    // which this ABI does not carry: they resolve to no program
+    // batch.shader -> program: chunk.shaders.get(index) for chunk batches, scene.shaders.get(index) otherwise
+    // (src/rasterizer.rs:763-766, :1285-1288, :1645-1648)
     auto program_of = [&](int32_t shader, int32_t chunk) -> uint32_t {
-        if (shader < 0 || chunk >= 0 || (uint32_t)shader >= f->n_shader_programs) return 0u;
-        return (uint32_t)shader + 1u;
+        if (shader < 0) return 0u;
+        if (chunk >= 0) {
+            const rxr_chunk &ck = f->chunks[chunk];
+            return (uint32_t)shader < ck.n_programs ? ck.program_base + (uint32_t)shader + 1u : 0u;
+        }
+        return (uint32_t)shader < f->n_shader_programs ? (uint32_t)shader + 1u : 0u;
     };
-    bool uses_programs = false;
+    bool uses_programs = false, uses_chunk_tex = false;
     size_t n_v3 = 0, n_t3 = 0;
     bool has_opacity = false;
     const bool use_meshes = f->use_meshes != 0;
@@ -619,10 +623,43 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
         n_items += 1;
     }
     size_t n_occ_total = f->n_occluders;
+    // this frame's chunk textures (terrain, baked shader textures): DevTexDesc indices after the resident ones
+    struct LocalTex {
+        const rxr_texture *t;
+        bool opaque;
+    };
+    std::vector<LocalTex> local_tex;
+    std::vector<int32_t> chunk_terrain(f->n_chunks, -1);
+    std::vector<std::vector<int32_t>> chunk_baked(f->n_chunks);
+    size_t local_texels = 0;
+    const uint32_t n_res_tex = (uint32_t)ctx->h_tex.size();
     for (uint32_t c = 0; c < f->n_chunks; ++c) {
-        if (f->chunks[c].n_occluders && !f->chunks[c].occluders) return fail(ctx, RXR_ERR_INVALID, "chunk: NULL occluders");
-        n_occ_total += f->chunks[c].n_occluders;
+        const rxr_chunk &ck = f->chunks[c];
+        if (ck.n_occluders && !ck.occluders) return fail(ctx, RXR_ERR_INVALID, "chunk: NULL occluders");
+        n_occ_total += ck.n_occluders;
+        if ((uint64_t)ck.program_base + ck.n_programs > ctx->programs.size())
+            return fail(ctx, RXR_ERR_INVALID, "chunk: program range exceeds the programs set with rxr_set_shaders");
+        if (ck.n_shader_textures && !ck.shader_textures) return fail(ctx, RXR_ERR_INVALID, "chunk: NULL shader_textures");
+        auto add_local = [&](const rxr_texture &t) -> int32_t {
+            if (t.width == 0 || t.height == 0 || t.width > 32768 || t.height > 32768) return -2;
+            bool opaque = true;
+            const size_t n = (size_t)t.width * t.height;
+            for (size_t k = 0; k < n && opaque; ++k) opaque = t.rgba[4 * k + 3] == 255;
+            local_tex.push_back(LocalTex{&t, opaque});
+            local_texels += n;
+            return (int32_t)(n_res_tex + local_tex.size() - 1);
+        };
+        if (ck.terrain_texture && ck.terrain_texture->rgba) {
+            if (ck.size == 0) return fail(ctx, RXR_ERR_INVALID, "chunk: size 0 with a terrain texture (the reference divides by it, chunk.rs:138)");
+            if ((chunk_terrain[c] = add_local(*ck.terrain_texture)) == -2) return fail(ctx, RXR_ERR_INVALID, "chunk: bad terrain texture size");
+        }
+        chunk_baked[c].assign(ck.n_shader_textures, -1);
+        for (uint32_t k = 0; k < ck.n_shader_textures; ++k)
+            if (ck.shader_textures[k].rgba && (chunk_baked[c][k] = add_local(ck.shader_textures[k])) == -2)
+                return fail(ctx, RXR_ERR_INVALID, "chunk: bad shader texture size");
     }
+    if (local_texels >= (1ull << 31)) return fail(ctx, RXR_ERR_INVALID, "chunk textures too large");
+    auto tex_opaque = [&](int32_t tex) { return (uint32_t)tex < n_res_tex ? ctx->h_tex[tex].all_opaque != 0 : local_tex[(uint32_t)tex - n_res_tex].opaque; };
 
     Layout L{};
     size_t o = 0;
@@ -642,6 +679,8 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
     L.off_occ = take(n_occ_total * sizeof(rxr_occluder));
     L.off_ld = take(f->n_linedefs * sizeof(rxr_linedef));
     L.off_chunks = take(f->n_chunks * sizeof(ChunkRange));
+    L.off_tdesc = take((n_res_tex + local_tex.size()) * sizeof(DevTexDesc));
+    L.off_ltex = take(local_texels * 4);
     L.off_b2 = take(f->n_batches2d * sizeof(DevBatch));
     L.off_p2 = take((n_t2 + n_l2) * sizeof(Prim2D));
     (void)n_items;
@@ -654,6 +693,57 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
     // the staging blob may still be in flight from the previous upload
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     uint8_t *st = (uint8_t *)ctx->h_stage;
+
+    // texel source, program, baked texture and the flags that follow from them, for one 3D batch header
+    // (src/rasterizer.rs:1101-1304).  `keep` comes in as the box test and goes out false when nothing of the
+    // batch can ever be written.
+    auto classify3d = [&](DevBatch &d, const rxr_source &source, int32_t chunk, int32_t shader, uint32_t list, bool &keep,
+                          const char *what) -> int {
+        const bool opacity_list = list == RXR_LIST_CHUNK_OPACITY;
+        d.program_plus1 = program_of(shader, chunk);
+        d.baked_plus1 = 0;
+        // chunk.shader_textures.get(shader_index) comes first, and only in the opaque pass (:1226-1267)
+        if (!opacity_list && shader >= 0 && chunk >= 0 && (size_t)shader < chunk_baked[chunk].size() && chunk_baked[chunk][shader] >= 0) {
+            d.baked_plus1 = (uint32_t)chunk_baked[chunk][shader] + 1u;
+            d.program_plus1 = 0;
+        }
+        bool prog_runs = d.program_plus1 && ctx->programs[d.program_plus1 - 1].shade_entry != 0xFFFFFFFFu;
+        const bool prog_opacity = prog_runs && (ctx->programs[d.program_plus1 - 1].flags & 1u);
+        if (!prog_runs) d.program_plus1 = 0;
+        if (prog_runs) d.flags |= DB_HAS_PROGRAM;
+        if (!keep) return RXR_OK;
+        bool alpha_varies = false, alpha_never_255 = false;
+        if (source.kind == RXR_SOURCE_TERRAIN && chunk >= 0) {  // chunk.sample_terrain_texture, :1189-1191
+            if (chunk_terrain[chunk] >= 0) {
+                d.tex = chunk_terrain[chunk];
+                d.flags |= DB_TERRAIN;
+                alpha_varies = !tex_opaque(d.tex);
+            } else {
+                d.tex = -1;
+                d.pixel = 0;  // no terrain texture: [0,0,0,0], chunk.rs:150
+                alpha_never_255 = true;
+            }
+        } else {
+            int rc2 = resolve_source(ctx, source, true, chunk, f->animation_frame, d.tex, d.pixel);
+            if (rc2 != RXR_OK) return fail(ctx, rc2, std::string(what) + ": texture tile index out of range or tile without textures (the reference panics)");
+            if (d.tex >= 0) alpha_varies = !tex_opaque(d.tex);
+            else alpha_never_255 = (d.pixel >> 24) != 255u;
+        }
+        if (d.baked_plus1) {  // the baked texel replaces colour AND alpha (:1253-1262)
+            alpha_varies = !tex_opaque((int32_t)d.baked_plus1 - 1);
+            alpha_never_255 = false;
+        }
+        if (opacity_list) return RXR_OK;  // the opacity pass writes unconditionally (:1678-1682)
+        if (prog_opacity) {
+            d.flags |= DB_FULL_ALPHA;
+        } else if (alpha_never_255) {
+            keep = false;  // encoded alpha != 255: never written (:1408)
+        } else if (alpha_varies) {
+            // a plain texture's alpha needs the uv only; terrain texels need the world position, baked textures replace the source
+            d.flags |= ((d.flags & DB_TERRAIN) || d.baked_plus1) ? DB_FULL_ALPHA : DB_ALPHA_TEST;
+        }
+        return RXR_OK;
+    };
 
     // ---- pass 2: flatten -----------------------------------------------------------------------
     const float W = (float)f->width, H = (float)f->height;
@@ -671,12 +761,6 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
         if (b.clipped_normals) d.flags |= DB_HAS_NORMALS;
         if (b.has_profile_id) d.flags |= DB_HAS_PROFILE;
         if (b.list == RXR_LIST_CHUNK_OPACITY) d.flags |= DB_OPACITY_LIST;
-        d.program_plus1 = program_of(b.shader, b.chunk);
-        const bool prog_runs = d.program_plus1 && ctx->programs[d.program_plus1 - 1].shade_entry != 0xFFFFFFFFu;
-        const bool prog_opacity = prog_runs && (ctx->programs[d.program_plus1 - 1].flags & 1u);
-        if (!prog_runs) d.program_plus1 = 0;
-        if (prog_runs) d.flags |= DB_HAS_PROGRAM;
-        if (prog_opacity) d.flags |= DB_PROGRAM_OPACITY;
         d.profile_id = b.profile_id;
         d.repeat_mode = b.repeat_mode;
         d.chunk = b.chunk;
@@ -687,17 +771,12 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
             const float *bb = b.bounding_box;
             keep = bb[0] < W && (bb[0] + bb[2]) > 0.0f && bb[1] < H && (bb[1] + bb[3]) > 0.0f;
         }
-        if (keep) {
-            rc = resolve_source(ctx, b.source, true, b.chunk, f->animation_frame, d.tex, d.pixel);
-            if (rc != RXR_OK) return fail(ctx, rc, "batch3d: texture tile index out of range or tile without textures (the reference panics)");
-            if (d.tex >= 0) {
-                if (!ctx->h_tex[d.tex].all_opaque) d.flags |= DB_ALPHA_TEST;
-            } else if ((d.pixel >> 24) != 255u && b.list != RXR_LIST_CHUNK_OPACITY && !prog_opacity) {
-                keep = false;  // encoded alpha != 255: never written (rasterizer.rs:1408)
-            }
-        }
+        if ((rc = classify3d(d, b.source, b.chunk, b.shader, b.list, keep, "batch3d")) != RXR_OK) return rc;
         if (!keep) d.flags |= DB_SKIP;
-        else if (prog_runs) uses_programs = true;
+        else {
+            if (d.program_plus1) uses_programs = true;
+            if ((d.flags & (DB_TERRAIN | DB_FULL_ALPHA)) || d.baked_plus1) uses_chunk_tex = true;
+        }
         b3[i] = d;
         base[i] = (uint32_t)tcur;
         if (b.n_vertices) {
@@ -756,28 +835,17 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
             d.flags = DB_HAS_NORMALS;  // meshes with triangles must carry normals (batch3d.rs:605)
             if (h.has_profile_id) d.flags |= DB_HAS_PROFILE;
             if (h.list == RXR_LIST_CHUNK_OPACITY) d.flags |= DB_OPACITY_LIST;
-            d.program_plus1 = program_of(h.shader, h.chunk);
-            const bool prog_runs = d.program_plus1 && ctx->programs[d.program_plus1 - 1].shade_entry != 0xFFFFFFFFu;
-            const bool prog_opacity = prog_runs && (ctx->programs[d.program_plus1 - 1].flags & 1u);
-            if (!prog_runs) d.program_plus1 = 0;
-            if (prog_runs) d.flags |= DB_HAS_PROGRAM;
-            if (prog_opacity) d.flags |= DB_PROGRAM_OPACITY;
             d.profile_id = h.profile_id;
             d.repeat_mode = h.repeat_mode;
             d.chunk = h.chunk;
             memcpy(d.ambient, h.ambient, 12);
             bool keep = !rejected && h.dev.n_tris > 0;       // the box reject itself happens on the device (dev_bbox)
-            if (keep) {
-                rc = resolve_source(ctx, h.source, true, h.chunk, f->animation_frame, d.tex, d.pixel);
-                if (rc != RXR_OK) return fail(ctx, rc, "mesh: texture tile index out of range or tile without textures (the reference panics)");
-                if (d.tex >= 0) {
-                    if (!ctx->h_tex[d.tex].all_opaque) d.flags |= DB_ALPHA_TEST;
-                } else if ((d.pixel >> 24) != 255u && h.list != RXR_LIST_CHUNK_OPACITY && !prog_opacity) {
-                    keep = false;
-                }
-            }
+            if ((rc = classify3d(d, h.source, h.chunk, h.shader, h.list, keep, "mesh")) != RXR_OK) return rc;
             if (!keep) d.flags |= DB_SKIP;
-            else if (prog_runs) uses_programs = true;
+            else {
+                if (d.program_plus1) uses_programs = true;
+                if ((d.flags & (DB_TERRAIN | DB_FULL_ALPHA)) || d.baked_plus1) uses_chunk_tex = true;
+            }
             b3[i] = d;
             base[i] = h.dev.tout_base;
         }
@@ -796,13 +864,37 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
         ChunkRange *cr = (ChunkRange *)(st + L.off_chunks);
         size_t cur = f->n_occluders;
         for (uint32_t c = 0; c < f->n_chunks; ++c) {
+            cr[c] = ChunkRange{};
             cr[c].occ_first = (uint32_t)cur;
             cr[c].occ_count = f->chunks[c].n_occluders;
+            cr[c].terrain_tex = chunk_terrain[c];
+            cr[c].origin_x = f->chunks[c].origin[0];
+            cr[c].origin_y = f->chunks[c].origin[1];
+            if (chunk_terrain[c] >= 0) {
+                const int64_t wdt = (int32_t)f->chunks[c].terrain_texture->width;
+                cr[c].pixels_per_tile = (int32_t)(wdt / f->chunks[c].size);  // `texture.width as i32 / self.size`, chunk.rs:138
+            }
             if (f->chunks[c].n_occluders) memcpy(oc + cur, f->chunks[c].occluders, f->chunks[c].n_occluders * sizeof(rxr_occluder));
             cur += f->chunks[c].n_occluders;
         }
     }
     if (f->n_linedefs) memcpy(st + L.off_ld, f->linedefs, f->n_linedefs * sizeof(rxr_linedef));
+    {
+        // texture descriptor table of the frame: the resident textures, then this frame's chunk textures
+        DevTexDesc *td = (DevTexDesc *)(st + L.off_tdesc);
+        if (n_res_tex) memcpy(td, ctx->h_tex.data(), n_res_tex * sizeof(DevTexDesc));
+        size_t cur = 0;
+        for (size_t k = 0; k < local_tex.size(); ++k) {
+            const rxr_texture &t = *local_tex[k].t;
+            DevTexDesc &e = td[n_res_tex + k];
+            e.offset = (uint32_t)cur;
+            e.w = t.width;
+            e.h = t.height;
+            e.all_opaque = (local_tex[k].opaque ? 1u : 0u) | 2u;
+            memcpy(st + L.off_ltex + cur * 4, t.rgba, (size_t)t.width * t.height * 4);
+            cur += (size_t)t.width * t.height;
+        }
+    }
 
     DevBatch *b2 = (DevBatch *)(st + L.off_b2);
     Prim2D *p2 = (Prim2D *)(st + L.off_p2);
@@ -836,8 +928,14 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
             keep = bb[0] < W + pad && (bb[0] + bb[2]) > 0.0f - pad && bb[1] < H + pad && (bb[1] + bb[3]) > 0.0f - pad;
         }
         if (keep) {
-            rc = resolve_source(ctx, b.source, false, b.chunk, f->animation_frame, d.tex, d.pixel);
-            if (rc != RXR_OK) return fail(ctx, rc, "batch2d: tile without textures (the reference panics)");
+            if (b.source.kind == RXR_SOURCE_TERRAIN && b.chunk >= 0 && chunk_terrain[b.chunk] >= 0) {  // :749-751
+                d.tex = chunk_terrain[b.chunk];
+                d.flags |= DB_TERRAIN;
+                uses_chunk_tex = true;
+            } else {
+                rc = resolve_source(ctx, b.source, false, b.chunk, f->animation_frame, d.tex, d.pixel);
+                if (rc != RXR_OK) return fail(ctx, rc, "batch2d: tile without textures (the reference panics)");
+            }
         } else {
             d.flags |= DB_SKIP;
         }
@@ -980,7 +1078,8 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
     P.n_prims2d = (uint32_t)p2cur;
     P.binned2d = binned2d ? 1u : 0u;
     ctx->frame_uses_programs = uses_programs;
-    P.vm_code = uses_programs ? (const uint32_t *)ctx->d_vm_code.p : nullptr;
+    P.vm_code = (const uint32_t *)ctx->d_vm_code.p;
+    P.kernel_level = uses_programs ? 2u : (uses_chunk_tex ? 1u : 0u);
     P.programs = (const DevProgram *)ctx->d_programs.p;
     P.patterns = (const DevPattern *)ctx->d_patterns.p;
     P.pattern_data = (const float *)ctx->d_pattern_data.p;
@@ -1041,8 +1140,9 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
         P.large2d_list = (uint32_t *)ctx->d_large2d.p;
         P.host_status2d = ctx->d_host_status + CNT_WORDS;
     }
-    P.tex = (const DevTexDesc *)ctx->d_tex.p;
     P.texels = (const uint32_t *)ctx->d_texels.p;
+    P.tex = (const DevTexDesc *)(d + L.off_tdesc);
+    P.frame_texels = (const uint32_t *)(d + L.off_ltex);
     P.bg_pixels = (const uint32_t *)(d + L.off_bg);
     ctx->frame_uses_meshes = use_meshes;
     if (use_meshes) {
@@ -1105,7 +1205,7 @@ static int render_impl(rxr_ctx *ctx, const RenderSpec &spec, void *dev_pixels, h
     // small scenes: one staging round of k_raster holds every triangle -> no set-up / binning launches at all
     const bool d3 = P.tiles_y && (P.flags & RXR_FLAG_D3_ACTIVE);
     P.fused_small = (d3 && P.n_tris3d <= RXR_STAGE_TRIS) ? ctx->small_mode : 0u;
-    if (P.vm_code && P.fused_small == 1u) P.fused_small = 2u;  // k_raster_vm reads the records k_setup3d writes
+    if (P.kernel_level && P.fused_small == 1u) P.fused_small = 2u;  // k_raster_vm reads the records k_setup3d writes
     if (d3 && P.fused_small) {
         if (ctx->frame_uses_meshes) rxr_launch_project(&ctx->PP, s);
         if (P.fused_small == 2u) rxr_launch_setup(&P, s);  // records only; no counters, bins or lists are touched

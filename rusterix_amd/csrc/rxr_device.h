@@ -17,7 +17,7 @@
 struct DevTexDesc {
     uint32_t offset;  // in texels (uint32 units) from the pool base
     uint32_t w, h;
-    uint32_t all_opaque;  // every texel has alpha == 255
+    uint32_t all_opaque;  // bit 0: every texel has alpha == 255; bit 1: texels live in the frame blob (RasterParams.frame_texels)
 };
 
 enum : uint32_t {
@@ -28,7 +28,9 @@ enum : uint32_t {
     DB_RECEIVES_LIGHT = 1u << 4,
     DB_OPACITY_LIST = 1u << 5,
     DB_HAS_PROGRAM = 1u << 6,     // the batch runs a Rusteria program per fragment (DevBatch.program_plus1)
-    DB_PROGRAM_OPACITY = 1u << 7, // ... which may write `opacity`: the z-write rule needs the program's result per candidate
+    DB_FULL_ALPHA = 1u << 7,      // the encoded alpha of a fragment needs the whole front half of the fragment block: a program
+                                  // that may write `opacity`, a terrain texel (sampled by world position) or a baked shader texture
+    DB_TERRAIN = 1u << 8,         // PixelSource::Terrain in a chunk: texel by world position (chunk.rs:133-151)
 };
 
 // flattened Batch3D / Batch2D header.  The texel source is resolved on the host at upload time:
@@ -47,7 +49,7 @@ struct DevBatch {
     uint32_t mode;  // 2D: RXR_MODE_*
     uint32_t n_verts;
     uint32_t program_plus1;  // 0: no program; else 1 + index into RasterParams.programs
-    uint32_t pad;
+    uint32_t baked_plus1;    // 0: none; else 1 + DevTexDesc index of the chunk's baked shader texture (rasterizer.rs:1226-1267)
 };  // 64 B
 
 // per-triangle record for the visibility loop (written by k_setup3d).  96 B = 6 x 16 B.
@@ -100,6 +102,10 @@ struct ScanArgs {
 
 struct ChunkRange {
     uint32_t occ_first, occ_count;
+    int32_t terrain_tex;      // DevTexDesc index of chunk.terrain_texture, -1 for None
+    int32_t origin_x, origin_y;
+    int32_t pixels_per_tile;  // texture.width as i32 / chunk.size
+    uint32_t pad[2];
 };
 
 // ---- Rusteria programs on the device (rxr_vm.h) --------------------------------------------------
@@ -216,7 +222,9 @@ struct RasterParams {
     uint32_t *counters2d, *counters2d_next;
     uint32_t *host_status2d;
 
-    // Rusteria programs (rxr_set_shaders); vm_code == NULL when the frame uses none
+    // Rusteria programs (rxr_set_shaders)
+    uint32_t kernel_level;             // 0: k_raster; 1: k_raster_chunk (a visible batch uses a terrain / baked texture);
+                                       // 2: k_raster_vm (a visible batch runs a program)
     const uint32_t *vm_code;
     const DevProgram *programs;
     const DevPattern *patterns;        // n_patterns colour patterns, then n_normal_patterns normal patterns
@@ -226,7 +234,8 @@ struct RasterParams {
     uint32_t *vm_fault;                // pinned host word: a non-zero VMF_* code if any fragment's program faulted
     float time;                        // Rasterizer.time
 
-    const DevTexDesc *tex;
+    const DevTexDesc *tex;             // resident textures first, then this frame's chunk textures
+    const uint32_t *frame_texels;      // texel base of the latter (inside the frame blob)
     const uint32_t *texels;
     const uint32_t *bg_pixels;     // RXR_BG_HOST_PIXELS
     uint32_t *out;                 // framebuffer; row `row0` of the band is at out + out_row0_offset

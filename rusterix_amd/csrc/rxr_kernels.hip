@@ -353,9 +353,35 @@ __device__ __forceinline__ void fragment_uv(const TriShade &S, float alpha, floa
     rxm::div2(iu, iv, irw, u, v);
 }
 
-__device__ __forceinline__ uint32_t batch_texel(const RasterParams &P, const DevBatch &B, float u, float v) {
+// texel base of a texture: the resident pool, or this frame's chunk textures in the frame blob
+__device__ __forceinline__ const uint32_t *texel_base(const RasterParams &P, const DevTexDesc &d) {
+    return (d.all_opaque & 2u) ? P.frame_texels : P.texels;
+}
+
+// Chunk::sample_terrain_texture(world_pos, Vec2::one()) (chunk.rs:133-151) with Texture::get_pixel (texture.rs:527-538)
+__device__ __forceinline__ uint32_t terrain_texel(const RasterParams &P, const DevBatch &B, float wx, float wy) {
+    const ChunkRange cr = P.chunks[B.chunk];
+    const DevTexDesc d = P.tex[B.tex];
+    float local_x = (wx / 1.0f) - (float)cr.origin_x;
+    float local_y = (wy / 1.0f) - (float)cr.origin_y;
+    float pixel_x = local_x * (float)cr.pixels_per_tile;
+    float pixel_y = local_y * (float)cr.pixels_per_tile;
+    uint32_t px = sat_u32(rclamp(floorf(pixel_x), 0.0f, (float)d.w - 1.0f));
+    uint32_t py = sat_u32(rclamp(floorf(pixel_y), 0.0f, (float)d.h - 1.0f));
+    px = min(px, d.w - 1u);
+    py = min(py, d.h - 1u);
+    return texel_base(P, d)[d.offset + py * d.w + px];
+}
+
+// the texel switch of the raster loops (rasterizer.rs:1101-1222, :672-758); (wx, wy) is the position terrain batches sample at
+template <int X>
+__device__ __forceinline__ uint32_t batch_texel(const RasterParams &P, const DevBatch &B, float u, float v, float wx, float wy) {
     if (B.tex < 0) return B.pixel;
-    return sample_texture(P.tex[B.tex], P.texels, u, v, P.sample_mode, B.repeat_mode);
+    if constexpr (X >= 1) {
+        if (B.flags & DB_TERRAIN) return terrain_texel(P, B, wx, wy);
+    }
+    const DevTexDesc &d = P.tex[B.tex];
+    return sample_texture(d, texel_base(P, d), u, v, P.sample_mode, B.repeat_mode);
 }
 
 // ---- the covered-fragment block of d3_rasterize after the depth test (rasterizer.rs:1062-1404) ----
@@ -367,7 +393,7 @@ struct Frag {
 };
 
 // everything before the light loop: uv, world position, normal, texel, ambient terms (:1062-1370)
-template <bool VM>
+template <int X>
 __device__ __forceinline__ void shade3d_begin(const RasterParams &P, const TriShade &S, uint32_t batch_id, float alpha, float beta,
                                               float z, float fx, float fy, Frag &F) {
     const DevBatch &B = P.batches3d[batch_id];
@@ -398,13 +424,20 @@ __device__ __forceinline__ void shade3d_begin(const RasterParams &P, const TriSh
         normal = mk3(0.0f, 0.0f, 0.0f);
     }
 
-    uint32_t texel = batch_texel(P, B, u, v);
+    uint32_t texel = batch_texel<X>(P, B, u, v, world.x, world.z);
     const float INV_255 = 1.0f / 255.0f;  // lib.rs:52
     f3 base = mk3(srgb_to_linear_fast((float)(texel & 0xFFu) * INV_255), srgb_to_linear_fast((float)((texel >> 8) & 0xFFu) * INV_255),
                   srgb_to_linear_fast((float)((texel >> 16) & 0xFFu) * INV_255));
     F.opacity = (float)(texel >> 24) / 255.0f;  // :1313
+    if (X >= 1 && B.baked_plus1) {  // chunk.shader_textures: the baked texel replaces colour and alpha, no program runs (:1239-1267)
+        const DevTexDesc &bd = P.tex[B.baked_plus1 - 1u];
+        uint32_t bt = sample_texture(bd, texel_base(P, bd), u, v, P.sample_mode, B.repeat_mode);
+        base = mk3(srgb_to_linear_fast((float)(bt & 0xFFu) * INV_255), srgb_to_linear_fast((float)((bt >> 8) & 0xFFu) * INV_255),
+                   srgb_to_linear_fast((float)((bt >> 16) & 0xFFu) * INV_255));
+        F.opacity = (float)(bt >> 24) * INV_255;  // execution.opacity.x = color.w of pixel_to_vec4 (:1262)
+    }
     float rough = 0.5f, metal = 0.0f;  // :1315-1316 (no-shader branch)
-    if constexpr (VM) {
+    if constexpr (X >= 2) {
         if (B.program_plus1) {  // :1283-1304
             rxvm::IO io;
             rxvm::io_defaults(io);
@@ -470,7 +503,7 @@ __device__ __forceinline__ float wave_max(float v) {
 // sphere cannot reach the bounding sphere of the wave's fragments is one for which every lane's
 // `distance >= end_distance` test (light.rs:539, 561, 586, 636) would return None, so skipping it
 // changes nothing; the surviving lights are then evaluated in their original order.
-template <bool VM>
+template <int X>
 __device__ __forceinline__ void shade3d_lights(const RasterParams &P, bool hit, Frag &F) {
     const unsigned long long hitmask = __ballot(hit);
     if (hitmask == 0ull) return;
@@ -481,7 +514,7 @@ __device__ __forceinline__ void shade3d_lights(const RasterParams &P, bool hit, 
     // NaN / inf world positions are not bounded by the sphere: no culling for this wave then
     const bool can_cull = __ballot(hit && !(r < INFINITY)) == 0ull;
     const float rmax = wave_max(r);
-    const float rough = VM ? F.rough : 0.5f, metal = VM ? F.metal : 0.0f;
+    const float rough = (X >= 2) ? F.rough : 0.5f, metal = (X >= 2) ? F.metal : 0.0f;
 
     for (uint32_t base_i = 0; base_i < P.n_lights; base_i += 64u) {
         const uint32_t mine = base_i + (uint32_t)lane;
@@ -538,31 +571,34 @@ __device__ __forceinline__ uint32_t shade3d_end(const Frag &F) {
 }
 
 // the covered-fragment block of d3_rasterize_opacity (rasterizer.rs:1497-1682, no shader)
-template <bool VM>
+template <int X>
 __device__ __forceinline__ uint32_t shade3d_opacity(const RasterParams &P, const TriShade &S, uint32_t batch_id, float alpha, float beta,
                                                     float z, float fx, float fy) {
     const DevBatch &B = P.batches3d[batch_id];
     float gamma = 1.0f - alpha - beta;
     float u, v;
     fragment_uv(S, alpha, beta, gamma, u, v);
-    uint32_t texel = batch_texel(P, B, u, v);
+    // screen_to_world (:1515, :1707-1727): needed by terrain texels and by programs
+    float wx = 0.0f, wy = 0.0f, wz = 0.0f;
+    if ((X >= 1 && (B.flags & DB_TERRAIN)) || (X >= 2 && B.program_plus1)) {
+        float x_ndc = 2.0f * (fx / P.fwidth) - 1.0f;
+        float y_ndc = 1.0f - 2.0f * (fy / P.fheight);
+        float vx, vy, vz, vw, ww;
+        mat4_mul(P.inv_proj, x_ndc, y_ndc, z, 1.0f, vx, vy, vz, vw);
+        vx = vx / vw;
+        vy = vy / vw;
+        vz = vz / vw;
+        vw = vw / vw;
+        mat4_mul(P.inv_view, vx, vy, vz, vw, wx, wy, wz, ww);
+    }
+    uint32_t texel = batch_texel<X>(P, B, u, v, wx, wz);
     const float INV_255 = 1.0f / 255.0f;
     float r = srgb_to_linear_fast((float)(texel & 0xFFu) * INV_255);
     float g = srgb_to_linear_fast((float)((texel >> 8) & 0xFFu) * INV_255);
     float b = srgb_to_linear_fast((float)((texel >> 16) & 0xFFu) * INV_255);
     float opacity = (float)(texel >> 24) / 255.0f;
-    if constexpr (VM) {
+    if constexpr (X >= 2) {
         if (B.program_plus1) {  // :1642-1667
-            // screen_to_world (:1515, :1707-1727)
-            float x_ndc = 2.0f * (fx / P.fwidth) - 1.0f;
-            float y_ndc = 1.0f - 2.0f * (fy / P.fheight);
-            float vx, vy, vz, vw, wx, wy, wz, ww;
-            mat4_mul(P.inv_proj, x_ndc, y_ndc, z, 1.0f, vx, vy, vz, vw);
-            vx = vx / vw;
-            vy = vy / vw;
-            vz = vz / vw;
-            vw = vw / vw;
-            mat4_mul(P.inv_view, vx, vy, vz, vw, wx, wy, wz, ww);
             rxvm::IO io;
             rxvm::io_defaults(io);
             io.color = rxvm::mk(r, g, b);
@@ -585,7 +621,7 @@ __device__ __forceinline__ uint32_t shade3d_opacity(const RasterParams &P, const
 }
 
 // one 2D fragment (rasterizer.rs:656-895); returns the new pixel
-template <bool VM>
+template <int X>
 __device__ __forceinline__ uint32_t fragment2d(const RasterParams &P, const Prim2D &T, const DevBatch &B, uint32_t px, uint32_t py,
                                                float fx, float fy, uint32_t dst) {
     // barycentric_weights_2d (rasterizer.rs:1731-1750)
@@ -606,8 +642,8 @@ __device__ __forceinline__ uint32_t fragment2d(const RasterParams &P, const Prim
     float gy = ((float)py - P.fheight / 2.0f) - (P.translationd2[1] - P.fheight / 2.0f);
     float wx = gx / P.scaled2, wy = gy / P.scaled2;
 
-    uint32_t texel = batch_texel(P, B, u, v);
-    if constexpr (VM) {
+    uint32_t texel = batch_texel<X>(P, B, u, v, wx, wy);  // 2D terrain: chunk.sample_terrain_texture(world, ..), :749-751
+    if constexpr (X >= 2) {
         if (B.program_plus1 && P.programs[B.program_plus1 - 1u].shade_entry != 0xFFFFFFFFu) {  // :760-797
             const float INV_255 = 1.0f / 255.0f;  // pixel_to_vec4, lib.rs:52-62
             rxvm::IO io;
@@ -958,17 +994,19 @@ struct Vis {
 };
 
 // one candidate triangle against this lane's pixel (rasterizer.rs:1020-1060 + the :1408 alpha rule)
-// the encoded alpha of an opaque-pass fragment whose program may write `opacity` (:1403-1408): the whole
-// front half of the fragment block has to run to know whether the fragment is written at all
-__device__ __noinline__ bool fragment_alpha_is_255_vm(const RasterParams &P, const TriShade *shade, uint32_t batch, float alpha, float beta,
-                                                      float z, float fx, float fy) {
+// the encoded alpha of an opaque-pass fragment whose alpha does not follow from (texture, uv) alone -- a program
+// that may write `opacity` (:1403-1408), a terrain texel, a baked shader texture: the whole front half of the
+// fragment block has to run to know whether the fragment is written at all
+template <int X>
+__device__ __noinline__ bool fragment_alpha_is_255_full(const RasterParams &P, const TriShade *shade, uint32_t batch, float alpha, float beta,
+                                                        float z, float fx, float fy) {
     const TriShade H = *shade;
     Frag F;
-    shade3d_begin<true>(P, H, batch, alpha, beta, z, fx, fy, F);
+    shade3d_begin<X>(P, H, batch, alpha, beta, z, fx, fy, F);
     return f32_to_u8_saturated(F.opacity) == 255u;
 }
 
-template <bool OPACITY, bool VM>
+template <bool OPACITY, int X>
 __device__ __forceinline__ void visit(const RasterParams &P, const TriSetup &S, const TriShade *shade, uint32_t t, uint32_t slot,
                                       uint32_t px, uint32_t py, float fx, float fy, Vis &vis, int surf_profile) {
     uint32_t min_x = S.bx & 0xFFFFu, max_x = S.bx >> 16, min_y = S.by & 0xFFFFu, max_y = S.by >> 16;
@@ -997,15 +1035,15 @@ __device__ __forceinline__ void visit(const RasterParams &P, const TriSetup &S, 
     float z = 1.0f / one_over_z;
     bool closer = z < vis.zmin || (z == vis.zmin && vis.best >= 0 && (int)t < vis.best);
     if (!closer) return;
-    if (VM && !OPACITY && (S.bflags & DB_PROGRAM_OPACITY)) {
-        if (!fragment_alpha_is_255_vm(P, shade, S.batch, alpha, beta, z, fx, fy)) return;
+    if (X >= 1 && !OPACITY && (S.bflags & DB_FULL_ALPHA)) {  // frames with such batches run k_raster_chunk / k_raster_vm (RasterParams.kernel_level)
+        if (!fragment_alpha_is_255_full<X>(P, shade, S.batch, alpha, beta, z, fx, fy)) return;
     } else if (!OPACITY && (S.bflags & DB_ALPHA_TEST)) {
         // the fragment is only written when its encoded alpha is 255 (:1408): sample it now
         const DevBatch &B = P.batches3d[S.batch];
         const TriShade H = *shade;
         float u, v;
         fragment_uv(H, alpha, beta, gamma, u, v);
-        uint32_t texel = batch_texel(P, B, u, v);
+        uint32_t texel = batch_texel<X>(P, B, u, v, 0.0f, 0.0f);  // never a terrain batch: those carry DB_FULL_ALPHA
         if ((texel >> 24) != 255u) return;
     }
     vis.zmin = z;
@@ -1052,7 +1090,7 @@ struct StageShade {
 //   3. all 256 threads copy the survivors' 96-byte TriSetup records into LDS with coalesced 16-byte
 //      loads,
 //   4. every lane walks the staged records (uniform LDS addresses -> broadcast reads).
-template <bool OPACITY, bool VM>
+template <bool OPACITY, int X>
 __device__ __forceinline__ void scan_lists(const RasterParams &P, Stage &st, uint32_t b0, uint32_t b1, uint32_t tile_x0,
                                            uint32_t tile_y0px, uint32_t px, uint32_t py, float fx, float fy, Vis &vis,
                                            int surf_profile) {
@@ -1109,7 +1147,7 @@ __device__ __forceinline__ void scan_lists(const RasterParams &P, Stage &st, uin
         for (uint32_t k = 0; k < n; ++k) {
             const TriSetup &S = *reinterpret_cast<const TriSetup *>(&st.tri[k * 6u]);
             const uint32_t t = st.ids[k];
-            visit<OPACITY, VM>(P, S, &P.tri_shade[t], t, k, px, py, fx, fy, vis, surf_profile);
+            visit<OPACITY, X>(P, S, &P.tri_shade[t], t, k, px, py, fx, fy, vis, surf_profile);
         }
         __syncthreads();  // the stage is reused by the next round
     }
@@ -1119,7 +1157,7 @@ __device__ __forceinline__ void scan_lists(const RasterParams &P, Stage &st, uin
 // written their records): no lists at all.  All records are copied to LDS with one round of coalesced
 // loads, THEN thread t tests record t against the tile from LDS and the survivors' indices are
 // ballot-compacted -- one global-memory latency per tile instead of three dependent ones.
-template <bool OPACITY, bool VM>
+template <bool OPACITY, int X>
 __device__ __forceinline__ void scan_implicit(const RasterParams &P, Stage &st, uint32_t tile_x0, uint32_t tile_y0px, uint32_t px, uint32_t py,
                                               float fx, float fy, Vis &vis, int surf_profile) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -1150,7 +1188,7 @@ __device__ __forceinline__ void scan_implicit(const RasterParams &P, Stage &st, 
     for (uint32_t k = 0; k < n; ++k) {
         const uint32_t t = st.ids[k];
         const TriSetup &S = *reinterpret_cast<const TriSetup *>(&st.tri[t * 6u]);
-        visit<OPACITY, VM>(P, S, &P.tri_shade[t], t, t, px, py, fx, fy, vis, surf_profile);
+        visit<OPACITY, X>(P, S, &P.tri_shade[t], t, t, px, py, fx, fy, vis, surf_profile);
     }
     __syncthreads();  // the stage is reused (second pass, 2D pass)
 }
@@ -1159,7 +1197,7 @@ __device__ __forceinline__ void scan_implicit(const RasterParams &P, Stage &st, 
 // staging round holds them all): no k_setup3d / k_scan / k_fill launches and no records in HBM --
 // thread t builds triangle t's TriSetup / TriShade itself (make_setup), tests its pixel box against
 // the tile, survivors are ballot-compacted straight into LDS, then every lane walks them.
-template <bool OPACITY, bool VM>
+template <bool OPACITY, int X>
 __device__ __forceinline__ void scan_fused(const RasterParams &P, Stage &st, StageShade &sh, uint32_t tile_x0, uint32_t tile_y0px, uint32_t px,
                                            uint32_t py, float fx, float fy, Vis &vis, int surf_profile) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -1193,7 +1231,7 @@ __device__ __forceinline__ void scan_fused(const RasterParams &P, Stage &st, Sta
     __syncthreads();
     for (uint32_t k = 0; k < n; ++k) {
         const TriSetup &SK = *reinterpret_cast<const TriSetup *>(&st.tri[k * 6u]);
-        visit<OPACITY, VM>(P, SK, &sh.shade[k], st.ids[k], k, px, py, fx, fy, vis, surf_profile);
+        visit<OPACITY, X>(P, SK, &sh.shade[k], st.ids[k], k, px, py, fx, fy, vis, surf_profile);
     }
     __syncthreads();  // a second pass (opacity, then opaque) rebuilds the stage
 }
@@ -1223,7 +1261,7 @@ __device__ __forceinline__ bool bresenham_hits(const Prim2D &Ln, int px, int py)
 }
 
 // one 2D primitive against this lane's pixel (rasterizer.rs:636-655 coverage, then fragment2d / the line colour)
-template <bool VM>
+template <int X>
 __device__ __forceinline__ uint32_t prim2d_pixel(const RasterParams &P, const Prim2D &T, uint32_t px, uint32_t py, float fx, float fy,
                                                  uint32_t color) {
     const uint32_t min_x = T.bx & 0xFFFFu, max_x = T.bx >> 16, min_y = T.by & 0xFFFFu, max_y = T.by >> 16;
@@ -1236,13 +1274,13 @@ __device__ __forceinline__ uint32_t prim2d_pixel(const RasterParams &P, const Pr
     float r1 = T.ea[1] * fx + T.eb[1] * fy + T.ec[1];
     float r2 = T.ea[2] * fx + T.eb[2] * fy + T.ec[2];
     in = in && !(r0 < 0.0f) && !(r1 < 0.0f) && !(r2 < 0.0f);
-    if (in) color = fragment2d<VM>(P, T, P.batches2d[T.batch_kind >> 2], px, py, fx, fy, color);
+    if (in) color = fragment2d<X>(P, T, P.batches2d[T.batch_kind >> 2], px, py, fx, fy, color);
     return color;
 }
 
 // stages the Prim2D records of `n` primitive ids (st.ids-like array `ids`, already in submission order)
 // through LDS in rounds of RXR_STAGE_TRIS and applies them to this lane's pixel in order
-template <bool VM>
+template <int X>
 __device__ __forceinline__ uint32_t walk_prims2d(const RasterParams &P, Stage &st, const uint32_t *ids, uint32_t n, bool implicit_ids,
                                                  uint32_t px, uint32_t py, float fx, float fy, uint32_t color) {
     const uint32_t tid = threadIdx.x;
@@ -1257,7 +1295,7 @@ __device__ __forceinline__ uint32_t walk_prims2d(const RasterParams &P, Stage &s
         __syncthreads();
         for (uint32_t k = 0; k < m; ++k) {
             const Prim2D &T = *reinterpret_cast<const Prim2D *>(&st.tri[k * 6u]);
-            color = prim2d_pixel<VM>(P, T, px, py, fx, fy, color);
+            color = prim2d_pixel<X>(P, T, px, py, fx, fy, color);
         }
         __syncthreads();
     }
@@ -1282,7 +1320,7 @@ struct ShadeStore {
 template <>
 struct ShadeStore<false> {};
 
-template <bool FUSED, bool VM>
+template <bool FUSED, int X>
 __device__ __forceinline__ void raster_tile(const RasterParams &P) {
     __shared__ Stage stage;
     __shared__ uint32_t s_bin[4];
@@ -1337,25 +1375,25 @@ __device__ __forceinline__ void raster_tile(const RasterParams &P) {
         op.zmin = 1.0f; op.best = -1; op.alpha = 0.0f; op.beta = 0.0f; op.slot = 0; op.batch = 0;
         uint32_t op_color = 0u;  // the opacity winner is shaded at once: the opaque pass rebuilds the stage
         if (P.has_opacity) {
-            if constexpr (FUSED) scan_fused<true, VM>(P, stage, shade_store.s, tile_x0, tile_y0px, px, py, fx, fy, op, -1);
-            else if (P.fused_small == 2u) scan_implicit<true, VM>(P, stage, tile_x0, tile_y0px, px, py, fx, fy, op, -1);
-            else scan_lists<true, VM>(P, stage, b0, b1, tile_x0, tile_y0px, px, py, fx, fy, op, -1);
+            if constexpr (FUSED) scan_fused<true, X>(P, stage, shade_store.s, tile_x0, tile_y0px, px, py, fx, fy, op, -1);
+            else if (P.fused_small == 2u) scan_implicit<true, X>(P, stage, tile_x0, tile_y0px, px, py, fx, fy, op, -1);
+            else scan_lists<true, X>(P, stage, b0, b1, tile_x0, tile_y0px, px, py, fx, fy, op, -1);
             if (op.best >= 0) {
                 const DevBatch &OB = P.batches3d[op.batch];
                 surf_profile = (OB.flags & DB_HAS_PROFILE) ? (int)OB.profile_id : -1;
                 TriShade OS;
                 if constexpr (FUSED) OS = shade_store.s.shade[op.slot];
                 else OS = P.tri_shade[op.best];
-                op_color = shade3d_opacity<VM>(P, OS, op.batch, op.alpha, op.beta, op.zmin, fx, fy);
+                op_color = shade3d_opacity<X>(P, OS, op.batch, op.alpha, op.beta, op.zmin, fx, fy);
             }
             __syncthreads();  // everyone has copied its record before the stage is rebuilt
         }
         Vis vis;
         vis.zmin = 1.0f; vis.best = -1; vis.alpha = 0.0f; vis.beta = 0.0f; vis.slot = 0; vis.batch = 0;
         PHASE_MARK(0);
-        if constexpr (FUSED) scan_fused<false, VM>(P, stage, shade_store.s, tile_x0, tile_y0px, px, py, fx, fy, vis, surf_profile);
-        else if (P.fused_small == 2u) scan_implicit<false, VM>(P, stage, tile_x0, tile_y0px, px, py, fx, fy, vis, surf_profile);
-        else scan_lists<false, VM>(P, stage, b0, b1, tile_x0, tile_y0px, px, py, fx, fy, vis, surf_profile);
+        if constexpr (FUSED) scan_fused<false, X>(P, stage, shade_store.s, tile_x0, tile_y0px, px, py, fx, fy, vis, surf_profile);
+        else if (P.fused_small == 2u) scan_implicit<false, X>(P, stage, tile_x0, tile_y0px, px, py, fx, fy, vis, surf_profile);
+        else scan_lists<false, X>(P, stage, b0, b1, tile_x0, tile_y0px, px, py, fx, fy, vis, surf_profile);
 
         PHASE_MARK(1);
         // resolve (rasterizer.rs:409-497): hit -> shaded colour; miss -> [0,0,0,255]
@@ -1369,10 +1407,10 @@ __device__ __forceinline__ void raster_tile(const RasterParams &P) {
             TriShade HS;
             if constexpr (FUSED) HS = shade_store.s.shade[vis.slot];
             else HS = P.tri_shade[vis.best];
-            shade3d_begin<VM>(P, HS, vis.batch, vis.alpha, vis.beta, vis.zmin, fx, fy, F);
+            shade3d_begin<X>(P, HS, vis.batch, vis.alpha, vis.beta, vis.zmin, fx, fy, F);
         }
         PHASE_MARK(2);
-        if (P.n_lights) shade3d_lights<VM>(P, hit, F);  // wave-uniform call
+        if (P.n_lights) shade3d_lights<X>(P, hit, F);  // wave-uniform call
         PHASE_MARK(3);
         color = hit ? shade3d_end(F) : pack4(0u, 0u, 0u, 255u);
         PHASE_MARK(4);
@@ -1421,7 +1459,7 @@ __device__ __forceinline__ void raster_tile(const RasterParams &P) {
             }
             if (keep) stage.ids[off + before] = tid;
             __syncthreads();
-            if (n) color = walk_prims2d<VM>(P, stage, stage.ids, n, false, px, py, fx, fy, color);
+            if (n) color = walk_prims2d<X>(P, stage, stage.ids, n, false, px, py, fx, fy, color);
         } else {
             // candidates = [large 2D primitives whose box touches the tile] ++ [this tile's bin list], gathered
             // into LDS, sorted by primitive index (submission order), then staged and applied in order
@@ -1473,7 +1511,7 @@ __device__ __forceinline__ void raster_tile(const RasterParams &P) {
             const uint32_t n_cand = s_bin[2];
             if (n_cand > RXR_SORT2D_MAX) {
                 // more candidates than the LDS sort holds: walk every primitive in order (correct, slow)
-                color = walk_prims2d<VM>(P, stage, nullptr, P.n_prims2d, true, px, py, fx, fy, color);
+                color = walk_prims2d<X>(P, stage, nullptr, P.n_prims2d, true, px, py, fx, fy, color);
             } else {
                 // bitonic sort of s_sort[0 .. n_cand) padded to the next power of two with 0xFFFFFFFF
                 uint32_t n2 = 1;
@@ -1496,7 +1534,7 @@ __device__ __forceinline__ void raster_tile(const RasterParams &P) {
                         __syncthreads();
                     }
                 }
-                color = walk_prims2d<VM>(P, stage, s_sort, n_cand, false, px, py, fx, fy, color);
+                color = walk_prims2d<X>(P, stage, s_sort, n_cand, false, px, py, fx, fy, color);
             }
         }
     }
@@ -1511,11 +1549,14 @@ __device__ __forceinline__ void raster_tile(const RasterParams &P) {
 }
 
 // two instantiations so that each path gets its own register allocation
-extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_RASTER_WAVES_PER_SIMD) k_raster(RasterParams P) { raster_tile<false, false>(P); }
-extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_RASTER_WAVES_PER_SIMD) k_raster_fused(RasterParams P) { raster_tile<true, false>(P); }
-// frames in which a batch runs a Rusteria program: the interpreter (rxr_vm.h) keeps its state in scratch memory,
-// so it gets its own instantiation and the kernels above stay as they are
-extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS) k_raster_vm(RasterParams P) { raster_tile<false, true>(P); }
+extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_RASTER_WAVES_PER_SIMD) k_raster(RasterParams P) { raster_tile<false, 0>(P); }
+extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_RASTER_WAVES_PER_SIMD) k_raster_fused(RasterParams P) { raster_tile<true, 0>(P); }
+// feature levels (template parameter X) so that the common kernels above carry none of the rarer paths:
+//   1  k_raster_chunk: chunk textures -- terrain texels sampled by world position, baked shader textures, and the
+//      full-fragment alpha test they need
+//   2  k_raster_vm:    level 1 + Rusteria programs; the interpreter (rxr_vm.h) keeps its state in scratch memory
+extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS) k_raster_chunk(RasterParams P) { raster_tile<false, 1>(P); }
+extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS) k_raster_vm(RasterParams P) { raster_tile<false, 2>(P); }
 
 #if RXR_PHASE_TIMING
 extern "C" int rxr_debug_phase_read(unsigned long long *out16, int reset) {
@@ -1560,7 +1601,8 @@ extern "C" void rxr_launch_fill(const RasterParams *P, hipStream_t s) {
 extern "C" void rxr_launch_raster(const RasterParams *P, hipStream_t s) {
     uint32_t tiles = P->tiles_x * P->tiles_y;
     if (tiles == 0) return;
-    if (P->vm_code) hipLaunchKernelGGL(k_raster_vm, dim3(tiles), dim3(RXR_TILE_THREADS), 0, s, *P);
+    if (P->kernel_level >= 2u) hipLaunchKernelGGL(k_raster_vm, dim3(tiles), dim3(RXR_TILE_THREADS), 0, s, *P);
+    else if (P->kernel_level == 1u) hipLaunchKernelGGL(k_raster_chunk, dim3(tiles), dim3(RXR_TILE_THREADS), 0, s, *P);
     else if (P->fused_small == 1u) hipLaunchKernelGGL(k_raster_fused, dim3(tiles), dim3(RXR_TILE_THREADS), 0, s, *P);
     else hipLaunchKernelGGL(k_raster, dim3(tiles), dim3(RXR_TILE_THREADS), 0, s, *P);
 }

@@ -1,0 +1,188 @@
+"""Chunk paths of the raster loops on the device against the oracle: terrain batches and the
+terrain texture sampled by world position (src/chunk.rs:133-151, src/rasterizer.rs:343-356, :515-525, :1189-1191), per-chunk
+shader programs (chunk.shaders) and baked shader textures (chunk.shader_textures, :1226-1267)."""
+import numpy as np
+import pytest
+
+from rusterix_amd import binding as B
+from rusterix_amd import scenes
+from rusterix_amd.binding import Program
+
+pytestmark = pytest.mark.gpu
+
+TOLERANCE = 1
+W, H = 208, 144
+
+
+def terrain_texture(tag, w, h, holes=False):
+    rng = np.random.default_rng([0x52585231, tag])
+    img = rng.integers(0, 256, size=(h, w, 4), dtype=np.uint8)
+    img[..., 3] = 255
+    if holes:
+        yy, xx = np.mgrid[0:h, 0:w]
+        img[((xx // 3 + yy // 3) % 3) == 0, 3] = 90
+    return B.Texture(img.reshape(-1), w, h)
+
+
+def floor_quad(api, x0, z0, x1, z1, y=0.0):
+    v = np.array([[x0, y, z0, 1], [x1, y, z0, 1], [x1, y, z1, 1], [x0, y, z1, 1]], np.float32)
+    i = np.array([[0, 1, 2], [0, 2, 3]], np.uint32)
+    uv = np.array([[0, 0], [1, 0], [1, 1], [0, 1]], np.float32)
+    return api.Batch3D.new(v, i, uv).with_computed_normals().cull_mode(B.CULL_OFF)
+
+
+def terrain_scene(api, holes=False, with_texture=True, lights=True, origin=(0, 0), size=8, tex_w=64):
+    scene = api.Scene.empty()
+    under = floor_quad(api, -2.0, -2.0, 10.0, 10.0, y=-0.5).source(B.PixelSource.Pixel((40, 60, 200, 255)))
+    scene.add_d3_static(under)
+    chunk = scene.add_chunk()
+    chunk.terrain(terrain_texture(11, tex_w, tex_w, holes) if with_texture else None, origin=origin, size=size)
+    chunk.terrain_batch3d(floor_quad(api, 0.0, 0.0, 8.0, 8.0).source(B.PixelSource.Terrain()))
+    chunk.add_batch3d(api.Batch3D.from_box(3.0, 0.0, 3.0, 1.0, 1.0, 1.0).with_computed_normals().source(B.PixelSource.Pixel((200, 180, 40, 255))))
+    if lights:
+        scene.lights([B.Light(B.LIGHT_POINT).with_position((4.0, 2.0, 4.0)).with_color((1.0, 0.9, 0.8)).with_intensity(2.0)
+                      .with_start_distance(1.0).with_end_distance(9.0).compile()])
+    assets = api.Assets.default()
+    cam = api.D3OrbitCamera.new()
+    cam.set_parameter_f32("distance", 9.0)
+    cam.center = (4.0, 0.0, 4.0)
+    cam.azimuth = 1.1
+    cam.elevation = 0.9
+
+    def setup():
+        v, p = cam.matrices(float(W), float(H))
+        return api.Rasterizer.setup(None, v, p).ambient((0.6, 0.6, 0.6, 1.0))
+
+    return scenes._result(api, scene, assets, setup, W, H, 40, "chunk-terrain")
+
+
+def compare(oracle, product, build, tol=0):
+    got = scenes.render(build(product))
+    ref = scenes.render(build(oracle))
+    diff = np.abs(got.astype(np.int16) - ref.astype(np.int16)).max(axis=2)
+    assert int(diff.max()) <= tol, f"{(diff > tol).sum()} pixels differ by more than {tol} (max {diff.max()}); first at {np.argwhere(diff > tol)[:3].tolist()}"
+    return got
+
+
+def test_terrain_batch_samples_the_terrain_texture_by_world_position(oracle, product):
+    got = compare(oracle, product, lambda api: terrain_scene(api), tol=TOLERANCE)
+    assert len(np.unique(got.reshape(-1, 4), axis=0)) > 500, "the terrain texture should be visible"
+
+
+def test_terrain_unlit_is_bit_exact(oracle, product):
+    compare(oracle, product, lambda api: terrain_scene(api, lights=False))
+
+
+@pytest.mark.parametrize("origin, size, tex_w", [((2, -3), 4, 64), ((0, 0), 16, 40), ((-8, -8), 3, 100)])
+def test_terrain_origin_size_and_odd_texture_sizes(oracle, product, origin, size, tex_w):
+    compare(oracle, product, lambda api: terrain_scene(api, lights=False, origin=origin, size=size, tex_w=tex_w))
+
+
+def test_terrain_texels_with_alpha_are_cut_out(oracle, product):
+    """texels whose alpha is not 255 are not written (src/rasterizer.rs:1408): the blue floor underneath shows through"""
+    got = compare(oracle, product, lambda api: terrain_scene(api, holes=True, lights=False))
+    blue = (got[..., 2] > got[..., 0] + 60) & (got[..., 2] > got[..., 1] + 60)
+    assert 0.05 < blue.mean() < 0.6
+
+
+def test_terrain_source_without_a_terrain_texture_draws_nothing(oracle, product):
+    got = compare(oracle, product, lambda api: terrain_scene(api, with_texture=False, lights=False))
+    assert ((got[..., 2] > got[..., 0] + 60) & (got[..., 2] > got[..., 1] + 60)).mean() > 0.3   # only the floor underneath and the box
+
+
+def test_terrain_batch2d(oracle, product):
+    def build(api):
+        scene = api.Scene.empty()
+        chunk = scene.add_chunk()
+        chunk.terrain(terrain_texture(12, 48, 48), origin=(1, 2), size=6)
+        chunk.add_batch2d(api.Batch2D.from_rectangle(10.0, 10.0, 60.0, 40.0).source(B.PixelSource.Pixel((255, 0, 0, 255))))
+        chunk.terrain_batch2d(api.Batch2D.from_rectangle(0.0, 0.0, float(W), float(H)).source(B.PixelSource.Terrain()))
+        scene.add_d2_static(api.Batch2D.from_rectangle(100.0, 60.0, 50.0, 50.0).source(B.PixelSource.Pixel((0, 255, 0, 128))))
+        m2d = B.Mat3.from_rows([[24.0, 0.0, 30.0], [0.0, 24.0, 20.0], [0.0, 0.0, 1.0]])   # 24 pixels per world unit
+
+        def setup():
+            return api.Rasterizer.setup(m2d, B.Mat4.identity(), B.Mat4.identity())
+
+        return scenes._result(api, scene, api.Assets.default(), setup, W, H, 40, "chunk-terrain-2d")
+
+    got = compare(oracle, product, build)
+    assert len(np.unique(got.reshape(-1, 4), axis=0)) > 300
+
+
+def chunk_shader_scene(api, baked, opacity_list=False, two_chunks=False):
+    scene = api.Scene.empty()
+    scene.add_program(Program([[("Push", 0.0, 0.0, 1.0), "SetColor"]]))   # scene.shaders[0]: must NOT be what chunk batches use
+    tint = Program([["Color", ("Push", 1.0, 0.3, 0.3), "Mul", "UV", ("Push", 2.0), "Mul", "Add", "SetColor"]])
+    green = Program([["Color", ("Push", 0.2, 1.0, 0.2), "Mul", "SetColor", "UV", ("GetComponents", [0]), ("Push", 8.0), "Mul", "Fract", "SetRoughness"]])
+    chunk = scene.add_chunk()
+    s0 = chunk.add_shader(tint, terrain_texture(21, 16, 16, holes=False) if baked else None)
+    box = api.Batch3D.from_box(-1.2, -0.5, -0.5, 1.0, 1.0, 1.0).cull_mode(B.CULL_OFF).with_computed_normals()
+    box.source(B.PixelSource.StaticTileIndex(0)).repeat_mode(B.REPEAT_REPEAT_XY).shader(s0)
+    (chunk.add_batch3d_opacity if opacity_list else chunk.add_batch3d)(box)
+    rect = api.Batch2D.from_rectangle(4.0, 4.0, 40.0, 30.0).source(B.PixelSource.StaticTileIndex(0)).shader(s0)
+    chunk.add_batch2d(rect)
+    target = scene.add_chunk() if two_chunks else chunk
+    s1 = target.add_shader(green, None)
+    box2 = api.Batch3D.from_box(0.2, -0.5, -0.5, 1.0, 1.0, 1.0).cull_mode(B.CULL_OFF).with_computed_normals()
+    box2.source(B.PixelSource.StaticTileIndex(0)).repeat_mode(B.REPEAT_REPEAT_XY).shader(s1)
+    target.add_batch3d(box2)
+    scene.add_d3_static(floor_quad(api, -3.0, -3.0, 3.0, 3.0, y=-0.6).source(B.PixelSource.Pixel((90, 90, 90, 255))))
+    scene.lights([B.Light(B.LIGHT_POINT).with_position((0.5, 1.5, 2.0)).with_color((1.0, 1.0, 0.9)).with_intensity(2.0)
+                  .with_start_distance(1.0).with_end_distance(8.0).compile()])
+    assets = api.Assets.default().textures([B.Tile.from_texture(scenes.noise_texture(8, 32, 32))])
+    cam = api.D3OrbitCamera.new()
+    cam.set_parameter_f32("distance", 3.2)
+    cam.azimuth = 1.2
+    cam.elevation = 0.5
+
+    def setup():
+        v, p = cam.matrices(float(W), float(H))
+        return api.Rasterizer.setup(None, v, p).ambient((0.4, 0.4, 0.4, 1.0))
+
+    return scenes._result(api, scene, assets, setup, W, H, 40, "chunk-shaders")
+
+
+@pytest.mark.parametrize("two_chunks", [False, True])
+def test_chunk_programs(oracle, product, two_chunks):
+    """chunk batches index chunk.shaders, not scene.shaders (src/rasterizer.rs:1285-1288)"""
+    got = compare(oracle, product, lambda api: chunk_shader_scene(api, baked=False, two_chunks=two_chunks), tol=TOLERANCE)
+    assert ((got[..., 2] > 200) & (got[..., 0] < 30) & (got[..., 1] < 30)).mean() < 0.01, "scene.shaders[0] (pure blue) must not run"
+
+
+def test_baked_shader_texture_replaces_the_texel_in_the_opaque_pass_only(oracle, product):
+    a = compare(oracle, product, lambda api: chunk_shader_scene(api, baked=True), tol=TOLERANCE)
+    b = compare(oracle, product, lambda api: chunk_shader_scene(api, baked=False), tol=TOLERANCE)
+    assert (a != b).any(axis=2).mean() > 0.02, "the baked texture should change the first box"
+    # the 2D rectangle runs the program either way (src/rasterizer.rs:760-797 has no shader_textures)
+    assert np.array_equal(a[6:30, 6:40], b[6:30, 6:40])
+
+
+def test_baked_shader_texture_with_alpha(oracle, product):
+    # a baked texture whose texels are not all opaque: its alpha decides whether the fragment is written (:1262, :1408)
+    def build_baked_holes(api):
+        scene = api.Scene.empty()
+        chunk = scene.add_chunk()
+        s0 = chunk.add_shader(Program([["Color", "SetColor"]]), terrain_texture(31, 16, 16, holes=True))
+        box = api.Batch3D.from_box(-0.5, -0.5, -0.5, 1.0, 1.0, 1.0).cull_mode(B.CULL_OFF).with_computed_normals()
+        box.source(B.PixelSource.Pixel((255, 255, 255, 255))).repeat_mode(B.REPEAT_REPEAT_XY).shader(s0)
+        chunk.add_batch3d(box)
+        scene.add_d3_static(api.Batch3D.from_box(-1.5, -1.5, -2.2, 3.0, 3.0, 0.2).with_computed_normals().source(B.PixelSource.Pixel((20, 200, 40, 255))))
+        cam = api.D3OrbitCamera.new()
+        cam.set_parameter_f32("distance", 2.6)
+        cam.azimuth = 1.3
+        cam.elevation = 0.3
+
+        def setup():
+            v, p = cam.matrices(float(W), float(H))
+            return api.Rasterizer.setup(None, v, p).ambient((0.8, 0.8, 0.8, 1.0))
+
+        return scenes._result(api, scene, api.Assets.default(), setup, W, H, 40, "baked-holes")
+
+    got = compare(oracle, product, build_baked_holes)
+    green = (got[..., 1] > got[..., 0] + 60) & (got[..., 1] > got[..., 2] + 60)
+    centre = green[H // 2 - 15:H // 2 + 15, W // 2 - 15:W // 2 + 15]
+    assert 0.1 < centre.mean() < 0.9
+
+
+def test_chunk_program_in_the_opacity_pass(oracle, product):
+    compare(oracle, product, lambda api: chunk_shader_scene(api, baked=True, opacity_list=True), tol=TOLERANCE)
