@@ -580,6 +580,7 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
         return (uint32_t)shader < f->n_shader_programs ? (uint32_t)shader + 1u : 0u;
     };
     bool uses_programs = false, uses_chunk_tex = false;
+    int32_t first_opacity_chunk = -1;  // opacity batches in two or more chunks: surface_id needs the exact prefix order (level 1)
     size_t n_v3 = 0, n_t3 = 0;
     bool has_opacity = false;
     const bool use_meshes = f->use_meshes != 0;
@@ -776,6 +777,10 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
         else {
             if (d.program_plus1) uses_programs = true;
             if ((d.flags & (DB_TERRAIN | DB_FULL_ALPHA)) || d.baked_plus1) uses_chunk_tex = true;
+            if (b.list == RXR_LIST_CHUNK_OPACITY) {
+                if (first_opacity_chunk < 0) first_opacity_chunk = b.chunk;
+                else if (first_opacity_chunk != b.chunk) uses_chunk_tex = true;
+            }
         }
         b3[i] = d;
         base[i] = (uint32_t)tcur;
@@ -845,6 +850,10 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
             else {
                 if (d.program_plus1) uses_programs = true;
                 if ((d.flags & (DB_TERRAIN | DB_FULL_ALPHA)) || d.baked_plus1) uses_chunk_tex = true;
+                if (h.list == RXR_LIST_CHUNK_OPACITY) {
+                    if (first_opacity_chunk < 0) first_opacity_chunk = h.chunk;
+                    else if (first_opacity_chunk != h.chunk) uses_chunk_tex = true;
+                }
             }
             b3[i] = d;
             base[i] = h.dev.tout_base;

@@ -991,7 +991,76 @@ struct Vis {
     float alpha, beta;
     uint32_t slot;   // staged slot of the winner (fused small-scene path: its TriShade lives in LDS)
     uint32_t batch;  // batch of the winner
+    // opacity pass, feature level >= 1 only: the "staircase" of prefix minima.  surface_id (rasterizer.rs:1682) is read by the
+    // opaque batches of chunk k when only the opacity batches of chunks <= k have run (:314-357), so a candidate with
+    // submission index t must see the opacity winner among fragments with index < t.  A fragment is a prefix minimum iff
+    // no fragment with a smaller index has z <= its z; the set is kept here (index ascending = z descending).  Of one
+    // batch's prefix minima only the last one (largest index) can ever be the answer for a candidate of ANOTHER batch, and it
+    // dominates whatever the others dominate, so each batch holds at most one of the 3 slots.
+    float fz[3];
+    int fid[3];
+    int fprof[3];    // profile id of the fragment's batch, -1 for None
+    int fbatch[3];
 };
+
+__device__ __forceinline__ void front_init(Vis &v) {
+    for (int i = 0; i < 3; ++i) {
+        v.fz[i] = 0.0f;
+        v.fid[i] = -1;
+        v.fprof[i] = -1;
+        v.fbatch[i] = -1;
+    }
+}
+// inserts fragment (z, id, prof) arriving in arbitrary order
+__device__ __forceinline__ void front_insert(Vis &v, float z, int id, int prof, int batch) {
+    if (!(z < 1.0f)) return;  // z_buffer_opacity starts at 1.0 (:283): never written
+    bool dominated = false;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        if (v.fid[i] >= 0 && v.fid[i] < id && v.fz[i] <= z) dominated = true;
+    if (dominated) return;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        if (v.fid[i] >= 0 && id < v.fid[i] && z <= v.fz[i]) v.fid[i] = -1;  // no longer a prefix minimum
+    // same batch already present: both are prefix minima, keep the later one
+    bool done = false;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        if (v.fid[i] >= 0 && v.fbatch[i] == batch) {
+            if (id > v.fid[i]) {
+                v.fz[i] = z;
+                v.fid[i] = id;
+            }
+            done = true;
+        }
+    if (done) return;
+    // take a free slot; if all three are taken drop the entry with the smallest index (only matters when four or more
+    // opacity batches nest as prefix minima in one pixel)
+    int slot = v.fid[0] < 0 ? 0 : (v.fid[1] < 0 ? 1 : (v.fid[2] < 0 ? 2 : -1));
+    if (slot < 0) {
+        slot = (v.fid[0] < v.fid[1]) ? (v.fid[0] < v.fid[2] ? 0 : 2) : (v.fid[1] < v.fid[2] ? 1 : 2);
+        if (id < v.fid[slot]) return;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        if (i == slot) {
+            v.fz[i] = z;
+            v.fid[i] = id;
+            v.fprof[i] = prof;
+            v.fbatch[i] = batch;
+        }
+}
+// surface_id as the candidate with submission index t sees it: the prefix minimum with the largest index < t
+__device__ __forceinline__ int front_lookup(const Vis &v, int t) {
+    int best_id = -1, prof = -1;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        if (v.fid[i] >= 0 && v.fid[i] < t && v.fid[i] > best_id) {
+            best_id = v.fid[i];
+            prof = v.fprof[i];
+        }
+    return prof;
+}
 
 // one candidate triangle against this lane's pixel (rasterizer.rs:1020-1060 + the :1408 alpha rule)
 // the encoded alpha of an opaque-pass fragment whose alpha does not follow from (texture, uv) alone -- a program
@@ -1008,7 +1077,7 @@ __device__ __noinline__ bool fragment_alpha_is_255_full(const RasterParams &P, c
 
 template <bool OPACITY, int X>
 __device__ __forceinline__ void visit(const RasterParams &P, const TriSetup &S, const TriShade *shade, uint32_t t, uint32_t slot,
-                                      uint32_t px, uint32_t py, float fx, float fy, Vis &vis, int surf_profile) {
+                                      uint32_t px, uint32_t py, float fx, float fy, Vis &vis, int surf_profile, const Vis *opf) {
     uint32_t min_x = S.bx & 0xFFFFu, max_x = S.bx >> 16, min_y = S.by & 0xFFFFu, max_y = S.by >> 16;
     bool in = px >= min_x && px < max_x && py >= min_y && py < max_y;
     // Edges::evaluate (edge.rs:28-36): reject iff a*px + b*py + c < 0 (NaN passes)
@@ -1021,7 +1090,14 @@ __device__ __forceinline__ void visit(const RasterParams &P, const TriSetup &S, 
     if (is_opacity != OPACITY) return;
     if (!OPACITY) {
         // surface_id[idx].is_some() && surface_id[idx] == batch.profile_id  (:1044-1048)
-        if (surf_profile >= 0 && (S.bflags & DB_HAS_PROFILE) && (uint32_t)surf_profile == S.profile_id) return;
+        if constexpr (X >= 1) {
+            if (S.bflags & DB_HAS_PROFILE) {
+                const int sp = front_lookup(*opf, (int)t);
+                if (sp >= 0 && (uint32_t)sp == S.profile_id) return;
+            }
+        } else {
+            if (surf_profile >= 0 && (S.bflags & DB_HAS_PROFILE) && (uint32_t)surf_profile == S.profile_id) return;
+        }
     }
     // barycentric_weights_3d (:1754-1773)
     float pcx = S.v2x - fx, pcy = S.v2y - fy;
@@ -1033,6 +1109,7 @@ __device__ __forceinline__ void visit(const RasterParams &P, const TriSetup &S, 
     float gamma = 1.0f - alpha - beta;
     float one_over_z = S.iz0 * alpha + S.iz1 * beta + S.iz2 * gamma;
     float z = 1.0f / one_over_z;
+    if constexpr (OPACITY && X >= 1) front_insert(vis, z, (int)t, (S.bflags & DB_HAS_PROFILE) ? (int)S.profile_id : -1, (int)S.batch);
     bool closer = z < vis.zmin || (z == vis.zmin && vis.best >= 0 && (int)t < vis.best);
     if (!closer) return;
     if (X >= 1 && !OPACITY && (S.bflags & DB_FULL_ALPHA)) {  // frames with such batches run k_raster_chunk / k_raster_vm (RasterParams.kernel_level)
@@ -1093,7 +1170,7 @@ struct StageShade {
 template <bool OPACITY, int X>
 __device__ __forceinline__ void scan_lists(const RasterParams &P, Stage &st, uint32_t b0, uint32_t b1, uint32_t tile_x0,
                                            uint32_t tile_y0px, uint32_t px, uint32_t py, float fx, float fy, Vis &vis,
-                                           int surf_profile) {
+                                           int surf_profile, const Vis *opf) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t n_large = min(P.counters[CNT_LARGE], P.n_tris3d);
     const uint32_t total = n_large + (b1 - b0);
@@ -1147,7 +1224,7 @@ __device__ __forceinline__ void scan_lists(const RasterParams &P, Stage &st, uin
         for (uint32_t k = 0; k < n; ++k) {
             const TriSetup &S = *reinterpret_cast<const TriSetup *>(&st.tri[k * 6u]);
             const uint32_t t = st.ids[k];
-            visit<OPACITY, X>(P, S, &P.tri_shade[t], t, k, px, py, fx, fy, vis, surf_profile);
+            visit<OPACITY, X>(P, S, &P.tri_shade[t], t, k, px, py, fx, fy, vis, surf_profile, opf);
         }
         __syncthreads();  // the stage is reused by the next round
     }
@@ -1159,7 +1236,7 @@ __device__ __forceinline__ void scan_lists(const RasterParams &P, Stage &st, uin
 // ballot-compacted -- one global-memory latency per tile instead of three dependent ones.
 template <bool OPACITY, int X>
 __device__ __forceinline__ void scan_implicit(const RasterParams &P, Stage &st, uint32_t tile_x0, uint32_t tile_y0px, uint32_t px, uint32_t py,
-                                              float fx, float fy, Vis &vis, int surf_profile) {
+                                              float fx, float fy, Vis &vis, int surf_profile, const Vis *opf) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t n_all = min(P.n_tris3d, (uint32_t)RXR_STAGE_TRIS);
     const float4 *g4 = reinterpret_cast<const float4 *>(P.tri_setup);
@@ -1188,7 +1265,7 @@ __device__ __forceinline__ void scan_implicit(const RasterParams &P, Stage &st, 
     for (uint32_t k = 0; k < n; ++k) {
         const uint32_t t = st.ids[k];
         const TriSetup &S = *reinterpret_cast<const TriSetup *>(&st.tri[t * 6u]);
-        visit<OPACITY, X>(P, S, &P.tri_shade[t], t, t, px, py, fx, fy, vis, surf_profile);
+        visit<OPACITY, X>(P, S, &P.tri_shade[t], t, t, px, py, fx, fy, vis, surf_profile, opf);
     }
     __syncthreads();  // the stage is reused (second pass, 2D pass)
 }
@@ -1199,7 +1276,7 @@ __device__ __forceinline__ void scan_implicit(const RasterParams &P, Stage &st, 
 // the tile, survivors are ballot-compacted straight into LDS, then every lane walks them.
 template <bool OPACITY, int X>
 __device__ __forceinline__ void scan_fused(const RasterParams &P, Stage &st, StageShade &sh, uint32_t tile_x0, uint32_t tile_y0px, uint32_t px,
-                                           uint32_t py, float fx, float fy, Vis &vis, int surf_profile) {
+                                           uint32_t py, float fx, float fy, Vis &vis, int surf_profile, const Vis *opf) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     bool keep = false;
     TriSetup S;
@@ -1231,7 +1308,7 @@ __device__ __forceinline__ void scan_fused(const RasterParams &P, Stage &st, Sta
     __syncthreads();
     for (uint32_t k = 0; k < n; ++k) {
         const TriSetup &SK = *reinterpret_cast<const TriSetup *>(&st.tri[k * 6u]);
-        visit<OPACITY, X>(P, SK, &sh.shade[k], st.ids[k], k, px, py, fx, fy, vis, surf_profile);
+        visit<OPACITY, X>(P, SK, &sh.shade[k], st.ids[k], k, px, py, fx, fy, vis, surf_profile, opf);
     }
     __syncthreads();  // a second pass (opacity, then opaque) rebuilds the stage
 }
@@ -1373,11 +1450,12 @@ __device__ __forceinline__ void raster_tile(const RasterParams &P) {
         int surf_profile = -1;
         Vis op;
         op.zmin = 1.0f; op.best = -1; op.alpha = 0.0f; op.beta = 0.0f; op.slot = 0; op.batch = 0;
+        front_init(op);
         uint32_t op_color = 0u;  // the opacity winner is shaded at once: the opaque pass rebuilds the stage
         if (P.has_opacity) {
-            if constexpr (FUSED) scan_fused<true, X>(P, stage, shade_store.s, tile_x0, tile_y0px, px, py, fx, fy, op, -1);
-            else if (P.fused_small == 2u) scan_implicit<true, X>(P, stage, tile_x0, tile_y0px, px, py, fx, fy, op, -1);
-            else scan_lists<true, X>(P, stage, b0, b1, tile_x0, tile_y0px, px, py, fx, fy, op, -1);
+            if constexpr (FUSED) scan_fused<true, X>(P, stage, shade_store.s, tile_x0, tile_y0px, px, py, fx, fy, op, -1, nullptr);
+            else if (P.fused_small == 2u) scan_implicit<true, X>(P, stage, tile_x0, tile_y0px, px, py, fx, fy, op, -1, nullptr);
+            else scan_lists<true, X>(P, stage, b0, b1, tile_x0, tile_y0px, px, py, fx, fy, op, -1, nullptr);
             if (op.best >= 0) {
                 const DevBatch &OB = P.batches3d[op.batch];
                 surf_profile = (OB.flags & DB_HAS_PROFILE) ? (int)OB.profile_id : -1;
@@ -1391,9 +1469,9 @@ __device__ __forceinline__ void raster_tile(const RasterParams &P) {
         Vis vis;
         vis.zmin = 1.0f; vis.best = -1; vis.alpha = 0.0f; vis.beta = 0.0f; vis.slot = 0; vis.batch = 0;
         PHASE_MARK(0);
-        if constexpr (FUSED) scan_fused<false, X>(P, stage, shade_store.s, tile_x0, tile_y0px, px, py, fx, fy, vis, surf_profile);
-        else if (P.fused_small == 2u) scan_implicit<false, X>(P, stage, tile_x0, tile_y0px, px, py, fx, fy, vis, surf_profile);
-        else scan_lists<false, X>(P, stage, b0, b1, tile_x0, tile_y0px, px, py, fx, fy, vis, surf_profile);
+        if constexpr (FUSED) scan_fused<false, X>(P, stage, shade_store.s, tile_x0, tile_y0px, px, py, fx, fy, vis, surf_profile, &op);
+        else if (P.fused_small == 2u) scan_implicit<false, X>(P, stage, tile_x0, tile_y0px, px, py, fx, fy, vis, surf_profile, &op);
+        else scan_lists<false, X>(P, stage, b0, b1, tile_x0, tile_y0px, px, py, fx, fy, vis, surf_profile, &op);
 
         PHASE_MARK(1);
         // resolve (rasterizer.rs:409-497): hit -> shaded colour; miss -> [0,0,0,255]

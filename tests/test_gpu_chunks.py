@@ -186,3 +186,49 @@ def test_baked_shader_texture_with_alpha(oracle, product):
 
 def test_chunk_program_in_the_opacity_pass(oracle, product):
     compare(oracle, product, lambda api: chunk_shader_scene(api, baked=True, opacity_list=True), tol=TOLERANCE)
+
+
+# ---- surface_id across chunks (src/rasterizer.rs:314-357, :1044-1048, :1682) ---------------------------------------------
+def two_window_scene(api, swap_chunk_order):
+    """Two chunks, each a wall with a 'window': an opacity-pass pane with profile id N in front of an opaque wall with the
+    same profile id (so the wall is skipped where the pane was drawn and the green backdrop shows through).  Seen in a
+    row, the panes overlap on screen.  A chunk's walls are tested against the opacity winner of the chunks processed SO
+    FAR, so which wall shows a hole depends on the chunk order -- the final winner alone gets it wrong."""
+    scene = api.Scene.empty()
+
+    def wall(z, profile, colour):
+        pane = api.Batch3D.from_box(-0.6, -0.6, z, 1.2, 1.2, 0.02).with_computed_normals().source(B.PixelSource.Pixel((90, 120, 250, 120)))
+        pane.profile_id(profile)
+        w = api.Batch3D.from_box(-1.5, -1.0, z - 0.3, 3.0, 2.0, 0.05).with_computed_normals().source(B.PixelSource.Pixel(colour + (255,)))
+        w.profile_id(profile)
+        return pane, w
+
+    near = wall(1.0, 7, (200, 60, 60))
+    far = wall(-1.0, 9, (60, 60, 200))
+    for pane, w in ([far, near] if swap_chunk_order else [near, far]):
+        chunk = scene.add_chunk()
+        chunk.add_batch3d_opacity(pane)
+        chunk.add_batch3d(w)
+    scene.add_d3_static(api.Batch3D.from_box(-3.0, -3.0, -3.0, 6.0, 6.0, 0.1).with_computed_normals().source(B.PixelSource.Pixel((30, 220, 60, 255))))
+    cam = api.D3OrbitCamera.new()
+    cam.set_parameter_f32("distance", 4.5)
+    cam.azimuth = float(np.float32(np.pi / 2))
+    cam.elevation = 0.0
+
+    def setup():
+        v, p = cam.matrices(float(W), float(H))
+        return api.Rasterizer.setup(None, v, p).ambient((1.0, 1.0, 1.0, 1.0))
+
+    return scenes._result(api, scene, api.Assets.default(), setup, W, H, 40, "two-windows")
+
+
+@pytest.mark.parametrize("swap", [False, True])
+def test_surface_id_follows_the_chunk_order(oracle, product, swap):
+    got = compare(oracle, product, lambda api: two_window_scene(api, swap))
+    assert len(np.unique(got.reshape(-1, 4), axis=0)) >= 4
+
+
+def test_surface_id_order_matters_in_this_scene(oracle):
+    a = scenes.render(two_window_scene(oracle, False))
+    b = scenes.render(two_window_scene(oracle, True))
+    assert (a != b).any(axis=2).mean() > 0.01, "the scene is meant to expose the order dependence"
