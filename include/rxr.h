@@ -369,8 +369,9 @@ int rxr_read_projected_mesh(rxr_ctx *ctx, uint32_t index, uint32_t counts[2], fl
 /* replaces the context's shader programs, pattern bank and palette (stay resident until the next call;
  * NULL or an empty set removes them).  Programs are restricted to what a per-fragment evaluation can
  * reproduce: RXR_ERR_UNSUPPORTED for Alloc / Iterate / Save, for SetEmissive (the
- * reference leaks it into every later fragment of the tile), for a global read before it is written in
- * the same invocation and for Return inside For (the reference unwinds that incorrectly).
+ * reference leaks it into every later fragment of the tile), for a local of `shade` or a global that is
+ * read before the same invocation wrote it (the reference resizes, never clears them) and for Return inside
+ * For (the reference unwinds that incorrectly).
  * Replaces: Execution::shade per fragment, src/rasterizer.rs:760-800, :1283-1304, :1642-1667. */
 int rxr_set_shaders(rxr_ctx *ctx, const rxr_shader_set *set);
 

@@ -246,6 +246,8 @@ void orc_assets_set_palette(void *a, const float *rgb3, const uint8_t *present, 
         e.palette_present.push_back(present ? present[i] : 1);
     }
 }
+static const char *g_last_vm_fault = "";
+const char *orc_last_vm_fault() { return g_last_vm_fault; }
 // one invocation of Execution::shade on a fresh Execution with the given inputs (tests/test_oracle_vm.py):
 // in/out = uv, color, roughness, metallic, emissive, opacity, bump, normal, hitpoint, time (10 x 3 floats)
 int orc_vm_shade(void *s, void *a, int program, float *fields30) {
@@ -259,7 +261,8 @@ int orc_vm_shade(void *s, void *a, int program, float *fields30) {
     ex.reset(p.globals);
     try {
         ex.shade((size_t)p.shade_index, p, ((Assets *)a)->vm_env);
-    } catch (const vm::Fault &) {
+    } catch (const vm::Fault &f) {
+        g_last_vm_fault = f.what;
         return RXR_ERR_INVALID;
     }
     for (int i = 0; i < 10; ++i) {

@@ -71,6 +71,10 @@ struct RenderSpec {
 
 }  // namespace
 
+// Execution fields whose lanes the raster loops do not (all) assign before each call (rasterizer.rs:773-785, :1259-1298,
+// :1637-1662): a read sees what an EARLIER fragment's program left there unless this invocation wrote the field first
+enum : uint32_t { PF_UV = 1, PF_ROUGHNESS = 2, PF_METALLIC = 4, PF_OPACITY = 8, PF_BUMP = 16, PF_NORMAL = 32, PF_HITPOINT = 64 };
+
 struct rxr_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -108,6 +112,7 @@ struct rxr_ctx {
     // Rusteria programs (rxr_set_shaders)
     DevBuf d_vm_code, d_programs, d_patterns, d_pattern_data, d_palette;
     std::vector<DevProgram> programs;
+    std::vector<uint32_t> program_field_reads;  // PF_* each program reads before writing (see rxr_set_shaders)
     uint32_t n_patterns = 0, n_normal_patterns = 0, n_palette = 0;
     bool frame_uses_programs = false;
 
@@ -580,6 +585,8 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
         return (uint32_t)shader < f->n_shader_programs ? (uint32_t)shader + 1u : 0u;
     };
     bool uses_programs = false, uses_chunk_tex = false;
+    bool any_3d_visible = false, any_3d_program = false;
+    uint32_t reads_2d = 0;  // PF_* read-before-written by the programs of visible 2D batches
     int32_t first_opacity_chunk = -1;  // opacity batches in two or more chunks: surface_id needs the exact prefix order (level 1)
     size_t n_v3 = 0, n_t3 = 0;
     bool has_opacity = false;
@@ -775,7 +782,8 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
         if ((rc = classify3d(d, b.source, b.chunk, b.shader, b.list, keep, "batch3d")) != RXR_OK) return rc;
         if (!keep) d.flags |= DB_SKIP;
         else {
-            if (d.program_plus1) uses_programs = true;
+            any_3d_visible = true;
+            if (d.program_plus1) uses_programs = any_3d_program = true;
             if ((d.flags & (DB_TERRAIN | DB_FULL_ALPHA)) || d.baked_plus1) uses_chunk_tex = true;
             if (b.list == RXR_LIST_CHUNK_OPACITY) {
                 if (first_opacity_chunk < 0) first_opacity_chunk = b.chunk;
@@ -848,7 +856,8 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
             if ((rc = classify3d(d, h.source, h.chunk, h.shader, h.list, keep, "mesh")) != RXR_OK) return rc;
             if (!keep) d.flags |= DB_SKIP;
             else {
-                if (d.program_plus1) uses_programs = true;
+                any_3d_visible = true;
+                if (d.program_plus1) uses_programs = any_3d_program = true;
                 if ((d.flags & (DB_TERRAIN | DB_FULL_ALPHA)) || d.baked_plus1) uses_chunk_tex = true;
                 if (h.list == RXR_LIST_CHUNK_OPACITY) {
                     if (first_opacity_chunk < 0) first_opacity_chunk = h.chunk;
@@ -928,6 +937,7 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
         if (d.program_plus1) {
             d.flags |= DB_HAS_PROGRAM;
             uses_programs = true;
+            reads_2d |= ctx->program_field_reads[d.program_plus1 - 1];
         }
         // batch-level box reject with pad 0.5, rasterizer.rs:594-600, against the whole screen
         bool keep = b.has_bounding_box != 0;
@@ -1086,6 +1096,12 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
     P.n_linedefs = f->n_linedefs;
     P.n_prims2d = (uint32_t)p2cur;
     P.binned2d = binned2d ? 1u : 0u;
+    // the 2D pass runs after the 3D passes on the SAME Execution (rasterizer.rs:310, :501): `normal` and `opacity.x` are
+    // assigned by every 3D fragment and never by the 2D loop, `hitpoint.z` by every 3D fragment that runs a program
+    if (any_3d_visible && (f->flags & RXR_FLAG_D3_ACTIVE) && (reads_2d & (PF_NORMAL | PF_OPACITY)))
+        return fail(ctx, RXR_ERR_UNSUPPORTED, "a 2D batch's program reads normal / opacity, which in the reference hold whatever the tile's last 3D fragment left there");
+    if (any_3d_program && (f->flags & RXR_FLAG_D3_ACTIVE) && (reads_2d & PF_HITPOINT))
+        return fail(ctx, RXR_ERR_UNSUPPORTED, "a 2D batch's program reads hitpoint while 3D batches run programs: hitpoint.z would hold the tile's last 3D program fragment's");
     ctx->frame_uses_programs = uses_programs;
     P.vm_code = (const uint32_t *)ctx->d_vm_code.p;
     P.kernel_level = uses_programs ? 2u : (uses_chunk_tex ? 1u : 0u);
@@ -1618,85 +1634,118 @@ struct Flattener {
     }
 };
 
-// conservative purity check for globals: a LoadGlobal is accepted only if the same global was stored by a
-// top-level operation of `shade` earlier in the same invocation (the reference's globals otherwise carry
-// the previous fragment's values)
-void collect_global_loads(const rxr_program &p, const uint32_t *w, size_t n, std::vector<uint32_t> &loads, std::vector<char> &visiting, int depth) {
-    size_t i = 0;
-    while (i < n && depth < 64) {
-        uint32_t op = w[i++];
-        switch (op) {
-            case RXR_NODE_LOAD_GLOBAL: loads.push_back(w[i]); i += 1; break;
-            case RXR_NODE_STORE_GLOBAL:
-            case RXR_NODE_LOAD_LOCAL:
-            case RXR_NODE_STORE_LOCAL: i += 1; break;
-            case RXR_NODE_GET_COMPONENTS:
-            case RXR_NODE_SET_COMPONENTS: i += 1 + w[i]; break;
-            case RXR_NODE_PUSH: i += 3; break;
-            case RXR_NODE_IF: {
-                uint32_t tl = w[i], el = w[i + 2];
-                i += 3;
-                collect_global_loads(p, w + i, tl, loads, visiting, depth + 1);
-                collect_global_loads(p, w + i + tl, el, loads, visiting, depth + 1);
-                i += (size_t)tl + el;
-                break;
-            }
-            case RXR_NODE_FOR: {
-                size_t tot = (size_t)w[i] + w[i + 1] + w[i + 2] + w[i + 3];
-                i += 4;
-                collect_global_loads(p, w + i, tot, loads, visiting, depth + 1);  // the four blocks are contiguous
-                i += tot;
-                break;
-            }
-            case RXR_NODE_FUNCTION_CALL: {
-                uint32_t index = w[i + 2];
-                i += 3;
-                if (index < p.n_functions && !visiting[index]) {
-                    visiting[index] = 1;
-                    collect_global_loads(p, p.functions[index].words, p.functions[index].n_words, loads, visiting, depth + 1);
-                    visiting[index] = 0;
-                }
-                break;
-            }
-            default: break;
-        }
-    }
-}
+// Purity check (definite assignment).  The reference keeps ONE Execution per tile: `shade`'s locals are resized, not
+// cleared (execution.rs:747), and globals are never reset, so a read that the same invocation has not written before
+// sees the previous fragment's value.  A program is accepted only if every LoadLocal of `shade` and every LoadGlobal
+// anywhere is definitely preceded by a store in the same invocation: stores count from their position onwards within a
+// block, an If contributes what BOTH branches store, a For what its init and its first condition evaluation store;
+// called functions get fresh zeroed locals (execution.rs:188) -- their global reads are checked against what is
+// assigned at the call, their global stores are not credited.
+struct Assigned {
+    uint64_t locals = 0;
+    uint32_t globals = 0;
+    uint32_t fields = 0;  // PF_*: Execution fields this invocation has written so far
+};
 
-bool globals_are_pure(const rxr_program &p) {
-    if (p.shade_index < 0 || (uint32_t)p.shade_index >= p.n_functions) return true;
-    const uint32_t *w = p.functions[p.shade_index].words;
-    const size_t n = p.functions[p.shade_index].n_words;
-    std::vector<char> stored(p.n_globals + 1, 0), visiting(p.n_functions, 0);
-    visiting[p.shade_index] = 1;
-    size_t i = 0;
-    while (i < n) {
-        const size_t at = i;
-        uint32_t op = w[i++];
-        size_t len = 0;
-        switch (op) {
-            case RXR_NODE_STORE_GLOBAL:
-                if (w[i] < p.n_globals) stored[w[i]] = 1;
-                len = 1;
-                break;
-            case RXR_NODE_LOAD_GLOBAL:
-            case RXR_NODE_LOAD_LOCAL:
-            case RXR_NODE_STORE_LOCAL: len = 1; break;
-            case RXR_NODE_GET_COMPONENTS:
-            case RXR_NODE_SET_COMPONENTS: len = 1 + w[i]; break;
-            case RXR_NODE_PUSH: len = 3; break;
-            case RXR_NODE_IF: len = 3 + (size_t)w[i] + w[i + 2]; break;
-            case RXR_NODE_FOR: len = 4 + (size_t)w[i] + w[i + 1] + w[i + 2] + w[i + 3]; break;
-            case RXR_NODE_FUNCTION_CALL: len = 3; break;
-            default: break;
+
+struct PurityCheck {
+    const rxr_program &p;
+    bool ok = true;
+    uint32_t reads_unassigned = 0;  // PF_* read before this invocation wrote them
+    uint32_t writes = 0;            // PF_* written anywhere in the program
+    std::vector<char> visiting;
+
+    explicit PurityCheck(const rxr_program &prog) : p(prog), visiting(prog.n_functions, 0) {}
+
+    // walks one block; `in_shade`: LoadLocal / StoreLocal refer to shade's (leaky) locals
+    Assigned block(const uint32_t *w, size_t n, Assigned a, bool in_shade, int depth) {
+        size_t i = 0;
+        while (i < n && ok && depth < 64) {
+            const uint32_t op = w[i++];
+            switch (op) {
+                case RXR_NODE_LOAD_LOCAL:
+                    if (in_shade && (w[i] >= 64 || !((a.locals >> w[i]) & 1ull))) ok = false;
+                    i += 1;
+                    break;
+                case RXR_NODE_STORE_LOCAL:
+                    if (in_shade && w[i] < 64) a.locals |= 1ull << w[i];
+                    i += 1;
+                    break;
+                case RXR_NODE_LOAD_GLOBAL:
+                    if (w[i] >= 32 || !((a.globals >> w[i]) & 1u)) ok = false;
+                    i += 1;
+                    break;
+                case RXR_NODE_STORE_GLOBAL:
+                    if (w[i] < 32) a.globals |= 1u << w[i];  // (what a callee stores is not credited to its caller, see FunctionCall)
+                    i += 1;
+                    break;
+                case RXR_NODE_UV: reads_unassigned |= PF_UV & ~a.fields; break;
+                case RXR_NODE_ROUGHNESS: reads_unassigned |= PF_ROUGHNESS & ~a.fields; break;
+                case RXR_NODE_METALLIC: reads_unassigned |= PF_METALLIC & ~a.fields; break;
+                case RXR_NODE_OPACITY: reads_unassigned |= PF_OPACITY & ~a.fields; break;
+                case RXR_NODE_BUMP: reads_unassigned |= PF_BUMP & ~a.fields; break;
+                case RXR_NODE_NORMAL: reads_unassigned |= PF_NORMAL & ~a.fields; break;
+                case RXR_NODE_HITPOINT: reads_unassigned |= PF_HITPOINT; break;
+                case RXR_NODE_SET_UV: a.fields |= PF_UV; writes |= PF_UV; break;
+                case RXR_NODE_SET_ROUGHNESS: a.fields |= PF_ROUGHNESS; writes |= PF_ROUGHNESS; break;
+                case RXR_NODE_SET_METALLIC: a.fields |= PF_METALLIC; writes |= PF_METALLIC; break;
+                case RXR_NODE_SET_OPACITY: a.fields |= PF_OPACITY; writes |= PF_OPACITY; break;
+                case RXR_NODE_SET_BUMP: a.fields |= PF_BUMP; writes |= PF_BUMP; break;
+                case RXR_NODE_SET_NORMAL: a.fields |= PF_NORMAL; writes |= PF_NORMAL; break;
+                case RXR_NODE_GET_COMPONENTS:
+                case RXR_NODE_SET_COMPONENTS: i += 1 + w[i]; break;
+                case RXR_NODE_PUSH: i += 3; break;
+                case RXR_NODE_IF: {
+                    const uint32_t tl = w[i], he = w[i + 1], el = w[i + 2];
+                    i += 3;
+                    Assigned t = block(w + i, tl, a, in_shade, depth + 1);
+                    Assigned e = he ? block(w + i + tl, el, a, in_shade, depth + 1) : a;
+                    a.locals = t.locals & e.locals;
+                    a.globals = t.globals & e.globals;
+                    a.fields = t.fields & e.fields;
+                    i += (size_t)tl + el;
+                    break;
+                }
+                case RXR_NODE_FOR: {
+                    const uint32_t l0 = w[i], l1 = w[i + 1], l2 = w[i + 2], l3 = w[i + 3];
+                    i += 4;
+                    const uint32_t *init = w + i, *cond = init + l0, *incr = cond + l1, *body = incr + l2;
+                    a = block(init, l0, a, in_shade, depth + 1);
+                    a = block(cond, l1, a, in_shade, depth + 1);       // the condition runs at least once
+                    Assigned b = block(body, l3, a, in_shade, depth + 1);
+                    (void)block(incr, l2, b, in_shade, depth + 1);
+                    i += (size_t)l0 + l1 + l2 + l3;
+                    break;
+                }
+                case RXR_NODE_FUNCTION_CALL: {
+                    const uint32_t index = w[i + 2];
+                    i += 3;
+                    if (index < p.n_functions && !visiting[index]) {
+                        visiting[index] = 1;
+                        Assigned callee;
+                        callee.globals = a.globals;
+                        callee.fields = a.fields;
+                        (void)block(p.functions[index].words, p.functions[index].n_words, callee, false, depth + 1);
+                        visiting[index] = 0;
+                    }
+                    break;
+                }
+                default: break;
+            }
         }
-        std::vector<uint32_t> loads;
-        collect_global_loads(p, w + at, 1 + len, loads, visiting, 0);
-        for (uint32_t g : loads)
-            if (g >= p.n_globals || !stored[g]) return false;
-        i += len;
+        return a;
     }
-    return true;
+};
+
+bool program_is_pure(const rxr_program &p, uint32_t &reads_unassigned, uint32_t &writes) {
+    reads_unassigned = writes = 0;
+    if (p.shade_index < 0 || (uint32_t)p.shade_index >= p.n_functions) return true;
+    PurityCheck c(p);
+    c.visiting[p.shade_index] = 1;
+    (void)c.block(p.functions[p.shade_index].words, p.functions[p.shade_index].n_words, Assigned{}, true, 0);
+    reads_unassigned = c.reads_unassigned;
+    writes = c.writes;
+    return c.ok;
 }
 
 }  // namespace
@@ -1706,6 +1755,7 @@ int rxr_set_shaders(rxr_ctx *ctx, const rxr_shader_set *set) {
     HIPCHK(ctx, hipSetDevice(ctx->device));
     ctx->has_frame = false;  // the resident frame's batch headers refer to the old programs
     ctx->programs.clear();
+    ctx->program_field_reads.clear();
     ctx->n_patterns = ctx->n_normal_patterns = ctx->n_palette = 0;
     if (!set) return RXR_OK;
     if ((set->n_programs && !set->programs) || (set->n_patterns && !set->patterns) || (set->n_normal_patterns && !set->normal_patterns) ||
@@ -1715,6 +1765,9 @@ int rxr_set_shaders(rxr_ctx *ctx, const rxr_shader_set *set) {
     // ---- validate + flatten every program into one code stream
     Flattener fl;
     std::vector<DevProgram> progs;
+    std::vector<uint32_t> field_reads;  // per program: PF_* read before written
+    uint32_t field_writes = 0;
+    bool have_masks = false;
     for (uint32_t pi = 0; pi < set->n_programs; ++pi) {
         const rxr_program &p = set->programs[pi];
         if (p.n_functions && !p.functions) return fail(ctx, RXR_ERR_INVALID, "rxr_set_shaders: NULL function array");
@@ -1743,13 +1796,24 @@ int rxr_set_shaders(rxr_ctx *ctx, const rxr_shader_set *set) {
                 for (size_t pos : fl.return_patches) fl.code[pos] = endfn;
             }
             for (auto &cp : fl.call_patches) fl.code[cp.first] = entries[cp.second];
-            if (!globals_are_pure(p))
-                return fail(ctx, RXR_ERR_UNSUPPORTED, "rxr_set_shaders: a global is read before this invocation wrote it (the reference would read the previous fragment's value)");
+            uint32_t ru = 0, wr = 0;
+            if (!program_is_pure(p, ru, wr))
+                return fail(ctx, RXR_ERR_UNSUPPORTED, "rxr_set_shaders: a local of `shade` or a global is read before this invocation wrote it (the reference would read the previous fragment's value)");
+            field_reads.push_back(ru);
+            field_writes |= wr;
+            have_masks = true;
             d.shade_entry = entries[p.shade_index];
             d.flags = fl.writes_opacity ? 1u : 0u;
         }
+        if (!have_masks) field_reads.push_back(0);
+        have_masks = false;
         progs.push_back(d);
     }
+    // uv.z, roughness.yz, metallic.yz, opacity.yz and bump are never assigned by the raster loops: once ANY program of the
+    // set writes such a field, a read that its own invocation has not preceded by a write would see an earlier fragment's lanes
+    for (uint32_t m : field_reads)
+        if (m & field_writes & (PF_UV | PF_ROUGHNESS | PF_METALLIC | PF_OPACITY | PF_BUMP))
+            return fail(ctx, RXR_ERR_UNSUPPORTED, "rxr_set_shaders: a program reads uv / roughness / metallic / opacity / bump before writing it while a program of the set writes that field (lanes the raster loops never reset would leak between fragments)");
     if (fl.code.size() >= (1ull << 31)) return fail(ctx, RXR_ERR_INVALID, "rxr_set_shaders: programs too large");
 
     // ---- patterns + palette
@@ -1803,6 +1867,7 @@ int rxr_set_shaders(rxr_ctx *ctx, const rxr_shader_set *set) {
     if ((rc = up(ctx->d_palette, pal.data(), pal.size() * 4)) != RXR_OK) return rc;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // the staging vectors die here
     ctx->programs = std::move(progs);
+    ctx->program_field_reads = std::move(field_reads);
     ctx->n_patterns = set->n_patterns;
     ctx->n_normal_patterns = set->n_normal_patterns;
     ctx->n_palette = set->n_palette;

@@ -126,7 +126,7 @@ enum : uint32_t {
     VM_GETC = 138,       // GetComponents: next word = n | idx0 << 4 | idx1 << 6 ... (2 bits each, 3 = "not x/y/z")
     VM_SETC = 139,       // SetComponents, same encoding
 };
-#define RXR_VM_STACK 32
+#define RXR_VM_STACK 64
 #define RXR_VM_LOCALS 48
 #define RXR_VM_GLOBALS 16
 #define RXR_VM_FRAMES 8

@@ -211,11 +211,15 @@ def test_tile_size_does_not_matter_for_pure_programs(oracle):
 @pytest.mark.parametrize("ops, why", [
     ([("Push", 0.5), "SetEmissive"], "emissive leaks"),
     ([("LoadGlobal", 0), "SetColor"], "global read before written"),
+    ([("LoadLocal", 0), "SetColor"], "stale local of the previous fragment"),
+    (["UV", "SetColor", ("Push", 1.0, 2.0, 3.0), "SetUV"], "uv.z of the previous fragment"),
+    (["Roughness", "SetColor", ("Push", 0.1, 0.2, 0.3), "SetRoughness"], "roughness.yz of the previous fragment"),
+    ([("Push", 1.0), ("If", [("Push", 2.0), ("StoreLocal", 0)], None), ("LoadLocal", 0), "SetColor"], "local written on one path only"),
     ([("For", [], [("Push", 0.0)], [], ["Return"])], "Return inside For"),
     ([("Push", 4.0), ("Push", 4.0), "Alloc"], "texture baking"),
 ])
 def test_unsupported_programs_are_refused(product, ops, why):
-    cfg = rect_scene(product, Program([ops], globals=1))
+    cfg = rect_scene(product, Program([ops], globals=1, shade_locals=1))
     with pytest.raises(B.RasterizeError) as e:
         scenes.render(cfg)
     assert e.value.code == B.RXR_ERR_UNSUPPORTED, why
@@ -223,7 +227,7 @@ def test_unsupported_programs_are_refused(product, ops, why):
 
 @pytest.mark.parametrize("ops, locals_", [
     (["Add"], 0),                                            # pop().unwrap() on an empty stack
-    ([("LoadLocal", 5)], 1),                                 # locals[5]
+    ([("Push", 1.0), ("StoreLocal", 5)], 1),                 # locals[5]
     ([("FunctionCall", 0, 0, 9)], 0),                        # user_functions[9]
     ([("Push", 1.0), ("Push", 2.0), ("Push", 1.0), "Clamp"], 0),
     ([("For", [], [("Push", 1.0)], [], [])], 0),             # endless loop: the reference panics after 10 M iterations
@@ -236,3 +240,130 @@ def test_program_faults_are_reported(oracle, product, ops, locals_):
         assert e.value.code == B.RXR_ERR_INVALID
     # and the context is usable afterwards
     compare(oracle, product, lambda api: rect_scene(api, Program([["UV", "SetColor"]])))
+
+
+# ---- random programs: the tree interpreter (oracle) against the flattened jump code (device) ---------------------------
+UNARY = ["Abs", "Neg", "Floor", "Ceil", "Round", "Fract", "Length", "Length2", "Length3", "Normalize", "Sqrt", "Not", "Radians", "Degrees"]
+BINARY = ["Add", "Sub", "Mul", "Div", "Min", "Max", "Mod", "Step", "Dot", "Dot2", "Dot3", "Cross", "Eq", "Ne", "Lt", "Le", "Gt", "Ge", "And", "Or"]
+SOURCES = ["UV", "UV", "UV", "Hitpoint", "Hitpoint", "Color", "Color", "Time", "Roughness", "Metallic", "Opacity", "Bump"]
+
+
+class ProgramGen:
+    """stack-safe random NodeOp trees: every block leaves the stack exactly `+delta` deeper than it found it"""
+
+    def __init__(self, rng, n_locals, n_functions):
+        self.rng, self.n_locals, self.n_functions = rng, n_locals, n_functions
+        self.first_callable = 0   # functions may only call later ones: no recursion (the reference would overflow its stack)
+        self.loadable = n_locals  # locals that are certainly written by now (a stale read would make the program impure)
+        # fields this program writes are never read by it (lanes the raster loops do not reset would leak, see rxr_set_shaders)
+        writable = ["SetRoughness", "SetMetallic", "SetBump", "SetUV"]
+        self.setters = ["SetColor"] + [w for w in writable if rng.random() < 0.5]
+        self.sources = [x for x in SOURCES if ("Set" + ("UV" if x == "UV" else x)) not in self.setters]
+
+    def value(self, depth):
+        """ops that push exactly one value"""
+        r = self.rng
+        k = r.integers(0, 12) if depth < 4 else r.integers(1, 4)
+        if k == 2 and not self.loadable:
+            k = 1
+        if k == 11 and not (self.first_callable < self.n_functions and depth < 3):
+            k = 3
+        if k == 0:
+            return [("Push", *[float(x) for x in np.round(r.uniform(-3, 3, 3), 2)])]
+        if k == 1:
+            return [str(r.choice(self.sources))]
+        if k == 2:
+            return [("LoadLocal", int(r.integers(0, self.loadable)))]
+        if k == 3:
+            return [str(self.sources[0]), ("Push", float(r.integers(1, 9))), "Mul"]
+        if k in (4, 5):
+            return self.value(depth + 1) + [str(r.choice(UNARY))]
+        if k in (6, 7, 8):
+            return self.value(depth + 1) + self.value(depth + 1) + [str(r.choice(BINARY))]
+        if k == 9:
+            t = int(r.integers(0, 3))
+            if t == 0:
+                return self.value(depth + 1) + self.value(depth + 1) + self.value(depth + 1) + ["Mix"]
+            if t == 1:
+                lo = float(np.round(r.uniform(-2, 0), 2))
+                return self.value(depth + 1) + [("Push", lo), ("Push", lo + float(np.round(r.uniform(0, 3), 2))), "Clamp"]
+            return self.value(depth + 1) + self.value(depth + 1) + self.value(depth + 1) + ["Smoothstep"]
+        if k == 10:
+            n = int(r.integers(1, 5))
+            sw = [int(x) for x in r.integers(0, 4, n)]   # 3 = "not a component"
+            if r.random() < 0.5:
+                return self.value(depth + 1) + [("GetComponents", sw)]
+            return self.value(depth + 1) + self.value(depth + 1) + [("SetComponents", sw)]
+        if k == 11:
+            f = int(r.integers(self.first_callable, self.n_functions))
+            return self.value(depth + 1) + self.value(depth + 1) + [("FunctionCall", 2, 3 + 4, 1 + f)]
+        return self.value(depth + 1) + self.value(depth + 1) + self.value(depth + 1) + ["Pack3"]
+
+    def statement(self, depth):
+        """ops that leave the stack as they found it"""
+        r = self.rng
+        k = r.integers(0, 8) if depth < 3 else 0
+        if k <= 2:
+            return self.value(depth + 1) + [("StoreLocal", int(r.integers(0, self.n_locals)))]
+        if k == 3:
+            return self.value(depth + 1) + [str(r.choice(self.setters))]
+        if k in (4, 5):
+            els = self.block(depth + 1) if r.random() < 0.6 else None
+            return self.value(depth + 1) + [("If", self.block(depth + 1), els)]
+        if k == 6:
+            i = self.n_locals + depth        # a counter local no random store touches (blocks nest at most 3 deep)
+            trips = float(r.integers(0, 5))
+            return [("For", [("Push", 0.0), ("StoreLocal", i)], [("LoadLocal", i), ("Push", trips), "Lt"],
+                     [("LoadLocal", i), ("Push", 1.0), "Add", ("StoreLocal", i)], self.block(depth + 1) + self.value(depth + 1))]  # + a temporary
+        return self.value(depth + 1) + ["Clear"]
+
+    def block(self, depth):
+        out = []
+        for _ in range(int(self.rng.integers(1, 4))):
+            out += self.statement(depth)
+        return out
+
+    def function(self):
+        body = self.block(2)
+        tail = self.value(2) + (["Return"] if self.rng.random() < 0.7 else [])
+        early = self.value(2) + [("If", self.value(2) + ["Return"], None)] if self.rng.random() < 0.5 else []
+        return early + body + tail
+
+    def program(self):
+        shade = []
+        for i in range(self.n_locals):
+            self.loadable = i
+            shade += self.value(1) + [("StoreLocal", i)]
+        self.loadable = self.n_locals
+        # the result: a random value plus a per-pixel term, wrapped into [0, 1) so that the frame shows structure
+        shade += self.block(0) + self.block(0) + self.value(0) + self.value(0) + ["Add", str(self.sources[0]), ("Push", 3.7), "Mul", "Add", "Fract", "SetColor"]
+        functions = []
+        shade_locals = self.n_locals
+        self.n_locals = self.loadable = 3       # helper functions: two arguments + one scratch local (a fresh zeroed frame)
+        for k in range(self.n_functions):
+            self.first_callable = k + 1
+            functions.append(self.function())
+        self.raw = [shade] + functions   # kept for debugging a failing seed
+        return Program([shade] + functions, shade_locals=shade_locals + 4)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_programs(oracle, product, seed):
+    rng = np.random.default_rng([0x52585231, 4242, seed])
+    # helper functions use locals 0..2 (two arguments + one scratch), `shade` has n_locals >= 3
+    gen = ProgramGen(rng, n_locals=int(rng.integers(3, 6)), n_functions=int(rng.integers(0, 3)))
+    prog = gen.program()
+    compare(oracle, product, lambda api: rect_scene(api, prog, time=0.5))
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_programs_as_cube_materials(oracle, product, seed):
+    """the same generator on the 3D opaque pass: colour / roughness / metallic feed the lighting (log2 / exp2: +-1)"""
+    rng = np.random.default_rng([0x52585231, 777, seed])
+    gen = ProgramGen(rng, n_locals=int(rng.integers(3, 6)), n_functions=int(rng.integers(0, 3)))
+    prog = gen.program()
+    got = scenes.render(cube_scene(product, prog))
+    ref = scenes.render(cube_scene(oracle, prog))
+    diff = np.abs(got.astype(np.int16) - ref.astype(np.int16)).max(axis=2)
+    # a colour that lands within an ulp of a quantisation or Fract boundary may flip on the +-1-ulp pow: allow a handful
+    assert (diff > TOLERANCE).sum() <= 5, f"{(diff > TOLERANCE).sum()} pixels differ by more than {TOLERANCE} (max {diff.max()})"
