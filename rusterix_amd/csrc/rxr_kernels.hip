@@ -814,26 +814,59 @@ __device__ __forceinline__ bool make_setup(const RasterParams &P, uint32_t t, Tr
 // k_setup3d: triangle set-up + bin counting.  One thread per triangle.
 // Replaces the per-tile re-derivation of per-triangle constants in rasterizer.rs:989-1017, 1054-1072.
 // =================================================================================================
+// Run-length aggregated "counter[bin] += 1": neighbouring triangles of a mesh (consecutive ids = consecutive lanes) fall
+// into the same few bins, and atomics on one address serialise in L2 -- so a run of adjacent lanes with the same bin
+// issues ONE atomic (by its first lane) for the whole run.  O(1) per call whatever the bins are; lanes whose neighbours
+// target other bins simply form runs of one.  Must be called by ALL lanes of the wave (`active` marks the ones that have
+// a bin); with RETURN each active lane gets a distinct slot (old value + its position in the run).
+template <bool RETURN>
+__device__ __forceinline__ uint32_t wave_bin_increment(uint32_t *counter, uint32_t bin, bool active) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t prev_bin = (uint32_t)__shfl_up((int)bin, 1, 64);
+    const bool prev_active = __shfl_up((int)active, 1, 64) != 0;
+    const bool head = !active || lane == 0u || !prev_active || bin != prev_bin;
+    const unsigned long long heads = __ballot(head);
+    // first lane of my run: the highest head at or below me
+    const unsigned long long below = heads & (lane == 63u ? ~0ull : ((2ull << lane) - 1ull));
+    const uint32_t first = 63u - (uint32_t)__clzll((long long)below);
+    uint32_t base = 0;
+    if (active && head) {
+        const unsigned long long above = lane == 63u ? 0ull : (heads >> (lane + 1u));
+        const uint32_t run = above ? (uint32_t)__ffsll((long long)above) : 64u - lane;
+        base = atomicAdd(&counter[bin], run);
+    }
+    if (!RETURN) return 0u;
+    base = (uint32_t)__shfl((int)base, (int)first, 64);
+    return base + (lane - first);
+}
+
 extern "C" __global__ void __launch_bounds__(256) k_setup3d(RasterParams P) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= P.n_tris3d) return;
+    bool live = false;
     TriSetup S;
     TriShade H;
-    const bool live = make_setup(P, t, S, H);
-    P.tri_shade[t] = H;
-    P.tri_setup[t] = S;
-    if (!live || P.fused_small) return;  // small scenes are not binned (see scan_lists, implicit list)
-    const uint32_t min_x = S.bx & 0xFFFFu, max_x = S.bx >> 16, min_y = S.by & 0xFFFFu, max_y = S.by >> 16;
-
-    uint32_t bx0, bx1, by0, by1;
-    if (!bin_range(P, min_x, max_x, min_y, max_y, bx0, bx1, by0, by1)) return;
-    uint32_t nb = (bx1 - bx0 + 1) * (by1 - by0 + 1);
+    if (t < P.n_tris3d) {
+        live = make_setup(P, t, S, H);
+        P.tri_shade[t] = H;
+        P.tri_setup[t] = S;
+    }
+    if (P.fused_small) return;  // small scenes are not binned (see scan_implicit); uniform
+    uint32_t bx0 = 0, bx1 = 0, by0 = 0, by1 = 0, nb = 0;
+    if (live) {
+        const uint32_t min_x = S.bx & 0xFFFFu, max_x = S.bx >> 16, min_y = S.by & 0xFFFFu, max_y = S.by >> 16;
+        if (bin_range(P, min_x, max_x, min_y, max_y, bx0, bx1, by0, by1)) nb = (bx1 - bx0 + 1) * (by1 - by0 + 1);
+    }
     if (nb > RXR_LARGE_BINS) {
         uint32_t slot = atomicAdd(&P.counters[CNT_LARGE], 1u);
         if (slot < P.n_tris3d) P.large_list[slot] = t;  // (always true while the counter invariant holds)
-    } else {
-        for (uint32_t by = by0; by <= by1; ++by)
-            for (uint32_t bx = bx0; bx <= bx1; ++bx) atomicAdd(&P.bin_count[by * P.tiles_x + bx], 1u);
+        nb = 0;
+    }
+    // step k of every lane's own (bx, by) walk, the whole wave in lockstep
+    const uint32_t w = bx1 - bx0 + 1;
+    for (uint32_t k = 0; __ballot(k < nb); ++k) {
+        const bool active = k < nb;
+        const uint32_t bin = active ? (by0 + k / w) * P.tiles_x + (bx0 + k % w) : 0u;
+        wave_bin_increment<false>(P.bin_count, bin, active);
     }
 }
 
@@ -920,19 +953,23 @@ extern "C" __global__ void __launch_bounds__(256) k_scan(ScanArgs A) {
 // =================================================================================================
 extern "C" __global__ void __launch_bounds__(256) k_fill(RasterParams P) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= P.n_tris3d) return;
-    uint32_t bxw = P.tri_setup[t].bx, byw = P.tri_setup[t].by;
-    uint32_t min_x = bxw & 0xFFFFu, max_x = bxw >> 16, min_y = byw & 0xFFFFu, max_y = byw >> 16;
-    uint32_t bx0, bx1, by0, by1;
-    if (!bin_range(P, min_x, max_x, min_y, max_y, bx0, bx1, by0, by1)) return;
-    uint32_t nb = (bx1 - bx0 + 1) * (by1 - by0 + 1);
-    if (nb > RXR_LARGE_BINS) return;
-    for (uint32_t by = by0; by <= by1; ++by)
-        for (uint32_t bx = bx0; bx <= bx1; ++bx) {
-            uint32_t bin = by * P.tiles_x + bx;
-            uint32_t pos = P.chunk_base[bin / RXR_SCAN_CHUNK] + P.bin_offset[bin] + atomicAdd(&P.bin_cursor[bin], 1u);
+    uint32_t bx0 = 0, bx1 = 0, by0 = 0, by1 = 0, nb = 0;
+    if (t < P.n_tris3d) {
+        uint32_t bxw = P.tri_setup[t].bx, byw = P.tri_setup[t].by;
+        uint32_t min_x = bxw & 0xFFFFu, max_x = bxw >> 16, min_y = byw & 0xFFFFu, max_y = byw >> 16;
+        if (bin_range(P, min_x, max_x, min_y, max_y, bx0, bx1, by0, by1)) nb = (bx1 - bx0 + 1) * (by1 - by0 + 1);
+        if (nb > RXR_LARGE_BINS) nb = 0;  // on the large list
+    }
+    const uint32_t w = bx1 - bx0 + 1;
+    for (uint32_t k = 0; __ballot(k < nb); ++k) {
+        const bool active = k < nb;
+        const uint32_t bin = active ? (by0 + k / w) * P.tiles_x + (bx0 + k % w) : 0u;
+        const uint32_t slot = wave_bin_increment<true>(P.bin_cursor, bin, active);
+        if (active) {
+            uint32_t pos = P.chunk_base[bin / RXR_SCAN_CHUNK] + P.bin_offset[bin] + slot;
             if (pos < P.list_capacity) P.bin_list[pos] = t;
         }
+    }
 }
 
 // =================================================================================================
