@@ -732,7 +732,7 @@ __device__ __forceinline__ bool bin_range(const RasterParams &P, uint32_t min_x,
 // batch arrays into the TriSetup / TriShade records (per-triangle constants of the reference's
 // per-fragment formulas, rasterizer.rs:989-995, 1054-1072, 1754-1767) and computes the clamped pixel
 // box (:998-1017, tile = whole width x row band).  Returns false when no pixel can be produced
-// (invisible edge, skipped batch, empty box); the records are valid either way.
+// (invisible edge, skipped batch, empty box); then only S.bx / S.by (an empty pixel box) are meaningful.
 __device__ __forceinline__ bool make_setup(const RasterParams &P, uint32_t t, TriSetup &S, TriShade &H) {
     // triangle -> batch: largest b with base[b] <= t
     uint32_t lo = 0, hi = P.n_batches3d;
@@ -742,10 +742,27 @@ __device__ __forceinline__ bool make_setup(const RasterParams &P, uint32_t t, Tr
         else hi = mid;
     }
     const DevBatch B = P.batches3d[lo];
+    const rxr_edges E = P.edges[t];
+
+    // triangles that can never produce a pixel (culled / clipped away: edges.visible == false, :989-992; skipped batch;
+    // batch box off screen) are known before any vertex is read: they only get an empty pixel box
+    bool skip = (B.flags & DB_SKIP) != 0;
+    if (P.dev_bbox) {
+        // device-projection path: the batch-level box reject (rasterizer.rs:978-983, whole screen) on the
+        // box accumulated by rxr_project.hip; Rect {x, y, width = max - min, height} as batch3d.rs:762-767
+        const DevBBox bb = P.dev_bbox[lo];
+        auto dec = [](uint32_t e) { return __uint_as_float((e & 0x80000000u) ? (e ^ 0x80000000u) : ~e); };
+        float bx = dec(bb.min_x), by = dec(bb.min_y), bw = dec(bb.max_x) - bx, bh = dec(bb.max_y) - by;
+        bool keep = bx < (float)P.width && (bx + bw) > 0.0f && by < (float)P.height && (by + bh) > 0.0f;
+        skip = skip || !keep;
+    }
+    if (!E.visible || skip) {
+        S.bx = S.by = 0u;
+        return false;
+    }
 
     uint32_t i0 = P.idx[3 * (size_t)t + 0] + B.vert_base, i1 = P.idx[3 * (size_t)t + 1] + B.vert_base, i2 = P.idx[3 * (size_t)t + 2] + B.vert_base;
     float4 v0 = P.pv[i0], v1 = P.pv[i1], v2 = P.pv[i2];
-    const rxr_edges E = P.edges[t];
 
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -792,17 +809,7 @@ __device__ __forceinline__ bool make_setup(const RasterParams &P, uint32_t t, Tr
     uint32_t min_y = sat_index(fmaxf(floorf(min_yf), (float)P.row0), 0xFFFFu);
     uint32_t max_y = sat_index(fminf(ceilf(max_yf), (float)P.row1), 0xFFFFu);
 
-    bool skip = (B.flags & DB_SKIP) != 0;
-    if (P.dev_bbox) {
-        // device-projection path: the batch-level box reject (rasterizer.rs:978-983, whole screen) on the
-        // box accumulated by rxr_project.hip; Rect {x, y, width = max - min, height} as batch3d.rs:762-767
-        const DevBBox bb = P.dev_bbox[lo];
-        auto dec = [](uint32_t e) { return __uint_as_float((e & 0x80000000u) ? (e ^ 0x80000000u) : ~e); };
-        float bx = dec(bb.min_x), by = dec(bb.min_y), bw = dec(bb.max_x) - bx, bh = dec(bb.max_y) - by;
-        bool keep = bx < (float)P.width && (bx + bw) > 0.0f && by < (float)P.height && (by + bh) > 0.0f;
-        skip = skip || !keep;
-    }
-    bool live = E.visible && !skip && min_x < max_x && min_y < max_y;
+    bool live = min_x < max_x && min_y < max_y;
     S.bx = live ? (min_x | (max_x << 16)) : 0u;
     S.by = live ? (min_y | (max_y << 16)) : 0u;
     return live;
@@ -847,8 +854,13 @@ extern "C" __global__ void __launch_bounds__(256) k_setup3d(RasterParams P) {
     TriShade H;
     if (t < P.n_tris3d) {
         live = make_setup(P, t, S, H);
-        P.tri_shade[t] = H;
-        P.tri_setup[t] = S;
+        if (live) {
+            P.tri_shade[t] = H;
+            P.tri_setup[t] = S;
+        } else {
+            // never a candidate: the lists skip it and the implicit-list path rejects its empty box
+            *reinterpret_cast<uint2 *>(&P.tri_setup[t].bx) = make_uint2(0u, 0u);
+        }
     }
     if (P.fused_small) return;  // small scenes are not binned (see scan_implicit); uniform
     uint32_t bx0 = 0, bx1 = 0, by0 = 0, by1 = 0, nb = 0;
