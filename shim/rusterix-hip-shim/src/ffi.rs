@@ -169,6 +169,13 @@ pub struct rxr_linedef {
 pub struct rxr_chunk {
     pub occluders: *const rxr_occluder,
     pub n_occluders: u32,
+    pub program_base: u32,
+    pub n_programs: u32,
+    pub shader_textures: *const rxr_texture,
+    pub n_shader_textures: u32,
+    pub terrain_texture: *const rxr_texture,
+    pub origin: [i32; 2],
+    pub size: i32,
 }
 
 #[repr(C)]
