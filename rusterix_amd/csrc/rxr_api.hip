@@ -98,6 +98,7 @@ struct rxr_ctx {
     uint32_t parity = 0;             // counter set of the next launch
     bool scratch_dirty = false;      // a pre-pass was queued without its raster launch
     bool scratch2d_dirty = false;
+    uint32_t min_kernel_level = 0;   // RXR_MIN_KERNEL_LEVEL (tuning)
     uint32_t small_mode = 2;         // RasterParams.fused_small for frames with <= RXR_STAGE_TRIS triangles;
                                      // RXR_SMALL_MODE=0|1|2 overrides it (tests / A-B runs)
 
@@ -234,6 +235,9 @@ int rxr_create(rxr_ctx **out, int device_id) {
     memset(ctx->h_counters, 0, (2 * CNT_WORDS + 4) * sizeof(uint32_t));
     if (const char *sm = getenv("RXR_SMALL_MODE")) {
         if (sm[0] >= '0' && sm[0] <= '2') ctx->small_mode = (uint32_t)(sm[0] - '0');
+    }
+    if (const char *kl = getenv("RXR_MIN_KERNEL_LEVEL")) {  // A-B runs: render with k_raster_chunk (1) / k_raster_vm (2) regardless
+        if (kl[0] >= '0' && kl[0] <= '2') ctx->min_kernel_level = (uint32_t)(kl[0] - '0');
     }
     if (hipHostGetDevicePointer((void **)&ctx->d_host_status, ctx->h_counters, 0) != hipSuccess) ctx->d_host_status = ctx->h_counters;
     *out = ctx;
@@ -1104,7 +1108,7 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
         return fail(ctx, RXR_ERR_UNSUPPORTED, "a 2D batch's program reads hitpoint while 3D batches run programs: hitpoint.z would hold the tile's last 3D program fragment's");
     ctx->frame_uses_programs = uses_programs;
     P.vm_code = (const uint32_t *)ctx->d_vm_code.p;
-    P.kernel_level = uses_programs ? 2u : (uses_chunk_tex ? 1u : 0u);
+    P.kernel_level = std::max(ctx->min_kernel_level, uses_programs ? 2u : (uses_chunk_tex ? 1u : 0u));
     P.programs = (const DevProgram *)ctx->d_programs.p;
     P.patterns = (const DevPattern *)ctx->d_patterns.p;
     P.pattern_data = (const float *)ctx->d_pattern_data.p;
@@ -1586,6 +1590,21 @@ struct Flattener {
                 }
                 case RXR_NODE_PUSH:
                     if (!need(3)) return bad(RXR_ERR_INVALID, "truncated program");
+                    // peephole: a constant followed by a component-wise binary operation becomes one instruction
+                    // ("tos = tos op c"), the commonest pair in compiled expressions
+                    if (i + 3 < n) {
+                        const uint32_t nx = w[i + 3];
+                        if (nx == RXR_NODE_ADD || nx == RXR_NODE_SUB || nx == RXR_NODE_MUL || nx == RXR_NODE_DIV || nx == RXR_NODE_MIN ||
+                            nx == RXR_NODE_MAX || nx == RXR_NODE_MOD || nx == RXR_NODE_LT || nx == RXR_NODE_LE || nx == RXR_NODE_GT ||
+                            nx == RXR_NODE_GE || nx == RXR_NODE_EQ || nx == RXR_NODE_NE) {
+                            code.push_back((uint32_t)VM_BINC | (nx << 8));
+                            code.push_back(w[i]);
+                            code.push_back(w[i + 1]);
+                            code.push_back(w[i + 2]);
+                            i += 4;
+                            break;
+                        }
+                    }
                     code.push_back(op);
                     code.push_back(w[i]);
                     code.push_back(w[i + 1]);
@@ -1814,6 +1833,7 @@ int rxr_set_shaders(rxr_ctx *ctx, const rxr_shader_set *set) {
     for (uint32_t m : field_reads)
         if (m & field_writes & (PF_UV | PF_ROUGHNESS | PF_METALLIC | PF_OPACITY | PF_BUMP))
             return fail(ctx, RXR_ERR_UNSUPPORTED, "rxr_set_shaders: a program reads uv / roughness / metallic / opacity / bump before writing it while a program of the set writes that field (lanes the raster loops never reset would leak between fragments)");
+    for (int k = 0; k < 4; ++k) fl.code.push_back(VM_ENDFN);  // the interpreter reads one word ahead of every opcode
     if (fl.code.size() >= (1ull << 31)) return fail(ctx, RXR_ERR_INVALID, "rxr_set_shaders: programs too large");
 
     // ---- patterns + palette

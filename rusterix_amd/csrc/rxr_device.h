@@ -125,6 +125,7 @@ enum : uint32_t {
     VM_FAULT = 137,      // statically known panic (e.g. a call of a function that does not exist)
     VM_GETC = 138,       // GetComponents: next word = n | idx0 << 4 | idx1 << 6 ... (2 bits each, 3 = "not x/y/z")
     VM_SETC = 139,       // SetComponents, same encoding
+    VM_BINC = 140,       // fused "Push c; <binary op>": bits 8..15 = the RXR_NODE_* binary opcode, then the f32 bits of c.x, c.y, c.z
 };
 #define RXR_VM_STACK 64
 #define RXR_VM_LOCALS 48

@@ -450,7 +450,8 @@ __device__ __forceinline__ void shade3d_begin(const RasterParams &P, const TriSh
             io.uv.y = v / 4.0f;
             io.hitpoint = rxvm::mk(world.x, world.y, world.z);
             io.time = rxvm::splat(P.time);
-            rxvm::shade(P, B.program_plus1 - 1u, io);
+            if constexpr (X == 2) rxvm::shade_inline(P, B.program_plus1 - 1u, io, rxvm::stack_block());
+            else rxvm::shade_call(P, B.program_plus1 - 1u, io);  // X == 3: from the visibility loop's alpha test
             base = mk3(io.color.x, io.color.y, io.color.z);  // :1319-1323
             normal = mk3(io.normal.x, io.normal.y, io.normal.z);
             rough = rclamp(io.roughness.x, 0.0f, 1.0f);
@@ -609,7 +610,7 @@ __device__ __forceinline__ uint32_t shade3d_opacity(const RasterParams &P, const
             io.time = rxvm::splat(P.time);
             io.roughness.x = 0.5f;
             io.metallic.x = 0.0f;
-            rxvm::shade(P, B.program_plus1 - 1u, io);
+            rxvm::shade_call(P, B.program_plus1 - 1u, io);
             r = io.color.x;
             g = io.color.y;
             b = io.color.z;
@@ -656,7 +657,7 @@ __device__ __forceinline__ uint32_t fragment2d(const RasterParams &P, const Prim
             io.time = rxvm::splat(P.time);
             io.roughness.x = 0.5f;
             io.metallic.x = 0.0f;
-            rxvm::shade(P, B.program_plus1 - 1u, io);
+            rxvm::shade_call(P, B.program_plus1 - 1u, io);
             texel = pack4(f32_to_u8_saturated(io.color.x), f32_to_u8_saturated(io.color.y), f32_to_u8_saturated(io.color.z), 255u);
         }
     }
@@ -1120,7 +1121,7 @@ __device__ __noinline__ bool fragment_alpha_is_255_full(const RasterParams &P, c
                                                         float z, float fx, float fy) {
     const TriShade H = *shade;
     Frag F;
-    shade3d_begin<X>(P, H, batch, alpha, beta, z, fx, fy, F);
+    shade3d_begin<(X >= 2 ? 3 : X)>(P, H, batch, alpha, beta, z, fx, fy, F);  // level 3 = level 2 with the interpreter out of line
     return f32_to_u8_saturated(F.opacity) == 255u;
 }
 
@@ -1682,8 +1683,19 @@ extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_RASTER_WAVES_
 //   1  k_raster_chunk: chunk textures -- terrain texels sampled by world position, baked shader textures, and the
 //      full-fragment alpha test they need
 //   2  k_raster_vm:    level 1 + Rusteria programs; the interpreter (rxr_vm.h) keeps its state in scratch memory
-extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS) k_raster_chunk(RasterParams P) { raster_tile<false, 1>(P); }
-extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS) k_raster_vm(RasterParams P) { raster_tile<false, 2>(P); }
+// These two contain real (out-of-line) calls that take the parameter block by reference.  Handing them the by-value
+// kernel argument would make the compiler copy all of it to scratch and turn every P.field into a scratch load
+// (measured: 3.5x on the whole kernel); the kernarg segment itself is addressable, so they read it in place.
+__device__ __forceinline__ const RasterParams &kernarg_params() {
+    return *(const RasterParams *)__builtin_amdgcn_kernarg_segment_ptr();
+}
+extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS) k_raster_chunk(RasterParams) { raster_tile<false, 1>(kernarg_params()); }
+// occupancy bound of k_raster_vm: 4 waves per SIMD (128 VGPRs; the LDS value stacks are sized to match).  Measured on the
+// reduced box grid with the configuration-C5 program: 1 wave/SIMD bound 373 us, 3: 268, 4: 247, 5: 253
+#ifndef RXR_VM_WAVES_PER_SIMD
+#define RXR_VM_WAVES_PER_SIMD 4
+#endif
+extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_VM_WAVES_PER_SIMD) k_raster_vm(RasterParams) { raster_tile<false, 2>(kernarg_params()); }
 
 #if RXR_PHASE_TIMING
 extern "C" int rxr_debug_phase_read(unsigned long long *out16, int reset) {

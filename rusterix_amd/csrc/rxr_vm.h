@@ -2,8 +2,7 @@
 // (rusteria/src/node/execution.rs:741-749) and Execution::execute (:109-727) over the jump code that
 // rxr_set_shaders flattens the reference's NodeOp trees into (rxr_device.h, VM_*).
 //
-// One invocation per fragment, state private to the lane (stack, locals, globals, frames live in scratch
-// memory: dynamically indexed).  The reference keeps ONE Execution per tile and lets state leak from one
+// One invocation per fragment, state private to the lane; see "the interpreter" below for how a wave runs them.  The reference keeps ONE Execution per tile and lets state leak from one
 // fragment into the next; rxr_set_shaders only accepts programs for which that cannot matter (see
 // include/rxr.h), and every invocation here starts from Execution::new's values plus the fields the raster
 // loops assign before each call.
@@ -66,228 +65,430 @@ __device__ __forceinline__ v3 pattern_sample(const RasterParams &P, const DevPat
 }
 __device__ __forceinline__ float rclampf(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
-#define VM_FAIL(code)  \
-    do {               \
-        fault = (code); \
-        goto done;     \
-    } while (0)
-#define VM_POP(dst)                                  \
-    do {                                             \
-        if (sp == 0u) VM_FAIL(VMF_STACK_UNDERFLOW);  \
-        dst = stack[--sp];                           \
-    } while (0)
-#define VM_PUSH(val)                                            \
-    do {                                                        \
-        if (sp >= RXR_VM_STACK) VM_FAIL(VMF_STACK_OVERFLOW);    \
-        stack[sp++] = (val);                                    \
-    } while (0)
-#define VM_UN(expr)      \
-    {                    \
-        v3 a;            \
-        VM_POP(a);       \
-        VM_PUSH(expr);   \
-        break;           \
-    }
-#define VM_BIN(expr)     \
-    {                    \
-        v3 a, b;         \
-        VM_POP(b);       \
-        VM_POP(a);       \
-        VM_PUSH(expr);   \
-        break;           \
-    }
+// ---- the interpreter ------------------------------------------------------------------------------
+// All lanes of a wave that need a program run call shade() together.  Instruction fetch and decode are
+// wave-uniform: every step executes the instruction at the SMALLEST program counter among the lanes still
+// running ("min-pc scheduling") on exactly the lanes that are at that address, so lanes that diverged at an
+// If / For / different programs re-join as soon as their paths meet, and the opcode switch is a scalar branch.
+// The value stack lives in LDS (RXR_VM_LDS_STACK entries per lane, [slot][component][lane]: conflict-free for any
+// per-lane depth) with its top entry cached in registers, so an operation touches LDS at most once; deeper
+// stacks, locals, globals and call frames are in scratch memory.
+#ifndef RXR_VM_LDS_STACK
+#define RXR_VM_LDS_STACK 6
+#endif
 
-// Execution::shade on program `pi`.  Returns 0 or a VMF_* code.
-__device__ __noinline__ uint32_t shade(const RasterParams &P, uint32_t pi, IO &io) {
+// (the LDS block is passed to every access instead of being stored here: a pointer kept in a struct that itself lives in
+// scratch would become a generic pointer)
+struct Stack {
+    v3 deep[RXR_VM_STACK - RXR_VM_LDS_STACK];  // slots beyond the LDS part (scratch)
+    v3 tos;                                  // entry sp - 1
+    uint32_t sp;
+    __device__ __forceinline__ v3 load(const float *lds, uint32_t slot) const {
+        if (slot < RXR_VM_LDS_STACK) {
+            const float *p = lds + (slot * 3u) * RXR_TILE_THREADS + threadIdx.x;
+            return mk(p[0], p[RXR_TILE_THREADS], p[2 * RXR_TILE_THREADS]);
+        }
+        return deep[slot - RXR_VM_LDS_STACK];
+    }
+    __device__ __forceinline__ void store(float *lds, uint32_t slot, v3 v) {
+        if (slot < RXR_VM_LDS_STACK) {
+            float *p = lds + (slot * 3u) * RXR_TILE_THREADS + threadIdx.x;
+            p[0] = v.x;
+            p[RXR_TILE_THREADS] = v.y;
+            p[2 * RXR_TILE_THREADS] = v.z;
+        } else {
+            deep[slot - RXR_VM_LDS_STACK] = v;
+        }
+    }
+    // callers check the depth first
+    __device__ __forceinline__ void push(float *lds, v3 v) {
+        if (sp) store(lds, sp - 1u, tos);
+        tos = v;
+        ++sp;
+    }
+    __device__ __forceinline__ v3 pop(const float *lds) {
+        v3 r = tos;
+        --sp;
+        if (sp) tos = load(lds, sp - 1u);
+        return r;
+    }
+    __device__ __forceinline__ void truncate(const float *lds, uint32_t n) {  // Vec::truncate: only ever shrinks
+        if (sp > n) {
+            sp = n;
+            if (sp) tos = load(lds, sp - 1u);
+        }
+    }
+};
+
+// smallest pc among the running lanes of the calling wave.  Ballots and shuffles FROM active lanes only: the lanes that
+// did not enter shade() (or left it) are masked off and must not be read.  One round when the wave has not diverged.
+__device__ __forceinline__ uint32_t wave_min_pc(uint32_t pc, bool running, unsigned long long running_mask) {
+    uint32_t cand = (uint32_t)__builtin_amdgcn_readlane((int)pc, __ffsll((long long)running_mask) - 1);
+    for (;;) {
+        const unsigned long long less = __ballot(running && pc < cand);
+        if (!less) return cand;
+        cand = (uint32_t)__builtin_amdgcn_readlane((int)pc, __ffsll((long long)less) - 1);
+    }
+}
+
+// the libm-backed opcodes, kept out of line: they are rare and their inlined bodies would set the register
+// budget of the whole interpreter
+__device__ __noinline__ v3 slow_unary(uint32_t op, v3 a) {
+    switch (op) {
+        case RXR_NODE_SIN: return mk(sinf(a.x), sinf(a.y), sinf(a.z));
+        case RXR_NODE_SIN1: return mk(sinf(a.x), 0.0f, 0.0f);
+        case RXR_NODE_SIN2: return mk(sinf(a.x), sinf(a.y), 0.0f);
+        case RXR_NODE_COS: return mk(cosf(a.x), cosf(a.y), cosf(a.z));
+        case RXR_NODE_COS1: return mk(sinf(a.x), 0.0f, 0.0f);  // execution.rs:337-344: the reference computes the sine
+        case RXR_NODE_COS2: return mk(sinf(a.x), sinf(a.y), 0.0f);
+        case RXR_NODE_TAN: return mk(tanf(a.x), tanf(a.y), tanf(a.z));
+        case RXR_NODE_ATAN: return mk(atanf(a.x), atanf(a.y), atanf(a.z));
+        default: return mk(logf(a.x), logf(a.y), logf(a.z));  // RXR_NODE_LOG
+    }
+}
+__device__ __noinline__ v3 slow_binary(uint32_t op, v3 a, v3 b) {
+    switch (op) {
+        case RXR_NODE_ATAN2: return mk(atan2f(a.x, b.x), atan2f(a.y, b.y), atan2f(a.z, b.z));
+        case RXR_NODE_POW: return mk(powf(a.x, b.x), powf(a.y, b.y), powf(a.z, b.z));
+        default: {  // RXR_NODE_ROTATE2D, :367-374: a = v, b = angle
+            float rad = b.x * (3.14159265358979323846f / 180.0f);
+            float s = sinf(rad), c = cosf(rad);
+            return mk(a.x * c - a.y * s, a.x * s + a.y * c, a.z);
+        }
+    }
+}
+
+#define VM_FAIL(code)       \
+    {                       \
+        fault = (code);     \
+        running = false;    \
+        break;              \
+    }
+#define VM_NEED(n) \
+    if (st.sp < (n)) VM_FAIL(VMF_STACK_UNDERFLOW)
+#define VM_ROOM \
+    if (st.sp >= RXR_VM_STACK) VM_FAIL(VMF_STACK_OVERFLOW)
+// one value in, one out: the top of the stack is rewritten in registers
+#define VM_UN(expr)        \
+    if (on) {              \
+        VM_NEED(1u)        \
+        const v3 a = st.tos; \
+        st.tos = (expr);   \
+        pc = upc + 1u;     \
+    }                      \
+    break;
+// two in, one out: one LDS read
+#define VM_BIN(expr)                      \
+    if (on) {                             \
+        VM_NEED(2u)                       \
+        const v3 b = st.tos;              \
+        const v3 a = st.load(vm_lds, st.sp - 2u); \
+        st.tos = (expr);                  \
+        --st.sp;                          \
+        pc = upc + 1u;                    \
+    }                                     \
+    break;
+#define VM_TER(expr)                      \
+    if (on) {                             \
+        VM_NEED(3u)                       \
+        const v3 c = st.tos;              \
+        const v3 b = st.load(vm_lds, st.sp - 2u); \
+        const v3 a = st.load(vm_lds, st.sp - 3u); \
+        st.tos = (expr);                  \
+        st.sp -= 2u;                      \
+        pc = upc + 1u;                    \
+    }                                     \
+    break;
+#define VM_GET(field)      \
+    if (on) {              \
+        VM_ROOM            \
+        st.push(vm_lds, field); \
+        pc = upc + 1u;     \
+    }                      \
+    break;
+#define VM_SET(field)      \
+    if (on) {              \
+        VM_NEED(1u)        \
+        field = st.pop(vm_lds); \
+        pc = upc + 1u;     \
+    }                      \
+    break;
+
+// Execution::shade on program `pi` for every calling lane.  Returns 0 or this lane's VMF_* code.
+// Inlined form: used where most fragments pass (the opaque pass).  A real call would make the interpreter save and
+// restore ~100 callee-saved VGPRs per invocation -- measured: 26 000 cycles per wave for an EMPTY program, the spill
+// traffic of all resident waves going through HBM.
+__device__ __forceinline__ uint32_t shade_inline(const RasterParams &P, uint32_t pi, IO &io, float *vm_lds) {
     const DevProgram prog = P.programs[pi];
     if (prog.shade_entry == 0xFFFFFFFFu) return 0u;  // shade_index None: nothing runs (:1291, :771, :1651)
-    const uint32_t *code = P.vm_code;
-    v3 stack[RXR_VM_STACK];
+    // the jump code is read-only for the whole launch and every fetch address is wave-uniform: through the constant
+    // address space the fetches become scalar loads (scalar cache) instead of vector loads that each cost an L2 round trip
+    typedef const uint32_t __attribute__((address_space(4))) *code_ptr;
+    const code_ptr code = (code_ptr)P.vm_code;
+    Stack st;
+    st.sp = 0;
+    st.tos = splat(0.0f);
     v3 locals[RXR_VM_LOCALS];
     v3 globals[RXR_VM_GLOBALS];
     uint32_t fr_pc[RXR_VM_FRAMES], fr_base[RXR_VM_FRAMES], fr_lbase[RXR_VM_FRAMES], fr_llen[RXR_VM_FRAMES];
     uint32_t loop_base[RXR_VM_LOOPS];
-    uint32_t sp = 0, nframes = 0, nloops = 0, lbase = 0, llen = prog.shade_locals, pc = prog.shade_entry, fault = 0;
-    bool has_ret = false;
+    uint32_t nframes = 0, nloops = 0, lbase = 0, llen = prog.shade_locals, pc = prog.shade_entry, fault = 0, steps = 0;
+    bool has_ret = false, running = true;
     v3 ret = splat(0.0f);
-    if (llen > RXR_VM_LOCALS) return VMF_LOCALS_OVERFLOW;
+    if (llen > RXR_VM_LOCALS) {
+        fault = VMF_LOCALS_OVERFLOW;
+        running = false;
+        llen = 0;
+    }
     for (uint32_t i = 0; i < llen; ++i) locals[i] = splat(0.0f);
-    for (uint32_t i = 0; i < RXR_VM_GLOBALS; ++i) globals[i] = splat(0.0f);
+    for (uint32_t i = 0; i < prog.n_globals && i < RXR_VM_GLOBALS; ++i) globals[i] = splat(0.0f);
 
-    for (uint32_t step = 0;; ++step) {
-        if (step >= RXR_VM_MAX_STEPS) VM_FAIL(VMF_STEP_LIMIT);
-        const uint32_t w = code[pc++];
+    for (;;) {
+        const unsigned long long running_mask = __ballot(running);
+        if (running_mask == 0ull) break;
+        // the instruction every lane at the smallest program counter executes now
+        const uint32_t upc = wave_min_pc(pc, running, running_mask);
+        const bool on = running && pc == upc;
+        if (on && ++steps > RXR_VM_MAX_STEPS) {
+            fault = VMF_STEP_LIMIT;
+            running = false;
+            continue;
+        }
+        const uint32_t w = code[upc];
+        const uint32_t imm0 = code[upc + 1u];  // (the stream is padded so that this is always readable)
         switch (w & 0xFFu) {
-            case RXR_NODE_LOAD_GLOBAL: {
-                uint32_t i = code[pc++];
-                if (i >= prog.n_globals) VM_FAIL(VMF_GLOBAL_INDEX);
-                VM_PUSH(globals[i]);
-                break;
-            }
-            case RXR_NODE_STORE_GLOBAL: {
-                uint32_t i = code[pc++];
-                if (i >= prog.n_globals) VM_FAIL(VMF_GLOBAL_INDEX);
-                VM_POP(globals[i]);
-                break;
-            }
-            case RXR_NODE_LOAD_LOCAL: {
-                uint32_t i = code[pc++];
-                if (i >= llen) VM_FAIL(VMF_LOCAL_INDEX);
-                VM_PUSH(locals[lbase + i]);
-                break;
-            }
-            case RXR_NODE_STORE_LOCAL: {
-                uint32_t i = code[pc++];
-                if (i >= llen) VM_FAIL(VMF_LOCAL_INDEX);
-                VM_POP(locals[lbase + i]);
-                break;
-            }
-            case RXR_NODE_SWAP: {
-                v3 a, b;
-                VM_POP(b);
-                VM_POP(a);
-                VM_PUSH(b);
-                VM_PUSH(a);
-                break;
-            }
-            case VM_GETC: {  // execution.rs:134-157
-                uint32_t enc = code[pc++], n = enc & 15u, k = 0;
-                v3 v;
-                VM_POP(v);
-                float r[3] = {0.0f, 0.0f, 0.0f};
-                for (uint32_t i = 0; i < n; ++i) {
-                    uint32_t c = (enc >> (4u + 2u * i)) & 3u;
-                    if (c == 3u) continue;
-                    float f = c == 0u ? v.x : (c == 1u ? v.y : v.z);
-                    if (k < 3u) r[k] = f;
-                    ++k;
+            case RXR_NODE_LOAD_GLOBAL:
+                if (on) {
+                    if (imm0 >= prog.n_globals) VM_FAIL(VMF_GLOBAL_INDEX)
+                    VM_ROOM
+                    st.push(vm_lds, globals[imm0]);
+                    pc = upc + 2u;
                 }
-                v3 o = k == 1u ? splat(r[0]) : (k == 2u ? mk(r[0], r[1], 0.0f) : (k == 3u ? mk(r[0], r[1], r[2]) : splat(0.0f)));
-                VM_PUSH(o);
                 break;
-            }
-            case VM_SETC: {  // :158-183
-                uint32_t enc = code[pc++], n = enc & 15u;
-                v3 value, target;
-                VM_POP(value);
-                VM_POP(target);
-                const uint32_t nc = (n >= 1u && n <= 3u) ? n : 0u;
-                for (uint32_t i = 0; i < nc; ++i) {
-                    uint32_t c = (enc >> (4u + 2u * i)) & 3u;
-                    float f = i == 0u ? value.x : (i == 1u ? value.y : value.z);
-                    if (c == 0u) target.x = f;
-                    else if (c == 1u) target.y = f;
-                    else if (c == 2u) target.z = f;
+            case RXR_NODE_STORE_GLOBAL:
+                if (on) {
+                    if (imm0 >= prog.n_globals) VM_FAIL(VMF_GLOBAL_INDEX)
+                    VM_NEED(1u)
+                    globals[imm0] = st.pop(vm_lds);
+                    pc = upc + 2u;
                 }
-                VM_PUSH(target);
                 break;
-            }
-            case RXR_NODE_PUSH: {
-                v3 v = mk(__uint_as_float(code[pc]), __uint_as_float(code[pc + 1]), __uint_as_float(code[pc + 2]));
-                pc += 3;
-                VM_PUSH(v);
+            case RXR_NODE_LOAD_LOCAL:
+                if (on) {
+                    if (imm0 >= llen) VM_FAIL(VMF_LOCAL_INDEX)
+                    VM_ROOM
+                    st.push(vm_lds, locals[lbase + imm0]);
+                    pc = upc + 2u;
+                }
                 break;
-            }
+            case RXR_NODE_STORE_LOCAL:
+                if (on) {
+                    if (imm0 >= llen) VM_FAIL(VMF_LOCAL_INDEX)
+                    VM_NEED(1u)
+                    locals[lbase + imm0] = st.pop(vm_lds);
+                    pc = upc + 2u;
+                }
+                break;
+            case RXR_NODE_SWAP:
+                if (on) {
+                    VM_NEED(2u)
+                    const v3 b = st.tos, a = st.load(vm_lds, st.sp - 2u);
+                    st.store(vm_lds, st.sp - 2u, b);
+                    st.tos = a;
+                    pc = upc + 1u;
+                }
+                break;
+            case VM_GETC:  // execution.rs:134-157
+                if (on) {
+                    VM_NEED(1u)
+                    const uint32_t enc = imm0, n = enc & 15u;
+                    const v3 v = st.tos;
+                    float r[3] = {0.0f, 0.0f, 0.0f};
+                    uint32_t k = 0;
+                    for (uint32_t i = 0; i < n; ++i) {
+                        uint32_t c = (enc >> (4u + 2u * i)) & 3u;
+                        if (c == 3u) continue;
+                        float f = c == 0u ? v.x : (c == 1u ? v.y : v.z);
+                        if (k == 0u) r[0] = f;
+                        else if (k == 1u) r[1] = f;
+                        else if (k == 2u) r[2] = f;
+                        ++k;
+                    }
+                    st.tos = k == 1u ? splat(r[0]) : (k == 2u ? mk(r[0], r[1], 0.0f) : (k == 3u ? mk(r[0], r[1], r[2]) : splat(0.0f)));
+                    pc = upc + 2u;
+                }
+                break;
+            case VM_SETC:  // :158-183
+                if (on) {
+                    VM_NEED(2u)
+                    const uint32_t enc = imm0, n = enc & 15u;
+                    const v3 value = st.tos;
+                    v3 target = st.load(vm_lds, st.sp - 2u);
+                    const uint32_t nc = (n >= 1u && n <= 3u) ? n : 0u;
+                    for (uint32_t i = 0; i < nc; ++i) {
+                        uint32_t c = (enc >> (4u + 2u * i)) & 3u;
+                        float f = i == 0u ? value.x : (i == 1u ? value.y : value.z);
+                        if (c == 0u) target.x = f;
+                        else if (c == 1u) target.y = f;
+                        else if (c == 2u) target.z = f;
+                    }
+                    st.tos = target;
+                    --st.sp;
+                    pc = upc + 2u;
+                }
+                break;
+            case RXR_NODE_PUSH:
+                if (on) {
+                    VM_ROOM
+                    st.push(vm_lds, mk(__uint_as_float(imm0), __uint_as_float(code[upc + 2u]), __uint_as_float(code[upc + 3u])));
+                    pc = upc + 4u;
+                }
+                break;
+            case VM_BINC:  // "Push c; op" fused by rxr_set_shaders: the same values, no stack traffic
+                if (on) {
+                    VM_NEED(1u)
+                    const v3 a = st.tos, b = mk(__uint_as_float(imm0), __uint_as_float(code[upc + 2u]), __uint_as_float(code[upc + 3u]));
+                    v3 r;
+                    switch ((w >> 8) & 0xFFu) {
+                        case RXR_NODE_ADD: r = mk(a.x + b.x, a.y + b.y, a.z + b.z); break;
+                        case RXR_NODE_SUB: r = mk(a.x - b.x, a.y - b.y, a.z - b.z); break;
+                        case RXR_NODE_MUL: r = mk(a.x * b.x, a.y * b.y, a.z * b.z); break;
+                        case RXR_NODE_DIV: r = mk(a.x / b.x, a.y / b.y, a.z / b.z); break;
+                        case RXR_NODE_MIN: r = mk(fminf(a.x, b.x), fminf(a.y, b.y), fminf(a.z, b.z)); break;
+                        case RXR_NODE_MAX: r = mk(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z)); break;
+                        case RXR_NODE_MOD: r = mk(a.x - b.x * floorf(a.x / b.x), a.y - b.y * floorf(a.y / b.y), a.z - b.z * floorf(a.z / b.z)); break;
+                        case RXR_NODE_LT: r = splat(a.x < b.x ? 1.0f : 0.0f); break;
+                        case RXR_NODE_LE: r = splat(a.x <= b.x ? 1.0f : 0.0f); break;
+                        case RXR_NODE_GT: r = splat(a.x > b.x ? 1.0f : 0.0f); break;
+                        case RXR_NODE_GE: r = splat(a.x >= b.x ? 1.0f : 0.0f); break;
+                        case RXR_NODE_EQ: r = splat(a.x == b.x ? 1.0f : 0.0f); break;
+                        default: r = splat(a.x != b.x ? 1.0f : 0.0f); break;  // RXR_NODE_NE
+                    }
+                    st.tos = r;
+                    pc = upc + 4u;
+                }
+                break;
             case RXR_NODE_CLEAR:
-                if (sp) --sp;
+                if (on) {
+                    if (st.sp) (void)st.pop(vm_lds);
+                    pc = upc + 1u;
+                }
                 break;
             case RXR_NODE_DUP:
-                if (sp) {
-                    v3 t = stack[sp - 1];
-                    VM_PUSH(t);
+                if (on) {
+                    if (st.sp) {
+                        VM_ROOM
+                        st.push(vm_lds, st.tos);
+                    }
+                    pc = upc + 1u;
                 }
                 break;
-            case RXR_NODE_PACK2: {
-                v3 x, y;
-                VM_POP(y);
-                VM_POP(x);
-                VM_PUSH(mk(x.x, y.x, 0.0f));
-                break;
-            }
-            case RXR_NODE_PACK3: {
-                v3 x, y, z;
-                VM_POP(z);
-                VM_POP(y);
-                VM_POP(x);
-                VM_PUSH(mk(x.x, y.x, z.x));
-                break;
-            }
+            case RXR_NODE_PACK2: VM_BIN(mk(a.x, b.x, 0.0f))
+            case RXR_NODE_PACK3: VM_TER(mk(a.x, b.x, c.x))
             // ---- control flow (flattened If / For / FunctionCall / Return)
-            case VM_JMP: pc = code[pc]; break;
-            case VM_JZ: {
-                v3 c;
-                VM_POP(c);
-                pc = (c.x != 0.0f) ? pc + 1 : code[pc];
+            case VM_JMP:
+                if (on) pc = imm0;
                 break;
-            }
+            case VM_JZ:
+                if (on) {
+                    VM_NEED(1u)
+                    const v3 c = st.pop(vm_lds);
+                    pc = (c.x != 0.0f) ? upc + 2u : imm0;
+                }
+                break;
             case VM_FOR_ENTER:
-                if (nloops >= RXR_VM_LOOPS) VM_FAIL(VMF_LOOP_DEPTH);
-                loop_base[nloops++] = sp;
+                if (on) {
+                    if (nloops >= RXR_VM_LOOPS) VM_FAIL(VMF_LOOP_DEPTH)
+                    loop_base[nloops++] = st.sp;
+                    pc = upc + 1u;
+                }
                 break;
             case VM_FOR_TRUNC:
-                if (sp > loop_base[nloops - 1]) sp = loop_base[nloops - 1];
+                if (on) {
+                    st.truncate(vm_lds, loop_base[nloops - 1u]);
+                    pc = upc + 1u;
+                }
                 break;
-            case VM_FOR_COND: {
-                v3 z;
-                VM_POP(z);
-                pc = (z.x == 0.0f) ? code[pc] : pc + 1;
+            case VM_FOR_COND:
+                if (on) {
+                    VM_NEED(1u)
+                    const v3 z = st.pop(vm_lds);
+                    pc = (z.x == 0.0f) ? imm0 : upc + 2u;
+                }
                 break;
-            }
-            case VM_FOR_EXIT: --nloops; break;
-            case VM_CALL: {  // :186-223
-                const uint32_t arity = code[pc], total = code[pc + 1], target = code[pc + 2];
-                pc += 3;
-                if (nframes >= RXR_VM_FRAMES) VM_FAIL(VMF_CALL_DEPTH);
-                const uint32_t nb = lbase + llen;
-                if (nb + total > RXR_VM_LOCALS) VM_FAIL(VMF_LOCALS_OVERFLOW);
-                for (uint32_t i = 0; i < total; ++i) locals[nb + i] = splat(0.0f);
-                for (uint32_t i = arity; i-- > 0u;) {
-                    if (sp) {
-                        if (i >= total) VM_FAIL(VMF_LOCAL_INDEX);
-                        locals[nb + i] = stack[--sp];
+            case VM_FOR_EXIT:
+                if (on) {
+                    --nloops;
+                    pc = upc + 1u;
+                }
+                break;
+            case VM_CALL:  // :186-223
+                if (on) {
+                    const uint32_t arity = imm0, total = code[upc + 2u], target = code[upc + 3u];
+                    if (nframes >= RXR_VM_FRAMES) VM_FAIL(VMF_CALL_DEPTH)
+                    const uint32_t nb = lbase + llen;
+                    if (nb + total > RXR_VM_LOCALS) VM_FAIL(VMF_LOCALS_OVERFLOW)
+                    for (uint32_t i = 0; i < total; ++i) locals[nb + i] = splat(0.0f);
+                    bool bad = false;
+                    for (uint32_t i = arity; i-- > 0u;) {
+                        if (st.sp) {
+                            if (i >= total) {
+                                bad = true;
+                                break;
+                            }
+                            locals[nb + i] = st.pop(vm_lds);
+                        }
                     }
+                    if (bad) VM_FAIL(VMF_LOCAL_INDEX)
+                    fr_pc[nframes] = upc + 4u;
+                    fr_base[nframes] = st.sp;
+                    fr_lbase[nframes] = lbase;
+                    fr_llen[nframes] = llen;
+                    ++nframes;
+                    lbase = nb;
+                    llen = total;
+                    pc = target;
                 }
-                fr_pc[nframes] = pc;
-                fr_base[nframes] = sp;
-                fr_lbase[nframes] = lbase;
-                fr_llen[nframes] = llen;
-                ++nframes;
-                lbase = nb;
-                llen = total;
-                pc = target;
                 break;
-            }
-            case VM_RETURN: {  // :224-234
-                v3 v;
-                if (sp) v = stack[--sp];
-                else if (has_ret) v = ret;
-                else v = splat(0.0f);
-                ret = v;
-                has_ret = true;
-                pc = code[pc];  // the function's VM_ENDFN
-                break;
-            }
-            case VM_ENDFN: {
-                if (nframes == 0u) goto done;  // end of `shade`
-                --nframes;
-                const uint32_t base = fr_base[nframes];
-                v3 r;
-                if (has_ret) {
-                    r = ret;
-                    has_ret = false;
-                } else if (sp > base) {
-                    r = stack[--sp];
-                } else {
-                    r = splat(0.0f);
+            case VM_RETURN:  // :224-234
+                if (on) {
+                    v3 v;
+                    if (st.sp) v = st.pop(vm_lds);
+                    else if (has_ret) v = ret;
+                    else v = splat(0.0f);
+                    ret = v;
+                    has_ret = true;
+                    pc = imm0;  // the function's VM_ENDFN
                 }
-                if (sp > base) sp = base;
-                lbase = fr_lbase[nframes];
-                llen = fr_llen[nframes];
-                pc = fr_pc[nframes];
-                VM_PUSH(r);
                 break;
-            }
-            case VM_FAULT: VM_FAIL(code[pc]);
+            case VM_ENDFN:
+                if (on) {
+                    if (nframes == 0u) {  // end of `shade`
+                        running = false;
+                        break;
+                    }
+                    --nframes;
+                    const uint32_t base = fr_base[nframes];
+                    v3 r;
+                    if (has_ret) {
+                        r = ret;
+                        has_ret = false;
+                    } else if (st.sp > base) {
+                        r = st.pop(vm_lds);
+                    } else {
+                        r = splat(0.0f);
+                    }
+                    st.truncate(vm_lds, base);
+                    lbase = fr_lbase[nframes];
+                    llen = fr_llen[nframes];
+                    pc = fr_pc[nframes];
+                    VM_ROOM
+                    st.push(vm_lds, r);
+                }
+                break;
+            case VM_FAULT:
+                if (on) VM_FAIL(imm0)
+                break;
             // ---- arithmetic
             case RXR_NODE_ADD: VM_BIN(mk(a.x + b.x, a.y + b.y, a.z + b.z))
             case RXR_NODE_SUB: VM_BIN(mk(a.x - b.x, a.y - b.y, a.z - b.z))
@@ -297,32 +498,27 @@ __device__ __noinline__ uint32_t shade(const RasterParams &P, uint32_t pi, IO &i
             case RXR_NODE_LENGTH2: VM_UN(mk(sqrtf(a.x * a.x + a.y * a.y), 0.0f, 0.0f))
             case RXR_NODE_LENGTH3: VM_UN(mk(sqrtf(a.x * a.x + a.y * a.y + a.z * a.z), 0.0f, 0.0f))
             case RXR_NODE_ABS: VM_UN(mk(fabsf(a.x), fabsf(a.y), fabsf(a.z)))
-            case RXR_NODE_SIN: VM_UN(mk(sinf(a.x), sinf(a.y), sinf(a.z)))
-            case RXR_NODE_SIN1: VM_UN(mk(sinf(a.x), 0.0f, 0.0f))
-            case RXR_NODE_SIN2: VM_UN(mk(sinf(a.x), sinf(a.y), 0.0f))
-            case RXR_NODE_COS: VM_UN(mk(cosf(a.x), cosf(a.y), cosf(a.z)))
-            case RXR_NODE_COS1: VM_UN(mk(sinf(a.x), 0.0f, 0.0f))        // :337-344: the reference computes the sine
-            case RXR_NODE_COS2: VM_UN(mk(sinf(a.x), sinf(a.y), 0.0f))
-            case RXR_NODE_TAN: VM_UN(mk(tanf(a.x), tanf(a.y), tanf(a.z)))
-            case RXR_NODE_ATAN: VM_UN(mk(atanf(a.x), atanf(a.y), atanf(a.z)))
-            case RXR_NODE_ATAN2: VM_BIN(mk(atan2f(a.x, b.x), atan2f(a.y, b.y), atan2f(a.z, b.z)))
-            case RXR_NODE_NORMALIZE: {  // :345-353
-                v3 a;
-                VM_POP(a);
-                float len = sqrtf((a.x * a.x + a.y * a.y) + a.z * a.z);
-                if (len > 0.0f) a = mk(a.x / len, a.y / len, a.z / len);
-                VM_PUSH(a);
+            case RXR_NODE_SIN:
+            case RXR_NODE_SIN1:
+            case RXR_NODE_SIN2:
+            case RXR_NODE_COS:
+            case RXR_NODE_COS1:
+            case RXR_NODE_COS2:
+            case RXR_NODE_TAN:
+            case RXR_NODE_ATAN:
+            case RXR_NODE_LOG: VM_UN(slow_unary(w & 0xFFu, a))
+            case RXR_NODE_ATAN2:
+            case RXR_NODE_POW:
+            case RXR_NODE_ROTATE2D: VM_BIN(slow_binary(w & 0xFFu, a, b))
+            case RXR_NODE_NORMALIZE:  // :345-353
+                if (on) {
+                    VM_NEED(1u)
+                    const v3 a = st.tos;
+                    float len = sqrtf((a.x * a.x + a.y * a.y) + a.z * a.z);
+                    if (len > 0.0f) st.tos = mk(a.x / len, a.y / len, a.z / len);
+                    pc = upc + 1u;
+                }
                 break;
-            }
-            case RXR_NODE_ROTATE2D: {  // :367-374
-                v3 angle, v;
-                VM_POP(angle);
-                VM_POP(v);
-                float rad = angle.x * (3.14159265358979323846f / 180.0f);
-                float s = sinf(rad), c = cosf(rad);
-                VM_PUSH(mk(v.x * c - v.y * s, v.x * s + v.y * c, v.z));
-                break;
-            }
             case RXR_NODE_DOT: VM_BIN(splat((a.x * b.x + a.y * b.y) + a.z * b.z))
             case RXR_NODE_DOT2: VM_BIN(mk(a.x * b.x + a.y * b.y, 0.0f, 0.0f))
             case RXR_NODE_DOT3: VM_BIN(mk(a.x * b.x + a.y * b.y + a.z * b.z, 0.0f, 0.0f))
@@ -332,49 +528,36 @@ __device__ __noinline__ uint32_t shade(const RasterParams &P, uint32_t pi, IO &i
             case RXR_NODE_ROUND: VM_UN(mk(roundf(a.x), roundf(a.y), roundf(a.z)))
             case RXR_NODE_FRACT: VM_UN(mk(a.x - floorf(a.x), a.y - floorf(a.y), a.z - floorf(a.z)))
             case RXR_NODE_MOD: VM_BIN(mk(a.x - b.x * floorf(a.x / b.x), a.y - b.y * floorf(a.y / b.y), a.z - b.z * floorf(a.z / b.z)))
-            case RXR_NODE_RADIANS: {
-                const float k = 3.14159265358979323846f / 180.0f;
-                VM_UN(mk(a.x * k, a.y * k, a.z * k))
-            }
-            case RXR_NODE_DEGREES: {
-                const float k = 57.2957795130823208767981548141051703f;
-                VM_UN(mk(a.x * k, a.y * k, a.z * k))
-            }
+            case RXR_NODE_RADIANS: VM_UN(mk(a.x * (3.14159265358979323846f / 180.0f), a.y * (3.14159265358979323846f / 180.0f), a.z * (3.14159265358979323846f / 180.0f)))
+            case RXR_NODE_DEGREES: VM_UN(mk(a.x * 57.2957795130823208767981548141051703f, a.y * 57.2957795130823208767981548141051703f, a.z * 57.2957795130823208767981548141051703f))
             case RXR_NODE_MIN: VM_BIN(mk(fminf(a.x, b.x), fminf(a.y, b.y), fminf(a.z, b.z)))
             case RXR_NODE_MAX: VM_BIN(mk(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z)))
-            case RXR_NODE_MIX: {  // a + (b - a) * c
-                v3 a, b, c;
-                VM_POP(c);
-                VM_POP(b);
-                VM_POP(a);
-                VM_PUSH(mk(a.x + (b.x - a.x) * c.x, a.y + (b.y - a.y) * c.y, a.z + (b.z - a.z) * c.z));
+            case RXR_NODE_MIX: VM_TER(mk(a.x + (b.x - a.x) * c.x, a.y + (b.y - a.y) * c.y, a.z + (b.z - a.z) * c.z))
+            case RXR_NODE_SMOOTHSTEP:  // :456-474: a = edge0, b = edge1, c = x
+                if (on) {
+                    VM_NEED(3u)
+                    const v3 c = st.tos, b = st.load(vm_lds, st.sp - 2u), a = st.load(vm_lds, st.sp - 3u);
+                    float denom = b.x - a.x;
+                    float t = denom != 0.0f ? (c.x - a.x) / denom : 0.0f;
+                    if (t < 0.0f) t = 0.0f;
+                    else if (t > 1.0f) t = 1.0f;
+                    st.tos = splat(t * t * (3.0f - 2.0f * t));
+                    st.sp -= 2u;
+                    pc = upc + 1u;
+                }
                 break;
-            }
-            case RXR_NODE_SMOOTHSTEP: {  // :456-474
-                v3 a, b, c;
-                VM_POP(c);
-                VM_POP(b);
-                VM_POP(a);
-                float denom = b.x - a.x;
-                float t = denom != 0.0f ? (c.x - a.x) / denom : 0.0f;
-                if (t < 0.0f) t = 0.0f;
-                else if (t > 1.0f) t = 1.0f;
-                VM_PUSH(splat(t * t * (3.0f - 2.0f * t)));
-                break;
-            }
             case RXR_NODE_STEP: VM_BIN(mk(b.x >= a.x ? 1.0f : 0.0f, b.y >= a.y ? 1.0f : 0.0f, b.z >= a.z ? 1.0f : 0.0f))
-            case RXR_NODE_CLAMP: {  // f32::clamp panics unless min <= max
-                v3 a, b, c;
-                VM_POP(c);
-                VM_POP(b);
-                VM_POP(a);
-                if (!(b.x <= c.x) || !(b.y <= c.y) || !(b.z <= c.z)) VM_FAIL(VMF_CLAMP_BOUNDS);
-                VM_PUSH(mk(rclampf(a.x, b.x, c.x), rclampf(a.y, b.y, c.y), rclampf(a.z, b.z, c.z)));
+            case RXR_NODE_CLAMP:  // f32::clamp panics unless min <= max: a = x, b = lo, c = hi
+                if (on) {
+                    VM_NEED(3u)
+                    const v3 c = st.tos, b = st.load(vm_lds, st.sp - 2u), a = st.load(vm_lds, st.sp - 3u);
+                    if (!(b.x <= c.x) || !(b.y <= c.y) || !(b.z <= c.z)) VM_FAIL(VMF_CLAMP_BOUNDS)
+                    st.tos = mk(rclampf(a.x, b.x, c.x), rclampf(a.y, b.y, c.y), rclampf(a.z, b.z, c.z));
+                    st.sp -= 2u;
+                    pc = upc + 1u;
+                }
                 break;
-            }
             case RXR_NODE_SQRT: VM_UN(mk(sqrtf(a.x), sqrtf(a.y), sqrtf(a.z)))
-            case RXR_NODE_LOG: VM_UN(mk(logf(a.x), logf(a.y), logf(a.z)))
-            case RXR_NODE_POW: VM_BIN(mk(powf(a.x, b.x), powf(a.y, b.y), powf(a.z, b.z)))
             case RXR_NODE_EQ: VM_BIN(splat(a.x == b.x ? 1.0f : 0.0f))
             case RXR_NODE_NE: VM_BIN(splat(a.x != b.x ? 1.0f : 0.0f))
             case RXR_NODE_LT: VM_BIN(splat(a.x < b.x ? 1.0f : 0.0f))
@@ -385,80 +568,105 @@ __device__ __noinline__ uint32_t shade(const RasterParams &P, uint32_t pi, IO &i
             case RXR_NODE_OR: VM_BIN(splat(((a.x != 0.0f) | (b.x != 0.0f)) ? 1.0f : 0.0f))
             case RXR_NODE_NOT: VM_UN(splat(a.x == 0.0f ? 1.0f : 0.0f))
             case RXR_NODE_NEG: VM_UN(mk(-a.x, -a.y, -a.z))
-            case RXR_NODE_PRINT: {  // println! only
-                v3 a;
-                VM_POP(a);
+            case RXR_NODE_PRINT:  // println! only
+                if (on) {
+                    VM_NEED(1u)
+                    (void)st.pop(vm_lds);
+                    pc = upc + 1u;
+                }
                 break;
-            }
             // ---- the fragment's fields
-            case RXR_NODE_UV: VM_PUSH(io.uv); break;
-            case RXR_NODE_SET_UV: VM_POP(io.uv); break;
-            case RXR_NODE_NORMAL: VM_PUSH(io.normal); break;
-            case RXR_NODE_SET_NORMAL: {  // .normalized()
-                v3 a;
-                VM_POP(a);
-                float len = sqrtf((a.x * a.x + a.y * a.y) + a.z * a.z);
-                io.normal = mk(a.x / len, a.y / len, a.z / len);
-                break;
-            }
-            case RXR_NODE_HITPOINT: VM_PUSH(io.hitpoint); break;
-            case RXR_NODE_TIME: VM_PUSH(io.time); break;
-            case RXR_NODE_COLOR: VM_PUSH(io.color); break;
-            case RXR_NODE_SET_COLOR: VM_POP(io.color); break;
-            case RXR_NODE_ROUGHNESS: VM_PUSH(io.roughness); break;
-            case RXR_NODE_SET_ROUGHNESS: VM_POP(io.roughness); break;
-            case RXR_NODE_METALLIC: VM_PUSH(io.metallic); break;
-            case RXR_NODE_SET_METALLIC: VM_POP(io.metallic); break;
-            case RXR_NODE_EMISSIVE: VM_PUSH(io.emissive); break;
-            case RXR_NODE_OPACITY: VM_PUSH(io.opacity); break;
-            case RXR_NODE_SET_OPACITY: VM_POP(io.opacity); break;
-            case RXR_NODE_BUMP: VM_PUSH(io.bump); break;
-            case RXR_NODE_SET_BUMP: VM_POP(io.bump); break;
-            case RXR_NODE_SAMPLE: {  // :570-578
-                v3 a, b;
-                VM_POP(b);
-                VM_POP(a);
-                uint32_t id = as_usize_sat(b.x);
-                v3 o = splat(0.0f);
-                if (id < P.n_patterns) o = pattern_sample(P, P.patterns[id], a);
-                VM_PUSH(o);
-                break;
-            }
-            case RXR_NODE_SAMPLE_NORMAL: {  // :579-594
-                v3 a, b;
-                VM_POP(b);
-                VM_POP(a);
-                uint32_t id = as_usize_sat(b.x);
-                v3 o = splat(0.0f);
-                if (id < P.n_normal_patterns) {
-                    v3 nm = pattern_sample(P, P.patterns[P.n_patterns + id], a);
-                    o = mk(nm.x * 2.0f - 1.0f, nm.y * 2.0f - 1.0f, nm.z * 2.0f - 1.0f);
-                }
-                VM_PUSH(o);
-                break;
-            }
-            case RXR_NODE_PALETTE_INDEX: {  // :694-701: pushes nothing for a missing / empty slot
-                v3 a;
-                VM_POP(a);
-                uint32_t id = as_usize_sat(a.x);
-                if (id < P.n_palette && P.palette[4u * id + 3u] != 0.0f) {
-                    v3 c = mk(P.palette[4u * id], P.palette[4u * id + 1u], P.palette[4u * id + 2u]);
-                    VM_PUSH(c);
+            case RXR_NODE_UV: VM_GET(io.uv)
+            case RXR_NODE_SET_UV: VM_SET(io.uv)
+            case RXR_NODE_NORMAL: VM_GET(io.normal)
+            case RXR_NODE_SET_NORMAL:  // .normalized()
+                if (on) {
+                    VM_NEED(1u)
+                    const v3 a = st.pop(vm_lds);
+                    float len = sqrtf((a.x * a.x + a.y * a.y) + a.z * a.z);
+                    io.normal = mk(a.x / len, a.y / len, a.z / len);
+                    pc = upc + 1u;
                 }
                 break;
-            }
-            default: VM_FAIL(VMF_BAD_OPCODE);
+            case RXR_NODE_HITPOINT: VM_GET(io.hitpoint)
+            case RXR_NODE_TIME: VM_GET(io.time)
+            case RXR_NODE_COLOR: VM_GET(io.color)
+            case RXR_NODE_SET_COLOR: VM_SET(io.color)
+            case RXR_NODE_ROUGHNESS: VM_GET(io.roughness)
+            case RXR_NODE_SET_ROUGHNESS: VM_SET(io.roughness)
+            case RXR_NODE_METALLIC: VM_GET(io.metallic)
+            case RXR_NODE_SET_METALLIC: VM_SET(io.metallic)
+            case RXR_NODE_EMISSIVE: VM_GET(io.emissive)
+            case RXR_NODE_OPACITY: VM_GET(io.opacity)
+            case RXR_NODE_SET_OPACITY: VM_SET(io.opacity)
+            case RXR_NODE_BUMP: VM_GET(io.bump)
+            case RXR_NODE_SET_BUMP: VM_SET(io.bump)
+            case RXR_NODE_SAMPLE:  // :570-578: a = uv, b = pattern id
+                if (on) {
+                    VM_NEED(2u)
+                    const v3 b = st.tos, a = st.load(vm_lds, st.sp - 2u);
+                    const uint32_t id = as_usize_sat(b.x);
+                    st.tos = id < P.n_patterns ? pattern_sample(P, P.patterns[id], a) : splat(0.0f);
+                    --st.sp;
+                    pc = upc + 1u;
+                }
+                break;
+            case RXR_NODE_SAMPLE_NORMAL:  // :579-594
+                if (on) {
+                    VM_NEED(2u)
+                    const v3 b = st.tos, a = st.load(vm_lds, st.sp - 2u);
+                    const uint32_t id = as_usize_sat(b.x);
+                    v3 o = splat(0.0f);
+                    if (id < P.n_normal_patterns) {
+                        v3 nm = pattern_sample(P, P.patterns[P.n_patterns + id], a);
+                        o = mk(nm.x * 2.0f - 1.0f, nm.y * 2.0f - 1.0f, nm.z * 2.0f - 1.0f);
+                    }
+                    st.tos = o;
+                    --st.sp;
+                    pc = upc + 1u;
+                }
+                break;
+            case RXR_NODE_PALETTE_INDEX:  // :694-701: pushes nothing for a missing / empty slot
+                if (on) {
+                    VM_NEED(1u)
+                    const v3 a = st.pop(vm_lds);
+                    const uint32_t id = as_usize_sat(a.x);
+                    if (id < P.n_palette && P.palette[4u * id + 3u] != 0.0f)
+                        st.push(vm_lds, mk(P.palette[4u * id], P.palette[4u * id + 1u], P.palette[4u * id + 2u]));  // (room: one was just popped)
+                    pc = upc + 1u;
+                }
+                break;
+            default:
+                if (on) VM_FAIL(VMF_BAD_OPCODE)
+                break;
         }
     }
-done:
     if (fault) *P.vm_fault = fault;
     return fault;
 }
 
+// this workgroup's LDS block for the value stacks
+__device__ __forceinline__ float *stack_block() {
+    __shared__ float vm_lds[RXR_VM_LDS_STACK * 3 * RXR_TILE_THREADS];
+    return vm_lds;
+}
+
+// out-of-line form for the rarer call sites (opacity pass, 2D pass, the visibility loop's alpha test): one shared copy
+// of the interpreter instead of one per site
+__device__ __noinline__ uint32_t shade_call(const RasterParams &P, uint32_t pi, IO &io_caller) {
+    IO io = io_caller;  // the caller's copy sits in scratch (its address crosses the call): work on registers, write back once
+    const uint32_t fault = shade_inline(P, pi, io, stack_block());
+    io_caller = io;
+    return fault;
+}
+
 #undef VM_FAIL
-#undef VM_POP
-#undef VM_PUSH
+#undef VM_NEED
+#undef VM_ROOM
 #undef VM_UN
 #undef VM_BIN
+#undef VM_TER
+#undef VM_GET
+#undef VM_SET
 
 }  // namespace rxvm

@@ -276,14 +276,27 @@ def map_scene(api, width=1920, height=1080, tile_size=40, n_lights=1, logo_size=
     return _result(api, scene, assets, setup, width, height, tile_size, name, n_lights=n_lights)
 
 
-def box_grid_scene(api, n=289, width=7680, height=4320, tile_size=40, sample_mode=B.SAMPLE_LINEAR, boxes_per_batch=None):
-    """C5: n batches of n boxes on an n x n lattice (n=289 -> 1 002 252 triangles)."""
+def box_grid_shader():
+    """The "per-batch shader" of configuration C5: a pure colour-only Rusteria program (no emissive, no globals,
+    nothing read before it is written) -- tints the texel by a stripe pattern in uv and the height of the hit point."""
+    return B.Program([[
+        "UV", ("Push", 4.0), "Mul", "Fract", ("GetComponents", [0]), ("Push", 0.5), "Lt",       # uv is interpolated_uv / 4
+        ("If", [("Push", 1.0, 0.85, 0.7)], [("Push", 0.7, 0.85, 1.0)]),
+        "Color", "Mul",
+        "Hitpoint", ("GetComponents", [1]), ("Push", 1.5), "Mul", ("Push", 0.4), "Add", "Mul",
+        "SetColor",
+    ]])
+
+
+def box_grid_scene(api, n=289, width=7680, height=4320, tile_size=40, sample_mode=B.SAMPLE_LINEAR, boxes_per_batch=None, shader=False):
+    """C5: n batches of n boxes on an n x n lattice (n=289 -> 1 002 252 triangles); `shader`: every batch runs box_grid_shader()."""
     rng = _rng(200)
     spacing, size = 0.2, 0.16
     tmpl = api.Batch3D.from_box(0.0, 0.0, 0.0, size, size, size)
     tv, ti, tuv, _ = tmpl.geometry()
     ys = rng.random((n, n)).astype(np.float32) * np.float32(0.4)
     scene = api.Scene.empty()
+    shader_index = scene.add_program(box_grid_shader()) if shader else None
     per = boxes_per_batch or n
     for bz in range(n):
         vs, is_, uvs = [], [], []
@@ -297,6 +310,8 @@ def box_grid_scene(api, n=289, width=7680, height=4320, tile_size=40, sample_mod
             uvs.append(tuv)
         b = api.Batch3D.new(np.concatenate(vs), np.concatenate(is_), np.concatenate(uvs))
         b = (b.source(B.PixelSource.StaticTileIndex(bz % 16)).repeat_mode(B.REPEAT_REPEAT_XY).with_computed_normals())
+        if shader_index is not None:
+            b.shader(shader_index)
         scene.add_d3_static(b)
     assets = api.Assets.default().textures([B.Tile.from_texture(noise_texture(300 + k)) for k in range(16)])
     extent = n * spacing

@@ -16,10 +16,14 @@ ap.add_argument("--lights", type=int, default=16)
 ap.add_argument("--width", type=int, default=3840)
 ap.add_argument("--height", type=int, default=2160)
 ap.add_argument("--frames", type=int, default=5)
+ap.add_argument("--scene", default="map", help="map | boxes | boxes_shader (the reduced C5 grid, 1920x1080)")
 a = ap.parse_args()
 prod = rusterix_amd.load()
 rxr = C.CDLL(rusterix_amd.lib_paths()["rxr"])
-cfg = scenes.map_scene(prod, width=a.width, height=a.height, n_lights=a.lights)
+if a.scene == "map":
+    cfg = scenes.map_scene(prod, width=a.width, height=a.height, n_lights=a.lights)
+else:
+    cfg = scenes.box_grid_scene(prod, n=96, width=1920, height=1080, shader=a.scene == "boxes_shader")
 scenes.render(cfg)
 out = (C.c_ulonglong * 16)()
 assert rxr.rxr_debug_phase_read(out, 1) == 0, "library was not built with -DRXR_PHASE_TIMING=1"

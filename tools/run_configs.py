@@ -35,6 +35,10 @@ def config(api, name):
         return scenes.box_grid_scene(api, n=289, width=7680, height=4320)
     if name == "C5s":  # reduced C5 for a full oracle comparison
         return scenes.box_grid_scene(api, n=96, width=1920, height=1080)
+    if name == "C5shader":  # configs[4] as named: Linear sampling + per-batch shader
+        return scenes.box_grid_scene(api, n=289, width=7680, height=4320, shader=True)
+    if name == "C5s_shader":
+        return scenes.box_grid_scene(api, n=96, width=1920, height=1080, shader=True)
     if name == "D2":  # 2D tile map: 60 x 34 textured / translucent rectangles + overlays + lines, render_2d mode
         return scenes.tile_map_2d_scene(api, width=1920, height=1080, nx=60, ny=34)
     raise SystemExit(f"unknown config {name}")
