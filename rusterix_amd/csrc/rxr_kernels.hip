@@ -32,6 +32,15 @@
 #include "rxr_project.h"
 #include "rxr_vm.h"
 
+// occupancy bound of k_raster_vm: 4 waves per SIMD (128 VGPRs; the LDS value stacks are sized to match).  Measured on the
+// reduced box grid with the configuration-C5 program: 1 wave/SIMD bound 373 us, 3: 268, 4: 247, 5: 253
+#ifndef RXR_VM_WAVES_PER_SIMD
+#define RXR_VM_WAVES_PER_SIMD 4
+#endif
+// 1: the opaque pass calls the out-of-line interpreter too (A-B runs: slower, 304 vs 236 us on the probe)
+#ifndef RXR_VM_ALWAYS_CALL
+#define RXR_VM_ALWAYS_CALL 0
+#endif
 #ifndef RXR_VEK_FUSED_MATVEC
 #define RXR_VEK_FUSED_MATVEC 1
 #endif
@@ -450,7 +459,7 @@ __device__ __forceinline__ void shade3d_begin(const RasterParams &P, const TriSh
             io.uv.y = v / 4.0f;
             io.hitpoint = rxvm::mk(world.x, world.y, world.z);
             io.time = rxvm::splat(P.time);
-            if constexpr (X == 2) rxvm::shade_inline(P, B.program_plus1 - 1u, io, rxvm::stack_block());
+            if constexpr (X == 2 && !RXR_VM_ALWAYS_CALL) rxvm::shade_inline(P, B.program_plus1 - 1u, io, rxvm::stack_block());
             else rxvm::shade_call(P, B.program_plus1 - 1u, io);  // X == 3: from the visibility loop's alpha test
             base = mk3(io.color.x, io.color.y, io.color.z);  // :1319-1323
             normal = mk3(io.normal.x, io.normal.y, io.normal.z);
@@ -1690,11 +1699,6 @@ __device__ __forceinline__ const RasterParams &kernarg_params() {
     return *(const RasterParams *)__builtin_amdgcn_kernarg_segment_ptr();
 }
 extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS) k_raster_chunk(RasterParams) { raster_tile<false, 1>(kernarg_params()); }
-// occupancy bound of k_raster_vm: 4 waves per SIMD (128 VGPRs; the LDS value stacks are sized to match).  Measured on the
-// reduced box grid with the configuration-C5 program: 1 wave/SIMD bound 373 us, 3: 268, 4: 247, 5: 253
-#ifndef RXR_VM_WAVES_PER_SIMD
-#define RXR_VM_WAVES_PER_SIMD 4
-#endif
 extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_VM_WAVES_PER_SIMD) k_raster_vm(RasterParams) { raster_tile<false, 2>(kernarg_params()); }
 
 #if RXR_PHASE_TIMING
