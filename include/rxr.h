@@ -374,6 +374,10 @@ int rxr_read_projected_mesh(rxr_ctx *ctx, uint32_t index, uint32_t counts[2], fl
  * For (the reference unwinds that incorrectly).
  * Replaces: Execution::shade per fragment, src/rasterizer.rs:760-800, :1283-1304, :1642-1667. */
 int rxr_set_shaders(rxr_ctx *ctx, const rxr_shader_set *set);
+/* the validation half of rxr_set_shaders without a device (no context needed): same status codes; on failure `message`
+ * receives the reason; code_words (optional) the length of the flattened jump code.  Lets a host decide up front whether
+ * a scene's programs can run on the device or must take the CPU path. */
+int rxr_check_shaders(const rxr_shader_set *set, uint32_t *code_words, char *message, uint32_t message_capacity);
 
 /* validates + flattens a projected frame and copies it to HBM (replaces nothing in the reference:
  * it is the host->device hand-over).  The frame stays resident until the next upload. */

@@ -1769,6 +1769,84 @@ bool program_is_pure(const rxr_program &p, uint32_t &reads_unassigned, uint32_t 
 
 }  // namespace
 
+namespace {
+
+// validates every program of the set and flattens them into one code stream; no device involved.
+// Returns RXR_OK or the status + message rxr_set_shaders / rxr_check_shaders report.
+int flatten_programs(const rxr_shader_set *set, std::vector<uint32_t> &code, std::vector<DevProgram> &progs, std::vector<uint32_t> &field_reads,
+                     std::string &err) {
+    auto bad = [&](int st, const std::string &m) {
+        err = m;
+        return st;
+    };
+    if (set->n_programs && !set->programs) return bad(RXR_ERR_INVALID, "NULL program array");
+    Flattener fl;
+    uint32_t field_writes = 0;
+    for (uint32_t pi = 0; pi < set->n_programs; ++pi) {
+        const rxr_program &p = set->programs[pi];
+        if (p.n_functions && !p.functions) return bad(RXR_ERR_INVALID, "NULL function array");
+        for (uint32_t k = 0; k < p.n_functions; ++k)
+            if (p.functions[k].n_words && !p.functions[k].words) return bad(RXR_ERR_INVALID, "NULL function body");
+        DevProgram d{};
+        d.shade_entry = 0xFFFFFFFFu;
+        d.shade_locals = p.shade_locals;
+        d.n_globals = p.n_globals;
+        uint32_t ru = 0, wr = 0;
+        if (p.shade_index >= 0) {
+            if ((uint32_t)p.shade_index >= p.n_functions)  // program.user_functions[index] would panic on the first fragment
+                return bad(RXR_ERR_INVALID, "shade_index out of range");
+            if (p.n_globals > RXR_VM_GLOBALS) return bad(RXR_ERR_UNSUPPORTED, "more globals than the device VM holds");
+            if (p.shade_locals > RXR_VM_LOCALS) return bad(RXR_ERR_UNSUPPORTED, "more locals than the device VM holds");
+            // structural check first (lengths), so that the purity walk below cannot run off the arrays
+            fl.n_functions = p.n_functions;
+            fl.writes_opacity = false;
+            fl.call_patches.clear();
+            std::vector<uint32_t> entries(p.n_functions);
+            for (uint32_t k = 0; k < p.n_functions; ++k) {
+                entries[k] = (uint32_t)fl.code.size();
+                fl.return_patches.clear();
+                if (!fl.block(p.functions[k].words, p.functions[k].n_words, 0, 0)) return bad(fl.status, fl.err);
+                const uint32_t endfn = (uint32_t)fl.code.size();
+                fl.code.push_back(VM_ENDFN);
+                for (size_t pos : fl.return_patches) fl.code[pos] = endfn;
+            }
+            for (auto &cp : fl.call_patches) fl.code[cp.first] = entries[cp.second];
+            if (!program_is_pure(p, ru, wr))
+                return bad(RXR_ERR_UNSUPPORTED, "a local of `shade` or a global is read before this invocation wrote it (the reference would read the previous fragment's value)");
+            field_writes |= wr;
+            d.shade_entry = entries[p.shade_index];
+            d.flags = fl.writes_opacity ? 1u : 0u;
+        }
+        field_reads.push_back(ru);
+        progs.push_back(d);
+    }
+    // uv.z, roughness.yz, metallic.yz, opacity.yz and bump are never assigned by the raster loops: once ANY program of the
+    // set writes such a field, a read that its own invocation has not preceded by a write would see an earlier fragment's lanes
+    for (uint32_t m : field_reads)
+        if (m & field_writes & (PF_UV | PF_ROUGHNESS | PF_METALLIC | PF_OPACITY | PF_BUMP))
+            return bad(RXR_ERR_UNSUPPORTED, "a program reads uv / roughness / metallic / opacity / bump before writing it while a program of the set writes that field (lanes the raster loops never reset would leak between fragments)");
+    for (int k = 0; k < 4; ++k) fl.code.push_back(VM_ENDFN);  // the interpreter reads one word ahead of every opcode
+    if (fl.code.size() >= (1ull << 31)) return bad(RXR_ERR_INVALID, "programs too large");
+    code = std::move(fl.code);
+    return RXR_OK;
+}
+
+}  // namespace
+
+int rxr_check_shaders(const rxr_shader_set *set, uint32_t *code_words, char *message, uint32_t message_capacity) {
+    std::vector<uint32_t> code, reads;
+    std::vector<DevProgram> progs;
+    std::string err;
+    int rc = set ? flatten_programs(set, code, progs, reads, err) : RXR_ERR_INVALID;
+    if (code_words) *code_words = (uint32_t)code.size();
+    if (message && message_capacity) {
+        size_t n = std::min<size_t>(err.size(), message_capacity - 1);
+        memcpy(message, err.data(), n);
+        message[n] = 0;
+    }
+    return rc;
+}
+
 int rxr_set_shaders(rxr_ctx *ctx, const rxr_shader_set *set) {
     if (!ctx) return RXR_ERR_INVALID;
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -1782,59 +1860,16 @@ int rxr_set_shaders(rxr_ctx *ctx, const rxr_shader_set *set) {
         return fail(ctx, RXR_ERR_INVALID, "rxr_set_shaders: NULL array");
 
     // ---- validate + flatten every program into one code stream
-    Flattener fl;
+    struct {
+        std::vector<uint32_t> code;
+    } fl;
     std::vector<DevProgram> progs;
     std::vector<uint32_t> field_reads;  // per program: PF_* read before written
-    uint32_t field_writes = 0;
-    bool have_masks = false;
-    for (uint32_t pi = 0; pi < set->n_programs; ++pi) {
-        const rxr_program &p = set->programs[pi];
-        if (p.n_functions && !p.functions) return fail(ctx, RXR_ERR_INVALID, "rxr_set_shaders: NULL function array");
-        for (uint32_t k = 0; k < p.n_functions; ++k)
-            if (p.functions[k].n_words && !p.functions[k].words) return fail(ctx, RXR_ERR_INVALID, "rxr_set_shaders: NULL function body");
-        DevProgram d{};
-        d.shade_entry = 0xFFFFFFFFu;
-        d.shade_locals = p.shade_locals;
-        d.n_globals = p.n_globals;
-        if (p.shade_index >= 0) {
-            if ((uint32_t)p.shade_index >= p.n_functions)  // program.user_functions[index] would panic on the first fragment
-                return fail(ctx, RXR_ERR_INVALID, "rxr_set_shaders: shade_index out of range");
-            if (p.n_globals > RXR_VM_GLOBALS) return fail(ctx, RXR_ERR_UNSUPPORTED, "rxr_set_shaders: more globals than the device VM holds");
-            if (p.shade_locals > RXR_VM_LOCALS) return fail(ctx, RXR_ERR_UNSUPPORTED, "rxr_set_shaders: more locals than the device VM holds");
-            // structural check first (lengths), so that the purity walk below cannot run off the arrays
-            fl.n_functions = p.n_functions;
-            fl.writes_opacity = false;
-            fl.call_patches.clear();
-            std::vector<uint32_t> entries(p.n_functions);
-            for (uint32_t k = 0; k < p.n_functions; ++k) {
-                entries[k] = (uint32_t)fl.code.size();
-                fl.return_patches.clear();
-                if (!fl.block(p.functions[k].words, p.functions[k].n_words, 0, 0)) return fail(ctx, fl.status, "rxr_set_shaders: " + fl.err);
-                const uint32_t endfn = (uint32_t)fl.code.size();
-                fl.code.push_back(VM_ENDFN);
-                for (size_t pos : fl.return_patches) fl.code[pos] = endfn;
-            }
-            for (auto &cp : fl.call_patches) fl.code[cp.first] = entries[cp.second];
-            uint32_t ru = 0, wr = 0;
-            if (!program_is_pure(p, ru, wr))
-                return fail(ctx, RXR_ERR_UNSUPPORTED, "rxr_set_shaders: a local of `shade` or a global is read before this invocation wrote it (the reference would read the previous fragment's value)");
-            field_reads.push_back(ru);
-            field_writes |= wr;
-            have_masks = true;
-            d.shade_entry = entries[p.shade_index];
-            d.flags = fl.writes_opacity ? 1u : 0u;
-        }
-        if (!have_masks) field_reads.push_back(0);
-        have_masks = false;
-        progs.push_back(d);
+    {
+        std::string err;
+        int frc = flatten_programs(set, fl.code, progs, field_reads, err);
+        if (frc != RXR_OK) return fail(ctx, frc, "rxr_set_shaders: " + err);
     }
-    // uv.z, roughness.yz, metallic.yz, opacity.yz and bump are never assigned by the raster loops: once ANY program of the
-    // set writes such a field, a read that its own invocation has not preceded by a write would see an earlier fragment's lanes
-    for (uint32_t m : field_reads)
-        if (m & field_writes & (PF_UV | PF_ROUGHNESS | PF_METALLIC | PF_OPACITY | PF_BUMP))
-            return fail(ctx, RXR_ERR_UNSUPPORTED, "rxr_set_shaders: a program reads uv / roughness / metallic / opacity / bump before writing it while a program of the set writes that field (lanes the raster loops never reset would leak between fragments)");
-    for (int k = 0; k < 4; ++k) fl.code.push_back(VM_ENDFN);  // the interpreter reads one word ahead of every opcode
-    if (fl.code.size() >= (1ull << 31)) return fail(ctx, RXR_ERR_INVALID, "rxr_set_shaders: programs too large");
 
     // ---- patterns + palette
     std::vector<DevPattern> pats;

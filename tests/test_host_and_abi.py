@@ -27,7 +27,8 @@ def test_header_declares_the_expected_entry_points():
     names = declared_functions()
     for must in ["rxr_create", "rxr_destroy", "rxr_last_error", "rxr_device_count", "rxr_set_textures", "rxr_upload_frame",
                  "rxr_render_rows", "rxr_render_rows_to", "rxr_render_stripes_to", "rxr_download_rows", "rxr_rasterize",
-                 "rxr_synchronize", "rxr_get_stats", "rxr_device_framebuffer", "rxr_profile_begin", "rxr_profile_read"]:
+                 "rxr_synchronize", "rxr_get_stats", "rxr_device_framebuffer", "rxr_profile_begin", "rxr_profile_read",
+                 "rxr_set_meshes", "rxr_read_projected_mesh", "rxr_set_shaders", "rxr_selftest_math"]:
         assert must in names, must
 
 
@@ -39,7 +40,9 @@ def test_library_exports_every_declared_symbol():
 
 def test_host_library_exports_builder_api():
     api = rusterix_amd.load()
-    for sym in ["rxh_rasterizer_rasterize", "rxh_rasterizer_upload", "rxh_context", "rxh_set_device", "rxh_last_error", "rxh_scene_project"]:
+    for sym in ["rxh_rasterizer_rasterize", "rxh_rasterizer_upload", "rxh_context", "rxh_set_device", "rxh_last_error", "rxh_scene_project",
+                "rxh_scene_add_program", "rxh_assets_set_patterns", "rxh_assets_set_palette", "rxh_chunk_set_terrain",
+                "rxh_chunk_set_terrain_batch2d", "rxh_chunk_add_shader_texture", "rxh_set_device_projection"]:
         assert hasattr(api.lib, sym), sym
 
 
