@@ -123,3 +123,91 @@ def test_random_scene_device_projection(product, seed):
     finally:
         lib.rxh_set_device_projection(0)
     assert np.array_equal(got, want), f"seed {seed}: {(got != want).any(axis=2).sum()} pixels differ between host and device projection"
+
+
+def build_chunks(api, seed, width, height):
+    """random chunked scenes: several chunks with opacity-pass batches, profile ids shared between panes and walls, terrain
+    textures (some with holes) sampled by world position, per-chunk programs and baked shader textures, a 2D overlay"""
+    from tests.test_gpu_shaders import ProgramGen
+
+    rng = np.random.default_rng([0x52585231, 9090, seed])
+    setters = ["SetColor", "SetRoughness", "SetMetallic"]   # what every program of the scene may write (and none reads)
+    scene = api.Scene.empty()
+    textures = [B.Tile([random_texture(rng, int(rng.integers(4, 40)), int(rng.integers(4, 40)), int(rng.integers(0, 3)))]) for _ in range(3)]
+    assets = api.Assets.default().textures(textures)
+    if rng.random() < 0.5:
+        scene.add_program(ProgramGen(rng, 3, 0, setters).program())   # scene.shaders[0]: chunk batches must not pick it up
+
+    def soup(nt, spread=1.0):
+        centre = rng.normal(0.0, 1.0 * spread, size=(nt, 1, 3))
+        verts = (centre + rng.normal(0.0, 0.7, size=(nt, 3, 3))).reshape(-1, 3).astype(np.float32)
+        v4 = np.concatenate([verts, np.ones((len(verts), 1), np.float32)], axis=1)
+        idx = np.arange(nt * 3, dtype=np.uint32).reshape(nt, 3)
+        uv = (rng.random((nt * 3, 2)) * 2.0).astype(np.float32)
+        return api.Batch3D.new(v4, idx, uv).with_computed_normals().cull_mode(int(rng.integers(0, 3)))
+
+    for c in range(int(rng.integers(1, 4))):
+        chunk = scene.add_chunk()
+        size = int(rng.integers(2, 9))
+        if rng.random() < 0.7:
+            tw = int(rng.integers(8, 48))
+            chunk.terrain(random_texture(rng, tw, int(rng.integers(8, 48)), int(rng.integers(0, 2))), origin=(int(rng.integers(-3, 3)), int(rng.integers(-3, 3))), size=size)
+        else:
+            chunk.terrain(None, origin=(0, 0), size=size)
+        n_shaders = int(rng.integers(0, 3))
+        for _ in range(n_shaders):
+            baked = random_texture(rng, 16, 16, int(rng.integers(0, 3))) if rng.random() < 0.4 else None
+            chunk.add_shader(ProgramGen(rng, 3, int(rng.integers(0, 2)), setters).program(), baked)
+        for _ in range(int(rng.integers(0, 3))):      # opacity pass
+            b = soup(int(rng.integers(1, 6))).source(B.PixelSource.StaticTileIndex(int(rng.integers(0, 3))))
+            if rng.random() < 0.7:
+                b.profile_id(int(rng.integers(0, 3)))
+            if n_shaders and rng.random() < 0.4:
+                b.shader(int(rng.integers(0, n_shaders)))
+            chunk.add_batch3d_opacity(b)
+        for _ in range(int(rng.integers(1, 4))):      # opaque
+            b = soup(int(rng.integers(2, 12)))
+            kind = rng.integers(0, 3)
+            b.source(B.PixelSource.Terrain() if kind == 0 else B.PixelSource.StaticTileIndex(int(rng.integers(0, 3))) if kind == 1
+                     else B.PixelSource.Pixel(tuple(int(x) for x in rng.integers(0, 256, 3)) + (255,)))
+            b.repeat_mode(int(rng.integers(0, 4)))
+            if rng.random() < 0.6:
+                b.profile_id(int(rng.integers(0, 3)))
+            if n_shaders and rng.random() < 0.5:
+                b.shader(int(rng.integers(0, n_shaders)))
+            chunk.add_batch3d(b)
+        if rng.random() < 0.5:
+            chunk.terrain_batch3d(soup(int(rng.integers(2, 8)), 1.5).source(B.PixelSource.Terrain()))
+    for _ in range(int(rng.integers(0, 2))):
+        b = soup(int(rng.integers(2, 10))).source(B.PixelSource.Pixel((60, 200, 90, 255)))
+        if rng.random() < 0.5:
+            b.profile_id(int(rng.integers(0, 3)))
+        scene.add_d3_static(b)
+    lights = []
+    for _ in range(int(rng.integers(0, 3))):
+        l = B.Light(B.LIGHT_POINT).with_position(tuple(float(x) for x in rng.normal(0, 2, 3)))
+        l.with_color(tuple(float(x) for x in rng.random(3))).with_intensity(float(rng.uniform(0.5, 2.5)))
+        l.with_start_distance(float(rng.uniform(0.2, 2.0))).with_end_distance(float(rng.uniform(3.0, 8.0)))
+        lights.append(l.compile())
+    scene.lights(lights)
+    cam = api.D3OrbitCamera.new()
+    cam.set_parameter_f32("distance", 4.0)
+    cam.azimuth = float(rng.uniform(0.0, 6.28))
+    cam.elevation = float(rng.uniform(-0.5, 0.9))
+    amb = tuple(float(x) for x in rng.random(4))
+
+    def setup():
+        v, p = cam.matrices(float(width), float(height))
+        return api.Rasterizer.setup(None, v, p).ambient(amb).sample_mode(int(rng.integers(0, 1)) if False else 0).time(0.25)
+
+    return scenes._result(api, scene, assets, setup, width, height, 40, f"fuzz-chunks{seed}")
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_chunk_scene(oracle, product, seed):
+    w, h = 168, 104
+    got = scenes.render(build_chunks(product, seed, w, h))
+    ref = scenes.render(build_chunks(oracle, seed, w, h))
+    diff = np.abs(got.astype(np.int16) - ref.astype(np.int16)).max(axis=2)
+    bad = np.argwhere(diff > TOLERANCE)
+    assert len(bad) <= 3, f"seed {seed}: {len(bad)} pixels off by more than {TOLERANCE}; first {bad[:3].tolist()} gpu={got[tuple(bad[0])]} oracle={ref[tuple(bad[0])]}"

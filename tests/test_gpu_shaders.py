@@ -251,13 +251,14 @@ SOURCES = ["UV", "UV", "UV", "Hitpoint", "Hitpoint", "Color", "Color", "Time", "
 class ProgramGen:
     """stack-safe random NodeOp trees: every block leaves the stack exactly `+delta` deeper than it found it"""
 
-    def __init__(self, rng, n_locals, n_functions):
+    def __init__(self, rng, n_locals, n_functions, setters=None):
         self.rng, self.n_locals, self.n_functions = rng, n_locals, n_functions
         self.first_callable = 0   # functions may only call later ones: no recursion (the reference would overflow its stack)
         self.loadable = n_locals  # locals that are certainly written by now (a stale read would make the program impure)
         # fields this program writes are never read by it (lanes the raster loops do not reset would leak, see rxr_set_shaders)
         writable = ["SetRoughness", "SetMetallic", "SetBump", "SetUV"]
-        self.setters = ["SetColor"] + [w for w in writable if rng.random() < 0.5]
+        # (all programs of one scene must agree on it: pass `setters`)
+        self.setters = list(setters) if setters is not None else ["SetColor"] + [w for w in writable if rng.random() < 0.5]
         self.sources = [x for x in SOURCES if ("Set" + ("UV" if x == "UV" else x)) not in self.setters]
 
     def value(self, depth):
