@@ -13,7 +13,8 @@
 //     and mul + 4 fma per numerator -- so divisions that share a denominator (normalisation, the
 //     perspective divide) also share the reciprocal.
 //   * sqrtf: v_sqrt_f32 followed by two one-ulp correction probes; the rest scales arguments below
-//     2^-96 and passes 0 / inf through.
+//     2^-96 and passes 0 / inf through.  (sqrt_core below goes one step further: a shorter sequence that
+//     is not the compiler's, proven equal by exhaustion over the whole window.)
 //   * log2f / exp2f: v_log_f32 / v_exp_f32 plus scaling for arguments below 2^-126 / -126.
 // Every helper here tests, for the whole wave, that all active lanes' operands are inside a window in
 // which those extra instructions are provably no-ops, runs the short sequence if so and the
@@ -67,15 +68,17 @@ __device__ __forceinline__ float div_chain(float n, float d, float r) {
     return fmaf(e2, r, q1);
 }
 
-// sqrt core: v_sqrt_f32 and the two one-ulp probes of hipcc's expansion, valid for 2^-96 <= x < inf
+// sqrt core, valid for 2^-96 <= x < inf: y = v_rsq_f32(x), s = x*y corrected once with h = y/2 (19 issue cycles; hipcc's
+// own expansion -- v_sqrt_f32 and two one-ulp probes -- costs 36 without its scaling prologue).  This is NOT the
+// compiler's sequence with no-ops removed: it is a different sequence whose result was compared with sqrtf for EVERY
+// float of the window on the device (tools/microbench/sqrt_variants.hip, all 1 879 048 192 operands, 0 differences;
+// rxr_selftest_math re-checks a strided sample of the whole window in every test run).
 __device__ __forceinline__ float sqrt_core(float x) {
-    float s = __builtin_amdgcn_sqrtf(x);
-    float s_dn = __uint_as_float(__float_as_uint(s) - 1u);
-    float s_up = __uint_as_float(__float_as_uint(s) + 1u);
-    float r_dn = fmaf(-s_dn, s, x);
-    float r_up = fmaf(-s_up, s, x);
-    float t = (r_dn <= 0.0f) ? s_dn : s;
-    return (r_up > 0.0f) ? s_up : t;
+    float y = __builtin_amdgcn_rsqf(x);
+    float s = x * y;
+    float h = 0.5f * y;
+    float r = fmaf(-s, s, x);
+    return fmaf(r, h, s);
 }
 
 // ---- public helpers (same value as the plain operator for EVERY input) --------------------------
@@ -171,6 +174,30 @@ __device__ __forceinline__ void normalize3(float x, float y, float z, float &ox,
     oy = y / m;
     oz = z / m;
     mag = m;
+}
+
+// The same for vectors that often have components that are exactly zero (axis-aligned surface normals): a zero
+// numerator would lose its sign in the correction steps of the chain (fma(+0, r, -0) = +0), so each quotient goes
+// through v_div_fixup_f32 -- the compiler's own last instruction, which returns a correctly signed zero for a zero
+// numerator and its first operand otherwise.  Components must be exactly zero or at least 2^-40 in magnitude.
+__device__ __forceinline__ uint32_t zero_or_window_key(float x) { return (__float_as_uint(x) & 0x7FFFFFFFu) - 1u; }  // 0 -> 0xFFFFFFFF
+__device__ __forceinline__ void normalize3_z(float x, float y, float z, float &ox, float &oy, float &oz) {
+    float m2 = (x * x + y * y) + z * z;
+#if RXR_EXACT_FAST
+    uint32_t k = min(min(zero_or_window_key(x), zero_or_window_key(y)), zero_or_window_key(z));
+    if (wave_all(sq_in_window(m2) && k >= 0x2B800000u /* 2^-40 */ - 1u)) {
+        float m = sqrt_core(m2);
+        float r = rcp_refined(m);
+        ox = __builtin_amdgcn_div_fixupf(div_chain(x, m, r), m, x);
+        oy = __builtin_amdgcn_div_fixupf(div_chain(y, m, r), m, y);
+        oz = __builtin_amdgcn_div_fixupf(div_chain(z, m, r), m, z);
+        return;
+    }
+#endif
+    float m = sqrtf(m2);
+    ox = x / m;
+    oy = y / m;
+    oz = z / m;
 }
 
 // exp2f(k * log2f(x)) as the reference's pow32_fast computes it (rasterizer.rs:1895-1901)

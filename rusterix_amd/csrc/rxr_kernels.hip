@@ -25,6 +25,7 @@
 // so the bins need not be sorted and overdraw is never shaded.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 
 #include "rxr_device.h"
@@ -99,6 +100,12 @@ __device__ __forceinline__ f3 norm3_fast(f3 a, float &mag) {
 __device__ __forceinline__ f3 norm3_fast(f3 a) {
     float m;
     return norm3_fast(a, m);
+}
+// the variant for surface normals: components that are exactly zero stay on the short path
+__device__ __forceinline__ f3 norm3_z(f3 a) {
+    f3 o;
+    rxm::normalize3_z(a.x, a.y, a.z, o.x, o.y, o.z);
+    return o;
 }
 
 // Rust f32::clamp keeps NaN
@@ -427,7 +434,7 @@ __device__ __forceinline__ void shade3d_begin(const RasterParams &P, const TriSh
     f3 normal;
     if (B.flags & DB_HAS_NORMALS) {  // :1083-1099
         f3 n0 = mk3(S.n0[0], S.n0[1], S.n0[2]), n1 = mk3(S.n1[0], S.n1[1], S.n1[2]), n2 = mk3(S.n2[0], S.n2[1], S.n2[2]);
-        normal = norm3(add3(add3(scale3(n0, alpha), scale3(n1, beta)), scale3(n2, gamma)));
+        normal = norm3_z(add3(add3(scale3(n0, alpha), scale3(n1, beta)), scale3(n2, gamma)));
         if (dot3(normal, view_dir) < 0.0f) normal = neg3(normal);
     } else {
         normal = mk3(0.0f, 0.0f, 0.0f);
@@ -437,7 +444,7 @@ __device__ __forceinline__ void shade3d_begin(const RasterParams &P, const TriSh
     const float INV_255 = 1.0f / 255.0f;  // lib.rs:52
     f3 base = mk3(srgb_to_linear_fast((float)(texel & 0xFFu) * INV_255), srgb_to_linear_fast((float)((texel >> 8) & 0xFFu) * INV_255),
                   srgb_to_linear_fast((float)((texel >> 16) & 0xFFu) * INV_255));
-    F.opacity = (float)(texel >> 24) / 255.0f;  // :1313
+    F.opacity = rxm::div1_known((float)(texel >> 24), 255.0f, true);  // :1313; byte / 255 is inside the division window
     if (X >= 1 && B.baked_plus1) {  // chunk.shader_textures: the baked texel replaces colour and alpha, no program runs (:1239-1267)
         const DevTexDesc &bd = P.tex[B.baked_plus1 - 1u];
         uint32_t bt = sample_texture(bd, texel_base(P, bd), u, v, P.sample_mode, B.repeat_mode);
@@ -469,7 +476,7 @@ __device__ __forceinline__ void shade3d_begin(const RasterParams &P, const TriSh
         }
     }
 
-    normal = norm3(normal);  // :1320
+    normal = norm3_z(normal);  // :1320
 
     f3 lit = mk3(0.0f, 0.0f, 0.0f);
     float occlusion;
@@ -1139,11 +1146,12 @@ __device__ __forceinline__ void visit(const RasterParams &P, const TriSetup &S, 
                                       uint32_t px, uint32_t py, float fx, float fy, Vis &vis, int surf_profile, const Vis *opf) {
     uint32_t min_x = S.bx & 0xFFFFu, max_x = S.bx >> 16, min_y = S.by & 0xFFFFu, max_y = S.by >> 16;
     bool in = px >= min_x && px < max_x && py >= min_y && py < max_y;
+    if (!in) return;  // small triangles: most waves of the tile have no lane inside the box and skip the edge functions
     // Edges::evaluate (edge.rs:28-36): reject iff a*px + b*py + c < 0 (NaN passes)
     float r0 = S.ea[0] * fx + S.eb[0] * fy + S.ec[0];
     float r1 = S.ea[1] * fx + S.eb[1] * fy + S.ec[1];
     float r2 = S.ea[2] * fx + S.eb[2] * fy + S.ec[2];
-    in = in && !(r0 < 0.0f) && !(r1 < 0.0f) && !(r2 < 0.0f);
+    in = !(r0 < 0.0f) && !(r1 < 0.0f) && !(r2 < 0.0f);
     if (!in) return;
     const bool is_opacity = (S.bflags & DB_OPACITY_LIST) != 0;
     if (is_opacity != OPACITY) return;
@@ -1218,6 +1226,170 @@ struct StageShade {
     TriShade shade[RXR_STAGE_TRIS];
 };
 
+// ---- row-parallel visibility (kernel k_raster_rows: binned scenes, feature level 0) -------------------------
+// In the walk above every wave tests every candidate against its 64 pixels; with many small triangles (a mesh, the
+// 1 M-triangle box grid: ~20 candidates per tile, each covering ~20 of 256 pixels) more than nine lanes in ten do
+// nothing useful.  Row mode turns the loop inside out for such rounds: the work items are the ROWS of the candidates'
+// pixel boxes clipped to the tile; item i belongs to the thread i (mod 256), which walks the row's pixels, evaluates
+// exactly the expressions of visit() and merges the fragment into a per-tile z-buffer in LDS with one 64-bit atomic
+// minimum on the key (z, submission index).  The reference's rule -- the fragment with the smallest z wins, ties go to
+// the smaller index (see the file header) -- IS the minimum of that key, so the order in which fragments arrive does
+// not matter.  After the last round every pixel's lane reads its key back and re-derives the barycentrics of the
+// winner from its record (same expressions, same floats).
+struct RowLds {
+    unsigned long long key[RXR_TILE_THREADS];
+    uint32_t row_start[RXR_STAGE_TRIS + 1];  // exclusive prefix of the staged candidates' row counts
+    uint32_t red[8];                         // per-wave totals: [0..3] rows | area << 12, [4..7] candidates with rows
+    uint32_t raw[RXR_STAGE_TRIS];            // scan_lists_rows: triangle id of every list entry of the round (= of every staged record)
+    uint32_t slot[RXR_STAGE_TRIS];           // scan_lists_rows: staged record of candidate k
+};
+// order-preserving map of non-NaN floats to unsigned integers
+__device__ __forceinline__ uint32_t z_order_bits(float z) {
+    const uint32_t b = __float_as_uint(z);
+    return b ^ ((b & 0x80000000u) ? 0xFFFFFFFFu : 0x80000000u);
+}
+// z_buffer starts at 1.0 and only `z < 1.0` is ever written (:1060): no key at or above this one is a hit
+#define RXR_ZKEY_INIT (0xBF800000ull << 32)
+// row mode when the candidates' clipped boxes cover on average less than this many of the tile's 256 pixels
+#ifndef RXR_ROWS_INLINE
+#define RXR_ROWS_INLINE __forceinline__
+#endif
+#ifndef RXR_RESOLVE_INLINE
+#define RXR_RESOLVE_INLINE __forceinline__
+#endif
+#ifndef RXR_ROW_MODE_MAX_AREA
+#define RXR_ROW_MODE_MAX_AREA 128
+#endif
+
+// One round of row mode over the `n` records staged in st (ids in st.ids).  Returns false (uniformly) without having
+// done anything when the round is better served by the pixel-parallel walk.
+template <bool INDIRECT>  // candidate k's record is st.tri[rl.slot[k] * 6] (scan_lists_rows) instead of st.tri[k * 6]
+__device__ RXR_ROWS_INLINE bool rows_round(const RasterParams &P, Stage &st, RowLds &rl, uint32_t n, uint32_t tile_x0, uint32_t tile_y0px) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    // clipped pixel box of staged candidate `tid`
+    uint32_t rows = 0, area = 0;
+    bool alpha_test = false;
+    if (tid < n) {
+        const TriSetup &R = *reinterpret_cast<const TriSetup *>(&st.tri[(INDIRECT ? rl.slot[tid] : tid) * 6u]);
+        alpha_test = (R.bflags & DB_ALPHA_TEST) != 0;
+        if (!(R.bflags & DB_OPACITY_LIST)) {
+            const uint32_t x0 = max(R.bx & 0xFFFFu, tile_x0), x1 = min(R.bx >> 16, tile_x0 + RXR_TILE_W);
+            const uint32_t y0 = max(R.by & 0xFFFFu, tile_y0px), y1 = min(R.by >> 16, tile_y0px + RXR_TILE_H);
+            if (x0 < x1 && y0 < y1) {
+                rows = y1 - y0;
+                area = rows * (x1 - x0);
+            }
+        }
+    }
+    // inclusive scan of (rows | area << 12) over the workgroup: rows total < 2^12, area total <= 2^15
+    const uint32_t packed = rows | (area << 12);
+    uint32_t inc = packed;
+#pragma unroll
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
+    }
+    const unsigned long long has = __ballot(rows != 0u);
+    // cut-out candidates need a texel per fragment (:1408): such rounds are left to the walk, which keeps the sampling code
+    // (and its registers) out of the row loop
+    const unsigned long long cutout = __ballot(rows != 0u && alpha_test);
+    if (lane == 63u) {
+        rl.red[wave] = inc;
+        rl.red[4u + wave] = cutout ? 0x10000u : (uint32_t)__popcll(has);
+    }
+    __syncthreads();
+    uint32_t before = 0, total = 0, cands = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < RXR_TILE_THREADS / 64; ++w) {
+        const uint32_t v = rl.red[w];
+        if (w < wave) before += v;
+        total += v;
+        cands += rl.red[4u + w];
+    }
+    const uint32_t rows_total = total & 0xFFFu, area_total = total >> 12;
+    if (cands == 0u || cands >= 0x10000u || area_total > cands * (uint32_t)RXR_ROW_MODE_MAX_AREA) {
+        __syncthreads();  // rl.red is rewritten by the next round
+        return false;
+    }
+    if (tid < n) rl.row_start[tid] = ((before + inc) & 0xFFFu) - rows;
+    if (tid == 0) rl.row_start[n] = rows_total;
+    __syncthreads();
+
+    for (uint32_t item = tid; item < rows_total; item += RXR_TILE_THREADS) {
+        // candidate of this row: the largest k with row_start[k] <= item (candidates without rows share their successor's start)
+        uint32_t lo = 0, hi = n;
+        while (hi - lo > 1u) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (rl.row_start[mid] <= item) lo = mid;
+            else hi = mid;
+        }
+        const TriSetup &S = *reinterpret_cast<const TriSetup *>(&st.tri[(INDIRECT ? rl.slot[lo] : lo) * 6u]);
+        const uint32_t t = st.ids[lo];
+        const uint32_t x0 = max(S.bx & 0xFFFFu, tile_x0), x1 = min(S.bx >> 16, tile_x0 + RXR_TILE_W);
+        const uint32_t y = max(S.by & 0xFFFFu, tile_y0px) + (item - rl.row_start[lo]);
+        const float fy = (float)y + 0.5f;
+        const float ea0 = S.ea[0], ea1 = S.ea[1], ea2 = S.ea[2], ec0 = S.ec[0], ec1 = S.ec[1], ec2 = S.ec[2];
+        const float by0 = S.eb[0] * fy, by1 = S.eb[1] * fy, by2 = S.eb[2] * fy;
+        const float v0x = S.v0x, v0y = S.v0y, v1x = S.v1x, v1y = S.v1y, v2x = S.v2x, v2y = S.v2y;
+        const float area_t = S.area, iz0 = S.iz0, iz1 = S.iz1, iz2 = S.iz2;
+        unsigned long long *const zrow = &rl.key[(y - tile_y0px) * RXR_TILE_W];
+        for (uint32_t x = x0; x < x1; ++x) {
+            const float fx = (float)x + 0.5f;
+            // Edges::evaluate (edge.rs:28-36)
+            const float r0 = ea0 * fx + by0 + ec0;
+            const float r1 = ea1 * fx + by1 + ec1;
+            const float r2 = ea2 * fx + by2 + ec2;
+            if ((r0 < 0.0f) || (r1 < 0.0f) || (r2 < 0.0f)) continue;
+            // barycentric_weights_3d and depth, as visit()
+            const float pcx = v2x - fx, pcy = v2y - fy;
+            const float pbx = v1x - fx, pby = v1y - fy;
+            const float apx = fx - v0x, apy = fy - v0y;
+            const float acx = v2x - v0x, acy = v2y - v0y;
+            const float alpha = (pcx * pby - pcy * pbx) / area_t;
+            const float beta = (acx * apy - acy * apx) / area_t;
+            const float gamma = 1.0f - alpha - beta;
+            const float one_over_z = iz0 * alpha + iz1 * beta + iz2 * gamma;
+            const float z = 1.0f / one_over_z;
+            if (!(z < 1.0f)) continue;  // never closer than the cleared buffer; also NaN
+            const unsigned long long key = ((unsigned long long)z_order_bits(z + 0.0f) << 32) | t;  // -0 -> +0: they compare equal
+            unsigned long long *const cell = &zrow[x - tile_x0];
+            if (key >= *(volatile unsigned long long *)cell) continue;  // (cells only ever decrease: a stale value is merely conservative)
+            atomicMin(cell, key);
+        }
+    }
+    __syncthreads();  // the stage and rl are reused by the next round
+    return true;
+}
+
+// after the last round: this lane's pixel takes the z-buffer's winner if it beats what the pixel-parallel rounds found
+// (the winner's shading record is fetched together with its set-up record: one memory latency instead of two)
+__device__ RXR_RESOLVE_INLINE void rows_resolve(const RasterParams &P, const RowLds &rl, uint32_t lx, uint32_t ly, float fx, float fy, Vis &vis,
+                                                TriShade &shade, int &shade_of) {
+    const unsigned long long key = rl.key[ly * RXR_TILE_W + lx];
+    if (key >= RXR_ZKEY_INIT) return;
+    const uint32_t t = (uint32_t)key;
+    const TriSetup S = P.tri_setup[t];
+    shade = P.tri_shade[t];
+    shade_of = (int)t;
+    const float pcx = S.v2x - fx, pcy = S.v2y - fy;
+    const float pbx = S.v1x - fx, pby = S.v1y - fy;
+    const float apx = fx - S.v0x, apy = fy - S.v0y;
+    const float acx = S.v2x - S.v0x, acy = S.v2y - S.v0y;
+    const float alpha = (pcx * pby - pcy * pbx) / S.area;
+    const float beta = (acx * apy - acy * apx) / S.area;
+    const float gamma = 1.0f - alpha - beta;
+    const float one_over_z = S.iz0 * alpha + S.iz1 * beta + S.iz2 * gamma;
+    const float z = 1.0f / one_over_z;
+    const bool closer = z < vis.zmin || (z == vis.zmin && vis.best >= 0 && (int)t < vis.best);
+    if (!closer) return;
+    vis.zmin = z;
+    vis.best = (int)t;
+    vis.alpha = alpha;
+    vis.beta = beta;
+    vis.slot = 0;
+    vis.batch = S.batch;
+}
+
 // Visibility pass over the tile's candidate triangles = [large-triangle list, filtered against the
 // tile rectangle] ++ [this tile's bin list].  Per round of RXR_STAGE_TRIS list entries:
 //   1. the first RXR_STAGE_TRIS threads fetch one entry each (large entries also fetch their pixel
@@ -1229,7 +1401,7 @@ struct StageShade {
 template <bool OPACITY, int X>
 __device__ __forceinline__ void scan_lists(const RasterParams &P, Stage &st, uint32_t b0, uint32_t b1, uint32_t tile_x0,
                                            uint32_t tile_y0px, uint32_t px, uint32_t py, float fx, float fy, Vis &vis,
-                                           int surf_profile, const Vis *opf) {
+                                           int surf_profile, const Vis *opf, RowLds *rl = nullptr) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t n_large = min(P.counters[CNT_LARGE], P.n_tris3d);
     const uint32_t total = n_large + (b1 - b0);
@@ -1279,11 +1451,79 @@ __device__ __forceinline__ void scan_lists(const RasterParams &P, Stage &st, uin
             st.tri[f] = g4[(size_t)st.ids[k] * 6u + j];
         }
         __syncthreads();
-        // 4. walk
+        // 4. walk (or, for rounds of small triangles, the rows of their boxes: rows_round)
+        if constexpr (!OPACITY && X == 0) {
+            if (rl != nullptr && rows_round<false>(P, st, *rl, n, tile_x0, tile_y0px)) continue;
+        }
         for (uint32_t k = 0; k < n; ++k) {
             const TriSetup &S = *reinterpret_cast<const TriSetup *>(&st.tri[k * 6u]);
             const uint32_t t = st.ids[k];
             visit<OPACITY, X>(P, S, &P.tri_shade[t], t, k, px, py, fx, fy, vis, surf_profile, opf);
+        }
+        __syncthreads();  // the stage is reused by the next round
+    }
+}
+
+// scan_lists for k_raster_rows (opaque pass, feature level 0).  Binned scenes of small triangles are bound by the chain of
+// dependent memory latencies per tile, not by arithmetic, so this variant stages FIRST and tests afterwards: the records
+// of all list entries of the round go to LDS as soon as their ids are known, the tile-level reject runs on the LDS copies
+// and compacts slot numbers instead of moving records -- one global round trip fewer than scan_lists (which reads the
+// edges from HBM for the reject and the records again for staging).  The round is then handed to rows_round or walked.
+template <int X>
+__device__ __forceinline__ void scan_lists_rows(const RasterParams &P, Stage &st, RowLds &rl, bool row_mode, uint32_t b0, uint32_t b1,
+                                                uint32_t tile_x0, uint32_t tile_y0px, uint32_t px, uint32_t py, float fx, float fy, Vis &vis,
+                                                int surf_profile, const Vis *opf) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t n_large = min(P.counters[CNT_LARGE], P.n_tris3d);
+    const uint32_t total = n_large + (b1 - b0);
+    const float4 *g4 = reinterpret_cast<const float4 *>(P.tri_setup);
+    for (uint32_t base = 0; base < total; base += RXR_STAGE_TRIS) {
+        const uint32_t m = min(total - base, (uint32_t)RXR_STAGE_TRIS);
+        // 1. ids of the round's list entries
+        if (tid < m) {
+            const uint32_t e = base + tid;
+            rl.raw[tid] = e < n_large ? P.large_list[e] : P.bin_list[b0 + (e - n_large)];
+        }
+        __syncthreads();
+        // 2. their records (ids outside this frame's records are never followed: clamped here, dropped in step 3)
+        for (uint32_t f = tid; f < m * 6u; f += RXR_TILE_THREADS) {
+            const uint32_t k = f / 6u, j = f - k * 6u;
+            st.tri[f] = g4[(size_t)min(rl.raw[k], P.n_tris3d - 1u) * 6u + j];
+        }
+        __syncthreads();
+        // 3. pixel box and tile-level edge reject on the LDS copies; survivors' slots are ballot-compacted
+        bool keep = false;
+        uint32_t id = 0;
+        if (tid < m) {
+            id = rl.raw[tid];
+            const TriSetup &R = *reinterpret_cast<const TriSetup *>(&st.tri[tid * 6u]);
+            const uint32_t min_x = R.bx & 0xFFFFu, max_x = R.bx >> 16, min_y = R.by & 0xFFFFu, max_y = R.by >> 16;
+            keep = id < P.n_tris3d && !(min_x >= tile_x0 + RXR_TILE_W || max_x <= tile_x0 || min_y >= tile_y0px + RXR_TILE_H || max_y <= tile_y0px);
+            if (keep && tile_outside_edges(R.ea, R.eb, R.ec, tile_x0, tile_y0px)) keep = false;
+        }
+        const unsigned long long mk = __ballot(keep);
+        const uint32_t before = (uint32_t)__popcll(mk & ((1ull << lane) - 1ull));
+        if (lane == 0) st.wave_cnt[wave] = (uint32_t)__popcll(mk);
+        __syncthreads();
+        uint32_t off = 0, n = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < RXR_TILE_THREADS / 64; ++w) {
+            const uint32_t c = st.wave_cnt[w];
+            if (w < wave) off += c;
+            n += c;
+        }
+        if (keep) {
+            rl.slot[off + before] = tid;
+            st.ids[off + before] = id;
+        }
+        __syncthreads();
+        // 4. the rows of the candidates' boxes, or the walk
+        if (row_mode && rows_round<true>(P, st, rl, n, tile_x0, tile_y0px)) continue;
+        for (uint32_t k = 0; k < n; ++k) {
+            const uint32_t sl = rl.slot[k];
+            const TriSetup &S = *reinterpret_cast<const TriSetup *>(&st.tri[sl * 6u]);
+            const uint32_t t = st.ids[k];
+            visit<false, X>(P, S, &P.tri_shade[t], t, sl, px, py, fx, fy, vis, surf_profile, opf);
         }
         __syncthreads();  // the stage is reused by the next round
     }
@@ -1456,11 +1696,19 @@ struct ShadeStore {
 template <>
 struct ShadeStore<false> {};
 
-template <bool FUSED, int X>
+template <bool F>
+struct RowStore {
+    RowLds r;
+};
+template <>
+struct RowStore<false> {};
+
+template <bool FUSED, int X, bool ROWS = false>
 __device__ __forceinline__ void raster_tile(const RasterParams &P) {
     __shared__ Stage stage;
     __shared__ uint32_t s_bin[4];
     __shared__ ShadeStore<FUSED> shade_store;
+    __shared__ RowStore<ROWS> row_store;
     const uint32_t bin = blockIdx.x;
     const uint32_t tx = bin % P.tiles_x, ty = bin / P.tiles_x;
     const uint32_t tid = threadIdx.x;
@@ -1493,7 +1741,15 @@ __device__ __forceinline__ void raster_tile(const RasterParams &P) {
     if (P.flags & RXR_FLAG_D3_ACTIVE) {
         constexpr bool fused = FUSED;
         uint32_t b0 = 0, b1 = 0;
-        if (!fused && P.fused_small == 0u) {  // (s_bin[0..1]: this tile's 3D list)
+        uint32_t my_bin_count = 0;
+        if constexpr (ROWS) {
+            // every thread reads the (uniform) list bounds itself: no LDS round trip and no barrier in front of the first
+            // list fetch; the bin count is handed back zeroed after the scan, when every thread has long read it
+            my_bin_count = P.bin_count[bin];
+            const uint32_t start = P.chunk_base[bin / RXR_SCAN_CHUNK] + P.bin_offset[bin];
+            b0 = min(start, P.list_capacity);
+            b1 = min(start + my_bin_count, P.list_capacity);
+        } else if (!fused && P.fused_small == 0u) {  // (s_bin[0..1]: this tile's 3D list)
             // this tile's bin list; the bin count is handed back zeroed for the next launch
             if (tid == 0) {
                 uint32_t cnt = P.bin_count[bin];
@@ -1527,10 +1783,19 @@ __device__ __forceinline__ void raster_tile(const RasterParams &P) {
         }
         Vis vis;
         vis.zmin = 1.0f; vis.best = -1; vis.alpha = 0.0f; vis.beta = 0.0f; vis.slot = 0; vis.batch = 0;
+        TriShade HS;     // shading record of the winner
+        int hs_of = -1;  // triangle whose record HS already holds (row mode fetches it early)
         PHASE_MARK(0);
         if constexpr (FUSED) scan_fused<false, X>(P, stage, shade_store.s, tile_x0, tile_y0px, px, py, fx, fy, vis, surf_profile, &op);
         else if (P.fused_small == 2u) scan_implicit<false, X>(P, stage, tile_x0, tile_y0px, px, py, fx, fy, vis, surf_profile, &op);
-        else scan_lists<false, X>(P, stage, b0, b1, tile_x0, tile_y0px, px, py, fx, fy, vis, surf_profile, &op);
+        else if constexpr (ROWS) {
+            // (the per-pixel surface_id of the opacity pass lives in the owning lane's registers: frames with opacity batches walk)
+            const bool row_mode = !P.has_opacity;
+            if (row_mode) row_store.r.key[ly * RXR_TILE_W + lx] = RXR_ZKEY_INIT;  // own cell; published by the barriers of the first staging round
+            scan_lists_rows<X>(P, stage, row_store.r, row_mode, b0, b1, tile_x0, tile_y0px, px, py, fx, fy, vis, surf_profile, &op);
+            if (tid == 0 && my_bin_count) P.bin_count[bin] = 0u;  // (a non-empty list went through the barriers of a round)
+            if (row_mode) rows_resolve(P, row_store.r, lx, ly, fx, fy, vis, HS, hs_of);  // (the last round ended with a barrier)
+        } else scan_lists<false, X>(P, stage, b0, b1, tile_x0, tile_y0px, px, py, fx, fy, vis, surf_profile, &op);
 
         PHASE_MARK(1);
         // resolve (rasterizer.rs:409-497): hit -> shaded colour; miss -> [0,0,0,255]
@@ -1541,9 +1806,8 @@ __device__ __forceinline__ void raster_tile(const RasterParams &P) {
         F.rough = 0.5f;
         F.metal = 0.0f;
         if (hit) {
-            TriShade HS;
             if constexpr (FUSED) HS = shade_store.s.shade[vis.slot];
-            else HS = P.tri_shade[vis.best];
+            else if (!ROWS || hs_of != vis.best) HS = P.tri_shade[vis.best];
             shade3d_begin<X>(P, HS, vis.batch, vis.alpha, vis.beta, vis.zmin, fx, fy, F);
         }
         PHASE_MARK(2);
@@ -1688,6 +1952,11 @@ __device__ __forceinline__ void raster_tile(const RasterParams &P) {
 // two instantiations so that each path gets its own register allocation
 extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_RASTER_WAVES_PER_SIMD) k_raster(RasterParams P) { raster_tile<false, 0>(P); }
 extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_RASTER_WAVES_PER_SIMD) k_raster_fused(RasterParams P) { raster_tile<true, 0>(P); }
+// binned scenes (more than RXR_STAGE_TRIS triangles): the walk may switch to row mode per round (rows_round)
+#ifndef RXR_ROWS_WAVES_PER_SIMD
+#define RXR_ROWS_WAVES_PER_SIMD 6  // C5: unbounded (87 VGPRs, 5 waves) 797 us, 6: 718, 7: 727 (and the teapot loses 15 %)
+#endif
+extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_ROWS_WAVES_PER_SIMD) k_raster_rows(RasterParams P) { raster_tile<false, 0, true>(P); }
 // feature levels (template parameter X) so that the common kernels above carry none of the rarer paths:
 //   1  k_raster_chunk: chunk textures -- terrain texels sampled by world position, baked shader textures, and the
 //      full-fragment alpha test they need
@@ -1744,8 +2013,10 @@ extern "C" void rxr_launch_fill(const RasterParams *P, hipStream_t s) {
 extern "C" void rxr_launch_raster(const RasterParams *P, hipStream_t s) {
     uint32_t tiles = P->tiles_x * P->tiles_y;
     if (tiles == 0) return;
+    static const bool no_rows = getenv("RXR_NO_ROWS") != nullptr;  // tuning knob: binned scenes walk every candidate per pixel (k_raster)
     if (P->kernel_level >= 2u) hipLaunchKernelGGL(k_raster_vm, dim3(tiles), dim3(RXR_TILE_THREADS), 0, s, *P);
     else if (P->kernel_level == 1u) hipLaunchKernelGGL(k_raster_chunk, dim3(tiles), dim3(RXR_TILE_THREADS), 0, s, *P);
     else if (P->fused_small == 1u) hipLaunchKernelGGL(k_raster_fused, dim3(tiles), dim3(RXR_TILE_THREADS), 0, s, *P);
+    else if (P->fused_small == 0u && (P->flags & RXR_FLAG_D3_ACTIVE) && !no_rows) hipLaunchKernelGGL(k_raster_rows, dim3(tiles), dim3(RXR_TILE_THREADS), 0, s, *P);
     else hipLaunchKernelGGL(k_raster, dim3(tiles), dim3(RXR_TILE_THREADS), 0, s, *P);
 }

@@ -64,7 +64,7 @@ __global__ void __launch_bounds__(256) k_selftest_math(uint64_t seed, uint32_t i
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t wave = gid >> 6;
     Rng g{mix64(seed ^ ((uint64_t)gid << 20))};
-    unsigned long long bad[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long bad[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (uint32_t it = 0; it < iters; ++it) {
         const uint32_t mode = (wave + it) & 3u;
         // ---- divisions sharing a denominator
@@ -120,8 +120,35 @@ __global__ void __launch_bounds__(256) k_selftest_math(uint64_t seed, uint32_t i
             float byte = (float)(g.next() & 255u);
             if (!same(rxm::div1_known(px, w, true), px / w) || !same(rxm::div1_known(byte, 255.0f, true), byte / 255.0f)) bad[7]++;
         }
+        // ---- normalisation of vectors with exactly-zero components (axis-aligned normals); every pattern of zeros,
+        //      both signs of zero, and (modes 2, 3) tiny non-zero components that must take the compiler's path
+        {
+            float x = gen(g, mode, -40, 39), y = gen(g, mode, -40, 39), z = gen(g, mode, -40, 39);
+            const uint32_t zr = g.next();
+            if (zr & 1u) x = __uint_as_float(zr & 0x80000000u);
+            if (zr & 2u) y = __uint_as_float((zr << 1) & 0x80000000u);
+            if (zr & 4u) z = __uint_as_float((zr << 2) & 0x80000000u);
+            if (mode == 0 && (zr & 8u)) {  // unit-length-ish normals
+                x = (float)((int)(g.next() & 2047u) - 1024) / 1024.0f;
+                y = (zr & 16u) ? 0.0f : (float)((int)(g.next() & 2047u) - 1024) / 1024.0f;
+                z = (zr & 32u) ? -0.0f : (float)((int)(g.next() & 2047u) - 1024) / 1024.0f;
+            }
+            float ox, oy, oz;
+            rxm::normalize3_z(x, y, z, ox, oy, oz);
+            float m = sqrtf((x * x + y * y) + z * z);
+            if (!same(ox, x / m) || !same(oy, y / m) || !same(oz, z / m)) bad[8]++;
+        }
+        // ---- square root: strided sweep of the whole window [2^-96, inf) -- the short sequence is not the compiler's
+        //      (tools/microbench/sqrt_variants.hip checks every operand; this re-checks a sample in every run)
+        {
+            const uint64_t span = 0x7f800000ull - 0x0f800000ull;
+            const uint64_t idx = (uint64_t)gid * iters + it;
+            const uint32_t bits = 0x0f800000u + (uint32_t)((idx * 2654435761ull + (seed & 0xFFFFFu)) % span);
+            const float x = __uint_as_float(bits);
+            if (!same(rxm::sqrt_exact(x), sqrtf(x))) bad[9]++;
+        }
     }
-    for (int k = 0; k < 8; ++k)
+    for (int k = 0; k < 10; ++k)
         if (bad[k]) atomicAdd(&mismatch[k], bad[k]);
 }
 

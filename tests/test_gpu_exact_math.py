@@ -11,7 +11,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-KINDS = ["div2", "div3", "div3_self", "normalize3", "sqrt", "pow", "div1", "static"]
+KINDS = ["div2", "div3", "div3_self", "normalize3", "sqrt", "pow", "div1", "static", "normalize3_zeros", "sqrt_sweep"]
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3])
@@ -22,7 +22,7 @@ def test_short_sequences_are_bit_identical(product, seed):
     product.lib.rxh_context.restype = C.c_void_p
     ctx = product.lib.rxh_context()
     assert ctx
-    out = (C.c_uint64 * 8)()
+    out = (C.c_uint64 * len(KINDS))()
     n = 1 << 36  # tuples per kind and seed (about half a second on an MI355X)
     rc = lib.rxr_selftest_math(ctx, n, seed, out)
     assert rc == 0
