@@ -1271,7 +1271,7 @@ __device__ RXR_ROWS_INLINE bool rows_round(const RasterParams &P, Stage &st, Row
     bool alpha_test = false;
     if (tid < n) {
         const TriSetup &R = *reinterpret_cast<const TriSetup *>(&st.tri[(INDIRECT ? rl.slot[tid] : tid) * 6u]);
-        alpha_test = (R.bflags & DB_ALPHA_TEST) != 0;
+        alpha_test = (R.bflags & (DB_ALPHA_TEST | DB_FULL_ALPHA)) != 0;
         if (!(R.bflags & DB_OPACITY_LIST)) {
             const uint32_t x0 = max(R.bx & 0xFFFFu, tile_x0), x1 = min(R.bx >> 16, tile_x0 + RXR_TILE_W);
             const uint32_t y0 = max(R.by & 0xFFFFu, tile_y0px), y1 = min(R.by >> 16, tile_y0px + RXR_TILE_H);
@@ -1742,7 +1742,8 @@ __device__ __forceinline__ void raster_tile(const RasterParams &P) {
         constexpr bool fused = FUSED;
         uint32_t b0 = 0, b1 = 0;
         uint32_t my_bin_count = 0;
-        if constexpr (ROWS) {
+        const bool rows_binned = ROWS && P.fused_small == 0u;  // (k_raster_chunk / k_raster_vm also serve small scenes)
+        if (rows_binned) {
             // every thread reads the (uniform) list bounds itself: no LDS round trip and no barrier in front of the first
             // list fetch; the bin count is handed back zeroed after the scan, when every thread has long read it
             my_bin_count = P.bin_count[bin];
@@ -1788,13 +1789,15 @@ __device__ __forceinline__ void raster_tile(const RasterParams &P) {
         PHASE_MARK(0);
         if constexpr (FUSED) scan_fused<false, X>(P, stage, shade_store.s, tile_x0, tile_y0px, px, py, fx, fy, vis, surf_profile, &op);
         else if (P.fused_small == 2u) scan_implicit<false, X>(P, stage, tile_x0, tile_y0px, px, py, fx, fy, vis, surf_profile, &op);
-        else if constexpr (ROWS) {
+        else if (rows_binned) {
             // (the per-pixel surface_id of the opacity pass lives in the owning lane's registers: frames with opacity batches walk)
-            const bool row_mode = !P.has_opacity;
-            if (row_mode) row_store.r.key[ly * RXR_TILE_W + lx] = RXR_ZKEY_INIT;  // own cell; published by the barriers of the first staging round
-            scan_lists_rows<X>(P, stage, row_store.r, row_mode, b0, b1, tile_x0, tile_y0px, px, py, fx, fy, vis, surf_profile, &op);
-            if (tid == 0 && my_bin_count) P.bin_count[bin] = 0u;  // (a non-empty list went through the barriers of a round)
-            if (row_mode) rows_resolve(P, row_store.r, lx, ly, fx, fy, vis, HS, hs_of);  // (the last round ended with a barrier)
+            if constexpr (ROWS) {
+                const bool row_mode = !P.has_opacity;
+                if (row_mode) row_store.r.key[ly * RXR_TILE_W + lx] = RXR_ZKEY_INIT;  // own cell; published by the barriers of the first staging round
+                scan_lists_rows<X>(P, stage, row_store.r, row_mode, b0, b1, tile_x0, tile_y0px, px, py, fx, fy, vis, surf_profile, &op);
+                if (tid == 0 && my_bin_count) P.bin_count[bin] = 0u;  // (a non-empty list went through the barriers of a round)
+                if (row_mode) rows_resolve(P, row_store.r, lx, ly, fx, fy, vis, HS, hs_of);  // (the last round ended with a barrier)
+            }
         } else scan_lists<false, X>(P, stage, b0, b1, tile_x0, tile_y0px, px, py, fx, fy, vis, surf_profile, &op);
 
         PHASE_MARK(1);
@@ -1967,8 +1970,8 @@ extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_ROWS_WAVES_PE
 __device__ __forceinline__ const RasterParams &kernarg_params() {
     return *(const RasterParams *)__builtin_amdgcn_kernarg_segment_ptr();
 }
-extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS) k_raster_chunk(RasterParams) { raster_tile<false, 1>(kernarg_params()); }
-extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_VM_WAVES_PER_SIMD) k_raster_vm(RasterParams) { raster_tile<false, 2>(kernarg_params()); }
+extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS) k_raster_chunk(RasterParams) { raster_tile<false, 1, true>(kernarg_params()); }
+extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_VM_WAVES_PER_SIMD) k_raster_vm(RasterParams) { raster_tile<false, 2, true>(kernarg_params()); }
 
 #if RXR_PHASE_TIMING
 extern "C" int rxr_debug_phase_read(unsigned long long *out16, int reset) {
