@@ -1,0 +1,146 @@
+"""Meshes of many small triangles: the binned pipeline and its row-parallel visibility (k_raster_rows, rows_round in
+rusterix_amd/csrc/rxr_kernels.hip) against the CPU oracle, bit for bit.
+
+Row mode replaces the per-pixel walk over a tile's candidates by an atomic minimum on the key (z, submission index) in a
+per-tile LDS z-buffer.  What has to hold (reference src/rasterizer.rs:1060, 1408 and the order of its triangle loop):
+the fragment with the smallest z wins, EXACT ties go to the triangle submitted first, cut-out texels never win, and the
+result does not depend on how rounds are split between row mode and the walk (large triangles, cut-out candidates and
+frames with opacity batches walk).  The scenes have no lights, so every colour path is exact and frames must be equal."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from rusterix_amd import binding as B
+from rusterix_amd import scenes
+from tests.test_gpu_fuzz import random_texture
+
+pytestmark = pytest.mark.gpu
+
+
+def small_triangles(rng, nt, size, spread, depth=1.0):
+    centre = rng.normal(0.0, 1.0, size=(nt, 1, 3)) * np.array([spread, spread * 0.6, depth])
+    verts = (centre + rng.normal(0.0, size, size=(nt, 3, 3))).reshape(-1, 3).astype(np.float32)
+    v4 = np.concatenate([verts, np.ones((len(verts), 1), np.float32)], axis=1)
+    idx = np.arange(nt * 3, dtype=np.uint32).reshape(nt, 3)
+    uv = (rng.random((nt * 3, 2)) * 2.0 - 0.5).astype(np.float32)
+    return v4, idx, uv
+
+
+def build(api, seed, width, height, variant):
+    """variant: 'plain' opaque meshes | 'ties' every mesh submitted twice with different colours | 'cutout' textures with
+    holes among the meshes | 'mixed' all of it plus screen-filling triangles (large list, walked rounds) |
+    'opacity' an opacity-pass pane in front (the whole frame walks)"""
+    rng = np.random.default_rng([0x52585231, 4242, seed])
+    textures = [B.Tile([random_texture(rng, int(rng.integers(4, 33)), int(rng.integers(4, 33)), mode)]) for mode in (0, 2, 1, 0)]
+    assets = api.Assets.default().textures(textures)
+    scene = api.Scene.empty()
+    n_meshes = int(rng.integers(2, 5))
+    for m in range(n_meshes):
+        nt = int(rng.integers(150, 700))
+        v4, idx, uv = small_triangles(rng, nt, float(rng.uniform(0.03, 0.12)), float(rng.uniform(0.8, 1.6)))
+        copies = 2 if variant in ("ties", "mixed") and m % 2 == 0 else 1
+        for c in range(copies):
+            b = api.Batch3D.new(v4.copy(), idx.copy(), uv.copy()).with_computed_normals().cull_mode(int(rng.integers(0, 3)) if c == 0 else 0)
+            if c == 1:
+                b.cull_mode(0)
+            kind = int(rng.integers(0, 3))
+            if variant in ("cutout", "mixed") and m % 2 == 1:
+                b.source(B.PixelSource.StaticTileIndex(1 + (m // 2) % 2)).repeat_mode(int(rng.integers(0, 4)))   # textures with alpha != 255
+            elif kind == 0:
+                b.source(B.PixelSource.StaticTileIndex(0 if c == 0 else 3)).repeat_mode(B.REPEAT_REPEAT_XY)
+            else:
+                b.source(B.PixelSource.Pixel(tuple(int(x) for x in rng.integers(0, 256, 3)) + (255,)))
+            b.ambient_color(tuple(float(x) for x in rng.random(3)))
+            scene.add_d3_static(b)
+    if variant == "mixed":
+        # two screen-filling triangles behind and one across the meshes
+        big = np.array([[-6, -4, -2.0, 1], [6, -4, -2.0, 1], [0, 6, -2.0, 1], [-6, 3, 1.5, 1], [6, 3, -1.5, 1], [0, -5, 0.2, 1]], np.float32)
+        b = api.Batch3D.new(big, np.array([[0, 1, 2], [3, 4, 5]], np.uint32), rng.random((6, 2)).astype(np.float32)).with_computed_normals().cull_mode(0)
+        b.source(B.PixelSource.StaticTileIndex(2)).ambient_color((0.4, 0.5, 0.6))
+        scene.add_d3_static(b)
+    if variant == "opacity":
+        chunk = scene.add_chunk()
+        chunk.terrain(None, origin=(0, 0), size=4)
+        pane = np.array([[-1.5, -1, 1.2, 1], [1.5, -1, 1.2, 1], [1.5, 1, 1.2, 1], [-1.5, 1, 1.2, 1]], np.float32)
+        b = api.Batch3D.new(pane, np.array([[0, 1, 2], [0, 2, 3]], np.uint32), np.array([[0, 0], [1, 0], [1, 1], [0, 1]], np.float32)).with_computed_normals().cull_mode(0)
+        b.source(B.PixelSource.StaticTileIndex(2))
+        chunk.add_batch3d_opacity(b)
+    cam = api.D3OrbitCamera.new()
+    cam.set_parameter_f32("distance", 3.0)
+    cam.azimuth = float(np.float32(np.pi / 2))
+    cam.elevation = float(rng.uniform(-0.2, 0.4))
+    sample = int(rng.integers(0, 2))
+    amb = tuple(float(x) for x in rng.random(4))
+
+    def setup():
+        v, p = cam.matrices(float(width), float(height))
+        return api.Rasterizer.setup(None, v, p).sample_mode(sample).ambient(amb)
+
+    return scenes._result(api, scene, assets, setup, width, height, 40, f"rows-{variant}{seed}")
+
+
+@pytest.mark.parametrize("variant", ["plain", "ties", "cutout", "mixed", "opacity"])
+@pytest.mark.parametrize("seed", range(3))
+def test_small_triangle_meshes(oracle, product, variant, seed):
+    w, h = 203 + 16 * seed, 131 + 9 * seed   # ragged right / bottom tiles
+    got = scenes.render(build(product, seed, w, h, variant))
+    ref = scenes.render(build(oracle, seed, w, h, variant))
+    diff = (got != ref).any(axis=2)
+    assert not diff.any(), f"{variant} seed {seed}: {int(diff.sum())} pixels differ; first {np.argwhere(diff)[:3].tolist()}"
+    assert (got[..., :3].max(axis=2) > 0).mean() > 0.05, "the scene did not produce a picture"
+
+
+def test_exact_ties_go_to_the_first_submission(oracle, product):
+    """two identical meshes in two colours: every fragment of the second has the same z as the first's, so nothing of the
+    second colour may show (rasterizer.rs:1060: `z < z_buffer` is strict) -- in row mode that is the index half of the key"""
+    frames = {}
+    for name, api in (("gpu", product), ("oracle", oracle)):
+        rng = np.random.default_rng(7)
+        v4, idx, uv = small_triangles(rng, 900, 0.08, 1.3)
+        scene = api.Scene.empty()
+        for colour in ((255, 0, 0, 255), (0, 255, 0, 255)):
+            b = api.Batch3D.new(v4.copy(), idx.copy(), uv.copy()).with_computed_normals().cull_mode(0)
+            scene.add_d3_static(b.source(B.PixelSource.Pixel(colour)).ambient_color((1.0, 1.0, 1.0)))
+        cam = api.D3OrbitCamera.new()
+        cam.set_parameter_f32("distance", 3.0)
+
+        def setup(cam=cam, api=api):
+            v, p = cam.matrices(320.0, 200.0)
+            return api.Rasterizer.setup(None, v, p)
+
+        frames[name] = scenes.render(scenes._result(api, scene, api.Assets.default(), setup, 320, 200, 40, "ties")).copy()
+    assert np.array_equal(frames["gpu"], frames["oracle"])
+    lit = frames["gpu"][..., :3].max(axis=2) > 0
+    assert lit.mean() > 0.05
+    assert not (frames["gpu"][..., 1][lit] > frames["gpu"][..., 0][lit]).any(), "a fragment of the second submission won a tie"
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_stripes_of_a_mesh_equal_the_full_frame(product, world):
+    """the multi-GPU sharding primitive (interleaved 16-row stripes) over the binned / row-mode path"""
+    import torch
+
+    from rusterix_amd import distributed as D
+
+    cfg = build(product, 1, 333, 250, "mixed")
+    full = scenes.render(cfg).copy()
+    lib = product.lib
+    rxr = C.CDLL(__import__("rusterix_amd").lib_paths()["rxr"])
+    lib.rxh_context.restype = C.c_void_p
+    lib.rxh_rasterizer_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+    rxr.rxr_render_stripes_to.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+    rxr.rxr_synchronize.argtypes = [C.c_void_p]
+    r = cfg.setup()
+    assert lib.rxh_rasterizer_upload(r._h, cfg.scene._h, cfg.width, cfg.height, cfg.tile_size, cfg.assets._h) == 0
+    ctx = lib.rxh_context()
+    spr = D.stripes_per_rank(cfg.height, world)
+    parts = []
+    for rank in range(world):
+        band = torch.full((spr * D.TILE_H, cfg.width, 4), 77, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        assert rxr.rxr_render_stripes_to(ctx, rank, world, C.c_void_p(band.data_ptr()), None) == 0
+        assert rxr.rxr_synchronize(ctx) == 0
+        parts.append(band.cpu().numpy())
+    frame = D.assemble_numpy(np.concatenate(parts, axis=0), cfg.height, cfg.width, world)
+    assert np.array_equal(frame, full)
