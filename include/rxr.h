@@ -414,6 +414,11 @@ int rxr_download_rows(rxr_ctx *ctx, uint8_t *pixels, uint32_t row0, uint32_t row
 /* the whole drop-in call: upload + render all rows + download.  `pixels` is width*height*4 bytes
  * of host memory, fully overwritten, as in the reference (src/rasterizer.rs:185-193). */
 int rxr_rasterize(rxr_ctx *ctx, const rxr_frame *frame, uint8_t *pixels);
+/* the second half of rxr_rasterize for callers that upload separately: renders every row of the uploaded frame and
+ * writes width*height*4 bytes to `pixels` (host memory).  Frames that need no per-tile lists (at most 128 3D triangles,
+ * few 2D primitives) are rendered in bands whose downloads overlap the rendering of the following bands; the result is
+ * byte-identical to rxr_render_rows + rxr_download_rows.  Replaces src/rasterizer.rs:256-579 + the final copy. */
+int rxr_render_download(rxr_ctx *ctx, uint8_t *pixels);
 
 int rxr_synchronize(rxr_ctx *ctx);
 int rxr_get_stats(rxr_ctx *ctx, rxr_stats *out);

@@ -779,8 +779,7 @@ int Rasterizer::rasterize(Scene &scene, uint8_t *pixels, size_t w, size_t h, siz
     int rc = upload(scene, w, h, tile_size, assets);
     if (rc != RXR_OK) return rc;
     rxr_ctx *ctx = context();
-    rc = rxr_render_rows(ctx, 0, (uint32_t)h);
-    if (rc == RXR_OK) rc = rxr_download_rows(ctx, pixels, 0, (uint32_t)h);
+    rc = rxr_render_download(ctx, pixels);
     if (rc != RXR_OK) g_error = rxr_last_error(ctx);
     return rc;
 }

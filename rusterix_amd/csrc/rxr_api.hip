@@ -78,6 +78,8 @@ enum : uint32_t { PF_UV = 1, PF_ROUGHNESS = 2, PF_METALLIC = 4, PF_OPACITY = 8, 
 struct rxr_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;   // rxr_rasterize: downloads of finished bands overlap the rendering of the next ones
+    hipEvent_t ev_band[8] = {};
     std::string err;
 
     // textures
@@ -226,6 +228,9 @@ int rxr_create(rxr_ctx **out, int device_id) {
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev2);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev_upload);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking);
+    for (hipEvent_t &ev : ctx->ev_band)
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
     if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_counters, (2 * CNT_WORDS + 4) * sizeof(uint32_t), hipHostMallocDefault);
     if (e != hipSuccess) {
         std::string msg = std::string("rxr_create: ") + hipGetErrorString(e);
@@ -260,6 +265,12 @@ void rxr_destroy(rxr_ctx *ctx) {
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->ev2) (void)hipEventDestroy(ctx->ev2);
     if (ctx->ev_upload) (void)hipEventDestroy(ctx->ev_upload);
+    for (hipEvent_t ev : ctx->ev_band)
+        if (ev) (void)hipEventDestroy(ev);
+    if (ctx->copy_stream) {
+        (void)hipStreamSynchronize(ctx->copy_stream);
+        (void)hipStreamDestroy(ctx->copy_stream);
+    }
     for (ProfSlot &p : ctx->prof) {
         (void)hipEventDestroy(p.e0);
         (void)hipEventDestroy(p.e1);
@@ -1476,9 +1487,47 @@ int rxr_rasterize(rxr_ctx *ctx, const rxr_frame *frame, uint8_t *pixels) {
     if (!ctx || !pixels) return RXR_ERR_INVALID;
     int rc = rxr_upload_frame(ctx, frame);
     if (rc != RXR_OK) return rc;
-    rc = rxr_render_rows(ctx, 0, frame->height);
-    if (rc != RXR_OK) return rc;
-    return rxr_download_rows(ctx, pixels, 0, frame->height);
+    return rxr_render_download(ctx, pixels);
+}
+
+int rxr_render_download(rxr_ctx *ctx, uint8_t *pixels) {
+    if (!ctx || !pixels) return RXR_ERR_INVALID;
+    if (!ctx->has_frame) return fail(ctx, RXR_ERR_INVALID, "rxr_render_download: no frame uploaded");
+    int rc = RXR_OK;
+    // The download of a 4K frame over PCIe takes longer than rendering it.  Frames whose launches cannot overflow a list
+    // (small scenes: no bins at all) are rendered in bands of tile rows and every finished band travels to the caller's
+    // buffer while the next ones render; rendering in bands is byte-identical to one launch (tested).  Measured: 3840x2160
+    // 0.90 -> 0.76 ms per call; at 1920x1080 the extra launches cost more than the overlap gains (0.26 -> 0.31 ms), hence
+    // the 4 Mpixel threshold.
+    const RasterParams &P = ctx->P;
+    const bool d3 = (P.flags & RXR_FLAG_D3_ACTIVE) != 0;
+    const bool no_lists = !P.binned2d && (!d3 || (P.n_tris3d <= RXR_STAGE_TRIS && ctx->small_mode != 0u)) && !ctx->frame_uses_meshes;
+    const uint32_t H = P.height;
+    static const bool no_pipeline = getenv("RXR_NO_DOWNLOAD_PIPELINE") != nullptr;  // A-B runs
+    if (!no_lists || no_pipeline || (size_t)P.width * H < (1u << 22)) {
+        rc = rxr_render_rows(ctx, 0, H);
+        if (rc != RXR_OK) return rc;
+        return rxr_download_rows(ctx, pixels, 0, H);
+    }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const uint32_t n_bands = 4;
+    const uint32_t tile_rows = (H + RXR_TILE_H - 1) / RXR_TILE_H;
+    uint32_t row_of[n_bands + 1];
+    for (uint32_t k = 0; k <= n_bands; ++k) row_of[k] = std::min<uint32_t>(H, (uint32_t)((uint64_t)tile_rows * k / n_bands) * RXR_TILE_H);
+    row_of[n_bands] = H;
+    for (uint32_t k = 0; k < n_bands; ++k) {
+        rc = rxr_render_rows(ctx, row_of[k], row_of[k + 1]);
+        if (rc != RXR_OK) return rc;
+        HIPCHK(ctx, hipEventRecord(ctx->ev_band[k], ctx->stream));
+    }
+    for (uint32_t k = 0; k < n_bands; ++k) {
+        const size_t off = (size_t)row_of[k] * P.width * 4, bytes = (size_t)(row_of[k + 1] - row_of[k]) * P.width * 4;
+        if (!bytes) continue;
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev_band[k], 0));
+        HIPCHK(ctx, hipMemcpyAsync(pixels + off, (uint8_t *)ctx->d_fb.p + off, bytes, hipMemcpyDeviceToHost, ctx->copy_stream));
+    }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->copy_stream));
+    return rxr_synchronize(ctx);  // (program faults are reported here)
 }
 
 int rxr_get_stats(rxr_ctx *ctx, rxr_stats *out) {

@@ -313,8 +313,8 @@ __device__ __forceinline__ bool light_color_at(const rxr_light &l, f3 point, uin
 }
 
 // rasterizer.rs:1875-1951 with emissive == 0 at every call site
-__device__ __forceinline__ f3 shade_fast_brdf(f3 base, float roughness, float metallic, f3 n, f3 v, f3 l, f3 radiance) {
-    float n_dot_l = fmaxf(dot3(n, l), 0.0f);
+// (n_dot_l = max(dot(n, l), 0): the point-light path of the caller has the same float at hand as its Lambert term)
+__device__ __forceinline__ f3 shade_fast_brdf(f3 base, float roughness, float metallic, f3 n, f3 v, f3 l, f3 radiance, float n_dot_l) {
     if (n_dot_l <= 0.0f) return mk3(0.0f, 0.0f, 0.0f);
     // Vec3::lerp(0.04, base, metallic) = mul_add(clamp01(t), b - a, a)
     float tm = rclamp(metallic, 0.0f, 1.0f);
@@ -495,7 +495,7 @@ __device__ __forceinline__ void shade3d_begin(const RasterParams &P, const TriSh
         if ((P.flags & RXR_FLAG_HAS_SUN) && P.day_factor > 0.0f) {
             f3 ldir = norm3(neg3(mk3(P.sun_dir[0], P.sun_dir[1], P.sun_dir[2])));
             float df = fmaxf(P.day_factor, 0.0f);
-            lit = add3(lit, shade_fast_brdf(base, rough, metal, normal, view_dir, ldir, mk3(df, df, df)));
+            lit = add3(lit, shade_fast_brdf(base, rough, metal, normal, view_dir, ldir, mk3(df, df, df), fmaxf(dot3(normal, ldir), 0.0f)));
         }
         lit = scale3(lit, occlusion);
     }
@@ -536,6 +536,16 @@ __device__ __forceinline__ void shade3d_lights(const RasterParams &P, bool hit, 
     for (uint32_t base_i = 0; base_i < P.n_lights; base_i += 64u) {
         const uint32_t mine = base_i + (uint32_t)lane;
         bool cand = mine < P.n_lights;
+        // smoothstep(end, start, d) divides by (start - end), the same for every fragment: the lane that owns the light in
+        // this step keeps the denominator's refined reciprocal (rxr_exact_math.h) and whether it is inside the window
+        float ss_rcp = 0.0f;
+        bool ss_ok = false;
+        if (cand) {
+            const float ssd = P.lights[mine].start_distance - P.lights[mine].end_distance;
+            ss_ok = rxm::in_window(ssd);
+            ss_rcp = rxm::rcp_refined(ssd);
+        }
+        const unsigned long long ss_ok_mask = __ballot(ss_ok);
         if (cand && can_cull) {
             const rxr_light &L = P.lights[mine];
             if (L.light_type == RXR_LIGHT_POINT || L.light_type == RXR_LIGHT_SPOT || L.light_type == RXR_LIGHT_AREA ||
@@ -548,8 +558,11 @@ __device__ __forceinline__ void shade3d_lights(const RasterParams &P, bool hit, 
         }
         unsigned long long todo = __ballot(cand);
         while (todo) {
-            const uint32_t li = base_i + (uint32_t)(__ffsll((long long)todo) - 1);
+            const int li_lane = __ffsll((long long)todo) - 1;
+            const uint32_t li = base_i + (uint32_t)li_lane;
             todo &= todo - 1ull;
+            const float ss_r = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ss_rcp), li_lane));
+            const bool ss_fast = (ss_ok_mask >> li_lane) & 1ull;
             if (!hit) continue;
             const rxr_light &L = P.lights[li];
             const f3 lp = mk3(L.position[0], L.position[1], L.position[2]);
@@ -563,20 +576,28 @@ __device__ __forceinline__ void shade3d_lights(const RasterParams &P, bool hit, 
                 ldir = norm3_fast(d, distance);
                 if (distance >= L.end_distance) continue;
                 float intensity = L.intensity;
-                if (!(distance <= L.start_distance)) intensity = L.intensity * smoothstep_rs(L.end_distance, L.start_distance, distance);
+                if (!(distance <= L.start_distance)) {
+                    // smoothstep_rs(end, start, distance) with the shared reciprocal
+                    const float sn = distance - L.end_distance, sd = L.start_distance - L.end_distance;
+                    float q;
+                    if (ss_fast && rxm::wave_all(rxm::in_window(sn))) q = rxm::div_chain(sn, sd, ss_r);
+                    else q = sn / sd;
+                    const float t = rclamp(q, 0.0f, 1.0f);
+                    intensity = L.intensity * (t * t * (3.0f - 2.0f * t));
+                }
                 incoming = apply_flicker(L, intensity, P.hash_anim);
             } else {
                 if (!light_color_at(L, F.world, P.hash_anim, false, incoming)) continue;
                 ldir = norm3_fast(sub3(lp, F.world));
             }
+            const float n_dot_l = fmaxf(dot3(F.normal, ldir), 0.0f);  // the Lambert term of radiance_at (light.rs:529-532) and of the BRDF
             f3 radiance;
             if (L.light_type == RXR_LIGHT_AMBIENT || L.light_type == RXR_LIGHT_AMBIENT_DAYLIGHT || L.light_type == RXR_LIGHT_DAYLIGHT) {
                 radiance = incoming;
             } else {
-                float lambert = fmaxf(dot3(F.normal, ldir), 0.0f);  // radiance_at, light.rs:529-532
-                radiance = scale3(incoming, lambert);
+                radiance = scale3(incoming, n_dot_l);
             }
-            F.lit = add3(F.lit, shade_fast_brdf(F.base, rough, metal, F.normal, F.view_dir, ldir, radiance));
+            F.lit = add3(F.lit, shade_fast_brdf(F.base, rough, metal, F.normal, F.view_dir, ldir, radiance, n_dot_l));
         }
     }
 }

@@ -271,5 +271,6 @@ extern "C" {
     pub fn rxr_render_stripes_to(ctx: *mut rxr_ctx, first: u32, stride: u32, dev: *mut c_void, stream: *mut c_void) -> c_int;
     pub fn rxr_download_rows(ctx: *mut rxr_ctx, pixels: *mut u8, row0: u32, row1: u32) -> c_int;
     pub fn rxr_rasterize(ctx: *mut rxr_ctx, frame: *const rxr_frame, pixels: *mut u8) -> c_int;
+    pub fn rxr_render_download(ctx: *mut rxr_ctx, pixels: *mut u8) -> c_int;
     pub fn rxr_synchronize(ctx: *mut rxr_ctx) -> c_int;
 }

@@ -415,3 +415,26 @@ def test_2d_many_rectangles_over_3d(oracle, product):
 
     got, ref = scenes.render(build(product)), scenes.render(build(oracle))
     assert_close(got, ref, "2D tile map over 3D")
+
+
+def test_pipelined_download_equals_single_launch(product):
+    """rxr_render_download renders large small-scene frames in four bands and downloads each while the next renders
+    (include/rxr.h); the caller's buffer must equal render_rows + download_rows byte for byte."""
+    import ctypes as C
+
+    cfg = scenes.map_scene(product, width=2304, height=1832, logo_size=64, n_lights=3)   # over the 4 Mpixel threshold; 1832 rows = 114.5 tile rows: ragged bands
+    piped = scenes.render(cfg).copy()          # Rasterizer::rasterize -> rxr_render_download
+    lib = product.lib
+    rxr = C.CDLL(__import__("rusterix_amd").lib_paths()["rxr"])
+    lib.rxh_context.restype = C.c_void_p
+    lib.rxh_rasterizer_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+    rxr.rxr_render_rows.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+    rxr.rxr_download_rows.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), C.c_uint32, C.c_uint32]
+    r = cfg.setup()
+    assert lib.rxh_rasterizer_upload(r._h, cfg.scene._h, cfg.width, cfg.height, cfg.tile_size, cfg.assets._h) == 0
+    ctx = lib.rxh_context()
+    single = np.zeros((cfg.height, cfg.width, 4), np.uint8)
+    assert rxr.rxr_render_rows(ctx, 0, cfg.height) == 0
+    assert rxr.rxr_download_rows(ctx, single.ctypes.data_as(C.POINTER(C.c_uint8)), 0, cfg.height) == 0
+    assert_exact(piped, single, "pipelined download vs single launch")
+    assert piped[..., 3].min() == 255
