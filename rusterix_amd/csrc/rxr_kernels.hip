@@ -1402,13 +1402,16 @@ __device__ RXR_RESOLVE_INLINE void rows_resolve(const RasterParams &P, const Row
     const float one_over_z = S.iz0 * alpha + S.iz1 * beta + S.iz2 * gamma;
     const float z = 1.0f / one_over_z;
     const bool closer = z < vis.zmin || (z == vis.zmin && vis.best >= 0 && (int)t < vis.best);
-    if (!closer) return;
-    vis.zmin = z;
-    vis.best = (int)t;
-    vis.alpha = alpha;
-    vis.beta = beta;
-    vis.slot = 0;
-    vis.batch = S.batch;
+    // Branch-free update.  Written as `if (!closer) return; vis.x = ...;` hipcc (ROCm 7.2) kept the OLD vis.batch for the lanes
+    // that win an exact tie (z == vis.zmin, smaller index): its if-conversion restored the old value for every lane of the
+    // `!(z < zmin)` region before merging (seen in the ISA; tests/test_gpu_rows.py "mixed" caught it as a wrong texture on
+    // duplicated geometry).  The selects below leave it nothing to merge.
+    vis.zmin = closer ? z : vis.zmin;
+    vis.best = closer ? (int)t : vis.best;
+    vis.alpha = closer ? alpha : vis.alpha;
+    vis.beta = closer ? beta : vis.beta;
+    vis.slot = closer ? 0u : vis.slot;
+    vis.batch = closer ? S.batch : vis.batch;
 }
 
 // Visibility pass over the tile's candidate triangles = [large-triangle list, filtered against the
@@ -1703,7 +1706,7 @@ __device__ __forceinline__ uint32_t walk_prims2d(const RasterParams &P, Stage &s
 
 // tuning knobs: occupancy bound of k_raster and the pixel footprint of a wave
 #ifndef RXR_RASTER_WAVES_PER_SIMD
-#define RXR_RASTER_WAVES_PER_SIMD 1
+#define RXR_RASTER_WAVES_PER_SIMD 8  // bench frame (4K, 16 lights), built without SLP vectorisation: unbounded (67 VGPRs) 217 us, 7: 211, 8: 210
 #endif
 #ifndef RXR_WAVE_8X8
 #define RXR_WAVE_8X8 0
@@ -1975,7 +1978,7 @@ __device__ __forceinline__ void raster_tile(const RasterParams &P) {
 
 // two instantiations so that each path gets its own register allocation
 extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_RASTER_WAVES_PER_SIMD) k_raster(RasterParams P) { raster_tile<false, 0>(P); }
-extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_RASTER_WAVES_PER_SIMD) k_raster_fused(RasterParams P) { raster_tile<true, 0>(P); }
+extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS) k_raster_fused(RasterParams P) { raster_tile<true, 0>(P); }
 // binned scenes (more than RXR_STAGE_TRIS triangles): the walk may switch to row mode per round (rows_round)
 #ifndef RXR_ROWS_WAVES_PER_SIMD
 #define RXR_ROWS_WAVES_PER_SIMD 6  // C5: unbounded (87 VGPRs, 5 waves) 797 us, 6: 718, 7: 727 (and the teapot loses 15 %)
@@ -2037,7 +2040,7 @@ extern "C" void rxr_launch_fill(const RasterParams *P, hipStream_t s) {
 extern "C" void rxr_launch_raster(const RasterParams *P, hipStream_t s) {
     uint32_t tiles = P->tiles_x * P->tiles_y;
     if (tiles == 0) return;
-    static const bool no_rows = getenv("RXR_NO_ROWS") != nullptr;  // tuning knob: binned scenes walk every candidate per pixel (k_raster)
+    const bool no_rows = getenv("RXR_NO_ROWS") != nullptr;  // tuning knob: binned scenes walk every candidate per pixel (k_raster)
     if (P->kernel_level >= 2u) hipLaunchKernelGGL(k_raster_vm, dim3(tiles), dim3(RXR_TILE_THREADS), 0, s, *P);
     else if (P->kernel_level == 1u) hipLaunchKernelGGL(k_raster_chunk, dim3(tiles), dim3(RXR_TILE_THREADS), 0, s, *P);
     else if (P->fused_small == 1u) hipLaunchKernelGGL(k_raster_fused, dim3(tiles), dim3(RXR_TILE_THREADS), 0, s, *P);

@@ -144,3 +144,22 @@ def test_stripes_of_a_mesh_equal_the_full_frame(product, world):
         parts.append(band.cpu().numpy())
     frame = D.assemble_numpy(np.concatenate(parts, axis=0), cfg.height, cfg.width, world)
     assert np.array_equal(frame, full)
+
+
+def test_row_mode_equals_the_walk_over_many_frames(oracle, product, monkeypatch):
+    """The bin lists are filled with atomics, so how a dense tile's candidates split into rounds -- and which rounds run
+    in row mode -- changes from frame to frame.  Sixty frames of the 'mixed' scene (duplicated meshes, cut-outs, large
+    triangles: ties between a walked round's winner and a row-mode candidate with a smaller index) must all equal the
+    oracle, and so must the same frames with row mode switched off (RXR_NO_ROWS: k_raster walks every candidate).
+    Regression test for a wrong-batch miscompile in rows_resolve (see its comment)."""
+    w, h = 203, 131
+    ref = scenes.render(build(oracle, 0, w, h, "mixed")).copy()
+    cfg = build(product, 0, w, h, "mixed")
+    for it in range(60):
+        if it % 3 == 2:
+            monkeypatch.setenv("RXR_NO_ROWS", "1")
+        else:
+            monkeypatch.delenv("RXR_NO_ROWS", raising=False)
+        got = scenes.render(cfg)
+        diff = (got != ref).any(axis=2)
+        assert not diff.any(), f"frame {it} ({'walk' if it % 3 == 2 else 'rows'}): {int(diff.sum())} pixels differ; first {np.argwhere(diff)[:3].tolist()}"
