@@ -206,7 +206,7 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6),
                 # HBM bytes of one launch from the rocprofv3 PMC passes of this same command (FETCH_SIZE with the
-                # gfx950 x2 correction + WRITE_SIZE; profiles/r01/e_bench_pmc_summary.json); only known for the
+                # gfx950 x2 correction + WRITE_SIZE; profiles/r01/h_bench_pmc_summary.json); only known for the
                 # default workload
                 "traffic": MEASURED_TRAFFIC_4K["fetch_x2"] + MEASURED_TRAFFIC_4K["write"] if default_workload else None,
                 "algorithmic_bytes_per_launch": int(alg),
@@ -218,7 +218,7 @@ def main():
                             "(DESIGN.md section 6)",
                     "wave_instructions_per_launch_4k": MEASURED_VALU_4K,
                     "issue_cycles_per_launch_4k": VALU_ISSUE_CYCLES_4K,
-                    "frac_of_simd_cycles": round(VALU_ISSUE_CYCLES_4K / (1024 * 2.4e3 * raster_avg_us), 3) if default_workload else None,
+                    "frac_of_simd_cycles": round(min(1.0, VALU_ISSUE_CYCLES_4K / (1024 * 2.4e3 * raster_avg_us)), 3) if default_workload else None,
                 },
             },
         }
@@ -232,12 +232,13 @@ def main():
 
 
 # rocprofv3 PMC passes of `python3 bench.py` (3840x2160, 16 lights, 1 GPU), per k_raster launch:
-# profiles/r01/e_bench_pmc_summary.json
-MEASURED_TRAFFIC_4K = {"write": 33177600, "fetch_x2": 2241053, "source": "profiles/r01/e_bench_pmc_summary.json"}
-MEASURED_VALU_4K = 155934525
-# the same instructions priced with the measured issue costs of tools/microbench/valu_rates.hip
-# (fma/mul/add 2 cycles, compares / selects / conversions / min / max 4, rcp / sqrt / log / exp 8 per wave64)
-VALU_ISSUE_CYCLES_4K = int(71.6e6 * 2 + 5.78e6 * 8 + (155.93e6 - 71.6e6 - 5.78e6) * 3.3)
+# profiles/r01/h_bench_pmc_summary.json (WRITE_SIZE includes 2.4 MB of register spills: k_raster is bounded to 64 VGPRs)
+MEASURED_TRAFFIC_4K = {"write": 35563241, "fetch_x2": 2262487, "source": "profiles/r01/h_bench_pmc_summary.json"}
+MEASURED_VALU_4K = 166895157
+# the same instructions priced with the measured issue costs of tools/microbench/valu_rates.hip (profiles/r01/valu_issue_rates.txt:
+# fma / mul / add 2.6 cycles per wave64 instruction, rcp / sqrt / rsq / log / exp 8.3, the rest -- compares, selects,
+# conversions, min / max at 4.3, moves and integer adds at 2.5 -- taken at 3.4): an estimate, good to about +-10 %
+VALU_ISSUE_CYCLES_4K = int((21.84e6 + 31.40e6 + 37.63e6) * 2.6 + 4.94e6 * 8.3 + (166.90e6 - 90.87e6 - 4.94e6) * 3.4)
 
 
 def scene_counts(cfg, api):
