@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define RXR_ABI_VERSION 2u
+#define RXR_ABI_VERSION 3u
 
 typedef enum rxr_status {
     RXR_OK = 0,
@@ -69,7 +69,8 @@ enum { RXR_LIST_CHUNK_OPACITY = 0, RXR_LIST_CHUNK = 1, RXR_LIST_CHUNK_TERRAIN = 
        RXR_LIST_DYNAMIC = 4, RXR_LIST_OVERLAY = 5 };
 /* background shader kinds (trait Shader, src/shader/mod.rs:9-33) that the device evaluates itself */
 enum { RXR_BG_NONE = 0, RXR_BG_VGRADIENT = 1 /* src/shader/vgradient.rs:11-15 */,
-       RXR_BG_HOST_PIXELS = 2 /* any other `dyn Shader`, evaluated by the host into background_pixels */ };
+       RXR_BG_HOST_PIXELS = 2 /* any other `dyn Shader`, evaluated by the host into background_pixels */,
+       RXR_BG_GRID = 3 /* GridShader, src/shader/grid.rs:10-109; parameters in rxr_frame.background_grid */ };
 
 /* rxr_frame.flags */
 #define RXR_FLAG_D2_ACTIVE             (1u << 0) /* RenderMode.d2_active, src/rendermode.rs:4-11   */
@@ -262,6 +263,9 @@ typedef struct rxr_frame {
     const float *mesh_transforms;     /* optional [n_meshes][16]: this frame's Batch3D.transform_3d of
                                          every registered mesh (moving objects need no re-registration);
                                          NULL = the transforms given to rxr_set_meshes                */
+    /* ABI 3 */
+    float background_grid[4];         /* RXR_BG_GRID: GridShader.grid_size, .subdivisions, .offset.x, .offset.y
+                                         (src/shader/grid.rs:4-8; defaults 30, 2, (0, 0), :12-16)      */
 } rxr_frame;
 
 /* ---- Rusteria shader programs -------------------------------------

@@ -57,6 +57,13 @@ void *orc_scene_new() { return new Scene(); }
 void orc_scene_free(void *s) { delete (Scene *)s; }
 void orc_scene_set_animation_frame(void *s, uint64_t f) { ((Scene *)s)->animation_frame = (size_t)f; }
 void orc_scene_set_background(void *s, int kind) { ((Scene *)s)->background = kind; }
+void orc_scene_set_background_grid(void *s, float grid_size, float subdivisions, float offset_x, float offset_y) {
+    float *g = ((Scene *)s)->background_grid;
+    g[0] = grid_size;
+    g[1] = subdivisions;
+    g[2] = offset_x;
+    g[3] = offset_y;
+}
 void orc_scene_add_light(void *s, const rxr_light *l, int dynamic) {
     if (dynamic) ((Scene *)s)->dynamic_lights.push_back(*l);
     else ((Scene *)s)->lights.push_back(*l);

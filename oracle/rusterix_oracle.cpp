@@ -1335,6 +1335,42 @@ static int raster_tile(const FrameCtx &fc, const TileRect &tile, std::vector<uin
         }
     }
 
+    if (!r.ignore_background_shader && scene.background == RXR_BG_GRID) {  // :292-308 with GridShader (shader/grid.rs:36-108)
+        const float screen_x = (float)fc.r->width, screen_y = (float)fc.r->height;
+        const float grid_size = scene.background_grid[0], sub_grid_div = scene.background_grid[1];
+        const float off_x = scene.background_grid[2], off_y = scene.background_grid[3];
+        auto closest_mul = [](float delta, float value) { return delta * roundf(value / delta); };
+        auto mul_dist = [&](float delta, float value) { return fabsf(value - closest_mul(delta, value)); };
+        const float bg_color[4] = {0.05f, 0.05f, 0.05f, 1.0f}, line_color[4] = {0.15f, 0.15f, 0.15f, 1.0f}, sub_line_color[4] = {0.11f, 0.11f, 0.11f, 1.0f};
+        for (size_t ty = 0; ty < tile.height; ++ty) {
+            for (size_t tx = 0; tx < tile.width; ++tx) {
+                const float uvx = (float)(tile.x + tx) / screen_x, uvy = (float)(tile.y + ty) / screen_y;
+                const float position_x = uvx * screen_x, position_y = uvy * screen_y;
+                const float origin_x = screen_x / 2.0f + off_x, origin_y = screen_y / 2.0f + off_y;
+                const float th = 1.0f, sth = 1.0f;
+                // align_pixel(origin, 1): 1 is odd
+                const float aligned_x = roundf(origin_x - 0.5f) + 0.5f, aligned_y = roundf(origin_y - 0.5f) + 0.5f;
+                const float rel_x = position_x - aligned_x, rel_y = position_y - aligned_y;
+                const float dist_x = mul_dist(grid_size, rel_x), dist_y = mul_dist(grid_size, rel_y);
+                const float *c = bg_color;
+                if (fminf(dist_x, dist_y) <= th * 0.5f) {
+                    c = line_color;
+                } else {
+                    const float dtf_x = fabsf(rel_x - grid_size * floorf(rel_x / grid_size)), dtf_y = fabsf(rel_y - grid_size * floorf(rel_y / grid_size));
+                    const float sub_size = grid_size / roundf(sub_grid_div);
+                    float sub_dist_x = mul_dist(sub_size, dtf_x), sub_dist_y = mul_dist(sub_size, dtf_y);
+                    const float rc_x = roundf(dist_x / sub_size), rc_y = roundf(dist_y / sub_size);
+                    const float extra = grid_size - sub_size * sub_grid_div;
+                    if (rc_x == sub_grid_div) sub_dist_x = sub_dist_x + extra;
+                    if (rc_y == sub_grid_div) sub_dist_y = sub_dist_y + extra;
+                    if (fminf(sub_dist_x, sub_dist_y) <= sth * 0.5f) c = sub_line_color;
+                }
+                const size_t idx = (ty * tile.width + tx) * 4;
+                for (int k = 0; k < 4; ++k) buffer[idx + k] = f32_to_u8_saturated(c[k]);  // vec4_to_pixel, lib.rs:64-79
+            }
+        }
+    }
+
     Execution execution;  // :310
     int rc = 0;
 

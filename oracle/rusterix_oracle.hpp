@@ -197,7 +197,8 @@ bool chunk_sample_terrain_texture(const Chunk &c, Vec2 world_pos, Vec2 scale, ui
 
 // src/scene.rs:8-50
 struct Scene {
-    int background = RXR_BG_NONE;  // Option<Box<dyn Shader>>: none | VGrayGradientShader
+    int background = RXR_BG_NONE;  // Option<Box<dyn Shader>>: none | VGrayGradientShader | GridShader
+    float background_grid[4] = {30.0f, 2.0f, 0.0f, 0.0f};  // GridShader: grid_size, subdivisions, offset (shader/grid.rs:12-16)
     std::vector<CompiledLight> lights;
     std::vector<CompiledLight> dynamic_lights;
     std::vector<Batch3D> d3_static, d3_dynamic, d3_overlay;

@@ -23,7 +23,7 @@ CULL_OFF, CULL_FRONT, CULL_BACK = 0, 1, 2
 LIGHT_POINT, LIGHT_AMBIENT, LIGHT_AMBIENT_DAYLIGHT, LIGHT_SPOT, LIGHT_AREA, LIGHT_DAYLIGHT = range(6)
 SOURCE_OTHER, SOURCE_STATIC_TILE, SOURCE_DYNAMIC_TILE, SOURCE_PIXEL, SOURCE_TERRAIN, SOURCE_MISSING = range(6)
 LIST_CHUNK_OPACITY, LIST_CHUNK, LIST_CHUNK_TERRAIN, LIST_STATIC, LIST_DYNAMIC, LIST_OVERLAY = range(6)
-BG_NONE, BG_VGRADIENT, BG_HOST_PIXELS = 0, 1, 2
+BG_NONE, BG_VGRADIENT, BG_HOST_PIXELS, BG_GRID = 0, 1, 2, 3
 
 RXR_OK, RXR_ERR_INVALID, RXR_ERR_NO_DEVICE, RXR_ERR_HIP, RXR_ERR_UNSUPPORTED, RXR_ERR_OOM = 0, -1, -2, -3, -4, -5
 
@@ -258,6 +258,27 @@ class VGrayGradientShader:
     kind = BG_VGRADIENT
 
 
+class GridShader:
+    """reference src/shader/grid.rs: `Shader::new()` defaults (:12-16) and the two parameter setters (:19-34)"""
+
+    kind = BG_GRID
+
+    def __init__(self):
+        self.grid_size, self.subdivisions, self.offset = 30.0, 2.0, (0.0, 0.0)
+
+    def set_parameter_f32(self, key, value):
+        if key == "grid_size":
+            self.grid_size = float(value)
+        elif key == "subdivisions":
+            self.subdivisions = float(value)
+        return self
+
+    def set_parameter_vec2(self, key, value):
+        if key == "offset":
+            self.offset = (float(value[0]), float(value[1]))
+        return self
+
+
 # ---- Rusteria programs (reference rusteria/src/node/{nodeop,program}.rs) -------------------------------
 # NodeOp variants in declaration order = the RXR_NODE_* opcodes of include/rxr.h
 NODE_OPS = [
@@ -341,6 +362,7 @@ def make_api(lib: C.CDLL, prefix: str, name: str):
         scene_free=fn("scene_free", None, vp),
         scene_set_animation_frame=fn("scene_set_animation_frame", None, vp, u64),
         scene_set_background=fn("scene_set_background", None, vp, i32),
+        scene_set_background_grid=fn("scene_set_background_grid", None, vp, f32, f32, f32, f32),
         scene_add_light=fn("scene_add_light", None, vp, C.POINTER(RxrLight), i32),
         scene_add_dynamic_tile=fn("scene_add_dynamic_tile", None, vp, ppb, pu, pu, u32),
         scene_add_chunk=fn("scene_add_chunk", i32, vp),
@@ -622,6 +644,8 @@ def make_api(lib: C.CDLL, prefix: str, name: str):
 
         def background(self, shader):
             L.scene_set_background(self._h, shader.kind if shader is not None else BG_NONE)
+            if shader is not None and shader.kind == BG_GRID:
+                L.scene_set_background_grid(self._h, shader.grid_size, shader.subdivisions, shader.offset[0], shader.offset[1])
             return self
 
         def lights(self, lights):
@@ -882,5 +906,5 @@ def make_api(lib: C.CDLL, prefix: str, name: str):
         D3OrbitCamera=D3OrbitCamera, D3FirstPCamera=D3FirstPCamera,
         # shared value types
         Texture=Texture, Tile=Tile, Light=Light, PixelSource=PixelSource, RenderMode=RenderMode,
-        VGrayGradientShader=VGrayGradientShader, Mat4=Mat4, Mat3=Mat3, Program=Program,
+        VGrayGradientShader=VGrayGradientShader, GridShader=GridShader, Mat4=Mat4, Mat3=Mat3, Program=Program,
     )

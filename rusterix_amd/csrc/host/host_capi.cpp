@@ -60,6 +60,14 @@ void *rxh_scene_new() { return new Scene(); }
 void rxh_scene_free(void *s) { delete (Scene *)s; }
 void rxh_scene_set_animation_frame(void *s, uint64_t f) { ((Scene *)s)->animation_frame = (size_t)f; }
 void rxh_scene_set_background(void *s, int kind) { ((Scene *)s)->background = (uint32_t)kind; }
+// GridShader::set_parameter_f32 / set_parameter_vec2 (shader/grid.rs:19-34)
+void rxh_scene_set_background_grid(void *s, float grid_size, float subdivisions, float offset_x, float offset_y) {
+    float *g = ((Scene *)s)->background_grid;
+    g[0] = grid_size;
+    g[1] = subdivisions;
+    g[2] = offset_x;
+    g[3] = offset_y;
+}
 void rxh_scene_add_light(void *s, const rxr_light *l, int dynamic) {
     (dynamic ? ((Scene *)s)->dynamic_lights : ((Scene *)s)->lights).push_back(*l);
 }

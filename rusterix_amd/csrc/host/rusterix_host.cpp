@@ -746,6 +746,7 @@ int Rasterizer::upload(Scene &scene, size_t w, size_t h, size_t tile_size, const
     f.sample_mode = sample_mode_;
     f.time = time_;
     f.background_kind = scene.background;
+    memcpy(f.background_grid, scene.background_grid, 16);
     f.batches3d = b3.data();
     f.n_batches3d = (uint32_t)b3.size();
     f.batches2d = b2.data();

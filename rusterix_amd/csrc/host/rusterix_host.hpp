@@ -176,7 +176,8 @@ struct Chunk {
 // src/scene.rs:8-50
 class Scene {
 public:
-    uint32_t background = RXR_BG_NONE;  // Option<Box<dyn Shader>>: VGrayGradientShader is evaluated on the device
+    uint32_t background = RXR_BG_NONE;  // Option<Box<dyn Shader>>: VGrayGradientShader and GridShader are evaluated on the device
+    float background_grid[4] = {30.0f, 2.0f, 0.0f, 0.0f};  // GridShader: grid_size, subdivisions, offset (shader/grid.rs:12-16)
     std::vector<CompiledLight> lights, dynamic_lights;
     std::vector<Batch3D> d3_static, d3_dynamic, d3_overlay;
     std::vector<Batch2D> d2_static, d2_dynamic;

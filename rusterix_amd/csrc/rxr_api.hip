@@ -581,6 +581,7 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
     if ((f->n_batches3d && !f->batches3d) || (f->n_batches2d && !f->batches2d) || (f->n_lights && !f->lights) ||
         (f->n_occluders && !f->occluders) || (f->n_linedefs && !f->linedefs) || (f->n_chunks && !f->chunks))
         return fail(ctx, RXR_ERR_INVALID, "rxr_upload_frame: NULL array with non-zero count");
+    if (f->background_kind > RXR_BG_GRID) return fail(ctx, RXR_ERR_INVALID, "rxr_upload_frame: unknown background_kind");
     if (f->background_kind == RXR_BG_HOST_PIXELS && !f->background_pixels)
         return fail(ctx, RXR_ERR_INVALID, "rxr_upload_frame: RXR_BG_HOST_PIXELS without background_pixels");
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -1101,6 +1102,7 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
     P.sample_mode = f->sample_mode;
     P.background_color = pack_px(f->background_color);
     P.background_kind = f->background_kind;
+    memcpy(P.bg_grid, f->background_grid, 16);
     memcpy(P.ambient, f->ambient, 16);
     memcpy(P.sun_dir, f->sun_dir, 12);
     P.day_factor = f->day_factor;

@@ -361,6 +361,34 @@ __device__ __forceinline__ uint32_t pack4(uint32_t r, uint32_t g, uint32_t b, ui
     return r | (g << 8) | (b << 16) | (a << 24);
 }
 
+// GridShader::shade_pixel (shader/grid.rs:36-108) at pixel (px, py): uv = (x / W, y / H), screen = (W, H) as the tile loop
+// passes them (rasterizer.rs:292-308).  vek's Vec2 arithmetic is component-wise; `round` is half away from zero, `min` drops NaN.
+__device__ __forceinline__ float grid_mul_dist(float delta, float value) {  // |value - delta * round(value / delta)|
+    return fabsf(value - delta * roundf(value / delta));
+}
+__device__ __forceinline__ uint32_t grid_shade(const RasterParams &P, uint32_t px, uint32_t py) {
+    const float grid = P.bg_grid[0], sub_div = P.bg_grid[1];
+    const float pos_x = ((float)px / P.fwidth) * P.fwidth, pos_y = ((float)py / P.fheight) * P.fheight;
+    const float origin_x = P.fwidth / 2.0f + P.bg_grid[2], origin_y = P.fheight / 2.0f + P.bg_grid[3];
+    // align_pixel(origin, 1): odd thickness
+    const float ao_x = roundf(origin_x - 0.5f) + 0.5f, ao_y = roundf(origin_y - 0.5f) + 0.5f;
+    const float rel_x = pos_x - ao_x, rel_y = pos_y - ao_y;
+    const float dist_x = grid_mul_dist(grid, rel_x), dist_y = grid_mul_dist(grid, rel_y);
+    const uint32_t line = pack4(f32_to_u8_saturated(0.15f), f32_to_u8_saturated(0.15f), f32_to_u8_saturated(0.15f), f32_to_u8_saturated(1.0f));
+    const uint32_t sub_line = pack4(f32_to_u8_saturated(0.11f), f32_to_u8_saturated(0.11f), f32_to_u8_saturated(0.11f), f32_to_u8_saturated(1.0f));
+    const uint32_t bg = pack4(f32_to_u8_saturated(0.05f), f32_to_u8_saturated(0.05f), f32_to_u8_saturated(0.05f), f32_to_u8_saturated(1.0f));
+    if (fminf(dist_x, dist_y) <= 1.0f * 0.5f) return line;
+    const float dtf_x = fabsf(rel_x - grid * floorf(rel_x / grid)), dtf_y = fabsf(rel_y - grid * floorf(rel_y / grid));
+    const float sub_size = grid / roundf(sub_div);
+    float sd_x = grid_mul_dist(sub_size, dtf_x), sd_y = grid_mul_dist(sub_size, dtf_y);
+    const float rc_x = roundf(dist_x / sub_size), rc_y = roundf(dist_y / sub_size);
+    const float extra = grid - sub_size * sub_div;
+    if (rc_x == sub_div) sd_x = sd_x + extra;
+    if (rc_y == sub_div) sd_y = sd_y + extra;
+    if (fminf(sd_x, sd_y) <= 1.0f * 0.5f) return sub_line;
+    return bg;
+}
+
 // perspective-correct uv of the fragment (rasterizer.rs:1062-1076)
 __device__ __forceinline__ void fragment_uv(const TriShade &S, float alpha, float beta, float gamma, float &u, float &v) {
     float iu = S.u0w * alpha + S.u1w * beta + S.u2w * gamma;
@@ -1757,6 +1785,8 @@ __device__ __forceinline__ void raster_tile(const RasterParams &P) {
         if (P.background_kind == RXR_BG_VGRADIENT) {
             uint32_t i = sat_u8(rclamp(((float)py / P.fheight) * 128.0f, 0.0f, 128.0f));  // shader/vgradient.rs:11-15
             color = pack4(i, i, i, 255u);
+        } else if (P.background_kind == RXR_BG_GRID) {
+            color = grid_shade(P, px, py);
         } else if (P.background_kind == RXR_BG_HOST_PIXELS && in_frame) {
             color = P.bg_pixels[(size_t)py * P.width + px];
         }

@@ -1,8 +1,8 @@
-//! Raw bindings of include/rxr.h (ABI version 1).  Field order and types mirror the C header exactly.
+//! Raw bindings of include/rxr.h (ABI version 3).  Field order and types mirror the C header exactly.
 #![allow(non_camel_case_types)]
 use std::os::raw::{c_char, c_int, c_void};
 
-pub const RXR_ABI_VERSION: u32 = 1;
+pub const RXR_ABI_VERSION: u32 = 3;
 pub const RXR_OK: c_int = 0;
 
 pub const RXR_FLAG_D2_ACTIVE: u32 = 1 << 0;
@@ -29,6 +29,7 @@ pub const RXR_LIST_OVERLAY: u32 = 5;
 pub const RXR_BG_NONE: u32 = 0;
 pub const RXR_BG_VGRADIENT: u32 = 1;
 pub const RXR_BG_HOST_PIXELS: u32 = 2;
+pub const RXR_BG_GRID: u32 = 3;
 
 #[repr(C)]
 pub struct rxr_ctx {
@@ -217,6 +218,7 @@ pub struct rxr_frame {
     pub view: [f32; 16],
     pub projection: [f32; 16],
     pub mesh_transforms: *const f32,
+    pub background_grid: [f32; 4],
 }
 
 #[repr(C)]

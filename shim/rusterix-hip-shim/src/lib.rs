@@ -230,7 +230,10 @@ impl RasterizeHip for Rasterizer {
             *TEXTURE_STAMP.lock().unwrap() = stamp;
         }
 
-        // background: VGrayGradientShader is evaluated on the device; any other `dyn Shader` on the host
+        // background: any `dyn Shader` is evaluated here by the reference's own code and handed over as pixels (bit-identical by
+        // construction).  The device can evaluate VGrayGradientShader (RXR_BG_VGRADIENT) and GridShader (RXR_BG_GRID +
+        // background_grid) itself, but a `Box<dyn Shader>` does not tell which one it is: that needs a `kind()` / parameter
+        // accessor on the trait (a two-line patch to src/shader/mod.rs), after which the pixel loop below is skipped for them.
         let mut bg_pixels: Vec<u8> = vec![];
         let mut background_kind = RXR_BG_NONE;
         if !self.render_mode.ignore_background_shader && !self.render_mode.supports3d() {
@@ -271,6 +274,8 @@ impl RasterizeHip for Rasterizer {
             linedefs: linedefs.as_ptr(), n_linedefs: linedefs.len() as u32,
             chunks: chunks.as_ptr(), n_chunks: chunks.len() as u32,
             n_shader_programs: scene.shaders.len() as u32,
+            use_meshes: 0, view: [0.0; 16], projection: [0.0; 16], mesh_transforms: std::ptr::null(),
+            background_grid: [30.0, 2.0, 0.0, 0.0],
         };
         assert!(pixels.len() >= width * height * 4);
         let rc = unsafe { rxr_rasterize(ctx, &frame, pixels.as_mut_ptr()) };

@@ -148,6 +148,33 @@ def test_2d_matrix_projection(oracle, product):
     assert_exact(got, ref, "2D with Mat3 projection")
 
 
+@pytest.mark.parametrize("params", [
+    dict(),                                                              # GridShader::new(): 30 / 2 / (0, 0)
+    dict(grid_size=17.0, subdivisions=3.0, offset=(5.5, -3.25)),
+    dict(grid_size=8.0, subdivisions=1.0, offset=(-100.0, 250.0)),
+    dict(grid_size=50.0, subdivisions=2.6, offset=(0.25, 0.75)),        # non-integer subdivisions: round() in sub_size, raw in `extra`
+    dict(grid_size=0.0, subdivisions=2.0),                               # division by zero: NaN everywhere -> background colour
+])
+@pytest.mark.parametrize("size", [(320, 200), (333, 211)])
+def test_grid_shader_background(oracle, product, params, size):
+    """F2: GridShader as the scene background (shader/grid.rs), evaluated per pixel on the device, under a 2D rectangle"""
+    def build(api):
+        sh = api.GridShader()
+        if "grid_size" in params:
+            sh.set_parameter_f32("grid_size", params["grid_size"]).set_parameter_f32("subdivisions", params["subdivisions"])
+        if "offset" in params:
+            sh.set_parameter_vec2("offset", params["offset"])
+        scene = api.Scene.empty().background(sh)
+        scene.add_d2_static(api.Batch2D.from_rectangle(40.0, 30.0, 90.0, 60.0).source(B.PixelSource.Pixel((200, 40, 90, 128))))
+        v, p = api.D3OrbitCamera.new().matrices(float(size[0]), float(size[1]))
+        return scenes._result(api, scene, api.Assets.default(), lambda: api.Rasterizer.setup(None, v, p).render_mode(B.RenderMode.render_2d()),
+                              size[0], size[1], 40, "grid")
+
+    got, ref = scenes.render(build(product)), scenes.render(build(oracle))
+    assert_exact(got, ref, f"grid shader {params} {size}")
+    assert len(np.unique(got[..., 0])) >= 2 or params.get("grid_size") == 0.0
+
+
 # ---- 3D -------------------------------------------------------------------------------------------------
 def test_empty_scene_3d_is_black(oracle, product):
     """SURVEY section 8c pin 3: in 3D mode every non-hit pixel is [0,0,0,255] regardless of the background."""

@@ -57,6 +57,32 @@ def test_vgradient_rows(oracle):
     assert (ignore == np.array([1, 2, 3, 4], np.uint8)).all()
 
 
+# 2b. GridShader (shader/grid.rs:36-108) in render_2d mode.  120 x 120, defaults (grid 30, 2 subdivisions, no offset):
+# origin 60 -> aligned origin round(59.5) + 0.5 = 60.5; a pixel is on a grid line when |rel - 30 round(rel / 30)| <= 0.5 with
+# rel = x - 60.5, i.e. the TWO columns either side of 0.5 + 30 k; sub-lines likewise around 15.5 + 30 k.
+def test_grid_shader_lines(oracle):
+    o = oracle
+    w = h = 120
+    v, p = cam(o, w, h)
+    scene = o.Scene.empty().background(o.GridShader())
+    img = render(o, scene, w, h, lambda: o.Rasterizer.setup(None, v, p).render_mode(B.RenderMode.render_2d()))
+    line, sub, bg = 38, 28, 13      # vec4_to_pixel of 0.15 / 0.11 / 0.05: trunc(c * 255 + 0.5)
+    row = img[10]                   # y = 10: 9.5 away from the lines at 0.5 and 20.5 below the sub-line at 15.5... neither
+    want = np.full(w, bg)
+    for k in (0, 30, 60, 90):
+        want[[k, k + 1]] = line
+    for k in (15, 45, 75, 105):
+        want[[k, k + 1]] = sub
+    assert (row[:, 0] == want).all(), np.flatnonzero(row[:, 0] != want)
+    assert (row[:, 3] == 255).all() and (row[:, 0] == row[:, 1]).all() and (row[:, 1] == row[:, 2]).all()
+    assert (img[:, 10, 0] == want).all()      # the shader is symmetric in x and y
+    # parameters: an offset moves the origin, grid_size 40 puts lines 40 apart
+    shader = o.GridShader().set_parameter_f32("grid_size", 40.0).set_parameter_vec2("offset", (7.0, 0.0))
+    img2 = render(o, o.Scene.empty().background(shader), w, h, lambda: o.Rasterizer.setup(None, v, p).render_mode(B.RenderMode.render_2d()))
+    cols = np.flatnonzero(img2[10, :, 0] == line)
+    assert cols.tolist() == [27, 28, 67, 68, 107, 108]      # aligned origin 67.5
+
+
 # 3. 3D mode, empty scene: every pixel [0,0,0,255] regardless of the background (rasterizer.rs:420-461)
 def test_empty_3d_scene_is_black(oracle):
     o = oracle
