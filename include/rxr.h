@@ -266,6 +266,11 @@ typedef struct rxr_frame {
     /* ABI 3 */
     float background_grid[4];         /* RXR_BG_GRID: GridShader.grid_size, .subdivisions, .offset.x, .offset.y
                                          (src/shader/grid.rs:4-8; defaults 30, 2, (0, 0), :12-16)      */
+    uint32_t has_brush_preview;       /* Rasterizer.brush_preview.is_some() (src/rasterizer.rs:13-17, :65): the editor's terrain
+                                         brush, blended over the pixels no 3D fragment reached (:435-458) and into the terrain
+                                         texels of chunk batches (:1192-1213, :1601-1622)               */
+    float brush_position[3];
+    float brush_radius, brush_falloff;
 } rxr_frame;
 
 /* ---- Rusteria shader programs -------------------------------------

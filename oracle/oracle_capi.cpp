@@ -300,6 +300,13 @@ void orc_rasterizer_render_mode(void *r, int d2, int d3, int ignore_bg) {
     x.ignore_background_shader = ignore_bg != 0;
 }
 void orc_rasterizer_sample_mode(void *r, int m) { ((RasterizerBox *)r)->r.sample_mode = m; }
+void orc_rasterizer_brush_preview(void *r, int on, float px, float py, float pz, float radius, float falloff) {
+    Rasterizer &x = *(Rasterizer *)r;
+    x.has_brush_preview = on != 0;
+    x.brush_position = Vec3{px, py, pz};
+    x.brush_radius = radius;
+    x.brush_falloff = falloff;
+}
 void orc_rasterizer_background(void *r, const uint8_t *px) {
     Rasterizer &x = ((RasterizerBox *)r)->r;
     x.has_background_color = px != nullptr;

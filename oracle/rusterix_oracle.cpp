@@ -721,6 +721,22 @@ static inline Vec3 screen_to_world(const Rasterizer &r, float x, float y, float 
     return Vec3{world_space.x, world_space.y, world_space.z};
 }
 
+// src/rasterizer.rs:1841-1869
+static inline void screen_ray(const Rasterizer &r, float x, float y, Vec3 &origin, Vec3 &dir) {
+    float ndc_x = 2.0f * (x / r.width) - 1.0f;
+    float ndc_y = 1.0f - 2.0f * (y / r.height);
+    Vec4 ndc_near{ndc_x, ndc_y, -1.0f, 1.0f}, ndc_far{ndc_x, ndc_y, 1.0f, 1.0f};
+    Vec4 view_near = r.inverse_projection_matrix * ndc_near;
+    Vec4 view_far = r.inverse_projection_matrix * ndc_far;
+    view_near = view_near / view_near.w;
+    view_far = view_far / view_far.w;
+    Vec4 world_near = r.inverse_view_matrix * view_near;
+    Vec4 world_far = r.inverse_view_matrix * view_far;
+    origin = Vec3{world_near.x, world_near.y, world_near.z};
+    Vec3 target{world_far.x, world_far.y, world_far.z};
+    dir = rvek::normalized(target - origin);
+}
+
 // src/rasterizer.rs:1875-1951
 static inline Vec3 shade_fast_brdf(Vec3 base_color, float roughness, float metallic, Vec3 emissive, Vec3 n, Vec3 v,
                                    Vec3 l, Vec3 light_radiance) {
@@ -749,8 +765,10 @@ static inline Vec3 shade_fast_brdf(Vec3 base_color, float roughness, float metal
 // texel switch shared by the three loops; `missing` is what the loop returns for unknown sources.
 // 3D: src/rasterizer.rs:1101-1222 (unknown -> [0,0,0,255]); 2D: :672-758 (unknown -> [0,0,0,0]).
 // Returns false where the reference would panic (3D tile_list[index] unchecked, :1103).
+// `world3`: the fragment's world position in the two 3D loops (the terrain brush preview measures its distance from it,
+// :1192-1213, :1601-1622), nullptr in the 2D loop (no brush preview there, :749-751)
 static inline bool fetch_texel(const FrameCtx &fc, const Source &src, int repeat_mode, float u, float v, bool is_3d,
-                               const Chunk *chunk, Vec2 terrain_pos, uint8_t texel[4]) {
+                               const Chunk *chunk, Vec2 terrain_pos, uint8_t texel[4], const Vec3 *world3 = nullptr) {
     const bool in_chunk = chunk != nullptr;
     const Rasterizer &r = *fc.r;
     auto zero = [&]() { texel[0] = texel[1] = texel[2] = texel[3] = 0; };
@@ -789,6 +807,16 @@ static inline bool fetch_texel(const FrameCtx &fc, const Source &src, int repeat
             if (in_chunk) {
                 // 3D: chunk.sample_terrain_texture(world_2d, Vec2::one()), :1191; 2D: (world, Vec2::one()), :751
                 if (!chunk_sample_terrain_texture(*chunk, terrain_pos, Vec2{1.0f, 1.0f}, texel)) return false;
+                if (r.has_brush_preview && world3) {  // :1193-1212
+                    float dist = rvek::magnitude(*world3 - r.brush_position);
+                    if (dist < r.brush_radius) {
+                        float normalized = dist / r.brush_radius;
+                        float falloff = rclamp(r.brush_falloff, 0.001f, 1.0f);
+                        float fade = rclamp((1.0f - normalized) / falloff, 0.0f, 1.0f);
+                        float blend = 0.2f + 0.6f * fade;
+                        for (int ch = 0; ch < 3; ++ch) texel[ch] = sat_u8(rmin((float)texel[ch] * (1.0f - blend) + 255.0f * blend, 255.0f));
+                    }
+                }
             } else if (is_3d) {
                 texel[0] = 255; texel[1] = 0; texel[2] = 0; texel[3] = 255;  // :1218
             } else {
@@ -908,7 +936,7 @@ static int d3_rasterize(const FrameCtx &fc, uint8_t *buffer, float *z_buffer, co
                 }
 
                 uint8_t texel[4];
-                if (!fetch_texel(fc, batch.source, batch.repeat_mode, interpolated_u, interpolated_v, true, chunk, world_2d, texel))
+                if (!fetch_texel(fc, batch.source, batch.repeat_mode, interpolated_u, interpolated_v, true, chunk, world_2d, texel, &world))
                     return RXR_ERR_INVALID;
 
                 float color[4];
@@ -1067,7 +1095,7 @@ static int d3_rasterize_opacity(const FrameCtx &fc, uint8_t *buffer, float *z_bu
                 Vec2 world_2d{world.x, world.z};
 
                 uint8_t texel[4];
-                if (!fetch_texel(fc, batch.source, batch.repeat_mode, interpolated_u, interpolated_v, true, chunk, world_2d, texel))
+                if (!fetch_texel(fc, batch.source, batch.repeat_mode, interpolated_u, interpolated_v, true, chunk, world_2d, texel, &world))
                     return RXR_ERR_INVALID;
 
                 float color[4];
@@ -1394,8 +1422,26 @@ static int raster_tile(const FrameCtx &fc, const TileRect &tile, std::vector<uin
             for (size_t tx = 0; tx < tile.width; ++tx) {
                 size_t idx = (ty * tile.width + tx) * 4;
                 size_t z_idx = ty * tile.width + tx;
-                if (z_buffer[z_idx] == 1.0f) {  // :420-461 (no miss nodes, no brush preview)
+                if (z_buffer[z_idx] == 1.0f) {  // :420-461 (render-graph miss nodes: none)
                     float color[4] = {0.0f, 0.0f, 0.0f, 1.0f};
+                    if (r.has_brush_preview) {  // :435-458; the ray starts at the pixel's corner, not its centre (:422-423)
+                        Vec3 origin, dir;
+                        screen_ray(r, (float)(tile.x + tx), (float)(tile.y + ty), origin, dir);
+                        if (std::fabs(dir.y) > 1e-5f) {
+                            float t = -origin.y / dir.y;
+                            if (t > 0.0f) {
+                                Vec3 world = origin + dir * t;
+                                float dist = rvek::magnitude(world - r.brush_position);
+                                if (dist < r.brush_radius) {
+                                    float normalized = dist / r.brush_radius;
+                                    float falloff = rclamp(r.brush_falloff, 0.001f, 1.0f);
+                                    float fade = rclamp((1.0f - normalized) / falloff, 0.0f, 1.0f);
+                                    float blend = 0.2f + 0.6f * fade;
+                                    for (int ch = 0; ch < 3; ++ch) color[ch] = rmin(color[ch] * (1.0f - blend) + blend, 1.0f);
+                                }
+                            }
+                        }
+                    }
                     vec4_to_pixel(color, &buffer[idx]);
                 }
                 if (z_buffer_opacity[z_idx] < 1.0f && z_buffer[z_idx] > z_buffer_opacity[z_idx]) {  // :464-495

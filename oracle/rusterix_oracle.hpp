@@ -232,6 +232,10 @@ struct Rasterizer {
     bool has_sun = false;
     Vec3 sun_dir;
     float day_factor = 0.0f;
+    // Rasterizer.brush_preview: Option<BrushPreview> (src/rasterizer.rs:13-17, :65)
+    bool has_brush_preview = false;
+    Vec3 brush_position;
+    float brush_radius = 0.0f, brush_falloff = 0.0f;
 };
 
 // ---- restated functions --------------------------------------------------------------------------

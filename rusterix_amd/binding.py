@@ -410,6 +410,7 @@ def make_api(lib: C.CDLL, prefix: str, name: str):
         rasterizer_render_mode=fn("rasterizer_render_mode", None, vp, i32, i32, i32),
         rasterizer_sample_mode=fn("rasterizer_sample_mode", None, vp, i32),
         rasterizer_background=fn("rasterizer_background", None, vp, pb),
+        rasterizer_brush_preview=fn("rasterizer_brush_preview", None, vp, i32, f32, f32, f32, f32, f32),
         rasterizer_ambient=fn("rasterizer_ambient", None, vp, pf),
         rasterizer_time=fn("rasterizer_time", None, vp, f32),
         rasterizer_preserve_transparency=fn("rasterizer_preserve_transparency", None, vp, i32),
@@ -792,6 +793,15 @@ def make_api(lib: C.CDLL, prefix: str, name: str):
         def background(self, pixel):
             px = (C.c_uint8 * 4)(*pixel)
             L.rasterizer_background(self._h, px)
+            return self
+
+        def brush_preview(self, position, radius, falloff):
+            """`rasterizer.brush_preview = Some(BrushPreview { position, radius, falloff })` (a public field in the reference,
+            src/rasterizer.rs:13-17, :65); position None = `None`"""
+            if position is None:
+                L.rasterizer_brush_preview(self._h, 0, 0.0, 0.0, 0.0, 0.0, 0.0)
+            else:
+                L.rasterizer_brush_preview(self._h, 1, float(position[0]), float(position[1]), float(position[2]), float(radius), float(falloff))
             return self
 
         def ambient(self, v4):

@@ -244,6 +244,15 @@ void rxh_rasterizer_render_mode(void *r, int d2, int d3, int ignore_bg) {
     x->ignore_background_shader = ignore_bg != 0;
 }
 void rxh_rasterizer_sample_mode(void *r, int m) { ((Rasterizer *)r)->sample_mode_ = (uint32_t)m; }
+void rxh_rasterizer_brush_preview(void *r, int on, float px, float py, float pz, float radius, float falloff) {
+    Rasterizer *x = (Rasterizer *)r;
+    x->has_brush_preview = on != 0;
+    x->brush_position[0] = px;
+    x->brush_position[1] = py;
+    x->brush_position[2] = pz;
+    x->brush_radius = radius;
+    x->brush_falloff = falloff;
+}
 void rxh_rasterizer_background(void *r, const uint8_t *px) {
     Rasterizer *x = (Rasterizer *)r;
     x->has_background_color = px != nullptr;

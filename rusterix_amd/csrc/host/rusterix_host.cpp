@@ -747,6 +747,10 @@ int Rasterizer::upload(Scene &scene, size_t w, size_t h, size_t tile_size, const
     f.time = time_;
     f.background_kind = scene.background;
     memcpy(f.background_grid, scene.background_grid, 16);
+    f.has_brush_preview = has_brush_preview ? 1u : 0u;
+    memcpy(f.brush_position, brush_position, 12);
+    f.brush_radius = brush_radius;
+    f.brush_falloff = brush_falloff;
     f.batches3d = b3.data();
     f.n_batches3d = (uint32_t)b3.size();
     f.batches2d = b2.data();

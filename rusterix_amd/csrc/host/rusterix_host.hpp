@@ -211,6 +211,10 @@ public:
     uint32_t hash_anim = 0;
     bool has_background_color = false;
     uint8_t background_color[4] = {0, 0, 0, 0};
+    // brush_preview: Option<BrushPreview> (src/rasterizer.rs:13-17, :65)
+    bool has_brush_preview = false;
+    float brush_position[3] = {0, 0, 0};
+    float brush_radius = 0.0f, brush_falloff = 0.0f;
     bool has_ambient = false;
     Vec4 ambient_color;
     Vec2 translationd2{0, 0};

@@ -1103,6 +1103,10 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
     P.background_color = pack_px(f->background_color);
     P.background_kind = f->background_kind;
     memcpy(P.bg_grid, f->background_grid, 16);
+    P.has_brush = f->has_brush_preview ? 1u : 0u;
+    memcpy(P.brush_pos, f->brush_position, 12);
+    P.brush_radius = f->brush_radius;
+    P.brush_falloff = f->brush_falloff;
     memcpy(P.ambient, f->ambient, 16);
     memcpy(P.sun_dir, f->sun_dir, 12);
     P.day_factor = f->day_factor;
@@ -1121,7 +1125,8 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
         return fail(ctx, RXR_ERR_UNSUPPORTED, "a 2D batch's program reads hitpoint while 3D batches run programs: hitpoint.z would hold the tile's last 3D program fragment's");
     ctx->frame_uses_programs = uses_programs;
     P.vm_code = (const uint32_t *)ctx->d_vm_code.p;
-    P.kernel_level = std::max(ctx->min_kernel_level, uses_programs ? 2u : (uses_chunk_tex ? 1u : 0u));
+    // (the brush preview is editor-only: it lives in the feature levels >= 1 so that k_raster does not carry it)
+    P.kernel_level = std::max(ctx->min_kernel_level, uses_programs ? 2u : ((uses_chunk_tex || (P.has_brush && (f->flags & RXR_FLAG_D3_ACTIVE))) ? 1u : 0u));
     P.programs = (const DevProgram *)ctx->d_programs.p;
     P.patterns = (const DevPattern *)ctx->d_patterns.p;
     P.pattern_data = (const float *)ctx->d_pattern_data.p;

@@ -235,6 +235,8 @@ struct RasterParams {
     uint32_t *vm_fault;                // pinned host word: a non-zero VMF_* code if any fragment's program faulted
     float time;                        // Rasterizer.time
     float bg_grid[4];                  // RXR_BG_GRID: grid_size, subdivisions, offset.x, offset.y
+    uint32_t has_brush;                // Rasterizer.brush_preview (feature level >= 1)
+    float brush_pos[3], brush_radius, brush_falloff;
 
     const DevTexDesc *tex;             // resident textures first, then this frame's chunk textures
     const uint32_t *frame_texels;      // texel base of the latter (inside the frame blob)

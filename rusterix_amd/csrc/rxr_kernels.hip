@@ -417,12 +417,40 @@ __device__ __forceinline__ uint32_t terrain_texel(const RasterParams &P, const D
     return texel_base(P, d)[d.offset + py * d.w + px];
 }
 
-// the texel switch of the raster loops (rasterizer.rs:1101-1222, :672-758); (wx, wy) is the position terrain batches sample at
+// Rasterizer.brush_preview over a terrain texel (rasterizer.rs:1193-1212, :1601-1622): a white disc around the brush position,
+// 20 % .. 80 % opaque, blended into RGB with `as u8` truncation; `world` is the fragment's world position
+__device__ __forceinline__ float brush_blend(const RasterParams &P, f3 world, bool &inside) {
+    const float dist = mag3(sub3(world, mk3(P.brush_pos[0], P.brush_pos[1], P.brush_pos[2])));
+    inside = dist < P.brush_radius;
+    const float normalized = dist / P.brush_radius;
+    const float falloff = rclamp(P.brush_falloff, 0.001f, 1.0f);
+    const float fade = rclamp((1.0f - normalized) / falloff, 0.0f, 1.0f);
+    return 0.2f + 0.6f * fade;
+}
+__device__ __forceinline__ uint32_t brush_over_texel(const RasterParams &P, uint32_t texel, f3 world) {
+    bool inside;
+    const float blend = brush_blend(P, world, inside);
+    if (!inside) return texel;
+    uint32_t out = texel & 0xFF000000u;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float c = (float)((texel >> (8 * i)) & 0xFFu);
+        out |= sat_u8(fminf(c * (1.0f - blend) + 255.0f * blend, 255.0f)) << (8 * i);
+    }
+    return out;
+}
+
+// the texel switch of the raster loops (rasterizer.rs:1101-1222, :672-758); (wx, wy) is the position terrain batches sample at;
+// `world3`: the fragment's world position in the two 3D loops (terrain brush preview), nullptr in the 2D loop
 template <int X>
-__device__ __forceinline__ uint32_t batch_texel(const RasterParams &P, const DevBatch &B, float u, float v, float wx, float wy) {
+__device__ __forceinline__ uint32_t batch_texel(const RasterParams &P, const DevBatch &B, float u, float v, float wx, float wy, const f3 *world3 = nullptr) {
     if (B.tex < 0) return B.pixel;
     if constexpr (X >= 1) {
-        if (B.flags & DB_TERRAIN) return terrain_texel(P, B, wx, wy);
+        if (B.flags & DB_TERRAIN) {
+            uint32_t t = terrain_texel(P, B, wx, wy);
+            if (P.has_brush && world3) t = brush_over_texel(P, t, *world3);
+            return t;
+        }
     }
     const DevTexDesc &d = P.tex[B.tex];
     return sample_texture(d, texel_base(P, d), u, v, P.sample_mode, B.repeat_mode);
@@ -468,7 +496,7 @@ __device__ __forceinline__ void shade3d_begin(const RasterParams &P, const TriSh
         normal = mk3(0.0f, 0.0f, 0.0f);
     }
 
-    uint32_t texel = batch_texel<X>(P, B, u, v, world.x, world.z);
+    uint32_t texel = batch_texel<X>(P, B, u, v, world.x, world.z, &world);
     const float INV_255 = 1.0f / 255.0f;  // lib.rs:52
     f3 base = mk3(srgb_to_linear_fast((float)(texel & 0xFFu) * INV_255), srgb_to_linear_fast((float)((texel >> 8) & 0xFFu) * INV_255),
                   srgb_to_linear_fast((float)((texel >> 16) & 0xFFu) * INV_255));
@@ -657,7 +685,8 @@ __device__ __forceinline__ uint32_t shade3d_opacity(const RasterParams &P, const
         vw = vw / vw;
         mat4_mul(P.inv_view, vx, vy, vz, vw, wx, wy, wz, ww);
     }
-    uint32_t texel = batch_texel<X>(P, B, u, v, wx, wz);
+    const f3 world3 = mk3(wx, wy, wz);
+    uint32_t texel = batch_texel<X>(P, B, u, v, wx, wz, &world3);
     const float INV_255 = 1.0f / 255.0f;
     float r = srgb_to_linear_fast((float)(texel & 0xFFu) * INV_255);
     float g = srgb_to_linear_fast((float)((texel >> 8) & 0xFFu) * INV_255);
@@ -778,6 +807,34 @@ __device__ __forceinline__ uint32_t fragment2d(const RasterParams &P, const Prim
     uint32_t ob = sat_u8(((float)tb * src_alpha) + ((float)db * dst_alpha));
     uint32_t oa = (P.flags & RXR_FLAG_PRESERVE_TRANSPARENCY) ? max(da, ta) : 255u;
     return pack4(orr, og, ob, oa);
+}
+
+// A pixel no 3D fragment reached, with a brush preview (rasterizer.rs:420-461): screen_ray (:1841-1869) through the pixel's
+// CORNER ((tile.x + tx) as f32, no + 0.5, :422-423), intersected with the plane y = 0, white blended over black.
+__device__ __noinline__ uint32_t miss_brush_preview(const RasterParams &P, uint32_t px, uint32_t py) {
+    const float ndc_x = 2.0f * ((float)px / P.fwidth) - 1.0f;
+    const float ndc_y = 1.0f - 2.0f * ((float)py / P.fheight);
+    float nx, ny, nz, nw, fx_, fy_, fz_, fw_;
+    mat4_mul(P.inv_proj, ndc_x, ndc_y, -1.0f, 1.0f, nx, ny, nz, nw);
+    mat4_mul(P.inv_proj, ndc_x, ndc_y, 1.0f, 1.0f, fx_, fy_, fz_, fw_);
+    nx = nx / nw; ny = ny / nw; nz = nz / nw; nw = nw / nw;
+    fx_ = fx_ / fw_; fy_ = fy_ / fw_; fz_ = fz_ / fw_; fw_ = fw_ / fw_;
+    float ox, oy, oz, ow, tx, ty, tz, tw;
+    mat4_mul(P.inv_view, nx, ny, nz, nw, ox, oy, oz, ow);
+    mat4_mul(P.inv_view, fx_, fy_, fz_, fw_, tx, ty, tz, tw);
+    const f3 origin = mk3(ox, oy, oz);
+    const f3 dir = norm3(sub3(mk3(tx, ty, tz), origin));
+    float c = 0.0f;
+    if (fabsf(dir.y) > 1e-5f) {
+        const float t = -origin.y / dir.y;
+        if (t > 0.0f) {
+            bool inside;
+            const float blend = brush_blend(P, add3(origin, scale3(dir, t)), inside);
+            if (inside) c = fminf(0.0f * (1.0f - blend) + blend, 1.0f);
+        }
+    }
+    const uint32_t g = f32_to_u8_saturated(c);
+    return pack4(g, g, g, f32_to_u8_saturated(1.0f));
 }
 
 // bins (launch-local tile rows l0..l1, tile columns bx0..bx1) touched by a clamped pixel box
@@ -1871,6 +1928,9 @@ __device__ __forceinline__ void raster_tile(const RasterParams &P) {
         if (P.n_lights) shade3d_lights<X>(P, hit, F);  // wave-uniform call
         PHASE_MARK(3);
         color = hit ? shade3d_end(F) : pack4(0u, 0u, 0u, 255u);
+        if constexpr (X >= 1) {
+            if (P.has_brush && !hit) color = miss_brush_preview(P, px, py);  // :435-458
+        }
         PHASE_MARK(4);
         if (op.best >= 0 && op.zmin < 1.0f && vis.zmin > op.zmin) {  // :464-495
             uint32_t src = op_color;

@@ -219,6 +219,10 @@ pub struct rxr_frame {
     pub projection: [f32; 16],
     pub mesh_transforms: *const f32,
     pub background_grid: [f32; 4],
+    pub has_brush_preview: u32,
+    pub brush_position: [f32; 3],
+    pub brush_radius: f32,
+    pub brush_falloff: f32,
 }
 
 #[repr(C)]

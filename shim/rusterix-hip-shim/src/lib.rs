@@ -276,6 +276,10 @@ impl RasterizeHip for Rasterizer {
             n_shader_programs: scene.shaders.len() as u32,
             use_meshes: 0, view: [0.0; 16], projection: [0.0; 16], mesh_transforms: std::ptr::null(),
             background_grid: [30.0, 2.0, 0.0, 0.0],
+            has_brush_preview: self.brush_preview.is_some() as u32,
+            brush_position: self.brush_preview.as_ref().map(|b| b.position.into_array()).unwrap_or([0.0; 3]),
+            brush_radius: self.brush_preview.as_ref().map(|b| b.radius).unwrap_or(0.0),
+            brush_falloff: self.brush_preview.as_ref().map(|b| b.falloff).unwrap_or(0.0),
         };
         assert!(pixels.len() >= width * height * 4);
         let rc = unsafe { rxr_rasterize(ctx, &frame, pixels.as_mut_ptr()) };

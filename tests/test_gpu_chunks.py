@@ -31,14 +31,16 @@ def floor_quad(api, x0, z0, x1, z1, y=0.0):
     return api.Batch3D.new(v, i, uv).with_computed_normals().cull_mode(B.CULL_OFF)
 
 
-def terrain_scene(api, holes=False, with_texture=True, lights=True, origin=(0, 0), size=8, tex_w=64):
+def terrain_scene(api, holes=False, with_texture=True, lights=True, origin=(0, 0), size=8, tex_w=64, brush=None, under=True, opacity_terrain=False):
     scene = api.Scene.empty()
-    under = floor_quad(api, -2.0, -2.0, 10.0, 10.0, y=-0.5).source(B.PixelSource.Pixel((40, 60, 200, 255)))
-    scene.add_d3_static(under)
+    if under:
+        scene.add_d3_static(floor_quad(api, -2.0, -2.0, 10.0, 10.0, y=-0.5).source(B.PixelSource.Pixel((40, 60, 200, 255))))
     chunk = scene.add_chunk()
     chunk.terrain(terrain_texture(11, tex_w, tex_w, holes) if with_texture else None, origin=origin, size=size)
     chunk.terrain_batch3d(floor_quad(api, 0.0, 0.0, 8.0, 8.0).source(B.PixelSource.Terrain()))
     chunk.add_batch3d(api.Batch3D.from_box(3.0, 0.0, 3.0, 1.0, 1.0, 1.0).with_computed_normals().source(B.PixelSource.Pixel((200, 180, 40, 255))))
+    if opacity_terrain:   # a terrain-textured pane in the opacity pass (rasterizer.rs:1596-1625)
+        chunk.add_batch3d_opacity(floor_quad(api, 1.0, 5.0, 7.0, 7.5, y=0.6).source(B.PixelSource.Terrain()))
     if lights:
         scene.lights([B.Light(B.LIGHT_POINT).with_position((4.0, 2.0, 4.0)).with_color((1.0, 0.9, 0.8)).with_intensity(2.0)
                       .with_start_distance(1.0).with_end_distance(9.0).compile()])
@@ -51,7 +53,10 @@ def terrain_scene(api, holes=False, with_texture=True, lights=True, origin=(0, 0
 
     def setup():
         v, p = cam.matrices(float(W), float(H))
-        return api.Rasterizer.setup(None, v, p).ambient((0.6, 0.6, 0.6, 1.0))
+        r = api.Rasterizer.setup(None, v, p).ambient((0.6, 0.6, 0.6, 1.0))
+        if brush is not None:
+            r.brush_preview(*brush)
+        return r
 
     return scenes._result(api, scene, assets, setup, W, H, 40, "chunk-terrain")
 
@@ -232,3 +237,18 @@ def test_surface_id_order_matters_in_this_scene(oracle):
     a = scenes.render(two_window_scene(oracle, False))
     b = scenes.render(two_window_scene(oracle, True))
     assert (a != b).any(axis=2).mean() > 0.01, "the scene is meant to expose the order dependence"
+
+
+@pytest.mark.parametrize("brush", [((4.0, 0.0, 4.0), 2.5, 0.5), ((1.0, 0.0, 7.0), 6.0, 0.0), ((9.5, 0.0, -1.0), 3.0, 5.0), ((4.0, 0.3, 4.0), 0.0, 1.0)])
+def test_brush_preview_on_terrain_texels_and_on_missed_pixels(oracle, product, brush):
+    """Rasterizer.brush_preview (rasterizer.rs:13-17): a white disc blended into the terrain texels of chunk batches (:1192-1213,
+    opacity pass :1601-1622) and over the pixels no 3D fragment reached (:435-458: screen_ray through the pixel corner, plane
+    y = 0).  Without the blue floor under the terrain the frame has missed pixels around it."""
+    got = compare(oracle, product, lambda api: terrain_scene(api, lights=False, brush=brush, under=False, opacity_terrain=True))
+    plain = scenes.render(terrain_scene(product, lights=False, under=False, opacity_terrain=True))
+    if brush[1] > 0.0:
+        assert (got != plain).any(), "the brush left no trace"
+
+
+def test_brush_preview_with_lights_and_holes(oracle, product):
+    compare(oracle, product, lambda api: terrain_scene(api, holes=True, brush=((3.0, 0.0, 5.0), 3.0, 0.4)), tol=TOLERANCE)

@@ -92,6 +92,23 @@ def test_empty_3d_scene_is_black(oracle):
     assert (img == np.array([0, 0, 0, 255], np.uint8)).all()
 
 
+# 3b. brush preview over missed pixels (rasterizer.rs:435-458): the ray of pixel (W/2, H/2) goes through the pixel's CORNER,
+# i.e. NDC (0, 0), i.e. the camera's centre; with the brush there the distance is 0, fade 1, blend 0.8 -> 0.8 * 255 + 0.5 = 204
+def test_brush_preview_over_missed_pixels(oracle):
+    o = oracle
+    w, h = 96, 64
+    camera = o.D3OrbitCamera.new()
+    camera.set_parameter_f32("distance", 5.0)
+    v, p = camera.matrices(float(w), float(h))
+    img = render(o, o.Scene.empty(), w, h, lambda: o.Rasterizer.setup(None, v, p).brush_preview((0.0, 0.0, 0.0), 2.0, 0.5))
+    assert tuple(img[h // 2, w // 2]) == (204, 204, 204, 255)
+    assert tuple(img[0, 0]) == (0, 0, 0, 255)                      # the ray of the top-left pixel points above the horizon
+    inside = img[..., 0] > 0
+    assert 51 <= img[..., 0][inside].min() <= 60                  # the rim of the disc: blend -> 0.2
+    none = render(o, o.Scene.empty(), w, h, lambda: o.Rasterizer.setup(None, v, p).brush_preview(None, 0.0, 0.0))
+    assert (none == np.array([0, 0, 0, 255], np.uint8)).all()
+
+
 # 4. sample_nearest: round half away from zero (texture.rs:307-323)
 def test_sample_nearest_rounding(oracle):
     o = oracle
