@@ -144,9 +144,10 @@ def _result(api, scene, assets, setup, width, height, tile_size, name, **extra):
 
 
 def cube_scene(api, width=800, height=600, tile_size=200, textured=False, distance=20.0, sample_mode=B.SAMPLE_NEAREST,
-               logo_size=1024):
-    """C1: benches/rasterize_cube.rs:7-33 (+ with_computed_normals, else the reference panics)."""
-    rect = api.Batch2D.from_rectangle(0.0, 0.0, 200.0, 200.0)
+               logo_size=1024, rect_size=200.0):
+    """C1: benches/rasterize_cube.rs:7-33 (+ with_computed_normals, else the reference panics).  `rect_size`: side of the 2D
+    rectangle drawn over the frame (200 in the reference's drivers; thumbnails use a smaller one so that the 3D part shows)."""
+    rect = api.Batch2D.from_rectangle(0.0, 0.0, float(rect_size), float(rect_size))
     box = api.Batch3D.from_box(-0.5, -0.5, -0.5, 1.0, 1.0, 1.0).cull_mode(B.CULL_OFF).with_computed_normals()
     if textured:
         rect.source(B.PixelSource.StaticTileIndex(0))
@@ -163,7 +164,7 @@ def cube_scene(api, width=800, height=600, tile_size=200, textured=False, distan
     return _result(api, scene, assets, setup, width, height, tile_size, "C1-cube")
 
 
-def teapot_scene(api, width=1920, height=1080, tile_size=60, obj_text=None, with_light=False, logo_size=1024):
+def teapot_scene(api, width=1920, height=1080, tile_size=60, obj_text=None, with_light=False, logo_size=1024, rect_size=200.0):
     """C2: examples/obj.rs:28-83 with the point light dropped (BASELINE.json: "no lights")."""
     if obj_text is not None:
         mesh = api.Batch3D.from_obj(obj_text)
@@ -172,7 +173,7 @@ def teapot_scene(api, width=1920, height=1080, tile_size=60, obj_text=None, with
         mesh = api.Batch3D.new(v, i, uv)
     mesh = (mesh.source(B.PixelSource.StaticTileIndex(0)).repeat_mode(B.REPEAT_REPEAT_XY)
             .transform(B.Mat4.scaling_3d((0.35, -0.35, 0.35))).with_computed_normals())
-    scene = api.Scene.from_static([api.Batch2D.from_rectangle(0.0, 0.0, 200.0, 200.0)], [mesh])
+    scene = api.Scene.from_static([api.Batch2D.from_rectangle(0.0, 0.0, float(rect_size), float(rect_size))], [mesh])
     scene.background(api.VGrayGradientShader())
     if with_light:
         scene.lights([B.Light(B.LIGHT_POINT).with_intensity(1.0).with_color((1.0, 1.0, 0.95))
@@ -221,7 +222,7 @@ def map_assets(api, logo_size=1024):
     return api.Assets.default().textures(tiles)
 
 
-def map_scene(api, width=1920, height=1080, tile_size=40, n_lights=1, logo_size=1024, sample_mode=B.SAMPLE_NEAREST):
+def map_scene(api, width=1920, height=1080, tile_size=40, n_lights=1, logo_size=1024, sample_mode=B.SAMPLE_NEAREST, rect_size=200.0):
     """C3 (n_lights=1) / C4 (n_lights=16, 3840x2160): the minigame room synthesised from
     minigame/world.rxm (the reference's own builder is stubbed at this snapshot)."""
     box = 15.0
@@ -242,7 +243,7 @@ def map_scene(api, width=1920, height=1080, tile_size=40, n_lights=1, logo_size=
     fence = _batch_of_quads(api, [_quad_wall(6, box, 6, 9, hgt), _quad_wall(6, 9, 0, 9, hgt)])
     fence = (fence.source(B.PixelSource.StaticTileIndex(MAP_TILES["fence"])).repeat_mode(B.REPEAT_REPEAT_XY)
              .with_computed_normals())
-    logo = (api.Batch2D.from_rectangle(0.0, 0.0, 200.0, 200.0).receives_light(False)
+    logo = (api.Batch2D.from_rectangle(0.0, 0.0, float(rect_size), float(rect_size)).receives_light(False)
             .source(B.PixelSource.StaticTileIndex(MAP_TILES["logo"])))
     scene = api.Scene.from_static([logo], [floor, walls, panel, fence]).background(api.VGrayGradientShader())
 
@@ -368,6 +369,44 @@ def tile_map_2d_scene(api, width=640, height=400, nx=30, ny=20, stacked=0, lines
                 .ambient((0.4, 0.4, 0.4, 1.0)).mapmini_add_linedef((200.0, 0.0), (200.0, 150.0)))
 
     return _result(api, scene, assets, setup, width, height, 40, "rects")
+
+
+def grid_editor_scene(api, width=320, height=200, grid_size=30.0, subdivisions=2.0, offset=(0.0, 0.0)):
+    """The 2D editor's view: GridShader background (reference src/shader/grid.rs) under a textured and a translucent rectangle."""
+    shader = api.GridShader().set_parameter_f32("grid_size", grid_size).set_parameter_f32("subdivisions", subdivisions).set_parameter_vec2("offset", offset)
+    scene = api.Scene.empty().background(shader)
+    scene.add_d2_static(api.Batch2D.from_rectangle(width * 0.1, height * 0.15, width * 0.3, height * 0.4).source(B.PixelSource.StaticTileIndex(0)))
+    scene.add_d2_static(api.Batch2D.from_rectangle(width * 0.3, height * 0.4, width * 0.4, height * 0.3).source(B.PixelSource.Pixel((200, 40, 90, 128))))
+    assets = api.Assets.default().textures([B.Tile.from_texture(noise_texture(910, 16, 16))])
+    v, p = api.D3OrbitCamera.new().matrices(float(width), float(height))
+    return _result(api, scene, assets, lambda: api.Rasterizer.setup(None, v, p).render_mode(B.RenderMode.render_2d()), width, height, 40, "grid-editor")
+
+
+def small_triangle_mesh_scene(api, width=320, height=200, n_triangles=1500, brush=None):
+    """A cloud of small textured triangles, submitted twice (exact depth ties), over an empty background: the binned pipeline's
+    row-parallel visibility; `brush` = (position, radius, falloff) adds the editor's brush preview over the missed pixels."""
+    rng = _rng(920)
+    centre = rng.normal(0.0, 1.0, size=(n_triangles, 1, 3)) * np.array([1.3, 0.8, 1.0])
+    verts = (centre + rng.normal(0.0, 0.07, size=(n_triangles, 3, 3))).reshape(-1, 3).astype(np.float32)
+    v4 = np.concatenate([verts, np.ones((len(verts), 1), np.float32)], axis=1)
+    idx = np.arange(n_triangles * 3, dtype=np.uint32).reshape(n_triangles, 3)
+    uv = (rng.random((n_triangles * 3, 2)) * 2.0).astype(np.float32)
+    scene = api.Scene.empty()
+    for k in range(2):
+        b = api.Batch3D.new(v4.copy(), idx.copy(), uv.copy()).with_computed_normals().cull_mode(B.CULL_OFF)
+        scene.add_d3_static(b.source(B.PixelSource.StaticTileIndex(k)).repeat_mode(B.REPEAT_REPEAT_XY).ambient_color((0.9, 0.8, 0.7)))
+    assets = api.Assets.default().textures([B.Tile.from_texture(noise_texture(921 + k, 16, 16)) for k in range(2)])
+    cam = api.D3OrbitCamera.new()
+    cam.set_parameter_f32("distance", 3.0)
+
+    def setup():
+        v, p = cam.matrices(float(width), float(height))
+        r = api.Rasterizer.setup(None, v, p)
+        if brush is not None:
+            r.brush_preview(*brush)
+        return r
+
+    return _result(api, scene, assets, setup, width, height, 40, "small-triangle-mesh")
 
 
 def render(cfg, out=None):
