@@ -22,6 +22,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+PROFILE_STRIDE = int(os.environ.get("RXR_BENCH_PROFILE_STRIDE", "8"))             # every 8th frame of the timed region carries HIP events around its kernels
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 vector (FMA counted as 2)
 
@@ -138,6 +139,10 @@ def main():
 
     run(args.warmup)
     fence()
+    # kernel durations are measured live with HIP events on the launch stream, on every PROFILE_STRIDE-th frame of the
+    # timed region: three event records per frame idle the GPU for 10-25 us, a tenth of this frame
+    rxr.rxr_profile_stride.argtypes = [C.c_void_p, C.c_uint32]
+    check(rxr.rxr_profile_stride(ctx, PROFILE_STRIDE))
     check(rxr.rxr_profile_begin(ctx, args.steps))
     fence()
     t0 = time.perf_counter()
@@ -211,6 +216,7 @@ def main():
                 "traffic": MEASURED_TRAFFIC_4K["fetch_x2"] + MEASURED_TRAFFIC_4K["write"] if default_workload else None,
                 "algorithmic_bytes_per_launch": int(alg),
                 "kernel_avg_us": round(raster_avg_us, 2),
+                "kernel_samples": int(n_prof.value),
                 "setup_kernels_avg_us": round(setup_avg_us, 2),
                 "measured_traffic_bytes_4k_1gpu": MEASURED_TRAFFIC_4K,
                 "valu": {

@@ -335,7 +335,9 @@ typedef struct rxr_shader_set {
     uint32_t n_palette;
 } rxr_shader_set;
 
-/* timings of the last rendered frame (HIP events on the context's stream), microseconds */
+/* the last rendered frame.  The *_us fields (HIP events around the kernels, microseconds) are only measured while
+ * profiling is on (rxr_profile_begin with n > 0) and are 0 otherwise: an event record idles the GPU for a few
+ * microseconds per kernel boundary, a tenth of a small 1080p frame. */
 typedef struct rxr_stats {
     float setup_us;      /* triangle set-up + binning kernels */
     float raster_us;     /* the tile raster / shade kernel    */
@@ -411,8 +413,12 @@ int rxr_render_stripes_to(rxr_ctx *ctx, uint32_t first, uint32_t stride, void *d
 
 /* per-launch kernel timing for the benchmark: after rxr_profile_begin(ctx, n) every render records
  * HIP events (on the stream it launches on) around its set-up kernels and its raster kernel into a
- * ring of n slots; rxr_profile_read synchronizes and returns the durations in microseconds. */
+ * ring of n slots; rxr_profile_read synchronizes and returns the durations in microseconds.
+ * rxr_profile_begin(ctx, 0) switches the event records off again (the default). */
 int rxr_profile_begin(rxr_ctx *ctx, uint32_t max_frames);
+/* sample every `stride`-th render only (default 1): three event records per frame cost 10-25 us of GPU idle time, so a
+ * benchmark that wants its kernel durations measured live without paying that on every frame samples, e.g., 1 in 8 */
+int rxr_profile_stride(rxr_ctx *ctx, uint32_t stride);
 int rxr_profile_read(rxr_ctx *ctx, float *setup_us, float *raster_us, uint32_t capacity, uint32_t *n_out);
 
 /* copies rows [row0,row1) of the context's framebuffer into host `pixels` (full-frame layout:

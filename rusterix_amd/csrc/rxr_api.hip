@@ -78,6 +78,7 @@ enum : uint32_t { PF_UV = 1, PF_ROUGHNESS = 2, PF_METALLIC = 4, PF_OPACITY = 8, 
 struct rxr_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    uint32_t prof_stride = 1, prof_calls = 0;  // rxr_profile_stride: every prof_stride-th render records events
     hipStream_t copy_stream = nullptr;   // rxr_rasterize: downloads of finished bands overlap the rendering of the next ones
     hipEvent_t ev_band[8] = {};
     std::string err;
@@ -1237,8 +1238,11 @@ static int render_impl(rxr_ctx *ctx, const RenderSpec &spec, void *dev_pixels, h
     P.out_base_row = (spec.external && !spec.compact) ? (int64_t)spec.row0 : 0;
     const size_t n_bins = (size_t)P.tiles_x * P.tiles_y;
 
-    hipEvent_t e0 = ctx->ev0, e1 = ctx->ev1, e2 = ctx->ev2;
-    if (!ctx->prof.empty()) {
+    // Kernel timing is opt-in (rxr_profile_begin): every event record is a barrier packet that idles the GPU for a few
+    // microseconds, which is a tenth of a 1080p frame of a small scene.  Without it rxr_stats' *_us fields stay zero.
+    const bool timed = !ctx->prof.empty() && (ctx->prof_calls++ % ctx->prof_stride) == 0u;
+    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+    if (timed) {
         ProfSlot &ps = ctx->prof[ctx->prof_next % ctx->prof.size()];
         e0 = ps.e0;
         e1 = ps.e1;
@@ -1248,7 +1252,7 @@ static int render_impl(rxr_ctx *ctx, const RenderSpec &spec, void *dev_pixels, h
     ctx->last_e0 = e0;
     ctx->last_e1 = e1;
     ctx->last_e2 = e2;
-    HIPCHK(ctx, hipEventRecord(e0, s));
+    if (timed) HIPCHK(ctx, hipEventRecord(e0, s));
     // small scenes: one staging round of k_raster holds every triangle -> no set-up / binning launches at all
     const bool d3 = P.tiles_y && (P.flags & RXR_FLAG_D3_ACTIVE);
     P.fused_small = (d3 && P.n_tris3d <= RXR_STAGE_TRIS) ? ctx->small_mode : 0u;
@@ -1319,9 +1323,9 @@ static int render_impl(rxr_ctx *ctx, const RenderSpec &spec, void *dev_pixels, h
         ctx->h_counters[CNT_WORDS + CNT_ENTRIES] = 0;
         ctx->h_counters[CNT_WORDS + CNT_OVERFLOW] = 0;
     }
-    HIPCHK(ctx, hipEventRecord(e1, s));
+    if (timed) HIPCHK(ctx, hipEventRecord(e1, s));
     rxr_launch_raster(&P, s);
-    HIPCHK(ctx, hipEventRecord(e2, s));
+    if (timed) HIPCHK(ctx, hipEventRecord(e2, s));
     HIPCHK(ctx, hipGetLastError());
     ctx->scratch_dirty = false;  // the raster launch that hands the bins back is queued
     ctx->scratch2d_dirty = false;
@@ -1395,6 +1399,7 @@ int rxr_profile_begin(rxr_ctx *ctx, uint32_t max_frames) {
     }
     ctx->prof.clear();
     ctx->prof_next = 0;
+    ctx->prof_calls = 0;
     if (max_frames > 65536) max_frames = 65536;
     for (uint32_t i = 0; i < max_frames; ++i) {
         ProfSlot p{};
@@ -1403,6 +1408,13 @@ int rxr_profile_begin(rxr_ctx *ctx, uint32_t max_frames) {
         HIPCHK(ctx, hipEventCreate(&p.e2));
         ctx->prof.push_back(p);
     }
+    return RXR_OK;
+}
+
+int rxr_profile_stride(rxr_ctx *ctx, uint32_t stride) {
+    if (!ctx || stride == 0) return RXR_ERR_INVALID;
+    ctx->prof_stride = stride;
+    ctx->prof_calls = 0;
     return RXR_OK;
 }
 

@@ -27,7 +27,7 @@ def test_header_declares_the_expected_entry_points():
     names = declared_functions()
     for must in ["rxr_create", "rxr_destroy", "rxr_last_error", "rxr_device_count", "rxr_set_textures", "rxr_upload_frame",
                  "rxr_render_rows", "rxr_render_rows_to", "rxr_render_stripes_to", "rxr_download_rows", "rxr_rasterize", "rxr_render_download",
-                 "rxr_synchronize", "rxr_get_stats", "rxr_device_framebuffer", "rxr_profile_begin", "rxr_profile_read",
+                 "rxr_synchronize", "rxr_get_stats", "rxr_device_framebuffer", "rxr_profile_begin", "rxr_profile_read", "rxr_profile_stride",
                  "rxr_set_meshes", "rxr_read_projected_mesh", "rxr_set_shaders", "rxr_selftest_math"]:
         assert must in names, must
 

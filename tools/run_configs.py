@@ -107,12 +107,23 @@ def main():
         ru = (C.c_float * args.frames)()
         n = C.c_uint32()
         rxr.rxr_profile_read(ctx, su, ru, args.frames, C.byref(n))
+        # the same loop without per-kernel event records (what a caller that does not profile gets)
+        rxr.rxr_profile_begin(ctx, 0)
+        for _ in range(3):
+            rxr.rxr_render_rows(ctx, 0, H)
+        rxr.rxr_synchronize(ctx)
+        t0 = time.perf_counter()
+        for _ in range(args.frames):
+            rxr.rxr_render_rows(ctx, 0, H)
+        rxr.rxr_synchronize(ctx)
+        t_loop_untimed = (time.perf_counter() - t0) / args.frames
         st = Stats()
         rxr.rxr_get_stats(ctx, C.byref(st))
         rec = dict(config=name, scene=cfg.name, device_projection=bool(args.device_projection), resolution=[W, H], triangles_3d=st.n_triangles3d, bin_entries=st.n_bin_entries,
                    scene_build_s=round(t_build, 2), upload_ms=round(t_upload * 1e3, 2),
                    setup_kernels_us=round(float(np.median(su[: n.value])), 1), raster_kernel_us=round(float(np.median(ru[: n.value])), 1),
                    frame_ms_device_resident=round(t_loop * 1e3, 4), mpix_per_s_device_resident=round(W * H / t_loop / 1e6, 1),
+                   frame_ms_device_resident_no_events=round(t_loop_untimed * 1e3, 4),
                    frame_ms_end_to_end=round(float(np.median(e2e)) * 1e3, 3), mpix_per_s_end_to_end=round(W * H / float(np.median(e2e)) / 1e6, 1))
         if name in args.oracle.split(","):
             from tests.oracle_api import load_oracle
