@@ -465,3 +465,31 @@ def test_pipelined_download_equals_single_launch(product):
     assert rxr.rxr_download_rows(ctx, single.ctypes.data_as(C.POINTER(C.c_uint8)), 0, cfg.height) == 0
     assert_exact(piped, single, "pipelined download vs single launch")
     assert piped[..., 3].min() == 255
+
+
+@pytest.mark.parametrize("shader", [False, True])
+def test_million_triangle_grid_full_size_is_bit_exact(oracle, product, shader):
+    """BASELINE.json configs[4] at its FULL size: 289 batches x 289 boxes = 1 002 252 triangles (991 848 after the frustum
+    reject), 7680 x 4320, Linear sampling, with and without the per-batch Rusteria program -- against the oracle on all host
+    threads (about a second per frame on the GPU box's 256 threads).  No lights: every colour path is exact."""
+    kw = dict(n=289, width=7680, height=4320, shader=shader)
+    got = scenes.render(scenes.box_grid_scene(product, **kw))
+    assert got[..., 3].min() == 255 and (got[..., :3].max(axis=2) > 0).mean() > 0.3
+    ref = scenes.render(scenes.box_grid_scene(oracle, **kw))
+    diff = (got != ref).any(axis=2)
+    assert not diff.any(), f"{int(diff.sum())} of {diff.size} pixels differ; first {np.argwhere(diff)[:3].tolist()}"
+
+
+@pytest.mark.parametrize("name, builder, kw, tol, max_differing", [
+    ("C2 teapot stand-in 1920x1080", scenes.teapot_scene, dict(width=1920, height=1080), 0, 0),
+    ("C3 map 1920x1080, 1 light", scenes.map_scene, dict(width=1920, height=1080, n_lights=1), 1, 64),
+    ("C4 map 3840x2160, 16 lights", scenes.map_scene, dict(width=3840, height=2160, n_lights=16), 1, 256),
+])
+def test_baseline_configs_at_full_size(oracle, product, name, builder, kw, tol, max_differing):
+    """BASELINE.json configs[1..3] at their full sizes against the oracle: bit-exact without lights; with lights (log2 / exp2
+    from different math libraries) nothing off by more than 1 and only a handful of pixels off at all."""
+    got = scenes.render(builder(product, **kw))
+    ref = scenes.render(builder(oracle, **kw))
+    diff = np.abs(got.astype(np.int16) - ref.astype(np.int16)).max(axis=2)
+    assert int(diff.max()) <= tol, f"{name}: max |diff| {int(diff.max())}"
+    assert int((diff > 0).sum()) <= max_differing, f"{name}: {int((diff > 0).sum())} pixels differ"
