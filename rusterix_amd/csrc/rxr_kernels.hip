@@ -1888,7 +1888,7 @@ __device__ __forceinline__ void raster_tile(const RasterParams &P) {
         if (P.background_kind == RXR_BG_VGRADIENT) {
             uint32_t i = sat_u8(rclamp(((float)py / P.fheight) * 128.0f, 0.0f, 128.0f));  // shader/vgradient.rs:11-15
             color = pack4(i, i, i, 255u);
-        } else if (P.background_kind == RXR_BG_GRID) {
+        } else if (X >= 1 && P.background_kind == RXR_BG_GRID) {  // (editor-only: feature level >= 1, see rxr_upload_frame)
             color = grid_shade(P, px, py);
         } else if (P.background_kind == RXR_BG_HOST_PIXELS && in_frame) {
             color = P.bg_pixels[(size_t)py * P.width + px];

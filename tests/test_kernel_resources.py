@@ -1,0 +1,57 @@
+"""Guards on the code object of the hot kernels (CPU only: hipcc cross-compiles gfx950 without a GPU).
+
+k_raster is fp32-VALU bound and sits at the edge of the SGPR file: merely compiling an editor-only path (the grid
+background) into it once added 9 % VALU instructions per frame as SGPR spill traffic, without any test noticing.  Rarer paths
+therefore live in the feature levels >= 1 (k_raster_chunk / k_raster_vm); this test keeps it that way by checking the
+registers, the scratch and the spill instructions of the common kernels in the ISA the build flags produce."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+@pytest.fixture(scope="module")
+def isa(tmp_path_factory):
+    import __graft_entry__ as G
+
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    out = tmp_path_factory.mktemp("isa") / "rxr_kernels.s"
+    flags = [f for f in G.HIP_FLAGS if f not in ("-shared", "-fPIC")]
+    subprocess.run([hipcc] + flags + ["--cuda-device-only", "-S", "-o", str(out), os.path.join(G.CSRC, "rxr_kernels.hip")],
+                   check=True, stderr=subprocess.DEVNULL)
+    return open(out).read()
+
+
+def kernel_body(isa, name):
+    start = isa.index(f"\n{name}:")
+    return isa[start:isa.index("s_endpgm", start)]
+
+
+def descriptor(isa, name, key):
+    m = re.search(rf"\.amdhsa_kernel {name}\n(.*?)\.end_amdhsa_kernel", isa, flags=re.S)
+    return int(re.search(rf"\.amdhsa_{key} (\d+)", m.group(1)).group(1))
+
+
+def test_k_raster_keeps_its_registers(isa):
+    assert descriptor(isa, "k_raster", "next_free_vgpr") <= 64          # 8 waves per SIMD
+    assert descriptor(isa, "k_raster", "private_segment_fixed_size") <= 16
+    spills = len(re.findall(r"v_(?:writelane|readlane)_b32", kernel_body(isa, "k_raster")))
+    assert spills <= 420, f"{spills} SGPR spill / reload instructions in k_raster (369 when this guard was written)"
+    assert "v_pk_fma_f32" not in kernel_body(isa, "k_raster"), "packed f32 (SLP vectorisation) is slower on gfx950: build with -fno-slp-vectorize"
+
+
+def test_k_raster_rows_keeps_its_occupancy(isa):
+    assert descriptor(isa, "k_raster_rows", "next_free_vgpr") <= 80     # 6 waves per SIMD
+    assert descriptor(isa, "k_raster_rows", "private_segment_fixed_size") <= 16
+    assert descriptor(isa, "k_raster_rows", "group_segment_fixed_size") <= 24 * 1024   # 6 workgroups per CU
+
+
+def test_row_mode_uses_the_lds_atomic(isa):
+    assert "ds_min_u64" in kernel_body(isa, "k_raster_rows")
