@@ -2112,14 +2112,34 @@ __device__ __forceinline__ void raster_tile(const RasterParams &P) {
     PHASE_FLUSH;
 }
 
+__device__ __forceinline__ const RasterParams &kernarg_params_early() { return *(const RasterParams *)__builtin_amdgcn_kernarg_segment_ptr(); }
 // two instantiations so that each path gets its own register allocation
+// Every raster kernel reads its parameter block in place in the kernarg segment (kernarg_params) instead of taking it by
+// value: with a by-value block the compiler fetches the fields at the top of the kernel, runs out of SGPRs and parks them
+// in VGPR lanes (369 v_writelane / v_readlane in k_raster, 51 of them executed by every wave before its first useful
+// instruction); read in place they are scalar loads at the point of use (17 spill instructions).  Measured A-B-A-B on one
+// box: bench frame 208 -> 198 us, the 1-light frame 126 -> 117 us.
+#ifndef RXR_RASTER_KERNARG_IN_PLACE
+#define RXR_RASTER_KERNARG_IN_PLACE 1
+#endif
+#if RXR_RASTER_KERNARG_IN_PLACE
+extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_RASTER_WAVES_PER_SIMD) k_raster(RasterParams) { raster_tile<false, 0>(kernarg_params_early()); }
+#else
 extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_RASTER_WAVES_PER_SIMD) k_raster(RasterParams P) { raster_tile<false, 0>(P); }
-extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS) k_raster_fused(RasterParams P) { raster_tile<true, 0>(P); }
+#endif
+extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS) k_raster_fused(RasterParams) { raster_tile<true, 0>(kernarg_params_early()); }
 // binned scenes (more than RXR_STAGE_TRIS triangles): the walk may switch to row mode per round (rows_round)
 #ifndef RXR_ROWS_WAVES_PER_SIMD
 #define RXR_ROWS_WAVES_PER_SIMD 6  // C5: unbounded (87 VGPRs, 5 waves) 797 us, 6: 718, 7: 727 (and the teapot loses 15 %)
 #endif
+#ifndef RXR_ROWS_KERNARG_IN_PLACE
+#define RXR_ROWS_KERNARG_IN_PLACE 1
+#endif
+#if RXR_ROWS_KERNARG_IN_PLACE
+extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_ROWS_WAVES_PER_SIMD) k_raster_rows(RasterParams) { raster_tile<false, 0, true>(kernarg_params_early()); }
+#else
 extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_ROWS_WAVES_PER_SIMD) k_raster_rows(RasterParams P) { raster_tile<false, 0, true>(P); }
+#endif
 // feature levels (template parameter X) so that the common kernels above carry none of the rarer paths:
 //   1  k_raster_chunk: chunk textures -- terrain texels sampled by world position, baked shader textures, and the
 //      full-fragment alpha test they need

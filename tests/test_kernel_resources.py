@@ -43,7 +43,7 @@ def test_k_raster_keeps_its_registers(isa):
     assert descriptor(isa, "k_raster", "next_free_vgpr") <= 64          # 8 waves per SIMD
     assert descriptor(isa, "k_raster", "private_segment_fixed_size") <= 16
     spills = len(re.findall(r"v_(?:writelane|readlane)_b32", kernel_body(isa, "k_raster")))
-    assert spills <= 420, f"{spills} SGPR spill / reload instructions in k_raster (369 when this guard was written)"
+    assert spills <= 60, f"{spills} SGPR spill / reload instructions in k_raster (17 with the parameter block read in place; 369 by value)"
     assert "v_pk_fma_f32" not in kernel_body(isa, "k_raster"), "packed f32 (SLP vectorisation) is slower on gfx950: build with -fno-slp-vectorize"
 
 
