@@ -125,7 +125,7 @@ def test_random_scene_device_projection(product, seed):
     assert np.array_equal(got, want), f"seed {seed}: {(got != want).any(axis=2).sum()} pixels differ between host and device projection"
 
 
-def build_chunks(api, seed, width, height):
+def build_chunks(api, seed, width, height, dense=1):
     """random chunked scenes: several chunks with opacity-pass batches, profile ids shared between panes and walls, terrain
     textures (some with holes) sampled by world position, per-chunk programs and baked shader textures, a 2D overlay"""
     from tests.test_gpu_shaders import ProgramGen
@@ -139,8 +139,9 @@ def build_chunks(api, seed, width, height):
         scene.add_program(ProgramGen(rng, 3, 0, setters).program())   # scene.shaders[0]: chunk batches must not pick it up
 
     def soup(nt, spread=1.0):
+        nt = nt * dense                                  # dense > 1: many small triangles -> the binned pipeline and row mode
         centre = rng.normal(0.0, 1.0 * spread, size=(nt, 1, 3))
-        verts = (centre + rng.normal(0.0, 0.7, size=(nt, 3, 3))).reshape(-1, 3).astype(np.float32)
+        verts = (centre + rng.normal(0.0, 0.7 if dense == 1 else 0.15, size=(nt, 3, 3))).reshape(-1, 3).astype(np.float32)
         v4 = np.concatenate([verts, np.ones((len(verts), 1), np.float32)], axis=1)
         idx = np.arange(nt * 3, dtype=np.uint32).reshape(nt, 3)
         uv = (rng.random((nt * 3, 2)) * 2.0).astype(np.float32)
@@ -208,6 +209,19 @@ def test_random_chunk_scene(oracle, product, seed):
     w, h = 168, 104
     got = scenes.render(build_chunks(product, seed, w, h))
     ref = scenes.render(build_chunks(oracle, seed, w, h))
+    diff = np.abs(got.astype(np.int16) - ref.astype(np.int16)).max(axis=2)
+    bad = np.argwhere(diff > TOLERANCE)
+    assert len(bad) <= 3, f"seed {seed}: {len(bad)} pixels off by more than {TOLERANCE}; first {bad[:3].tolist()} gpu={got[tuple(bad[0])]} oracle={ref[tuple(bad[0])]}"
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_chunk_scene_binned(oracle, product, seed):
+    """the same generator with 40 times as many, smaller triangles: more than 128 triangles per frame, so the chunk / program
+    kernels (k_raster_chunk, k_raster_vm) go through the binned pipeline, its row-parallel visibility and -- with opacity
+    batches or full-alpha candidates in a round -- the walk"""
+    w, h = 168, 104
+    got = scenes.render(build_chunks(product, 200 + seed, w, h, dense=40))
+    ref = scenes.render(build_chunks(oracle, 200 + seed, w, h, dense=40))
     diff = np.abs(got.astype(np.int16) - ref.astype(np.int16)).max(axis=2)
     bad = np.argwhere(diff > TOLERANCE)
     assert len(bad) <= 3, f"seed {seed}: {len(bad)} pixels off by more than {TOLERANCE}; first {bad[:3].tolist()} gpu={got[tuple(bad[0])]} oracle={ref[tuple(bad[0])]}"
