@@ -605,6 +605,8 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
     bool any_3d_visible = false, any_3d_program = false;
     uint32_t reads_2d = 0;  // PF_* read-before-written by the programs of visible 2D batches
     int32_t first_opacity_chunk = -1;  // opacity batches in two or more chunks: surface_id needs the exact prefix order (level 1)
+    bool seen_profiled_opaque = false; // ... and so does an opacity batch submitted AFTER an opaque batch that carries a profile id:
+                                       // that opaque batch must not see it (rasterizer.rs:314-357; found by tools/fuzz_sweep.py)
     size_t n_v3 = 0, n_t3 = 0;
     bool has_opacity = false;
     const bool use_meshes = f->use_meshes != 0;
@@ -805,6 +807,9 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
             if (b.list == RXR_LIST_CHUNK_OPACITY) {
                 if (first_opacity_chunk < 0) first_opacity_chunk = b.chunk;
                 else if (first_opacity_chunk != b.chunk) uses_chunk_tex = true;
+                if (seen_profiled_opaque) uses_chunk_tex = true;
+            } else if (d.flags & DB_HAS_PROFILE) {
+                seen_profiled_opaque = true;
             }
         }
         b3[i] = d;
@@ -879,6 +884,9 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
                 if (h.list == RXR_LIST_CHUNK_OPACITY) {
                     if (first_opacity_chunk < 0) first_opacity_chunk = h.chunk;
                     else if (first_opacity_chunk != h.chunk) uses_chunk_tex = true;
+                    if (seen_profiled_opaque) uses_chunk_tex = true;
+                } else if (d.flags & DB_HAS_PROFILE) {
+                    seen_profiled_opaque = true;
                 }
             }
             b3[i] = d;

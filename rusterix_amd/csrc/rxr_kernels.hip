@@ -1329,25 +1329,27 @@ __device__ __forceinline__ void visit(const RasterParams &P, const TriSetup &S, 
     float one_over_z = S.iz0 * alpha + S.iz1 * beta + S.iz2 * gamma;
     float z = 1.0f / one_over_z;
     if constexpr (OPACITY && X >= 1) front_insert(vis, z, (int)t, (S.bflags & DB_HAS_PROFILE) ? (int)S.profile_id : -1, (int)S.batch);
-    bool closer = z < vis.zmin || (z == vis.zmin && vis.best >= 0 && (int)t < vis.best);
-    if (!closer) return;
-    if (X >= 1 && !OPACITY && (S.bflags & DB_FULL_ALPHA)) {  // frames with such batches run k_raster_chunk / k_raster_vm (RasterParams.kernel_level)
-        if (!fragment_alpha_is_255_full<X>(P, shade, S.batch, alpha, beta, z, fx, fy)) return;
-    } else if (!OPACITY && (S.bflags & DB_ALPHA_TEST)) {
-        // the fragment is only written when its encoded alpha is 255 (:1408): sample it now
-        const DevBatch &B = P.batches3d[S.batch];
-        const TriShade H = *shade;
-        float u, v;
-        fragment_uv(H, alpha, beta, gamma, u, v);
-        uint32_t texel = batch_texel<X>(P, B, u, v, 0.0f, 0.0f);  // never a terrain batch: those carry DB_FULL_ALPHA
-        if ((texel >> 24) != 255u) return;
+    bool take = z < vis.zmin || (z == vis.zmin && vis.best >= 0 && (int)t < vis.best);
+    if (take) {
+        if (X >= 1 && !OPACITY && (S.bflags & DB_FULL_ALPHA)) {  // frames with such batches run k_raster_chunk / k_raster_vm (RasterParams.kernel_level)
+            take = fragment_alpha_is_255_full<X>(P, shade, S.batch, alpha, beta, z, fx, fy);
+        } else if (!OPACITY && (S.bflags & DB_ALPHA_TEST)) {
+            // the fragment is only written when its encoded alpha is 255 (:1408): sample it now
+            const DevBatch &B = P.batches3d[S.batch];
+            const TriShade H = *shade;
+            float u, v;
+            fragment_uv(H, alpha, beta, gamma, u, v);
+            uint32_t texel = batch_texel<X>(P, B, u, v, 0.0f, 0.0f);  // never a terrain batch: those carry DB_FULL_ALPHA
+            take = (texel >> 24) == 255u;
+        }
     }
-    vis.zmin = z;
-    vis.best = (int)t;
-    vis.alpha = alpha;
-    vis.beta = beta;
-    vis.slot = slot;
-    vis.batch = S.batch;
+    // branch-free update: see rows_resolve for what hipcc's if-conversion did to the `if (!closer) return; vis.x = ...;` form
+    vis.zmin = take ? z : vis.zmin;
+    vis.best = take ? (int)t : vis.best;
+    vis.alpha = take ? alpha : vis.alpha;
+    vis.beta = take ? beta : vis.beta;
+    vis.slot = take ? slot : vis.slot;
+    vis.batch = take ? S.batch : vis.batch;
 }
 
 // Exact trivial reject of a triangle for a whole tile: Edges::evaluate computes r = (a*x + b*y) + c per

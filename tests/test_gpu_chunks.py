@@ -239,6 +239,42 @@ def test_surface_id_order_matters_in_this_scene(oracle):
     assert (a != b).any(axis=2).mean() > 0.01, "the scene is meant to expose the order dependence"
 
 
+def wall_before_the_pane_scene(api, pane_first):
+    """ONE opacity pane (profile 7), in the second chunk, in front of a wall with the same profile id that lives in the FIRST
+    chunk: the wall is drawn before any opacity batch has run, so it must not be skipped behind the pane (surface_id is still
+    None, rasterizer.rs:314-357, :1044-1048).  With the chunks the other way round it is."""
+    scene = api.Scene.empty()
+    pane = api.Batch3D.from_box(-0.6, -0.6, 1.0, 1.2, 1.2, 0.02).with_computed_normals().source(B.PixelSource.Pixel((90, 120, 250, 120))).profile_id(7)
+    wall = api.Batch3D.from_box(-1.5, -1.0, 0.0, 3.0, 2.0, 0.05).with_computed_normals().source(B.PixelSource.Pixel((200, 60, 60, 255))).profile_id(7)
+    order = [("pane", pane), ("wall", wall)] if pane_first else [("wall", wall), ("pane", pane)]
+    for kind, batch in order:
+        chunk = scene.add_chunk()
+        (chunk.add_batch3d_opacity if kind == "pane" else chunk.add_batch3d)(batch)
+    scene.add_d3_static(api.Batch3D.from_box(-3.0, -3.0, -3.0, 6.0, 6.0, 0.1).with_computed_normals().source(B.PixelSource.Pixel((30, 220, 60, 255))))
+    cam = api.D3OrbitCamera.new()
+    cam.set_parameter_f32("distance", 4.5)
+    cam.azimuth = float(np.float32(np.pi / 2))
+    cam.elevation = 0.0
+
+    def setup():
+        v, p = cam.matrices(float(W), float(H))
+        return api.Rasterizer.setup(None, v, p).ambient((1.0, 1.0, 1.0, 1.0))
+
+    return scenes._result(api, scene, api.Assets.default(), setup, W, H, 40, "wall-before-pane")
+
+
+@pytest.mark.parametrize("pane_first", [False, True])
+def test_opaque_batch_submitted_before_the_only_opacity_batch(oracle, product, pane_first):
+    """found by tools/fuzz_sweep.py (seed 1043): with opacity batches in a single chunk the frame used to run the kernel that
+    tests every opaque candidate against the FINAL opacity winner"""
+    got = compare(oracle, product, lambda api: wall_before_the_pane_scene(api, pane_first))
+    centre = got[H // 2, W // 2]
+    if pane_first:
+        assert centre[1] > centre[0], "behind the pane the wall is skipped: the green backdrop shows through"
+    else:
+        assert centre[0] > centre[1], "the wall was drawn before the pane existed: it stays"
+
+
 @pytest.mark.parametrize("brush", [((4.0, 0.0, 4.0), 2.5, 0.5), ((1.0, 0.0, 7.0), 6.0, 0.0), ((9.5, 0.0, -1.0), 3.0, 5.0), ((4.0, 0.3, 4.0), 0.0, 1.0)])
 def test_brush_preview_on_terrain_texels_and_on_missed_pixels(oracle, product, brush):
     """Rasterizer.brush_preview (rasterizer.rs:13-17): a white disc blended into the terrain texels of chunk batches (:1192-1213,

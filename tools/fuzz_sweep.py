@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""One-off wide sweep of the seeded scene generators of tests/ (GPU against the oracle), far more seeds than the test suite
+runs.  usage: python tools/fuzz_sweep.py [first_seed] [n_seeds]"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import rusterix_amd  # noqa: E402
+from rusterix_amd import scenes  # noqa: E402
+from tests.oracle_api import load_oracle  # noqa: E402
+from tests import test_gpu_fuzz as F  # noqa: E402
+from tests import test_gpu_rows as R  # noqa: E402
+
+prod, orc = rusterix_amd.load(), load_oracle()
+first = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+bad = []
+
+
+def check(tag, got, ref, tol, max_bad):
+    diff = np.abs(got.astype(np.int16) - ref.astype(np.int16)).max(axis=2)
+    nb = int((diff > tol).sum())
+    if nb > max_bad:
+        bad.append((tag, nb, int(diff.max()), np.argwhere(diff > tol)[:2].tolist()))
+
+
+for s in range(first, first + n):
+    w, h = 160 + 16 * (s % 3), 100 + 7 * (s % 4)
+    check(("soup", s), scenes.render(F.build(prod, s, w, h)), scenes.render(F.build(orc, s, w, h)), 1, 3)
+    check(("chunks", s), scenes.render(F.build_chunks(prod, s, 168, 104)), scenes.render(F.build_chunks(orc, s, 168, 104)), 1, 3)
+    check(("chunks-dense", s), scenes.render(F.build_chunks(prod, s, 168, 104, dense=40)), scenes.render(F.build_chunks(orc, s, 168, 104, dense=40)), 1, 3)
+    for variant in ("plain", "ties", "cutout", "mixed", "opacity"):
+        ww, hh = 203 + 16 * (s % 3), 131 + 9 * (s % 3)
+        check((variant, s), scenes.render(R.build(prod, s, ww, hh, variant)), scenes.render(R.build(orc, s, ww, hh, variant)), 0, 0)
+    if (s - first) % 20 == 19:
+        print(f"... {s - first + 1} seeds, {len(bad)} failures so far", flush=True)
+print("seeds", first, "..", first + n - 1, "failures:", len(bad))
+for b in bad[:20]:
+    print("  ", b)
+sys.exit(1 if bad else 0)
