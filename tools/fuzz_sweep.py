@@ -13,11 +13,13 @@ from rusterix_amd import scenes  # noqa: E402
 from tests.oracle_api import load_oracle  # noqa: E402
 from tests import test_gpu_fuzz as F  # noqa: E402
 from tests import test_gpu_rows as R  # noqa: E402
+from tests import test_gpu_shaders as S  # noqa: E402
 
 prod, orc = rusterix_amd.load(), load_oracle()
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 bad = []
+refused = []
 
 
 def check(tag, got, ref, tol, max_bad):
@@ -35,9 +37,22 @@ for s in range(first, first + n):
     for variant in ("plain", "ties", "cutout", "mixed", "opacity"):
         ww, hh = 203 + 16 * (s % 3), 131 + 9 * (s % 3)
         check((variant, s), scenes.render(R.build(prod, s, ww, hh, variant)), scenes.render(R.build(orc, s, ww, hh, variant)), 0, 0)
+    # random Rusteria programs: as a 2D rectangle's shader (exact) and as a lit cube's material (+-1, a handful of pixels)
+    try:
+        rng = np.random.default_rng([0x52585231, 4242, s])
+        prog = S.ProgramGen(rng, n_locals=int(rng.integers(3, 6)), n_functions=int(rng.integers(0, 3))).program()
+        check(("program-2d", s), scenes.render(S.rect_scene(prod, prog, time=0.5)), scenes.render(S.rect_scene(orc, prog, time=0.5)), 0, 0)
+        rng = np.random.default_rng([0x52585231, 777, s])
+        prog = S.ProgramGen(rng, n_locals=int(rng.integers(3, 6)), n_functions=int(rng.integers(0, 3))).program()
+        check(("program-cube", s), scenes.render(S.cube_scene(prod, prog)), scenes.render(S.cube_scene(orc, prog)), 1, 5)
+    except Exception as e:  # a refused program (RXR_ERR_UNSUPPORTED) is not a parity failure
+        refused.append((s, str(e)[:80]))
+    if s % 10 == 0:
+        kw = dict(width=320 + 16 * (s % 5), height=200 + 8 * (s % 7), nx=10 + s % 23, ny=6 + s % 17, stacked=(s % 4) * 300)
+        check(("tile-map-2d", s), scenes.render(scenes.tile_map_2d_scene(prod, **kw)), scenes.render(scenes.tile_map_2d_scene(orc, **kw)), 0, 0)
     if (s - first) % 20 == 19:
         print(f"... {s - first + 1} seeds, {len(bad)} failures so far", flush=True)
-print("seeds", first, "..", first + n - 1, "failures:", len(bad))
+print("seeds", first, "..", first + n - 1, "failures:", len(bad), "refused programs:", len(refused), refused[:3])
 for b in bad[:20]:
     print("  ", b)
 sys.exit(1 if bad else 0)
