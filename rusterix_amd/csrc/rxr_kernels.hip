@@ -811,7 +811,7 @@ __device__ __forceinline__ uint32_t fragment2d(const RasterParams &P, const Prim
 
 // A pixel no 3D fragment reached, with a brush preview (rasterizer.rs:420-461): screen_ray (:1841-1869) through the pixel's
 // CORNER ((tile.x + tx) as f32, no + 0.5, :422-423), intersected with the plane y = 0, white blended over black.
-__device__ __noinline__ uint32_t miss_brush_preview(const RasterParams &P, uint32_t px, uint32_t py) {
+__device__ __forceinline__ uint32_t miss_brush_preview(const RasterParams &P, uint32_t px, uint32_t py) {
     const float ndc_x = 2.0f * ((float)px / P.fwidth) - 1.0f;
     const float ndc_y = 1.0f - 2.0f * ((float)py / P.fheight);
     float nx, ny, nz, nw, fx_, fy_, fz_, fw_;
@@ -1222,6 +1222,7 @@ struct Vis {
 };
 
 __device__ __forceinline__ void front_init(Vis &v) {
+#pragma unroll
     for (int i = 0; i < 3; ++i) {
         v.fz[i] = 0.0f;
         v.fid[i] = -1;
@@ -1257,7 +1258,10 @@ __device__ __forceinline__ void front_insert(Vis &v, float z, int id, int prof, 
     int slot = v.fid[0] < 0 ? 0 : (v.fid[1] < 0 ? 1 : (v.fid[2] < 0 ? 2 : -1));
     if (slot < 0) {
         slot = (v.fid[0] < v.fid[1]) ? (v.fid[0] < v.fid[2] ? 0 : 2) : (v.fid[1] < v.fid[2] ? 1 : 2);
-        if (id < v.fid[slot]) return;
+        // (selects, not v.fid[slot]: a run-time index would put the whole staircase -- and with it the opacity winner that every
+        // pixel reads in the resolve step -- into scratch memory)
+        const int fid_slot = slot == 0 ? v.fid[0] : (slot == 1 ? v.fid[1] : v.fid[2]);
+        if (id < fid_slot) return;
     }
 #pragma unroll
     for (int i = 0; i < 3; ++i)
@@ -1285,12 +1289,26 @@ __device__ __forceinline__ int front_lookup(const Vis &v, int t) {
 // that may write `opacity` (:1403-1408), a terrain texel, a baked shader texture: the whole front half of the
 // fragment block has to run to know whether the fragment is written at all
 template <int X>
-__device__ __noinline__ bool fragment_alpha_is_255_full(const RasterParams &P, const TriShade *shade, uint32_t batch, float alpha, float beta,
-                                                        float z, float fx, float fy) {
+__device__ __forceinline__ bool fragment_alpha_is_255_body(const RasterParams &P, const TriShade *shade, uint32_t batch, float alpha, float beta,
+                                                           float z, float fx, float fy) {
     const TriShade H = *shade;
     Frag F;
     shade3d_begin<(X >= 2 ? 3 : X)>(P, H, batch, alpha, beta, z, fx, fy, F);  // level 3 = level 2 with the interpreter out of line
     return f32_to_u8_saturated(F.opacity) == 255u;
+}
+// Level 2 keeps it out of line (the interpreter's registers).  Level 1 inlines it: a real call anywhere in a kernel makes the
+// compiler reserve the call ABI's registers and wait for all memory traffic around it -- k_raster_chunk ran the bench
+// frame at 329 us against k_raster's 197 us with the SAME instruction count until its only call went away.
+template <int X>
+__device__ __noinline__ bool fragment_alpha_is_255_call(const RasterParams &P, const TriShade *shade, uint32_t batch, float alpha, float beta,
+                                                        float z, float fx, float fy) {
+    return fragment_alpha_is_255_body<X>(P, shade, batch, alpha, beta, z, fx, fy);
+}
+template <int X>
+__device__ __forceinline__ bool fragment_alpha_is_255_full(const RasterParams &P, const TriShade *shade, uint32_t batch, float alpha, float beta,
+                                                           float z, float fx, float fy) {
+    if constexpr (X == 1) return fragment_alpha_is_255_body<X>(P, shade, batch, alpha, beta, z, fx, fy);
+    else return fragment_alpha_is_255_call<X>(P, shade, batch, alpha, beta, z, fx, fy);
 }
 
 template <bool OPACITY, int X>
@@ -1395,7 +1413,7 @@ struct RowLds {
     uint32_t row_start[RXR_STAGE_TRIS + 1];  // exclusive prefix of the staged candidates' row counts
     uint32_t red[8];                         // per-wave totals: [0..3] rows | area << 12, [4..7] candidates with rows
     uint32_t raw[RXR_STAGE_TRIS];            // scan_lists_rows: triangle id of every list entry of the round (= of every staged record)
-    uint32_t slot[RXR_STAGE_TRIS];           // scan_lists_rows: staged record of candidate k
+    uint8_t slot[RXR_STAGE_TRIS];            // scan_lists_rows: staged record of candidate k (bytes: 8 workgroups per CU must fit in 160 KB)
 };
 // order-preserving map of non-NaN floats to unsigned integers
 __device__ __forceinline__ uint32_t z_order_bits(float z) {
@@ -1670,7 +1688,7 @@ __device__ __forceinline__ void scan_lists_rows(const RasterParams &P, Stage &st
             n += c;
         }
         if (keep) {
-            rl.slot[off + before] = tid;
+            rl.slot[off + before] = (uint8_t)tid;
             st.ids[off + before] = id;
         }
         __syncthreads();
@@ -2132,7 +2150,7 @@ extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_RASTER_WAVES_
 extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS) k_raster_fused(RasterParams) { raster_tile<true, 0>(kernarg_params_early()); }
 // binned scenes (more than RXR_STAGE_TRIS triangles): the walk may switch to row mode per round (rows_round)
 #ifndef RXR_ROWS_WAVES_PER_SIMD
-#define RXR_ROWS_WAVES_PER_SIMD 6  // C5: unbounded (87 VGPRs, 5 waves) 797 us, 6: 718, 7: 727 (and the teapot loses 15 %)
+#define RXR_ROWS_WAVES_PER_SIMD 8  // C5: unbounded (87 VGPRs, 5 waves) 797 us, 6: 718, 7: 727; with the parameter block in place 6: 654, 8: 628
 #endif
 #ifndef RXR_ROWS_KERNARG_IN_PLACE
 #define RXR_ROWS_KERNARG_IN_PLACE 1
@@ -2152,7 +2170,13 @@ extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_ROWS_WAVES_PE
 __device__ __forceinline__ const RasterParams &kernarg_params() {
     return *(const RasterParams *)__builtin_amdgcn_kernarg_segment_ptr();
 }
-extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS) k_raster_chunk(RasterParams) { raster_tile<false, 1, true>(kernarg_params()); }
+// Bench frame forced through this kernel (RXR_MIN_KERNEL_LEVEL=1): unbounded (97 VGPRs, 5 waves per SIMD) 297 us, 6: 230, 7: 219,
+// 8: 209 (k_raster: 197).  Before the staircase left scratch memory (front_insert) and the last real call was inlined it
+// took 330 us with the same VALU instruction count: per-wave latency, not arithmetic.
+#ifndef RXR_CHUNK_WAVES_PER_SIMD
+#define RXR_CHUNK_WAVES_PER_SIMD 8
+#endif
+extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_CHUNK_WAVES_PER_SIMD) k_raster_chunk(RasterParams) { raster_tile<false, 1, true>(kernarg_params()); }
 extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_VM_WAVES_PER_SIMD) k_raster_vm(RasterParams) { raster_tile<false, 2, true>(kernarg_params()); }
 
 #if RXR_PHASE_TIMING
