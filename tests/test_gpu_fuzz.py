@@ -197,9 +197,18 @@ def build_chunks(api, seed, width, height, dense=1):
     cam.elevation = float(rng.uniform(-0.5, 0.9))
     amb = tuple(float(x) for x in rng.random(4))
 
+    # the editor's brush preview on some seeds (its own random stream: the scenes of the other seeds stay what they were)
+    rng_b = np.random.default_rng([0x52585231, 9191, seed])
+    brush = None
+    if rng_b.random() < 0.35:
+        brush = (tuple(float(x) for x in rng_b.normal(0.0, 1.5, 3)), float(rng_b.uniform(0.5, 4.0)), float(rng_b.choice([0.0, 0.3, 1.0, 2.0])))
+
     def setup():
         v, p = cam.matrices(float(width), float(height))
-        return api.Rasterizer.setup(None, v, p).ambient(amb).sample_mode(int(rng.integers(0, 1)) if False else 0).time(0.25)
+        r = api.Rasterizer.setup(None, v, p).ambient(amb).sample_mode(int(rng.integers(0, 1)) if False else 0).time(0.25)
+        if brush is not None:
+            r.brush_preview(*brush)
+        return r
 
     return scenes._result(api, scene, assets, setup, width, height, 40, f"fuzz-chunks{seed}")
 
