@@ -102,6 +102,7 @@ struct rxr_ctx {
     bool scratch_dirty = false;      // a pre-pass was queued without its raster launch
     bool scratch2d_dirty = false;
     uint32_t min_kernel_level = 0;   // RXR_MIN_KERNEL_LEVEL (tuning)
+    bool programs_static = false;    // every program of the set has a stack depth that is a function of the pc (tag_static_depths)
     uint32_t small_mode = 2;         // RasterParams.fused_small for frames with <= RXR_STAGE_TRIS triangles;
                                      // RXR_SMALL_MODE=0|1|2 overrides it (tests / A-B runs)
 
@@ -1138,6 +1139,7 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
     // carry them -- merely compiling the grid shader into it cost the bench frame 9 % more VALU instructions in SGPR spills)
     const bool editor_paths = (P.has_brush && (f->flags & RXR_FLAG_D3_ACTIVE)) || f->background_kind == RXR_BG_GRID;
     P.kernel_level = std::max(ctx->min_kernel_level, uses_programs ? 2u : ((uses_chunk_tex || editor_paths) ? 1u : 0u));
+    if (P.kernel_level == 2u && uses_programs && ctx->programs_static) P.kernel_level = 3u;  // k_raster_vm_s: wave-uniform stack pointer
     P.programs = (const DevProgram *)ctx->d_programs.p;
     P.patterns = (const DevPattern *)ctx->d_patterns.p;
     P.pattern_data = (const float *)ctx->d_pattern_data.p;
@@ -1911,6 +1913,115 @@ int flatten_programs(const rxr_shader_set *set, std::vector<uint32_t> &code, std
 
 }  // namespace
 
+// Static stack depths.  For a program without calls and without PaletteIndex (the one opcode that pushes or not depending on
+// data) the depth of the value stack is a function of the program counter alone.  This pass proves it by abstract
+// interpretation of the flat code (state = depth + the For-loop bases; every join must agree; every instruction must have its
+// operands and its room) and writes the depth BEFORE each instruction into bits 16..23 of its opcode word.  When that works
+// for every program of a set the interpreter runs with a wave-uniform stack pointer read from the code stream (rxr_vm.h,
+// kernel k_raster_vm_s): the per-lane stack bookkeeping becomes scalar.  Returns false when any program stays dynamic.
+static bool tag_static_depths(std::vector<uint32_t> &code, const std::vector<DevProgram> &progs) {
+    struct State {
+        int depth;
+        std::vector<int> loops;
+        bool operator==(const State &o) const { return depth == o.depth && loops == o.loops; }
+    };
+    std::vector<int> seen(code.size(), -1);          // index into states, per pc
+    std::vector<State> states;
+    std::vector<std::pair<uint32_t, State>> work;
+    auto length_of = [](uint32_t op) -> uint32_t {
+        switch (op) {
+            case RXR_NODE_LOAD_GLOBAL: case RXR_NODE_STORE_GLOBAL: case RXR_NODE_LOAD_LOCAL: case RXR_NODE_STORE_LOCAL:
+            case VM_GETC: case VM_SETC: case VM_JMP: case VM_JZ: case VM_FOR_COND: case VM_RETURN: case VM_FAULT: return 2;
+            case RXR_NODE_PUSH: case VM_BINC: case VM_CALL: return 4;
+            default: return 1;
+        }
+    };
+    for (const DevProgram &p : progs) {
+        if (p.shade_entry == 0xFFFFFFFFu) continue;
+        work.clear();
+        work.push_back({p.shade_entry, State{0, {}}});
+        while (!work.empty()) {
+            auto [pc, st] = work.back();
+            work.pop_back();
+            for (;;) {
+                if (pc >= code.size()) return false;
+                const uint32_t w = code[pc], op = w & 0xFFu;
+                if (op == VM_ENDFN) break;  // end of `shade`: the stack is not looked at any more
+                if (seen[pc] >= 0) {
+                    if (!(states[(size_t)seen[pc]] == st)) return false;  // two paths arrive with different stacks
+                    break;
+                }
+                seen[pc] = (int)states.size();
+                states.push_back(st);
+                if (st.depth < 0 || st.depth > 255) return false;
+                const uint32_t len = length_of(op);
+                if (pc + len > code.size()) return false;
+                int need = 0, delta = 0;
+                bool room = false;
+                switch (op) {
+                    case RXR_NODE_LOAD_GLOBAL: case RXR_NODE_LOAD_LOCAL: case RXR_NODE_PUSH:
+                    case RXR_NODE_UV: case RXR_NODE_NORMAL: case RXR_NODE_HITPOINT: case RXR_NODE_TIME: case RXR_NODE_COLOR:
+                    case RXR_NODE_ROUGHNESS: case RXR_NODE_METALLIC: case RXR_NODE_EMISSIVE: case RXR_NODE_OPACITY: case RXR_NODE_BUMP:
+                        room = true; delta = 1; break;
+                    case RXR_NODE_STORE_GLOBAL: case RXR_NODE_STORE_LOCAL: case RXR_NODE_PRINT:
+                    case RXR_NODE_SET_UV: case RXR_NODE_SET_NORMAL: case RXR_NODE_SET_COLOR: case RXR_NODE_SET_ROUGHNESS:
+                    case RXR_NODE_SET_METALLIC: case RXR_NODE_SET_OPACITY: case RXR_NODE_SET_BUMP:
+                    case VM_JZ: case VM_FOR_COND:
+                        need = 1; delta = -1; break;
+                    case RXR_NODE_SWAP: need = 2; break;
+                    case VM_GETC: case VM_BINC:
+                    case RXR_NODE_LENGTH: case RXR_NODE_LENGTH2: case RXR_NODE_LENGTH3: case RXR_NODE_ABS: case RXR_NODE_SIN: case RXR_NODE_SIN1:
+                    case RXR_NODE_SIN2: case RXR_NODE_COS: case RXR_NODE_COS1: case RXR_NODE_COS2: case RXR_NODE_TAN: case RXR_NODE_ATAN:
+                    case RXR_NODE_NORMALIZE: case RXR_NODE_FLOOR: case RXR_NODE_CEIL: case RXR_NODE_ROUND: case RXR_NODE_FRACT:
+                    case RXR_NODE_DEGREES: case RXR_NODE_RADIANS: case RXR_NODE_SQRT: case RXR_NODE_LOG: case RXR_NODE_NOT: case RXR_NODE_NEG:
+                        need = 1; break;
+                    case VM_SETC: case RXR_NODE_PACK2:
+                    case RXR_NODE_ADD: case RXR_NODE_SUB: case RXR_NODE_MUL: case RXR_NODE_DIV: case RXR_NODE_ATAN2: case RXR_NODE_ROTATE2D:
+                    case RXR_NODE_DOT: case RXR_NODE_DOT2: case RXR_NODE_DOT3: case RXR_NODE_CROSS: case RXR_NODE_MOD: case RXR_NODE_MIN:
+                    case RXR_NODE_MAX: case RXR_NODE_STEP: case RXR_NODE_POW: case RXR_NODE_EQ: case RXR_NODE_NE: case RXR_NODE_LT:
+                    case RXR_NODE_LE: case RXR_NODE_GT: case RXR_NODE_GE: case RXR_NODE_AND: case RXR_NODE_OR:
+                    case RXR_NODE_SAMPLE: case RXR_NODE_SAMPLE_NORMAL:
+                        need = 2; delta = -1; break;
+                    case RXR_NODE_PACK3: case RXR_NODE_MIX: case RXR_NODE_SMOOTHSTEP: case RXR_NODE_CLAMP:
+                        need = 3; delta = -2; break;
+                    case RXR_NODE_CLEAR: delta = st.depth > 0 ? -1 : 0; break;
+                    case RXR_NODE_DUP:
+                        if (st.depth > 0) { room = true; delta = 1; }
+                        break;
+                    case VM_RETURN: delta = st.depth > 0 ? -1 : 0; break;   // (no calls: the function is `shade`)
+                    case VM_JMP: case VM_FOR_ENTER: case VM_FOR_TRUNC: case VM_FOR_EXIT: case VM_FAULT: break;
+                    default: return false;   // VM_CALL, PaletteIndex, anything unknown: dynamic
+                }
+                if (st.depth < need) return false;                       // a stack underflow must be reported by the dynamic interpreter
+                if (room && st.depth >= (int)RXR_VM_STACK) return false;  // ... and so must an overflow
+                code[pc] = (w & 0xFF00FFFFu) | ((uint32_t)st.depth << 16);
+                State nx = st;
+                nx.depth += delta;
+                if (op == VM_FOR_ENTER) {
+                    if (nx.loops.size() >= RXR_VM_LOOPS) return false;
+                    nx.loops.push_back(st.depth);
+                } else if (op == VM_FOR_TRUNC) {
+                    if (nx.loops.empty()) return false;
+                    nx.depth = std::min(nx.depth, nx.loops.back());
+                } else if (op == VM_FOR_EXIT) {
+                    if (nx.loops.empty()) return false;
+                    nx.loops.pop_back();
+                }
+                if (op == VM_FAULT) break;                                // the lane stops here
+                if (op == VM_JMP || op == VM_RETURN) {
+                    pc = code[pc + 1];
+                    st = nx;
+                    continue;
+                }
+                if (op == VM_JZ || op == VM_FOR_COND) work.push_back({code[pc + 1], nx});
+                pc += len;
+                st = nx;
+            }
+        }
+    }
+    return true;
+}
+
 int rxr_check_shaders(const rxr_shader_set *set, uint32_t *code_words, char *message, uint32_t message_capacity) {
     std::vector<uint32_t> code, reads;
     std::vector<DevProgram> progs;
@@ -1930,6 +2041,7 @@ int rxr_set_shaders(rxr_ctx *ctx, const rxr_shader_set *set) {
     HIPCHK(ctx, hipSetDevice(ctx->device));
     ctx->has_frame = false;  // the resident frame's batch headers refer to the old programs
     ctx->programs.clear();
+    ctx->programs_static = false;
     ctx->program_field_reads.clear();
     ctx->n_patterns = ctx->n_normal_patterns = ctx->n_palette = 0;
     if (!set) return RXR_OK;
@@ -1947,6 +2059,12 @@ int rxr_set_shaders(rxr_ctx *ctx, const rxr_shader_set *set) {
         std::string err;
         int frc = flatten_programs(set, fl.code, progs, field_reads, err);
         if (frc != RXR_OK) return fail(ctx, frc, "rxr_set_shaders: " + err);
+    }
+    {
+        const bool no_static = getenv("RXR_VM_NO_STATIC") != nullptr;  // A-B runs / tests: always the dynamic interpreter
+        std::vector<uint32_t> tagged = fl.code;
+        ctx->programs_static = !no_static && !progs.empty() && tag_static_depths(tagged, progs);
+        if (ctx->programs_static) fl.code.swap(tagged);   // (a failed attempt leaves partial tags behind: keep the clean stream then)
     }
 
     // ---- patterns + palette

@@ -456,6 +456,11 @@ __device__ __forceinline__ uint32_t batch_texel(const RasterParams &P, const Dev
     return sample_texture(d, texel_base(P, d), u, v, P.sample_mode, B.repeat_mode);
 }
 
+// Feature levels (template parameter X of the raster code): 0 common, 1 chunk paths, 2 + programs with the interpreter inlined
+// in the opaque pass, 3 = 2 with every interpreter site out of line; 4 / 5 = 2 / 3 with the wave-uniform stack pointer
+// (all programs of the set have static stack depths, rxr_vm.h SSP)
+template <int X> struct vm_level { static constexpr bool ssp = X >= 4; static constexpr bool inline_site = X == 2 || X == 4; static constexpr int out_of_line = X >= 4 ? 5 : 3; };
+
 // ---- the covered-fragment block of d3_rasterize after the depth test (rasterizer.rs:1062-1404) ----
 // Split in three so that the light loop runs in wave-uniform control flow (see shade3d_lights).
 struct Frag {
@@ -522,8 +527,8 @@ __device__ __forceinline__ void shade3d_begin(const RasterParams &P, const TriSh
             io.uv.y = v / 4.0f;
             io.hitpoint = rxvm::mk(world.x, world.y, world.z);
             io.time = rxvm::splat(P.time);
-            if constexpr (X == 2 && !RXR_VM_ALWAYS_CALL) rxvm::shade_inline(P, B.program_plus1 - 1u, io, rxvm::stack_block());
-            else rxvm::shade_call(P, B.program_plus1 - 1u, io);  // X == 3: from the visibility loop's alpha test
+            if constexpr (vm_level<X>::inline_site && !RXR_VM_ALWAYS_CALL) rxvm::shade_inline<vm_level<X>::ssp>(P, B.program_plus1 - 1u, io, rxvm::stack_block());
+            else rxvm::shade_call<vm_level<X>::ssp>(P, B.program_plus1 - 1u, io);  // X == 3 / 5: from the visibility loop's alpha test
             base = mk3(io.color.x, io.color.y, io.color.z);  // :1319-1323
             normal = mk3(io.normal.x, io.normal.y, io.normal.z);
             rough = rclamp(io.roughness.x, 0.0f, 1.0f);
@@ -704,7 +709,7 @@ __device__ __forceinline__ uint32_t shade3d_opacity(const RasterParams &P, const
             io.time = rxvm::splat(P.time);
             io.roughness.x = 0.5f;
             io.metallic.x = 0.0f;
-            rxvm::shade_call(P, B.program_plus1 - 1u, io);
+            rxvm::shade_call<vm_level<X>::ssp>(P, B.program_plus1 - 1u, io);
             r = io.color.x;
             g = io.color.y;
             b = io.color.z;
@@ -751,7 +756,7 @@ __device__ __forceinline__ uint32_t fragment2d(const RasterParams &P, const Prim
             io.time = rxvm::splat(P.time);
             io.roughness.x = 0.5f;
             io.metallic.x = 0.0f;
-            rxvm::shade_call(P, B.program_plus1 - 1u, io);
+            rxvm::shade_call<vm_level<X>::ssp>(P, B.program_plus1 - 1u, io);
             texel = pack4(f32_to_u8_saturated(io.color.x), f32_to_u8_saturated(io.color.y), f32_to_u8_saturated(io.color.z), 255u);
         }
     }
@@ -1293,7 +1298,7 @@ __device__ __forceinline__ bool fragment_alpha_is_255_body(const RasterParams &P
                                                            float z, float fx, float fy) {
     const TriShade H = *shade;
     Frag F;
-    shade3d_begin<(X >= 2 ? 3 : X)>(P, H, batch, alpha, beta, z, fx, fy, F);  // level 3 = level 2 with the interpreter out of line
+    shade3d_begin<(X >= 2 ? vm_level<X>::out_of_line : X)>(P, H, batch, alpha, beta, z, fx, fy, F);  // levels 3 / 5: the interpreter out of line
     return f32_to_u8_saturated(F.opacity) == 255u;
 }
 // Level 2 keeps it out of line (the interpreter's registers).  Level 1 inlines it: a real call anywhere in a kernel makes the
@@ -2178,6 +2183,8 @@ __device__ __forceinline__ const RasterParams &kernarg_params() {
 #endif
 extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_CHUNK_WAVES_PER_SIMD) k_raster_chunk(RasterParams) { raster_tile<false, 1, true>(kernarg_params()); }
 extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_VM_WAVES_PER_SIMD) k_raster_vm(RasterParams) { raster_tile<false, 2, true>(kernarg_params()); }
+// the same with the wave-uniform stack pointer, for sets whose programs all have static stack depths (kernel_level 3)
+extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_VM_WAVES_PER_SIMD) k_raster_vm_s(RasterParams) { raster_tile<false, 4, true>(kernarg_params()); }
 
 #if RXR_PHASE_TIMING
 extern "C" int rxr_debug_phase_read(unsigned long long *out16, int reset) {
@@ -2223,7 +2230,8 @@ extern "C" void rxr_launch_raster(const RasterParams *P, hipStream_t s) {
     uint32_t tiles = P->tiles_x * P->tiles_y;
     if (tiles == 0) return;
     const bool no_rows = getenv("RXR_NO_ROWS") != nullptr;  // tuning knob: binned scenes walk every candidate per pixel (k_raster)
-    if (P->kernel_level >= 2u) hipLaunchKernelGGL(k_raster_vm, dim3(tiles), dim3(RXR_TILE_THREADS), 0, s, *P);
+    if (P->kernel_level >= 3u) hipLaunchKernelGGL(k_raster_vm_s, dim3(tiles), dim3(RXR_TILE_THREADS), 0, s, *P);
+    else if (P->kernel_level == 2u) hipLaunchKernelGGL(k_raster_vm, dim3(tiles), dim3(RXR_TILE_THREADS), 0, s, *P);
     else if (P->kernel_level == 1u) hipLaunchKernelGGL(k_raster_chunk, dim3(tiles), dim3(RXR_TILE_THREADS), 0, s, *P);
     else if (P->fused_small == 1u) hipLaunchKernelGGL(k_raster_fused, dim3(tiles), dim3(RXR_TILE_THREADS), 0, s, *P);
     else if (P->fused_small == 0u && (P->flags & RXR_FLAG_D3_ACTIVE) && !no_rows) hipLaunchKernelGGL(k_raster_rows, dim3(tiles), dim3(RXR_TILE_THREADS), 0, s, *P);

@@ -218,6 +218,12 @@ __device__ __noinline__ v3 slow_binary(uint32_t op, v3 a, v3 b) {
 // Inlined form: used where most fragments pass (the opaque pass).  A real call would make the interpreter save and
 // restore ~100 callee-saved VGPRs per invocation -- measured: 26 000 cycles per wave for an EMPTY program, the spill
 // traffic of all resident waves going through HBM.
+// SSP ("static stack pointer"): every program of the set carries the stack depth before each instruction in bits 16..23 of
+// its opcode word (rxr_api.hip, tag_static_depths).  The word comes through the scalar cache, so `st.sp` is then a
+// wave-uniform value: slot addresses, the LDS / scratch split of the stack and the operand checks become scalar code and the
+// per-lane depth register disappears (a lane that is not at the current pc does not use its depth until it is, and then
+// it is re-derived).  The handlers below are unchanged: their updates of st.sp are simply dead in this instantiation.
+template <bool SSP>
 __device__ __forceinline__ uint32_t shade_inline(const RasterParams &P, uint32_t pi, IO &io, float *vm_lds) {
     const DevProgram prog = P.programs[pi];
     if (prog.shade_entry == 0xFFFFFFFFu) return 0u;  // shade_index None: nothing runs (:1291, :771, :1651)
@@ -256,6 +262,7 @@ __device__ __forceinline__ uint32_t shade_inline(const RasterParams &P, uint32_t
         }
         const uint32_t w = code[upc];
         const uint32_t imm0 = code[upc + 1u];  // (the stream is padded so that this is always readable)
+        if constexpr (SSP) st.sp = (w >> 16) & 0xFFu;
         switch (w & 0xFFu) {
             case RXR_NODE_LOAD_GLOBAL:
                 if (on) {
@@ -653,9 +660,10 @@ __device__ __forceinline__ float *stack_block() {
 
 // out-of-line form for the rarer call sites (opacity pass, 2D pass, the visibility loop's alpha test): one shared copy
 // of the interpreter instead of one per site
+template <bool SSP>
 __device__ __noinline__ uint32_t shade_call(const RasterParams &P, uint32_t pi, IO &io_caller) {
     IO io = io_caller;  // the caller's copy sits in scratch (its address crosses the call): work on registers, write back once
-    const uint32_t fault = shade_inline(P, pi, io, stack_block());
+    const uint32_t fault = shade_inline<SSP>(P, pi, io, stack_block());
     io_caller = io;
     return fault;
 }

@@ -368,3 +368,22 @@ def test_random_programs_as_cube_materials(oracle, product, seed):
     diff = np.abs(got.astype(np.int16) - ref.astype(np.int16)).max(axis=2)
     # a colour that lands within an ulp of a quantisation or Fract boundary may flip on the +-1-ulp pow: allow a handful
     assert (diff > TOLERANCE).sum() <= 5, f"{(diff > TOLERANCE).sum()} pixels differ by more than {TOLERANCE} (max {diff.max()})"
+
+
+@pytest.mark.parametrize("seed", [0, 3, 7, 11, 19, 23])
+def test_static_and_dynamic_stack_pointer_agree(oracle, product, seed, monkeypatch):
+    """Programs whose stack depth is a function of the program counter run with a wave-uniform stack pointer read from the
+    code stream (k_raster_vm_s, rxr_api.hip tag_static_depths); RXR_VM_NO_STATIC forces the per-lane bookkeeping.  Both must
+    give the oracle's frame -- for the grid's colour program (an If with two pushes) and for random programs."""
+    if seed == 0:
+        build = lambda api: scenes.box_grid_scene(api, n=24, width=320, height=200, shader=True)   # noqa: E731
+    else:
+        rng = np.random.default_rng([0x52585231, 4242, seed])
+        prog = ProgramGen(rng, n_locals=int(rng.integers(3, 6)), n_functions=0).program()
+        build = lambda api: rect_scene(api, prog, time=0.5)   # noqa: E731
+    ref = scenes.render(build(oracle)).copy()
+    monkeypatch.delenv("RXR_VM_NO_STATIC", raising=False)
+    static = scenes.render(build(product)).copy()
+    monkeypatch.setenv("RXR_VM_NO_STATIC", "1")
+    dynamic = scenes.render(build(product)).copy()
+    assert np.array_equal(static, ref) and np.array_equal(dynamic, ref)
