@@ -80,17 +80,19 @@ __device__ __forceinline__ float rclampf(float x, float lo, float hi) { return x
 // (the LDS block is passed to every access instead of being stored here: a pointer kept in a struct that itself lives in
 // scratch would become a generic pointer)
 struct Stack {
-    v3 deep[RXR_VM_STACK - RXR_VM_LDS_STACK];  // slots beyond the LDS part (scratch)
+    // The slots beyond the LDS part live in a SEPARATE array in scratch memory, handed to every access (`deep`).  As a member
+    // of this struct its run-time index kept the whole struct -- the top of the stack included -- in scratch: every VM
+    // instruction started with a scratch load of `tos` and ended with a scratch store (seen in the ISA).
     v3 tos;                                  // entry sp - 1
     uint32_t sp;
-    __device__ __forceinline__ v3 load(const float *lds, uint32_t slot) const {
+    __device__ __forceinline__ v3 load(const float *lds, const v3 *deep, uint32_t slot) const {
         if (slot < RXR_VM_LDS_STACK) {
             const float *p = lds + (slot * 3u) * RXR_TILE_THREADS + threadIdx.x;
             return mk(p[0], p[RXR_TILE_THREADS], p[2 * RXR_TILE_THREADS]);
         }
         return deep[slot - RXR_VM_LDS_STACK];
     }
-    __device__ __forceinline__ void store(float *lds, uint32_t slot, v3 v) {
+    __device__ __forceinline__ void store(float *lds, v3 *deep, uint32_t slot, v3 v) {
         if (slot < RXR_VM_LDS_STACK) {
             float *p = lds + (slot * 3u) * RXR_TILE_THREADS + threadIdx.x;
             p[0] = v.x;
@@ -101,21 +103,21 @@ struct Stack {
         }
     }
     // callers check the depth first
-    __device__ __forceinline__ void push(float *lds, v3 v) {
-        if (sp) store(lds, sp - 1u, tos);
+    __device__ __forceinline__ void push(float *lds, v3 *deep, v3 v) {
+        if (sp) store(lds, deep, sp - 1u, tos);
         tos = v;
         ++sp;
     }
-    __device__ __forceinline__ v3 pop(const float *lds) {
+    __device__ __forceinline__ v3 pop(const float *lds, const v3 *deep) {
         v3 r = tos;
         --sp;
-        if (sp) tos = load(lds, sp - 1u);
+        if (sp) tos = load(lds, deep, sp - 1u);
         return r;
     }
-    __device__ __forceinline__ void truncate(const float *lds, uint32_t n) {  // Vec::truncate: only ever shrinks
+    __device__ __forceinline__ void truncate(const float *lds, const v3 *deep, uint32_t n) {  // Vec::truncate: only ever shrinks
         if (sp > n) {
             sp = n;
-            if (sp) tos = load(lds, sp - 1u);
+            if (sp) tos = load(lds, deep, sp - 1u);
         }
     }
 };
@@ -182,7 +184,7 @@ __device__ __noinline__ v3 slow_binary(uint32_t op, v3 a, v3 b) {
     if (on) {                             \
         VM_NEED(2u)                       \
         const v3 b = st.tos;              \
-        const v3 a = st.load(vm_lds, st.sp - 2u); \
+        const v3 a = st.load(vm_lds, deep, st.sp - 2u); \
         st.tos = (expr);                  \
         --st.sp;                          \
         pc = upc + 1u;                    \
@@ -192,8 +194,8 @@ __device__ __noinline__ v3 slow_binary(uint32_t op, v3 a, v3 b) {
     if (on) {                             \
         VM_NEED(3u)                       \
         const v3 c = st.tos;              \
-        const v3 b = st.load(vm_lds, st.sp - 2u); \
-        const v3 a = st.load(vm_lds, st.sp - 3u); \
+        const v3 b = st.load(vm_lds, deep, st.sp - 2u); \
+        const v3 a = st.load(vm_lds, deep, st.sp - 3u); \
         st.tos = (expr);                  \
         st.sp -= 2u;                      \
         pc = upc + 1u;                    \
@@ -202,14 +204,14 @@ __device__ __noinline__ v3 slow_binary(uint32_t op, v3 a, v3 b) {
 #define VM_GET(field)      \
     if (on) {              \
         VM_ROOM            \
-        st.push(vm_lds, field); \
+        st.push(vm_lds, deep, field); \
         pc = upc + 1u;     \
     }                      \
     break;
 #define VM_SET(field)      \
     if (on) {              \
         VM_NEED(1u)        \
-        field = st.pop(vm_lds); \
+        field = st.pop(vm_lds, deep); \
         pc = upc + 1u;     \
     }                      \
     break;
@@ -234,6 +236,7 @@ __device__ __forceinline__ uint32_t shade_inline(const RasterParams &P, uint32_t
     Stack st;
     st.sp = 0;
     st.tos = splat(0.0f);
+    v3 deep[RXR_VM_STACK - RXR_VM_LDS_STACK];  // stack slots beyond the LDS part (scratch memory)
     v3 locals[RXR_VM_LOCALS];
     v3 globals[RXR_VM_GLOBALS];
     uint32_t fr_pc[RXR_VM_FRAMES], fr_base[RXR_VM_FRAMES], fr_lbase[RXR_VM_FRAMES], fr_llen[RXR_VM_FRAMES];
@@ -260,15 +263,19 @@ __device__ __forceinline__ uint32_t shade_inline(const RasterParams &P, uint32_t
             running = false;
             continue;
         }
-        const uint32_t w = code[upc];
-        const uint32_t imm0 = code[upc + 1u];  // (the stream is padded so that this is always readable)
+        // the whole instruction (at most four words) in one go: an immediate fetched inside a handler would be a second
+        // scalar-memory round trip per instruction (the stream is padded so that upc + 3 is always readable)
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        typedef const u32x4 __attribute__((address_space(4), aligned(4))) *code4_ptr;
+        const u32x4 insn = *(code4_ptr)(code + upc);   // one s_load_dwordx4
+        const uint32_t w = insn.x, imm0 = insn.y, imm1 = insn.z, imm2 = insn.w;
         if constexpr (SSP) st.sp = (w >> 16) & 0xFFu;
         switch (w & 0xFFu) {
             case RXR_NODE_LOAD_GLOBAL:
                 if (on) {
                     if (imm0 >= prog.n_globals) VM_FAIL(VMF_GLOBAL_INDEX)
                     VM_ROOM
-                    st.push(vm_lds, globals[imm0]);
+                    st.push(vm_lds, deep, globals[imm0]);
                     pc = upc + 2u;
                 }
                 break;
@@ -276,7 +283,7 @@ __device__ __forceinline__ uint32_t shade_inline(const RasterParams &P, uint32_t
                 if (on) {
                     if (imm0 >= prog.n_globals) VM_FAIL(VMF_GLOBAL_INDEX)
                     VM_NEED(1u)
-                    globals[imm0] = st.pop(vm_lds);
+                    globals[imm0] = st.pop(vm_lds, deep);
                     pc = upc + 2u;
                 }
                 break;
@@ -284,7 +291,7 @@ __device__ __forceinline__ uint32_t shade_inline(const RasterParams &P, uint32_t
                 if (on) {
                     if (imm0 >= llen) VM_FAIL(VMF_LOCAL_INDEX)
                     VM_ROOM
-                    st.push(vm_lds, locals[lbase + imm0]);
+                    st.push(vm_lds, deep, locals[lbase + imm0]);
                     pc = upc + 2u;
                 }
                 break;
@@ -292,15 +299,15 @@ __device__ __forceinline__ uint32_t shade_inline(const RasterParams &P, uint32_t
                 if (on) {
                     if (imm0 >= llen) VM_FAIL(VMF_LOCAL_INDEX)
                     VM_NEED(1u)
-                    locals[lbase + imm0] = st.pop(vm_lds);
+                    locals[lbase + imm0] = st.pop(vm_lds, deep);
                     pc = upc + 2u;
                 }
                 break;
             case RXR_NODE_SWAP:
                 if (on) {
                     VM_NEED(2u)
-                    const v3 b = st.tos, a = st.load(vm_lds, st.sp - 2u);
-                    st.store(vm_lds, st.sp - 2u, b);
+                    const v3 b = st.tos, a = st.load(vm_lds, deep, st.sp - 2u);
+                    st.store(vm_lds, deep, st.sp - 2u, b);
                     st.tos = a;
                     pc = upc + 1u;
                 }
@@ -330,7 +337,7 @@ __device__ __forceinline__ uint32_t shade_inline(const RasterParams &P, uint32_t
                     VM_NEED(2u)
                     const uint32_t enc = imm0, n = enc & 15u;
                     const v3 value = st.tos;
-                    v3 target = st.load(vm_lds, st.sp - 2u);
+                    v3 target = st.load(vm_lds, deep, st.sp - 2u);
                     const uint32_t nc = (n >= 1u && n <= 3u) ? n : 0u;
                     for (uint32_t i = 0; i < nc; ++i) {
                         uint32_t c = (enc >> (4u + 2u * i)) & 3u;
@@ -347,14 +354,14 @@ __device__ __forceinline__ uint32_t shade_inline(const RasterParams &P, uint32_t
             case RXR_NODE_PUSH:
                 if (on) {
                     VM_ROOM
-                    st.push(vm_lds, mk(__uint_as_float(imm0), __uint_as_float(code[upc + 2u]), __uint_as_float(code[upc + 3u])));
+                    st.push(vm_lds, deep, mk(__uint_as_float(imm0), __uint_as_float(imm1), __uint_as_float(imm2)));
                     pc = upc + 4u;
                 }
                 break;
             case VM_BINC:  // "Push c; op" fused by rxr_set_shaders: the same values, no stack traffic
                 if (on) {
                     VM_NEED(1u)
-                    const v3 a = st.tos, b = mk(__uint_as_float(imm0), __uint_as_float(code[upc + 2u]), __uint_as_float(code[upc + 3u]));
+                    const v3 a = st.tos, b = mk(__uint_as_float(imm0), __uint_as_float(imm1), __uint_as_float(imm2));
                     v3 r;
                     switch ((w >> 8) & 0xFFu) {
                         case RXR_NODE_ADD: r = mk(a.x + b.x, a.y + b.y, a.z + b.z); break;
@@ -377,7 +384,7 @@ __device__ __forceinline__ uint32_t shade_inline(const RasterParams &P, uint32_t
                 break;
             case RXR_NODE_CLEAR:
                 if (on) {
-                    if (st.sp) (void)st.pop(vm_lds);
+                    if (st.sp) (void)st.pop(vm_lds, deep);
                     pc = upc + 1u;
                 }
                 break;
@@ -385,7 +392,7 @@ __device__ __forceinline__ uint32_t shade_inline(const RasterParams &P, uint32_t
                 if (on) {
                     if (st.sp) {
                         VM_ROOM
-                        st.push(vm_lds, st.tos);
+                        st.push(vm_lds, deep, st.tos);
                     }
                     pc = upc + 1u;
                 }
@@ -399,7 +406,7 @@ __device__ __forceinline__ uint32_t shade_inline(const RasterParams &P, uint32_t
             case VM_JZ:
                 if (on) {
                     VM_NEED(1u)
-                    const v3 c = st.pop(vm_lds);
+                    const v3 c = st.pop(vm_lds, deep);
                     pc = (c.x != 0.0f) ? upc + 2u : imm0;
                 }
                 break;
@@ -412,14 +419,14 @@ __device__ __forceinline__ uint32_t shade_inline(const RasterParams &P, uint32_t
                 break;
             case VM_FOR_TRUNC:
                 if (on) {
-                    st.truncate(vm_lds, loop_base[nloops - 1u]);
+                    st.truncate(vm_lds, deep, loop_base[nloops - 1u]);
                     pc = upc + 1u;
                 }
                 break;
             case VM_FOR_COND:
                 if (on) {
                     VM_NEED(1u)
-                    const v3 z = st.pop(vm_lds);
+                    const v3 z = st.pop(vm_lds, deep);
                     pc = (z.x == 0.0f) ? imm0 : upc + 2u;
                 }
                 break;
@@ -431,7 +438,7 @@ __device__ __forceinline__ uint32_t shade_inline(const RasterParams &P, uint32_t
                 break;
             case VM_CALL:  // :186-223
                 if (on) {
-                    const uint32_t arity = imm0, total = code[upc + 2u], target = code[upc + 3u];
+                    const uint32_t arity = imm0, total = imm1, target = imm2;
                     if (nframes >= RXR_VM_FRAMES) VM_FAIL(VMF_CALL_DEPTH)
                     const uint32_t nb = lbase + llen;
                     if (nb + total > RXR_VM_LOCALS) VM_FAIL(VMF_LOCALS_OVERFLOW)
@@ -443,7 +450,7 @@ __device__ __forceinline__ uint32_t shade_inline(const RasterParams &P, uint32_t
                                 bad = true;
                                 break;
                             }
-                            locals[nb + i] = st.pop(vm_lds);
+                            locals[nb + i] = st.pop(vm_lds, deep);
                         }
                     }
                     if (bad) VM_FAIL(VMF_LOCAL_INDEX)
@@ -460,7 +467,7 @@ __device__ __forceinline__ uint32_t shade_inline(const RasterParams &P, uint32_t
             case VM_RETURN:  // :224-234
                 if (on) {
                     v3 v;
-                    if (st.sp) v = st.pop(vm_lds);
+                    if (st.sp) v = st.pop(vm_lds, deep);
                     else if (has_ret) v = ret;
                     else v = splat(0.0f);
                     ret = v;
@@ -481,16 +488,16 @@ __device__ __forceinline__ uint32_t shade_inline(const RasterParams &P, uint32_t
                         r = ret;
                         has_ret = false;
                     } else if (st.sp > base) {
-                        r = st.pop(vm_lds);
+                        r = st.pop(vm_lds, deep);
                     } else {
                         r = splat(0.0f);
                     }
-                    st.truncate(vm_lds, base);
+                    st.truncate(vm_lds, deep, base);
                     lbase = fr_lbase[nframes];
                     llen = fr_llen[nframes];
                     pc = fr_pc[nframes];
                     VM_ROOM
-                    st.push(vm_lds, r);
+                    st.push(vm_lds, deep, r);
                 }
                 break;
             case VM_FAULT:
@@ -543,7 +550,7 @@ __device__ __forceinline__ uint32_t shade_inline(const RasterParams &P, uint32_t
             case RXR_NODE_SMOOTHSTEP:  // :456-474: a = edge0, b = edge1, c = x
                 if (on) {
                     VM_NEED(3u)
-                    const v3 c = st.tos, b = st.load(vm_lds, st.sp - 2u), a = st.load(vm_lds, st.sp - 3u);
+                    const v3 c = st.tos, b = st.load(vm_lds, deep, st.sp - 2u), a = st.load(vm_lds, deep, st.sp - 3u);
                     float denom = b.x - a.x;
                     float t = denom != 0.0f ? (c.x - a.x) / denom : 0.0f;
                     if (t < 0.0f) t = 0.0f;
@@ -557,7 +564,7 @@ __device__ __forceinline__ uint32_t shade_inline(const RasterParams &P, uint32_t
             case RXR_NODE_CLAMP:  // f32::clamp panics unless min <= max: a = x, b = lo, c = hi
                 if (on) {
                     VM_NEED(3u)
-                    const v3 c = st.tos, b = st.load(vm_lds, st.sp - 2u), a = st.load(vm_lds, st.sp - 3u);
+                    const v3 c = st.tos, b = st.load(vm_lds, deep, st.sp - 2u), a = st.load(vm_lds, deep, st.sp - 3u);
                     if (!(b.x <= c.x) || !(b.y <= c.y) || !(b.z <= c.z)) VM_FAIL(VMF_CLAMP_BOUNDS)
                     st.tos = mk(rclampf(a.x, b.x, c.x), rclampf(a.y, b.y, c.y), rclampf(a.z, b.z, c.z));
                     st.sp -= 2u;
@@ -578,7 +585,7 @@ __device__ __forceinline__ uint32_t shade_inline(const RasterParams &P, uint32_t
             case RXR_NODE_PRINT:  // println! only
                 if (on) {
                     VM_NEED(1u)
-                    (void)st.pop(vm_lds);
+                    (void)st.pop(vm_lds, deep);
                     pc = upc + 1u;
                 }
                 break;
@@ -589,7 +596,7 @@ __device__ __forceinline__ uint32_t shade_inline(const RasterParams &P, uint32_t
             case RXR_NODE_SET_NORMAL:  // .normalized()
                 if (on) {
                     VM_NEED(1u)
-                    const v3 a = st.pop(vm_lds);
+                    const v3 a = st.pop(vm_lds, deep);
                     float len = sqrtf((a.x * a.x + a.y * a.y) + a.z * a.z);
                     io.normal = mk(a.x / len, a.y / len, a.z / len);
                     pc = upc + 1u;
@@ -611,7 +618,7 @@ __device__ __forceinline__ uint32_t shade_inline(const RasterParams &P, uint32_t
             case RXR_NODE_SAMPLE:  // :570-578: a = uv, b = pattern id
                 if (on) {
                     VM_NEED(2u)
-                    const v3 b = st.tos, a = st.load(vm_lds, st.sp - 2u);
+                    const v3 b = st.tos, a = st.load(vm_lds, deep, st.sp - 2u);
                     const uint32_t id = as_usize_sat(b.x);
                     st.tos = id < P.n_patterns ? pattern_sample(P, P.patterns[id], a) : splat(0.0f);
                     --st.sp;
@@ -621,7 +628,7 @@ __device__ __forceinline__ uint32_t shade_inline(const RasterParams &P, uint32_t
             case RXR_NODE_SAMPLE_NORMAL:  // :579-594
                 if (on) {
                     VM_NEED(2u)
-                    const v3 b = st.tos, a = st.load(vm_lds, st.sp - 2u);
+                    const v3 b = st.tos, a = st.load(vm_lds, deep, st.sp - 2u);
                     const uint32_t id = as_usize_sat(b.x);
                     v3 o = splat(0.0f);
                     if (id < P.n_normal_patterns) {
@@ -636,10 +643,10 @@ __device__ __forceinline__ uint32_t shade_inline(const RasterParams &P, uint32_t
             case RXR_NODE_PALETTE_INDEX:  // :694-701: pushes nothing for a missing / empty slot
                 if (on) {
                     VM_NEED(1u)
-                    const v3 a = st.pop(vm_lds);
+                    const v3 a = st.pop(vm_lds, deep);
                     const uint32_t id = as_usize_sat(a.x);
                     if (id < P.n_palette && P.palette[4u * id + 3u] != 0.0f)
-                        st.push(vm_lds, mk(P.palette[4u * id], P.palette[4u * id + 1u], P.palette[4u * id + 2u]));  // (room: one was just popped)
+                        st.push(vm_lds, deep, mk(P.palette[4u * id], P.palette[4u * id + 1u], P.palette[4u * id + 2u]));  // (room: one was just popped)
                     pc = upc + 1u;
                 }
                 break;
