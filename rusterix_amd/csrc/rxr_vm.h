@@ -8,8 +8,8 @@
 // loops assign before each call.
 //
 // Where the reference panics the lane stops and reports a VMF_* code through RasterParams.vm_fault;
-// rxr_synchronize turns it into RXR_ERR_INVALID.  Loops are bounded by RXR_VM_MAX_STEPS instructions per
-// invocation so that every wave reaches the end of the kernel.
+// rxr_synchronize turns it into RXR_ERR_INVALID.  An invocation is bounded by RXR_VM_MAX_STEPS backward jumps and
+// calls (the only ways to execute an instruction twice) so that every wave reaches the end of the kernel.
 //
 // sin / cos / tan / atan / atan2 / pow / ln come from the device math library and differ from the host's
 // libm by a few ulp: programs that use them are compared at +-1 per 8-bit channel.
@@ -79,6 +79,10 @@ __device__ __forceinline__ float rclampf(float x, float lo, float hi) { return x
 
 // (the LDS block is passed to every access instead of being stored here: a pointer kept in a struct that itself lives in
 // scratch would become a generic pointer)
+// the LDS part is addressed through an explicit LDS pointer type: an access to it can then never be merged with an access to
+// the scratch part into one access through a generic pointer (which this compiler also fails to select: "Illegal
+// instruction detected ... $src_private_base")
+typedef float __attribute__((address_space(3))) lds_float;
 struct Stack {
     // The slots beyond the LDS part live in a SEPARATE array in scratch memory, handed to every access (`deep`).  As a member
     // of this struct its run-time index kept the whole struct -- the top of the stack included -- in scratch: every VM
@@ -87,14 +91,14 @@ struct Stack {
     uint32_t sp;
     __device__ __forceinline__ v3 load(const float *lds, const v3 *deep, uint32_t slot) const {
         if (slot < RXR_VM_LDS_STACK) {
-            const float *p = lds + (slot * 3u) * RXR_TILE_THREADS + threadIdx.x;
+            const lds_float *p = (const lds_float *)lds + (slot * 3u) * RXR_TILE_THREADS + threadIdx.x;
             return mk(p[0], p[RXR_TILE_THREADS], p[2 * RXR_TILE_THREADS]);
         }
         return deep[slot - RXR_VM_LDS_STACK];
     }
     __device__ __forceinline__ void store(float *lds, v3 *deep, uint32_t slot, v3 v) {
         if (slot < RXR_VM_LDS_STACK) {
-            float *p = lds + (slot * 3u) * RXR_TILE_THREADS + threadIdx.x;
+            lds_float *p = (lds_float *)lds + (slot * 3u) * RXR_TILE_THREADS + threadIdx.x;
             p[0] = v.x;
             p[RXR_TILE_THREADS] = v.y;
             p[2 * RXR_TILE_THREADS] = v.z;
@@ -122,12 +126,16 @@ struct Stack {
     }
 };
 
+// A lane that has finished (or faulted) parks its program counter here: "still running", "at the current instruction" and
+// "behind the candidate" are then single compares of the pc, and the interpreter has one state variable less to carry.
+#define VM_PC_STOPPED 0xFFFFFFFFu
+
 // smallest pc among the running lanes of the calling wave.  Ballots and shuffles FROM active lanes only: the lanes that
 // did not enter shade() (or left it) are masked off and must not be read.  One round when the wave has not diverged.
-__device__ __forceinline__ uint32_t wave_min_pc(uint32_t pc, bool running, unsigned long long running_mask) {
+__device__ __forceinline__ uint32_t wave_min_pc(uint32_t pc, unsigned long long running_mask) {
     uint32_t cand = (uint32_t)__builtin_amdgcn_readlane((int)pc, __ffsll((long long)running_mask) - 1);
     for (;;) {
-        const unsigned long long less = __ballot(running && pc < cand);
+        const unsigned long long less = __builtin_amdgcn_ballot_w64(pc < cand);   // (a stopped lane sits at VM_PC_STOPPED)
         if (!less) return cand;
         cand = (uint32_t)__builtin_amdgcn_readlane((int)pc, __ffsll((long long)less) - 1);
     }
@@ -160,16 +168,36 @@ __device__ __noinline__ v3 slow_binary(uint32_t op, v3 a, v3 b) {
     }
 }
 
+// calls f(integral_constant<K>) for K == op, LO <= op < HI, through a balanced tree of comparisons (see shade_inline)
+template <uint32_t K>
+struct OpConst { static constexpr uint32_t value = K; };
+template <uint32_t LO, uint32_t HI, class F>
+__device__ __forceinline__ void vm_dispatch(uint32_t op, F &f) {
+    if constexpr (HI - LO == 1u) {
+        f(OpConst<LO>{});
+    } else {
+        constexpr uint32_t MID = (LO + HI) / 2u;
+        if (op < MID) vm_dispatch<LO, MID>(op, f);
+        else vm_dispatch<MID, HI>(op, f);
+    }
+}
+
 #define VM_FAIL(code)       \
     {                       \
         fault = (code);     \
-        running = false;    \
+        pc = VM_PC_STOPPED; \
         break;              \
     }
-#define VM_NEED(n) \
-    if (st.sp < (n)) VM_FAIL(VMF_STACK_UNDERFLOW)
-#define VM_ROOM \
-    if (st.sp >= RXR_VM_STACK) VM_FAIL(VMF_STACK_OVERFLOW)
+// (with static depths the host has proved operands and room for every instruction -- tag_static_depths in rxr_api.hip
+// leaves a program dynamic otherwise -- so the checks are compiled out and most handlers leave `fault` alone)
+#define VM_NEED(n)        \
+    if constexpr (!SSP) { \
+        if (st.sp < (n)) VM_FAIL(VMF_STACK_UNDERFLOW) \
+    }
+#define VM_ROOM           \
+    if constexpr (!SSP) { \
+        if (st.sp >= RXR_VM_STACK) VM_FAIL(VMF_STACK_OVERFLOW) \
+    }
 // one value in, one out: the top of the stack is rewritten in registers
 #define VM_UN(expr)        \
     if (on) {              \
@@ -242,27 +270,22 @@ __device__ __forceinline__ uint32_t shade_inline(const RasterParams &P, uint32_t
     uint32_t fr_pc[RXR_VM_FRAMES], fr_base[RXR_VM_FRAMES], fr_lbase[RXR_VM_FRAMES], fr_llen[RXR_VM_FRAMES];
     uint32_t loop_base[RXR_VM_LOOPS];
     uint32_t nframes = 0, nloops = 0, lbase = 0, llen = prog.shade_locals, pc = prog.shade_entry, fault = 0, steps = 0;
-    bool has_ret = false, running = true;
+    bool has_ret = false;
     v3 ret = splat(0.0f);
     if (llen > RXR_VM_LOCALS) {
         fault = VMF_LOCALS_OVERFLOW;
-        running = false;
+        pc = VM_PC_STOPPED;
         llen = 0;
     }
     for (uint32_t i = 0; i < llen; ++i) locals[i] = splat(0.0f);
     for (uint32_t i = 0; i < prog.n_globals && i < RXR_VM_GLOBALS; ++i) globals[i] = splat(0.0f);
 
     for (;;) {
-        const unsigned long long running_mask = __ballot(running);
+        const unsigned long long running_mask = __builtin_amdgcn_ballot_w64(pc != VM_PC_STOPPED);
         if (running_mask == 0ull) break;
         // the instruction every lane at the smallest program counter executes now
-        const uint32_t upc = wave_min_pc(pc, running, running_mask);
-        const bool on = running && pc == upc;
-        if (on && ++steps > RXR_VM_MAX_STEPS) {
-            fault = VMF_STEP_LIMIT;
-            running = false;
-            continue;
-        }
+        const uint32_t upc = wave_min_pc(pc, running_mask);
+        const bool on = pc == upc;
         // the whole instruction (at most four words) in one go: an immediate fetched inside a handler would be a second
         // scalar-memory round trip per instruction (the stream is padded so that upc + 3 is always readable)
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -270,7 +293,16 @@ __device__ __forceinline__ uint32_t shade_inline(const RasterParams &P, uint32_t
         const u32x4 insn = *(code4_ptr)(code + upc);   // one s_load_dwordx4
         const uint32_t w = insn.x, imm0 = insn.y, imm1 = insn.z, imm2 = insn.w;
         if constexpr (SSP) st.sp = (w >> 16) & 0xFFu;
-        switch (w & 0xFFu) {
+        const uint32_t op = w & 0xFFu;
+        // One instruction, for the opcode K known at COMPILE time: the switch below folds to a single case in each of its
+        // instantiations, and vm_dispatch() reaches the right one through a binary tree of wave-uniform comparisons.  Why not
+        // a plain `switch (op)`: its lowered form is one region with a hundred conditional branches and a few divergent ones
+        // inside the handlers, which the compiler's control-flow structurizer linearises as a whole -- every handler then
+        // hands the complete interpreter state (30-odd VGPRs) through "flow" blocks, 30 to 60 register moves per VM
+        // instruction (two thirds of its VALU work).  In the tree every node is a region with ONE conditional branch, which
+        // the structurizer leaves alone, and a handler touches only the registers it changes.
+        auto handler = [&](auto K) __attribute__((always_inline)) {
+        switch (decltype(K)::value) {
             case RXR_NODE_LOAD_GLOBAL:
                 if (on) {
                     if (imm0 >= prog.n_globals) VM_FAIL(VMF_GLOBAL_INDEX)
@@ -401,7 +433,12 @@ __device__ __forceinline__ uint32_t shade_inline(const RasterParams &P, uint32_t
             case RXR_NODE_PACK3: VM_TER(mk(a.x, b.x, c.x))
             // ---- control flow (flattened If / For / FunctionCall / Return)
             case VM_JMP:
-                if (on) pc = imm0;
+                if (on) {
+                    if (imm0 <= upc) {  // the only way back in `shade`'s own code: a For loop's closing jump
+                        if (++steps > RXR_VM_MAX_STEPS) VM_FAIL(VMF_STEP_LIMIT)
+                    }
+                    pc = imm0;
+                }
                 break;
             case VM_JZ:
                 if (on) {
@@ -440,6 +477,7 @@ __device__ __forceinline__ uint32_t shade_inline(const RasterParams &P, uint32_t
                 if (on) {
                     const uint32_t arity = imm0, total = imm1, target = imm2;
                     if (nframes >= RXR_VM_FRAMES) VM_FAIL(VMF_CALL_DEPTH)
+                    if (++steps > RXR_VM_MAX_STEPS) VM_FAIL(VMF_STEP_LIMIT)
                     const uint32_t nb = lbase + llen;
                     if (nb + total > RXR_VM_LOCALS) VM_FAIL(VMF_LOCALS_OVERFLOW)
                     for (uint32_t i = 0; i < total; ++i) locals[nb + i] = splat(0.0f);
@@ -478,7 +516,7 @@ __device__ __forceinline__ uint32_t shade_inline(const RasterParams &P, uint32_t
             case VM_ENDFN:
                 if (on) {
                     if (nframes == 0u) {  // end of `shade`
-                        running = false;
+                        pc = VM_PC_STOPPED;
                         break;
                     }
                     --nframes;
@@ -653,6 +691,13 @@ __device__ __forceinline__ uint32_t shade_inline(const RasterParams &P, uint32_t
             default:
                 if (on) VM_FAIL(VMF_BAD_OPCODE)
                 break;
+        }
+        };
+        if (op < (uint32_t)RXR_NODE_COUNT) vm_dispatch<0u, (uint32_t)RXR_NODE_COUNT>(op, handler);
+        else if (op >= (uint32_t)VM_JMP && op <= (uint32_t)VM_BINC) vm_dispatch<(uint32_t)VM_JMP, (uint32_t)VM_BINC + 1u>(op, handler);
+        else if (on) {
+            fault = VMF_BAD_OPCODE;
+            pc = VM_PC_STOPPED;
         }
     }
     if (fault) *P.vm_fault = fault;
