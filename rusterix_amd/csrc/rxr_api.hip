@@ -603,6 +603,7 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
         return (uint32_t)shader < f->n_shader_programs ? (uint32_t)shader + 1u : 0u;
     };
     bool uses_programs = false, uses_chunk_tex = false;
+    bool vis_programs = false;  // an opaque-pass batch whose program may write `opacity`: the visibility loop has to run it (DB_FULL_ALPHA)
     bool any_3d_visible = false, any_3d_program = false;
     uint32_t reads_2d = 0;  // PF_* read-before-written by the programs of visible 2D batches
     int32_t first_opacity_chunk = -1;  // opacity batches in two or more chunks: surface_id needs the exact prefix order (level 1)
@@ -764,6 +765,7 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
         if (opacity_list) return RXR_OK;  // the opacity pass writes unconditionally (:1678-1682)
         if (prog_opacity) {
             d.flags |= DB_FULL_ALPHA;
+            vis_programs = true;
         } else if (alpha_never_255) {
             keep = false;  // encoded alpha != 255: never written (:1408)
         } else if (alpha_varies) {
@@ -1140,6 +1142,9 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
     const bool editor_paths = (P.has_brush && (f->flags & RXR_FLAG_D3_ACTIVE)) || f->background_kind == RXR_BG_GRID;
     P.kernel_level = std::max(ctx->min_kernel_level, uses_programs ? 2u : ((uses_chunk_tex || editor_paths) ? 1u : 0u));
     if (P.kernel_level == 2u && uses_programs && ctx->programs_static) P.kernel_level = 3u;  // k_raster_vm_s: wave-uniform stack pointer
+    // k_raster_vm_sv: ... and no program decides whether an opaque fragment is written, so the visibility loop is the one of
+    // k_raster_chunk, without a call of the interpreter in it
+    if (P.kernel_level == 3u && !vis_programs && !getenv("RXR_VM_VIS_CALLS")) P.kernel_level = 4u;
     P.programs = (const DevProgram *)ctx->d_programs.p;
     P.patterns = (const DevPattern *)ctx->d_patterns.p;
     P.pattern_data = (const float *)ctx->d_pattern_data.p;

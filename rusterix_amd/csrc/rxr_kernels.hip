@@ -462,7 +462,9 @@ __device__ __forceinline__ uint32_t batch_texel(const RasterParams &P, const Dev
 // Feature levels (template parameter X of the raster code): 0 common, 1 chunk paths, 2 + programs with the interpreter inlined
 // in the opaque pass, 3 = 2 with every interpreter site out of line; 4 / 5 = 2 / 3 with the wave-uniform stack pointer
 // (all programs of the set have static stack depths, rxr_vm.h SSP)
-template <int X> struct vm_level { static constexpr bool ssp = X >= 4; static constexpr bool inline_site = X == 2 || X == 4; static constexpr int out_of_line = X >= 4 ? 5 : 3; };
+// 6 = 4 for frames in which no program decides whether an opaque fragment is written (none of the opaque pass's programs
+// writes `opacity`): the visibility loop's alpha test is level 1's, inlined, and the loop contains no call
+template <int X> struct vm_level { static constexpr bool ssp = X >= 4; static constexpr bool inline_site = X == 2 || X == 4 || X == 6; static constexpr int out_of_line = X >= 4 ? 5 : 3; static constexpr bool vis_programs = X != 6; };
 
 // ---- the covered-fragment block of d3_rasterize after the depth test (rasterizer.rs:1062-1404) ----
 // Split in three so that the light loop runs in wave-uniform control flow (see shade3d_lights).
@@ -1315,7 +1317,7 @@ __device__ __noinline__ bool fragment_alpha_is_255_call(const RasterParams &P, c
 template <int X>
 __device__ __forceinline__ bool fragment_alpha_is_255_full(const RasterParams &P, const TriShade *shade, uint32_t batch, float alpha, float beta,
                                                            float z, float fx, float fy) {
-    if constexpr (X == 1) return fragment_alpha_is_255_body<X>(P, shade, batch, alpha, beta, z, fx, fy);
+    if constexpr (X == 1 || !vm_level<X>::vis_programs) return fragment_alpha_is_255_body<1>(P, shade, batch, alpha, beta, z, fx, fy);
     else return fragment_alpha_is_255_call<X>(P, shade, batch, alpha, beta, z, fx, fy);
 }
 
@@ -2188,6 +2190,8 @@ extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_CHUNK_WAVES_P
 extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_VM_WAVES_PER_SIMD) k_raster_vm(RasterParams) { raster_tile<false, 2, true>(kernarg_params()); }
 // the same with the wave-uniform stack pointer, for sets whose programs all have static stack depths (kernel_level 3)
 extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_VM_WAVES_PER_SIMD) k_raster_vm_s(RasterParams) { raster_tile<false, 4, true>(kernarg_params()); }
+// ... and without interpreter calls in the visibility loop (kernel_level 4; vm_level<6>)
+extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_VM_WAVES_PER_SIMD) k_raster_vm_sv(RasterParams) { raster_tile<false, 6, true>(kernarg_params()); }
 
 #if RXR_PHASE_TIMING
 extern "C" int rxr_debug_phase_read(unsigned long long *out16, int reset) {
@@ -2233,7 +2237,8 @@ extern "C" void rxr_launch_raster(const RasterParams *P, hipStream_t s) {
     uint32_t tiles = P->tiles_x * P->tiles_y;
     if (tiles == 0) return;
     const bool no_rows = getenv("RXR_NO_ROWS") != nullptr;  // tuning knob: binned scenes walk every candidate per pixel (k_raster)
-    if (P->kernel_level >= 3u) hipLaunchKernelGGL(k_raster_vm_s, dim3(tiles), dim3(RXR_TILE_THREADS), 0, s, *P);
+    if (P->kernel_level >= 4u) hipLaunchKernelGGL(k_raster_vm_sv, dim3(tiles), dim3(RXR_TILE_THREADS), 0, s, *P);
+    else if (P->kernel_level == 3u) hipLaunchKernelGGL(k_raster_vm_s, dim3(tiles), dim3(RXR_TILE_THREADS), 0, s, *P);
     else if (P->kernel_level == 2u) hipLaunchKernelGGL(k_raster_vm, dim3(tiles), dim3(RXR_TILE_THREADS), 0, s, *P);
     else if (P->kernel_level == 1u) hipLaunchKernelGGL(k_raster_chunk, dim3(tiles), dim3(RXR_TILE_THREADS), 0, s, *P);
     else if (P->fused_small == 1u) hipLaunchKernelGGL(k_raster_fused, dim3(tiles), dim3(RXR_TILE_THREADS), 0, s, *P);

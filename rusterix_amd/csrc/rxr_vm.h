@@ -134,6 +134,7 @@ struct Stack {
 // did not enter shade() (or left it) are masked off and must not be read.  One round when the wave has not diverged.
 __device__ __forceinline__ uint32_t wave_min_pc(uint32_t pc, unsigned long long running_mask) {
     uint32_t cand = (uint32_t)__builtin_amdgcn_readlane((int)pc, __ffsll((long long)running_mask) - 1);
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(pc < cand) == 0ull, 1)) return cand;   // nobody behind the first running lane: the usual case, kept out of the loop's bookkeeping
     for (;;) {
         const unsigned long long less = __builtin_amdgcn_ballot_w64(pc < cand);   // (a stopped lane sits at VM_PC_STOPPED)
         if (!less) return cand;
@@ -171,12 +172,50 @@ __device__ __noinline__ v3 slow_binary(uint32_t op, v3 a, v3 b) {
 // calls f(integral_constant<K>) for K == op, LO <= op < HI, through a balanced tree of comparisons (see shade_inline)
 template <uint32_t K>
 struct OpConst { static constexpr uint32_t value = K; };
+// How often an opcode is expected at run time (a guess from what shader programs are made of: arithmetic, pushes, field
+// access and locals are hot, libm calls and stack shuffles are not).  A VM instruction costs about as many SCALAR issue slots
+// as it has scalar instructions (measured: ~33 of them, 4 cycles each, against ~20 VALU), and every level of the tree is a
+// compare and a branch -- so the tree splits each range where the WEIGHT halves, not the count: hot opcodes sit 2-3 levels up.
+constexpr uint32_t op_weight(uint32_t op) {
+    switch (op) {
+        case RXR_NODE_PUSH: case RXR_NODE_ADD: case RXR_NODE_SUB: case RXR_NODE_MUL: case RXR_NODE_DIV: case RXR_NODE_LOAD_LOCAL:
+        case RXR_NODE_STORE_LOCAL: case RXR_NODE_UV: case RXR_NODE_COLOR: case RXR_NODE_SET_COLOR: case RXR_NODE_HITPOINT:
+        case VM_BINC: case VM_GETC: case VM_JZ: case VM_JMP: case VM_ENDFN:
+            return 32u;
+        case RXR_NODE_DOT: case RXR_NODE_LENGTH: case RXR_NODE_FRACT: case RXR_NODE_FLOOR: case RXR_NODE_MIX: case RXR_NODE_SMOOTHSTEP:
+        case RXR_NODE_CLAMP: case RXR_NODE_MIN: case RXR_NODE_MAX: case RXR_NODE_ABS: case RXR_NODE_NORMAL: case RXR_NODE_SAMPLE:
+        case RXR_NODE_PACK2: case RXR_NODE_PACK3: case RXR_NODE_STEP: case RXR_NODE_MOD: case RXR_NODE_NORMALIZE: case RXR_NODE_LT:
+        case RXR_NODE_GT: case RXR_NODE_SET_ROUGHNESS: case RXR_NODE_SET_METALLIC: case RXR_NODE_NEG: case RXR_NODE_SQRT:
+        case VM_SETC: case VM_CALL: case VM_RETURN: case VM_FOR_COND: case VM_FOR_ENTER: case VM_FOR_TRUNC: case VM_FOR_EXIT:
+            return 8u;
+        default: return 1u;
+    }
+}
+constexpr uint32_t op_weight_sum(uint32_t lo, uint32_t hi) {
+    uint32_t s = 0;
+    for (uint32_t i = lo; i < hi; ++i) s += op_weight(i);
+    return s;
+}
+// the split point of [lo, hi): the first m with weight(lo..m) >= half, kept strictly inside the range
+constexpr uint32_t op_split(uint32_t lo, uint32_t hi) {
+    const uint32_t total = op_weight_sum(lo, hi);
+    uint32_t acc = 0, best = lo + 1u, best_d = 0xFFFFFFFFu;
+    for (uint32_t m = lo + 1u; m < hi; ++m) {
+        acc += op_weight(m - 1u);
+        const uint32_t d = 2u * acc > total ? 2u * acc - total : total - 2u * acc;
+        if (d < best_d) {
+            best_d = d;
+            best = m;
+        }
+    }
+    return best;
+}
 template <uint32_t LO, uint32_t HI, class F>
 __device__ __forceinline__ void vm_dispatch(uint32_t op, F &f) {
     if constexpr (HI - LO == 1u) {
         f(OpConst<LO>{});
     } else {
-        constexpr uint32_t MID = (LO + HI) / 2u;
+        constexpr uint32_t MID = op_split(LO, HI);
         if (op < MID) vm_dispatch<LO, MID>(op, f);
         else vm_dispatch<MID, HI>(op, f);
     }

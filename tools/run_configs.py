@@ -39,6 +39,15 @@ def config(api, name):
         return scenes.box_grid_scene(api, n=289, width=7680, height=4320, shader=True)
     if name == "C5s_shader":
         return scenes.box_grid_scene(api, n=96, width=1920, height=1080, shader=True)
+    if name.startswith("C5s_vm:"):  # interpreter cost probes: C5s_shader's scene with a synthetic program (empty | u40 | b20 | g20 | m20)
+        kind = name.split(":", 1)[1]
+        body = {"empty": [],
+                "u40": ["Color"] + ["Abs"] * 40 + ["SetColor"],
+                "b20": ["Color"] + [("Push", 1.0), "Mul"] * 20 + ["SetColor"],
+                "g20": ["Color", "SetColor"] * 20,
+                "m20": ["Color"] + ["Color", "Mul"] * 20 + ["SetColor"]}[kind]
+        scenes.box_grid_shader = lambda: B.Program([body])
+        return scenes.box_grid_scene(api, n=96, width=1920, height=1080, shader=True)
     if name == "D2":  # 2D tile map: 60 x 34 textured / translucent rectangles + overlays + lines, render_2d mode
         return scenes.tile_map_2d_scene(api, width=1920, height=1080, nx=60, ny=34)
     raise SystemExit(f"unknown config {name}")
