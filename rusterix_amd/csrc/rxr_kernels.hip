@@ -33,13 +33,13 @@
 #include "rxr_project.h"
 #include "rxr_vm.h"
 
-// occupancy of k_raster_vm / k_raster_vm_s: 5 waves per SIMD = 96 VGPRs AND at most 32 KB of LDS per workgroup, which is why the
-// interpreter's LDS value stack holds 3 entries per lane (rxr_vm.h, RXR_VM_LDS_STACK; the top of the stack lives in registers,
-// so expressions up to depth 4 never touch scratch memory).  1 M triangles with the configuration-C5 program: 6 LDS entries
-// (38 KB: 4 workgroups per CU, whatever the register bound says) 1906 us, 3 entries + 5 waves 1772 us; 4 entries + 5 waves
-// 2049 us (32.5 KB rounds up past a fifth of the CU), 2 entries + 6 waves (80 VGPRs, spills) 2227 us; 8 entries 3228 us.
+// occupancy of k_raster_vm / k_raster_vm_s / k_raster_vm_sv: 6 waves per SIMD = 80 VGPRs AND at most 26.6 KB of LDS per workgroup,
+// which is why the interpreter's LDS value stack holds 2 entries per lane (rxr_vm.h, RXR_VM_LDS_STACK; the top of the stack lives
+// in registers, so expressions up to depth 3 never touch scratch memory).  1 M triangles with the configuration-C5 program, raster
+// kernel: 3 entries + 5 waves (96 VGPRs) 1178 us, 2 entries + 6 waves 1085 us, 1 entry + 7 waves (72 VGPRs, spills) 1337 us.
+// (Before the interpreter's dispatch became a tree -- rxr_vm.h -- its state needed the registers and 6 waves lost to 5.)
 #ifndef RXR_VM_WAVES_PER_SIMD
-#define RXR_VM_WAVES_PER_SIMD 5
+#define RXR_VM_WAVES_PER_SIMD 6
 #endif
 // 1: the opaque pass calls the out-of-line interpreter too (A-B runs: slower, 304 vs 236 us on the probe)
 #ifndef RXR_VM_ALWAYS_CALL

@@ -74,7 +74,7 @@ __device__ __forceinline__ float rclampf(float x, float lo, float hi) { return x
 // per-lane depth) with its top entry cached in registers, so an operation touches LDS at most once; deeper
 // stacks, locals, globals and call frames are in scratch memory.
 #ifndef RXR_VM_LDS_STACK
-#define RXR_VM_LDS_STACK 3  // sized for 5 workgroups per CU: see RXR_VM_WAVES_PER_SIMD in rxr_kernels.hip
+#define RXR_VM_LDS_STACK 2  // sized for 6 workgroups per CU: see RXR_VM_WAVES_PER_SIMD in rxr_kernels.hip
 #endif
 
 // (the LDS block is passed to every access instead of being stored here: a pointer kept in a struct that itself lives in

@@ -65,3 +65,18 @@ def test_k_raster_chunk_has_no_calls_and_little_scratch(isa):
     assert descriptor(isa, "k_raster_chunk", "next_free_vgpr") <= 64
     assert descriptor(isa, "k_raster_chunk", "private_segment_fixed_size") <= 64
     assert descriptor(isa, "k_raster_chunk", "group_segment_fixed_size") <= 20 * 1024
+
+
+def test_interpreter_kernels_keep_six_waves(isa):
+    """k_raster_vm*: 6 waves per SIMD need <= 80 VGPRs and 6 workgroups per CU need <= 160 KB / 6 of LDS each"""
+    for k in ("k_raster_vm", "k_raster_vm_s", "k_raster_vm_sv"):
+        assert descriptor(isa, k, "next_free_vgpr") <= 80, k
+        assert descriptor(isa, k, "group_segment_fixed_size") <= 160 * 1024 // 6, k
+
+
+def test_interpreter_dispatch_is_a_tree_of_scalar_branches(isa):
+    """the opcode dispatch must not come back as one structurized switch: that form handed the whole interpreter state through
+    flow blocks (30-60 v_mov per VM instruction, rxr_vm.h).  The register moves of the whole kernel are the fingerprint."""
+    body = kernel_body(isa, "k_raster_vm_sv")
+    moves = len(re.findall(r"\bv_mov_b32", body))
+    assert moves < 3200, f"{moves} v_mov_b32 in k_raster_vm_sv"
