@@ -1679,10 +1679,25 @@ struct Flattener {
                     // ("tos = tos op c"), the commonest pair in compiled expressions
                     if (i + 3 < n) {
                         const uint32_t nx = w[i + 3];
-                        if (nx == RXR_NODE_ADD || nx == RXR_NODE_SUB || nx == RXR_NODE_MUL || nx == RXR_NODE_DIV || nx == RXR_NODE_MIN ||
-                            nx == RXR_NODE_MAX || nx == RXR_NODE_MOD || nx == RXR_NODE_LT || nx == RXR_NODE_LE || nx == RXR_NODE_GT ||
-                            nx == RXR_NODE_GE || nx == RXR_NODE_EQ || nx == RXR_NODE_NE) {
-                            code.push_back((uint32_t)VM_BINC | (nx << 8));
+                        int fused = -1;
+                        switch (nx) {
+                            case RXR_NODE_ADD: fused = VM_BINC_ADD; break;
+                            case RXR_NODE_SUB: fused = VM_BINC_SUB; break;
+                            case RXR_NODE_MUL: fused = VM_BINC_MUL; break;
+                            case RXR_NODE_DIV: fused = VM_BINC_DIV; break;
+                            case RXR_NODE_MIN: fused = VM_BINC_MIN; break;
+                            case RXR_NODE_MAX: fused = VM_BINC_MAX; break;
+                            case RXR_NODE_MOD: fused = VM_BINC_MOD; break;
+                            case RXR_NODE_LT: fused = VM_BINC_LT; break;
+                            case RXR_NODE_LE: fused = VM_BINC_LE; break;
+                            case RXR_NODE_GT: fused = VM_BINC_GT; break;
+                            case RXR_NODE_GE: fused = VM_BINC_GE; break;
+                            case RXR_NODE_EQ: fused = VM_BINC_EQ; break;
+                            case RXR_NODE_NE: fused = VM_BINC_NE; break;
+                            default: break;
+                        }
+                        if (fused >= 0) {
+                            code.push_back((uint32_t)VM_BINC | ((uint32_t)fused << 8));
                             code.push_back(w[i]);
                             code.push_back(w[i + 1]);
                             code.push_back(w[i + 2]);

@@ -125,8 +125,12 @@ enum : uint32_t {
     VM_FAULT = 137,      // statically known panic (e.g. a call of a function that does not exist)
     VM_GETC = 138,       // GetComponents: next word = n | idx0 << 4 | idx1 << 6 ... (2 bits each, 3 = "not x/y/z")
     VM_SETC = 139,       // SetComponents, same encoding
-    VM_BINC = 140,       // fused "Push c; <binary op>": bits 8..15 = the RXR_NODE_* binary opcode, then the f32 bits of c.x, c.y, c.z
+    VM_BINC = 140,       // fused "Push c; <binary op>": bits 8..15 = which one (VM_BINC_*), then the f32 bits of c.x, c.y, c.z
 };
+// the binary operations VM_BINC fuses, numbered densely (the interpreter dispatches on them through a balanced tree)
+enum { VM_BINC_ADD = 0, VM_BINC_SUB, VM_BINC_MUL, VM_BINC_DIV, VM_BINC_MIN, VM_BINC_MAX, VM_BINC_MOD, VM_BINC_LT, VM_BINC_LE, VM_BINC_GT,
+       VM_BINC_GE, VM_BINC_EQ, VM_BINC_NE, VM_BINC_COUNT };
+
 #define RXR_VM_STACK 64
 #define RXR_VM_LOCALS 48
 #define RXR_VM_GLOBALS 16

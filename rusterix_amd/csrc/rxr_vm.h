@@ -210,6 +210,17 @@ constexpr uint32_t op_split(uint32_t lo, uint32_t hi) {
     }
     return best;
 }
+// (the same with halves of equal size)
+template <uint32_t LO, uint32_t HI, class F>
+__device__ __forceinline__ void vm_dispatch_even(uint32_t op, F &f) {
+    if constexpr (HI - LO == 1u) {
+        f(OpConst<LO>{});
+    } else {
+        constexpr uint32_t MID = (LO + HI) / 2u;
+        if (op < MID) vm_dispatch_even<LO, MID>(op, f);
+        else vm_dispatch_even<MID, HI>(op, f);
+    }
+}
 template <uint32_t LO, uint32_t HI, class F>
 __device__ __forceinline__ void vm_dispatch(uint32_t op, F &f) {
     if constexpr (HI - LO == 1u) {
@@ -429,30 +440,39 @@ __device__ __forceinline__ uint32_t shade_inline(const RasterParams &P, uint32_t
                     pc = upc + 4u;
                 }
                 break;
-            case VM_BINC:  // "Push c; op" fused by rxr_set_shaders: the same values, no stack traffic
+            case VM_BINC: {  // "Push c; op" fused by rxr_set_shaders: the same values, no stack traffic
+                // which operation: a second tree of uniform branches, OUTSIDE the divergent part (inside `if (on)` the
+                // structurizer would turn a switch into a chain of thirteen masked blocks)
                 if (on) {
                     VM_NEED(1u)
-                    const v3 a = st.tos, b = mk(__uint_as_float(imm0), __uint_as_float(imm1), __uint_as_float(imm2));
-                    v3 r;
-                    switch ((w >> 8) & 0xFFu) {
-                        case RXR_NODE_ADD: r = mk(a.x + b.x, a.y + b.y, a.z + b.z); break;
-                        case RXR_NODE_SUB: r = mk(a.x - b.x, a.y - b.y, a.z - b.z); break;
-                        case RXR_NODE_MUL: r = mk(a.x * b.x, a.y * b.y, a.z * b.z); break;
-                        case RXR_NODE_DIV: r = mk(a.x / b.x, a.y / b.y, a.z / b.z); break;
-                        case RXR_NODE_MIN: r = mk(fminf(a.x, b.x), fminf(a.y, b.y), fminf(a.z, b.z)); break;
-                        case RXR_NODE_MAX: r = mk(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z)); break;
-                        case RXR_NODE_MOD: r = mk(a.x - b.x * floorf(a.x / b.x), a.y - b.y * floorf(a.y / b.y), a.z - b.z * floorf(a.z / b.z)); break;
-                        case RXR_NODE_LT: r = splat(a.x < b.x ? 1.0f : 0.0f); break;
-                        case RXR_NODE_LE: r = splat(a.x <= b.x ? 1.0f : 0.0f); break;
-                        case RXR_NODE_GT: r = splat(a.x > b.x ? 1.0f : 0.0f); break;
-                        case RXR_NODE_GE: r = splat(a.x >= b.x ? 1.0f : 0.0f); break;
-                        case RXR_NODE_EQ: r = splat(a.x == b.x ? 1.0f : 0.0f); break;
-                        default: r = splat(a.x != b.x ? 1.0f : 0.0f); break;  // RXR_NODE_NE
+                }
+                const v3 a = st.tos, b = mk(__uint_as_float(imm0), __uint_as_float(imm1), __uint_as_float(imm2));
+                v3 r = a;
+                auto fused = [&](auto J) __attribute__((always_inline)) {
+                    switch (decltype(J)::value) {
+                        case VM_BINC_ADD: r = mk(a.x + b.x, a.y + b.y, a.z + b.z); break;
+                        case VM_BINC_SUB: r = mk(a.x - b.x, a.y - b.y, a.z - b.z); break;
+                        case VM_BINC_MUL: r = mk(a.x * b.x, a.y * b.y, a.z * b.z); break;
+                        case VM_BINC_DIV: r = mk(a.x / b.x, a.y / b.y, a.z / b.z); break;
+                        case VM_BINC_MIN: r = mk(fminf(a.x, b.x), fminf(a.y, b.y), fminf(a.z, b.z)); break;
+                        case VM_BINC_MAX: r = mk(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z)); break;
+                        case VM_BINC_MOD: r = mk(a.x - b.x * floorf(a.x / b.x), a.y - b.y * floorf(a.y / b.y), a.z - b.z * floorf(a.z / b.z)); break;
+                        case VM_BINC_LT: r = splat(a.x < b.x ? 1.0f : 0.0f); break;
+                        case VM_BINC_LE: r = splat(a.x <= b.x ? 1.0f : 0.0f); break;
+                        case VM_BINC_GT: r = splat(a.x > b.x ? 1.0f : 0.0f); break;
+                        case VM_BINC_GE: r = splat(a.x >= b.x ? 1.0f : 0.0f); break;
+                        case VM_BINC_EQ: r = splat(a.x == b.x ? 1.0f : 0.0f); break;
+                        default: r = splat(a.x != b.x ? 1.0f : 0.0f); break;  // VM_BINC_NE
                     }
+                };
+                const uint32_t which = (w >> 8) & 0xFFu;
+                vm_dispatch_even<0u, (uint32_t)VM_BINC_COUNT>(which < (uint32_t)VM_BINC_COUNT ? which : (uint32_t)VM_BINC_NE, fused);
+                if (on) {
                     st.tos = r;
                     pc = upc + 4u;
                 }
                 break;
+            }
             case RXR_NODE_CLEAR:
                 if (on) {
                     if (st.sp) (void)st.pop(vm_lds, deep);
