@@ -387,3 +387,48 @@ def test_static_and_dynamic_stack_pointer_agree(oracle, product, seed, monkeypat
     monkeypatch.setenv("RXR_VM_NO_STATIC", "1")
     dynamic = scenes.render(build(product)).copy()
     assert np.array_equal(static, ref) and np.array_equal(dynamic, ref)
+
+
+@pytest.mark.parametrize("scene", ["grid", "cube", "rows-cutout"])
+def test_visibility_with_and_without_interpreter_calls_agree(oracle, product, scene, monkeypatch):
+    """Frames whose opaque-pass programs never write `opacity` run k_raster_vm_sv (kernel level 4: the visibility loop of the
+    chunk kernel, no call of the interpreter in it); RXR_VM_VIS_CALLS forces level 3.  Both must give the oracle's frame."""
+    colour = Program([["Color", "UV", ("Push", 3.0), "Mul", "Fract", "Mul", ("Push", 1.3), "Mul", "SetColor"]])
+    if scene == "grid":
+        build = lambda api: scenes.box_grid_scene(api, n=24, width=320, height=200, shader=True)   # noqa: E731
+        tol = 0
+    elif scene == "cube":
+        build = lambda api: cube_scene(api, colour)   # noqa: E731
+        tol = TOLERANCE
+    else:
+        from tests import test_gpu_rows as R
+        from tests.test_gpu_fuzz import random_texture
+
+        def build(api):   # small-triangle meshes with cut-out textures (the alpha test of the visibility loop), every batch with the program
+            rng = np.random.default_rng(99)
+            textures = [B.Tile([random_texture(rng, 16, 16, mode)]) for mode in (0, 2, 1)]
+            assets = api.Assets.default().textures(textures)
+            scene = api.Scene.empty()
+            index = scene.add_program(colour)
+            for m in range(3):
+                v4, idx, uv = R.small_triangles(rng, 400, 0.09, 1.2)
+                b = api.Batch3D.new(v4, idx, uv).with_computed_normals().cull_mode(0)
+                b.source(B.PixelSource.StaticTileIndex(m)).repeat_mode(B.REPEAT_REPEAT_XY).shader(index)
+                scene.add_d3_static(b)
+            cam = api.D3OrbitCamera.new()
+            cam.set_parameter_f32("distance", 3.0)
+
+            def setup():
+                v, p = cam.matrices(219.0, 140.0)
+                return api.Rasterizer.setup(None, v, p)
+
+            return scenes._result(api, scene, assets, setup, 219, 140, 40, "rows-cutout-program")
+        tol = 0
+    ref = scenes.render(build(oracle)).copy()
+    monkeypatch.delenv("RXR_VM_VIS_CALLS", raising=False)
+    level4 = scenes.render(build(product)).copy()
+    monkeypatch.setenv("RXR_VM_VIS_CALLS", "1")
+    level3 = scenes.render(build(product)).copy()
+    for name, got in (("level 4", level4), ("level 3", level3)):
+        diff = np.abs(got.astype(np.int16) - ref.astype(np.int16)).max(axis=2)
+        assert (diff > tol).sum() <= (5 if tol else 0), f"{scene} {name}: {(diff > tol).sum()} pixels differ (max {diff.max()})"
