@@ -1145,6 +1145,7 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
     // k_raster_vm_sv: ... and no program decides whether an opaque fragment is written, so the visibility loop is the one of
     // k_raster_chunk, without a call of the interpreter in it
     if (P.kernel_level == 3u && !vis_programs && !getenv("RXR_VM_VIS_CALLS")) P.kernel_level = 4u;
+    else if (P.kernel_level == 2u && uses_programs && !vis_programs && !getenv("RXR_VM_VIS_CALLS")) P.kernel_level = 5u;  // k_raster_vm_v
     P.programs = (const DevProgram *)ctx->d_programs.p;
     P.patterns = (const DevPattern *)ctx->d_patterns.p;
     P.pattern_data = (const float *)ctx->d_pattern_data.p;

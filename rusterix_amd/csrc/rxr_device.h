@@ -230,7 +230,7 @@ struct RasterParams {
     // Rusteria programs (rxr_set_shaders)
     uint32_t kernel_level;             // 0: k_raster; 1: k_raster_chunk (a visible batch uses a terrain / baked texture);
                                        // 2: k_raster_vm (a visible batch runs a program); 3: k_raster_vm_s (all programs have static
-                                       // stack depths); 4: k_raster_vm_sv (3, and no opaque-pass program writes `opacity`)
+                                       // stack depths); 4: k_raster_vm_sv (3, and no opaque-pass program writes `opacity`); 5: k_raster_vm_v (2, likewise)
     const uint32_t *vm_code;
     const DevProgram *programs;
     const DevPattern *patterns;        // n_patterns colour patterns, then n_normal_patterns normal patterns

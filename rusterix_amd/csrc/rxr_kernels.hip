@@ -464,7 +464,8 @@ __device__ __forceinline__ uint32_t batch_texel(const RasterParams &P, const Dev
 // (all programs of the set have static stack depths, rxr_vm.h SSP)
 // 6 = 4 for frames in which no program decides whether an opaque fragment is written (none of the opaque pass's programs
 // writes `opacity`): the visibility loop's alpha test is level 1's, inlined, and the loop contains no call
-template <int X> struct vm_level { static constexpr bool ssp = X >= 4; static constexpr bool inline_site = X == 2 || X == 4 || X == 6; static constexpr int out_of_line = X >= 4 ? 5 : 3; static constexpr bool vis_programs = X != 6; };
+// 7 = 2 for such frames (programs with calls or PaletteIndex: per-lane stack pointer)
+template <int X> struct vm_level { static constexpr bool ssp = X >= 4 && X <= 6; static constexpr bool inline_site = X == 2 || X == 4 || X == 6 || X == 7; static constexpr int out_of_line = ssp ? 5 : 3; static constexpr bool vis_programs = X < 6; };
 
 // ---- the covered-fragment block of d3_rasterize after the depth test (rasterizer.rs:1062-1404) ----
 // Split in three so that the light loop runs in wave-uniform control flow (see shade3d_lights).
@@ -2192,6 +2193,8 @@ extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_VM_WAVES_PER_
 extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_VM_WAVES_PER_SIMD) k_raster_vm_s(RasterParams) { raster_tile<false, 4, true>(kernarg_params()); }
 // ... and without interpreter calls in the visibility loop (kernel_level 4; vm_level<6>)
 extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_VM_WAVES_PER_SIMD) k_raster_vm_sv(RasterParams) { raster_tile<false, 6, true>(kernarg_params()); }
+// the per-lane stack pointer without interpreter calls in the visibility loop (kernel_level 5; vm_level<7>)
+extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_VM_WAVES_PER_SIMD) k_raster_vm_v(RasterParams) { raster_tile<false, 7, true>(kernarg_params()); }
 
 #if RXR_PHASE_TIMING
 extern "C" int rxr_debug_phase_read(unsigned long long *out16, int reset) {
@@ -2237,7 +2240,8 @@ extern "C" void rxr_launch_raster(const RasterParams *P, hipStream_t s) {
     uint32_t tiles = P->tiles_x * P->tiles_y;
     if (tiles == 0) return;
     const bool no_rows = getenv("RXR_NO_ROWS") != nullptr;  // tuning knob: binned scenes walk every candidate per pixel (k_raster)
-    if (P->kernel_level >= 4u) hipLaunchKernelGGL(k_raster_vm_sv, dim3(tiles), dim3(RXR_TILE_THREADS), 0, s, *P);
+    if (P->kernel_level >= 5u) hipLaunchKernelGGL(k_raster_vm_v, dim3(tiles), dim3(RXR_TILE_THREADS), 0, s, *P);
+    else if (P->kernel_level == 4u) hipLaunchKernelGGL(k_raster_vm_sv, dim3(tiles), dim3(RXR_TILE_THREADS), 0, s, *P);
     else if (P->kernel_level == 3u) hipLaunchKernelGGL(k_raster_vm_s, dim3(tiles), dim3(RXR_TILE_THREADS), 0, s, *P);
     else if (P->kernel_level == 2u) hipLaunchKernelGGL(k_raster_vm, dim3(tiles), dim3(RXR_TILE_THREADS), 0, s, *P);
     else if (P->kernel_level == 1u) hipLaunchKernelGGL(k_raster_chunk, dim3(tiles), dim3(RXR_TILE_THREADS), 0, s, *P);

@@ -389,15 +389,18 @@ def test_static_and_dynamic_stack_pointer_agree(oracle, product, seed, monkeypat
     assert np.array_equal(static, ref) and np.array_equal(dynamic, ref)
 
 
-@pytest.mark.parametrize("scene", ["grid", "cube", "rows-cutout"])
+@pytest.mark.parametrize("scene", ["grid", "cube", "cube-calls", "rows-cutout"])
 def test_visibility_with_and_without_interpreter_calls_agree(oracle, product, scene, monkeypatch):
     """Frames whose opaque-pass programs never write `opacity` run k_raster_vm_sv (kernel level 4: the visibility loop of the
-    chunk kernel, no call of the interpreter in it); RXR_VM_VIS_CALLS forces level 3.  Both must give the oracle's frame."""
+    chunk kernel, no call of the interpreter in it; level 5, k_raster_vm_v, when a program has calls and the stack pointer
+    is per lane); RXR_VM_VIS_CALLS forces levels 3 / 2.  Both must give the oracle's frame."""
     colour = Program([["Color", "UV", ("Push", 3.0), "Mul", "Fract", "Mul", ("Push", 1.3), "Mul", "SetColor"]])
+    if scene == "cube-calls":
+        colour = Program([["Color", "UV", ("FunctionCall", 1, 1, 1), "Mul", "SetColor"], [("LoadLocal", 0), ("Push", 3.0), "Mul", "Fract", ("Push", 1.3), "Mul"]])
     if scene == "grid":
         build = lambda api: scenes.box_grid_scene(api, n=24, width=320, height=200, shader=True)   # noqa: E731
         tol = 0
-    elif scene == "cube":
+    elif scene in ("cube", "cube-calls"):
         build = lambda api: cube_scene(api, colour)   # noqa: E731
         tol = TOLERANCE
     else:

@@ -69,7 +69,7 @@ def test_k_raster_chunk_has_no_calls_and_little_scratch(isa):
 
 def test_interpreter_kernels_keep_six_waves(isa):
     """k_raster_vm*: 6 waves per SIMD need <= 80 VGPRs and 6 workgroups per CU need <= 160 KB / 6 of LDS each"""
-    for k in ("k_raster_vm", "k_raster_vm_s", "k_raster_vm_sv"):
+    for k in ("k_raster_vm", "k_raster_vm_s", "k_raster_vm_sv", "k_raster_vm_v"):
         assert descriptor(isa, k, "next_free_vgpr") <= 80, k
         assert descriptor(isa, k, "group_segment_fixed_size") <= 160 * 1024 // 6, k
 
