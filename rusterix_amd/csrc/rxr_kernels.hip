@@ -981,13 +981,51 @@ __device__ __forceinline__ uint32_t wave_bin_increment(uint32_t *counter, uint32
     return base + (lane - first);
 }
 
+// The records leave through LDS: a thread's own 96 + 80 bytes are eleven 16-byte stores at a stride of 96 / 80 bytes across the
+// wave (every store instruction touches 64 cache lines, a sixth of each); transposed, the workgroup's 256 records are one
+// contiguous 24 KB / 20 KB block that consecutive lanes write 16 bytes at a time.
+#ifndef RXR_SETUP_TRANSPOSE
+#define RXR_SETUP_TRANSPOSE 1
+#endif
 extern "C" __global__ void __launch_bounds__(256) k_setup3d(RasterParams P) {
-    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t t0 = blockIdx.x * blockDim.x;
+    uint32_t t = t0 + threadIdx.x;
     bool live = false;
-    TriSetup S;
-    TriShade H;
+    TriSetup S = {};
+    TriShade H = {};
+    if (t < P.n_tris3d) live = make_setup(P, t, S, H);
+#if RXR_SETUP_TRANSPOSE
+    {
+        // (a triangle that can never be a candidate -- culled, clipped away, empty box -- has bx = by = 0: the lists skip it and
+        // the implicit-list path rejects its empty box; its other fields are whatever make_setup got to, zero at the least)
+        __shared__ uint4 xpose[256 * 6];
+        const uint32_t tid = threadIdx.x;
+        const uint32_t n_here = min(256u, P.n_tris3d - t0);   // the grid covers n_tris3d: t0 < n_tris3d
+        uint4 rec[6];
+        __builtin_memcpy(rec, &S, sizeof(S));
+#pragma unroll
+        for (int i = 0; i < 6; ++i) xpose[tid * 6u + i] = rec[i];
+        __syncthreads();
+        uint4 *dst = reinterpret_cast<uint4 *>(P.tri_setup + t0);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const uint32_t k = (uint32_t)i * 256u + tid;
+            if (k < n_here * 6u) dst[k] = xpose[k];
+        }
+        __syncthreads();
+        __builtin_memcpy(rec, &H, sizeof(H));
+#pragma unroll
+        for (int i = 0; i < 5; ++i) xpose[tid * 5u + i] = rec[i];
+        __syncthreads();
+        dst = reinterpret_cast<uint4 *>(P.tri_shade + t0);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const uint32_t k = (uint32_t)i * 256u + tid;
+            if (k < n_here * 5u) dst[k] = xpose[k];
+        }
+    }
+#else
     if (t < P.n_tris3d) {
-        live = make_setup(P, t, S, H);
         if (live) {
             P.tri_shade[t] = H;
             P.tri_setup[t] = S;
@@ -996,6 +1034,7 @@ extern "C" __global__ void __launch_bounds__(256) k_setup3d(RasterParams P) {
             *reinterpret_cast<uint2 *>(&P.tri_setup[t].bx) = make_uint2(0u, 0u);
         }
     }
+#endif
     if (P.fused_small) return;  // small scenes are not binned (see scan_implicit); uniform
     uint32_t bx0 = 0, bx1 = 0, by0 = 0, by1 = 0, nb = 0;
     if (live) {
