@@ -92,7 +92,7 @@ struct rxr_ctx {
     void *h_stage = nullptr;
     size_t h_stage_cap = 0;
     DevBuf d_frame;
-    DevBuf d_tri_setup, d_tri_shade, d_bin_count, d_bins, d_list, d_large, d_counters, d_fb;
+    DevBuf d_tri_setup, d_tri_shade, d_tri_box, d_bin_count, d_bins, d_list, d_large, d_counters, d_fb;
     DevBuf d_bin2d_count, d_bins2d, d_list2d, d_large2d;
     uint32_t list2d_capacity = 0, parity2d = 0;
     uint32_t *h_counters = nullptr;  // pinned, CNT_WORDS; written by k_scan through d_host_status
@@ -255,7 +255,7 @@ void rxr_destroy(rxr_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    DevBuf *bufs[] = {&ctx->d_obj, &ctx->d_proj_out, &ctx->d_proj_misc, &ctx->d_tex, &ctx->d_texels, &ctx->d_frame, &ctx->d_tri_setup, &ctx->d_tri_shade, &ctx->d_bin_count, &ctx->d_bins, &ctx->d_bin2d_count, &ctx->d_bins2d,
+    DevBuf *bufs[] = {&ctx->d_obj, &ctx->d_proj_out, &ctx->d_proj_misc, &ctx->d_tex, &ctx->d_texels, &ctx->d_frame, &ctx->d_tri_setup, &ctx->d_tri_shade, &ctx->d_tri_box, &ctx->d_bin_count, &ctx->d_bins, &ctx->d_bin2d_count, &ctx->d_bins2d,
                       &ctx->d_list2d, &ctx->d_large2d,
                       &ctx->d_list, &ctx->d_large, &ctx->d_counters, &ctx->d_fb,
                       &ctx->d_vm_code, &ctx->d_programs, &ctx->d_patterns, &ctx->d_pattern_data, &ctx->d_palette};
@@ -1058,6 +1058,7 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
     size_t n_bins = (size_t)tiles_x * tiles_y_all;
     if ((rc = ensure(ctx, ctx->d_tri_setup, (n_t3 ? n_t3 : 1) * sizeof(TriSetup))) != RXR_OK) return rc;
     if ((rc = ensure(ctx, ctx->d_tri_shade, (n_t3 ? n_t3 : 1) * sizeof(TriShade))) != RXR_OK) return rc;
+    if ((rc = ensure(ctx, ctx->d_tri_box, (n_t3 ? n_t3 : 1) * sizeof(uint2))) != RXR_OK) return rc;
     const size_t n_chunks = (n_bins + RXR_SCAN_CHUNK - 1) / RXR_SCAN_CHUNK + 1;
     {
         // bin_count lives in its OWN buffer: the invariant "all-zero between launches" (k_raster hands every
@@ -1181,6 +1182,7 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
     P.batch_tri_base = (const uint32_t *)(d + L.off_base);
     P.tri_setup = (TriSetup *)ctx->d_tri_setup.p;
     P.tri_shade = (TriShade *)ctx->d_tri_shade.p;
+    P.tri_box = (uint2 *)ctx->d_tri_box.p;
     P.bin_count = (uint32_t *)ctx->d_bin_count.p;
     P.bin_offset = (uint32_t *)ctx->d_bins.p;
     P.bin_cursor = P.bin_offset + n_bins + 1;

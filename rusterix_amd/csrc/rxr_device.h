@@ -203,6 +203,7 @@ struct RasterParams {
     // set-up outputs
     TriSetup *tri_setup;
     TriShade *tri_shade;
+    uint2 *tri_box;                    // (bx, by) of every TriSetup once more, densely: k_fill reads these 8 bytes instead of a 96-byte stride
     uint32_t *bin_count;           // tiles_x * tiles_y; all-zero between launches (k_raster clears its own bin)
     uint32_t *bin_offset;          // chunk-local exclusive scan of bin_count; add chunk_base[bin / RXR_SCAN_CHUNK]
     uint32_t *bin_cursor;

@@ -993,7 +993,10 @@ extern "C" __global__ void __launch_bounds__(256) k_setup3d(RasterParams P) {
     bool live = false;
     TriSetup S = {};
     TriShade H = {};
-    if (t < P.n_tris3d) live = make_setup(P, t, S, H);
+    if (t < P.n_tris3d) {
+        live = make_setup(P, t, S, H);
+        P.tri_box[t] = make_uint2(S.bx, S.by);
+    }
 #if RXR_SETUP_TRANSPOSE
     {
         // (a triangle that can never be a candidate -- culled, clipped away, empty box -- has bx = by = 0: the lists skip it and
@@ -1146,7 +1149,8 @@ extern "C" __global__ void __launch_bounds__(256) k_fill(RasterParams P) {
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t bx0 = 0, bx1 = 0, by0 = 0, by1 = 0, nb = 0;
     if (t < P.n_tris3d) {
-        uint32_t bxw = P.tri_setup[t].bx, byw = P.tri_setup[t].by;
+        const uint2 box = P.tri_box[t];
+        uint32_t bxw = box.x, byw = box.y;
         uint32_t min_x = bxw & 0xFFFFu, max_x = bxw >> 16, min_y = byw & 0xFFFFu, max_y = byw >> 16;
         if (bin_range(P, min_x, max_x, min_y, max_y, bx0, bx1, by0, by1)) nb = (bx1 - bx0 + 1) * (by1 - by0 + 1);
         if (nb > RXR_LARGE_BINS) nb = 0;  // on the large list
