@@ -1004,6 +1004,12 @@ extern "C" __global__ void __launch_bounds__(256) k_setup3d(RasterParams P) {
         __shared__ uint4 xpose[256 * 6];
         const uint32_t tid = threadIdx.x;
         const uint32_t n_here = min(256u, P.n_tris3d - t0);   // the grid covers n_tris3d: t0 < n_tris3d
+        // a workgroup without a single live triangle (the unused output slots behind a device-projected mesh: two thirds of
+        // the slots of an unclipped scene) only marks its records as empty
+        if (!__syncthreads_or(live ? 1 : 0)) {
+            if (t < P.n_tris3d) *reinterpret_cast<uint2 *>(&P.tri_setup[t].bx) = make_uint2(0u, 0u);
+            return;   // (nothing to bin either)
+        }
         uint4 rec[6];
         __builtin_memcpy(rec, &S, sizeof(S));
 #pragma unroll
