@@ -54,6 +54,24 @@ __device__ __forceinline__ uint32_t find_mesh(const uint32_t *prefix, uint32_t n
     return lo;
 }
 
+// The same for the 64 consecutive items of a wave (i = first + lane, lanes in item order; call with all lanes that have an
+// item): they nearly always belong to one mesh, so the search runs once, for the wave's first item, with scalar loads through
+// the constant address space (the prefix is read-only for the launch) -- not nine dependent vector-memory round trips at the
+// head of every thread.  Only a wave that straddles a mesh boundary searches per lane.
+__device__ __forceinline__ uint32_t find_mesh_wave(const uint32_t *prefix, uint32_t n, uint32_t i) {
+    typedef const uint32_t __attribute__((address_space(4))) *cptr;
+    const cptr cp = (cptr)prefix;
+    const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)i);
+    uint32_t lo = 0, hi = n;
+    while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (cp[mid] <= first) lo = mid;
+        else hi = mid;
+    }
+    if (lo + 1u < n && cp[lo + 1u] <= first + 63u) return find_mesh(prefix, n, i);   // wave-uniform branch
+    return lo;
+}
+
 // projection to the screen, batch3d.rs:689-700
 __device__ __forceinline__ float4 to_screen(const ProjectParams &P, float4 vs) {
     float4 r = mat4_mul(P.projection, vs);
@@ -176,7 +194,7 @@ extern "C" __global__ void __launch_bounds__(256) k_proj_vertices(ProjectParams 
     uint32_t b = 0;
     float4 s = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (active) {
-        b = find_mesh(P.vin_prefix, P.n_meshes, i);
+        b = find_mesh_wave(P.vin_prefix, P.n_meshes, i);
         const DevMesh &M = P.meshes[b];
         active = !M.rejected;
         if (active) {
@@ -198,7 +216,7 @@ extern "C" __global__ void __launch_bounds__(256) k_clip_count(ProjectParams P) 
         P.append[t] = 0ull;
         return;
     }
-    uint32_t b = find_mesh(P.tin_prefix, P.n_meshes, t);
+    uint32_t b = find_mesh_wave(P.tin_prefix, P.n_meshes, t);
     const DevMesh &M = P.meshes[b];
     if (M.rejected) {
         P.append[t] = 0ull;
@@ -288,7 +306,7 @@ __device__ __forceinline__ AppendCount prefix_at(const ProjectParams &P, uint32_
 extern "C" __global__ void __launch_bounds__(256) k_clip_emit(ProjectParams P) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= P.n_tris_in) return;
-    uint32_t b = find_mesh(P.tin_prefix, P.n_meshes, t);
+    uint32_t b = find_mesh_wave(P.tin_prefix, P.n_meshes, t);
     const DevMesh &M = P.meshes[b];
     if (M.rejected) return;
     const uint32_t *ix = P.obj_idx + 3 * (size_t)t;
@@ -359,7 +377,7 @@ extern "C" __global__ void __launch_bounds__(256) k_clip_emit(ProjectParams P) {
 extern "C" __global__ void __launch_bounds__(256) k_proj_edges(ProjectParams P) {
     uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= P.n_tris_out) return;
-    uint32_t b = find_mesh(P.tout_prefix, P.n_meshes, s);
+    uint32_t b = find_mesh_wave(P.tout_prefix, P.n_meshes, s);
     const DevMesh &M = P.meshes[b];
     uint32_t local = s - M.tout_base;
     rxr_edges E;
