@@ -31,7 +31,7 @@ struct alignas(128) DevBBox {
 // at the mesh's first triangle)
 typedef unsigned long long AppendCount;
 
-#define RXR_PROJ_SCAN_CHUNK 2048u
+#define RXR_PROJ_SCAN_CHUNK 8192u
 
 struct ProjectParams {
     uint32_t n_meshes, n_verts_in, n_tris_in;  // totals over all meshes (object space)
