@@ -374,9 +374,8 @@ extern "C" __global__ void __launch_bounds__(256) k_clip_emit(ProjectParams P) {
 }
 
 // per frame: Edges for every triangle slot (:706-739 + edge.rs:12-24); unused slots become invisible
-extern "C" __global__ void __launch_bounds__(256) k_proj_edges(ProjectParams P) {
-    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= P.n_tris_out) return;
+// one slot's record (all zero = unused / invisible)
+__device__ __forceinline__ rxr_edges edges_of_slot(const ProjectParams &P, uint32_t s) {
     uint32_t b = find_mesh_wave(P.tout_prefix, P.n_meshes, s);
     const DevMesh &M = P.meshes[b];
     uint32_t local = s - M.tout_base;
@@ -394,10 +393,7 @@ extern "C" __global__ void __launch_bounds__(256) k_proj_edges(ProjectParams P) 
             used = (local - M.n_tris) < (uint32_t)(tot >> 32);  // appended fans: edge_visibility defaults to true (:731-732)
         }
     }
-    if (!used) {
-        P.edges[s] = E;
-        return;
-    }
+    if (!used) return E;
     const uint32_t *ix = P.idx + 3 * (size_t)s;
     float4 v0 = P.pv[M.vout_base + ix[0]], v1 = P.pv[M.vout_base + ix[1]], v2 = P.pv[M.vout_base + ix[2]];
     // is_front_facing, :742-746
@@ -428,7 +424,29 @@ extern "C" __global__ void __launch_bounds__(256) k_proj_edges(ProjectParams P) 
         E.c[i] = qx[i] * py[i] - qy[i] * px[i];
     }
     E.visible = (evis && visible) ? 1u : 0u;
-    P.edges[s] = E;
+    return E;
+}
+// The 40-byte records leave through LDS as the workgroup's contiguous 10 KB block (see k_setup3d in rxr_kernels.hip).
+extern "C" __global__ void __launch_bounds__(256) k_proj_edges(ProjectParams P) {
+    __shared__ uint2 xpose[256 * 5];
+    const uint32_t t0 = blockIdx.x * blockDim.x, tid = threadIdx.x, s = t0 + tid;
+    const uint32_t n_here = min(256u, P.n_tris_out - t0);   // the grid covers n_tris_out
+    rxr_edges E;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) E.a[i] = E.b[i] = E.c[i] = 0.0f;
+    E.visible = 0;
+    if (s < P.n_tris_out) E = edges_of_slot(P, s);
+    uint2 rec[5];
+    __builtin_memcpy(rec, &E, sizeof(E));
+#pragma unroll
+    for (int i = 0; i < 5; ++i) xpose[tid * 5u + i] = rec[i];
+    __syncthreads();
+    uint2 *dst = reinterpret_cast<uint2 *>(P.edges + t0);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const uint32_t k = (uint32_t)i * 256u + tid;
+        if (k < n_here * 5u) dst[k] = xpose[k];
+    }
 }
 
 // ---- host-callable launchers ------------------------------------------------------------------------
