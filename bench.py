@@ -239,7 +239,7 @@ def main():
 
 # rocprofv3 PMC passes of `python3 bench.py` (3840x2160, 16 lights, 1 GPU), per k_raster launch:
 # profiles/r01/h_bench_pmc_summary.json (WRITE_SIZE includes 2.4 MB of register spills: k_raster is bounded to 64 VGPRs)
-MEASURED_TRAFFIC_4K = {"write": 35536960, "fetch_x2": 2249652, "source": "profiles/r01/i_bench_pmc_summary.json"}
+MEASURED_TRAFFIC_4K = {"write": 35542191, "fetch_x2": 2248244, "source": "profiles/r01/i_bench_pmc_summary.json"}
 MEASURED_VALU_4K = 156887443
 # the same instructions priced with the measured issue costs of tools/microbench/valu_rates.hip (profiles/r01/valu_issue_rates.txt:
 # fma / mul / add 2.6 cycles per wave64 instruction, rcp / sqrt / rsq / log / exp 8.3, the rest -- compares, selects,
