@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define RXR_ABI_VERSION 3u
+#define RXR_ABI_VERSION 4u
 
 typedef enum rxr_status {
     RXR_OK = 0,
@@ -39,7 +39,10 @@ typedef enum rxr_status {
     RXR_ERR_NO_DEVICE = -2,   /* no HIP device, or device id out of range                         */
     RXR_ERR_HIP = -3,         /* a HIP runtime call failed; see rxr_last_error                    */
     RXR_ERR_UNSUPPORTED = -4, /* scene uses a feature the device path does not implement (yet)    */
-    RXR_ERR_OOM = -5
+    RXR_ERR_OOM = -5,
+    RXR_ERR_OVERFLOW = -6     /* rxr_synchronize: a bin list overflowed in a launch that was queued BEFORE the last one (an
+                                 asynchronous caller that does not synchronize per frame): that frame was shipped incomplete.
+                                 The lists have been grown and the last launch rendered again; render the lost frames again. */
 } rxr_status;
 
 /* ---- enums mirrored from the reference ------------------------------------------------------ */
@@ -351,10 +354,34 @@ typedef struct rxr_ctx rxr_ctx;
 /* ---- entry points ----------------------------------------------------------------------------
  * Each replaces a slice of Rasterizer::rasterize (src/rasterizer.rs:185-580):                     */
 
-/* creates a context on HIP device `device_id` (one process per GPU; no reference counterpart --
- * the reference uses rayon's global pool, src/rasterizer.rs:273-275) */
+/* creates a context on HIP device `device_id` (no reference counterpart -- the reference uses rayon's global pool,
+ * src/rasterizer.rs:273-275) */
 int rxr_create(rxr_ctx **out, int device_id);
 void rxr_destroy(rxr_ctx *ctx);
+
+/* ABI 4.  A multi-device context: one member context per entry of device_ids (a device may be listed more than once: N
+ * logical members on one GPU, which is how the single-GPU tests check byte identity), driven from this one process.  The
+ * reference renders tiles independently and concatenates them at the end (src/rasterizer.rs:273-275, :559-579); this does
+ * the same across GPUs.  On such a handle
+ *   - rxr_set_textures / rxr_set_meshes / rxr_set_shaders / rxr_upload_frame replicate to every member (in parallel, one
+ *     host thread and one PCIe link per device);
+ *   - rxr_rasterize / rxr_render_download shard the frame by interleaved RXR_STRIPE_ROWS-row stripes (member i of N renders
+ *     stripes i, i+N, ...) and EVERY device copies its own stripes straight into the caller's `pixels`;
+ *   - rxr_render_gather assembles the frame in the memory of one member's device instead (peer copies over xGMI);
+ *   - rxr_synchronize / rxr_get_stats / rxr_last_error cover all members; rxr_profile_* and rxr_selftest_math refer to
+ *     member 0; the single-device calls that take device pointers, streams or row ranges (rxr_render_rows*,
+ *     rxr_render_stripes_to, rxr_download_rows) return RXR_ERR_UNSUPPORTED -- use them on rxr_member(ctx, i).
+ * The result is byte-identical to the single-device frame (tests/test_gpu_multi.py). */
+int rxr_create_multi(rxr_ctx **out, const int *device_ids, int n_devices);
+/* 1 for a plain context, the number of members for a multi-device one */
+int rxr_member_count(const rxr_ctx *ctx);
+/* member `index` of a multi-device context (owned by it; never destroy it), or `ctx` itself for index 0 of a plain one */
+rxr_ctx *rxr_member(rxr_ctx *ctx, int index);
+
+/* optional: page-locks the caller's pixel buffer (hipHostRegister, visible to every device) so that the downloads of
+ * rxr_rasterize / rxr_render_download are direct DMA.  Unpinned buffers work too (the runtime locks them on the fly per copy). */
+int rxr_pin_host_buffer(rxr_ctx *ctx, void *ptr, size_t bytes);
+int rxr_unpin_host_buffer(rxr_ctx *ctx, void *ptr);
 /* last error text for this context (or for rxr_create when ctx == NULL) */
 const char *rxr_last_error(const rxr_ctx *ctx);
 /* number of visible HIP devices, 0 if none (never fails) */
@@ -435,6 +462,26 @@ int rxr_rasterize(rxr_ctx *ctx, const rxr_frame *frame, uint8_t *pixels);
  * byte-identical to rxr_render_rows + rxr_download_rows.  Replaces src/rasterizer.rs:256-579 + the final copy. */
 int rxr_render_download(rxr_ctx *ctx, uint8_t *pixels);
 
+/* device-resident consumers: renders the whole uploaded frame and leaves it, in frame layout, in DEVICE memory of member
+ * `root` (`dev_pixels` on that device, or that member's own framebuffer when NULL), complete on `hip_stream` (a stream of
+ * the root's device; NULL = the root member's own stream).  On a multi-device context every other member renders its
+ * stripes and pushes them to the root with peer copies over xGMI (one link per source GPU, all concurrent, each stripe
+ * landing at its final place), the root renders its own stripes in place.  On a plain context (root 0) it is
+ * rxr_render_rows_to over all rows.  Asynchronous; rxr_synchronize waits for it.
+ * Replaces the tile loop + the final tile concatenation, src/rasterizer.rs:256-579. */
+int rxr_render_gather(rxr_ctx *ctx, int root, void *dev_pixels, void *hip_stream);
+
+/* Waits for everything the context has queued -- on its own streams AND on the caller's stream of the last
+ * rxr_render_rows_to / rxr_render_stripes_to -- and reports what the launches since the previous call left behind:
+ *   RXR_OK            every frame since the last call is complete (a bin-list overflow of the LAST launch is repaired here:
+ *                     the lists are grown and that launch is rendered again);
+ *   RXR_ERR_OVERFLOW  see above: an EARLIER launch overflowed; its frame was incomplete;
+ *   RXR_ERR_INVALID   a fragment's Rusteria program did what makes the reference panic;
+ *   RXR_ERR_UNSUPPORTED a pixel's opacity staircase overflowed (four nested opacity batches).
+ * Stream contract: every render of a context uses the context's one set of scratch buffers.  A render on a different
+ * stream than the previous one is ordered behind it by the library; rxr_upload_frame / rxr_set_* wait (on the host) for
+ * all renders, including those on caller streams, before they overwrite anything.  A caller that queues frame after
+ * frame without synchronizing must call rxr_synchronize before it declares those frames done. */
 int rxr_synchronize(rxr_ctx *ctx);
 int rxr_get_stats(rxr_ctx *ctx, rxr_stats *out);
 /* device pointer of the context framebuffer (width*height*4 bytes of the last uploaded frame) */

@@ -5,4 +5,4 @@ bound to the product host library, whose `Rasterizer::rasterize` hands the proje
 C ABI of include/rxr.h to the HIP kernels.  There is no CPU fallback: if the libraries are not built
 or no GPU is visible, calls fail loudly.
 """
-from .libs import load, load_rxr, lib_paths  # noqa: F401
+from .libs import load, load_rxr, lib_paths, rxr_abi, RxrStats  # noqa: F401

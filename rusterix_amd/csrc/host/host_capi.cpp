@@ -48,6 +48,8 @@ extern "C" {
 
 const char *rxh_last_error() { return last_error().c_str(); }
 void rxh_set_device(int device) { set_device(device); }
+// more than one device: the context becomes a multi-device one (rxr_create_multi); a device may repeat (logical members)
+void rxh_set_devices(const int *devices, int n) { set_devices(devices, n); }
 // the process-wide rxr_ctx (NULL + rxh_last_error() when no GPU): lets callers drive the split-phase
 // ABI (rxr_render_rows_to / rxr_get_stats) after rxh_rasterizer_upload
 void *rxh_context() { return context(); }

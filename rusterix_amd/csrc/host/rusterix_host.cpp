@@ -403,10 +403,15 @@ void Scene::project_2d(const Mat3 *m2d) {
 }
 
 // ---- device context -----------------------------------------------------------------------------
+// The host layer keeps ONE device context (plain or multi-device) and its upload caches per process.  In the reference
+// every Rasterizer is an independent value; here Rasterizers on different threads share that context, so every entry point
+// that touches it (context, set_device(s), Rasterizer::upload / rasterize) holds g_mu for its whole duration: calls from
+// several threads are serialised, never interleaved.
 namespace {
-std::mutex g_mu;
+std::recursive_mutex g_mu;
 rxr_ctx *g_ctx = nullptr;
 int g_device = -1;
+std::vector<int> g_devices;  // more than one entry: rxr_create_multi
 std::string g_error;
 uint64_t g_tex_static_gen = 0, g_tex_dynamic_gen = 0;
 uint64_t g_shaders_gen = 0, g_shader_env_gen = 0;
@@ -419,20 +424,38 @@ bool device_projection() { return g_device_projection; }
 
 const std::string &last_error() { return g_error; }
 
+namespace {
+void drop_context_locked() {
+    if (g_ctx) rxr_destroy(g_ctx);
+    g_ctx = nullptr;
+    g_mesh_fingerprint = 0;
+    g_tex_static_gen = g_tex_dynamic_gen = 0;
+    g_shaders_gen = g_shader_env_gen = 0;
+}
+}  // namespace
+
 void set_device(int device) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    if (g_ctx && device != g_device) {
-        rxr_destroy(g_ctx);
-        g_ctx = nullptr;
-        g_mesh_fingerprint = 0;
-        g_tex_static_gen = g_tex_dynamic_gen = 0;
-        g_shaders_gen = g_shader_env_gen = 0;
-    }
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (g_ctx && (device != g_device || g_devices.size() > 1)) drop_context_locked();
     g_device = device;
+    g_devices.clear();
+}
+
+void set_devices(const int *devices, int n) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    std::vector<int> want(devices, devices + (n > 0 ? n : 0));
+    if (want.size() <= 1) {
+        set_device(want.empty() ? -1 : want[0]);
+        return;
+    }
+    if (g_ctx && want != g_devices) drop_context_locked();
+    if (g_ctx && g_devices.empty()) drop_context_locked();
+    g_devices = want;
+    g_device = want[0];
 }
 
 rxr_ctx *context(std::string *error) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
     if (!g_ctx) {
         int dev = g_device;
         if (dev < 0) {
@@ -442,7 +465,7 @@ rxr_ctx *context(std::string *error) {
             int n = rxr_device_count();
             if (n > 0) dev %= n;
         }
-        int rc = rxr_create(&g_ctx, dev);
+        int rc = g_devices.size() > 1 ? rxr_create_multi(&g_ctx, g_devices.data(), (int)g_devices.size()) : rxr_create(&g_ctx, dev);
         if (rc != RXR_OK) {
             g_error = rxr_last_error(nullptr);
             if (error) *error = g_error;
@@ -538,6 +561,7 @@ rxr_batch2d view2d(const Batch2D &b, int chunk) {
 }  // namespace
 
 int Rasterizer::upload(Scene &scene, size_t w, size_t h, size_t tile_size, const Assets &assets) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
     std::string err;
     rxr_ctx *ctx = context(&err);
     if (!ctx) return RXR_ERR_NO_DEVICE;
@@ -777,6 +801,7 @@ int Rasterizer::upload(Scene &scene, size_t w, size_t h, size_t tile_size, const
 }
 
 int Rasterizer::rasterize(Scene &scene, uint8_t *pixels, size_t w, size_t h, size_t tile_size, const Assets &assets) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
     if (tile_size == 0) {
         g_error = "tile_size 0 (step_by(0) panics in the reference)";
         return RXR_ERR_INVALID;

@@ -235,7 +235,8 @@ public:
     int upload(Scene &scene, size_t width, size_t height, size_t tile_size, const Assets &assets);
 };
 
-// the process-wide device context (one process per GPU).  Device index from RXR_DEVICE, else
+// the process-wide device context.  Every function that uses it holds one process-wide lock for its whole duration, so
+// Rasterizers on several threads are serialised (the reference's are independent values; this layer shares one context).  Device index from RXR_DEVICE, else
 // LOCAL_RANK, else 0.
 rxr_ctx *context(std::string *error = nullptr);
 // device-side projection: when on, Rasterizer::upload registers the object-space
@@ -244,6 +245,9 @@ rxr_ctx *context(std::string *error = nullptr);
 void set_device_projection(bool on);
 bool device_projection();
 void set_device(int device);
+// more than one entry: the context becomes a multi-device one (rxr_create_multi): rasterize() then shards every frame over
+// these GPUs inside the library.  A device may be listed more than once (logical members on one GPU).
+void set_devices(const int *devices, int n);
 const std::string &last_error();
 
 // cameras: src/camera/d3orbit.rs:23-56,186-195 and src/camera/d3firstp.rs:17-42

@@ -17,8 +17,7 @@
 #include <vector>
 
 #include "../../include/rusterix_vek.hpp"  // host-side Mat4 products for the device-projection path
-#include "rxr_device.h"
-#include "rxr_project.h"
+#include "rxr_ctx.h"
 
 extern "C" void rxr_launch_proj_static(const ProjectParams *P, hipStream_t s);
 extern "C" void rxr_launch_project(const ProjectParams *P, hipStream_t s);
@@ -34,144 +33,55 @@ namespace {
 
 thread_local std::string g_create_error;
 
-struct DevBuf {
-    void *p = nullptr;
-    size_t cap = 0;
-};
-
-struct TileRange {
-    uint32_t first, n;
-};
-
-// host-side record of one registered mesh (rxr_set_meshes)
-struct HostMesh {
-    DevMesh dev;              // static part (bases, counts, cull mode); view_model / rejected are per frame
-    float transform[16];
-    float aabb_lo[3], aabb_hi[3];
-    bool has_vertices;
-    uint32_t repeat_mode;
-    rxr_source source;
-    float ambient[3];
-    int32_t shader;
-    uint32_t has_profile_id, profile_id, list;
-    int32_t chunk;
-};
-
-struct ProfSlot {
-    hipEvent_t e0, e1, e2;
-};
-
-// one render launch sequence.  Band mode: rows [row0,row1), stride 1.  Stripe mode: every `stride`-th
-// 16-row stripe from `first` into a compact buffer.
-struct RenderSpec {
-    uint32_t row0, row1;
-    uint32_t tile_y0, tile_stride, tiles_y;
-    bool compact, external;
-};
-
 }  // namespace
 
-// Execution fields whose lanes the raster loops do not (all) assign before each call (rasterizer.rs:773-785, :1259-1298,
-// :1637-1662): a read sees what an EARLIER fragment's program left there unless this invocation wrote the field first
-enum : uint32_t { PF_UV = 1, PF_ROUGHNESS = 2, PF_METALLIC = 4, PF_OPACITY = 8, PF_BUMP = 16, PF_NORMAL = 32, PF_HITPOINT = 64 };
-
-struct rxr_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    uint32_t prof_stride = 1, prof_calls = 0;  // rxr_profile_stride: every prof_stride-th render records events
-    hipStream_t copy_stream = nullptr;   // rxr_rasterize: downloads of finished bands overlap the rendering of the next ones
-    hipEvent_t ev_band[8] = {};
-    std::string err;
-
-    // textures
-    DevBuf d_tex, d_texels;
-    std::vector<DevTexDesc> h_tex;
-    std::vector<TileRange> tiles_static, tiles_dynamic;
-
-    // frame blob
-    void *h_stage = nullptr;
-    size_t h_stage_cap = 0;
-    DevBuf d_frame;
-    DevBuf d_tri_setup, d_tri_shade, d_tri_box, d_bin_count, d_bins, d_list, d_large, d_counters, d_fb;
-    DevBuf d_bin2d_count, d_bins2d, d_list2d, d_large2d;
-    uint32_t list2d_capacity = 0, parity2d = 0;
-    uint32_t *h_counters = nullptr;  // pinned, CNT_WORDS; written by k_scan through d_host_status
-    uint32_t *d_host_status = nullptr;
-    uint32_t list_capacity = 0;
-    uint32_t parity = 0;             // counter set of the next launch
-    bool scratch_dirty = false;      // a pre-pass was queued without its raster launch
-    bool scratch2d_dirty = false;
-    uint32_t min_kernel_level = 0;   // RXR_MIN_KERNEL_LEVEL (tuning)
-    bool programs_static = false;    // every program of the set has a stack depth that is a function of the pc (tag_static_depths)
-    uint32_t small_mode = 2;         // RasterParams.fused_small for frames with <= RXR_STAGE_TRIS triangles;
-                                     // RXR_SMALL_MODE=0|1|2 overrides it (tests / A-B runs)
-
-    // device-side projection (rxr_set_meshes)
-    std::vector<HostMesh> meshes;
-    DevBuf d_obj, d_proj_out, d_proj_misc;
-    ProjectParams PP{};
-    size_t mesh_verts_out = 0, mesh_tris_out = 0;
-    size_t pp_off_meshes = 0;  // byte offset of the per-frame DevMesh array inside d_proj_misc
-    bool frame_uses_meshes = false;
-
-    // Rusteria programs (rxr_set_shaders)
-    DevBuf d_vm_code, d_programs, d_patterns, d_pattern_data, d_palette;
-    std::vector<DevProgram> programs;
-    std::vector<uint32_t> program_field_reads;  // PF_* each program reads before writing (see rxr_set_shaders)
-    uint32_t n_patterns = 0, n_normal_patterns = 0, n_palette = 0;
-    bool frame_uses_programs = false;
-
-    bool has_frame = false;
-    RasterParams P{};       // template for the resident frame (pointers resolved)
-    uint32_t n_tris2d = 0;
-
-    // last render
-    bool rendered = false;
-    RenderSpec last_spec{};
-    void *last_out = nullptr;
-    hipStream_t last_stream = nullptr;
-    hipStream_t upload_ordered_on = nullptr;  // stream already ordered behind the last upload
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev_upload = nullptr;
-    hipEvent_t last_e0 = nullptr, last_e1 = nullptr, last_e2 = nullptr;
-    std::vector<ProfSlot> prof;  // rxr_profile_begin ring
-    size_t prof_next = 0;
-    rxr_stats stats{};
-};
-
-namespace {
-
-int fail(rxr_ctx *ctx, int code, const std::string &msg) {
+int rxr_fail(rxr_ctx *ctx, int code, const std::string &msg) {
     if (ctx) ctx->err = msg;
     else g_create_error = msg;
     return code;
 }
 
-#define HIPCHK(ctx, call)                                                                                  \
-    do {                                                                                                   \
-        hipError_t e_ = (call);                                                                            \
-        if (e_ != hipSuccess)                                                                              \
-            return fail(ctx, RXR_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));              \
-    } while (0)
+// Nothing this context has queued may still be running when the host rewrites the pinned staging blob, the frame blob is
+// overwritten by the next host->device copy, or a scratch buffer is reallocated.  Renders issued through
+// rxr_render_rows_to / rxr_render_stripes_to run on the CALLER's stream (ctx->last_stream): that one is waited for as well.
+int rxr_quiesce(rxr_ctx *ctx) {
+    if (ctx->last_stream && ctx->last_stream != ctx->stream) HIPCHK(ctx, hipStreamSynchronize(ctx->last_stream));
+    if (ctx->copy_stream) HIPCHK(ctx, hipStreamSynchronize(ctx->copy_stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return RXR_OK;
+}
 
-int ensure(rxr_ctx *ctx, DevBuf &b, size_t bytes) {
+int rxr_ensure(rxr_ctx *ctx, DevBuf &b, size_t bytes) {
     if (bytes <= b.cap) return RXR_OK;
     if (b.p) {
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        int rc = rxr_quiesce(ctx);
+        if (rc != RXR_OK) return rc;
         HIPCHK(ctx, hipFree(b.p));
         b.p = nullptr;
         b.cap = 0;
     }
     size_t cap = bytes + bytes / 4 + 4096;
     hipError_t e = hipMalloc(&b.p, cap);
-    if (e != hipSuccess) return fail(ctx, RXR_ERR_OOM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    if (e != hipSuccess) return rxr_fail(ctx, RXR_ERR_OOM, std::string("hipMalloc: ") + hipGetErrorString(e));
     b.cap = cap;
     return RXR_OK;
 }
 
+// Execution fields whose lanes the raster loops do not (all) assign before each call (rasterizer.rs:773-785, :1259-1298,
+// :1637-1662): a read sees what an EARLIER fragment's program left there unless this invocation wrote the field first
+enum : uint32_t { PF_UV = 1, PF_ROUGHNESS = 2, PF_METALLIC = 4, PF_OPACITY = 8, PF_BUMP = 16, PF_NORMAL = 32, PF_HITPOINT = 64 };
+
+namespace {
+
+int fail(rxr_ctx *ctx, int code, const std::string &msg) { return rxr_fail(ctx, code, msg); }
+
+int ensure(rxr_ctx *ctx, DevBuf &b, size_t bytes) { return rxr_ensure(ctx, b, bytes); }
+
 int ensure_stage(rxr_ctx *ctx, size_t bytes) {
     if (bytes <= ctx->h_stage_cap) return RXR_OK;
     if (ctx->h_stage) {
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        int rc = rxr_quiesce(ctx);
+        if (rc != RXR_OK) return rc;
         HIPCHK(ctx, hipHostFree(ctx->h_stage));
         ctx->h_stage = nullptr;
         ctx->h_stage_cap = 0;
@@ -230,18 +140,23 @@ int rxr_create(rxr_ctx **out, int device_id) {
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev2);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev_upload);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_render, hipEventDisableTiming);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking);
     for (hipEvent_t &ev : ctx->ev_band)
         if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_counters, (2 * CNT_WORDS + 4) * sizeof(uint32_t), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_counters, HS_WORDS * sizeof(uint32_t), hipHostMallocDefault);
     if (e != hipSuccess) {
         std::string msg = std::string("rxr_create: ") + hipGetErrorString(e);
-        delete ctx;
+        rxr_destroy(ctx);
         return fail(nullptr, RXR_ERR_HIP, msg);
     }
-    memset(ctx->h_counters, 0, (2 * CNT_WORDS + 4) * sizeof(uint32_t));
+    memset(ctx->h_counters, 0, HS_WORDS * sizeof(uint32_t));
     if (const char *sm = getenv("RXR_SMALL_MODE")) {
         if (sm[0] >= '0' && sm[0] <= '2') ctx->small_mode = (uint32_t)(sm[0] - '0');
+    }
+    if (const char *lf = getenv("RXR_LIST_CAPACITY_FLOOR")) {  // tests: a small floor makes ordinary scenes overflow their bin lists
+        const long v = atol(lf);
+        if (v > 0) ctx->list_floor = (size_t)v;
     }
     if (const char *kl = getenv("RXR_MIN_KERNEL_LEVEL")) {  // A-B runs: render with k_raster_chunk (1) / k_raster_vm (2) regardless
         if (kl[0] >= '0' && kl[0] <= '2') ctx->min_kernel_level = (uint32_t)(kl[0] - '0');
@@ -253,9 +168,13 @@ int rxr_create(rxr_ctx **out, int device_id) {
 
 void rxr_destroy(rxr_ctx *ctx) {
     if (!ctx) return;
+    if (ctx->group) {
+        rxr_group_destroy(ctx);
+        return;
+    }
     (void)hipSetDevice(ctx->device);
-    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    DevBuf *bufs[] = {&ctx->d_obj, &ctx->d_proj_out, &ctx->d_proj_misc, &ctx->d_tex, &ctx->d_texels, &ctx->d_frame, &ctx->d_tri_setup, &ctx->d_tri_shade, &ctx->d_tri_box, &ctx->d_bin_count, &ctx->d_bins, &ctx->d_bin2d_count, &ctx->d_bins2d,
+    if (ctx->stream) (void)rxr_quiesce(ctx);
+    DevBuf *bufs[] = {&ctx->d_stripes, &ctx->d_obj, &ctx->d_proj_out, &ctx->d_proj_misc, &ctx->d_tex, &ctx->d_texels, &ctx->d_frame, &ctx->d_tri_setup, &ctx->d_tri_shade, &ctx->d_tri_box, &ctx->d_bin_count, &ctx->d_bins, &ctx->d_bin2d_count, &ctx->d_bins2d,
                       &ctx->d_list2d, &ctx->d_large2d,
                       &ctx->d_list, &ctx->d_large, &ctx->d_counters, &ctx->d_fb,
                       &ctx->d_vm_code, &ctx->d_programs, &ctx->d_patterns, &ctx->d_pattern_data, &ctx->d_palette};
@@ -267,6 +186,7 @@ void rxr_destroy(rxr_ctx *ctx) {
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->ev2) (void)hipEventDestroy(ctx->ev2);
     if (ctx->ev_upload) (void)hipEventDestroy(ctx->ev_upload);
+    if (ctx->ev_render) (void)hipEventDestroy(ctx->ev_render);
     for (hipEvent_t ev : ctx->ev_band)
         if (ev) (void)hipEventDestroy(ev);
     if (ctx->copy_stream) {
@@ -286,7 +206,12 @@ int rxr_set_textures(rxr_ctx *ctx, const rxr_tile *static_tiles, uint32_t n_stat
                      uint32_t n_dynamic) {
     if (!ctx) return RXR_ERR_INVALID;
     if ((n_static && !static_tiles) || (n_dynamic && !dynamic_tiles)) return fail(ctx, RXR_ERR_INVALID, "rxr_set_textures: NULL tile array");
+    if (ctx->group) return rxr_group_set_textures(ctx, static_tiles, n_static, dynamic_tiles, n_dynamic);
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    {
+        int qrc = rxr_quiesce(ctx);  // a render (possibly on the caller's stream) may still read the old texels
+        if (qrc != RXR_OK) return qrc;
+    }
     ctx->h_tex.clear();
     ctx->tiles_static.clear();
     ctx->tiles_dynamic.clear();
@@ -353,8 +278,12 @@ int rxr_set_textures(rxr_ctx *ctx, const rxr_tile *static_tiles, uint32_t n_stat
 int rxr_set_meshes(rxr_ctx *ctx, const rxr_mesh3d *meshes, uint32_t n_meshes) {
     if (!ctx) return RXR_ERR_INVALID;
     if (n_meshes && !meshes) return fail(ctx, RXR_ERR_INVALID, "rxr_set_meshes: NULL mesh array");
+    if (ctx->group) return rxr_group_set_meshes(ctx, meshes, n_meshes);
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    {
+        int qrc = rxr_quiesce(ctx);
+        if (qrc != RXR_OK) return qrc;
+    }
     ctx->meshes.clear();
     ctx->has_frame = false;
     size_t vin = 0, tin = 0, vout = 0, tout = 0;
@@ -365,7 +294,7 @@ int rxr_set_meshes(rxr_ctx *ctx, const rxr_mesh3d *meshes, uint32_t n_meshes) {
         if (m.n_triangles && !m.normals)
             return fail(ctx, RXR_ERR_INVALID, "mesh without normals (clip_and_project panics at batch3d.rs:605)");
         if (m.cull_mode > RXR_CULL_BACK) return fail(ctx, RXR_ERR_INVALID, "mesh: bad cull mode");
-        for (uint32_t t = 0; t < m.n_triangles * 3u; ++t)
+        for (size_t t = 0; t < (size_t)m.n_triangles * 3u; ++t)
             if (m.indices[t] >= m.n_vertices) return fail(ctx, RXR_ERR_INVALID, "mesh: vertex index out of range");
         HostMesh h{};
         h.dev.vin_base = (uint32_t)vin;
@@ -495,6 +424,9 @@ int rxr_read_projected_mesh(rxr_ctx *ctx, uint32_t index, uint32_t counts[2], fl
                             float *clipped_normals, uint32_t *clipped_indices, rxr_edges *edges, float bounding_box[5],
                             uint32_t capacity_vertices, uint32_t capacity_triangles) {
     if (!ctx || !counts) return RXR_ERR_INVALID;
+    if (ctx->group)
+        return rxr_read_projected_mesh(rxr_member(ctx, 0), index, counts, projected_vertices, clipped_uvs, clipped_normals, clipped_indices, edges,
+                                       bounding_box, capacity_vertices, capacity_triangles);
     if (index >= ctx->meshes.size()) return fail(ctx, RXR_ERR_INVALID, "rxr_read_projected_mesh: no such mesh");
     int rc = rxr_synchronize(ctx);
     if (rc != RXR_OK) return rc;
@@ -576,6 +508,7 @@ static int resolve_source(rxr_ctx *ctx, const rxr_source &src, bool is_3d, int c
 int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
     if (!ctx) return RXR_ERR_INVALID;
     if (!f) return fail(ctx, RXR_ERR_INVALID, "rxr_upload_frame: frame is NULL");
+    if (ctx->group) return rxr_group_upload_frame(ctx, f);
     if (f->abi_version != RXR_ABI_VERSION) return fail(ctx, RXR_ERR_INVALID, "rxr_upload_frame: abi_version mismatch");
     if (f->width == 0 || f->height == 0 || f->width > 32768 || f->height > 32768)
         return fail(ctx, RXR_ERR_INVALID, "rxr_upload_frame: width/height must be in 1..32768");
@@ -624,7 +557,7 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
         if (b.n_triangles && (!b.clipped_indices || !b.edges)) return fail(ctx, RXR_ERR_INVALID, "batch3d: NULL indices/edges");
         if (b.n_vertices && (!b.projected_vertices || !b.clipped_uvs)) return fail(ctx, RXR_ERR_INVALID, "batch3d: NULL vertex arrays");
         if (b.chunk >= (int32_t)f->n_chunks) return fail(ctx, RXR_ERR_INVALID, "batch3d: chunk index out of range");
-        for (uint32_t t = 0; t < b.n_triangles * 3u; ++t)
+        for (size_t t = 0; t < (size_t)b.n_triangles * 3u; ++t)
             if (b.clipped_indices[t] >= b.n_vertices) return fail(ctx, RXR_ERR_INVALID, "batch3d: vertex index out of range");
         if (b.list == RXR_LIST_CHUNK_OPACITY) has_opacity = true;
         n_v3 += b.n_vertices;
@@ -639,7 +572,7 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
         if (b.chunk >= (int32_t)f->n_chunks) return fail(ctx, RXR_ERR_INVALID, "batch2d: chunk index out of range");
         if (b.mode > RXR_MODE_LINE_LOOP) return fail(ctx, RXR_ERR_INVALID, "batch2d: bad mode");
         if (b.mode == RXR_MODE_TRIANGLES || b.mode == RXR_MODE_LINES)
-            for (uint32_t t = 0; t < b.n_triangles * 3u; ++t) {
+            for (size_t t = 0; t < (size_t)b.n_triangles * 3u; ++t) {
                 if (b.mode == RXR_MODE_LINES && (t % 3u) == 2u) continue;  // only .0/.1 are read, :902
                 if (b.indices[t] >= b.n_vertices) return fail(ctx, RXR_ERR_INVALID, "batch2d: vertex index out of range");
             }
@@ -719,8 +652,9 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
     int rc;
     if ((rc = ensure_stage(ctx, L.total)) != RXR_OK) return rc;
     if ((rc = ensure(ctx, ctx->d_frame, L.total)) != RXR_OK) return rc;
-    // the staging blob may still be in flight from the previous upload
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    // the staging blob may still be in flight from the previous upload, and the previous frame's renders -- possibly on
+    // the caller's stream -- still read the frame blob and the scratch buffers
+    if ((rc = rxr_quiesce(ctx)) != RXR_OK) return rc;
     uint8_t *st = (uint8_t *)ctx->h_stage;
 
     // texel source, program, baked texture and the flags that follow from them, for one 3D batch header
@@ -1077,7 +1011,7 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
         if (ctx->d_bin2d_count.p != before) HIPCHK(ctx, hipMemsetAsync(ctx->d_bin2d_count.p, 0, ctx->d_bin2d_count.cap, ctx->stream));
         if ((rc = ensure(ctx, ctx->d_bins2d, (2 * (n_bins + 1) + 2 * n_chunks + 8) * sizeof(uint32_t))) != RXR_OK) return rc;
         if ((rc = ensure(ctx, ctx->d_large2d, p2cur * sizeof(uint32_t))) != RXR_OK) return rc;
-        size_t want2d = std::max<size_t>(1u << 18, p2cur * 8);
+        size_t want2d = ctx->list_floor ? ctx->list_floor : std::max<size_t>(1u << 18, p2cur * 8);
         if (want2d > ctx->list2d_capacity) {
             if ((rc = ensure(ctx, ctx->d_list2d, want2d * sizeof(uint32_t))) != RXR_OK) return rc;
             ctx->list2d_capacity = (uint32_t)std::min<size_t>(ctx->d_list2d.cap / sizeof(uint32_t), 0xFFFFFFF0u);
@@ -1088,7 +1022,7 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
         if ((rc = ensure(ctx, ctx->d_counters, 4 * CNT_WORDS * sizeof(uint32_t))) != RXR_OK) return rc;  // 2 sets for 3D, 2 for 2D
         if (ctx->d_counters.p != before) HIPCHK(ctx, hipMemsetAsync(ctx->d_counters.p, 0, ctx->d_counters.cap, ctx->stream));
     }
-    size_t want_list = std::max<size_t>(1u << 20, n_t3 * 4);
+    size_t want_list = ctx->list_floor ? ctx->list_floor : std::max<size_t>(1u << 20, n_t3 * 4);
     if (want_list > ctx->list_capacity) {
         if ((rc = ensure(ctx, ctx->d_list, want_list * sizeof(uint32_t))) != RXR_OK) return rc;
         ctx->list_capacity = (uint32_t)std::min<size_t>(ctx->d_list.cap / sizeof(uint32_t), 0xFFFFFFF0u);
@@ -1155,7 +1089,8 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
     P.n_patterns = ctx->n_patterns;
     P.n_normal_patterns = ctx->n_normal_patterns;
     P.n_palette = ctx->n_palette;
-    P.vm_fault = ctx->d_host_status + 2 * CNT_WORDS;
+    P.vm_fault = ctx->d_host_status + HS_VM_FAULT;
+    P.staircase_overflow = ctx->d_host_status + HS_STAIRCASE;
     P.time = f->time;
     {
         // tiles outside the union of the 2D pixel boxes skip the 2D pass without touching memory
@@ -1234,10 +1169,14 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
     return RXR_OK;
 }
 
-static int render_impl(rxr_ctx *ctx, const RenderSpec &spec, void *dev_pixels, hipStream_t s) {
+static int render_impl(rxr_ctx *ctx, const RenderSpec &spec, void *dev_pixels, hipStream_t s, bool retry = false) {
     if (!ctx) return RXR_ERR_INVALID;
     if (!ctx->has_frame) return fail(ctx, RXR_ERR_INVALID, "render: no frame uploaded");
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    // every launch sequence uses the context's one set of scratch buffers (records, bins, counters): a render on another
+    // stream than the previous one is ordered behind it
+    if (ctx->rendered && ctx->last_stream != s) HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_render, 0));
+    if (retry) ctx->rerenders++;
     if (!ctx->upload_ordered_on || ctx->upload_ordered_on != s) {
         if (s != ctx->stream) {
             // the upload ran on the context stream: order the external stream behind it (once per upload)
@@ -1260,7 +1199,7 @@ static int render_impl(rxr_ctx *ctx, const RenderSpec &spec, void *dev_pixels, h
 
     // Kernel timing is opt-in (rxr_profile_begin): every event record is a barrier packet that idles the GPU for a few
     // microseconds, which is a tenth of a 1080p frame of a small scene.  Without it rxr_stats' *_us fields stay zero.
-    const bool timed = !ctx->prof.empty() && (ctx->prof_calls++ % ctx->prof_stride) == 0u;
+    const bool timed = !retry && !ctx->prof.empty() && (ctx->prof_calls++ % ctx->prof_stride) == 0u;  // (a re-render after a list overflow takes no profiling slot)
     hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
     if (timed) {
         ProfSlot &ps = ctx->prof[ctx->prof_next % ctx->prof.size()];
@@ -1309,10 +1248,9 @@ static int render_impl(rxr_ctx *ctx, const RenderSpec &spec, void *dev_pixels, h
         A.host_status = P.host_status;
         rxr_launch_scan(&A, s);
         rxr_launch_fill(&P, s);
-    } else {
-        ctx->h_counters[CNT_ENTRIES] = 0;
-        ctx->h_counters[CNT_OVERFLOW] = 0;
     }
+    // (the pinned status words are never written by the host while launches may be in flight: earlier queued k_scan
+    // launches write them; rxr_synchronize clears them once the streams have drained)
     (void)n_bins;
     // 2D binning pre-pass (many 2D primitives): count -> scan -> fill; k_raster sorts each tile's list
     const bool prepass2d = P.tiles_y && (P.flags & RXR_FLAG_D2_ACTIVE) && P.binned2d;
@@ -1339,17 +1277,18 @@ static int render_impl(rxr_ctx *ctx, const RenderSpec &spec, void *dev_pixels, h
         A.host_status = P.host_status2d;
         rxr_launch_scan(&A, s);
         rxr_launch_bin2d_fill(&P, s);
-    } else {
-        ctx->h_counters[CNT_WORDS + CNT_ENTRIES] = 0;
-        ctx->h_counters[CNT_WORDS + CNT_OVERFLOW] = 0;
     }
     if (timed) HIPCHK(ctx, hipEventRecord(e1, s));
     rxr_launch_raster(&P, s);
     if (timed) HIPCHK(ctx, hipEventRecord(e2, s));
     HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipEventRecord(ctx->ev_render, s));
     ctx->scratch_dirty = false;  // the raster launch that hands the bins back is queued
     ctx->scratch2d_dirty = false;
     ctx->rendered = true;
+    ctx->last_had_prepass = prepass;
+    ctx->last_had_prepass2d = prepass2d;
+    ctx->launches_since_sync++;
     ctx->last_spec = spec;
     ctx->last_out = dev_pixels;
     ctx->last_stream = s;
@@ -1375,6 +1314,11 @@ static int band_spec(rxr_ctx *ctx, uint32_t row0, uint32_t row1, bool external, 
 
 int rxr_render_rows(rxr_ctx *ctx, uint32_t row0, uint32_t row1) {
     if (!ctx) return RXR_ERR_INVALID;
+    if (ctx->group) {
+        (void)row0;
+        (void)row1;
+        return fail(ctx, RXR_ERR_UNSUPPORTED, "rxr_render_rows on a multi-device context: use rxr_rasterize / rxr_render_download / rxr_render_gather, or drive the members (rxr_member) yourself");
+    }
     RenderSpec spec{};
     int rc = band_spec(ctx, row0, row1, false, spec);
     if (rc != RXR_OK) return rc;
@@ -1384,6 +1328,7 @@ int rxr_render_rows(rxr_ctx *ctx, uint32_t row0, uint32_t row1) {
 int rxr_render_rows_to(rxr_ctx *ctx, uint32_t row0, uint32_t row1, void *dev_pixels, void *hip_stream) {
     if (!ctx) return RXR_ERR_INVALID;
     if (!dev_pixels) return fail(ctx, RXR_ERR_INVALID, "rxr_render_rows_to: dev_pixels is NULL");
+    if (ctx->group) return fail(ctx, RXR_ERR_UNSUPPORTED, "rxr_render_rows_to on a multi-device context: device pointers and streams belong to ONE device (use rxr_member)");
     RenderSpec spec{};
     int rc = band_spec(ctx, row0, row1, true, spec);
     if (rc != RXR_OK) return rc;
@@ -1393,6 +1338,7 @@ int rxr_render_rows_to(rxr_ctx *ctx, uint32_t row0, uint32_t row1, void *dev_pix
 int rxr_render_stripes_to(rxr_ctx *ctx, uint32_t first, uint32_t stride, void *dev_pixels, void *hip_stream) {
     if (!ctx) return RXR_ERR_INVALID;
     if (!dev_pixels) return fail(ctx, RXR_ERR_INVALID, "rxr_render_stripes_to: dev_pixels is NULL");
+    if (ctx->group) return fail(ctx, RXR_ERR_UNSUPPORTED, "rxr_render_stripes_to on a multi-device context: device pointers and streams belong to ONE device (use rxr_member)");
     if (!ctx->has_frame) return fail(ctx, RXR_ERR_INVALID, "render: no frame uploaded");
     if (stride == 0) return fail(ctx, RXR_ERR_INVALID, "rxr_render_stripes_to: stride 0");
     const uint32_t n_stripes = (ctx->P.height + RXR_TILE_H - 1) / RXR_TILE_H;
@@ -1409,6 +1355,7 @@ int rxr_render_stripes_to(rxr_ctx *ctx, uint32_t first, uint32_t stride, void *d
 
 int rxr_profile_begin(rxr_ctx *ctx, uint32_t max_frames) {
     if (!ctx) return RXR_ERR_INVALID;
+    if (ctx->group) return rxr_profile_begin(rxr_member(ctx, 0), max_frames);  // kernel timing of a multi-device context: member 0's
     HIPCHK(ctx, hipSetDevice(ctx->device));
     int rc = rxr_synchronize(ctx);
     if (rc != RXR_OK) return rc;
@@ -1433,6 +1380,7 @@ int rxr_profile_begin(rxr_ctx *ctx, uint32_t max_frames) {
 
 int rxr_profile_stride(rxr_ctx *ctx, uint32_t stride) {
     if (!ctx || stride == 0) return RXR_ERR_INVALID;
+    if (ctx->group) return rxr_profile_stride(rxr_member(ctx, 0), stride);
     ctx->prof_stride = stride;
     ctx->prof_calls = 0;
     return RXR_OK;
@@ -1440,6 +1388,7 @@ int rxr_profile_stride(rxr_ctx *ctx, uint32_t stride) {
 
 int rxr_profile_read(rxr_ctx *ctx, float *setup_us, float *raster_us, uint32_t capacity, uint32_t *n_out) {
     if (!ctx || !n_out) return RXR_ERR_INVALID;
+    if (ctx->group) return rxr_profile_read(rxr_member(ctx, 0), setup_us, raster_us, capacity, n_out);
     int rc = rxr_synchronize(ctx);
     if (rc != RXR_OK) return rc;
     uint32_t n = (uint32_t)std::min<size_t>(std::min<size_t>(ctx->prof_next, ctx->prof.size()), capacity);
@@ -1455,38 +1404,45 @@ int rxr_profile_read(rxr_ctx *ctx, float *setup_us, float *raster_us, uint32_t c
     return RXR_OK;
 }
 
-// waits for the last render and re-renders with a larger bin list if it overflowed
+int rxr_render_spec(rxr_ctx *ctx, const RenderSpec &spec, void *dev_pixels, hipStream_t s) { return render_impl(ctx, spec, dev_pixels, s); }
+
+// Waits for everything this context has queued and reports what the launches since the previous call left in the pinned
+// status words.  Those words are sticky (the device only sets / raises them), so an overflow or a program fault of ANY
+// launch since the last call is seen, not only the last one's:
+//   - a bin list overflowed: the lists are grown; the LAST launch is rendered again (its output is then complete); if
+//     earlier launches were queued in between (an asynchronous caller that does not synchronize per frame) their frames
+//     were shipped incomplete and the call returns RXR_ERR_OVERFLOW to say so;
+//   - a fragment's program faulted, or an opacity staircase dropped an entry: an error, see the messages.
 int rxr_synchronize(rxr_ctx *ctx) {
     if (!ctx) return RXR_ERR_INVALID;
+    if (ctx->group) return rxr_group_synchronize(ctx);
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    bool earlier_incomplete = false;
     for (int attempt = 0; attempt < 4; ++attempt) {
-        if (ctx->last_stream && ctx->last_stream != ctx->stream) HIPCHK(ctx, hipStreamSynchronize(ctx->last_stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        int qrc = rxr_quiesce(ctx);
+        if (qrc != RXR_OK) return qrc;
+        const uint32_t launches = ctx->launches_since_sync;
+        ctx->launches_since_sync = 0;
         if (!ctx->rendered) return RXR_OK;
-        if (ctx->h_counters[2 * CNT_WORDS]) {
+        uint32_t *hc = ctx->h_counters;
+        if (hc[HS_VM_FAULT]) {
             // a fragment's program did what makes the reference panic (rxr_vm.h, VMF_*)
             static const char *const what[] = {"", "stack underflow", "stack overflow", "local index out of range", "global index out of range",
                                                "call depth", "loop depth", "instruction limit (runaway loop)", "clamp with min > max",
                                                "call of a missing function", "bad opcode", "too many locals"};
-            uint32_t code = ctx->h_counters[2 * CNT_WORDS];
-            ctx->h_counters[2 * CNT_WORDS] = 0;
+            uint32_t code = hc[HS_VM_FAULT];
+            hc[HS_VM_FAULT] = 0;
             return fail(ctx, RXR_ERR_INVALID, std::string("shader program fault: ") + (code < sizeof(what) / sizeof(what[0]) ? what[code] : "?"));
         }
-        ctx->stats.n_bin_entries = ctx->h_counters[CNT_ENTRIES];
-        if (ctx->h_counters[CNT_WORDS + CNT_OVERFLOW]) {
-            // 2D bin list overflow: grow and render the same launch again
-            size_t want = (size_t)ctx->h_counters[CNT_WORDS + CNT_ENTRIES] + ctx->h_counters[CNT_WORDS + CNT_ENTRIES] / 2 + 1024;
-            int rc = ensure(ctx, ctx->d_list2d, want * sizeof(uint32_t));
-            if (rc != RXR_OK) return rc;
-            ctx->list2d_capacity = (uint32_t)std::min<size_t>(ctx->d_list2d.cap / sizeof(uint32_t), 0xFFFFFFF0u);
-            ctx->P.bin2d_list = (uint32_t *)ctx->d_list2d.p;
-            ctx->P.list2d_capacity = ctx->list2d_capacity;
-            ctx->h_counters[CNT_WORDS + CNT_OVERFLOW] = 0;
-            rc = render_impl(ctx, ctx->last_spec, ctx->last_out, ctx->last_stream);
-            if (rc != RXR_OK) return rc;
-            continue;
+        if (hc[HS_STAIRCASE]) {
+            hc[HS_STAIRCASE] = 0;
+            return fail(ctx, RXR_ERR_UNSUPPORTED,
+                        "four or more opacity batches nest as prefix minima in one pixel: the device keeps three per pixel (surface_id, "
+                        "rasterizer.rs:314-357, :1044-1048) and had to drop one; the frame may differ from the reference");
         }
-        if (!ctx->h_counters[CNT_OVERFLOW]) {
+        if (ctx->last_had_prepass) ctx->stats.n_bin_entries = hc[CNT_ENTRIES];
+        const bool over3d = hc[CNT_OVERFLOW] != 0, over2d = hc[CNT_WORDS + CNT_OVERFLOW] != 0;
+        if (!over3d && !over2d) {
             float a = 0, b = 0;
             if (ctx->last_e0 && hipEventElapsedTime(&a, ctx->last_e0, ctx->last_e1) == hipSuccess &&
                 hipEventElapsedTime(&b, ctx->last_e1, ctx->last_e2) == hipSuccess) {
@@ -1494,23 +1450,39 @@ int rxr_synchronize(rxr_ctx *ctx) {
                 ctx->stats.raster_us = b * 1000.0f;
                 ctx->stats.total_us = (a + b) * 1000.0f;
             }
+            if (earlier_incomplete)
+                return fail(ctx, RXR_ERR_OVERFLOW,
+                            "a bin list overflowed in a launch that was not the last one before this rxr_synchronize: that frame was "
+                            "incomplete (the lists have been grown and the last launch rendered again)");
             return RXR_OK;
         }
-        // bin list overflow: grow and render the same launch again
-        size_t want = (size_t)ctx->h_counters[CNT_ENTRIES] + ctx->h_counters[CNT_ENTRIES] / 2 + 1024;
-        int rc = ensure(ctx, ctx->d_list, want * sizeof(uint32_t));
-        if (rc != RXR_OK) return rc;
-        ctx->list_capacity = (uint32_t)std::min<size_t>(ctx->d_list.cap / sizeof(uint32_t), 0xFFFFFFF0u);
-        ctx->P.bin_list = (uint32_t *)ctx->d_list.p;
-        ctx->P.list_capacity = ctx->list_capacity;
-        rc = render_impl(ctx, ctx->last_spec, ctx->last_out, ctx->last_stream);
-        if (rc != RXR_OK) return rc;
+        if (launches > 1u) earlier_incomplete = true;
+        int rc;
+        if (over2d) {
+            const size_t seen = std::max(hc[CNT_WORDS + HS_MAX_ENTRIES], hc[CNT_WORDS + CNT_ENTRIES]);
+            if ((rc = ensure(ctx, ctx->d_list2d, (seen + seen / 2 + 1024) * sizeof(uint32_t))) != RXR_OK) return rc;
+            ctx->list2d_capacity = (uint32_t)std::min<size_t>(ctx->d_list2d.cap / sizeof(uint32_t), 0xFFFFFFF0u);
+            ctx->P.bin2d_list = (uint32_t *)ctx->d_list2d.p;
+            ctx->P.list2d_capacity = ctx->list2d_capacity;
+            hc[CNT_WORDS + CNT_OVERFLOW] = hc[CNT_WORDS + HS_MAX_ENTRIES] = 0;
+        }
+        if (over3d) {
+            const size_t seen = std::max(hc[HS_MAX_ENTRIES], hc[CNT_ENTRIES]);
+            if ((rc = ensure(ctx, ctx->d_list, (seen + seen / 2 + 1024) * sizeof(uint32_t))) != RXR_OK) return rc;
+            ctx->list_capacity = (uint32_t)std::min<size_t>(ctx->d_list.cap / sizeof(uint32_t), 0xFFFFFFF0u);
+            ctx->P.bin_list = (uint32_t *)ctx->d_list.p;
+            ctx->P.list_capacity = ctx->list_capacity;
+            hc[CNT_OVERFLOW] = hc[HS_MAX_ENTRIES] = 0;
+        }
+        // the same launch again, now with room (the streams are idle: see rxr_quiesce above)
+        if ((rc = render_impl(ctx, ctx->last_spec, ctx->last_out, ctx->last_stream, true)) != RXR_OK) return rc;
     }
     return fail(ctx, RXR_ERR_OOM, "bin list kept overflowing");
 }
 
 int rxr_download_rows(rxr_ctx *ctx, uint8_t *pixels, uint32_t row0, uint32_t row1) {
     if (!ctx || !pixels) return RXR_ERR_INVALID;
+    if (ctx->group) return fail(ctx, RXR_ERR_UNSUPPORTED, "rxr_download_rows on a multi-device context: use rxr_rasterize / rxr_render_download");
     if (!ctx->has_frame || row0 > row1 || row1 > ctx->P.height) return fail(ctx, RXR_ERR_INVALID, "rxr_download_rows: bad row range or no frame");
     int rc = rxr_synchronize(ctx);
     if (rc != RXR_OK) return rc;
@@ -1531,6 +1503,7 @@ int rxr_rasterize(rxr_ctx *ctx, const rxr_frame *frame, uint8_t *pixels) {
 
 int rxr_render_download(rxr_ctx *ctx, uint8_t *pixels) {
     if (!ctx || !pixels) return RXR_ERR_INVALID;
+    if (ctx->group) return rxr_group_render_download(ctx, pixels);
     if (!ctx->has_frame) return fail(ctx, RXR_ERR_INVALID, "rxr_render_download: no frame uploaded");
     int rc = RXR_OK;
     // The download of a 4K frame over PCIe takes longer than rendering it.  Frames whose launches cannot overflow a list
@@ -1571,11 +1544,12 @@ int rxr_render_download(rxr_ctx *ctx, uint8_t *pixels) {
 
 int rxr_get_stats(rxr_ctx *ctx, rxr_stats *out) {
     if (!ctx || !out) return RXR_ERR_INVALID;
+    if (ctx->group) return rxr_group_get_stats(ctx, out);
     *out = ctx->stats;
     return RXR_OK;
 }
 
-void *rxr_device_framebuffer(rxr_ctx *ctx) { return ctx ? ctx->d_fb.p : nullptr; }
+void *rxr_device_framebuffer(rxr_ctx *ctx) { return (ctx && !ctx->group) ? ctx->d_fb.p : nullptr; }
 
 // ---- Rusteria programs: NodeOp tree (include/rxr.h) -> jump code (rxr_device.h) ------------------
 namespace {
@@ -2061,7 +2035,12 @@ int rxr_check_shaders(const rxr_shader_set *set, uint32_t *code_words, char *mes
 
 int rxr_set_shaders(rxr_ctx *ctx, const rxr_shader_set *set) {
     if (!ctx) return RXR_ERR_INVALID;
+    if (ctx->group) return rxr_group_set_shaders(ctx, set);
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    {
+        int qrc = rxr_quiesce(ctx);  // a render (possibly on the caller's stream) may still run the old programs
+        if (qrc != RXR_OK) return qrc;
+    }
     ctx->has_frame = false;  // the resident frame's batch headers refer to the old programs
     ctx->programs.clear();
     ctx->programs_static = false;
@@ -2150,6 +2129,7 @@ int rxr_set_shaders(rxr_ctx *ctx, const rxr_shader_set *set) {
 
 int rxr_selftest_math(rxr_ctx *ctx, uint64_t n_tuples, uint64_t seed, uint64_t mismatches[RXR_MATH_KINDS]) {
     if (!ctx || !mismatches) return fail(ctx, RXR_ERR_INVALID, "rxr_selftest_math: NULL argument");
+    if (ctx->group) return rxr_selftest_math(rxr_member(ctx, 0), n_tuples, seed, mismatches);
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const uint32_t iters = 256;
     uint64_t per_block = 256ull * iters;

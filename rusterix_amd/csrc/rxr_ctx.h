@@ -1,0 +1,161 @@
+// rxr_ctx.h -- the context object behind the C ABI (private to rxr_api.hip and rxr_multi.hip).
+//
+// A plain context is one HIP device: its streams, the resident textures / meshes / programs, the frame blob and the
+// device scratch.  A multi-device context (rxr_create_multi) is a handle whose `group` lists one plain context per
+// device plus one host worker thread per member; it owns no device memory itself (rxr_multi.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "rxr_device.h"
+#include "rxr_project.h"
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+struct TileRange {
+    uint32_t first, n;
+};
+
+// host-side record of one registered mesh (rxr_set_meshes)
+struct HostMesh {
+    DevMesh dev;              // static part (bases, counts, cull mode); view_model / rejected are per frame
+    float transform[16];
+    float aabb_lo[3], aabb_hi[3];
+    bool has_vertices;
+    uint32_t repeat_mode;
+    rxr_source source;
+    float ambient[3];
+    int32_t shader;
+    uint32_t has_profile_id, profile_id, list;
+    int32_t chunk;
+};
+
+struct ProfSlot {
+    hipEvent_t e0, e1, e2;
+};
+
+// one render launch sequence.  Band mode: rows [row0,row1), stride 1.  Stripe mode: every `stride`-th
+// 16-row stripe from `first`, into a compact buffer (compact) or at its place in a whole frame (!compact).
+struct RenderSpec {
+    uint32_t row0, row1;
+    uint32_t tile_y0, tile_stride, tiles_y;
+    bool compact, external;
+};
+
+// pinned host words the device writes (rxr_ctx.h_counters): [0, CNT_WORDS) 3D bins, [CNT_WORDS, 2 CNT_WORDS) 2D bins,
+// then the words below.  The overflow flags and the maxima are STICKY: the device only ever sets / raises them, the host
+// clears them in rxr_synchronize after both streams have drained.
+enum : uint32_t {
+    HS_VM_FAULT = 2 * CNT_WORDS,        // a non-zero VMF_* code if any fragment's program faulted
+    HS_STAIRCASE = 2 * CNT_WORDS + 1,   // != 0: a pixel's opacity staircase (rxr_kernels.hip front_insert) had to drop an entry
+    HS_WORDS = 2 * CNT_WORDS + 4,
+};
+// inside a set of CNT_WORDS host words: CNT_ENTRIES = entries of the LAST launch, CNT_OVERFLOW = sticky flag,
+// CNT_LARGE (unused by the host otherwise) = the largest entry count seen by a launch that overflowed
+#define HS_MAX_ENTRIES CNT_LARGE
+
+struct rxr_group;
+
+struct rxr_ctx {
+    int device = 0;
+    rxr_group *group = nullptr;          // != nullptr: multi-device handle (every other member below is unused)
+    hipStream_t stream = nullptr;
+    uint32_t prof_stride = 1, prof_calls = 0;  // rxr_profile_stride: every prof_stride-th render records events
+    hipStream_t copy_stream = nullptr;   // rxr_rasterize: downloads of finished bands overlap the rendering of the next ones
+    hipEvent_t ev_band[8] = {};
+    std::string err;
+
+    // textures
+    DevBuf d_tex, d_texels;
+    std::vector<DevTexDesc> h_tex;
+    std::vector<TileRange> tiles_static, tiles_dynamic;
+
+    // frame blob
+    void *h_stage = nullptr;
+    size_t h_stage_cap = 0;
+    DevBuf d_frame;
+    DevBuf d_tri_setup, d_tri_shade, d_tri_box, d_bin_count, d_bins, d_list, d_large, d_counters, d_fb;
+    DevBuf d_bin2d_count, d_bins2d, d_list2d, d_large2d;
+    DevBuf d_stripes;                // multi-device member: this device's stripes, compact (rxr_multi.hip)
+    uint32_t list2d_capacity = 0, parity2d = 0;
+    uint32_t *h_counters = nullptr;  // pinned, HS_WORDS; written by the device through d_host_status
+    uint32_t *d_host_status = nullptr;
+    uint32_t list_capacity = 0;
+    size_t list_floor = 0;           // RXR_LIST_CAPACITY_FLOOR (tests): initial size of the bin lists instead of the generous default
+    uint32_t parity = 0;             // counter set of the next launch
+    bool scratch_dirty = false;      // a pre-pass was queued without its raster launch
+    bool scratch2d_dirty = false;
+    uint32_t min_kernel_level = 0;   // RXR_MIN_KERNEL_LEVEL (tuning)
+    bool programs_static = false;    // every program of the set has a stack depth that is a function of the pc (tag_static_depths)
+    uint32_t small_mode = 2;         // RasterParams.fused_small for frames with <= RXR_STAGE_TRIS triangles;
+                                     // RXR_SMALL_MODE=0|1|2 overrides it (tests / A-B runs)
+
+    // device-side projection (rxr_set_meshes)
+    std::vector<HostMesh> meshes;
+    DevBuf d_obj, d_proj_out, d_proj_misc;
+    ProjectParams PP{};
+    size_t mesh_verts_out = 0, mesh_tris_out = 0;
+    size_t pp_off_meshes = 0;  // byte offset of the per-frame DevMesh array inside d_proj_misc
+    bool frame_uses_meshes = false;
+
+    // Rusteria programs (rxr_set_shaders)
+    DevBuf d_vm_code, d_programs, d_patterns, d_pattern_data, d_palette;
+    std::vector<DevProgram> programs;
+    std::vector<uint32_t> program_field_reads;  // PF_* each program reads before writing (see rxr_set_shaders)
+    std::vector<uint32_t> program_flags;        // PG_* per program (see rxr_set_shaders)
+    uint32_t n_patterns = 0, n_normal_patterns = 0, n_palette = 0;
+    bool frame_uses_programs = false;
+
+    bool has_frame = false;
+    RasterParams P{};       // template for the resident frame (pointers resolved)
+    uint32_t n_tris2d = 0;
+
+    // last render
+    bool rendered = false;
+    bool last_had_prepass = false, last_had_prepass2d = false;
+    uint32_t launches_since_sync = 0;   // renders queued since rxr_synchronize last drained the streams
+    uint32_t rerenders = 0;             // launches rendered again by rxr_synchronize after a list overflow
+    RenderSpec last_spec{};
+    void *last_out = nullptr;
+    hipStream_t last_stream = nullptr;
+    hipStream_t upload_ordered_on = nullptr;  // stream already ordered behind the last upload
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev_upload = nullptr;
+    hipEvent_t ev_render = nullptr;     // recorded behind every render launch sequence (orders a render on ANOTHER stream behind it)
+    hipEvent_t last_e0 = nullptr, last_e1 = nullptr, last_e2 = nullptr;
+    std::vector<ProfSlot> prof;  // rxr_profile_begin ring
+    size_t prof_next = 0;
+    rxr_stats stats{};
+};
+
+// ---- helpers shared by the two translation units (defined in rxr_api.hip) -------------------------
+int rxr_fail(rxr_ctx *ctx, int code, const std::string &msg);
+int rxr_ensure(rxr_ctx *ctx, DevBuf &b, size_t bytes);
+// waits until nothing queued by this context -- on its own streams or on the caller's stream of the last render -- is
+// still running: the precondition for rewriting the staging blob, the frame blob or any scratch buffer
+int rxr_quiesce(rxr_ctx *ctx);
+// one render launch sequence of a plain context (rxr_api.hip)
+extern "C" int rxr_render_spec(rxr_ctx *ctx, const RenderSpec &spec, void *dev_pixels, hipStream_t s);
+
+#define HIPCHK(ctx, call)                                                                                  \
+    do {                                                                                                   \
+        hipError_t e_ = (call);                                                                            \
+        if (e_ != hipSuccess)                                                                              \
+            return rxr_fail(ctx, RXR_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));          \
+    } while (0)
+
+// ---- multi-device handles (rxr_multi.hip); every function expects ctx->group != nullptr -------------
+void rxr_group_destroy(rxr_ctx *ctx);
+int rxr_group_set_textures(rxr_ctx *ctx, const rxr_tile *static_tiles, uint32_t n_static, const rxr_tile *dynamic_tiles, uint32_t n_dynamic);
+int rxr_group_set_meshes(rxr_ctx *ctx, const rxr_mesh3d *meshes, uint32_t n_meshes);
+int rxr_group_set_shaders(rxr_ctx *ctx, const rxr_shader_set *set);
+int rxr_group_upload_frame(rxr_ctx *ctx, const rxr_frame *frame);
+int rxr_group_render(rxr_ctx *ctx);                          // every member renders its stripes (asynchronous)
+int rxr_group_download(rxr_ctx *ctx, uint8_t *pixels);       // ... and ships them to host `pixels`; blocks
+int rxr_group_render_download(rxr_ctx *ctx, uint8_t *pixels);
+int rxr_group_synchronize(rxr_ctx *ctx);
+int rxr_group_get_stats(rxr_ctx *ctx, rxr_stats *out);

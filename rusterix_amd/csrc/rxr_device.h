@@ -239,6 +239,7 @@ struct RasterParams {
     const float *palette;              // n_palette x 4: r, g, b, present (0 / 1)
     uint32_t n_programs, n_patterns, n_normal_patterns, n_palette;
     uint32_t *vm_fault;                // pinned host word: a non-zero VMF_* code if any fragment's program faulted
+    uint32_t *staircase_overflow;      // pinned host word: set when a pixel's opacity staircase had to drop an entry (front_insert)
     float time;                        // Rasterizer.time
     float bg_grid[4];                  // RXR_BG_GRID: grid_size, subdivisions, offset.x, offset.y
     uint32_t has_brush;                // Rasterizer.brush_preview (feature level >= 1)

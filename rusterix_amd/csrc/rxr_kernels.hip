@@ -1136,8 +1136,14 @@ extern "C" __global__ void __launch_bounds__(256) k_scan(ScanArgs A) {
         const uint32_t overflow = carry > A.list_capacity ? 1u : 0u;
         A.counters[CNT_ENTRIES] = carry;
         A.counters[CNT_OVERFLOW] = overflow;
+        // host words: the entry count of this launch; the overflow flag and the largest overflowing count are STICKY (only
+        // ever set / raised here, cleared by rxr_synchronize once the streams have drained), so that an asynchronous caller
+        // learns about ANY overflowed launch, not only the last one
         A.host_status[CNT_ENTRIES] = carry;
-        A.host_status[CNT_OVERFLOW] = overflow;
+        if (overflow) {
+            A.host_status[CNT_OVERFLOW] = 1u;
+            if (carry > A.host_status[CNT_LARGE]) A.host_status[CNT_LARGE] = carry;  // (HS_MAX_ENTRIES, rxr_ctx.h)
+        }
     }
     if (lane < CNT_WORDS) A.counters_next[lane] = 0u;
 }

@@ -1,0 +1,208 @@
+"""Multi-device contexts (rxr_create_multi, rusterix_amd/csrc/rxr_multi.hip) on ONE GPU: N logical members on device 0.
+
+The reference renders tiles independently and concatenates them at the end (reference src/rasterizer.rs:273-275, :559-579);
+the library does the same across devices.  What must hold: the frame a caller of rasterize() gets from
+an N-member context is byte-identical to the single-device frame -- for host consumers (every member copies its stripes into
+`pixels`) and for device consumers (rxr_render_gather: peer copies into the root's frame) -- whatever N, the frame height
+(ragged last stripe), the sharding mode and the scene's pipeline (implicit list, binned lists, device projection, programs).
+Also here: the stream / status contract of rxr.h (renders on caller streams, sticky overflow status)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import rusterix_amd
+from rusterix_amd import scenes
+from tests.test_gpu_parity import assert_exact
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def single_again(product):
+    """puts the process-wide context back to one plain device-0 context after the test"""
+    yield
+    for k in ("RXR_MULTI_SHARD", "RXR_MULTI_COPY", "RXR_LIST_CAPACITY_FLOOR"):
+        os.environ.pop(k, None)
+    product.lib.rxh_set_device(0)
+    product.lib.rxh_set_device_projection(0)
+
+
+def use_members(product, n):
+    ids = (C.c_int * n)(*([0] * n))
+    product.lib.rxh_set_devices(ids, n)
+    ctx = product.lib.rxh_context()
+    assert ctx, product.lib.rxh_last_error()
+    rxr = rusterix_amd.rxr_abi()
+    assert rxr.rxr_member_count(ctx) == n
+    return rxr, ctx
+
+
+def single_frame(product, cfg):
+    product.lib.rxh_set_device(0)
+    return scenes.render(cfg).copy()
+
+
+@pytest.mark.parametrize("n", [2, 3, 8])
+def test_rasterize_on_n_members_equals_single(product, single_again, n):
+    cfg = scenes.map_scene(product, width=400, height=250, logo_size=64, n_lights=3)  # 250 rows: ragged last stripe
+    ref = single_frame(product, cfg)
+    use_members(product, n)
+    out = np.full(cfg.width * cfg.height * 4, 77, np.uint8)
+    got = scenes.render(cfg, out).copy()
+    assert_exact(got, ref, f"{n}-member rasterize vs single device")
+    # a second frame through the same context (resident textures, new upload)
+    got2 = scenes.render(cfg, np.full(cfg.width * cfg.height * 4, 11, np.uint8)).copy()
+    assert_exact(got2, ref, f"{n}-member rasterize, second frame")
+
+
+@pytest.mark.parametrize("mode", ["bands", "copy1d"])
+def test_sharding_variants_equal_single(product, single_again, mode):
+    cfg = scenes.map_scene(product, width=336, height=203, logo_size=64, n_lights=2)
+    ref = single_frame(product, cfg)
+    if mode == "bands":
+        os.environ["RXR_MULTI_SHARD"] = "bands"
+    else:
+        os.environ["RXR_MULTI_COPY"] = "1d"
+    use_members(product, 3)
+    assert_exact(scenes.render(cfg).copy(), ref, f"3 members, {mode}")
+
+
+def test_more_members_than_stripes(product, single_again):
+    cfg = scenes.cube_scene(product, width=96, height=40, tile_size=16, textured=True, distance=3.0, logo_size=32)  # 3 stripes
+    ref = single_frame(product, cfg)
+    use_members(product, 5)
+    assert_exact(scenes.render(cfg).copy(), ref, "5 members, 3 stripes")
+
+
+@pytest.mark.parametrize("device_projection", [False, True])
+def test_binned_scene_on_members(product, single_again, device_projection):
+    """the binned pipeline (per-member bin lists restricted to its stripes), host- and device-projected, with the per-batch program"""
+    product.lib.rxh_set_device_projection(1 if device_projection else 0)
+    cfg = scenes.box_grid_scene(product, n=40, width=640, height=360, shader=True)
+    ref = single_frame(product, cfg)
+    use_members(product, 4)
+    assert_exact(scenes.render(cfg).copy(), ref, f"4 members, box grid, device_projection={device_projection}")
+
+
+def test_bin_list_overflow_is_repaired_per_member(product, single_again):
+    os.environ["RXR_LIST_CAPACITY_FLOOR"] = "512"
+    cfg = scenes.teapot_scene(product, width=640, height=360, logo_size=64)
+    use_members(product, 3)  # new member contexts: they read the floor
+    got = scenes.render(cfg).copy()
+    os.environ.pop("RXR_LIST_CAPACITY_FLOOR")
+    ref = single_frame(product, cfg)
+    assert_exact(got, ref, "3 members with overflowing bin lists")
+
+
+def test_render_gather_into_root_framebuffer_and_caller_buffer(product, single_again):
+    import torch
+
+    cfg = scenes.map_scene(product, width=400, height=250, logo_size=64, n_lights=3)
+    ref = single_frame(product, cfg)
+    rxr, ctx = use_members(product, 4)
+    r = cfg.setup()
+    assert product.lib.rxh_rasterizer_upload(r._h, cfg.scene._h, cfg.width, cfg.height, cfg.tile_size, cfg.assets._h) == 0
+    for root in (0, 2):
+        # the root member's own framebuffer
+        assert rxr.rxr_render_gather(ctx, root, None, None) == 0, rxr.rxr_last_error(ctx)
+        assert rxr.rxr_synchronize(ctx) == 0, rxr.rxr_last_error(ctx)
+        out = np.zeros((cfg.height, cfg.width, 4), np.uint8)
+        assert rxr.rxr_download_rows(rxr.rxr_member(ctx, root), out.ctypes.data, 0, cfg.height) == 0
+        assert_exact(out, ref, f"gather into member {root}'s framebuffer")
+        # caller-owned device memory on a caller stream
+        stream = torch.cuda.Stream()
+        buf = torch.full((cfg.height, cfg.width, 4), 9, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        assert rxr.rxr_render_gather(ctx, root, C.c_void_p(buf.data_ptr()), C.c_void_p(stream.cuda_stream)) == 0
+        stream.synchronize()
+        assert_exact(buf.cpu().numpy(), ref, f"gather into a caller buffer, root {root}")
+    # band / stripe / row entry points are single-device calls
+    assert rxr.rxr_render_rows(ctx, 0, cfg.height) == rusterix_amd.binding.RXR_ERR_UNSUPPORTED
+    assert b"multi-device" in rxr.rxr_last_error(ctx)
+
+
+def test_plain_context_gather_and_member_api(product, single_again):
+    cfg = scenes.map_scene(product, width=320, height=192, logo_size=64, n_lights=1)
+    ref = single_frame(product, cfg)
+    rxr = rusterix_amd.rxr_abi()
+    ctx = product.lib.rxh_context()
+    assert rxr.rxr_member_count(ctx) == 1 and rxr.rxr_member(ctx, 0) == ctx and not rxr.rxr_member(ctx, 1)
+    r = cfg.setup()
+    assert product.lib.rxh_rasterizer_upload(r._h, cfg.scene._h, cfg.width, cfg.height, cfg.tile_size, cfg.assets._h) == 0
+    assert rxr.rxr_render_gather(ctx, 0, None, None) == 0
+    out = np.zeros((cfg.height, cfg.width, 4), np.uint8)
+    assert rxr.rxr_download_rows(ctx, out.ctypes.data, 0, cfg.height) == 0
+    assert_exact(out, ref, "plain context: rxr_render_gather == all rows")
+    assert rxr.rxr_render_gather(ctx, 1, None, None) == rusterix_amd.binding.RXR_ERR_INVALID
+
+
+def test_pinned_pixels(product, single_again):
+    cfg = scenes.map_scene(product, width=400, height=250, logo_size=64, n_lights=3)
+    ref = single_frame(product, cfg)
+    rxr, ctx = use_members(product, 3)
+    out = np.zeros(cfg.width * cfg.height * 4, np.uint8)
+    assert rxr.rxr_pin_host_buffer(ctx, out.ctypes.data, out.nbytes) == 0, rxr.rxr_last_error(ctx)
+    try:
+        assert_exact(scenes.render(cfg, out).copy(), ref, "3 members into a pinned buffer")
+    finally:
+        assert rxr.rxr_unpin_host_buffer(ctx, out.ctypes.data) == 0
+
+
+# ---- the stream / status contract of rxr.h ----------------------------------------------------------------------
+
+def test_upload_waits_for_renders_on_caller_streams(product, single_again):
+    """a frame rendered on a CALLER stream must not be disturbed by the next upload (the staging blob, the frame blob and the
+    scratch buffers are rewritten by it): rxr_upload_frame waits for that stream"""
+    import torch
+
+    rxr = rusterix_amd.rxr_abi()
+    heavy = scenes.box_grid_scene(product, n=64, width=1280, height=720)
+    other = scenes.map_scene(product, width=1280, height=720, logo_size=64, n_lights=2)
+    ref_heavy, ref_other = scenes.render(heavy).copy(), scenes.render(other).copy()
+    stream = torch.cuda.Stream()
+    sptr = C.c_void_p(stream.cuda_stream)
+    a = torch.zeros((720, 1280, 4), dtype=torch.uint8, device="cuda")
+    b = torch.zeros((720, 1280, 4), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    ctx = product.lib.rxh_context()
+    for _ in range(3):
+        r = heavy.setup()
+        assert product.lib.rxh_rasterizer_upload(r._h, heavy.scene._h, 1280, 720, heavy.tile_size, heavy.assets._h) == 0
+        assert rxr.rxr_render_rows_to(ctx, 0, 720, C.c_void_p(a.data_ptr()), sptr) == 0
+        r = other.setup()  # no synchronisation in between
+        assert product.lib.rxh_rasterizer_upload(r._h, other.scene._h, 1280, 720, other.tile_size, other.assets._h) == 0
+        assert rxr.rxr_render_rows_to(ctx, 0, 720, C.c_void_p(b.data_ptr()), None) == 0  # the context's own stream
+        assert rxr.rxr_synchronize(ctx) == 0
+        stream.synchronize()
+        assert_exact(a.cpu().numpy(), ref_heavy, "frame on the caller stream, next upload queued behind it")
+        assert_exact(b.cpu().numpy(), ref_other, "next frame on the context stream")
+
+
+def test_overflow_of_an_earlier_launch_is_reported(product, single_again):
+    """launches queued without a synchronize in between: the sticky status says that one of them overflowed"""
+    import torch
+
+    cfg = scenes.teapot_scene(product, width=640, height=360, logo_size=64)
+    ref = single_frame(product, cfg)
+    os.environ["RXR_LIST_CAPACITY_FLOOR"] = "512"
+    rxr, ctx = use_members(product, 2)  # fresh member contexts: they read the floor
+    os.environ.pop("RXR_LIST_CAPACITY_FLOOR")
+    m0 = rxr.rxr_member(ctx, 0)
+    r = cfg.setup()
+    assert product.lib.rxh_rasterizer_upload(r._h, cfg.scene._h, cfg.width, cfg.height, cfg.tile_size, cfg.assets._h) == 0
+    first = torch.zeros((cfg.height, cfg.width, 4), dtype=torch.uint8, device="cuda")
+    last = torch.zeros((cfg.height, cfg.width, 4), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    # two launches of member 0 back to back, both overflow: the second is repaired, the first is reported
+    assert rxr.rxr_render_rows_to(m0, 0, cfg.height, C.c_void_p(first.data_ptr()), None) == 0
+    assert rxr.rxr_render_rows_to(m0, 0, cfg.height, C.c_void_p(last.data_ptr()), None) == 0
+    rc = rxr.rxr_synchronize(m0)
+    assert rc == -6, (rc, rxr.rxr_last_error(m0))  # RXR_ERR_OVERFLOW
+    assert_exact(last.cpu().numpy(), ref, "the last launch is rendered again with grown lists")
+    # from now on the lists are large enough
+    assert rxr.rxr_render_rows_to(m0, 0, cfg.height, C.c_void_p(first.data_ptr()), None) == 0
+    assert rxr.rxr_render_rows_to(m0, 0, cfg.height, C.c_void_p(last.data_ptr()), None) == 0
+    assert rxr.rxr_synchronize(m0) == 0, rxr.rxr_last_error(m0)
+    assert_exact(first.cpu().numpy(), ref, "after the lists have grown")
