@@ -2,6 +2,7 @@
 # A-B-A-B of the in-tree library against build/variants/librxr_hip_prev.so: bench line + configurations (host- and device-projected).
 cd "$(dirname "$0")/.."
 cp rusterix_amd/csrc/librxr_hip.so /tmp/new.so
+trap 'cp /tmp/new.so rusterix_amd/csrc/librxr_hip.so' EXIT   # the product library comes back on ANY exit
 for r in 1 2; do
 for name in new prev; do
   if [ $name = prev ]; then cp build/variants/librxr_hip_prev.so rusterix_amd/csrc/librxr_hip.so; else cp /tmp/new.so rusterix_amd/csrc/librxr_hip.so; fi

@@ -3,6 +3,7 @@
 cd "$(dirname "$0")/.."
 V=$1; shift
 cp rusterix_amd/csrc/librxr_hip.so /tmp/orig.so
+trap 'cp /tmp/orig.so rusterix_amd/csrc/librxr_hip.so' EXIT   # the product library comes back on ANY exit
 for round in 1 2; do
   for which in base $V; do
     if [ $which = base ]; then cp /tmp/orig.so rusterix_amd/csrc/librxr_hip.so; else cp build/variants/librxr_hip_$which.so rusterix_amd/csrc/librxr_hip.so; fi

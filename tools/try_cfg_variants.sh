@@ -5,6 +5,7 @@ set -u
 cd "$(dirname "$0")/.."
 CFG=$1; shift
 cp rusterix_amd/csrc/librxr_hip.so /tmp/librxr_hip_orig.so
+trap 'cp /tmp/librxr_hip_orig.so rusterix_amd/csrc/librxr_hip.so' EXIT   # the product library comes back on ANY exit
 for name in base "$@"; do
   if [ "$name" != base ]; then cp "build/variants/librxr_hip_$name.so" rusterix_amd/csrc/librxr_hip.so; fi
   timeout 300 python tools/run_configs.py --configs "$CFG" --oracle none --frames 20 2>&1 | python -c "

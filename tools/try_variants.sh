@@ -5,6 +5,7 @@ set -u
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 cp rusterix_amd/csrc/librxr_hip.so /tmp/librxr_hip_orig.so
+trap 'cp /tmp/librxr_hip_orig.so rusterix_amd/csrc/librxr_hip.so' EXIT   # the product library comes back on ANY exit
 for so in build/variants/librxr_hip_*.so; do
   name=$(basename "$so" .so); name=${name#librxr_hip_}
   cp "$so" rusterix_amd/csrc/librxr_hip.so

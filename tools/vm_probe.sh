@@ -2,6 +2,8 @@
 # Interpreter cost probes (tools/run_configs.py C5s_vm:*) for the in-tree library and kernel-variant builds.   usage: tools/vm_probe.sh [names...]
 cd "$(dirname "$0")/.."
 cp rusterix_amd/csrc/librxr_hip.so /tmp/librxr_hip_orig.so
+# the product library is put back on ANY exit (an interrupted run must not leave a variant build behind for the tests / bench)
+trap 'cp /tmp/librxr_hip_orig.so rusterix_amd/csrc/librxr_hip.so' EXIT
 for name in base "$@"; do
   if [ "$name" != base ]; then cp "build/variants/librxr_hip_$name.so" rusterix_amd/csrc/librxr_hip.so; fi
   for v in C5s_vm:empty C5s_vm:u40 C5s_vm:b20 C5s_vm:g20 C5s_vm:m20 C5s_shader C5shader; do
@@ -14,4 +16,3 @@ for l in sys.stdin:
 "
   done
 done
-cp /tmp/librxr_hip_orig.so rusterix_amd/csrc/librxr_hip.so
