@@ -66,6 +66,14 @@ enum { RXR_SOURCE_OTHER = 0,         /* Off / TileId / MaterialId / Sequence / C
        RXR_SOURCE_TERRAIN = 4,       /* Terrain (chunk terrain texture)                            */
        RXR_SOURCE_MISSING = 5 };     /* EntityTile/ItemTile whose lookup failed on the host: [0,0,0,0];
                                         a successful lookup is passed as RXR_SOURCE_DYNAMIC_TILE     */
+/* Host-side only -- these two never cross the ABI (rxr_upload_frame answers them with RXR_ERR_INVALID): EntityTile(id, index) /
+ * ItemTile(id, index), src/map/pixelsource.rs:29-30.  The raster loops look (id, index) up per fragment in
+ * assets.entity_tiles / assets.item_tiles (FxHashMap<u32, IndexMap<String, Tile>>; src/rasterizer.rs:1140-1187, :705-748,
+ * :1548-1595); the lookup is frame-constant, so the HOST does it once per batch and hands the device
+ * RXR_SOURCE_DYNAMIC_TILE (hit: the tile travels with the dynamic tiles of rxr_set_textures) or RXR_SOURCE_MISSING (unknown
+ * id, or no `index`-th sequence: [0,0,0,0] in all three loops).  The host mirror and the oracle use these values for the
+ * unresolved variants. */
+enum { RXR_HOST_SOURCE_ENTITY_TILE = 64, RXR_HOST_SOURCE_ITEM_TILE = 65 };
 /* which Scene list a 3D batch came from; order of the array is submission order
  * (src/rasterizer.rs:314-405) */
 enum { RXR_LIST_CHUNK_OPACITY = 0, RXR_LIST_CHUNK = 1, RXR_LIST_CHUNK_TERRAIN = 2, RXR_LIST_STATIC = 3,

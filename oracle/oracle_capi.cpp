@@ -157,6 +157,13 @@ void orc_batch3d_set_source(void *b, uint32_t kind, uint32_t index, const uint8_
     s.index = index;
     if (pixel) memcpy(s.pixel, pixel, 4);
 }
+// PixelSource::EntityTile(id, seq) / ItemTile(id, seq)
+void orc_batch3d_set_source_seq(void *b, int is_item, uint32_t id, uint32_t seq) {
+    Source &s = ((Batch3D *)b)->source;
+    s.kind = is_item ? RXR_HOST_SOURCE_ITEM_TILE : RXR_HOST_SOURCE_ENTITY_TILE;
+    s.index = id;
+    s.seq = seq;
+}
 void orc_batch3d_set_repeat_mode(void *b, int m) { ((Batch3D *)b)->repeat_mode = m; }
 void orc_batch3d_set_cull_mode(void *b, int m) { ((Batch3D *)b)->cull_mode = m; }
 void orc_batch3d_set_ambient_color(void *b, float r, float g, float bl) { ((Batch3D *)b)->ambient_color = Vec3{r, g, bl}; }
@@ -209,6 +216,12 @@ void orc_batch2d_set_source(void *b, uint32_t kind, uint32_t index, const uint8_
     s.index = index;
     if (pixel) memcpy(s.pixel, pixel, 4);
 }
+void orc_batch2d_set_source_seq(void *b, int is_item, uint32_t id, uint32_t seq) {
+    Source &s = ((Batch2D *)b)->source;
+    s.kind = is_item ? RXR_HOST_SOURCE_ITEM_TILE : RXR_HOST_SOURCE_ENTITY_TILE;
+    s.index = id;
+    s.seq = seq;
+}
 void orc_batch2d_set_receives_light(void *b, int v) { ((Batch2D *)b)->receives_light = v != 0; }
 void orc_batch2d_set_shader(void *b, int shader) { ((Batch2D *)b)->shader = shader; }
 int orc_scene_push_batch2d(void *s, void *b, int dynamic, int chunk) {
@@ -229,6 +242,12 @@ void *orc_assets_new() { return new Assets(); }
 void orc_assets_free(void *a) { delete (Assets *)a; }
 void orc_assets_add_tile(void *a, const uint8_t *const *frames, const uint32_t *ws, const uint32_t *hs, uint32_t n) {
     ((Assets *)a)->tile_list.push_back(make_tile(frames, ws, hs, n));
+}
+// assets.entity_tiles / item_tiles: makes `id` known (an entry without sequences) ...
+void orc_assets_add_sequence_id(void *a, int is_item, uint32_t id) { (is_item ? ((Assets *)a)->item_tiles : ((Assets *)a)->entity_tiles)[id]; }
+// ... and appends one sequence tile to it (IndexMap insertion order = get_index order)
+void orc_assets_add_sequence_tile(void *a, int is_item, uint32_t id, const uint8_t *const *frames, const uint32_t *ws, const uint32_t *hs, uint32_t n) {
+    (is_item ? ((Assets *)a)->item_tiles : ((Assets *)a)->entity_tiles)[id].push_back(make_tile(frames, ws, hs, n));
 }
 
 // rusteria's global pattern banks (textures/patterns.rs) and assets.palette, as data

@@ -800,6 +800,23 @@ static inline bool fetch_texel(const FrameCtx &fc, const Source &src, int repeat
         case RXR_SOURCE_PIXEL:
             memcpy(texel, src.pixel, 4);
             return true;
+        case RXR_HOST_SOURCE_ENTITY_TILE:
+        case RXR_HOST_SOURCE_ITEM_TILE: {
+            // PixelSource::EntityTile(id, index) / ItemTile(id, index): src/rasterizer.rs:1140-1187 (3D), :705-748 (2D),
+            // :1548-1595 (opacity pass) -- the same in all three: assets.entity_tiles.get(&id) -> .get_index(index) ->
+            // textures[animation_frame % len].sample(..); either lookup failing gives [0, 0, 0, 0]
+            const auto &tiles = src.kind == RXR_HOST_SOURCE_ENTITY_TILE ? fc.assets->entity_tiles : fc.assets->item_tiles;
+            const auto it = tiles.find(src.index);
+            if (it == tiles.end() || src.seq >= it->second.size()) {
+                zero();
+                return true;
+            }
+            const Tile &textile = it->second[src.seq];
+            if (textile.textures.empty()) return false;  // `% 0` panics
+            size_t index = fc.scene->animation_frame % textile.textures.size();
+            texture_sample(textile.textures[index], u, v, r.sample_mode, repeat_mode, texel);
+            return true;
+        }
         case RXR_SOURCE_MISSING:
             zero();
             return true;

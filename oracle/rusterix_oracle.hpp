@@ -18,6 +18,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <map>
 #include <vector>
 
 #include "../include/rusterix_vek.hpp"
@@ -94,9 +95,10 @@ struct Rect {
 
 // src/map/pixelsource.rs:23-37 (variants the raster loops distinguish; see include/rxr.h)
 struct Source {
-    uint32_t kind = RXR_SOURCE_OTHER;
+    uint32_t kind = RXR_SOURCE_OTHER;  // RXR_SOURCE_*, or RXR_HOST_SOURCE_ENTITY_TILE / _ITEM_TILE (index = id, seq = sequence index)
     uint32_t index = 0;
     uint8_t pixel[4] = {0, 0, 0, 0};
+    uint32_t seq = 0;
 };
 
 // src/texture.rs:46-54
@@ -112,6 +114,9 @@ struct Tile {
 // pattern banks (rusteria/src/textures/patterns.rs) so that tests can supply their own
 struct Assets {
     std::vector<Tile> tile_list;
+    // src/server/assets.rs:28, :34: FxHashMap<u32, IndexMap<String, Tile>>.  The raster loops only use `.get(&id)` and
+    // `.get_index(i)` (rasterizer.rs:1140-1187), so an id -> ordered list of tiles carries everything they read
+    std::map<uint32_t, std::vector<Tile>> entity_tiles, item_tiles;
     vm::Env vm_env;
 };
 

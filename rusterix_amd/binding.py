@@ -22,6 +22,7 @@ MODE_TRIANGLES, MODE_LINES, MODE_LINE_STRIP, MODE_LINE_LOOP = 0, 1, 2, 3
 CULL_OFF, CULL_FRONT, CULL_BACK = 0, 1, 2
 LIGHT_POINT, LIGHT_AMBIENT, LIGHT_AMBIENT_DAYLIGHT, LIGHT_SPOT, LIGHT_AREA, LIGHT_DAYLIGHT = range(6)
 SOURCE_OTHER, SOURCE_STATIC_TILE, SOURCE_DYNAMIC_TILE, SOURCE_PIXEL, SOURCE_TERRAIN, SOURCE_MISSING = range(6)
+HOST_SOURCE_ENTITY_TILE, HOST_SOURCE_ITEM_TILE = 64, 65  # never cross the ABI: resolved by the host (include/rxr.h)
 LIST_CHUNK_OPACITY, LIST_CHUNK, LIST_CHUNK_TERRAIN, LIST_STATIC, LIST_DYNAMIC, LIST_OVERLAY = range(6)
 BG_NONE, BG_VGRADIENT, BG_HOST_PIXELS, BG_GRID = 0, 1, 2, 3
 
@@ -133,6 +134,19 @@ class PixelSource:
     @staticmethod
     def Terrain():
         return PixelSource(SOURCE_TERRAIN)
+
+    @staticmethod
+    def EntityTile(entity_id, index):
+        """PixelSource::EntityTile(id, index): assets.entity_tiles[id].get_index(index) (reference src/rasterizer.rs:1140-1163)"""
+        s = PixelSource(HOST_SOURCE_ENTITY_TILE, entity_id)
+        s.seq = index
+        return s
+
+    @staticmethod
+    def ItemTile(item_id, index):
+        s = PixelSource(HOST_SOURCE_ITEM_TILE, item_id)
+        s.seq = index
+        return s
 
     @staticmethod
     def Missing():
@@ -383,6 +397,10 @@ def make_api(lib: C.CDLL, prefix: str, name: str):
         batch3d_set_normals=fn("batch3d_set_normals", None, vp, pf, u32),
         batch3d_compute_vertex_normals=fn("batch3d_compute_vertex_normals", None, vp),
         batch3d_set_source=fn("batch3d_set_source", None, vp, u32, u32, pb),
+        batch3d_set_source_seq=fn("batch3d_set_source_seq", None, vp, i32, u32, u32),
+        batch2d_set_source_seq=fn("batch2d_set_source_seq", None, vp, i32, u32, u32),
+        assets_add_sequence_id=fn("assets_add_sequence_id", None, vp, i32, u32),
+        assets_add_sequence_tile=fn("assets_add_sequence_tile", None, vp, i32, u32, ppb, pu, pu, u32),
         batch3d_set_repeat_mode=fn("batch3d_set_repeat_mode", None, vp, i32),
         batch3d_set_cull_mode=fn("batch3d_set_cull_mode", None, vp, i32),
         batch3d_set_ambient_color=fn("batch3d_set_ambient_color", None, vp, f32, f32, f32),
@@ -479,6 +497,9 @@ def make_api(lib: C.CDLL, prefix: str, name: str):
         compute_vertex_normals = with_computed_normals
 
         def source(self, src: PixelSource):
+            if src.kind in (HOST_SOURCE_ENTITY_TILE, HOST_SOURCE_ITEM_TILE):
+                L.batch3d_set_source_seq(self._h, 1 if src.kind == HOST_SOURCE_ITEM_TILE else 0, src.index, src.seq)
+                return self
             px = (C.c_uint8 * 4)(*src.pixel)
             L.batch3d_set_source(self._h, src.kind, src.index, px)
             return self
@@ -554,6 +575,9 @@ def make_api(lib: C.CDLL, prefix: str, name: str):
             return self
 
         def source(self, src: PixelSource):
+            if src.kind in (HOST_SOURCE_ENTITY_TILE, HOST_SOURCE_ITEM_TILE):
+                L.batch2d_set_source_seq(self._h, 1 if src.kind == HOST_SOURCE_ITEM_TILE else 0, src.index, src.seq)
+                return self
             px = (C.c_uint8 * 4)(*src.pixel)
             L.batch2d_set_source(self._h, src.kind, src.index, px)
             return self
@@ -740,6 +764,19 @@ def make_api(lib: C.CDLL, prefix: str, name: str):
                 frames, ws, hs, n = tile_args(t)
                 L.assets_add_tile(self._h, frames, ws, hs, n)
             return self
+
+        def entity_tiles(self, tiles_by_id, item=False):
+            """assets.entity_tiles (or, with item=True, assets.item_tiles): {id: [Tile, ...]} -- the sequences of an id in
+            IndexMap insertion order (reference src/server/assets.rs:28, :34); an id with an empty list is known but has no sequence"""
+            for ident, tiles in tiles_by_id.items():
+                L.assets_add_sequence_id(self._h, 1 if item else 0, int(ident))
+                for t in tiles:
+                    frames, ws, hs, n = tile_args(t)
+                    L.assets_add_sequence_tile(self._h, 1 if item else 0, int(ident), frames, ws, hs, n)
+            return self
+
+        def item_tiles(self, tiles_by_id):
+            return self.entity_tiles(tiles_by_id, item=True)
 
         def patterns(self, textures, normal=False):
             """rusteria's global pattern bank (rusteria/src/textures/patterns.rs) as data: a list of float32

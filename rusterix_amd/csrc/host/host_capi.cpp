@@ -151,6 +151,10 @@ void rxh_batch3d_set_normals(void *b, const float *n3, uint32_t n) {
 }
 void rxh_batch3d_compute_vertex_normals(void *b) { ((Batch3D *)b)->compute_vertex_normals(); }
 void rxh_batch3d_set_source(void *b, uint32_t kind, uint32_t index, const uint8_t *pixel) { set_source(((Batch3D *)b)->source_, kind, index, pixel); }
+// PixelSource::EntityTile(id, seq) / ItemTile(id, seq)
+void rxh_batch3d_set_source_seq(void *b, int is_item, uint32_t id, uint32_t seq) {
+    ((Batch3D *)b)->source_ = is_item ? PixelSource::ItemTile(id, seq) : PixelSource::EntityTile(id, seq);
+}
 void rxh_batch3d_set_repeat_mode(void *b, int m) { ((Batch3D *)b)->repeat_mode_ = (uint32_t)m; }
 void rxh_batch3d_set_cull_mode(void *b, int m) { ((Batch3D *)b)->cull_mode_ = (CullMode)m; }
 void rxh_batch3d_set_ambient_color(void *b, float r, float g, float bl) { ((Batch3D *)b)->ambient_color_ = Vec3{r, g, bl}; }
@@ -189,6 +193,9 @@ void rxh_batch2d_free(void *b) { delete (Batch2D *)b; }
 void rxh_batch2d_set_mode(void *b, int m) { ((Batch2D *)b)->mode_ = (uint32_t)m; }
 void rxh_batch2d_set_repeat_mode(void *b, int m) { ((Batch2D *)b)->repeat_mode_ = (uint32_t)m; }
 void rxh_batch2d_set_source(void *b, uint32_t kind, uint32_t index, const uint8_t *pixel) { set_source(((Batch2D *)b)->source_, kind, index, pixel); }
+void rxh_batch2d_set_source_seq(void *b, int is_item, uint32_t id, uint32_t seq) {
+    ((Batch2D *)b)->source_ = is_item ? PixelSource::ItemTile(id, seq) : PixelSource::EntityTile(id, seq);
+}
 void rxh_batch2d_set_receives_light(void *b, int v) { ((Batch2D *)b)->receives_light_ = v != 0; }
 void rxh_batch2d_set_shader(void *b, int shader) { ((Batch2D *)b)->shader_ = shader; }
 int rxh_scene_push_batch2d(void *s, void *b, int dynamic, int chunk) {
@@ -208,6 +215,19 @@ void rxh_assets_free(void *a) { delete (Assets *)a; }
 void rxh_assets_add_tile(void *a, const uint8_t *const *frames, const uint32_t *ws, const uint32_t *hs, uint32_t n) {
     Assets *as = (Assets *)a;
     as->tile_list.push_back(make_tile(frames, ws, hs, n));
+    as->generation = next_generation();
+}
+
+// assets.entity_tiles / item_tiles: makes `id` known (an entry without sequences) ...
+void rxh_assets_add_sequence_id(void *a, int is_item, uint32_t id) {
+    Assets *as = (Assets *)a;
+    (is_item ? as->item_tiles : as->entity_tiles)[id];
+    as->generation = next_generation();
+}
+// ... and appends one sequence tile to it (IndexMap insertion order = get_index order)
+void rxh_assets_add_sequence_tile(void *a, int is_item, uint32_t id, const uint8_t *const *frames, const uint32_t *ws, const uint32_t *hs, uint32_t n) {
+    Assets *as = (Assets *)a;
+    (is_item ? as->item_tiles : as->entity_tiles)[id].push_back(make_tile(frames, ws, hs, n));
     as->generation = next_generation();
 }
 

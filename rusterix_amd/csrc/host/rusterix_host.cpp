@@ -511,7 +511,26 @@ void tile_views(const std::vector<Tile> &tiles, std::vector<rxr_texture> &texs, 
     }
 }
 
-rxr_batch3d view3d(const Batch3D &b, uint32_t list, int chunk) {
+// EntityTile(id, index) / ItemTile(id, index) -> what the device gets: the tile's slot among the dynamic tiles, or
+// RXR_SOURCE_MISSING where the reference's two lookups fail (rasterizer.rs:1140-1187, :705-748, :1548-1595)
+struct SequenceSlots {
+    std::map<std::pair<uint32_t, uint32_t>, uint32_t> entity, item;
+    rxr_source resolve(const PixelSource &p) const {
+        rxr_source o{};
+        o.kind = p.kind;
+        o.index = p.index;
+        memcpy(o.pixel, p.pixel, 4);
+        if (p.kind == RXR_HOST_SOURCE_ENTITY_TILE || p.kind == RXR_HOST_SOURCE_ITEM_TILE) {
+            const auto &m = p.kind == RXR_HOST_SOURCE_ENTITY_TILE ? entity : item;
+            const auto it = m.find({p.index, p.seq});
+            o.kind = it == m.end() ? (uint32_t)RXR_SOURCE_MISSING : (uint32_t)RXR_SOURCE_DYNAMIC_TILE;
+            o.index = it == m.end() ? 0u : it->second;
+        }
+        return o;
+    }
+};
+
+rxr_batch3d view3d(const Batch3D &b, uint32_t list, int chunk, const SequenceSlots &slots) {
     rxr_batch3d o{};
     o.projected_vertices = b.projected_vertices.data();
     o.clipped_uvs = b.clipped_uvs.data();
@@ -524,9 +543,7 @@ rxr_batch3d view3d(const Batch3D &b, uint32_t list, int chunk) {
     o.bounding_box[0] = b.bounding_box.x; o.bounding_box[1] = b.bounding_box.y;
     o.bounding_box[2] = b.bounding_box.width; o.bounding_box[3] = b.bounding_box.height;
     o.repeat_mode = b.repeat_mode_;
-    o.source.kind = b.source_.kind;
-    o.source.index = b.source_.index;
-    memcpy(o.source.pixel, b.source_.pixel, 4);
+    o.source = slots.resolve(b.source_);
     o.ambient_color[0] = b.ambient_color_.x; o.ambient_color[1] = b.ambient_color_.y; o.ambient_color[2] = b.ambient_color_.z;
     o.shader = b.shader_;
     o.has_profile_id = b.has_profile_id ? 1u : 0u;
@@ -536,7 +553,7 @@ rxr_batch3d view3d(const Batch3D &b, uint32_t list, int chunk) {
     return o;
 }
 
-rxr_batch2d view2d(const Batch2D &b, int chunk) {
+rxr_batch2d view2d(const Batch2D &b, int chunk, const SequenceSlots &slots) {
     rxr_batch2d o{};
     o.projected_vertices = b.projected_vertices.data();
     o.uvs = b.uvs.data();
@@ -549,9 +566,7 @@ rxr_batch2d view2d(const Batch2D &b, int chunk) {
     o.bounding_box[2] = b.bounding_box.width; o.bounding_box[3] = b.bounding_box.height;
     o.mode = b.mode_;
     o.repeat_mode = b.repeat_mode_;
-    o.source.kind = b.source_.kind;
-    o.source.index = b.source_.index;
-    memcpy(o.source.pixel, b.source_.pixel, 4);
+    o.source = slots.resolve(b.source_);
     o.receives_light = b.receives_light_ ? 1u : 0u;
     o.shader = b.shader_;
     o.chunk = chunk;
@@ -580,12 +595,35 @@ int Rasterizer::upload(Scene &scene, size_t w, size_t h, size_t tile_size, const
     for (const Chunk &c : scene.chunks)  // :219-223
         for (const CompiledLight &l : c.lights) scene.dynamic_lights.push_back(l);
 
+    // the dynamic tiles the device sees: scene.dynamic_textures, then every sequence tile of assets.entity_tiles and
+    // assets.item_tiles (ids ascending, sequences in insertion order); EntityTile / ItemTile sources are resolved to these slots
+    SequenceSlots slots;
+    std::vector<const Tile *> dyn_tiles;
+    for (const Tile &t : scene.dynamic_textures) dyn_tiles.push_back(&t);
+    for (int pass = 0; pass < 2; ++pass)
+        for (const auto &kv : pass == 0 ? assets.entity_tiles : assets.item_tiles)
+            for (size_t k = 0; k < kv.second.size(); ++k) {
+                (pass == 0 ? slots.entity : slots.item)[{kv.first, (uint32_t)k}] = (uint32_t)dyn_tiles.size();
+                dyn_tiles.push_back(&kv.second[k]);
+            }
+
     // textures: re-upload only when the asset set changed
     if (g_tex_static_gen != assets.generation || g_tex_dynamic_gen != scene.dynamic_textures_generation) {
         std::vector<rxr_texture> ts, td;
         std::vector<rxr_tile> tiles_s, tiles_d;
         tile_views(assets.tile_list, ts, tiles_s);
-        tile_views(scene.dynamic_textures, td, tiles_d);
+        {
+            size_t n = 0;
+            for (const Tile *t : dyn_tiles) n += t->textures.size();
+            td.reserve(n);
+            for (const Tile *t : dyn_tiles) {
+                rxr_tile rt{};
+                rt.textures = td.data() + td.size();
+                rt.n_textures = (uint32_t)t->textures.size();
+                for (const Texture &x : t->textures) td.push_back(rxr_texture{x.data.data(), x.width, x.height});
+                tiles_d.push_back(rt);
+            }
+        }
         int rc = rxr_set_textures(ctx, tiles_s.data(), (uint32_t)tiles_s.size(), tiles_d.data(), (uint32_t)tiles_d.size());
         if (rc != RXR_OK) {
             g_error = rxr_last_error(ctx);
@@ -646,11 +684,11 @@ int Rasterizer::upload(Scene &scene, size_t w, size_t h, size_t tile_size, const
     std::vector<rxr_texture> chunk_terrain_textures(scene.chunks.size());
     for (size_t c = 0; c < scene.chunks.size(); ++c) {
         const Chunk &ch = scene.chunks[c];
-        for (const Batch3D &b : ch.batches3d_opacity) b3.push_back(view3d(b, RXR_LIST_CHUNK_OPACITY, (int)c));
-        for (const Batch3D &b : ch.batches3d) b3.push_back(view3d(b, RXR_LIST_CHUNK, (int)c));
-        for (const Batch3D &b : ch.terrain_batch3d) b3.push_back(view3d(b, RXR_LIST_CHUNK_TERRAIN, (int)c));  // :343-356
-        for (const Batch2D &b : ch.batches2d) b2.push_back(view2d(b, (int)c));
-        for (const Batch2D &b : ch.terrain_batch2d) b2.push_back(view2d(b, (int)c));  // :515-525
+        for (const Batch3D &b : ch.batches3d_opacity) b3.push_back(view3d(b, RXR_LIST_CHUNK_OPACITY, (int)c, slots));
+        for (const Batch3D &b : ch.batches3d) b3.push_back(view3d(b, RXR_LIST_CHUNK, (int)c, slots));
+        for (const Batch3D &b : ch.terrain_batch3d) b3.push_back(view3d(b, RXR_LIST_CHUNK_TERRAIN, (int)c, slots));  // :343-356
+        for (const Batch2D &b : ch.batches2d) b2.push_back(view2d(b, (int)c, slots));
+        for (const Batch2D &b : ch.terrain_batch2d) b2.push_back(view2d(b, (int)c, slots));  // :515-525
         rxr_chunk rc{};
         rc.occluders = ch.occluded_sectors.data();
         rc.n_occluders = (uint32_t)ch.occluded_sectors.size();
@@ -671,9 +709,9 @@ int Rasterizer::upload(Scene &scene, size_t w, size_t h, size_t tile_size, const
         rc.size = ch.size;
         chunks.push_back(rc);
     }
-    for (const Batch3D &b : scene.d3_static) b3.push_back(view3d(b, RXR_LIST_STATIC, -1));
-    for (const Batch3D &b : scene.d3_dynamic) b3.push_back(view3d(b, RXR_LIST_DYNAMIC, -1));
-    for (const Batch3D &b : scene.d3_overlay) b3.push_back(view3d(b, RXR_LIST_OVERLAY, -1));
+    for (const Batch3D &b : scene.d3_static) b3.push_back(view3d(b, RXR_LIST_STATIC, -1, slots));
+    for (const Batch3D &b : scene.d3_dynamic) b3.push_back(view3d(b, RXR_LIST_DYNAMIC, -1, slots));
+    for (const Batch3D &b : scene.d3_overlay) b3.push_back(view3d(b, RXR_LIST_OVERLAY, -1, slots));
 
     // device-side projection: the same batches in the same order, as object-space meshes
     std::vector<rxr_mesh3d> meshes;
@@ -696,9 +734,7 @@ int Rasterizer::upload(Scene &scene, size_t w, size_t h, size_t tile_size, const
             memcpy(m.transform_3d, b.transform_3d.m, 64);
             m.cull_mode = (uint32_t)b.cull_mode_;
             m.repeat_mode = b.repeat_mode_;
-            m.source.kind = b.source_.kind;
-            m.source.index = b.source_.index;
-            memcpy(m.source.pixel, b.source_.pixel, 4);
+            m.source = slots.resolve(b.source_);
             m.ambient_color[0] = b.ambient_color_.x; m.ambient_color[1] = b.ambient_color_.y; m.ambient_color[2] = b.ambient_color_.z;
             m.shader = b.shader_;
             m.has_profile_id = b.has_profile_id ? 1u : 0u;
@@ -740,8 +776,8 @@ int Rasterizer::upload(Scene &scene, size_t w, size_t h, size_t tile_size, const
         }
         b3.clear();
     }
-    for (const Batch2D &b : scene.d2_static) b2.push_back(view2d(b, -1));
-    for (const Batch2D &b : scene.d2_dynamic) b2.push_back(view2d(b, -1));
+    for (const Batch2D &b : scene.d2_static) b2.push_back(view2d(b, -1, slots));
+    for (const Batch2D &b : scene.d2_dynamic) b2.push_back(view2d(b, -1, slots));
 
     std::vector<rxr_light> lights(scene.lights);
     lights.insert(lights.end(), scene.dynamic_lights.begin(), scene.dynamic_lights.end());

@@ -13,6 +13,7 @@
 // All citations are file:line under /root/reference/.
 #pragma once
 #include <cstdint>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -33,9 +34,12 @@ enum class CullMode { Off = 0, Front = 1, Back = 2 };  // src/batch/mod.rs:17-26
 
 // src/map/pixelsource.rs:23-37
 struct PixelSource {
-    uint32_t kind = RXR_SOURCE_OTHER;
+    uint32_t kind = RXR_SOURCE_OTHER;  // RXR_SOURCE_*, or RXR_HOST_SOURCE_ENTITY_TILE / _ITEM_TILE (index = id, seq = sequence index)
     uint32_t index = 0;
     uint8_t pixel[4] = {0, 0, 0, 0};
+    uint32_t seq = 0;
+    static PixelSource EntityTile(uint32_t id, uint32_t index) { PixelSource s; s.kind = RXR_HOST_SOURCE_ENTITY_TILE; s.index = id; s.seq = index; return s; }
+    static PixelSource ItemTile(uint32_t id, uint32_t index) { PixelSource s; s.kind = RXR_HOST_SOURCE_ITEM_TILE; s.index = id; s.seq = index; return s; }
     static PixelSource Off() { return {}; }
     static PixelSource StaticTileIndex(uint16_t i) { PixelSource s; s.kind = RXR_SOURCE_STATIC_TILE; s.index = i; return s; }
     static PixelSource DynamicTileIndex(uint16_t i) { PixelSource s; s.kind = RXR_SOURCE_DYNAMIC_TILE; s.index = i; return s; }
@@ -61,6 +65,10 @@ struct Pattern {
 
 struct Assets {
     std::vector<Tile> tile_list;
+    // src/server/assets.rs:28, :34 (FxHashMap<u32, IndexMap<String, Tile>>): id -> sequence tiles in insertion order, which is all
+    // the raster loops use (`.get(&id)`, `.get_index(i)`, rasterizer.rs:1140-1187).  Rasterizer::upload resolves
+    // EntityTile / ItemTile sources against these and ships the tiles with the dynamic textures.
+    std::map<uint32_t, std::vector<Tile>> entity_tiles, item_tiles;
     uint64_t generation = next_generation();  // re-stamped on every mutation; lets the rasterizer skip texture re-uploads
     Assets &textures(std::vector<Tile> tiles) { tile_list = std::move(tiles); generation = next_generation(); return *this; }
     // what a Rusteria program reads besides its own code: assets.palette (ThePalette.colors) and rusteria's

@@ -497,6 +497,8 @@ static int resolve_source(rxr_ctx *ctx, const rxr_source &src, bool is_3d, int c
         case RXR_SOURCE_DYNAMIC_TILE: return from_tiles(ctx->tiles_dynamic);
         case RXR_SOURCE_PIXEL: pixel = pack_px(src.pixel); return RXR_OK;
         case RXR_SOURCE_MISSING: pixel = 0; return RXR_OK;
+        case RXR_HOST_SOURCE_ENTITY_TILE:
+        case RXR_HOST_SOURCE_ITEM_TILE: return RXR_ERR_INVALID;  // host-side variants: the host resolves them (include/rxr.h)
         case RXR_SOURCE_TERRAIN:
             if (chunk >= 0) pixel = 0;                       // chunk without a terrain texture, chunk.rs:150
             else pixel = is_3d ? 0xFF0000FFu : 0u;           // [255,0,0,255] (:1218) | [0,0,0,0] (:753)

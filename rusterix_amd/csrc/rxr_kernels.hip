@@ -1297,7 +1297,7 @@ __device__ __forceinline__ void front_init(Vis &v) {
     }
 }
 // inserts fragment (z, id, prof) arriving in arbitrary order
-__device__ __forceinline__ void front_insert(Vis &v, float z, int id, int prof, int batch) {
+__device__ __forceinline__ void front_insert(Vis &v, float z, int id, int prof, int batch, uint32_t *overflow_flag) {
     if (!(z < 1.0f)) return;  // z_buffer_opacity starts at 1.0 (:283): never written
     bool dominated = false;
 #pragma unroll
@@ -1319,10 +1319,12 @@ __device__ __forceinline__ void front_insert(Vis &v, float z, int id, int prof, 
             done = true;
         }
     if (done) return;
-    // take a free slot; if all three are taken drop the entry with the smallest index (only matters when four or more
-    // opacity batches nest as prefix minima in one pixel)
+    // take a free slot; if all three are taken drop the entry with the smallest index (only happens when four or more
+    // opacity batches nest as prefix minima in one pixel).  The drop is reported: rxr_synchronize returns RXR_ERR_UNSUPPORTED
+    // for the frame (pinned host word; the store is this rare path's only cost)
     int slot = v.fid[0] < 0 ? 0 : (v.fid[1] < 0 ? 1 : (v.fid[2] < 0 ? 2 : -1));
     if (slot < 0) {
+        *overflow_flag = 1u;
         slot = (v.fid[0] < v.fid[1]) ? (v.fid[0] < v.fid[2] ? 0 : 2) : (v.fid[1] < v.fid[2] ? 1 : 2);
         // (selects, not v.fid[slot]: a run-time index would put the whole staircase -- and with it the opacity winner that every
         // pixel reads in the resolve step -- into scratch memory)
@@ -1412,7 +1414,7 @@ __device__ __forceinline__ void visit(const RasterParams &P, const TriSetup &S, 
     float gamma = 1.0f - alpha - beta;
     float one_over_z = S.iz0 * alpha + S.iz1 * beta + S.iz2 * gamma;
     float z = 1.0f / one_over_z;
-    if constexpr (OPACITY && X >= 1) front_insert(vis, z, (int)t, (S.bflags & DB_HAS_PROFILE) ? (int)S.profile_id : -1, (int)S.batch);
+    if constexpr (OPACITY && X >= 1) front_insert(vis, z, (int)t, (S.bflags & DB_HAS_PROFILE) ? (int)S.profile_id : -1, (int)S.batch, P.staircase_overflow);
     bool take = z < vis.zmin || (z == vis.zmin && vis.best >= 0 && (int)t < vis.best);
     if (take) {
         if (X >= 1 && !OPACITY && (S.bflags & DB_FULL_ALPHA)) {  // frames with such batches run k_raster_chunk / k_raster_vm (RasterParams.kernel_level)

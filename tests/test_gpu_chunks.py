@@ -239,6 +239,48 @@ def test_surface_id_order_matters_in_this_scene(oracle):
     assert (a != b).any(axis=2).mean() > 0.01, "the scene is meant to expose the order dependence"
 
 
+def nested_windows_scene(api, k):
+    """k windows seen in a row, each in its own chunk, submitted FAR -> NEAR: every pane is nearer than all panes submitted before
+    it, so every one of them is a prefix minimum of its pixels (the "staircase" of rxr_kernels.hip front_insert has k steps).  Each
+    chunk's wall carries its pane's profile id and is tested against the opacity winner of the chunks processed so far
+    (rasterizer.rs:314-357, :1044-1048)."""
+    scene = api.Scene.empty()
+    for i in range(k):
+        z = -1.5 + 3.0 * i / max(1, k - 1)  # far ... near (the camera looks down -z from z = +4.5)
+        pane = api.Batch3D.from_box(-0.6, -0.6, z, 1.2, 1.2, 0.02).with_computed_normals().source(B.PixelSource.Pixel((90, 120, 250, 120))).profile_id(10 + i)
+        wall = api.Batch3D.from_box(-1.5, -1.0, z - 0.2, 3.0, 2.0, 0.05).with_computed_normals().source(B.PixelSource.Pixel((40 + 50 * i, 200 - 40 * i, 60, 255)))
+        wall.profile_id(10 + i)
+        chunk = scene.add_chunk()
+        chunk.add_batch3d_opacity(pane)
+        chunk.add_batch3d(wall)
+    scene.add_d3_static(api.Batch3D.from_box(-3.0, -3.0, -3.0, 6.0, 6.0, 0.1).with_computed_normals().source(B.PixelSource.Pixel((30, 220, 60, 255))))
+    cam = api.D3OrbitCamera.new()
+    cam.set_parameter_f32("distance", 4.5)
+    cam.azimuth = float(np.float32(np.pi / 2))
+    cam.elevation = 0.0
+
+    def setup():
+        v, p = cam.matrices(float(W), float(H))
+        return api.Rasterizer.setup(None, v, p).ambient((1.0, 1.0, 1.0, 1.0))
+
+    return scenes._result(api, scene, api.Assets.default(), setup, W, H, 40, f"{k}-nested-windows")
+
+
+def test_three_nested_opacity_batches_are_exact(oracle, product):
+    compare(oracle, product, lambda api: nested_windows_scene(api, 3))
+
+
+def test_four_nested_opacity_batches_are_refused_loudly(oracle, product):
+    """the device keeps three prefix minima per pixel; a fourth used to be dropped silently.  Now the
+    frame fails with RXR_ERR_UNSUPPORTED, so that a caller can take the CPU path for it."""
+    scenes.render(nested_windows_scene(oracle, 4))  # the reference algorithm has no such limit
+    with pytest.raises(B.RasterizeError) as e:
+        scenes.render(nested_windows_scene(product, 4))
+    assert e.value.code == B.RXR_ERR_UNSUPPORTED and "opacity batches nest" in str(e.value)
+    # the context is usable afterwards
+    compare(oracle, product, lambda api: nested_windows_scene(api, 2))
+
+
 def wall_before_the_pane_scene(api, pane_first):
     """ONE opacity pane (profile 7), in the second chunk, in front of a wall with the same profile id that lives in the FIRST
     chunk: the wall is drawn before any opacity batch has run, so it must not be skipped behind the pane (surface_id is still
