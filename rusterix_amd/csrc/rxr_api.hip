@@ -69,7 +69,13 @@ int rxr_ensure(rxr_ctx *ctx, DevBuf &b, size_t bytes) {
 
 // Execution fields whose lanes the raster loops do not (all) assign before each call (rasterizer.rs:773-785, :1259-1298,
 // :1637-1662): a read sees what an EARLIER fragment's program left there unless this invocation wrote the field first
-enum : uint32_t { PF_UV = 1, PF_ROUGHNESS = 2, PF_METALLIC = 4, PF_OPACITY = 8, PF_BUMP = 16, PF_NORMAL = 32, PF_HITPOINT = 64 };
+enum : uint32_t { PF_UV = 1, PF_ROUGHNESS = 2, PF_METALLIC = 4, PF_OPACITY = 8, PF_BUMP = 16, PF_NORMAL = 32, PF_HITPOINT = 64, PF_EMISSIVE = 128 };
+// DevProgram.flags
+enum : uint32_t {
+    PG_WRITES_OPACITY = 1,     // contains SetOpacity: an opaque-pass batch running it needs the program in the visibility loop
+    PG_WRITES_EMISSIVE = 2,    // contains SetEmissive (anywhere, callees included)
+    PG_ASSIGNS_EMISSIVE = 4,   // `shade` executes a SetEmissive on EVERY path to its end (definite assignment, see PurityCheck)
+};
 
 namespace {
 
@@ -540,6 +546,9 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
     bool uses_programs = false, uses_chunk_tex = false;
     bool vis_programs = false;  // an opaque-pass batch whose program may write `opacity`: the visibility loop has to run it (DB_FULL_ALPHA)
     bool any_3d_visible = false, any_3d_program = false;
+    // emissive (rasterizer.rs:1323, :1394): see the check behind the 3D batches below
+    bool emissive_writer_3d = false;        // a visible 3D batch (either pass) runs a program that contains SetEmissive
+    bool opaque_without_emissive = false;   // a visible opaque-pass 3D batch whose fragments do NOT assign emissive themselves
     uint32_t reads_2d = 0;  // PF_* read-before-written by the programs of visible 2D batches
     int32_t first_opacity_chunk = -1;  // opacity batches in two or more chunks: surface_id needs the exact prefix order (level 1)
     bool seen_profiled_opaque = false; // ... and so does an opacity batch submitted AFTER an opaque batch that carries a profile id:
@@ -673,7 +682,9 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
             d.program_plus1 = 0;
         }
         bool prog_runs = d.program_plus1 && ctx->programs[d.program_plus1 - 1].shade_entry != 0xFFFFFFFFu;
-        const bool prog_opacity = prog_runs && (ctx->programs[d.program_plus1 - 1].flags & 1u);
+        const bool prog_opacity = prog_runs && (ctx->programs[d.program_plus1 - 1].flags & PG_WRITES_OPACITY);
+        if (keep && prog_runs && (ctx->programs[d.program_plus1 - 1].flags & PG_WRITES_EMISSIVE)) emissive_writer_3d = true;
+        if (keep && !opacity_list && !(prog_runs && (ctx->programs[d.program_plus1 - 1].flags & PG_ASSIGNS_EMISSIVE))) opaque_without_emissive = true;
         if (!prog_runs) d.program_plus1 = 0;
         if (prog_runs) d.flags |= DB_HAS_PROGRAM;
         if (!keep) return RXR_OK;
@@ -1072,6 +1083,15 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
         return fail(ctx, RXR_ERR_UNSUPPORTED, "a 2D batch's program reads normal / opacity, which in the reference hold whatever the tile's last 3D fragment left there");
     if (any_3d_program && (f->flags & RXR_FLAG_D3_ACTIVE) && (reads_2d & PF_HITPOINT))
         return fail(ctx, RXR_ERR_UNSUPPORTED, "a 2D batch's program reads hitpoint while 3D batches run programs: hitpoint.z would hold the tile's last 3D program fragment's");
+    // `emissive` is only ever written by SetEmissive and never reset by the raster loops: every opaque 3D fragment adds whatever
+    // the last SetEmissive executed in its TILE left behind (rasterizer.rs:310, :1323, :1394) -- a function of the tile size and of
+    // the traversal order, which a per-fragment evaluation cannot (and should not) reproduce.  A frame is accepted when that
+    // state cannot be observed: no program of a 3D batch on screen writes emissive, or EVERY opaque 3D batch on screen runs a
+    // program that assigns emissive itself on every path before the fragment reads it.
+    if (emissive_writer_3d && opaque_without_emissive && (f->flags & RXR_FLAG_D3_ACTIVE))
+        return fail(ctx, RXR_ERR_UNSUPPORTED,
+                    "a 3D batch's program writes emissive while another opaque 3D batch of the frame does not assign it on every path: in the "
+                    "reference that batch's fragments would add the emissive of whichever fragment ran before them in the tile");
     ctx->frame_uses_programs = uses_programs;
     P.vm_code = (const uint32_t *)ctx->d_vm_code.p;
     // (the brush preview and the grid background are editor-only: they live in the feature levels >= 1 so that k_raster does not
@@ -1561,7 +1581,7 @@ struct Flattener {
     std::vector<std::pair<size_t, uint32_t>> call_patches;  // (position of the target word, function index)
     std::vector<size_t> return_patches;                     // positions to fill with the current function's ENDFN address
     uint32_t n_functions = 0;
-    bool writes_opacity = false;
+    bool writes_opacity = false, writes_emissive = false;
     std::string err;
     int status = RXR_OK;
 
@@ -1720,7 +1740,12 @@ struct Flattener {
                 case RXR_NODE_SAVE:
                     return bad(RXR_ERR_UNSUPPORTED, "Alloc / Iterate / Save (texture baking) are not part of per-fragment shading");
                 case RXR_NODE_SET_EMISSIVE:
-                    return bad(RXR_ERR_UNSUPPORTED, "SetEmissive: the reference leaks emissive into every later fragment of its tile");
+                    // `emissive` is never reset by the raster loops: every opaque 3D fragment adds whatever the LAST SetEmissive
+                    // of its tile left (rasterizer.rs:1323, :1394).  Whether a frame can run such a program without that leak
+                    // is decided per frame (rxr_upload_frame: every visible opaque 3D batch must assign it itself)
+                    writes_emissive = true;
+                    code.push_back(op);
+                    break;
                 case RXR_NODE_SET_OPACITY:
                     writes_opacity = true;
                     code.push_back(op);
@@ -1751,6 +1776,7 @@ struct PurityCheck {
     bool ok = true;
     uint32_t reads_unassigned = 0;  // PF_* read before this invocation wrote them
     uint32_t writes = 0;            // PF_* written anywhere in the program
+    uint32_t exit_fields = ~0u;     // PF_* assigned at EVERY `Return` of shade itself (a Return leaves before the code behind it)
     std::vector<char> visiting;
 
     explicit PurityCheck(const rxr_program &prog) : p(prog), visiting(prog.n_functions, 0) {}
@@ -1784,6 +1810,11 @@ struct PurityCheck {
                 case RXR_NODE_BUMP: reads_unassigned |= PF_BUMP & ~a.fields; break;
                 case RXR_NODE_NORMAL: reads_unassigned |= PF_NORMAL & ~a.fields; break;
                 case RXR_NODE_HITPOINT: reads_unassigned |= PF_HITPOINT; break;
+                case RXR_NODE_EMISSIVE: reads_unassigned |= PF_EMISSIVE & ~a.fields; break;
+                case RXR_NODE_SET_EMISSIVE: a.fields |= PF_EMISSIVE; writes |= PF_EMISSIVE; break;
+                case RXR_NODE_RETURN:
+                    if (in_shade) exit_fields &= a.fields;
+                    break;
                 case RXR_NODE_SET_UV: a.fields |= PF_UV; writes |= PF_UV; break;
                 case RXR_NODE_SET_ROUGHNESS: a.fields |= PF_ROUGHNESS; writes |= PF_ROUGHNESS; break;
                 case RXR_NODE_SET_METALLIC: a.fields |= PF_METALLIC; writes |= PF_METALLIC; break;
@@ -1835,14 +1866,16 @@ struct PurityCheck {
     }
 };
 
-bool program_is_pure(const rxr_program &p, uint32_t &reads_unassigned, uint32_t &writes) {
-    reads_unassigned = writes = 0;
+// `assigned_at_exit`: the PF_* fields that `shade` has written itself on every path to its end (its last instruction or a Return)
+bool program_is_pure(const rxr_program &p, uint32_t &reads_unassigned, uint32_t &writes, uint32_t &assigned_at_exit) {
+    reads_unassigned = writes = assigned_at_exit = 0;
     if (p.shade_index < 0 || (uint32_t)p.shade_index >= p.n_functions) return true;
     PurityCheck c(p);
     c.visiting[p.shade_index] = 1;
-    (void)c.block(p.functions[p.shade_index].words, p.functions[p.shade_index].n_words, Assigned{}, true, 0);
+    const Assigned end = c.block(p.functions[p.shade_index].words, p.functions[p.shade_index].n_words, Assigned{}, true, 0);
     reads_unassigned = c.reads_unassigned;
     writes = c.writes;
+    assigned_at_exit = end.fields & c.exit_fields;
     return c.ok;
 }
 
@@ -1870,7 +1903,7 @@ int flatten_programs(const rxr_shader_set *set, std::vector<uint32_t> &code, std
         d.shade_entry = 0xFFFFFFFFu;
         d.shade_locals = p.shade_locals;
         d.n_globals = p.n_globals;
-        uint32_t ru = 0, wr = 0;
+        uint32_t ru = 0, wr = 0, at_exit = 0;
         if (p.shade_index >= 0) {
             if ((uint32_t)p.shade_index >= p.n_functions)  // program.user_functions[index] would panic on the first fragment
                 return bad(RXR_ERR_INVALID, "shade_index out of range");
@@ -1878,7 +1911,7 @@ int flatten_programs(const rxr_shader_set *set, std::vector<uint32_t> &code, std
             if (p.shade_locals > RXR_VM_LOCALS) return bad(RXR_ERR_UNSUPPORTED, "more locals than the device VM holds");
             // structural check first (lengths), so that the purity walk below cannot run off the arrays
             fl.n_functions = p.n_functions;
-            fl.writes_opacity = false;
+            fl.writes_opacity = fl.writes_emissive = false;
             fl.call_patches.clear();
             std::vector<uint32_t> entries(p.n_functions);
             for (uint32_t k = 0; k < p.n_functions; ++k) {
@@ -1890,11 +1923,12 @@ int flatten_programs(const rxr_shader_set *set, std::vector<uint32_t> &code, std
                 for (size_t pos : fl.return_patches) fl.code[pos] = endfn;
             }
             for (auto &cp : fl.call_patches) fl.code[cp.first] = entries[cp.second];
-            if (!program_is_pure(p, ru, wr))
+            if (!program_is_pure(p, ru, wr, at_exit))
                 return bad(RXR_ERR_UNSUPPORTED, "a local of `shade` or a global is read before this invocation wrote it (the reference would read the previous fragment's value)");
             field_writes |= wr;
             d.shade_entry = entries[p.shade_index];
-            d.flags = fl.writes_opacity ? 1u : 0u;
+            d.flags = (fl.writes_opacity ? PG_WRITES_OPACITY : 0u) | (fl.writes_emissive ? PG_WRITES_EMISSIVE : 0u) |
+                      ((at_exit & PF_EMISSIVE) ? PG_ASSIGNS_EMISSIVE : 0u);
         }
         field_reads.push_back(ru);
         progs.push_back(d);
@@ -1902,8 +1936,8 @@ int flatten_programs(const rxr_shader_set *set, std::vector<uint32_t> &code, std
     // uv.z, roughness.yz, metallic.yz, opacity.yz and bump are never assigned by the raster loops: once ANY program of the
     // set writes such a field, a read that its own invocation has not preceded by a write would see an earlier fragment's lanes
     for (uint32_t m : field_reads)
-        if (m & field_writes & (PF_UV | PF_ROUGHNESS | PF_METALLIC | PF_OPACITY | PF_BUMP))
-            return bad(RXR_ERR_UNSUPPORTED, "a program reads uv / roughness / metallic / opacity / bump before writing it while a program of the set writes that field (lanes the raster loops never reset would leak between fragments)");
+        if (m & field_writes & (PF_UV | PF_ROUGHNESS | PF_METALLIC | PF_OPACITY | PF_BUMP | PF_EMISSIVE))
+            return bad(RXR_ERR_UNSUPPORTED, "a program reads uv / roughness / metallic / opacity / bump / emissive before writing it while a program of the set writes that field (lanes the raster loops never reset would leak between fragments)");
     for (int k = 0; k < 4; ++k) fl.code.push_back(VM_ENDFN);  // the interpreter reads one word ahead of every opcode
     if (fl.code.size() >= (1ull << 31)) return bad(RXR_ERR_INVALID, "programs too large");
     code = std::move(fl.code);
@@ -1964,7 +1998,7 @@ static bool tag_static_depths(std::vector<uint32_t> &code, const std::vector<Dev
                         room = true; delta = 1; break;
                     case RXR_NODE_STORE_GLOBAL: case RXR_NODE_STORE_LOCAL: case RXR_NODE_PRINT:
                     case RXR_NODE_SET_UV: case RXR_NODE_SET_NORMAL: case RXR_NODE_SET_COLOR: case RXR_NODE_SET_ROUGHNESS:
-                    case RXR_NODE_SET_METALLIC: case RXR_NODE_SET_OPACITY: case RXR_NODE_SET_BUMP:
+                    case RXR_NODE_SET_METALLIC: case RXR_NODE_SET_OPACITY: case RXR_NODE_SET_BUMP: case RXR_NODE_SET_EMISSIVE:
                     case VM_JZ: case VM_FOR_COND:
                         need = 1; delta = -1; break;
                     case RXR_NODE_SWAP: need = 2; break;

@@ -473,6 +473,8 @@ struct Frag {
     f3 world, normal, view_dir, base, lit;
     float opacity;
     float rough, metal;  // mat_roughness / mat_metallic (:1321-1322): 0.5 / 0 unless a program ran
+    f3 emis;             // mat_emissive (:1323): what THIS fragment's program assigned (feature levels >= 2; frames in which a
+                         // fragment could see another fragment's emissive are refused by rxr_upload_frame), else 0
 };
 
 // everything before the light loop: uv, world position, normal, texel, ambient terms (:1062-1370)
@@ -540,6 +542,7 @@ __device__ __forceinline__ void shade3d_begin(const RasterParams &P, const TriSh
             rough = rclamp(io.roughness.x, 0.0f, 1.0f);
             metal = rclamp(io.metallic.x, 0.0f, 1.0f);
             F.opacity = io.opacity.x;  // :1403
+            F.emis = mk3(io.emissive.x, io.emissive.y, io.emissive.z);  // :1323
         }
     }
 
@@ -669,10 +672,14 @@ __device__ __forceinline__ void shade3d_lights(const RasterParams &P, bool hit, 
     }
 }
 
-// encode (:1394-1404); + mat_emissive is + 0
+// encode (:1394-1404).  `lit += mat_emissive` (:1394): below feature level 2 no program runs and emissive is 0 -- adding it cannot
+// change the encoded byte (x + 0 == x except -0 + 0 == +0, and both encode to 0)
+template <int X>
 __device__ __forceinline__ uint32_t shade3d_end(const Frag &F) {
-    return pack4(f32_to_u8_saturated(linear_to_srgb_fast(F.lit.x)), f32_to_u8_saturated(linear_to_srgb_fast(F.lit.y)),
-                 f32_to_u8_saturated(linear_to_srgb_fast(F.lit.z)), f32_to_u8_saturated(F.opacity));
+    f3 lit = F.lit;
+    if constexpr (X >= 2) lit = add3(lit, F.emis);
+    return pack4(f32_to_u8_saturated(linear_to_srgb_fast(lit.x)), f32_to_u8_saturated(linear_to_srgb_fast(lit.y)),
+                 f32_to_u8_saturated(linear_to_srgb_fast(lit.z)), f32_to_u8_saturated(F.opacity));
 }
 
 // the covered-fragment block of d3_rasterize_opacity (rasterizer.rs:1497-1682, no shader)
@@ -2049,7 +2056,7 @@ __device__ __forceinline__ void raster_tile(const RasterParams &P) {
         // resolve (rasterizer.rs:409-497): hit -> shaded colour; miss -> [0,0,0,255]
         const bool hit = vis.best >= 0;
         Frag F;
-        F.world = F.normal = F.view_dir = F.base = F.lit = mk3(0.0f, 0.0f, 0.0f);
+        F.world = F.normal = F.view_dir = F.base = F.lit = F.emis = mk3(0.0f, 0.0f, 0.0f);
         F.opacity = 0.0f;
         F.rough = 0.5f;
         F.metal = 0.0f;
@@ -2061,7 +2068,7 @@ __device__ __forceinline__ void raster_tile(const RasterParams &P) {
         PHASE_MARK(2);
         if (P.n_lights) shade3d_lights<X>(P, hit, F);  // wave-uniform call
         PHASE_MARK(3);
-        color = hit ? shade3d_end(F) : pack4(0u, 0u, 0u, 255u);
+        color = hit ? shade3d_end<X>(F) : pack4(0u, 0u, 0u, 255u);
         if constexpr (X >= 1) {
             if (P.has_brush && !hit) color = miss_brush_preview(P, px, py);  // :435-458
         }

@@ -708,6 +708,7 @@ __device__ __forceinline__ uint32_t shade_inline(const RasterParams &P, uint32_t
             case RXR_NODE_METALLIC: VM_GET(io.metallic)
             case RXR_NODE_SET_METALLIC: VM_SET(io.metallic)
             case RXR_NODE_EMISSIVE: VM_GET(io.emissive)
+            case RXR_NODE_SET_EMISSIVE: VM_SET(io.emissive)
             case RXR_NODE_OPACITY: VM_GET(io.opacity)
             case RXR_NODE_SET_OPACITY: VM_SET(io.opacity)
             case RXR_NODE_BUMP: VM_GET(io.bump)

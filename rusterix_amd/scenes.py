@@ -16,6 +16,7 @@ The scene drivers model reference callers:
 from __future__ import annotations
 
 import math
+import os
 import types
 
 import numpy as np
@@ -164,12 +165,28 @@ def cube_scene(api, width=800, height=600, tile_size=200, textured=False, distan
     return _result(api, scene, assets, setup, width, height, tile_size, "C1-cube")
 
 
-def teapot_scene(api, width=1920, height=1080, tile_size=60, obj_text=None, with_light=False, logo_size=1024, rect_size=200.0):
+TEAPOT_FIXTURE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "teapot_mesh.npz")
+
+
+def teapot_mesh():
+    """The arrays `Batch3D::from_obj` makes of the reference's examples/teapot.obj (1202 v / 2256 f; Utah teapot, mesh data only),
+    from the committed fixture (tests/golden/make_teapot_fixture.py); the stand-in of equal counts only if the fixture is absent.
+    Returns (vertices[n,4], indices[m,3], uvs[n,2], is_real)."""
+    if os.path.exists(TEAPOT_FIXTURE):
+        z = np.load(TEAPOT_FIXTURE)
+        pos = z["positions"].astype(np.float32)
+        v = np.concatenate([pos, np.ones((len(pos), 1), np.float32)], axis=1)
+        return v, z["indices"].astype(np.uint32), v[:, :2].copy(), True  # no `vt` in the file: uv = (x, y), src/wavefront.rs:92-95
+    return standin_teapot_mesh() + (False,)
+
+
+def teapot_scene(api, width=1920, height=1080, tile_size=60, obj_text=None, with_light=False, logo_size=1024, rect_size=200.0, standin=False):
     """C2: examples/obj.rs:28-83 with the point light dropped (BASELINE.json: "no lights")."""
+    real = True
     if obj_text is not None:
         mesh = api.Batch3D.from_obj(obj_text)
     else:
-        v, i, uv = standin_teapot_mesh()
+        v, i, uv, real = teapot_mesh() if not standin else standin_teapot_mesh() + (False,)
         mesh = api.Batch3D.new(v, i, uv)
     mesh = (mesh.source(B.PixelSource.StaticTileIndex(0)).repeat_mode(B.REPEAT_REPEAT_XY)
             .transform(B.Mat4.scaling_3d((0.35, -0.35, 0.35))).with_computed_normals())
@@ -186,7 +203,7 @@ def teapot_scene(api, width=1920, height=1080, tile_size=60, obj_text=None, with
         v, p = cam.matrices(float(width), float(height))
         return api.Rasterizer.setup(None, v, p).ambient((0.8, 0.8, 0.8, 0.8))
 
-    return _result(api, scene, assets, setup, width, height, tile_size, "C2-teapot")
+    return _result(api, scene, assets, setup, width, height, tile_size, "C2-teapot" if real else "C2-teapot-standin-mesh")
 
 
 def _quad_wall(x0, z0, x1, z1, h):

@@ -481,7 +481,7 @@ def test_million_triangle_grid_full_size_is_bit_exact(oracle, product, shader):
 
 
 @pytest.mark.parametrize("name, builder, kw, tol, max_differing", [
-    ("C2 teapot stand-in 1920x1080", scenes.teapot_scene, dict(width=1920, height=1080), 0, 0),
+    ("C2 teapot 1920x1080", scenes.teapot_scene, dict(width=1920, height=1080), 0, 0),
     ("C3 map 1920x1080, 1 light", scenes.map_scene, dict(width=1920, height=1080, n_lights=1), 1, 64),
     ("C4 map 3840x2160, 16 lights", scenes.map_scene, dict(width=3840, height=2160, n_lights=16), 1, 256),
 ])

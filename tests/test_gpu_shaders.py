@@ -209,7 +209,6 @@ def test_tile_size_does_not_matter_for_pure_programs(oracle):
 
 # ---- what the device refuses or reports --------------------------------------------------------------------
 @pytest.mark.parametrize("ops, why", [
-    ([("Push", 0.5), "SetEmissive"], "emissive leaks"),
     ([("LoadGlobal", 0), "SetColor"], "global read before written"),
     ([("LoadLocal", 0), "SetColor"], "stale local of the previous fragment"),
     (["UV", "SetColor", ("Push", 1.0, 2.0, 3.0), "SetUV"], "uv.z of the previous fragment"),
@@ -223,6 +222,87 @@ def test_unsupported_programs_are_refused(product, ops, why):
     with pytest.raises(B.RasterizeError) as e:
         scenes.render(cfg)
     assert e.value.code == B.RXR_ERR_UNSUPPORTED, why
+
+
+# ---- emissive (rasterizer.rs:1323, :1394): accepted where no fragment can see another fragment's value -----------------------
+EMISSIVE = ["UV", ("GetComponents", [0]), ("Push", 4.0), "Mul", ("Push", 0.3), "Mul", ("Push", 0.05), ("Push", 0.0), "Pack3", "SetEmissive"]
+
+
+def emissive_scene(api, programs, lights=True, opacity_pane=None):
+    """three boxes next to each other, box i running programs[i] (None: no program), over nothing: every 3D batch on screen
+    decides the frame's fate.  `opacity_pane`: a program for an opacity-pass pane in front of them."""
+    scene = api.Scene.empty()
+    for i, prog in enumerate(programs):
+        box = api.Batch3D.from_box(-1.7 + 1.15 * i, -0.5, -0.5, 1.0, 1.0, 1.0).cull_mode(B.CULL_OFF).with_computed_normals()
+        box.source(B.PixelSource.StaticTileIndex(0)).repeat_mode(B.REPEAT_REPEAT_XY)
+        if prog is not None:
+            box.shader(scene.add_program(prog))
+        scene.add_d3_static(box)
+    if opacity_pane is not None:
+        chunk = scene.add_chunk()
+        pane = api.Batch3D.from_box(-1.0, -0.2, 0.9, 2.0, 0.4, 0.02).with_computed_normals().source(B.PixelSource.Pixel((90, 120, 250, 120)))
+        pane.shader(scene.add_program(opacity_pane, chunk=chunk.index))
+        chunk.add_batch3d_opacity(pane)
+    if lights:
+        scene.lights([B.Light(B.LIGHT_POINT).with_position((1.5, 1.0, 2.0)).with_color((1.0, 0.95, 0.8)).with_intensity(2.0)
+                      .with_start_distance(1.0).with_end_distance(8.0).compile()])
+    assets = api.Assets.default().textures([B.Tile.from_texture(scenes.noise_texture(6, 32, 32))])
+    cam = api.D3OrbitCamera.new()
+    cam.set_parameter_f32("distance", 3.2)
+    cam.azimuth = float(np.float32(np.pi / 2))
+    cam.elevation = 0.35
+
+    def setup():
+        v, p = cam.matrices(float(W), float(H))
+        return api.Rasterizer.setup(None, v, p).ambient((0.3, 0.3, 0.35, 1.0))
+
+    return scenes._result(api, scene, assets, setup, W, H, 40, "emissive-boxes")
+
+
+GLOW = Program([EMISSIVE])
+GLOW_BOTH_BRANCHES = Program([["UV", ("GetComponents", [1]), ("Push", 0.1), "Lt",
+                               ("If", [("Push", 0.4, 0.1, 0.0), "SetEmissive"], [("Push", 0.0, 0.1, 0.5), "SetEmissive"]), "Color", ("Push", 0.5), "Mul", "SetColor"]])
+NO_GLOW_BUT_ASSIGNS = Program([[("Push", 0.0), "SetEmissive", "Color", "SetColor"]])
+
+
+@pytest.mark.parametrize("lights", [False, True])
+def test_emissive_when_every_opaque_batch_assigns_it(oracle, product, lights):
+    got = compare(oracle, product, lambda api: emissive_scene(api, [GLOW, GLOW_BOTH_BRANCHES, NO_GLOW_BUT_ASSIGNS], lights), tol=TOLERANCE if lights else 0)
+    plain = scenes.render(emissive_scene(product, [NO_GLOW_BUT_ASSIGNS] * 3, lights))
+    assert (got != plain).any(), "the emissive term left no trace"
+
+
+def test_emissive_frame_does_not_depend_on_the_tile_size(oracle):
+    """what makes the accepted case safe: with every opaque fragment assigning emissive itself, the reference's per-tile
+    Execution (rasterizer.rs:310) has nothing to leak -- unlike tests/test_oracle_vm.py's leaking scene"""
+    cfg = emissive_scene(oracle, [GLOW, GLOW_BOTH_BRANCHES, NO_GLOW_BUT_ASSIGNS])
+    a = scenes.render(cfg).copy()
+    for ts in (16, 200):
+        cfg.tile_size = ts
+        assert np.array_equal(a, scenes.render(cfg))
+
+
+def test_emissive_written_in_the_opacity_pass_is_harmless_when_the_opaque_batches_assign_theirs(oracle, product):
+    compare(oracle, product, lambda api: emissive_scene(api, [GLOW, NO_GLOW_BUT_ASSIGNS, GLOW], opacity_pane=GLOW), tol=TOLERANCE)
+
+
+@pytest.mark.parametrize("programs, pane, why", [
+    ([GLOW, None, GLOW], None, "a batch without a program would add its neighbour's emissive"),
+    ([GLOW, Program([["Color", "SetColor"]]), GLOW], None, "a program that never assigns emissive"),
+    ([GLOW, Program([["UV", ("GetComponents", [0]), ("Push", 0.1), "Lt", ("If", [("Push", 0.5), "SetEmissive"], None)]]), GLOW], None, "assigned on one path only"),
+    ([GLOW, Program([["UV", ("GetComponents", [0]), ("Push", 0.1), "Lt", ("If", ["Return"], None), ("Push", 0.5), "SetEmissive"]]), GLOW], None,
+     "a Return leaves before the assignment"),
+    ([None, None, None], GLOW, "an opacity-pass program leaks into the opaque batches behind it"),
+])
+def test_emissive_leaks_are_refused(product, programs, pane, why):
+    with pytest.raises(B.RasterizeError) as e:
+        scenes.render(emissive_scene(product, programs, opacity_pane=pane))
+    assert e.value.code == B.RXR_ERR_UNSUPPORTED and "emissive" in str(e.value), why
+
+
+def test_emissive_in_a_2d_program_is_accepted(oracle, product):
+    """the 2D pass runs after every 3D pass of the tile (rasterizer.rs:501) and nothing there reads emissive"""
+    compare(oracle, product, lambda api: rect_scene(api, Program([[("Push", 0.5), "SetEmissive", "Color", ("Push", 0.5), "Mul", "SetColor"]])))
 
 
 @pytest.mark.parametrize("ops, locals_", [

@@ -152,3 +152,23 @@ def test_real_teapot_counts():
     prod = rusterix_amd.load()
     b = prod.Batch3D.from_obj(open("/root/reference/examples/teapot.obj").read())
     assert b.counts() == (1202, 2256)
+
+
+def test_teapot_fixture_is_the_mesh_the_scenes_use():
+    """tests/golden/teapot_mesh.npz (made by tests/golden/make_teapot_fixture.py from the reference's examples/teapot.obj): C2 runs
+    on the real geometry wherever this repository goes, also where /root/reference does not exist (the GPU box)"""
+    v, idx, uv, real = scenes.teapot_mesh()
+    assert real and v.shape == (1202, 4) and idx.shape == (2256, 3) and (v[:, 3] == 1.0).all()
+    assert np.array_equal(uv, v[:, :2])  # no `vt` in the file: wavefront.rs:92-95
+    assert idx.max() == 1201 and len(np.unique(idx)) > 1100
+    assert scenes.teapot_scene(rusterix_amd.load(), width=64, height=36, logo_size=16).name == "C2-teapot"
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/examples/teapot.obj"), reason="reference checkout not present")
+def test_teapot_fixture_equals_the_reference_file(oracle):
+    """both OBJ readers (product host mirror and oracle) turn the reference's file into exactly the fixture's arrays"""
+    text = open("/root/reference/examples/teapot.obj").read()
+    v, idx, uv, _ = scenes.teapot_mesh()
+    for api in (rusterix_amd.load(), oracle):
+        g = api.Batch3D.from_obj(text).geometry()
+        assert g[0].tobytes() == v.tobytes() and g[1].astype(np.uint32).tobytes() == idx.tobytes() and g[2].tobytes() == uv.tobytes()

@@ -63,7 +63,6 @@ def test_constant_and_binary_operation_are_fused_only_when_adjacent():
 
 
 @pytest.mark.parametrize("prog, expect", [
-    (P([("Push", 0.5), "SetEmissive"]), "SetEmissive"),
     (P([("Push", 4.0), ("Push", 4.0), "Alloc"]), "Alloc"),
     (P([("For", [], [("Push", 0.0)], [], ["Return"])]), "Return inside For"),
     (P([("LoadGlobal", 0), "SetColor"], globals=1), "read before"),
@@ -95,6 +94,9 @@ def test_refusals(prog, expect):
     P([("Push", 0.1, 0.2, 0.3), "SetRoughness", "Roughness", "SetColor"]),
     # a program without a shade function is never run: anything goes
     Program([[("Push", 0.5), "SetEmissive"]], shade_index=None),
+    # SetEmissive is a property of the FRAME (which other batches are on screen, rxr_upload_frame), not of the program
+    P([("Push", 0.5), "SetEmissive"]),
+    P([("Push", 0.5), "SetEmissive", "Emissive", "SetColor"]),
 ])
 def test_accepts(prog):
     rc, msg, _ = check(prog)
@@ -107,6 +109,15 @@ def test_a_written_field_taints_reads_in_other_programs_of_the_set():
     assert check(reader)[0] == 0                       # nobody writes bump: it stays at Execution::new's zero
     rc, msg, _ = check(writer, reader)
     assert rc == B.RXR_ERR_UNSUPPORTED and "bump" in msg
+
+
+def test_emissive_read_before_written_is_tainted_by_any_writer():
+    reader = P(["Emissive", "SetColor"])
+    assert check(reader)[0] == 0                       # nobody writes emissive: it stays at Execution::new's zero
+    rc, msg, _ = check(P([("Push", 0.5), "SetEmissive"]), reader)
+    assert rc == B.RXR_ERR_UNSUPPORTED and "emissive" in msg
+    rc, msg, _ = check(P(["Emissive", "SetColor", ("Push", 0.5), "SetEmissive"]))   # its own later write taints the next fragment's read
+    assert rc == B.RXR_ERR_UNSUPPORTED and "emissive" in msg
 
 
 @pytest.mark.parametrize("words", [[9999], [B.NODE_OPCODE["Push"], 1, 2], [B.NODE_OPCODE["If"], 5, 0, 0, 1], [B.NODE_OPCODE["LoadLocal"]]])
