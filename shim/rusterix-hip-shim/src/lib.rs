@@ -1,6 +1,7 @@
-//! `RasterizerHip`: drop-in for `rusterix::Rasterizer::rasterize` that keeps scene set-up,
-//! `Scene::project` and the `Edges` precompute in Rust (reference src/rasterizer.rs:185-223) and hands
-//! everything after it (`:256-579`) to the gfx950 kernels through include/rxr.h.
+//! `RasterizeHip`: drop-in for `rusterix::Rasterizer::rasterize` that keeps scene set-up, `Scene::project` and the `Edges`
+//! precompute in Rust (reference src/rasterizer.rs:185-223) and hands everything after it (`:256-579`) to the gfx950 kernels
+//! through include/rxr.h (ABI 4; `ffi.rs` is generated from the header by tools/gen_ffi.py and asserts every struct layout at
+//! compile time).
 //!
 //! Usage in examples/cube.rs, examples/obj.rs, examples/map.rs -- one changed line:
 //!
@@ -11,51 +12,273 @@
 //!     .rasterize_hip(&mut scene, pixels, width, height, 40, &assets);   // was .rasterize(..)
 //! ```
 //!
-//! When no GPU is present (`rxr_create` fails) or the scene uses a feature the device path does not
-//! implement (`RXR_ERR_UNSUPPORTED`: Rusteria shader programs), the call falls back to the
-//! reference's own CPU `rasterize`, so the examples keep working everywhere.  That fallback lives
-//! HERE, in the caller's crate -- the library itself never falls back.
+//! What crosses the boundary per frame: the projected batches of every list in submission order (chunks: opacity, opaque,
+//! terrain; then static, dynamic, overlay), lights, occluders, linedefs, the per-chunk data (`rxr_chunk`: occluders, program
+//! range, baked shader textures, terrain texture / origin / size).  Once per change: textures (`rxr_set_textures`, entity /
+//! item sequence tiles resolved here and appended to the dynamic tiles) and Rusteria programs (`rxr_set_shaders`: the `NodeOp`
+//! trees serialised depth-first by `serialise_ops`, pattern banks, palette).  With `RXR_DEVICE_PROJECTION=1` the object-space
+//! batches are registered once (`rxr_set_meshes`) and a frame sends matrices only.  `RXR_DEVICES=0,1,2,3` makes the context a
+//! multi-device one (`rxr_create_multi`): the library shards every frame over those GPUs by itself.
+//!
+//! CPU fallback (HERE, in the caller's crate -- the library itself never falls back): no GPU (`rxr_create` fails), a render
+//! graph with nodes (the editor's procedural sky: `render_miss_d3` / `render_setup`, src/rasterizer.rs:227-253, :424-432, is not
+//! on the device), or any error status of the library -- `RXR_ERR_UNSUPPORTED` for programs whose result depends on the
+//! reference's per-tile `Execution` state (impure programs, leaking `SetEmissive`, a fourth nested opacity batch, ...).
+//!
+//! NOT compiled in this repository's build image (no rustc / cargo there).  It is written against the reference snapshot's
+//! types (file:line cited at each use) plus the accessor patch of INTEGRATION.md section 2.
 pub mod ffi;
 
 use ffi::*;
+use rusteria::{NodeOp, Program};
 use rusterix::prelude::*;
 use std::sync::Mutex;
 use vek::Mat4;
 
+// ---- context ---------------------------------------------------------------------------------------------------
 struct Ctx(*mut rxr_ctx);
 unsafe impl Send for Ctx {}
-static CTX: Mutex<Option<Ctx>> = Mutex::new(None);
-static TEXTURE_STAMP: Mutex<(usize, usize)> = Mutex::new((0, 0)); // (assets ptr, tile count): re-upload when it changes
 
-fn mat4_cols(m: &Mat4<f32>) -> [f32; 16] {
-    // vek stores column-major: cols[c][r] -> m[c*4 + r]
-    let c = m.into_col_array();
-    c
+#[derive(Default)]
+struct Caches {
+    ctx: Option<Ctx>,
+    tried: bool,
+    textures: u64, // fingerprints of what the device currently holds
+    shaders: u64,
+    meshes: u64,
+}
+static STATE: Mutex<Option<Caches>> = Mutex::new(None);
+
+fn create_context() -> Option<Ctx> {
+    let mut p: *mut rxr_ctx = std::ptr::null_mut();
+    // RXR_DEVICES=0,1,2,3: one member context per GPU, frames sharded inside the library (include/rxr.h rxr_create_multi)
+    if let Ok(list) = std::env::var("RXR_DEVICES") {
+        let ids: Vec<i32> = list.split(',').filter_map(|s| s.trim().parse().ok()).collect();
+        if ids.len() > 1 {
+            return if unsafe { rxr_create_multi(&mut p, ids.as_ptr(), ids.len() as i32) } == RXR_OK { Some(Ctx(p)) } else { None };
+        }
+    }
+    let dev = std::env::var("RXR_DEVICE").ok().and_then(|s| s.parse().ok()).unwrap_or(0);
+    if unsafe { rxr_create(&mut p, dev) } == RXR_OK { Some(Ctx(p)) } else { None }
 }
 
-fn source_of(src: &PixelSource, assets: &Assets, dynamic_base: usize, extra_tiles: &mut Vec<*const Tile>) -> rxr_source {
+fn fnv(h: &mut u64, bytes: &[u8]) {
+    for b in bytes {
+        *h = (*h ^ *b as u64).wrapping_mul(1099511628211);
+    }
+}
+fn fnv_usize(h: &mut u64, v: usize) {
+    fnv(h, &(v as u64).to_le_bytes());
+}
+
+// ---- NodeOp tree -> the word stream of include/rxr.h ------------------------------------------------------------
+/// Depth-first serialisation of `Program.user_functions[i]` (rusteria/src/node/nodeop.rs:12-103): opcode = the variant's
+/// position in the enum, payloads as documented in include/rxr.h.  Block lengths are in words.
+fn serialise_ops(ops: &[NodeOp], out: &mut Vec<u32>, uses_patterns: &mut bool) {
+    for op in ops {
+        match op {
+            NodeOp::LoadGlobal(i) => out.extend_from_slice(&[RXR_NODE_LOAD_GLOBAL, *i as u32]),
+            NodeOp::StoreGlobal(i) => out.extend_from_slice(&[RXR_NODE_STORE_GLOBAL, *i as u32]),
+            NodeOp::LoadLocal(i) => out.extend_from_slice(&[RXR_NODE_LOAD_LOCAL, *i as u32]),
+            NodeOp::StoreLocal(i) => out.extend_from_slice(&[RXR_NODE_STORE_LOCAL, *i as u32]),
+            NodeOp::GetComponents(sw) | NodeOp::SetComponents(sw) => {
+                out.push(if matches!(op, NodeOp::GetComponents(_)) { RXR_NODE_GET_COMPONENTS } else { RXR_NODE_SET_COMPONENTS });
+                out.push(sw.len() as u32);
+                out.extend(sw.iter().map(|c| *c as u32));
+            }
+            NodeOp::If(then_code, else_code) => {
+                let (mut t, mut e) = (vec![], vec![]);
+                serialise_ops(then_code, &mut t, uses_patterns);
+                if let Some(ec) = else_code {
+                    serialise_ops(ec, &mut e, uses_patterns);
+                }
+                out.extend_from_slice(&[RXR_NODE_IF, t.len() as u32, else_code.is_some() as u32, e.len() as u32]);
+                out.extend(t);
+                out.extend(e);
+            }
+            // For(init, cond, incr, body): rusteria/src/node/execution.rs:247
+            NodeOp::For(init, cond, incr, body) => {
+                let mut blocks: [Vec<u32>; 4] = Default::default();
+                for (dst, src) in blocks.iter_mut().zip([init, cond, incr, body]) {
+                    serialise_ops(src, dst, uses_patterns);
+                }
+                out.push(RXR_NODE_FOR);
+                out.extend(blocks.iter().map(|b| b.len() as u32));
+                for b in blocks {
+                    out.extend(b);
+                }
+            }
+            NodeOp::Push(v) => out.extend_from_slice(&[RXR_NODE_PUSH, v.x.to_bits(), v.y.to_bits(), v.z.to_bits()]),
+            NodeOp::FunctionCall(arity, total_locals, index) => {
+                out.extend_from_slice(&[RXR_NODE_FUNCTION_CALL, *arity as u32, *total_locals as u32, *index as u32])
+            }
+            NodeOp::Sample => {
+                *uses_patterns = true;
+                out.push(RXR_NODE_SAMPLE)
+            }
+            NodeOp::SampleNormal => {
+                *uses_patterns = true;
+                out.push(RXR_NODE_SAMPLE_NORMAL)
+            }
+            other => out.push(unit_opcode(other)),
+        }
+    }
+}
+
+/// the payload-free variants, in declaration order
+fn unit_opcode(op: &NodeOp) -> u32 {
+    use NodeOp::*;
+    match op {
+        Swap => RXR_NODE_SWAP, Return => RXR_NODE_RETURN, Dup => RXR_NODE_DUP, Clear => RXR_NODE_CLEAR, Pack2 => RXR_NODE_PACK2,
+        Pack3 => RXR_NODE_PACK3, Add => RXR_NODE_ADD, Sub => RXR_NODE_SUB, Mul => RXR_NODE_MUL, Div => RXR_NODE_DIV,
+        Length => RXR_NODE_LENGTH, Length2 => RXR_NODE_LENGTH2, Length3 => RXR_NODE_LENGTH3, Abs => RXR_NODE_ABS, Sin => RXR_NODE_SIN,
+        Sin1 => RXR_NODE_SIN1, Sin2 => RXR_NODE_SIN2, Cos => RXR_NODE_COS, Cos1 => RXR_NODE_COS1, Cos2 => RXR_NODE_COS2,
+        Tan => RXR_NODE_TAN, Atan => RXR_NODE_ATAN, Atan2 => RXR_NODE_ATAN2, Rotate2D => RXR_NODE_ROTATE2D, Dot => RXR_NODE_DOT,
+        Dot2 => RXR_NODE_DOT2, Dot3 => RXR_NODE_DOT3, Cross => RXR_NODE_CROSS, Normalize => RXR_NODE_NORMALIZE, Floor => RXR_NODE_FLOOR,
+        Ceil => RXR_NODE_CEIL, Round => RXR_NODE_ROUND, Fract => RXR_NODE_FRACT, Mod => RXR_NODE_MOD, Degrees => RXR_NODE_DEGREES,
+        Radians => RXR_NODE_RADIANS, Min => RXR_NODE_MIN, Max => RXR_NODE_MAX, Mix => RXR_NODE_MIX, Smoothstep => RXR_NODE_SMOOTHSTEP,
+        Step => RXR_NODE_STEP, Clamp => RXR_NODE_CLAMP, Sqrt => RXR_NODE_SQRT, Pow => RXR_NODE_POW, Log => RXR_NODE_LOG,
+        Print => RXR_NODE_PRINT, Eq => RXR_NODE_EQ, Ne => RXR_NODE_NE, Lt => RXR_NODE_LT, Le => RXR_NODE_LE, Gt => RXR_NODE_GT,
+        Ge => RXR_NODE_GE, And => RXR_NODE_AND, Or => RXR_NODE_OR, Not => RXR_NODE_NOT, Neg => RXR_NODE_NEG, UV => RXR_NODE_UV,
+        SetUV => RXR_NODE_SET_UV, Normal => RXR_NODE_NORMAL, SetNormal => RXR_NODE_SET_NORMAL, Hitpoint => RXR_NODE_HITPOINT,
+        Time => RXR_NODE_TIME, Color => RXR_NODE_COLOR, SetColor => RXR_NODE_SET_COLOR, Roughness => RXR_NODE_ROUGHNESS,
+        SetRoughness => RXR_NODE_SET_ROUGHNESS, Metallic => RXR_NODE_METALLIC, SetMetallic => RXR_NODE_SET_METALLIC,
+        Emissive => RXR_NODE_EMISSIVE, SetEmissive => RXR_NODE_SET_EMISSIVE, Opacity => RXR_NODE_OPACITY, SetOpacity => RXR_NODE_SET_OPACITY,
+        Bump => RXR_NODE_BUMP, SetBump => RXR_NODE_SET_BUMP, Alloc => RXR_NODE_ALLOC, Iterate => RXR_NODE_ITERATE, Save => RXR_NODE_SAVE,
+        PaletteIndex => RXR_NODE_PALETTE_INDEX,
+        // the variants with payloads are handled by serialise_ops
+        LoadGlobal(_) | StoreGlobal(_) | LoadLocal(_) | StoreLocal(_) | GetComponents(_) | SetComponents(_) | If(..) | For(..) | Push(_)
+        | FunctionCall(..) | Sample | SampleNormal => unreachable!(),
+    }
+}
+
+/// one program's functions as word streams (owned: the rxr_function views point into them)
+struct FlatProgram {
+    functions: Vec<Vec<u32>>,
+    views: Vec<rxr_function>,
+}
+
+/// `rxr_set_shaders`: scene.shaders first, then every chunk's shaders in the frame's chunk order (rxr_chunk.program_base).
+/// Returns Ok(program_base per chunk) or the library's status.
+fn upload_programs(ctx: *mut rxr_ctx, scene: &Scene, chunk_keys: &[(i32, i32)], assets: &Assets, cache: &mut u64) -> Result<Vec<u32>, i32> {
+    let mut all: Vec<&Program> = scene.shaders.iter().collect();
+    let mut bases = vec![];
+    for k in chunk_keys {
+        bases.push(all.len() as u32);
+        all.extend(scene.chunks[k].shaders.iter());
+    }
+    let mut uses_patterns = false;
+    let mut flat: Vec<FlatProgram> = all
+        .iter()
+        .map(|p| {
+            let functions: Vec<Vec<u32>> = p
+                .user_functions
+                .iter()
+                .map(|f| {
+                    let mut w = vec![];
+                    serialise_ops(f, &mut w, &mut uses_patterns);
+                    w
+                })
+                .collect();
+            FlatProgram { functions, views: vec![] }
+        })
+        .collect();
+    // fingerprint: the word streams + the palette (patterns are process-global and immutable once computed)
+    let mut h = 1469598103934665603u64;
+    for (p, f) in all.iter().zip(&flat) {
+        fnv_usize(&mut h, p.globals);
+        fnv_usize(&mut h, p.shade_index.map(|i| i + 1).unwrap_or(0));
+        fnv_usize(&mut h, p.shade_locals);
+        for w in &f.functions {
+            fnv_usize(&mut h, w.len());
+            for x in w {
+                fnv(&mut h, &x.to_le_bytes());
+            }
+        }
+    }
+    let palette: Vec<f32> = assets.palette.colors.iter().flat_map(|c| c.as_ref().map(|c| c.to_vec3().into_array()).unwrap_or([0.0; 3])).collect();
+    let present: Vec<u8> = assets.palette.colors.iter().map(|c| c.is_some() as u8).collect();
+    for x in &palette {
+        fnv(&mut h, &x.to_bits().to_le_bytes());
+    }
+    fnv(&mut h, &present);
+    fnv_usize(&mut h, uses_patterns as usize);
+    if h == *cache {
+        return Ok(bases);
+    }
+    for f in flat.iter_mut() {
+        f.views = f.functions.iter().map(|w| rxr_function { words: w.as_ptr(), n_words: w.len() as u32 }).collect();
+    }
+    let programs: Vec<rxr_program> = all
+        .iter()
+        .zip(&flat)
+        .map(|(p, f)| rxr_program {
+            n_globals: p.globals as u32,
+            shade_index: p.shade_index.map(|i| i as i32).unwrap_or(-1),
+            shade_locals: p.shade_locals as u32,
+            functions: f.views.as_ptr(),
+            n_functions: f.views.len() as u32,
+        })
+        .collect();
+    // rusteria's process-global pattern banks (rusteria/src/textures/patterns.rs:89, :119; TexStorage.data: Vec<Vec3<f32>>,
+    // vek's default Vec3 is repr(C)): only touched when a program samples them -- the first call builds all of them
+    let pat = |src: &'static [rusteria::textures::TexStorage]| -> Vec<rxr_pattern> {
+        src.iter().map(|t| rxr_pattern { rgb: t.data.as_ptr() as *const f32, width: t.width as u32, height: t.height as u32 }).collect()
+    };
+    let (patterns, normal_patterns) = if uses_patterns {
+        (pat(rusteria::textures::patterns::patterns()), pat(rusteria::textures::patterns::patterns_normal()))
+    } else {
+        (vec![], vec![])
+    };
+    let set = rxr_shader_set {
+        programs: programs.as_ptr(),
+        n_programs: programs.len() as u32,
+        patterns: patterns.as_ptr(),
+        n_patterns: patterns.len() as u32,
+        normal_patterns: normal_patterns.as_ptr(),
+        n_normal_patterns: normal_patterns.len() as u32,
+        palette_rgb: palette.as_ptr(),
+        palette_present: present.as_ptr(),
+        n_palette: present.len() as u32,
+    };
+    let rc = unsafe { rxr_set_shaders(ctx, &set) };
+    if rc != RXR_OK {
+        *cache = 0;
+        return Err(rc);
+    }
+    *cache = h;
+    Ok(bases)
+}
+
+// ---- flattening ------------------------------------------------------------------------------------------------
+fn mat4_cols(m: &Mat4<f32>) -> [f32; 16] {
+    m.into_col_array() // vek stores column-major: cols[c][r] -> m[c*4 + r]
+}
+
+/// PixelSource -> rxr_source.  EntityTile / ItemTile (src/map/pixelsource.rs:29-30) are looked up HERE, once per batch
+/// (the raster loops do it per fragment: src/rasterizer.rs:1140-1187, :705-748, :1548-1595): a hit is appended to the dynamic
+/// tiles (`extra`), a miss becomes RXR_SOURCE_MISSING ([0, 0, 0, 0]).
+fn source_of(src: &PixelSource, assets: &Assets, dynamic_base: usize, extra: &mut Vec<*const Tile>) -> rxr_source {
+    let plain = |kind: u32, index: u32, pixel: [u8; 4]| rxr_source { kind, index, pixel };
+    let mut hit = |tile: Option<&Tile>| match tile {
+        Some(t) => {
+            let p = t as *const Tile;
+            let slot = extra.iter().position(|q| *q == p).unwrap_or_else(|| {
+                extra.push(p);
+                extra.len() - 1
+            });
+            plain(RXR_SOURCE_DYNAMIC_TILE, (dynamic_base + slot) as u32, [0; 4])
+        }
+        None => plain(RXR_SOURCE_MISSING, 0, [0; 4]),
+    };
     match src {
-        PixelSource::StaticTileIndex(i) => rxr_source { kind: RXR_SOURCE_STATIC_TILE, index: *i as u32, pixel: [0; 4] },
-        PixelSource::DynamicTileIndex(i) => rxr_source { kind: RXR_SOURCE_DYNAMIC_TILE, index: *i as u32, pixel: [0; 4] },
-        PixelSource::Pixel(p) => rxr_source { kind: RXR_SOURCE_PIXEL, index: 0, pixel: *p },
-        PixelSource::Terrain => rxr_source { kind: RXR_SOURCE_TERRAIN, index: 0, pixel: [0; 4] },
-        // hash lookups are resolved on the host (src/rasterizer.rs:1140-1187): a hit is appended to
-        // the dynamic tile table, a miss becomes RXR_SOURCE_MISSING ([0,0,0,0])
-        PixelSource::EntityTile(id, index) => match assets.entity_tiles.get(id).and_then(|s| s.get_index(*index as usize)) {
-            Some((_, tile)) => {
-                extra_tiles.push(tile as *const Tile);
-                rxr_source { kind: RXR_SOURCE_DYNAMIC_TILE, index: (dynamic_base + extra_tiles.len() - 1) as u32, pixel: [0; 4] }
-            }
-            None => rxr_source { kind: RXR_SOURCE_MISSING, index: 0, pixel: [0; 4] },
-        },
-        PixelSource::ItemTile(id, index) => match assets.item_tiles.get(id).and_then(|s| s.get_index(*index as usize)) {
-            Some((_, tile)) => {
-                extra_tiles.push(tile as *const Tile);
-                rxr_source { kind: RXR_SOURCE_DYNAMIC_TILE, index: (dynamic_base + extra_tiles.len() - 1) as u32, pixel: [0; 4] }
-            }
-            None => rxr_source { kind: RXR_SOURCE_MISSING, index: 0, pixel: [0; 4] },
-        },
-        _ => rxr_source { kind: RXR_SOURCE_OTHER, index: 0, pixel: [0; 4] },
+        PixelSource::StaticTileIndex(i) => plain(RXR_SOURCE_STATIC_TILE, *i as u32, [0; 4]),
+        PixelSource::DynamicTileIndex(i) => plain(RXR_SOURCE_DYNAMIC_TILE, *i as u32, [0; 4]),
+        PixelSource::Pixel(p) => plain(RXR_SOURCE_PIXEL, 0, *p),
+        PixelSource::Terrain => plain(RXR_SOURCE_TERRAIN, 0, [0; 4]),
+        PixelSource::EntityTile(id, index) => hit(assets.entity_tiles.get(id).and_then(|s| s.get_index(*index as usize)).map(|kv| kv.1)),
+        PixelSource::ItemTile(id, index) => hit(assets.item_tiles.get(id).and_then(|s| s.get_index(*index as usize)).map(|kv| kv.1)),
+        _ => plain(RXR_SOURCE_OTHER, 0, [0; 4]),
     }
 }
 
@@ -78,26 +301,35 @@ fn light_of(l: &CompiledLight) -> rxr_light {
     }
 }
 
-/// Owned, flattened copies of what cannot be passed by pointer (usize indices, private Edges).
+fn occluder_of(e: &(BBox, f32)) -> rxr_occluder {
+    rxr_occluder { min: e.0.min.into_array(), max: e.0.max.into_array(), occlusion: e.1 }
+}
+
+fn edges_of(e: &Edges) -> rxr_edges {
+    let (a, b, c) = e.coefficients(); // accessor added by the patch in INTEGRATION.md (Edges is repr(Rust) with private fields)
+    rxr_edges { a, b, c, visible: e.visible as u32 }
+}
+
+fn texture_of(t: &Texture) -> rxr_texture {
+    rxr_texture { rgba: t.data.as_ptr(), width: t.width as u32, height: t.height as u32 }
+}
+
+/// owned repacks of what cannot be passed by pointer: `usize` index triples, private `Edges`, `Vec3` normals
 #[derive(Default)]
-struct Flat3D {
+struct Repack {
     indices: Vec<u32>,
     edges: Vec<rxr_edges>,
     normals: Vec<f32>,
 }
 
-fn flatten3d(b: &Batch3D) -> Flat3D {
-    let mut f = Flat3D::default();
-    f.indices.reserve(b.clipped_indices.len() * 3);
-    for &(i0, i1, i2) in &b.clipped_indices {
-        f.indices.extend_from_slice(&[i0 as u32, i1 as u32, i2 as u32]); // usize -> u32 (asserted < 2^32 by the ABI)
-    }
-    f.edges = b.edges.iter().map(|e| {
-        let (a, bb, c) = e.coefficients(); // accessor added by the patch in INTEGRATION.md
-        rxr_edges { a, b: bb, c, visible: e.visible as u32 }
-    }).collect();
-    f.normals = b.clipped_normals.iter().flat_map(|n| [n.x, n.y, n.z]).collect();
-    f
+struct Item3D<'a> {
+    batch: &'a Batch3D,
+    list: u32,
+    chunk: i32,
+}
+struct Item2D<'a> {
+    batch: &'a Batch2D,
+    chunk: i32,
 }
 
 pub trait RasterizeHip {
@@ -106,186 +338,360 @@ pub trait RasterizeHip {
 
 impl RasterizeHip for Rasterizer {
     fn rasterize_hip(&mut self, scene: &mut Scene, pixels: &mut [u8], width: usize, height: usize, tile_size: usize, assets: &Assets) {
-        let ctx = {
-            let mut g = CTX.lock().unwrap();
-            if g.is_none() {
-                let mut p: *mut rxr_ctx = std::ptr::null_mut();
-                let dev = std::env::var("RXR_DEVICE").ok().and_then(|s| s.parse().ok()).unwrap_or(0);
-                if unsafe { rxr_create(&mut p, dev) } == RXR_OK {
-                    *g = Some(Ctx(p));
-                }
-            }
-            match g.as_ref() {
-                Some(c) => c.0,
-                None => return self.rasterize(scene, pixels, width, height, tile_size, assets), // no GPU: reference CPU path
-            }
-        };
-        if !scene.shaders.is_empty() {
-            return self.rasterize(scene, pixels, width, height, tile_size, assets); // N2 not on the device yet
+        let mut guard = STATE.lock().unwrap();
+        let st = guard.get_or_insert_with(Caches::default);
+        if !st.tried {
+            st.tried = true;
+            st.ctx = create_context();
         }
+        let ctx = match &st.ctx {
+            Some(c) => c.0,
+            None => return self.rasterize(scene, pixels, width, height, tile_size, assets), // no GPU: the reference's CPU path
+        };
+        // the editor's procedural sky lives in render-graph nodes (render_setup / render_ambient_color / render_miss_d3,
+        // src/rasterizer.rs:227-253, :424-432): not on the device
+        if !self.render_graph.collect_nodes_from(0, 0).is_empty() || !self.render_graph.collect_nodes_from(0, 1).is_empty() {
+            return self.rasterize(scene, pixels, width, height, tile_size, assets);
+        }
+        assert!(pixels.len() >= width * height * 4);
+        let device_projection = std::env::var("RXR_DEVICE_PROJECTION").map(|v| v == "1").unwrap_or(false);
 
         // ---- the host half of Rasterizer::rasterize, verbatim (src/rasterizer.rs:194-223) ----
         self.width = width as f32;
         self.height = height as f32;
-        self.hash_anim = rusterix::hash_u32(scene.animation_frame as u32); // made `pub` by the patch
-        scene.project(self.projection_matrix_2d, self.view_matrix, self.projection_matrix, self.width, self.height);
+        self.hash_anim = rusterix::hash_u32(scene.animation_frame as u32); // hoisted and made `pub` by the patch (:199-208)
+        if device_projection {
+            // the 3D half of Scene::project runs on the device; the 2D half stays here (src/scene.rs:163-187)
+            for chunk in scene.chunks.values_mut() {
+                for b in &mut chunk.batches2d {
+                    b.project(self.projection_matrix_2d);
+                }
+                if let Some(t) = &mut chunk.terrain_batch2d {
+                    t.project(self.projection_matrix_2d);
+                }
+            }
+            for b in scene.d2_static.iter_mut().chain(scene.d2_dynamic.iter_mut()) {
+                b.project(self.projection_matrix_2d);
+            }
+        } else {
+            scene.project(self.projection_matrix_2d, self.view_matrix, self.projection_matrix, self.width, self.height); // :210
+        }
+        let mut appended = 0usize;
         for chunk in scene.chunks.values() {
             for light in &chunk.lights {
-                scene.dynamic_lights.push(light.clone());
+                scene.dynamic_lights.push(light.clone()); // :219-223
+                appended += 1;
             }
         }
 
-        // ---- flatten ----
+        if !device_frame(self, scene, pixels, width, height, tile_size, assets, ctx, st, device_projection) {
+            // RXR_ERR_UNSUPPORTED (state leaks of the reference's per-tile Execution, a fourth nested opacity batch, an impure
+            // program, ...) or a device error: this frame is rendered by the reference's own CPU loops.  rasterize() projects
+            // the scene itself and appends the chunk lights again (:219-223): take ours off first, so that the CPU frame sees
+            // exactly what a plain rasterize() call would.
+            let keep = scene.dynamic_lights.len().saturating_sub(appended);
+            scene.dynamic_lights.truncate(keep);
+            self.rasterize(scene, pixels, width, height, tile_size, assets);
+        }
+    }
+}
+
+/// Everything after the host half: flatten the projected scene, keep the device's resident data current, render.  Takes the
+/// scene immutably; `false` = the caller renders this frame on the CPU.
+#[allow(clippy::too_many_arguments)]
+fn device_frame(this: &Rasterizer, scene: &Scene, pixels: &mut [u8], width: usize, height: usize, tile_size: usize, assets: &Assets, ctx: *mut rxr_ctx,
+                st: &mut Caches, device_projection: bool) -> bool {
+    {
+        // ---- submission order of src/rasterizer.rs:314-405 / :503-552 (chunks in the map's iteration order) ----
+        let chunk_keys: Vec<(i32, i32)> = scene.chunks.keys().copied().collect();
+        let mut items3: Vec<Item3D> = vec![];
+        let mut items2: Vec<Item2D> = vec![];
+        for (ci, k) in chunk_keys.iter().enumerate() {
+            let chunk = &scene.chunks[k];
+            let ci = ci as i32;
+            items3.extend(chunk.batches3d_opacity.iter().map(|b| Item3D { batch: b, list: RXR_LIST_CHUNK_OPACITY, chunk: ci }));
+            items3.extend(chunk.batches3d.iter().map(|b| Item3D { batch: b, list: RXR_LIST_CHUNK, chunk: ci }));
+            items3.extend(chunk.terrain_batch3d.iter().map(|b| Item3D { batch: b, list: RXR_LIST_CHUNK_TERRAIN, chunk: ci })); // :343-356
+            items2.extend(chunk.batches2d.iter().map(|b| Item2D { batch: b, chunk: ci }));
+            items2.extend(chunk.terrain_batch2d.iter().map(|b| Item2D { batch: b, chunk: ci })); // :515-525
+        }
+        items3.extend(scene.d3_static.iter().map(|b| Item3D { batch: b, list: RXR_LIST_STATIC, chunk: -1 }));
+        items3.extend(scene.d3_dynamic.iter().map(|b| Item3D { batch: b, list: RXR_LIST_DYNAMIC, chunk: -1 }));
+        items3.extend(scene.d3_overlay.iter().map(|b| Item3D { batch: b, list: RXR_LIST_OVERLAY, chunk: -1 }));
+        items2.extend(scene.d2_static.iter().map(|b| Item2D { batch: b, chunk: -1 }));
+        items2.extend(scene.d2_dynamic.iter().map(|b| Item2D { batch: b, chunk: -1 }));
+
+        // ---- Rusteria programs (scene.shaders + chunk.shaders) ----
+        let program_bases = match upload_programs(ctx, scene, &chunk_keys, assets, &mut st.shaders) {
+            Ok(b) => b,
+            Err(_) => return false, // e.g. an impure program
+        };
+
+        // ---- sources first: entity / item sequence tiles extend the dynamic tile table ----
         let mut extra_tiles: Vec<*const Tile> = vec![];
         let dynamic_base = scene.dynamic_textures.len();
-        let mut flats: Vec<Flat3D> = vec![];
-        let mut b3: Vec<rxr_batch3d> = vec![];
-        let mut b2_idx: Vec<Vec<u32>> = vec![];
-        let mut b2_edges: Vec<Vec<rxr_edges>> = vec![];
-        let mut b2: Vec<rxr_batch2d> = vec![];
-        let mut chunk_occ: Vec<Vec<rxr_occluder>> = vec![];
+        let src3: Vec<rxr_source> = items3.iter().map(|i| source_of(&i.batch.source, assets, dynamic_base, &mut extra_tiles)).collect();
+        let src2: Vec<rxr_source> = items2.iter().map(|i| source_of(&i.batch.source, assets, dynamic_base, &mut extra_tiles)).collect();
 
-        let mut push3d = |b: &Batch3D, list: u32, chunk: i32, flats: &mut Vec<Flat3D>, b3: &mut Vec<rxr_batch3d>,
-                          extra: &mut Vec<*const Tile>| {
-            flats.push(flatten3d(b));
-            let f = flats.last().unwrap();
-            let bb = b.bounding_box.unwrap_or_default();
-            b3.push(rxr_batch3d {
-                projected_vertices: b.projected_vertices.as_ptr() as *const f32,
-                clipped_uvs: b.clipped_uvs.as_ptr() as *const f32,
-                clipped_normals: if b.normals.is_empty() { std::ptr::null() } else { f.normals.as_ptr() },
-                clipped_indices: f.indices.as_ptr(),
-                edges: f.edges.as_ptr(),
-                n_vertices: b.projected_vertices.len() as u32,
-                n_triangles: b.edges.len() as u32,
-                has_bounding_box: b.bounding_box.is_some() as u32,
-                bounding_box: [bb.x, bb.y, bb.width, bb.height],
-                repeat_mode: b.repeat_mode as u32,
-                source: source_of(&b.source, assets, dynamic_base, extra),
-                ambient_color: b.ambient_color.into_array(),
-                shader: b.shader.map(|s| s as i32).unwrap_or(-1),
-                has_profile_id: b.profile_id.is_some() as u32,
-                profile_id: b.profile_id.unwrap_or(0),
-                list,
-                chunk,
-            });
-        };
-        // submission order of src/rasterizer.rs:314-405 (chunks in the map's iteration order)
-        for (ci, chunk) in scene.chunks.values().enumerate() {
-            for b in &chunk.batches3d_opacity { push3d(b, RXR_LIST_CHUNK_OPACITY, ci as i32, &mut flats, &mut b3, &mut extra_tiles); }
-            for b in &chunk.batches3d { push3d(b, RXR_LIST_CHUNK, ci as i32, &mut flats, &mut b3, &mut extra_tiles); }
-            chunk_occ.push(chunk.occluded_sectors.iter().map(|(bb, o)| rxr_occluder { min: bb.min.into_array(), max: bb.max.into_array(), occlusion: *o }).collect());
-        }
-        for b in &scene.d3_static { push3d(b, RXR_LIST_STATIC, -1, &mut flats, &mut b3, &mut extra_tiles); }
-        for b in &scene.d3_dynamic { push3d(b, RXR_LIST_DYNAMIC, -1, &mut flats, &mut b3, &mut extra_tiles); }
-        for b in &scene.d3_overlay { push3d(b, RXR_LIST_OVERLAY, -1, &mut flats, &mut b3, &mut extra_tiles); }
-
-        let mut push2d = |b: &Batch2D, chunk: i32| {
-            b2_idx.push(b.indices.iter().flat_map(|&(a, bb, c)| [a as u32, bb as u32, c as u32]).collect());
-            b2_edges.push(b.edges.iter().map(|e| { let (a, bb, c) = e.coefficients(); rxr_edges { a, b: bb, c, visible: e.visible as u32 } }).collect());
-            let bb = b.bounding_box.unwrap_or_default();
-            b2.push(rxr_batch2d {
-                projected_vertices: b.projected_vertices.as_ptr() as *const f32,
-                uvs: b.uvs.as_ptr() as *const f32,
-                indices: b2_idx.last().unwrap().as_ptr(),
-                edges: b2_edges.last().unwrap().as_ptr(),
-                n_vertices: b.projected_vertices.len() as u32,
-                n_triangles: b.indices.len() as u32,
-                has_bounding_box: b.bounding_box.is_some() as u32,
-                bounding_box: [bb.x, bb.y, bb.width, bb.height],
-                mode: b.mode as u32,
-                repeat_mode: b.repeat_mode as u32,
-                source: source_of(&b.source, assets, dynamic_base, &mut extra_tiles),
-                receives_light: b.receives_light as u32,
-                shader: b.shader.map(|s| s as i32).unwrap_or(-1),
-                chunk,
-            });
-        };
-        for (ci, chunk) in scene.chunks.values().enumerate() { for b in &chunk.batches2d { push2d(b, ci as i32); } }
-        for b in &scene.d2_static { push2d(b, -1); }
-        for b in &scene.d2_dynamic { push2d(b, -1); }
-
-        let lights: Vec<rxr_light> = scene.lights.iter().chain(&scene.dynamic_lights).map(light_of).collect();
-        let occluders: Vec<rxr_occluder> = self.mapmini.occluded_sectors.iter()
-            .map(|(bb, o)| rxr_occluder { min: bb.min.into_array(), max: bb.max.into_array(), occlusion: *o }).collect();
-        let linedefs: Vec<rxr_linedef> = self.mapmini.linedefs.iter()
-            .map(|l| rxr_linedef { start: l.start.into_array(), end: l.end.into_array() }).collect();
-        let chunks: Vec<rxr_chunk> = chunk_occ.iter().map(|v| rxr_chunk { occluders: v.as_ptr(), n_occluders: v.len() as u32 }).collect();
-
-        // ---- textures: assets.tile_list (static) + scene.dynamic_textures + resolved entity/item tiles ----
-        let tile_view = |t: &Tile, store: &mut Vec<Vec<rxr_texture>>| -> rxr_tile {
-            store.push(t.textures.iter().map(|x| rxr_texture { rgba: x.data.as_ptr(), width: x.width as u32, height: x.height as u32 }).collect());
-            let v = store.last().unwrap();
-            rxr_tile { textures: v.as_ptr(), n_textures: v.len() as u32 }
-        };
-        let stamp = (assets as *const Assets as usize, assets.tile_list.len() + scene.dynamic_textures.len() + extra_tiles.len());
-        if *TEXTURE_STAMP.lock().unwrap() != stamp {
-            let mut store = vec![];
-            let st: Vec<rxr_tile> = assets.tile_list.iter().map(|t| tile_view(t, &mut store)).collect();
-            let mut dy: Vec<rxr_tile> = scene.dynamic_textures.iter().map(|t| tile_view(t, &mut store)).collect();
-            for t in &extra_tiles { dy.push(tile_view(unsafe { &**t }, &mut store)); }
-            if unsafe { rxr_set_textures(ctx, st.as_ptr(), st.len() as u32, dy.as_ptr(), dy.len() as u32) } != RXR_OK {
-                return self.rasterize(scene, pixels, width, height, tile_size, assets);
+        // ---- textures: assets.tile_list (static) + scene.dynamic_textures + resolved sequence tiles ----
+        {
+            let mut h = 1469598103934665603u64;
+            let mut mix_tile = |t: &Tile| {
+                fnv_usize(&mut h, t.textures.len());
+                for x in &t.textures {
+                    fnv_usize(&mut h, x.data.as_ptr() as usize);
+                    fnv_usize(&mut h, x.width);
+                    fnv_usize(&mut h, x.height);
+                }
+            };
+            assets.tile_list.iter().for_each(&mut mix_tile);
+            scene.dynamic_textures.iter().for_each(&mut mix_tile);
+            extra_tiles.iter().for_each(|t| mix_tile(unsafe { &**t }));
+            if h != st.textures {
+                let mut store: Vec<Vec<rxr_texture>> = vec![];
+                let mut view = |t: &Tile| -> (usize, u32) {
+                    store.push(t.textures.iter().map(texture_of).collect());
+                    (store.len() - 1, t.textures.len() as u32)
+                };
+                let s_idx: Vec<(usize, u32)> = assets.tile_list.iter().map(&mut view).collect();
+                let mut d_idx: Vec<(usize, u32)> = scene.dynamic_textures.iter().map(&mut view).collect();
+                d_idx.extend(extra_tiles.iter().map(|t| view(unsafe { &**t })));
+                let tiles = |idx: &[(usize, u32)]| -> Vec<rxr_tile> { idx.iter().map(|(i, n)| rxr_tile { textures: store[*i].as_ptr(), n_textures: *n }).collect() };
+                let (st_tiles, dy_tiles) = (tiles(&s_idx), tiles(&d_idx));
+                if unsafe { rxr_set_textures(ctx, st_tiles.as_ptr(), st_tiles.len() as u32, dy_tiles.as_ptr(), dy_tiles.len() as u32) } != RXR_OK {
+                    st.textures = 0;
+                    return false;
+                }
+                st.textures = h;
             }
-            *TEXTURE_STAMP.lock().unwrap() = stamp;
         }
+
+        // ---- 3D batches: host-projected arrays, or (RXR_DEVICE_PROJECTION=1) object-space meshes registered once ----
+        let header = |i: &Item3D, src: rxr_source| (i.batch.repeat_mode as u32, src, i.batch.ambient_color.into_array(), i.batch.shader.map(|s| s as i32).unwrap_or(-1),
+                                                     i.batch.profile_id.is_some() as u32, i.batch.profile_id.unwrap_or(0), i.list, i.chunk);
+        let mut repacks: Vec<Repack> = vec![];
+        let mut b3: Vec<rxr_batch3d> = vec![];
+        let mut mesh_transforms: Vec<f32> = vec![];
+        if device_projection {
+            let mut h = 1469598103934665603u64;
+            for (i, s) in items3.iter().zip(&src3) {
+                let b = i.batch;
+                for v in [b.vertices.as_ptr() as usize, b.vertices.len(), b.indices.as_ptr() as usize, b.indices.len(), b.normals.len(), b.cull_mode as usize,
+                          b.repeat_mode as usize, s.kind as usize, s.index as usize, i.list as usize, (i.chunk + 1) as usize,
+                          b.shader.map(|x| x + 1).unwrap_or(0), b.profile_id.map(|x| x as usize + 1).unwrap_or(0)] {
+                    fnv_usize(&mut h, v);
+                }
+                fnv(&mut h, &s.pixel);
+                mesh_transforms.extend_from_slice(&mat4_cols(&b.transform_3d)); // per frame: moving objects need no re-registration
+            }
+            if h != st.meshes {
+                for i in &items3 {
+                    let b = i.batch;
+                    if !b.indices.is_empty() && b.normals.len() < b.vertices.len() {
+                        return false; // clip_and_project indexes this.normals (batch3d.rs:605): let the reference panic as it would
+                    }
+                    repacks.push(Repack {
+                        indices: b.indices.iter().flat_map(|&(a, bb, c)| [a as u32, bb as u32, c as u32]).collect(),
+                        edges: vec![],
+                        normals: b.normals.iter().flat_map(|n| [n.x, n.y, n.z]).collect(),
+                    });
+                }
+                let meshes: Vec<rxr_mesh3d> = items3
+                    .iter()
+                    .zip(&repacks)
+                    .zip(&src3)
+                    .map(|((i, r), s)| {
+                        let b = i.batch;
+                        let (repeat_mode, source, ambient_color, shader, has_profile_id, profile_id, list, chunk) = header(i, *s);
+                        rxr_mesh3d {
+                            vertices: b.vertices.as_ptr() as *const f32,
+                            indices: r.indices.as_ptr(),
+                            uvs: b.uvs.as_ptr() as *const f32,
+                            normals: if r.normals.is_empty() { std::ptr::null() } else { r.normals.as_ptr() },
+                            n_vertices: b.vertices.len() as u32,
+                            n_triangles: b.indices.len() as u32,
+                            transform_3d: mat4_cols(&b.transform_3d),
+                            cull_mode: b.cull_mode as u32,
+                            repeat_mode, source, ambient_color, shader, has_profile_id, profile_id, list, chunk,
+                        }
+                    })
+                    .collect();
+                if unsafe { rxr_set_meshes(ctx, meshes.as_ptr(), meshes.len() as u32) } != RXR_OK {
+                    st.meshes = 0;
+                    return false;
+                }
+                st.meshes = h;
+            }
+        } else {
+            repacks = items3
+                .iter()
+                .map(|i| Repack {
+                    indices: i.batch.clipped_indices.iter().flat_map(|&(a, bb, c)| [a as u32, bb as u32, c as u32]).collect(), // usize -> u32
+                    edges: i.batch.edges.iter().map(edges_of).collect(),
+                    normals: i.batch.clipped_normals.iter().flat_map(|n| [n.x, n.y, n.z]).collect(),
+                })
+                .collect();
+            b3 = items3
+                .iter()
+                .zip(&repacks)
+                .zip(&src3)
+                .map(|((i, r), s)| {
+                    let b = i.batch;
+                    let bb = b.bounding_box.unwrap_or(Rect { x: 0.0, y: 0.0, width: 0.0, height: 0.0 });
+                    let (repeat_mode, source, ambient_color, shader, has_profile_id, profile_id, list, chunk) = header(i, *s);
+                    rxr_batch3d {
+                        projected_vertices: b.projected_vertices.as_ptr() as *const f32,
+                        clipped_uvs: b.clipped_uvs.as_ptr() as *const f32,
+                        clipped_normals: if b.normals.is_empty() { std::ptr::null() } else { r.normals.as_ptr() }, // :1083
+                        clipped_indices: r.indices.as_ptr(),
+                        edges: r.edges.as_ptr(),
+                        n_vertices: b.projected_vertices.len() as u32,
+                        n_triangles: b.edges.len() as u32,
+                        has_bounding_box: b.bounding_box.is_some() as u32,
+                        bounding_box: [bb.x, bb.y, bb.width, bb.height],
+                        repeat_mode, source, ambient_color, shader, has_profile_id, profile_id, list, chunk,
+                    }
+                })
+                .collect();
+        }
+
+        // ---- 2D batches ----
+        let repacks2: Vec<Repack> = items2
+            .iter()
+            .map(|i| Repack {
+                indices: i.batch.indices.iter().flat_map(|&(a, bb, c)| [a as u32, bb as u32, c as u32]).collect(),
+                edges: i.batch.edges.iter().map(edges_of).collect(),
+                normals: vec![],
+            })
+            .collect();
+        let b2: Vec<rxr_batch2d> = items2
+            .iter()
+            .zip(&repacks2)
+            .zip(&src2)
+            .map(|((i, r), s)| {
+                let b = i.batch;
+                let bb = b.bounding_box.unwrap_or(Rect { x: 0.0, y: 0.0, width: 0.0, height: 0.0 });
+                rxr_batch2d {
+                    projected_vertices: b.projected_vertices.as_ptr() as *const f32,
+                    uvs: b.uvs.as_ptr() as *const f32,
+                    indices: r.indices.as_ptr(),
+                    edges: r.edges.as_ptr(),
+                    n_vertices: b.projected_vertices.len() as u32,
+                    n_triangles: b.indices.len() as u32,
+                    has_bounding_box: b.bounding_box.is_some() as u32,
+                    bounding_box: [bb.x, bb.y, bb.width, bb.height],
+                    mode: b.mode as u32,
+                    repeat_mode: b.repeat_mode as u32,
+                    source: *s,
+                    receives_light: b.receives_light as u32,
+                    shader: b.shader.map(|x| x as i32).unwrap_or(-1),
+                    chunk: i.chunk,
+                }
+            })
+            .collect();
+
+        // ---- lights, occluders, linedefs, chunks ----
+        let lights: Vec<rxr_light> = scene.lights.iter().chain(&scene.dynamic_lights).map(light_of).collect(); // :1373
+        // MapMini.occluded_sectors / .linedefs are private: accessors from the patch in INTEGRATION.md
+        let occluders: Vec<rxr_occluder> = this.mapmini.occluded_sectors().iter().map(occluder_of).collect();
+        let linedefs: Vec<rxr_linedef> = this.mapmini.linedefs().iter().map(|l| rxr_linedef { start: l.start.into_array(), end: l.end.into_array() }).collect();
+        let chunk_occ: Vec<Vec<rxr_occluder>> = chunk_keys.iter().map(|k| scene.chunks[k].occluded_sectors.iter().map(occluder_of).collect()).collect();
+        // chunk.shader_textures: Vec<Option<Texture>> (src/chunk.rs:53); rgba == NULL for None
+        let chunk_baked: Vec<Vec<rxr_texture>> = chunk_keys
+            .iter()
+            .map(|k| scene.chunks[k].shader_textures.iter().map(|t| t.as_ref().map(texture_of).unwrap_or(rxr_texture { rgba: std::ptr::null(), width: 0, height: 0 })).collect())
+            .collect();
+        let chunk_terrain: Vec<Option<rxr_texture>> = chunk_keys.iter().map(|k| scene.chunks[k].terrain_texture.as_ref().map(texture_of)).collect();
+        let chunks: Vec<rxr_chunk> = chunk_keys
+            .iter()
+            .enumerate()
+            .map(|(ci, k)| {
+                let c = &scene.chunks[k];
+                rxr_chunk {
+                    occluders: chunk_occ[ci].as_ptr(),
+                    n_occluders: chunk_occ[ci].len() as u32,
+                    program_base: program_bases[ci],
+                    n_programs: c.shaders.len() as u32,
+                    shader_textures: chunk_baked[ci].as_ptr(),
+                    n_shader_textures: chunk_baked[ci].len() as u32,
+                    terrain_texture: chunk_terrain[ci].as_ref().map(|t| t as *const rxr_texture).unwrap_or(std::ptr::null()),
+                    origin: c.origin.into_array(),
+                    size: c.size,
+                }
+            })
+            .collect();
 
         // background: any `dyn Shader` is evaluated here by the reference's own code and handed over as pixels (bit-identical by
         // construction).  The device can evaluate VGrayGradientShader (RXR_BG_VGRADIENT) and GridShader (RXR_BG_GRID +
         // background_grid) itself, but a `Box<dyn Shader>` does not tell which one it is: that needs a `kind()` / parameter
         // accessor on the trait (a two-line patch to src/shader/mod.rs), after which the pixel loop below is skipped for them.
+        // In 3D mode the background is overwritten by the resolve loop anyway (src/rasterizer.rs:420-461).
         let mut bg_pixels: Vec<u8> = vec![];
         let mut background_kind = RXR_BG_NONE;
-        if !self.render_mode.ignore_background_shader && !self.render_mode.supports3d() {
+        if !this.render_mode.ignore_background_shader && !this.render_mode.supports3d() {
             if let Some(shader) = &scene.background {
                 background_kind = RXR_BG_HOST_PIXELS;
                 bg_pixels.reserve(width * height * 4);
                 let screen = vek::Vec2::new(width as f32, height as f32);
-                for y in 0..height { for x in 0..width {
-                    bg_pixels.extend_from_slice(&shader.shade_pixel(vek::Vec2::new(x as f32 / screen.x, y as f32 / screen.y), screen));
-                } }
+                for y in 0..height {
+                    for x in 0..width {
+                        bg_pixels.extend_from_slice(&shader.shade_pixel(vek::Vec2::new(x as f32 / screen.x, y as f32 / screen.y), screen)); // :292-308
+                    }
+                }
             }
-        } // in 3D mode the background is overwritten by the resolve loop (src/rasterizer.rs:420-461)
+        }
 
-        let (translationd2, scaled2) = self.d2_transform(); // accessor added by the patch
+        let (translationd2, scaled2) = this.d2_transform(); // accessor added by the patch (private fields, :68-69)
         let frame = rxr_frame {
             abi_version: RXR_ABI_VERSION,
-            width: width as u32, height: height as u32, tile_size: tile_size as u32,
-            inverse_view: mat4_cols(&self.inverse_view_matrix),
-            inverse_projection: mat4_cols(&self.inverse_projection_matrix),
-            camera_pos: self.camera_pos.into_array(),
-            translationd2: translationd2.into_array(), scaled2,
-            hash_anim: self.hash_anim, animation_frame: scene.animation_frame as u64,
-            flags: (self.render_mode.supports2d() as u32 * RXR_FLAG_D2_ACTIVE) | (self.render_mode.supports3d() as u32 * RXR_FLAG_D3_ACTIVE)
-                | (self.render_mode.ignore_background_shader as u32 * RXR_FLAG_IGNORE_BG_SHADER)
-                | (self.preserve_transparency as u32 * RXR_FLAG_PRESERVE_TRANSPARENCY)
-                | (self.background_color.is_some() as u32 * RXR_FLAG_HAS_BACKGROUND_COLOR)
-                | (self.ambient_color.is_some() as u32 * RXR_FLAG_HAS_AMBIENT) | (self.sun_dir.is_some() as u32 * RXR_FLAG_HAS_SUN),
-            background_color: self.background_color.unwrap_or([0; 4]),
-            ambient: self.ambient_color.map(|a| a.into_array()).unwrap_or([0.0; 4]),
-            sun_dir: self.sun_dir.map(|s| s.into_array()).unwrap_or([0.0; 3]),
-            day_factor: self.day_factor,
-            sample_mode: self.sample_mode as u32, time: self.time,
-            background_kind, background_pixels: if bg_pixels.is_empty() { std::ptr::null() } else { bg_pixels.as_ptr() },
-            batches3d: b3.as_ptr(), n_batches3d: b3.len() as u32,
-            batches2d: b2.as_ptr(), n_batches2d: b2.len() as u32,
-            lights: lights.as_ptr(), n_lights: lights.len() as u32,
-            occluders: occluders.as_ptr(), n_occluders: occluders.len() as u32,
-            linedefs: linedefs.as_ptr(), n_linedefs: linedefs.len() as u32,
-            chunks: chunks.as_ptr(), n_chunks: chunks.len() as u32,
+            width: width as u32,
+            height: height as u32,
+            tile_size: tile_size as u32,
+            inverse_view: mat4_cols(&this.inverse_view_matrix),
+            inverse_projection: mat4_cols(&this.inverse_projection_matrix),
+            camera_pos: this.camera_pos.into_array(),
+            translationd2: translationd2.into_array(),
+            scaled2,
+            hash_anim: this.hash_anim,
+            animation_frame: scene.animation_frame as u64,
+            flags: (this.render_mode.supports2d() as u32 * RXR_FLAG_D2_ACTIVE)
+                | (this.render_mode.supports3d() as u32 * RXR_FLAG_D3_ACTIVE)
+                | (this.render_mode.ignore_background_shader as u32 * RXR_FLAG_IGNORE_BG_SHADER)
+                | (this.preserve_transparency as u32 * RXR_FLAG_PRESERVE_TRANSPARENCY)
+                | (this.background_color.is_some() as u32 * RXR_FLAG_HAS_BACKGROUND_COLOR)
+                | (this.ambient_color.is_some() as u32 * RXR_FLAG_HAS_AMBIENT)
+                | (this.sun_dir.is_some() as u32 * RXR_FLAG_HAS_SUN),
+            background_color: this.background_color.unwrap_or([0; 4]),
+            ambient: this.ambient_color.map(|a| a.into_array()).unwrap_or([0.0; 4]),
+            sun_dir: this.sun_dir.map(|s| s.into_array()).unwrap_or([0.0; 3]),
+            day_factor: this.day_factor,
+            sample_mode: this.sample_mode as u32,
+            time: this.time,
+            background_kind,
+            background_pixels: if bg_pixels.is_empty() { std::ptr::null() } else { bg_pixels.as_ptr() },
+            batches3d: b3.as_ptr(),
+            n_batches3d: b3.len() as u32,
+            batches2d: b2.as_ptr(),
+            n_batches2d: b2.len() as u32,
+            lights: lights.as_ptr(),
+            n_lights: lights.len() as u32,
+            occluders: occluders.as_ptr(),
+            n_occluders: occluders.len() as u32,
+            linedefs: linedefs.as_ptr(),
+            n_linedefs: linedefs.len() as u32,
+            chunks: chunks.as_ptr(),
+            n_chunks: chunks.len() as u32,
             n_shader_programs: scene.shaders.len() as u32,
-            use_meshes: 0, view: [0.0; 16], projection: [0.0; 16], mesh_transforms: std::ptr::null(),
+            use_meshes: device_projection as u32,
+            view: if device_projection { mat4_cols(&this.view_matrix) } else { [0.0; 16] },
+            projection: if device_projection { mat4_cols(&this.projection_matrix) } else { [0.0; 16] },
+            mesh_transforms: if device_projection && !mesh_transforms.is_empty() { mesh_transforms.as_ptr() } else { std::ptr::null() },
             background_grid: [30.0, 2.0, 0.0, 0.0],
-            has_brush_preview: self.brush_preview.is_some() as u32,
-            brush_position: self.brush_preview.as_ref().map(|b| b.position.into_array()).unwrap_or([0.0; 3]),
-            brush_radius: self.brush_preview.as_ref().map(|b| b.radius).unwrap_or(0.0),
-            brush_falloff: self.brush_preview.as_ref().map(|b| b.falloff).unwrap_or(0.0),
+            has_brush_preview: this.brush_preview.is_some() as u32,
+            brush_position: this.brush_preview.as_ref().map(|b| b.position.into_array()).unwrap_or([0.0; 3]),
+            brush_radius: this.brush_preview.as_ref().map(|b| b.radius).unwrap_or(0.0),
+            brush_falloff: this.brush_preview.as_ref().map(|b| b.falloff).unwrap_or(0.0),
         };
-        assert!(pixels.len() >= width * height * 4);
-        let rc = unsafe { rxr_rasterize(ctx, &frame, pixels.as_mut_ptr()) };
-        if rc != RXR_OK {
-            // RXR_ERR_UNSUPPORTED / device error: render this frame with the reference's CPU loops instead
-            self.rasterize(scene, pixels, width, height, tile_size, assets);
-        }
+        unsafe { rxr_rasterize(ctx, &frame, pixels.as_mut_ptr()) == RXR_OK }
     }
 }
