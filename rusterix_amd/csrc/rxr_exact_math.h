@@ -200,6 +200,29 @@ __device__ __forceinline__ void normalize3_z(float x, float y, float z, float &o
     oz = z / m;
 }
 
+// Rust's `x as u32` / `x as usize` / `x as u8` (saturating, NaN -> 0) in one instruction: v_cvt_u32_f32
+// truncates toward zero, clamps to [0, 2^32 - 1] and turns NaN into 0 -- exactly the cast.  C's `(uint32_t)x` is undefined out
+// of range, so the compiler may not be asked for it; the instruction is named directly.  Checked against the compare-and-
+// select form over a strided sweep of ALL float bit patterns in every test run (rxr_selftest_math, kind 10).
+// RXR_HW_SAT_CVT=0 compiles the compare-and-select form (A-B runs).
+#ifndef RXR_HW_SAT_CVT
+#define RXR_HW_SAT_CVT 1
+#endif
+__device__ __forceinline__ uint32_t sat_u32_ref(float x) {
+    if (!(x > 0.0f)) return 0u;  // NaN, negatives, zero
+    if (x >= 4294967296.0f) return 0xFFFFFFFFu;
+    return (uint32_t)x;
+}
+__device__ __forceinline__ uint32_t sat_u32(float x) {
+#if RXR_HW_SAT_CVT
+    uint32_t r;
+    asm("v_cvt_u32_f32_e32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+#else
+    return sat_u32_ref(x);
+#endif
+}
+
 // exp2f(k * log2f(x)) as the reference's pow32_fast computes it (rasterizer.rs:1895-1901)
 __device__ __forceinline__ float pow_exp2_log2(float x, float k) {
 #if RXR_EXACT_FAST

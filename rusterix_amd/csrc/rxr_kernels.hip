@@ -48,6 +48,10 @@
 #ifndef RXR_VEK_FUSED_MATVEC
 #define RXR_VEK_FUSED_MATVEC 1
 #endif
+// 0 (A-B runs only: emissive programs then render wrongly): the opaque pass does not carry a program's emissive to the encode step
+#ifndef RXR_VM_EMISSIVE
+#define RXR_VM_EMISSIVE 1
+#endif
 
 // -DRXR_PHASE_TIMING=1 (tuning builds only): per-phase wave-cycle totals of the raster kernel, read with
 // rxr_debug_phase_read; see tools/phase_timing.py
@@ -56,23 +60,32 @@
 #endif
 #if RXR_PHASE_TIMING
 __device__ unsigned long long g_phase[1024][16];  // spread over 1024 slots: same-address atomics would serialise
-#define PHASE_DECL unsigned long long ph_t = __builtin_readcyclecounter(), ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+// slots: 0 prologue (+ opacity pass), 1 list staging / walk, 2 shade begin, 3 lights, 4 shade end, 5 2D pass, 6 store,
+// 7 row mode (rows_round), 8 = number of waves, 9 rows_resolve, 10 per-pixel walk of a binned round
+struct PhaseClock {
+    unsigned long long t, acc[12];
+};
+#define PHASE_DECL PhaseClock ph_clock = {__builtin_readcyclecounter(), {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}}; PhaseClock *const ph = &ph_clock
+#define PHASE_PARAM , PhaseClock *ph
+#define PHASE_ARG , ph
 #define PHASE_MARK(k)                                          \
     do {                                                       \
         unsigned long long now_ = __builtin_readcyclecounter(); \
-        ph_acc[k] += now_ - ph_t;                              \
-        ph_t = now_;                                           \
+        ph->acc[k] += now_ - ph->t;                            \
+        ph->t = now_;                                          \
     } while (0)
 #define PHASE_FLUSH                                                              \
     do {                                                                         \
         if ((threadIdx.x & 63u) == 0) {                                          \
-            unsigned slot_ = (blockIdx.x * 4u + (threadIdx.x >> 6)) & 1023u;                   \
-            for (int k_ = 0; k_ < 8; ++k_) atomicAdd(&g_phase[slot_][k_], ph_acc[k_]);   \
+            unsigned slot_ = ((blockIdx.y * gridDim.x + blockIdx.x) * 4u + (threadIdx.x >> 6)) & 1023u;                   \
+            for (int k_ = 0; k_ < 12; ++k_) if (k_ != 8) atomicAdd(&g_phase[slot_][k_], ph->acc[k_]);   \
             atomicAdd(&g_phase[slot_][8], 1ull);                                        \
         }                                                                        \
     } while (0)
 #else
 #define PHASE_DECL
+#define PHASE_PARAM
+#define PHASE_ARG
 #define PHASE_MARK(k)
 #define PHASE_FLUSH
 #endif
@@ -131,23 +144,12 @@ __device__ __forceinline__ void mat4_mul(const float *m, float x, float y, float
     ow = madd(m[15], w, madd(m[11], z, madd(m[7], y, m[3] * x)));
 }
 
-// `x as u8` / `as u32` with Rust semantics (saturate, NaN -> 0)
-__device__ __forceinline__ uint32_t sat_u8(float x) {
-    if (!(x > 0.0f)) return 0u;  // NaN, negatives, zero
-    if (x >= 255.0f) return 255u;
-    return (uint32_t)x;
-}
-__device__ __forceinline__ uint32_t sat_u32(float x) {
-    if (!(x > 0.0f)) return 0u;
-    if (x >= 4294967296.0f) return 0xFFFFFFFFu;
-    return (uint32_t)x;
-}
+// `x as u8` / `as u32` with Rust semantics (saturate, NaN -> 0): the saturating hardware conversion (rxm::sat_u32) and an
+// integer minimum -- two instructions where the compare-and-select form needs five
+__device__ __forceinline__ uint32_t sat_u8(float x) { return min(rxm::sat_u32(x), 255u); }
+__device__ __forceinline__ uint32_t sat_u32(float x) { return rxm::sat_u32(x); }
 // `x as usize` followed by a clamp to [0, hi] (hi < 2^31)
-__device__ __forceinline__ uint32_t sat_index(float x, uint32_t hi) {
-    if (!(x > 0.0f)) return 0u;
-    if (x >= (float)hi) return hi;
-    return (uint32_t)x;
-}
+__device__ __forceinline__ uint32_t sat_index(float x, uint32_t hi) { return min(rxm::sat_u32(x), hi); }
 
 // lib.rs:64-68
 __device__ __forceinline__ uint32_t f32_to_u8_saturated(float x) {
@@ -542,7 +544,9 @@ __device__ __forceinline__ void shade3d_begin(const RasterParams &P, const TriSh
             rough = rclamp(io.roughness.x, 0.0f, 1.0f);
             metal = rclamp(io.metallic.x, 0.0f, 1.0f);
             F.opacity = io.opacity.x;  // :1403
+#if RXR_VM_EMISSIVE
             F.emis = mk3(io.emissive.x, io.emissive.y, io.emissive.z);  // :1323
+#endif
         }
     }
 
@@ -677,7 +681,9 @@ __device__ __forceinline__ void shade3d_lights(const RasterParams &P, bool hit, 
 template <int X>
 __device__ __forceinline__ uint32_t shade3d_end(const Frag &F) {
     f3 lit = F.lit;
+#if RXR_VM_EMISSIVE
     if constexpr (X >= 2) lit = add3(lit, F.emis);
+#endif
     return pack4(f32_to_u8_saturated(linear_to_srgb_fast(lit.x)), f32_to_u8_saturated(linear_to_srgb_fast(lit.y)),
                  f32_to_u8_saturated(linear_to_srgb_fast(lit.z)), f32_to_u8_saturated(F.opacity));
 }
@@ -1359,6 +1365,36 @@ __device__ __forceinline__ int front_lookup(const Vis &v, int t) {
     return prof;
 }
 
+// barycentric_weights_3d (rasterizer.rs:1754-1773) and the fragment's depth (:1054-1058) for the pixel centre (fx, fy): the three
+// correctly rounded divisions of the reference -- alpha and beta by the triangle's `area`, 1 / one_over_z -- through the
+// shared-reciprocal sequences of rxr_exact_math.h (the same floats as `/`; a wave with an operand outside the window, e.g. a
+// barycentric that is exactly zero, takes the plain operators).  Must be called in wave-uniform-or-divergent control flow
+// alike: the window vote counts active lanes only.
+#ifndef RXR_FAST_BARY
+#define RXR_FAST_BARY 1
+#endif
+__device__ __forceinline__ void bary_depth(float v0x, float v0y, float v1x, float v1y, float v2x, float v2y, float area, float iz0, float iz1, float iz2,
+                                           float fx, float fy, float &alpha, float &beta, float &z) {
+    const float pcx = v2x - fx, pcy = v2y - fy;
+    const float pbx = v1x - fx, pby = v1y - fy;
+    const float apx = fx - v0x, apy = fy - v0y;
+    const float acx = v2x - v0x, acy = v2y - v0y;
+    const float na = pcx * pby - pcy * pbx, nb = acx * apy - acy * apx;
+#if RXR_FAST_BARY
+    rxm::div2(na, nb, area, alpha, beta);
+#else
+    alpha = na / area;
+    beta = nb / area;
+#endif
+    const float gamma = 1.0f - alpha - beta;
+    const float one_over_z = iz0 * alpha + iz1 * beta + iz2 * gamma;
+#if RXR_FAST_BARY
+    z = rxm::div1_known(1.0f, one_over_z, rxm::in_window(one_over_z));
+#else
+    z = 1.0f / one_over_z;
+#endif
+}
+
 // one candidate triangle against this lane's pixel (rasterizer.rs:1020-1060 + the :1408 alpha rule)
 // the encoded alpha of an opaque-pass fragment whose alpha does not follow from (texture, uv) alone -- a program
 // that may write `opacity` (:1403-1408), a terrain texel, a baked shader texture: the whole front half of the
@@ -1412,15 +1448,9 @@ __device__ __forceinline__ void visit(const RasterParams &P, const TriSetup &S, 
         }
     }
     // barycentric_weights_3d (:1754-1773)
-    float pcx = S.v2x - fx, pcy = S.v2y - fy;
-    float pbx = S.v1x - fx, pby = S.v1y - fy;
-    float apx = fx - S.v0x, apy = fy - S.v0y;
-    float acx = S.v2x - S.v0x, acy = S.v2y - S.v0y;
-    float alpha = (pcx * pby - pcy * pbx) / S.area;
-    float beta = (acx * apy - acy * apx) / S.area;
-    float gamma = 1.0f - alpha - beta;
-    float one_over_z = S.iz0 * alpha + S.iz1 * beta + S.iz2 * gamma;
-    float z = 1.0f / one_over_z;
+    float alpha, beta, z;
+    bary_depth(S.v0x, S.v0y, S.v1x, S.v1y, S.v2x, S.v2y, S.area, S.iz0, S.iz1, S.iz2, fx, fy, alpha, beta, z);
+    const float gamma = 1.0f - alpha - beta;
     if constexpr (OPACITY && X >= 1) front_insert(vis, z, (int)t, (S.bflags & DB_HAS_PROFILE) ? (int)S.profile_id : -1, (int)S.batch, P.staircase_overflow);
     bool take = z < vis.zmin || (z == vis.zmin && vis.best >= 0 && (int)t < vis.best);
     if (take) {
@@ -1489,6 +1519,7 @@ struct RowLds {
     uint32_t red[8];                         // per-wave totals: [0..3] rows | area << 12, [4..7] candidates with rows
     uint32_t raw[RXR_STAGE_TRIS];            // scan_lists_rows: triangle id of every list entry of the round (= of every staged record)
     uint8_t slot[RXR_STAGE_TRIS];            // scan_lists_rows: staged record of candidate k (bytes: 8 workgroups per CU must fit in 160 KB)
+    uint8_t chunk_owner[RXR_TILE_THREADS];   // rows_round: first owner of every 64-item chunk of the round's pixel items
 };
 // order-preserving map of non-NaN floats to unsigned integers
 __device__ __forceinline__ uint32_t z_order_bits(float z) {
@@ -1510,11 +1541,25 @@ __device__ __forceinline__ uint32_t z_order_bits(float z) {
 
 // One round of row mode over the `n` records staged in st (ids in st.ids).  Returns false (uniformly) without having
 // done anything when the round is better served by the pixel-parallel walk.
-template <bool INDIRECT>  // candidate k's record is st.tri[rl.slot[k] * 6] (scan_lists_rows) instead of st.tri[k * 6]
+//
+// RXR_ROWS_PIXEL_ITEMS (default): the work items are the PIXELS of the candidates' clipped boxes, not their rows.  With a row
+// per thread every wave runs its x loop as often as its widest row needs (a tile of the 1 M-triangle grid: ~95 rows of 1..16
+// pixels in two of the four waves, the other two idle) -- most lanes wait most of the time.  With a pixel per thread the
+// ~380 box pixels of such a tile are two passes of all four waves, each lane evaluating exactly the expressions of visit()
+// once.  The owner of item i is found without a search per lane: the prefix sums of the box areas are in LDS, every
+// 64-item chunk looks its first owner up once (a parallel binary search, one chunk per thread) and a lane steps forward
+// from there (runs of one candidate are ~20 items long).
+#ifndef RXR_ROWS_PIXEL_ITEMS
+#define RXR_ROWS_PIXEL_ITEMS 1
+#endif
+// INDIRECT: candidate k's record is st.tri[rl.slot[k] * 6] (scan_lists_rows) instead of st.tri[k * 6]
+// PIX: pixel items (above); false = one item per row with an x loop, which the interpreter kernels keep (their register budget is
+// spent on the interpreter: pixel items cost k_raster_vm_sv 3-4 % on the 1 M-triangle grid while they save k_raster_rows 9 %)
+template <bool INDIRECT, bool PIX>
 __device__ RXR_ROWS_INLINE bool rows_round(const RasterParams &P, Stage &st, RowLds &rl, uint32_t n, uint32_t tile_x0, uint32_t tile_y0px) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     // clipped pixel box of staged candidate `tid`
-    uint32_t rows = 0, area = 0;
+    uint32_t rows = 0, area = 0, geo = 0;
     bool alpha_test = false;
     if (tid < n) {
         const TriSetup &R = *reinterpret_cast<const TriSetup *>(&st.tri[(INDIRECT ? rl.slot[tid] : tid) * 6u]);
@@ -1525,16 +1570,23 @@ __device__ RXR_ROWS_INLINE bool rows_round(const RasterParams &P, Stage &st, Row
             if (x0 < x1 && y0 < y1) {
                 rows = y1 - y0;
                 area = rows * (x1 - x0);
+                // decode data of the pixel items: box origin inside the tile, width, and ceil(4096 / width): for offsets
+                // below 256 and widths up to 16, (offset * that) >> 12 == offset / width exactly
+                const uint32_t w = x1 - x0;
+                geo = (x0 - tile_x0) | ((y0 - tile_y0px) << 4) | (w << 8) | (((4096u + w - 1u) / w) << 13);
             }
         }
     }
-    // inclusive scan of (rows | area << 12) over the workgroup: rows total < 2^12, area total <= 2^15
-    const uint32_t packed = rows | (area << 12);
+    // inclusive scan over the workgroup of the areas (each <= 256, at most 128 candidates: below 2^15), or of
+    // (rows | area << 12): rows total < 2^12, area total <= 2^15
+    const uint32_t packed = PIX ? area : (rows | (area << 12));
     uint32_t inc = packed;
+    if (wave * 64u < n) {  // (wave-uniform: the waves behind the last candidate have nothing to add)
 #pragma unroll
-    for (uint32_t d = 1; d < 64; d <<= 1) {
-        const uint32_t o = __shfl_up(inc, d, 64);
-        if (lane >= d) inc += o;
+        for (uint32_t d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += o;
+        }
     }
     const unsigned long long has = __ballot(rows != 0u);
     // cut-out candidates need a texel per fragment (:1408): such rounds are left to the walk, which keeps the sampling code
@@ -1553,11 +1605,58 @@ __device__ RXR_ROWS_INLINE bool rows_round(const RasterParams &P, Stage &st, Row
         total += v;
         cands += rl.red[4u + w];
     }
-    const uint32_t rows_total = total & 0xFFFu, area_total = total >> 12;
+    const uint32_t rows_total = PIX ? 0u : (total & 0xFFFu), area_total = PIX ? total : (total >> 12);
     if (cands == 0u || cands >= 0x10000u || area_total > cands * (uint32_t)RXR_ROW_MODE_MAX_AREA) {
         __syncthreads();  // rl.red is rewritten by the next round
         return false;
     }
+    if constexpr (PIX) {
+    if (tid < n) {
+        rl.row_start[tid] = before + inc - area;  // exclusive prefix of the areas
+        rl.raw[tid] = geo;                        // (the list entries' ids have moved to st.ids by now)
+    }
+    if (tid == 0) rl.row_start[n] = area_total;
+    __syncthreads();
+    // first owner of every 64-item chunk (area_total <= 128 * 128: at most 256 chunks): the largest k with row_start[k] <= chunk * 64
+    if (tid * 64u < area_total) {
+        uint32_t lo = 0, hi = n;
+        while (hi - lo > 1u) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (rl.row_start[mid] <= tid * 64u) lo = mid;
+            else hi = mid;
+        }
+        rl.chunk_owner[tid] = (uint8_t)lo;
+    }
+    __syncthreads();
+    for (uint32_t base = 0; base < area_total; base += RXR_TILE_THREADS) {
+        const uint32_t item = base + tid;
+        if (item >= area_total) break;  // (no barrier inside the loop)
+        uint32_t k = rl.chunk_owner[item >> 6];
+        while (rl.row_start[k + 1u] <= item) ++k;  // candidates without pixels share their successor's start; row_start[n] = area_total > item
+        const uint32_t g = rl.raw[k];
+        const uint32_t local = item - rl.row_start[k];
+        const uint32_t ry = (local * (g >> 13)) >> 12, rx = local - ry * ((g >> 8) & 31u);
+        const uint32_t lx = (g & 15u) + rx, ly = ((g >> 4) & 15u) + ry;
+        const TriSetup &S = *reinterpret_cast<const TriSetup *>(&st.tri[(INDIRECT ? rl.slot[k] : k) * 6u]);
+        const uint32_t t = st.ids[k];
+        const float fx = (float)(tile_x0 + lx) + 0.5f, fy = (float)(tile_y0px + ly) + 0.5f;
+        // Edges::evaluate (edge.rs:28-36)
+        const float r0 = S.ea[0] * fx + S.eb[0] * fy + S.ec[0];
+        const float r1 = S.ea[1] * fx + S.eb[1] * fy + S.ec[1];
+        const float r2 = S.ea[2] * fx + S.eb[2] * fy + S.ec[2];
+        if ((r0 < 0.0f) || (r1 < 0.0f) || (r2 < 0.0f)) continue;
+        // barycentric_weights_3d and depth, as visit()
+        float alpha, beta, z;
+        bary_depth(S.v0x, S.v0y, S.v1x, S.v1y, S.v2x, S.v2y, S.area, S.iz0, S.iz1, S.iz2, fx, fy, alpha, beta, z);
+        if (!(z < 1.0f)) continue;  // never closer than the cleared buffer; also NaN
+        const unsigned long long key = ((unsigned long long)z_order_bits(z + 0.0f) << 32) | t;  // -0 -> +0: they compare equal
+        unsigned long long *const cell = &rl.key[ly * RXR_TILE_W + lx];
+        // (cells only ever decrease: a stale value is merely conservative.  A relaxed workgroup-scope atomic load, so that the read
+        // is an LDS instruction -- a `volatile` read through the generic pointer became a FLAT load with a wait for ALL memory traffic)
+        if (key >= __hip_atomic_load(cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) continue;
+        atomicMin(cell, key);
+    }
+    } else {
     if (tid < n) rl.row_start[tid] = ((before + inc) & 0xFFFu) - rows;
     if (tid == 0) rl.row_start[n] = rows_total;
     __syncthreads();
@@ -1604,6 +1703,7 @@ __device__ RXR_ROWS_INLINE bool rows_round(const RasterParams &P, Stage &st, Row
             atomicMin(cell, key);
         }
     }
+    }
     __syncthreads();  // the stage and rl are reused by the next round
     return true;
 }
@@ -1618,15 +1718,8 @@ __device__ RXR_RESOLVE_INLINE void rows_resolve(const RasterParams &P, const Row
     const TriSetup S = P.tri_setup[t];
     shade = P.tri_shade[t];
     shade_of = (int)t;
-    const float pcx = S.v2x - fx, pcy = S.v2y - fy;
-    const float pbx = S.v1x - fx, pby = S.v1y - fy;
-    const float apx = fx - S.v0x, apy = fy - S.v0y;
-    const float acx = S.v2x - S.v0x, acy = S.v2y - S.v0y;
-    const float alpha = (pcx * pby - pcy * pbx) / S.area;
-    const float beta = (acx * apy - acy * apx) / S.area;
-    const float gamma = 1.0f - alpha - beta;
-    const float one_over_z = S.iz0 * alpha + S.iz1 * beta + S.iz2 * gamma;
-    const float z = 1.0f / one_over_z;
+    float alpha, beta, z;
+    bary_depth(S.v0x, S.v0y, S.v1x, S.v1y, S.v2x, S.v2y, S.area, S.iz0, S.iz1, S.iz2, fx, fy, alpha, beta, z);
     const bool closer = z < vis.zmin || (z == vis.zmin && vis.best >= 0 && (int)t < vis.best);
     // Branch-free update.  Written as `if (!closer) return; vis.x = ...;` hipcc (ROCm 7.2) kept the OLD vis.batch for the lanes
     // that win an exact tie (z == vis.zmin, smaller index): its if-conversion restored the old value for every lane of the
@@ -1703,7 +1796,7 @@ __device__ __forceinline__ void scan_lists(const RasterParams &P, Stage &st, uin
         __syncthreads();
         // 4. walk (or, for rounds of small triangles, the rows of their boxes: rows_round)
         if constexpr (!OPACITY && X == 0) {
-            if (rl != nullptr && rows_round<false>(P, st, *rl, n, tile_x0, tile_y0px)) continue;
+            if (rl != nullptr && rows_round<false, RXR_ROWS_PIXEL_ITEMS != 0>(P, st, *rl, n, tile_x0, tile_y0px)) continue;
         }
         for (uint32_t k = 0; k < n; ++k) {
             const TriSetup &S = *reinterpret_cast<const TriSetup *>(&st.tri[k * 6u]);
@@ -1722,7 +1815,7 @@ __device__ __forceinline__ void scan_lists(const RasterParams &P, Stage &st, uin
 template <int X>
 __device__ __forceinline__ void scan_lists_rows(const RasterParams &P, Stage &st, RowLds &rl, bool row_mode, uint32_t b0, uint32_t b1,
                                                 uint32_t tile_x0, uint32_t tile_y0px, uint32_t px, uint32_t py, float fx, float fy, Vis &vis,
-                                                int surf_profile, const Vis *opf) {
+                                                int surf_profile, const Vis *opf PHASE_PARAM) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t n_large = min(P.counters[CNT_LARGE], P.n_tris3d);
     const uint32_t total = n_large + (b1 - b0);
@@ -1768,7 +1861,11 @@ __device__ __forceinline__ void scan_lists_rows(const RasterParams &P, Stage &st
         }
         __syncthreads();
         // 4. the rows of the candidates' boxes, or the walk
-        if (row_mode && rows_round<true>(P, st, rl, n, tile_x0, tile_y0px)) continue;
+        PHASE_MARK(1);
+        if (row_mode && rows_round<true, (RXR_ROWS_PIXEL_ITEMS != 0) && (X < 2)>(P, st, rl, n, tile_x0, tile_y0px)) {
+            PHASE_MARK(7);
+            continue;
+        }
         for (uint32_t k = 0; k < n; ++k) {
             const uint32_t sl = rl.slot[k];
             const TriSetup &S = *reinterpret_cast<const TriSetup *>(&st.tri[sl * 6u]);
@@ -1776,6 +1873,7 @@ __device__ __forceinline__ void scan_lists_rows(const RasterParams &P, Stage &st
             visit<false, X>(P, S, &P.tri_shade[t], t, sl, px, py, fx, fy, vis, surf_profile, opf);
         }
         __syncthreads();  // the stage is reused by the next round
+        PHASE_MARK(10);
     }
 }
 
@@ -1959,8 +2057,9 @@ __device__ __forceinline__ void raster_tile(const RasterParams &P) {
     __shared__ uint32_t s_bin[4];
     __shared__ ShadeStore<FUSED> shade_store;
     __shared__ RowStore<ROWS> row_store;
-    const uint32_t bin = blockIdx.x;
-    const uint32_t tx = bin % P.tiles_x, ty = bin / P.tiles_x;
+    // 2-D grid (tiles_x, tiles_y): no integer division in front of every tile
+    const uint32_t tx = blockIdx.x, ty = blockIdx.y;
+    const uint32_t bin = ty * P.tiles_x + tx;
     const uint32_t tid = threadIdx.x;
     const uint32_t tile_x0 = tx * RXR_TILE_W, tile_y0px = (P.tile_y0 + ty * P.tile_stride) * RXR_TILE_H;
 #if RXR_WAVE_8X8
@@ -2046,9 +2145,11 @@ __device__ __forceinline__ void raster_tile(const RasterParams &P) {
             if constexpr (ROWS) {
                 const bool row_mode = !P.has_opacity;
                 if (row_mode) row_store.r.key[ly * RXR_TILE_W + lx] = RXR_ZKEY_INIT;  // own cell; published by the barriers of the first staging round
-                scan_lists_rows<X>(P, stage, row_store.r, row_mode, b0, b1, tile_x0, tile_y0px, px, py, fx, fy, vis, surf_profile, &op);
+                scan_lists_rows<X>(P, stage, row_store.r, row_mode, b0, b1, tile_x0, tile_y0px, px, py, fx, fy, vis, surf_profile, &op PHASE_ARG);
                 if (tid == 0 && my_bin_count) P.bin_count[bin] = 0u;  // (a non-empty list went through the barriers of a round)
+                PHASE_MARK(1);
                 if (row_mode) rows_resolve(P, row_store.r, lx, ly, fx, fy, vis, HS, hs_of);  // (the last round ended with a barrier)
+                PHASE_MARK(9);
             }
         } else scan_lists<false, X>(P, stage, b0, b1, tile_x0, tile_y0px, px, py, fx, fy, vis, surf_profile, &op);
 
@@ -2301,15 +2402,15 @@ extern "C" void rxr_launch_fill(const RasterParams *P, hipStream_t s) {
     hipLaunchKernelGGL(k_fill, dim3(blocks), dim3(256), 0, s, *P);
 }
 extern "C" void rxr_launch_raster(const RasterParams *P, hipStream_t s) {
-    uint32_t tiles = P->tiles_x * P->tiles_y;
-    if (tiles == 0) return;
+    if (P->tiles_x * P->tiles_y == 0) return;
+    const dim3 tiles(P->tiles_x, P->tiles_y);  // tiles_y <= 2048 (frames of at most 32768 rows)
     const bool no_rows = getenv("RXR_NO_ROWS") != nullptr;  // tuning knob: binned scenes walk every candidate per pixel (k_raster)
-    if (P->kernel_level >= 5u) hipLaunchKernelGGL(k_raster_vm_v, dim3(tiles), dim3(RXR_TILE_THREADS), 0, s, *P);
-    else if (P->kernel_level == 4u) hipLaunchKernelGGL(k_raster_vm_sv, dim3(tiles), dim3(RXR_TILE_THREADS), 0, s, *P);
-    else if (P->kernel_level == 3u) hipLaunchKernelGGL(k_raster_vm_s, dim3(tiles), dim3(RXR_TILE_THREADS), 0, s, *P);
-    else if (P->kernel_level == 2u) hipLaunchKernelGGL(k_raster_vm, dim3(tiles), dim3(RXR_TILE_THREADS), 0, s, *P);
-    else if (P->kernel_level == 1u) hipLaunchKernelGGL(k_raster_chunk, dim3(tiles), dim3(RXR_TILE_THREADS), 0, s, *P);
-    else if (P->fused_small == 1u) hipLaunchKernelGGL(k_raster_fused, dim3(tiles), dim3(RXR_TILE_THREADS), 0, s, *P);
-    else if (P->fused_small == 0u && (P->flags & RXR_FLAG_D3_ACTIVE) && !no_rows) hipLaunchKernelGGL(k_raster_rows, dim3(tiles), dim3(RXR_TILE_THREADS), 0, s, *P);
-    else hipLaunchKernelGGL(k_raster, dim3(tiles), dim3(RXR_TILE_THREADS), 0, s, *P);
+    if (P->kernel_level >= 5u) hipLaunchKernelGGL(k_raster_vm_v, tiles, dim3(RXR_TILE_THREADS), 0, s, *P);
+    else if (P->kernel_level == 4u) hipLaunchKernelGGL(k_raster_vm_sv, tiles, dim3(RXR_TILE_THREADS), 0, s, *P);
+    else if (P->kernel_level == 3u) hipLaunchKernelGGL(k_raster_vm_s, tiles, dim3(RXR_TILE_THREADS), 0, s, *P);
+    else if (P->kernel_level == 2u) hipLaunchKernelGGL(k_raster_vm, tiles, dim3(RXR_TILE_THREADS), 0, s, *P);
+    else if (P->kernel_level == 1u) hipLaunchKernelGGL(k_raster_chunk, tiles, dim3(RXR_TILE_THREADS), 0, s, *P);
+    else if (P->fused_small == 1u) hipLaunchKernelGGL(k_raster_fused, tiles, dim3(RXR_TILE_THREADS), 0, s, *P);
+    else if (P->fused_small == 0u && (P->flags & RXR_FLAG_D3_ACTIVE) && !no_rows) hipLaunchKernelGGL(k_raster_rows, tiles, dim3(RXR_TILE_THREADS), 0, s, *P);
+    else hipLaunchKernelGGL(k_raster, tiles, dim3(RXR_TILE_THREADS), 0, s, *P);
 }

@@ -3,6 +3,7 @@
 // Diagnostics only (rxr_selftest_math in include/rxr.h); not on the frame path.
 #include <hip/hip_runtime.h>
 
+#include "../../include/rxr.h"
 #include "rxr_exact_math.h"
 
 namespace {
@@ -64,7 +65,7 @@ __global__ void __launch_bounds__(256) k_selftest_math(uint64_t seed, uint32_t i
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t wave = gid >> 6;
     Rng g{mix64(seed ^ ((uint64_t)gid << 20))};
-    unsigned long long bad[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long bad[RXR_MATH_KINDS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (uint32_t it = 0; it < iters; ++it) {
         const uint32_t mode = (wave + it) & 3u;
         // ---- divisions sharing a denominator
@@ -147,8 +148,20 @@ __global__ void __launch_bounds__(256) k_selftest_math(uint64_t seed, uint32_t i
             const float x = __uint_as_float(bits);
             if (!same(rxm::sqrt_exact(x), sqrtf(x))) bad[9]++;
         }
+        // ---- the saturating float -> u32 conversion (Rust's `as` casts) named as one instruction: a strided sweep of ALL bit
+        //      patterns (every exponent, both signs, NaNs, infinities, denormals), plus the neighbourhoods of the clamp points
+        {
+            const uint64_t idx = (uint64_t)gid * iters + it;
+            uint32_t bits = (uint32_t)((idx * 2654435761ull + (seed & 0xFFFFFFu)) & 0xFFFFFFFFull);
+            if ((it & 7u) == 0u) {
+                const uint32_t anchors[8] = {0x00000000u, 0x80000000u, 0x3F800000u, 0x437F0000u /* 255 */, 0x4F800000u /* 2^32 */, 0x4F7FFFFFu, 0x7F800000u, 0x7FC00000u};
+                bits = anchors[(it >> 3) & 7u] + ((g.next() & 15u) - 8u);
+            }
+            const float x = __uint_as_float(bits);
+            if (rxm::sat_u32(x) != rxm::sat_u32_ref(x)) bad[10]++;
+        }
     }
-    for (int k = 0; k < 10; ++k)
+    for (int k = 0; k < RXR_MATH_KINDS; ++k)
         if (bad[k]) atomicAdd(&mismatch[k], bad[k]);
 }
 

@@ -16,12 +16,14 @@ ap.add_argument("--lights", type=int, default=16)
 ap.add_argument("--width", type=int, default=3840)
 ap.add_argument("--height", type=int, default=2160)
 ap.add_argument("--frames", type=int, default=5)
-ap.add_argument("--scene", default="map", help="map | boxes | boxes_shader (the reduced C5 grid, 1920x1080)")
+ap.add_argument("--scene", default="map", help="map | boxes | boxes_shader (the reduced C5 grid, 1920x1080) | c5 | c5_shader (the full 1 M-triangle grid)")
 a = ap.parse_args()
 prod = rusterix_amd.load()
 rxr = C.CDLL(rusterix_amd.lib_paths()["rxr"])
 if a.scene == "map":
     cfg = scenes.map_scene(prod, width=a.width, height=a.height, n_lights=a.lights)
+elif a.scene.startswith("c5"):
+    cfg = scenes.box_grid_scene(prod, n=289, width=7680, height=4320, shader=a.scene == "c5_shader")
 else:
     cfg = scenes.box_grid_scene(prod, n=96, width=1920, height=1080, shader=a.scene == "boxes_shader")
 scenes.render(cfg)
@@ -33,9 +35,10 @@ for _ in range(a.frames):
     scenes.render(cfg)
 print(f"wall per frame incl. host work: {(time.time() - t0) / a.frames * 1e3:.2f} ms")
 assert rxr.rxr_debug_phase_read(out, 1) == 0
-names = ["prologue", "visibility (lists+walk)", "shade begin", "lights", "shade end", "2D pass", "store", "-"]
-tot = sum(out[k] for k in range(8))
+names = {0: "prologue (+ opacity pass)", 1: "lists: staging / walk", 7: "row mode (rows_round)", 10: "walk of a binned round", 9: "rows_resolve", 2: "shade begin", 3: "lights",
+         4: "shade end", 5: "2D pass", 6: "store"}
+tot = sum(out[k] for k in names)
 waves = out[8]
-print(f"lights={a.lights} waves={waves} cycles/wave={tot / max(waves, 1):.0f}")
-for k in range(7):
-    print(f"  {names[k]:26s} {out[k] / max(waves, 1):9.0f} cyc/wave  {100.0 * out[k] / max(tot, 1):5.1f} %")
+print(f"scene={a.scene} lights={a.lights} waves={waves} cycles/wave={tot / max(waves, 1):.0f}")
+for k, name in names.items():
+    print(f"  {name:26s} {out[k] / max(waves, 1):9.0f} cyc/wave  {100.0 * out[k] / max(tot, 1):5.1f} %")
