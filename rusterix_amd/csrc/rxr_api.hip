@@ -389,6 +389,7 @@ int rxr_set_meshes(rxr_ctx *ctx, const rxr_mesh3d *meshes, uint32_t n_meshes) {
     const size_t m_evis = take(tin + 1), m_app = take((tin + 1) * 8), m_ct = take(n_chunks * 8), m_cb = take(n_chunks * 8);
     const size_t m_ticket = take(16), m_bbox = take((size_t)n_meshes * sizeof(DevBBox));
     const size_t m_dm = take((size_t)n_meshes * sizeof(DevMesh));
+    const size_t m_live = take((size_t)n_meshes * sizeof(uint32_t));
     if ((rc = ensure(ctx, ctx->d_proj_misc, o)) != RXR_OK) return rc;
     HIPCHK(ctx, hipMemsetAsync(ctx->d_proj_misc.p, 0, o, ctx->stream));
     ctx->pp_off_meshes = m_dm;
@@ -420,6 +421,7 @@ int rxr_set_meshes(rxr_ctx *ctx, const rxr_mesh3d *meshes, uint32_t n_meshes) {
     PP.chunk_base = (AppendCount *)(mm + m_cb);
     PP.ticket = (uint32_t *)(mm + m_ticket);
     PP.bbox = (DevBBox *)(mm + m_bbox);
+    PP.mesh_live = (uint32_t *)(mm + m_live);
     rxr_launch_proj_static(&PP, ctx->stream);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -1183,6 +1185,7 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
         P.idx = PP.idx;
         P.edges = PP.edges;
         P.dev_bbox = PP.bbox;
+        P.mesh_live = PP.mesh_live;
     }
     ctx->n_tris2d = (uint32_t)t2cur;
     ctx->has_frame = true;

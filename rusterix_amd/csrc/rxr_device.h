@@ -199,6 +199,8 @@ struct RasterParams {
     const DevBatch *batches3d;
     const uint32_t *batch_tri_base;  // n_batches3d + 1 prefix array for the triangle -> batch search
     const struct DevBBox *dev_bbox;  // device-projection path: per-batch boxes accumulated on the device (else NULL)
+    const uint32_t *mesh_live;       // device-projection path: per batch, the triangle slots in use (rxr_project.h); slots behind them
+                                     // hold no triangle and nothing may be read from their records (else NULL)
 
     // set-up outputs
     TriSetup *tri_setup;

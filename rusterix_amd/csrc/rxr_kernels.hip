@@ -888,6 +888,10 @@ __device__ __forceinline__ bool make_setup(const RasterParams &P, uint32_t t, Tr
         if (P.batch_tri_base[mid] <= t) lo = mid;
         else hi = mid;
     }
+    if (P.mesh_live && t - P.batch_tri_base[lo] >= P.mesh_live[lo]) {  // an unused slot of a device-projected mesh: nothing to read
+        S.bx = S.by = 0u;
+        return false;
+    }
     const DevBatch B = P.batches3d[lo];
     const rxr_edges E = P.edges[t];
 
@@ -1000,8 +1004,31 @@ __device__ __forceinline__ uint32_t wave_bin_increment(uint32_t *counter, uint32
 #ifndef RXR_SETUP_TRANSPOSE
 #define RXR_SETUP_TRANSPOSE 1
 #endif
+// device-projected frames: true (uniformly) for a workgroup whose 256 slots all lie behind the live triangles of one mesh.  The
+// pools are capacity based (3 slots per input triangle): an unclipped scene leaves two thirds of them unused, and k_setup3d /
+// k_fill used to walk them all (1 M-triangle grid: 161 us instead of 87).  Such a workgroup writes and reads nothing; the bin
+// lists never name its slots.  Not in small-scene mode, where the raster kernel scans the records themselves.
+__device__ __forceinline__ bool dead_slots_block(const RasterParams &P, uint32_t t0) {
+    if (!P.mesh_live || P.fused_small) return false;
+    const uint32_t t1 = min(t0 + 255u, P.n_tris3d - 1u);
+    uint32_t b[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const uint32_t t = k ? t1 : t0;
+        uint32_t lo = 0, hi = P.n_batches3d;
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (P.batch_tri_base[mid] <= t) lo = mid;
+            else hi = mid;
+        }
+        b[k] = lo;
+    }
+    return b[0] == b[1] && t0 - P.batch_tri_base[b[0]] >= P.mesh_live[b[0]];
+}
+
 extern "C" __global__ void __launch_bounds__(256) k_setup3d(RasterParams P) {
     const uint32_t t0 = blockIdx.x * blockDim.x;
+    if (dead_slots_block(P, t0)) return;
     uint32_t t = t0 + threadIdx.x;
     bool live = false;
     TriSetup S = {};
@@ -1170,6 +1197,7 @@ extern "C" __global__ void __launch_bounds__(256) k_fill(RasterParams P) {
     // of mid-sized triangles (teapot at 1080p: k_fill 19 us for 2256 triangles).  Instead the wave flattens its pairs: an
     // exclusive prefix sum of the lanes' bin counts, then pair i belongs to lane (i mod 64), which finds the owning
     // triangle by a binary search over the prefix with shuffles -- ceil(pairs / 64) round trips, all lanes busy.
+    if (dead_slots_block(P, blockIdx.x * blockDim.x)) return;  // (k_setup3d left these slots' boxes unwritten)
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t bx0 = 0, bx1 = 0, by0 = 0, by1 = 0, nb = 0;

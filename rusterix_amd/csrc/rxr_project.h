@@ -61,4 +61,6 @@ struct ProjectParams {
     AppendCount *chunk_base;
     uint32_t *ticket;             // scan last-block ticket (cleared by the last block)
     DevBBox *bbox;                // per mesh
+    uint32_t *mesh_live;          // per mesh and frame: triangle slots in use = originals + appended fans (0 for a rejected mesh);
+                                  // the slots behind them are dead: k_proj_edges, k_setup3d and k_fill skip whole workgroups of them
 };

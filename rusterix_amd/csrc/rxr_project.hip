@@ -426,11 +426,31 @@ __device__ __forceinline__ rxr_edges edges_of_slot(const ProjectParams &P, uint3
     E.visible = (evis && visible) ? 1u : 0u;
     return E;
 }
+// per frame, one thread per mesh: how many of its 3 * n_tris triangle slots are in use (the pools are capacity based: an
+// unclipped scene leaves two thirds of them unused)
+extern "C" __global__ void __launch_bounds__(256) k_proj_live(ProjectParams P) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= P.n_meshes) return;
+    const DevMesh &M = P.meshes[b];
+    uint32_t live = 0;
+    if (!M.rejected) {
+        const AppendCount tot = prefix_at(P, M.tin_base + M.n_tris) - prefix_at(P, M.tin_base);
+        live = M.n_tris + (uint32_t)(tot >> 32);
+    }
+    P.mesh_live[b] = live;
+}
+
 // The 40-byte records leave through LDS as the workgroup's contiguous 10 KB block (see k_setup3d in rxr_kernels.hip).
 extern "C" __global__ void __launch_bounds__(256) k_proj_edges(ProjectParams P) {
     __shared__ uint2 xpose[256 * 5];
     const uint32_t t0 = blockIdx.x * blockDim.x, tid = threadIdx.x, s = t0 + tid;
     const uint32_t n_here = min(256u, P.n_tris_out - t0);   // the grid covers n_tris_out
+    {
+        // a workgroup whose slots all lie behind the live triangles of ONE mesh writes nothing: its consumers (k_setup3d, k_fill)
+        // skip the same slots by the same rule, so stale records there are never read.  (wave-uniform: t0 comes from blockIdx)
+        const uint32_t b0 = find_mesh(P.tout_prefix, P.n_meshes, t0), b1 = find_mesh(P.tout_prefix, P.n_meshes, t0 + n_here - 1u);
+        if (b0 == b1 && t0 - P.tout_prefix[b0] >= P.mesh_live[b0]) return;
+    }
     rxr_edges E;
 #pragma unroll
     for (int i = 0; i < 3; ++i) E.a[i] = E.b[i] = E.c[i] = 0.0f;
@@ -462,6 +482,7 @@ extern "C" void rxr_launch_project(const ProjectParams *P, hipStream_t s) {
     uint32_t nt1 = P->n_tris_in + 1u;
     hipLaunchKernelGGL(k_clip_count, dim3((nt1 + 255u) / 256u), dim3(256), 0, s, *P);
     hipLaunchKernelGGL(k_proj_scan, dim3((nt1 + RXR_PROJ_SCAN_CHUNK - 1u) / RXR_PROJ_SCAN_CHUNK), dim3(256), 0, s, *P);
+    hipLaunchKernelGGL(k_proj_live, dim3((P->n_meshes + 255u) / 256u), dim3(256), 0, s, *P);
     if (P->n_tris_in) hipLaunchKernelGGL(k_clip_emit, dim3((P->n_tris_in + 255u) / 256u), dim3(256), 0, s, *P);
     if (P->n_tris_out) hipLaunchKernelGGL(k_proj_edges, dim3((P->n_tris_out + 255u) / 256u), dim3(256), 0, s, *P);
 }
