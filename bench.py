@@ -42,9 +42,9 @@ FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 vector (FMA coun
 # PMC passes need the profiler (tools/profile_bench.sh); the numbers are copied here from the committed summary.
 PROFILE = {
     "source": "profiles/r02/bench_pmc_summary.json (tools/profile_bench.sh; rocprofv3 --pmc, separate passes)",
-    "write_bytes": 35542191,       # WRITE_SIZE: framebuffer 33.18 MB + register spills
-    "fetch_bytes_x2": 2248244,     # FETCH_SIZE with the gfx950 x2 correction
-    "valu_wave_instructions": 156887443,
+    "write_bytes": 33177600,       # WRITE_SIZE: exactly the framebuffer (3840 * 2160 * 4)
+    "fetch_bytes_x2": 2177026,     # FETCH_SIZE with the gfx950 x2 correction
+    "valu_wave_instructions": 152693238,
 }
 
 
