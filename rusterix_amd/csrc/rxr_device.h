@@ -7,7 +7,8 @@
 
 // GPU tile = binning granule = one 256-thread workgroup.  16x16 pixels; a wave covers 16x4.
 #define RXR_TILE_W 16
-#define RXR_TILE_H 16
+#define RXR_TILE_H 16   // (16 x 32 tiles with 512-thread workgroups were tried in round 2: the pre-pass gains 12 %, the raster
+                        // kernels lose 10-20 % -- barriers over eight waves, coarser occupancy steps; profiles/r02/s_tile32.txt)
 #define RXR_TILE_THREADS (RXR_TILE_W * RXR_TILE_H)
 // a triangle whose clamped pixel box touches more bins than this goes to the "large" list that
 // every tile scans (with a scalar box reject) instead of being inserted into each bin

@@ -1598,16 +1598,17 @@ __device__ RXR_ROWS_INLINE bool rows_round(const RasterParams &P, Stage &st, Row
             if (x0 < x1 && y0 < y1) {
                 rows = y1 - y0;
                 area = rows * (x1 - x0);
-                // decode data of the pixel items: box origin inside the tile, width, and ceil(4096 / width): for offsets
-                // below 256 and widths up to 16, (offset * that) >> 12 == offset / width exactly
+                // decode data of the pixel items: box origin inside the tile, width, and ceil(8192 / width): for offsets
+                // below 512 and widths up to 16, (offset * that) >> 13 == offset / width exactly (checked for every pair)
                 const uint32_t w = x1 - x0;
-                geo = (x0 - tile_x0) | ((y0 - tile_y0px) << 4) | (w << 8) | (((4096u + w - 1u) / w) << 13);
+                geo = (x0 - tile_x0) | ((y0 - tile_y0px) << 4) | (w << 9) | (((8192u + w - 1u) / w) << 14);
+                static_assert(RXR_TILE_W == 16 && RXR_TILE_H <= 32, "bit fields of `geo`");
             }
         }
     }
     // inclusive scan over the workgroup of the areas (each <= 256, at most 128 candidates: below 2^15), or of
-    // (rows | area << 12): rows total < 2^12, area total <= 2^15
-    const uint32_t packed = PIX ? area : (rows | (area << 12));
+    // (rows | area << 13): rows total <= 2^12, area total <= 2^16
+    const uint32_t packed = PIX ? area : (rows | (area << 13));
     uint32_t inc = packed;
     if (wave * 64u < n) {  // (wave-uniform: the waves behind the last candidate have nothing to add)
 #pragma unroll
@@ -1633,7 +1634,7 @@ __device__ RXR_ROWS_INLINE bool rows_round(const RasterParams &P, Stage &st, Row
         total += v;
         cands += rl.red[4u + w];
     }
-    const uint32_t rows_total = PIX ? 0u : (total & 0xFFFu), area_total = PIX ? total : (total >> 12);
+    const uint32_t rows_total = PIX ? 0u : (total & 0x1FFFu), area_total = PIX ? total : (total >> 13);
     if (cands == 0u || cands >= 0x10000u || area_total > cands * (uint32_t)RXR_ROW_MODE_MAX_AREA) {
         __syncthreads();  // rl.red is rewritten by the next round
         return false;
@@ -1663,8 +1664,8 @@ __device__ RXR_ROWS_INLINE bool rows_round(const RasterParams &P, Stage &st, Row
         while (rl.row_start[k + 1u] <= item) ++k;  // candidates without pixels share their successor's start; row_start[n] = area_total > item
         const uint32_t g = rl.raw[k];
         const uint32_t local = item - rl.row_start[k];
-        const uint32_t ry = (local * (g >> 13)) >> 12, rx = local - ry * ((g >> 8) & 31u);
-        const uint32_t lx = (g & 15u) + rx, ly = ((g >> 4) & 15u) + ry;
+        const uint32_t ry = (local * (g >> 14)) >> 13, rx = local - ry * ((g >> 9) & 31u);
+        const uint32_t lx = (g & 15u) + rx, ly = ((g >> 4) & 31u) + ry;
         const TriSetup &S = *reinterpret_cast<const TriSetup *>(&st.tri[(INDIRECT ? rl.slot[k] : k) * 6u]);
         const uint32_t t = st.ids[k];
         const float fx = (float)(tile_x0 + lx) + 0.5f, fy = (float)(tile_y0px + ly) + 0.5f;
@@ -1685,7 +1686,7 @@ __device__ RXR_ROWS_INLINE bool rows_round(const RasterParams &P, Stage &st, Row
         atomicMin(cell, key);
     }
     } else {
-    if (tid < n) rl.row_start[tid] = ((before + inc) & 0xFFFu) - rows;
+    if (tid < n) rl.row_start[tid] = ((before + inc) & 0x1FFFu) - rows;
     if (tid == 0) rl.row_start[n] = rows_total;
     __syncthreads();
 
