@@ -9,9 +9,10 @@
 #define RXR_TILE_W 16
 #define RXR_TILE_H 16
 // (Both neighbours were measured in round 2, profiles/r02/s_tile32.txt and t_tile8.txt.  16 x 32 tiles, 512-thread workgroups:
-// the pre-pass gains 12 %, the raster kernels lose 10-20 % (barriers over eight waves, coarser occupancy steps).  16 x 8 tiles,
-// 128-thread workgroups: the per-tile work -- list bounds, staging, reject, scans -- doubles: the 1 M-triangle grid 561 -> 855 us,
-// the bench frame 205 -> 257 us.)
+// the pre-pass gains 12 %, the raster kernels lose 10-20 % (barriers over eight waves).  16 x 8 tiles, 128-thread workgroups:
+// the 1 M-triangle grid 561 -> 855 us, the bench frame 205 -> 257 us AT THE SAME VALU INSTRUCTION COUNT (1 182 against 1 178 per
+// wave): with ~17 KB of LDS per workgroup only nine 2-wave workgroups fit a CU -- 4.5 waves per SIMD instead of 8 -- and the
+// per-wave latency chain (records, winner's record, texel) is no longer covered.)
 #define RXR_TILE_THREADS (RXR_TILE_W * RXR_TILE_H)
 // a triangle whose clamped pixel box touches more bins than this goes to the "large" list that
 // every tile scans (with a scalar box reject) instead of being inserted into each bin
