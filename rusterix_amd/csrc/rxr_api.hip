@@ -1465,7 +1465,7 @@ int rxr_synchronize(rxr_ctx *ctx) {
                         "four or more opacity batches nest as prefix minima in one pixel: the device keeps three per pixel (surface_id, "
                         "rasterizer.rs:314-357, :1044-1048) and had to drop one; the frame may differ from the reference");
         }
-        if (ctx->last_had_prepass) ctx->stats.n_bin_entries = hc[CNT_ENTRIES];
+        ctx->stats.n_bin_entries = ctx->last_had_prepass ? hc[CNT_ENTRIES] : 0u;
         const bool over3d = hc[CNT_OVERFLOW] != 0, over2d = hc[CNT_WORDS + CNT_OVERFLOW] != 0;
         if (!over3d && !over2d) {
             float a = 0, b = 0;
