@@ -95,6 +95,31 @@ namespace {
 struct f3 {
     float x, y, z;
 };
+// A record of a read-only table at a WAVE-UNIFORM index, fetched through the constant address space: scalar loads (s_load, scalar
+// cache) instead of vector loads.  Behind any earlier store of the kernel the compiler can no longer prove that a plain global
+// load is unclobbered and issues it as a VECTOR load plus v_readfirstlane -- for the lights that was an L2 round trip per light and
+// wave on the critical path of the light loop (seen in the ISA: global_load_dwordx4 ... s_waitcnt vmcnt ... v_readfirstlane).
+// Only fields that are used are loaded.  The tables (lights, linedefs) are written by the upload and never by a kernel.
+#ifndef RXR_UNIFORM_SCALAR_LOADS
+#define RXR_UNIFORM_SCALAR_LOADS 1
+#endif
+template <class T>
+__device__ __forceinline__ T uniform_record(const T *table, uint32_t i) {
+#if RXR_UNIFORM_SCALAR_LOADS
+    // word by word: a struct has no copy constructor from another address space; the loads are merged again (s_load_dwordx16 ...)
+    static_assert(sizeof(T) % 4 == 0 && alignof(T) >= 4, "records of 32-bit fields");
+    typedef const uint32_t __attribute__((address_space(4))) *word_ptr;
+    const word_ptr src = (word_ptr)(table + i);
+    T out;
+    uint32_t *dst = reinterpret_cast<uint32_t *>(&out);
+#pragma unroll
+    for (uint32_t k = 0; k < sizeof(T) / 4; ++k) dst[k] = src[k];
+    return out;
+#else
+    return table[i];
+#endif
+}
+
 __device__ __forceinline__ f3 mk3(float x, float y, float z) { return f3{x, y, z}; }
 __device__ __forceinline__ f3 add3(f3 a, f3 b) { return f3{a.x + b.x, a.y + b.y, a.z + b.z}; }
 __device__ __forceinline__ f3 sub3(f3 a, f3 b) { return f3{a.x - b.x, a.y - b.y, a.z - b.z}; }
@@ -352,7 +377,8 @@ __device__ __forceinline__ float get_occlusion(const rxr_occluder *occ, uint32_t
 // MapMini::is_visible (map/mini.rs:68-95)
 __device__ __forceinline__ bool mapmini_is_visible(const rxr_linedef *ld, uint32_t n, float ax, float ay, float bx, float by) {
     for (uint32_t i = 0; i < n; ++i) {
-        float b1x = ld[i].start[0], b1y = ld[i].start[1], b2x = ld[i].end[0], b2y = ld[i].end[1];
+        const rxr_linedef seg = uniform_record(ld, i);
+        float b1x = seg.start[0], b1y = seg.start[1], b2x = seg.end[0], b2y = seg.end[1];
         float d = (bx - ax) * (b2y - b1y) - (by - ay) * (b2x - b1x);
         if (d == 0.0f) continue;
         float u = ((b1x - ax) * (b2y - b1y) - (b1y - ay) * (b2x - b1x)) / d;
@@ -638,7 +664,7 @@ __device__ __forceinline__ void shade3d_lights(const RasterParams &P, bool hit, 
             const float ss_r = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ss_rcp), li_lane));
             const bool ss_fast = (ss_ok_mask >> li_lane) & 1ull;
             if (!hit) continue;
-            const rxr_light &L = P.lights[li];
+            const rxr_light L = uniform_record(P.lights, li);
             const f3 lp = mk3(L.position[0], L.position[1], L.position[2]);
             f3 incoming, ldir;
             if (L.light_type == RXR_LIGHT_POINT) {
@@ -797,7 +823,7 @@ __device__ __forceinline__ uint32_t fragment2d(const RasterParams &P, const Prim
             acc2 += P.ambient[2] * occlusion;
         }
         for (uint32_t li = 0; li < P.n_lights; ++li) {
-            const rxr_light &L = P.lights[li];
+            const rxr_light L = uniform_record(P.lights, li);
             f3 lc;
             if (!light_color_at(L, mk3(wx, 0.0f, wy), P.hash_anim, true, lc)) continue;
             bool visible = true;
