@@ -1,5 +1,6 @@
 // rusterix_host.cpp -- see rusterix_host.hpp.  Build with -ffp-contract=off (Rust never fuses).
 #include "rusterix_host.hpp"
+#include "../rxr_parallel.h"
 
 #include <algorithm>
 #include <atomic>
@@ -376,30 +377,64 @@ void Batch2D::project(const Mat3 *matrix) {
 }
 
 // ---- Scene --------------------------------------------------------------------------------------
-bool Scene::project(const Mat3 *m2d, const Mat4 &view, const Mat4 &proj, float w, float h) {
-    bool ok = true;
-    for (Chunk &c : chunks) {
-        for (Batch2D &b : c.batches2d) b.project(m2d);
-        for (Batch2D &b : c.terrain_batch2d) b.project(m2d);
-        for (Batch3D &b : c.batches3d_opacity) ok &= b.clip_and_project(view, proj, w, h);
-        for (Batch3D &b : c.batches3d) ok &= b.clip_and_project(view, proj, w, h);
-        for (Batch3D &b : c.terrain_batch3d) ok &= b.clip_and_project(view, proj, w, h);
+// src/scene.rs:155-215: every batch list is projected with rayon's par_iter_mut -- the batches are independent.  Here: one job per
+// batch through the worker pool (rxr_parallel.h), largest lists first come out of the atomic cursor in submission order; frames with
+// little geometry run inline.
+namespace {
+struct ProjectJobs {
+    std::vector<Batch2D *> d2;
+    std::vector<Batch3D *> d3;
+    size_t weight = 0;
+    void add(std::vector<Batch2D> &l) {
+        for (Batch2D &b : l) {
+            d2.push_back(&b);
+            weight += b.vertices.size() / 2 + b.indices.size();
+        }
     }
-    for (Batch2D &b : d2_static) b.project(m2d);
-    for (Batch2D &b : d2_dynamic) b.project(m2d);
-    for (Batch3D &b : d3_static) ok &= b.clip_and_project(view, proj, w, h);
-    for (Batch3D &b : d3_dynamic) ok &= b.clip_and_project(view, proj, w, h);
-    for (Batch3D &b : d3_overlay) ok &= b.clip_and_project(view, proj, w, h);
-    return ok;
+    void add(std::vector<Batch3D> &l) {
+        for (Batch3D &b : l) {
+            d3.push_back(&b);
+            weight += 4 * (b.vertices.size() / 4 + b.indices.size());  // clipping, Edges::new, bounding box
+        }
+    }
+};
+}  // namespace
+
+bool Scene::project(const Mat3 *m2d, const Mat4 &view, const Mat4 &proj, float w, float h) {
+    ProjectJobs jobs;
+    for (Chunk &c : chunks) {
+        jobs.add(c.batches2d);
+        jobs.add(c.terrain_batch2d);
+        jobs.add(c.batches3d_opacity);
+        jobs.add(c.batches3d);
+        jobs.add(c.terrain_batch3d);
+    }
+    jobs.add(d2_static);
+    jobs.add(d2_dynamic);
+    jobs.add(d3_static);
+    jobs.add(d3_dynamic);
+    jobs.add(d3_overlay);
+    std::atomic<bool> ok{true};
+    const size_t n3 = jobs.d3.size();
+    rxr_parallel::run(n3 + jobs.d2.size(), jobs.weight, [&](size_t i) {
+        if (i < n3) {
+            if (!jobs.d3[i]->clip_and_project(view, proj, w, h)) ok.store(false, std::memory_order_relaxed);
+        } else {
+            jobs.d2[i - n3]->project(m2d);
+        }
+    });
+    return ok.load();
 }
 
 void Scene::project_2d(const Mat3 *m2d) {
+    ProjectJobs jobs;
     for (Chunk &c : chunks) {
-        for (Batch2D &b : c.batches2d) b.project(m2d);
-        for (Batch2D &b : c.terrain_batch2d) b.project(m2d);
+        jobs.add(c.batches2d);
+        jobs.add(c.terrain_batch2d);
     }
-    for (Batch2D &b : d2_static) b.project(m2d);
-    for (Batch2D &b : d2_dynamic) b.project(m2d);
+    jobs.add(d2_static);
+    jobs.add(d2_dynamic);
+    rxr_parallel::run(jobs.d2.size(), jobs.weight, [&](size_t i) { jobs.d2[i]->project(m2d); });
 }
 
 // ---- device context -----------------------------------------------------------------------------

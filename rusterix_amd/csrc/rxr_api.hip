@@ -18,6 +18,7 @@
 
 #include "../../include/rusterix_vek.hpp"  // host-side Mat4 products for the device-projection path
 #include "rxr_ctx.h"
+#include "rxr_parallel.h"
 
 extern "C" void rxr_launch_proj_static(const ProjectParams *P, hipStream_t s);
 extern "C" void rxr_launch_project(const ProjectParams *P, hipStream_t s);
@@ -570,11 +571,20 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
         if (b.n_triangles && (!b.clipped_indices || !b.edges)) return fail(ctx, RXR_ERR_INVALID, "batch3d: NULL indices/edges");
         if (b.n_vertices && (!b.projected_vertices || !b.clipped_uvs)) return fail(ctx, RXR_ERR_INVALID, "batch3d: NULL vertex arrays");
         if (b.chunk >= (int32_t)f->n_chunks) return fail(ctx, RXR_ERR_INVALID, "batch3d: chunk index out of range");
-        for (size_t t = 0; t < (size_t)b.n_triangles * 3u; ++t)
-            if (b.clipped_indices[t] >= b.n_vertices) return fail(ctx, RXR_ERR_INVALID, "batch3d: vertex index out of range");
         if (b.list == RXR_LIST_CHUNK_OPACITY) has_opacity = true;
         n_v3 += b.n_vertices;
         n_t3 += b.n_triangles;
+    }
+    {
+        // every index of every batch (the kernels trust them): one job per batch on the host worker pool (rxr_parallel.h)
+        std::atomic<bool> bad{false};
+        rxr_parallel::run(f->n_batches3d, n_t3, [&](size_t i) {
+            const rxr_batch3d &b = f->batches3d[i];
+            uint32_t worst = 0;
+            for (size_t t = 0; t < (size_t)b.n_triangles * 3u; ++t) worst = std::max(worst, b.clipped_indices[t]);
+            if (b.n_triangles && worst >= b.n_vertices) bad.store(true, std::memory_order_relaxed);
+        });
+        if (bad.load()) return fail(ctx, RXR_ERR_INVALID, "batch3d: vertex index out of range");
     }
     if (n_v3 >= (1ull << 31) || n_t3 >= (1ull << 31)) return fail(ctx, RXR_ERR_INVALID, "frame too large (>= 2^31 vertices or triangles)");
     size_t n_t2 = 0, n_l2 = 0, n_items = 0;
@@ -766,19 +776,25 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
         }
         b3[i] = d;
         base[i] = (uint32_t)tcur;
-        if (b.n_vertices) {
-            memcpy(st + L.off_pv + vcur * 16, b.projected_vertices, (size_t)b.n_vertices * 16);
-            memcpy(st + L.off_uv + vcur * 8, b.clipped_uvs, (size_t)b.n_vertices * 8);
-            if (b.clipped_normals) memcpy(st + L.off_nrm + vcur * 12, b.clipped_normals, (size_t)b.n_vertices * 12);
-        }
-        if (b.n_triangles) {
-            memcpy(st + L.off_idx + tcur * 12, b.clipped_indices, (size_t)b.n_triangles * 12);
-            memcpy(st + L.off_edges + tcur * sizeof(rxr_edges), b.edges, (size_t)b.n_triangles * sizeof(rxr_edges));
-        }
         vcur += b.n_vertices;
         tcur += b.n_triangles;
     }
     base[f->n_batches3d] = (uint32_t)tcur;
+    // the arrays themselves: independent per batch (offsets are in the headers just written), through the host worker pool --
+    // 124 MB for the 1 M-triangle grid, which one thread copies in about as long as the GPU takes for forty frames
+    rxr_parallel::run(f->n_batches3d, n_v3 + n_t3, [&](size_t i) {
+        const rxr_batch3d &b = f->batches3d[i];
+        const size_t v0 = b3[i].vert_base, t0 = b3[i].tri_base;
+        if (b.n_vertices) {
+            memcpy(st + L.off_pv + v0 * 16, b.projected_vertices, (size_t)b.n_vertices * 16);
+            memcpy(st + L.off_uv + v0 * 8, b.clipped_uvs, (size_t)b.n_vertices * 8);
+            if (b.clipped_normals) memcpy(st + L.off_nrm + v0 * 12, b.clipped_normals, (size_t)b.n_vertices * 12);
+        }
+        if (b.n_triangles) {
+            memcpy(st + L.off_idx + t0 * 12, b.clipped_indices, (size_t)b.n_triangles * 12);
+            memcpy(st + L.off_edges + t0 * sizeof(rxr_edges), b.edges, (size_t)b.n_triangles * sizeof(rxr_edges));
+        }
+    });
 
     if (use_meshes) {
         // headers of the device-projected batches + the per-frame half of DevMesh (view * model, frustum reject)

@@ -102,6 +102,9 @@ def projected(api, cfg):
     (scenes.teapot_scene, dict(width=480, height=270, logo_size=16)),
     (scenes.map_scene, dict(width=640, height=360, logo_size=16, n_lights=2)),
     (scenes.box_grid_scene, dict(n=6, width=256, height=144)),
+    # 48 batches of 48 boxes: above RXR_PARALLEL_MIN_WEIGHT, so Scene::project hands the batches to the host worker pool
+    # (rusterix_amd/csrc/rxr_parallel.h; the reference's par_iter_mut, src/scene.rs:162-211) -- same bits, batch for batch
+    (scenes.box_grid_scene, dict(n=48, width=640, height=360)),
 ])
 def test_projection_matches_oracle_bit_for_bit(oracle, builder, kw):
     prod = rusterix_amd.load()
