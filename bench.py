@@ -43,8 +43,8 @@ FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 vector (FMA coun
 PROFILE = {
     "source": "profiles/r02/bench_pmc_summary.json (tools/profile_bench.sh; rocprofv3 --pmc, separate passes)",
     "write_bytes": 33177600,       # WRITE_SIZE: exactly the framebuffer (3840 * 2160 * 4)
-    "fetch_bytes_x2": 2177026,     # FETCH_SIZE with the gfx950 x2 correction
-    "valu_wave_instructions": 152693238,
+    "fetch_bytes_x2": 2186156,     # FETCH_SIZE with the gfx950 x2 correction
+    "valu_wave_instructions": 151602512,
 }
 
 
