@@ -2152,6 +2152,9 @@ __device__ __forceinline__ uint32_t walk_prims2d(const RasterParams &P, Stage &s
 #ifndef RXR_RASTER_WAVES_PER_SIMD
 #define RXR_RASTER_WAVES_PER_SIMD 8  // bench frame (4K, 16 lights), built without SLP vectorisation: unbounded (67 VGPRs) 217 us, 7: 211, 8: 210
 #endif
+#ifndef RXR_XCD_GROUP
+#define RXR_XCD_GROUP 0
+#endif
 #ifndef RXR_WAVE_8X8
 #define RXR_WAVE_8X8 0
 #endif
@@ -2177,8 +2180,24 @@ __device__ __forceinline__ void raster_tile(const RasterParams &P) {
     __shared__ uint32_t s_bin[4];
     __shared__ ShadeStore<FUSED> shade_store;
     __shared__ RowStore<ROWS> row_store;
-    // 2-D grid (tiles_x, tiles_y): no integer division in front of every tile
+    // 2-D grid, no integer division in front of every tile.  Workgroups go to the eight XCDs round robin in launch order
+    // (x fastest), and every XCD has its own L2: with column = blockIdx.x, horizontally adjacent tiles -- which share the records
+    // of the triangles that straddle them -- always sit on different XCDs.  RXR_XCD_GROUP = G > 0 hands each XCD groups of G
+    // adjacent columns instead (block x stands for column (q / G) * 8G + (x & 7) * G + q % G, q = x / 8; the grid is padded to
+    // a multiple of 8G columns).  Measured (tools/try_cfg_parity.sh, one box): the 1 M-triangle grid's frame 0.706 ms plain, 0.708 /
+    // 0.700 / 0.700 ms with G = 2 / 4 / 8 -- nothing beyond noise, the raster kernels are bound by instruction issue and
+    // dependent latencies, not by L2 misses -- while the bench frame loses 1 / 5 / 7 % (neighbouring columns differ in cost, and
+    // round robin by single columns is the finest balance there is).  Whole vertical bands per XCD lose far more: grid 561 ->
+    // 810 us, bench frame 199 -> 217 us.  Hence G = 0: the hardware's own round robin.
+#if RXR_XCD_GROUP
+    constexpr uint32_t G = RXR_XCD_GROUP;
+    static_assert((G & (G - 1u)) == 0u, "power of two");
+    const uint32_t q = blockIdx.x >> 3;
+    const uint32_t tx = (q / G) * (8u * G) + (blockIdx.x & 7u) * G + (q % G), ty = blockIdx.y;
+    if (tx >= P.tiles_x) return;  // (workgroup-uniform; the padding columns)
+#else
     const uint32_t tx = blockIdx.x, ty = blockIdx.y;
+#endif
     const uint32_t bin = ty * P.tiles_x + tx;
     const uint32_t tid = threadIdx.x;
     const uint32_t tile_x0 = tx * RXR_TILE_W, tile_y0px = (P.tile_y0 + ty * P.tile_stride) * RXR_TILE_H;
@@ -2523,7 +2542,12 @@ extern "C" void rxr_launch_fill(const RasterParams *P, hipStream_t s) {
 }
 extern "C" void rxr_launch_raster(const RasterParams *P, hipStream_t s) {
     if (P->tiles_x * P->tiles_y == 0) return;
+#if RXR_XCD_GROUP
+    const uint32_t pad = 8u * RXR_XCD_GROUP;
+    const dim3 tiles(pad * ((P->tiles_x + pad - 1u) / pad), P->tiles_y);  // (see raster_tile: groups of adjacent columns per XCD)
+#else
     const dim3 tiles(P->tiles_x, P->tiles_y);  // tiles_y <= 2048 (frames of at most 32768 rows)
+#endif
     const bool no_rows = getenv("RXR_NO_ROWS") != nullptr;  // tuning knob: binned scenes walk every candidate per pixel (k_raster)
     if (P->kernel_level >= 5u) hipLaunchKernelGGL(k_raster_vm_v, tiles, dim3(RXR_TILE_THREADS), 0, s, *P);
     else if (P->kernel_level == 4u) hipLaunchKernelGGL(k_raster_vm_sv, tiles, dim3(RXR_TILE_THREADS), 0, s, *P);
