@@ -485,7 +485,8 @@ int rxr_render_gather(rxr_ctx *ctx, int root, void *dev_pixels, void *hip_stream
  *                     the lists are grown and that launch is rendered again);
  *   RXR_ERR_OVERFLOW  see above: an EARLIER launch overflowed; its frame was incomplete;
  *   RXR_ERR_INVALID   a fragment's Rusteria program did what makes the reference panic;
- *   RXR_ERR_UNSUPPORTED a pixel's opacity staircase overflowed (four nested opacity batches).
+ *   RXR_ERR_UNSUPPORTED a pixel's opacity staircase overflowed (four nested GROUPS of opacity batches -- runs of opacity batches
+ *                       without a profiled opaque batch between them --).
  * Stream contract: every render of a context uses the context's one set of scratch buffers.  A render on a different
  * stream than the previous one is ordered behind it by the library; rxr_upload_frame / rxr_set_* wait (on the host) for
  * all renders, including those on caller streams, before they overwrite anything.  A caller that queues frame after

@@ -734,6 +734,22 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
         return RXR_OK;
     };
 
+    // Opacity groups (rxr_kernels.hip front_insert): the surface_id staircase of a pixel keeps one entry per GROUP of opacity
+    // batches -- a maximal run, in submission order, with no opaque batch that carries a profile id in between.  Only such
+    // batches ever read surface_id (:1044-1048), and their triangles' indices lie outside every group's index range, so of a
+    // group's prefix minima only the last can be what they see.  (Counting a batch that turns out to be skipped as a separator
+    // only makes groups smaller, which is always safe.)
+    uint32_t opacity_group = 0;
+    auto opacity_group_of = [&](DevBatch &d, bool opacity_list, bool has_profile) -> int {
+        if (opacity_list) {
+            if (opacity_group >= 0xFFFFu) return fail(ctx, RXR_ERR_UNSUPPORTED, "more than 65534 groups of opacity batches");
+            d.flags |= opacity_group << DB_GROUP_SHIFT;
+        } else if (has_profile) {
+            ++opacity_group;
+        }
+        return RXR_OK;
+    };
+
     // ---- pass 2: flatten -----------------------------------------------------------------------
     const float W = (float)f->width, H = (float)f->height;
     DevBatch *b3 = (DevBatch *)(st + L.off_b3);
@@ -753,6 +769,7 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
         d.profile_id = b.profile_id;
         d.repeat_mode = b.repeat_mode;
         d.chunk = b.chunk;
+        if ((rc = opacity_group_of(d, b.list == RXR_LIST_CHUNK_OPACITY, b.has_profile_id != 0)) != RXR_OK) return rc;
         memcpy(d.ambient, b.ambient_color, 12);
         // batch-level box reject, rasterizer.rs:978-983, evaluated against the whole screen
         bool keep = b.has_bounding_box && b.n_triangles > 0;
@@ -841,6 +858,7 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
             d.profile_id = h.profile_id;
             d.repeat_mode = h.repeat_mode;
             d.chunk = h.chunk;
+            if ((rc = opacity_group_of(d, h.list == RXR_LIST_CHUNK_OPACITY, h.has_profile_id)) != RXR_OK) return rc;
             memcpy(d.ambient, h.ambient, 12);
             bool keep = !rejected && h.dev.n_tris > 0;       // the box reject itself happens on the device (dev_bbox)
             if ((rc = classify3d(d, h.source, h.chunk, h.shader, h.list, keep, "mesh")) != RXR_OK) return rc;
@@ -1478,7 +1496,7 @@ int rxr_synchronize(rxr_ctx *ctx) {
         if (hc[HS_STAIRCASE]) {
             hc[HS_STAIRCASE] = 0;
             return fail(ctx, RXR_ERR_UNSUPPORTED,
-                        "four or more opacity batches nest as prefix minima in one pixel: the device keeps three per pixel (surface_id, "
+                        "four or more groups of opacity batches nest as prefix minima in one pixel: the device keeps three per pixel (surface_id, "
                         "rasterizer.rs:314-357, :1044-1048) and had to drop one; the frame may differ from the reference");
         }
         ctx->stats.n_bin_entries = ctx->last_had_prepass ? hc[CNT_ENTRIES] : 0u;

@@ -36,6 +36,8 @@ enum : uint32_t {
     DB_FULL_ALPHA = 1u << 7,      // the encoded alpha of a fragment needs the whole front half of the fragment block: a program
                                   // that may write `opacity`, a terrain texel (sampled by world position) or a baked shader texture
     DB_TERRAIN = 1u << 8,         // PixelSource::Terrain in a chunk: texel by world position (chunk.rs:133-151)
+    // bits 16..31 of an OPACITY batch's flags: its opacity group (rxr_upload_frame; rxr_kernels.hip front_insert)
+    DB_GROUP_SHIFT = 16,
 };
 
 // flattened Batch3D / Batch2D header.  The texel source is resolved on the host at upload time:

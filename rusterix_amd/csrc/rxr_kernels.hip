@@ -1428,7 +1428,10 @@ __device__ __forceinline__ void front_init(Vis &v) {
         v.fbatch[i] = -1;
     }
 }
-// inserts fragment (z, id, prof) arriving in arbitrary order
+// inserts fragment (z, id, prof) arriving in arbitrary order.  `batch` is the fragment's opacity GROUP (DevBatch.flags >> 16,
+// rxr_upload_frame): a maximal run of opacity batches in submission order with no profiled opaque batch between them.  Only
+// opaque candidates with a profile id ever look the staircase up, and none of them has an index inside a group's index range --
+// so, exactly as for the prefix minima of one batch, of a group's prefix minima only the last one can be an answer.
 __device__ __forceinline__ void front_insert(Vis &v, float z, int id, int prof, int batch, uint32_t *overflow_flag) {
     if (!(z < 1.0f)) return;  // z_buffer_opacity starts at 1.0 (:283): never written
     bool dominated = false;
@@ -1439,7 +1442,7 @@ __device__ __forceinline__ void front_insert(Vis &v, float z, int id, int prof, 
 #pragma unroll
     for (int i = 0; i < 3; ++i)
         if (v.fid[i] >= 0 && id < v.fid[i] && z <= v.fz[i]) v.fid[i] = -1;  // no longer a prefix minimum
-    // same batch already present: both are prefix minima, keep the later one
+    // same group already present: both are prefix minima, keep the later one (its batch may differ: the profile goes with it)
     bool done = false;
 #pragma unroll
     for (int i = 0; i < 3; ++i)
@@ -1447,12 +1450,13 @@ __device__ __forceinline__ void front_insert(Vis &v, float z, int id, int prof, 
             if (id > v.fid[i]) {
                 v.fz[i] = z;
                 v.fid[i] = id;
+                v.fprof[i] = prof;
             }
             done = true;
         }
     if (done) return;
     // take a free slot; if all three are taken drop the entry with the smallest index (only happens when four or more
-    // opacity batches nest as prefix minima in one pixel).  The drop is reported: rxr_synchronize returns RXR_ERR_UNSUPPORTED
+    // opacity GROUPS nest as prefix minima in one pixel).  The drop is reported: rxr_synchronize returns RXR_ERR_UNSUPPORTED
     // for the frame (pinned host word; the store is this rare path's only cost)
     int slot = v.fid[0] < 0 ? 0 : (v.fid[1] < 0 ? 1 : (v.fid[2] < 0 ? 2 : -1));
     if (slot < 0) {
@@ -1570,7 +1574,7 @@ __device__ __forceinline__ void visit(const RasterParams &P, const TriSetup &S, 
     float alpha, beta, z;
     bary_depth(S.v0x, S.v0y, S.v1x, S.v1y, S.v2x, S.v2y, S.area, S.iz0, S.iz1, S.iz2, fx, fy, alpha, beta, z);
     const float gamma = 1.0f - alpha - beta;
-    if constexpr (OPACITY && X >= 1) front_insert(vis, z, (int)t, (S.bflags & DB_HAS_PROFILE) ? (int)S.profile_id : -1, (int)S.batch, P.staircase_overflow);
+    if constexpr (OPACITY && X >= 1) front_insert(vis, z, (int)t, (S.bflags & DB_HAS_PROFILE) ? (int)S.profile_id : -1, (int)(S.bflags >> DB_GROUP_SHIFT), P.staircase_overflow);
     bool take = z < vis.zmin || (z == vis.zmin && vis.best >= 0 && (int)t < vis.best);
     if (take) {
         if (X >= 1 && !OPACITY && (S.bflags & DB_FULL_ALPHA)) {  // frames with such batches run k_raster_chunk / k_raster_vm (RasterParams.kernel_level)

@@ -271,7 +271,8 @@ def test_three_nested_opacity_batches_are_exact(oracle, product):
 
 
 def test_four_nested_opacity_batches_are_refused_loudly(oracle, product):
-    """the device keeps three prefix minima per pixel; a fourth used to be dropped silently.  Now the
+    """the device keeps three prefix minima per pixel, one per opacity group (here every pane is a group of its own: each chunk's
+    profiled wall separates it from the next pane); a fourth used to be dropped silently.  Now the
     frame fails with RXR_ERR_UNSUPPORTED, so that a caller can take the CPU path for it."""
     scenes.render(nested_windows_scene(oracle, 4))  # the reference algorithm has no such limit
     with pytest.raises(B.RasterizeError) as e:
@@ -279,6 +280,46 @@ def test_four_nested_opacity_batches_are_refused_loudly(oracle, product):
     assert e.value.code == B.RXR_ERR_UNSUPPORTED and "opacity batches nest" in str(e.value)
     # the context is usable afterwards
     compare(oracle, product, lambda api: nested_windows_scene(api, 2))
+
+
+def panes_of_one_chunk_scene(api, k, second_chunk):
+    """k panes of ONE chunk submitted far -> near (k prefix minima per pixel, all from one opacity GROUP: no profiled opaque batch
+    lies between them in submission order), then that chunk's walls, one per pane and with the pane's profile id: what the walls
+    see is the nearest pane only.  `second_chunk` adds a chunk with its own pane + wall behind them (a second group)."""
+    scene = api.Scene.empty()
+    chunk = scene.add_chunk()
+    for i in range(k):
+        z = -1.5 + 3.0 * i / max(1, k - 1)
+        off = 0.12 * (i % 3) - 0.12  # the panes overlap only partly, so that some pixels see fewer of them
+        chunk.add_batch3d_opacity(api.Batch3D.from_box(-0.6 + off, -0.6 - off, z, 1.2, 1.2, 0.02).with_computed_normals()
+                                  .source(B.PixelSource.Pixel((90, 120 + 10 * i, 250 - 20 * i, 120))).profile_id(10 + i))
+    for i in range(k):
+        z = -1.5 + 3.0 * i / max(1, k - 1)
+        chunk.add_batch3d(api.Batch3D.from_box(-1.5, -1.0, z - 0.2, 3.0, 2.0, 0.05).with_computed_normals()
+                          .source(B.PixelSource.Pixel((40 + 30 * i, 200 - 25 * i, 60, 255))).profile_id(10 + i))
+    if second_chunk:
+        c2 = scene.add_chunk()
+        c2.add_batch3d_opacity(api.Batch3D.from_box(-0.3, -0.3, 1.9, 0.9, 0.9, 0.02).with_computed_normals().source(B.PixelSource.Pixel((250, 90, 90, 100))).profile_id(99))
+        c2.add_batch3d(api.Batch3D.from_box(-1.0, -0.8, 1.7, 2.0, 1.6, 0.05).with_computed_normals().source(B.PixelSource.Pixel((200, 200, 40, 255))).profile_id(99))
+    scene.add_d3_static(api.Batch3D.from_box(-3.0, -3.0, -3.0, 6.0, 6.0, 0.1).with_computed_normals().source(B.PixelSource.Pixel((30, 220, 60, 255))))
+    cam = api.D3OrbitCamera.new()
+    cam.set_parameter_f32("distance", 4.5)
+    cam.azimuth = float(np.float32(np.pi / 2))
+    cam.elevation = 0.0
+
+    def setup():
+        v, p = cam.matrices(float(W), float(H))
+        return api.Rasterizer.setup(None, v, p).ambient((1.0, 1.0, 1.0, 1.0))
+
+    return scenes._result(api, scene, api.Assets.default(), setup, W, H, 40, f"{k}-panes-one-chunk")
+
+
+@pytest.mark.parametrize("k,second_chunk", [(4, False), (6, False), (6, True), (9, True)])
+def test_many_nested_panes_of_one_group_are_exact(oracle, product, k, second_chunk):
+    """the staircase keeps one entry per opacity GROUP (run of opacity batches without a profiled opaque batch between them): any
+    number of nested panes of one chunk is exact; before, the fourth was refused"""
+    got = compare(oracle, product, lambda api: panes_of_one_chunk_scene(api, k, second_chunk))
+    assert len(np.unique(got.reshape(-1, 4), axis=0)) >= 4
 
 
 def wall_before_the_pane_scene(api, pane_first):
