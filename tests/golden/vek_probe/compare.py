@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """Which rounding does vek 0.17.2 use?  usage: python3 compare.py probe.txt   (probe.txt = output of `cargo run --release`)
 
-For each of the four operations prints the variants of expected.txt that reproduce ALL 64 probe lines, next to the variant
+For each of the six operations prints the variants of expected.txt that reproduce ALL 64 probe lines, next to the variant
 include/rusterix_vek.hpp implements ("header").  If the header's variant is not among the matching ones, flip it there
-(RXR_VEK_FUSED_MATVEC for the matrix products; `normalized` / `lerp` by editing the two functions), rebuild, re-run the
+(RXR_VEK_FUSED_MATVEC for the matrix products; `normalized` / `lerp` / `dot` by editing the functions -- `dot3` of the device
+code, rusterix_amd/csrc/rxr_kernels.hip, follows the header's `dot`), rebuild, re-run the
 tests and regenerate tests/golden/ -- every consumer (oracle, host mirror, device kernels) includes that one header."""
 import collections
 import os
@@ -18,7 +19,7 @@ probe = {}
 for line in open(sys.argv[1]):
     case, op, *words = line.split()
     probe[(int(case), op)] = words
-for op in ("matvec", "matmat", "normalized", "lerp"):
+for op in ("matvec", "matmat", "normalized", "lerp", "dot", "magnitude"):
     variants = [v for v in exp[(0, op)] if v != "header"]
     matching = [v for v in variants if all(exp[(c, op)][v] == probe[(c, op)] for c in range(64))]
     header = [v for v in variants if all(exp[(c, op)][v] == exp[(c, op)]["header"] for c in range(64))]

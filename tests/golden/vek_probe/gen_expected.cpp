@@ -1,5 +1,5 @@
 // Writes the tables tests/golden/vek_probe/expected.txt is made of: for the same 64 seeded inputs as src/main.rs, the results
-// of every candidate rounding of the four vek operations, plus (variant "header") what include/rusterix_vek.hpp computes in
+// of every candidate rounding of the six vek operations, plus (variant "header") what include/rusterix_vek.hpp computes in
 // the mode this repository is built in.  Build: g++ -O2 -std=c++17 -ffp-contract=off -I../../../include gen_expected.cpp
 #include <cmath>
 #include <cstdint>
@@ -60,6 +60,17 @@ int main() {
         { float d[3]; for (int k = 0; k < 3; ++k) d[k] = a[k] + (b[k] - a[k]) * tc; hex("lerp", "unfused", i, d, 3); }
         { float d[3]; for (int k = 0; k < 3; ++k) d[k] = a[k] * (1.0f - tc) + b[k] * tc; hex("lerp", "precise", i, d, 3); }
         { rvek::Vec3 h = rvek::lerp(rvek::Vec3{a[0], a[1], a[2]}, rvek::Vec3{b[0], b[1], b[2]}, t); float hh[3] = {h.x, h.y, h.z}; hex("lerp", "header", i, hh, 3); }
+        // Vec3::dot: products summed left to right | right to left | accumulated with mul_add from either end
+        { float d = (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; hex("dot", "sum", i, &d, 1); }
+        { float d = a[0] * b[0] + (a[1] * b[1] + a[2] * b[2]); hex("dot", "sum_right", i, &d, 1); }
+        { float d = std::fmaf(a[2], b[2], std::fmaf(a[1], b[1], a[0] * b[0])); hex("dot", "mul_add", i, &d, 1); }
+        { float d = std::fmaf(a[0], b[0], std::fmaf(a[1], b[1], a[2] * b[2])); hex("dot", "mul_add_right", i, &d, 1); }
+        { float d = rvek::dot(rvek::Vec3{a[0], a[1], a[2]}, rvek::Vec3{b[0], b[1], b[2]}); hex("dot", "header", i, &d, 1); }
+        // Vec3::magnitude = sqrt(dot(v, v)) with the same candidates for the dot product
+        { float d = std::sqrt((a[0] * a[0] + a[1] * a[1]) + a[2] * a[2]); hex("magnitude", "sum", i, &d, 1); }
+        { float d = std::sqrt(a[0] * a[0] + (a[1] * a[1] + a[2] * a[2])); hex("magnitude", "sum_right", i, &d, 1); }
+        { float d = std::sqrt(std::fmaf(a[2], a[2], std::fmaf(a[1], a[1], a[0] * a[0]))); hex("magnitude", "mul_add", i, &d, 1); }
+        { float d = rvek::magnitude(rvek::Vec3{a[0], a[1], a[2]}); hex("magnitude", "header", i, &d, 1); }
     }
     return 0;
 }

@@ -1,5 +1,6 @@
 // Prints the bit patterns vek 0.17.2 produces for the four operations whose rounding the MI355X back end had to restate
-// without the crate's source (include/rusterix_vek.hpp): Mat4 * Vec4, Mat4 * Mat4, Vec3::normalized, Vec3::lerp.
+// without the crate's source (include/rusterix_vek.hpp): Mat4 * Vec4, Mat4 * Mat4, Vec3::normalized, Vec3::lerp, and the two
+// reductions the lighting code calls directly, Vec3::dot and Vec3::magnitude.
 // Build and run where cargo exists, then:  cargo run --release > probe.txt && python3 compare.py probe.txt
 // Inputs come from an integer LCG turned into floats by exact operations, identical in gen_expected.cpp.
 use vek::{Mat4, Vec3, Vec4};
@@ -38,5 +39,7 @@ fn main() {
         println!("{} matmat {}", i, hex(&mm.concat()));
         println!("{} normalized {}", i, hex(&[nv.x, nv.y, nv.z]));
         println!("{} lerp {}", i, hex(&[l.x, l.y, l.z]));
+        println!("{} dot {}", i, hex(&[a.dot(b)]));
+        println!("{} magnitude {}", i, hex(&[a.magnitude()]));
     }
 }

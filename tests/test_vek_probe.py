@@ -31,7 +31,7 @@ def test_expected_table_is_current(tmp_path):
 
 def test_header_implements_the_variants_the_docs_name_and_all_variants_differ(tmp_path):
     t = table(generate(tmp_path))
-    claimed = {"matvec": "fused", "matmat": "fused", "normalized": "div", "lerp": "mul_add"}
+    claimed = {"matvec": "fused", "matmat": "fused", "normalized": "div", "lerp": "mul_add", "dot": "sum", "magnitude": "sum"}
     for op, variant in claimed.items():
         assert all(t[(c, op)]["header"] == t[(c, op)][variant] for c in range(64)), op
         others = [v for v in t[(0, op)] if v not in ("header", variant)]
@@ -49,7 +49,7 @@ def test_compare_script_names_the_matching_variant(tmp_path):
     t = table(open(os.path.join(PROBE, "expected.txt")).read())
     probe = tmp_path / "probe.txt"
     # a fake probe: the unfused products, the reciprocal normalisation, the precise lerp
-    pick = {"matvec": "unfused", "matmat": "unfused", "normalized": "rcp", "lerp": "precise"}
+    pick = {"matvec": "unfused", "matmat": "unfused", "normalized": "rcp", "lerp": "precise", "dot": "mul_add", "magnitude": "mul_add"}
     probe.write_text("".join(f"{c} {op} {' '.join(t[(c, op)][pick[op]])}\n" for c in range(64) for op in pick))
     out = subprocess.run([sys.executable, os.path.join(PROBE, "compare.py"), str(probe)], check=True, capture_output=True, text=True).stdout
     for op, variant in pick.items():
