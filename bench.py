@@ -35,6 +35,11 @@ sys.path.insert(0, ROOT)
 PROFILE_STRIDE = int(os.environ.get("RXR_BENCH_PROFILE_STRIDE", "8"))  # every 8th frame of the timed region carries HIP events around its kernels
 MIN_TIMED_S = float(os.environ.get("RXR_BENCH_MIN_TIMED_S", "1.0"))
 MAX_BATCHES = 5000
+# Rehearsal of the N > 1 code path on a box with ONE GPU (tests/test_gpu_bench_rehearsal.py): every rank uses GPU 0 and the exchange
+# goes through gloo with host staging, because RCCL refuses two ranks on one device.  Everything else -- rank bookkeeping, stripes,
+# pipelining indices, the byte-identity check, the multi-device end-to-end leg, the JSON line -- is the code the driver runs.  The
+# line says "rehearsal": true and its numbers mean nothing.
+REHEARSAL = os.environ.get("RXR_BENCH_REHEARSAL") == "1"
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 vector (FMA counted as 2)
 
@@ -77,14 +82,14 @@ def spawn_ranks(args):
     import torch
 
     have = torch.cuda.device_count()
-    if have < args.gpus:
+    if have < args.gpus and not REHEARSAL:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) are visible")
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     procs = []
     for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK="0" if REHEARSAL else str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     rc = 0
@@ -126,7 +131,11 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if REHEARSAL:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    ctl = "cpu" if REHEARSAL else "cuda"  # where the control-plane tensors (timings, batch count) live
 
     import rusterix_amd
     from rusterix_amd import distributed as D
@@ -164,7 +173,7 @@ def main():
     if not sharded:
         frames = [torch.empty((H, W, 4), dtype=torch.uint8, device="cuda") for _ in range(NBUF)]
     else:
-        gather = D.StripeGather(H, W, world, rank, device="cuda", nbuf=NBUF, mode=args.exchange)
+        gather = D.StripeGather(H, W, world, rank, device="cuda", nbuf=NBUF, mode=args.exchange, host_staged=REHEARSAL)
         frames = gather.frames  # None on ranks that do not own the frame (gather mode: only rank 0 does)
 
     def run(n):
@@ -197,7 +206,7 @@ def main():
         fence()
         dt = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            t = torch.tensor([dt], dtype=torch.float64, device=ctl)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt
@@ -210,7 +219,7 @@ def main():
     first = timed_batch()  # sizes the run (timed like the others, not discarded)
     n_batches = int(min(MAX_BATCHES, max(1, np.ceil(1.25 * MIN_TIMED_S / max(first, 1e-6)))))
     if world > 1:
-        nb = torch.tensor([n_batches], dtype=torch.int64, device="cuda")
+        nb = torch.tensor([n_batches], dtype=torch.int64, device=ctl)
         dist.broadcast(nb, src=0)
         n_batches = int(nb.item())
     ring = min(65536, n_batches * args.steps // PROFILE_STRIDE + args.steps + 8)
@@ -270,6 +279,7 @@ def main():
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True,
             "scaling": "strong",
+            **({"rehearsal": True} if REHEARSAL else {}),
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
@@ -331,7 +341,7 @@ def end_to_end(prod, host, rxr, cfg, W, H, world):
     from rusterix_amd import scenes
 
     if world > 1:
-        ids = (C.c_int * world)(*range(world))
+        ids = (C.c_int * world)(*([0] * world if REHEARSAL else range(world)))
         host.rxh_set_devices(ids, world)
     out = np.zeros(W * H * 4, np.uint8)
 

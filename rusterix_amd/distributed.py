@@ -71,11 +71,15 @@ class StripeGather:
     mode "allgather" : dist.all_gather_into_tensor (every rank assembles the frame)
     """
 
-    def __init__(self, height: int, width: int, world: int, rank: int, device, nbuf: int = 2, mode: str = "gather", root: int = 0):
+    def __init__(self, height: int, width: int, world: int, rank: int, device, nbuf: int = 2, mode: str = "gather", root: int = 0,
+                 host_staged: bool = False):
         import torch
 
         assert mode in ("gather", "allgather")
         self.h, self.w, self.world, self.rank, self.mode, self.root = height, width, world, rank, mode, root
+        # host_staged: the collective runs on host copies of the bands (a backend without device collectives: bench.py's
+        # one-GPU rehearsal over gloo); synchronous, for rehearsals only
+        self.host_staged = host_staged
         self.spr = stripes_per_rank(height, world)
         rows = self.spr * TILE_H
         self.nbuf = nbuf
@@ -108,6 +112,20 @@ class StripeGather:
         b = i % self.nbuf
         if self.world == 1:
             self.gathered[b].copy_(self.bands[b])
+        elif self.host_staged:
+            import torch
+
+            torch.cuda.current_stream().synchronize()  # (the render of frame i was queued on the current stream)
+            mine = self.bands[b].cpu()
+            if self.mode == "allgather":
+                parts = [torch.empty_like(mine) for _ in range(self.world)]
+                dist.all_gather(parts, mine)
+            else:
+                parts = [torch.empty_like(mine) for _ in range(self.world)] if self.rank == self.root else None
+                dist.gather(mine, parts, dst=self.root)
+            if self.owns_frame:
+                for r in range(self.world):
+                    self.slots[b][r].copy_(parts[r])
         elif self.mode == "allgather":
             self._work[b] = dist.all_gather_into_tensor(self.gathered[b], self.bands[b], async_op=True)
         else:

@@ -1,0 +1,29 @@
+"""bench.py's N > 1 path, rehearsed on ONE GPU (RXR_BENCH_REHEARSAL=1: both ranks on GPU 0, exchange over gloo with host staging --
+RCCL refuses two ranks on a device).  No multi-GPU hardware is available to the builder, so this is what keeps the rank
+bookkeeping, the stripe partition, the pipelining indices, the byte-identity check against the single-launch frame (asserted
+inside bench.py), the multi-device end-to-end leg and the JSON line from being run for the first time by the driver."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("world,exchange", [(2, "gather"), (3, "allgather")])
+def test_bench_runs_its_multi_rank_path(world, exchange):
+    env = dict(os.environ, RXR_BENCH_REHEARSAL="1", RXR_BENCH_MIN_TIMED_S="0.05")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    pr = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "6", "--warmup", "2", "--no-cpu",
+                         "--width", "1280", "--height", "720", "--exchange", exchange], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert pr.returncode == 0, pr.stdout[-2000:] + pr.stderr[-4000:]
+    lines = [l for l in pr.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, pr.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == world and d["rehearsal"] is True and d["steps"] == 6
+    assert f"{world} GPUs" in d["config"]["sharding"] and exchange in d["config"]["sharding"]
+    assert d["value"] > 0 and "e2e_ms" in d and f"{world} GPUs" in d["e2e_what"]
