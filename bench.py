@@ -69,8 +69,9 @@ def parse_args():
     ap.add_argument("--lights", type=int, default=16)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
-    ap.add_argument("--exchange", choices=["gather", "allgather"], default="gather",
-                    help="N>1: gather the stripes to rank 0 (default, what the north-star asks for) or all-gather them")
+    ap.add_argument("--exchange", choices=["gather", "allgather", "rotate"], default="gather",
+                    help="N>1: gather the stripes to rank 0 (default, what the north-star asks for), all-gather them, or gather frame i "
+                         "to rank i mod N (every frame still whole on one GPU, but no single GPU's links carry every frame)")
     ap.add_argument("--force-gather", action="store_true",
                     help="debug: run the stripe -> gather -> assemble path even at N=1 (never used by the driver)")
     return ap.parse_args()
@@ -240,7 +241,8 @@ def main():
     setup_avg_us = float(np.mean(setup_us[: n_prof.value])) if n_prof.value else float("nan")
 
     # sanity (on the rank that owns the assembled frame): not empty, every pixel resolved
-    if frames is not None:
+    last_root = gather.root_of(args.steps - 1) if sharded else 0
+    if frames is not None and (not sharded or args.exchange != "rotate" or rank == last_root):
         final = frames[(args.steps - 1) % NBUF][:H]
         assert int(final[..., 3].min().item()) == 255 and int(final[..., :3].max().item()) > 0, "benchmark frame is not a rendered frame"
         if sharded:
@@ -296,7 +298,8 @@ def main():
                 "resolution": [W, H],
                 "triangles_3d": n_tris,
                 "sharding": "single GPU" if world == 1 else f"interleaved 16-row stripes over {world} GPUs (one process per GPU) + RCCL {args.exchange} "
-                                                           "to rank 0 over xGMI, pipelined with the next frame's render",
+                                                           + ("to rank (frame mod N)" if args.exchange == "rotate" else "to rank 0")
+                                                           + " over xGMI, pipelined with the next frame's render",
             },
             "roofline": {
                 "bound": "hbm",

@@ -69,13 +69,16 @@ class StripeGather:
 
     mode "gather"    : dist.gather to `root` (default; only the root assembles and owns the frame)
     mode "allgather" : dist.all_gather_into_tensor (every rank assembles the frame)
+    mode "rotate"    : dist.gather to rank (i mod world) for frame i: every frame is still gathered whole, but the root -- whose
+                       N-1 incoming links bound the fixed-root gather -- changes from frame to frame, so all N*(N-1) directed
+                       xGMI links carry traffic (a consumer per GPU: encoders, displays, N-way multi-view)
     """
 
     def __init__(self, height: int, width: int, world: int, rank: int, device, nbuf: int = 2, mode: str = "gather", root: int = 0,
                  host_staged: bool = False):
         import torch
 
-        assert mode in ("gather", "allgather")
+        assert mode in ("gather", "allgather", "rotate")
         self.h, self.w, self.world, self.rank, self.mode, self.root = height, width, world, rank, mode, root
         # host_staged: the collective runs on host copies of the bands (a backend without device collectives: bench.py's
         # one-GPU rehearsal over gloo); synchronous, for rehearsals only
@@ -84,7 +87,7 @@ class StripeGather:
         rows = self.spr * TILE_H
         self.nbuf = nbuf
         self.bands = [torch.zeros((rows, width, 4), dtype=torch.uint8, device=device) for _ in range(nbuf)]
-        self.owns_frame = mode == "allgather" or rank == root or world == 1
+        self.owns_frame = mode in ("allgather", "rotate") or rank == root or world == 1
         if self.owns_frame:
             self.gathered = [torch.zeros((world * rows, width, 4), dtype=torch.uint8, device=device) for _ in range(nbuf)]
             self.frames = [torch.zeros((self.spr * world * TILE_H, width, 4), dtype=torch.uint8, device=device) for _ in range(nbuf)]
@@ -96,6 +99,10 @@ class StripeGather:
 
     def band(self, i):
         return self.bands[i % self.nbuf]
+
+    def root_of(self, i):
+        """the rank on which frame i is assembled (every rank in all-gather mode: then this names rank 0)"""
+        return i % self.world if self.mode == "rotate" else self.root
 
     def exchange(self, i):
         """Blocking form: returns the assembled frame (height x width x 4) on ranks that own it, else None."""
@@ -121,21 +128,23 @@ class StripeGather:
                 parts = [torch.empty_like(mine) for _ in range(self.world)]
                 dist.all_gather(parts, mine)
             else:
-                parts = [torch.empty_like(mine) for _ in range(self.world)] if self.rank == self.root else None
-                dist.gather(mine, parts, dst=self.root)
-            if self.owns_frame:
+                root = self.root_of(i)
+                parts = [torch.empty_like(mine) for _ in range(self.world)] if self.rank == root else None
+                dist.gather(mine, parts, dst=root)
+            if parts is not None:
                 for r in range(self.world):
                     self.slots[b][r].copy_(parts[r])
         elif self.mode == "allgather":
             self._work[b] = dist.all_gather_into_tensor(self.gathered[b], self.bands[b], async_op=True)
         else:
-            self._work[b] = dist.gather(self.bands[b], self.slots[b] if self.rank == self.root else None, dst=self.root, async_op=True)
+            root = self.root_of(i)
+            self._work[b] = dist.gather(self.bands[b], self.slots[b] if self.rank == root else None, dst=root, async_op=True)
 
     def exchange_end(self, i):
         b = i % self.nbuf
         w = self._work.pop(b, None)
         if w is not None:
             w.wait()
-        if not self.owns_frame:
+        if not self.owns_frame or (self.mode == "rotate" and self.world > 1 and self.rank != self.root_of(i)):
             return None
         return assemble_torch(self.gathered[b], self.h, self.w, self.world, out=self.frames[b])

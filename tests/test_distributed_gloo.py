@@ -37,7 +37,7 @@ def _worker(rank, world, port, frame, result_dir, mode):
 
         def check(i, out):
             nonlocal ok
-            if g.owns_frame:
+            if g.owns_frame and (mode != "rotate" or rank == g.root_of(i)):  # (rotate: frame i lives on rank i mod world only)
                 ok &= out is not None and np.array_equal(out.numpy(), want(i))
             else:
                 ok &= out is None
@@ -59,7 +59,7 @@ def _worker(rank, world, port, frame, result_dir, mode):
 
 
 @pytest.mark.parametrize("world,size,mode", [(2, (360, 640), "gather"), (3, (203, 77), "gather"), (2, (16, 32), "gather"),
-                                             (2, (100, 64), "allgather")])
+                                             (2, (100, 64), "allgather"), (3, (120, 48), "rotate"), (2, (64, 40), "rotate")])
 def test_stripe_exchange_roundtrip(tmp_path, oracle, world, size, mode):
     from rusterix_amd import scenes
 
@@ -71,7 +71,7 @@ def test_stripe_exchange_roundtrip(tmp_path, oracle, world, size, mode):
         ok, owns = np.load(tmp_path / f"ok{r}.npy")
         assert ok, f"rank {r} assembled a wrong frame"
         owners += int(owns)
-    assert owners == (world if mode == "allgather" else 1)
+    assert owners == (world if mode in ("allgather", "rotate") else 1)
 
 
 def test_partition_covers_every_row_once():

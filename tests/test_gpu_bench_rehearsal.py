@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("world,exchange", [(2, "gather"), (3, "allgather")])
+@pytest.mark.parametrize("world,exchange", [(2, "gather"), (3, "allgather"), (3, "rotate")])
 def test_bench_runs_its_multi_rank_path(world, exchange):
     env = dict(os.environ, RXR_BENCH_REHEARSAL="1", RXR_BENCH_MIN_TIMED_S="0.05")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
