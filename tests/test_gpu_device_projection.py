@@ -71,6 +71,17 @@ SCENES = [
 ]
 
 
+def _panes(api, **kw):
+    """six nested panes of one chunk + a second chunk (tests/test_gpu_chunks.py): chunk lists, opacity groups and surface_id with
+    device-projected meshes"""
+    from tests.test_gpu_chunks import panes_of_one_chunk_scene
+
+    return panes_of_one_chunk_scene(api, **kw)
+
+
+SCENES.append(("nested_panes", _panes, dict(k=6, second_chunk=True)))
+
+
 @pytest.mark.parametrize("name,builder,kw", SCENES, ids=[s[0] for s in SCENES])
 def test_frames_identical_to_host_projection(product, devproj, name, builder, kw):
     devproj.off()
@@ -83,7 +94,7 @@ def test_frames_identical_to_host_projection(product, devproj, name, builder, kw
     assert np.array_equal(again, want)
 
 
-@pytest.mark.parametrize("name,builder,kw", SCENES[:4] + SCENES[5:], ids=[s[0] for s in SCENES[:4] + SCENES[5:]])
+@pytest.mark.parametrize("name,builder,kw", SCENES[:4] + SCENES[5:6], ids=[s[0] for s in SCENES[:4] + SCENES[5:6]])  # (scenes of static batches only)
 def test_projected_arrays_match_host_mirror(product, devproj, name, builder, kw):
     # host mirror projection (bit-identical to the oracle: tests/test_host_and_abi.py)
     devproj.off()
