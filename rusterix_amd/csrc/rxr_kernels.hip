@@ -100,6 +100,9 @@ struct f3 {
 // load is unclobbered and issues it as a VECTOR load plus v_readfirstlane -- for the lights that was an L2 round trip per light and
 // wave on the critical path of the light loop (seen in the ISA: global_load_dwordx4 ... s_waitcnt vmcnt ... v_readfirstlane).
 // Only fields that are used are loaded.  The tables (lights, linedefs) are written by the upload and never by a kernel.
+#ifndef RXR_UNIFORM_2D_BATCH
+#define RXR_UNIFORM_2D_BATCH 1
+#endif
 #ifndef RXR_UNIFORM_SCALAR_LOADS
 #define RXR_UNIFORM_SCALAR_LOADS 1
 #endif
@@ -473,7 +476,9 @@ __device__ __forceinline__ uint32_t brush_over_texel(const RasterParams &P, uint
 
 // the texel switch of the raster loops (rasterizer.rs:1101-1222, :672-758); (wx, wy) is the position terrain batches sample at;
 // `world3`: the fragment's world position in the two 3D loops (terrain brush preview), nullptr in the 2D loop
-template <int X>
+// UNIFORM: `B` is the same batch for every lane (the 2D pass walks one primitive at a time) -- its texture descriptor then
+// comes through the scalar cache like the batch header itself (uniform_record)
+template <int X, bool UNIFORM = false>
 __device__ __forceinline__ uint32_t batch_texel(const RasterParams &P, const DevBatch &B, float u, float v, float wx, float wy, const f3 *world3 = nullptr) {
     if (B.tex < 0) return B.pixel;
     if constexpr (X >= 1) {
@@ -483,8 +488,13 @@ __device__ __forceinline__ uint32_t batch_texel(const RasterParams &P, const Dev
             return t;
         }
     }
-    const DevTexDesc &d = P.tex[B.tex];
-    return sample_texture(d, texel_base(P, d), u, v, P.sample_mode, B.repeat_mode);
+    if constexpr (UNIFORM) {
+        const DevTexDesc d = uniform_record(P.tex, (uint32_t)B.tex);
+        return sample_texture(d, texel_base(P, d), u, v, P.sample_mode, B.repeat_mode);
+    } else {
+        const DevTexDesc &d = P.tex[B.tex];
+        return sample_texture(d, texel_base(P, d), u, v, P.sample_mode, B.repeat_mode);
+    }
 }
 
 // Feature levels (template parameter X of the raster code): 0 common, 1 chunk paths, 2 + programs with the interpreter inlined
@@ -787,7 +797,7 @@ __device__ __forceinline__ uint32_t fragment2d(const RasterParams &P, const Prim
     float gy = ((float)py - P.fheight / 2.0f) - (P.translationd2[1] - P.fheight / 2.0f);
     float wx = gx / P.scaled2, wy = gy / P.scaled2;
 
-    uint32_t texel = batch_texel<X>(P, B, u, v, wx, wy);  // 2D terrain: chunk.sample_terrain_texture(world, ..), :749-751
+    uint32_t texel = batch_texel<X, RXR_UNIFORM_2D_BATCH != 0>(P, B, u, v, wx, wy);  // 2D terrain: chunk.sample_terrain_texture(world, ..), :749-751
     if constexpr (X >= 2) {
         if (B.program_plus1 && P.programs[B.program_plus1 - 1u].shade_entry != 0xFFFFFFFFu) {  // :760-797
             const float INV_255 = 1.0f / 255.0f;  // pixel_to_vec4, lib.rs:52-62
@@ -2122,7 +2132,15 @@ __device__ __forceinline__ uint32_t prim2d_pixel(const RasterParams &P, const Pr
     float r1 = T.ea[1] * fx + T.eb[1] * fy + T.ec[1];
     float r2 = T.ea[2] * fx + T.eb[2] * fy + T.ec[2];
     in = in && !(r0 < 0.0f) && !(r1 < 0.0f) && !(r2 < 0.0f);
-    if (in) color = fragment2d<X>(P, T, P.batches2d[T.batch_kind >> 2], px, py, fx, fy, color);
+    if (in) {
+        // (the primitive is the same for every lane: its batch header comes through the scalar cache, not as a vector load per wave)
+#if RXR_UNIFORM_2D_BATCH
+        const DevBatch B = uniform_record(P.batches2d, T.batch_kind >> 2);
+        color = fragment2d<X>(P, T, B, px, py, fx, fy, color);
+#else
+        color = fragment2d<X>(P, T, P.batches2d[T.batch_kind >> 2], px, py, fx, fy, color);
+#endif
+    }
     return color;
 }
 
