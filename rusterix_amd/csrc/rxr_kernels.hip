@@ -175,6 +175,9 @@ __device__ __forceinline__ void mat4_mul(const float *m, float x, float y, float
 // `x as u8` / `as u32` with Rust semantics (saturate, NaN -> 0): the saturating hardware conversion (rxm::sat_u32) and an
 // integer minimum -- two instructions where the compare-and-select form needs five
 __device__ __forceinline__ uint32_t sat_u8(float x) { return min(rxm::sat_u32(x), 255u); }
+// byte / 255.0 -- the correctly rounded quotient of the reference (NOT byte * (1/255): T5 keeps the two apart) -- through the short
+// division chain of rxr_exact_math.h: the operands are statically inside its window, +0 included (selftest kind "static")
+__device__ __forceinline__ float byte_over_255(uint32_t b) { return rxm::div1_known((float)b, 255.0f, true); }
 __device__ __forceinline__ uint32_t sat_u32(float x) { return rxm::sat_u32(x); }
 // `x as usize` followed by a clamp to [0, hi] (hi < 2^31)
 __device__ __forceinline__ uint32_t sat_index(float x, uint32_t hi) { return min(rxm::sat_u32(x), hi); }
@@ -751,7 +754,7 @@ __device__ __forceinline__ uint32_t shade3d_opacity(const RasterParams &P, const
     float r = srgb_to_linear_fast((float)(texel & 0xFFu) * INV_255);
     float g = srgb_to_linear_fast((float)((texel >> 8) & 0xFFu) * INV_255);
     float b = srgb_to_linear_fast((float)((texel >> 16) & 0xFFu) * INV_255);
-    float opacity = (float)(texel >> 24) / 255.0f;
+    float opacity = byte_over_255(texel >> 24);
     if constexpr (X >= 2) {
         if (B.program_plus1) {  // :1642-1667
             rxvm::IO io;
@@ -853,13 +856,13 @@ __device__ __forceinline__ uint32_t fragment2d(const RasterParams &P, const Prim
         acc0 = rclamp(acc0, 0.0f, 1.0f);
         acc1 = rclamp(acc1, 0.0f, 1.0f);
         acc2 = rclamp(acc2, 0.0f, 1.0f);
-        tr = sat_u8(rclamp(((float)tr / 255.0f) * acc0 * 255.0f, 0.0f, 255.0f));
-        tg = sat_u8(rclamp(((float)tg / 255.0f) * acc1 * 255.0f, 0.0f, 255.0f));
-        tb = sat_u8(rclamp(((float)tb / 255.0f) * acc2 * 255.0f, 0.0f, 255.0f));
+        tr = sat_u8(rclamp((byte_over_255(tr) * acc0) * 255.0f, 0.0f, 255.0f));
+        tg = sat_u8(rclamp((byte_over_255(tg) * acc1) * 255.0f, 0.0f, 255.0f));
+        tb = sat_u8(rclamp((byte_over_255(tb) * acc2) * 255.0f, 0.0f, 255.0f));
     }
 
     if (ta == 255u) return pack4(tr, tg, tb, ta);  // :878-879
-    float src_alpha = (float)ta / 255.0f;
+    float src_alpha = byte_over_255(ta);
     float dst_alpha = 1.0f - src_alpha;
     uint32_t dr = dst & 0xFFu, dg = (dst >> 8) & 0xFFu, db = (dst >> 16) & 0xFFu, da = dst >> 24;
     uint32_t orr = sat_u8(((float)tr * src_alpha) + ((float)dr * dst_alpha));
@@ -2338,9 +2341,9 @@ __device__ __forceinline__ void raster_tile(const RasterParams &P) {
         if (op.best >= 0 && op.zmin < 1.0f && vis.zmin > op.zmin) {  // :464-495
             uint32_t src = op_color;
             float src_r = (float)(src & 0xFFu), src_g = (float)((src >> 8) & 0xFFu), src_b = (float)((src >> 16) & 0xFFu);
-            float src_a = (float)(src >> 24) / 255.0f;
+            float src_a = byte_over_255(src >> 24);
             float dst_r = (float)(color & 0xFFu), dst_g = (float)((color >> 8) & 0xFFu), dst_b = (float)((color >> 16) & 0xFFu);
-            float dst_a = (float)(color >> 24) / 255.0f;
+            float dst_a = byte_over_255(color >> 24);
             float inv_a = 1.0f - src_a;
             float out_r = src_r * src_a + dst_r * inv_a;
             float out_g = src_g * src_a + dst_g * inv_a;
