@@ -7,7 +7,7 @@ from rusterix_amd.binding import make_api
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
-ORACLE_SO = os.path.join(ORACLE_DIR, "librusterix_oracle.so")
+ORACLE_SO = os.environ.get("RXR_ORACLE_SO") or os.path.join(ORACLE_DIR, "librusterix_oracle.so")  # (tools/sanitize_cpu.sh points this at the ASan build)
 
 _cached = None
 
@@ -20,7 +20,7 @@ def load_oracle():
     global _cached
     if _cached is None:
         srcs = [os.path.join(ORACLE_DIR, f) for f in ("rusterix_oracle.cpp", "oracle_capi.cpp", "rusterix_oracle.hpp", "rusteria_vm.hpp")]
-        if not os.path.exists(ORACLE_SO) or any(os.path.getmtime(s) > os.path.getmtime(ORACLE_SO) for s in srcs):
+        if not os.environ.get("RXR_ORACLE_SO") and (not os.path.exists(ORACLE_SO) or any(os.path.getmtime(s) > os.path.getmtime(ORACLE_SO) for s in srcs)):
             build_oracle()
         lib = ctypes.CDLL(ORACLE_SO)
         api = make_api(lib, "orc_", "oracle")
