@@ -9,8 +9,9 @@ _cached = None
 
 
 def lib_paths():
-    # RXR_HOST_SO: another build of the host mirror (tools/sanitize_cpu.sh: AddressSanitizer); the device library is always the in-tree one
-    return dict(rxr=os.path.join(_HERE, "csrc", "librxr_hip.so"), host=os.environ.get("RXR_HOST_SO") or os.path.join(_HERE, "csrc", "librusterix_host.so"))
+    # RXR_HOST_SO / RXR_DEVICE_SO: other builds of the two libraries (tools/sanitize_cpu.sh: host code under AddressSanitizer)
+    return dict(rxr=os.environ.get("RXR_DEVICE_SO") or os.path.join(_HERE, "csrc", "librxr_hip.so"),
+                host=os.environ.get("RXR_HOST_SO") or os.path.join(_HERE, "csrc", "librusterix_host.so"))
 
 
 def load_rxr():
