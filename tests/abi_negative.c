@@ -1,0 +1,201 @@
+/* The C ABI from a plain C caller's side, on a machine WITH a GPU: one valid frame, then the same frame with one thing wrong at
+ * a time -- every malformed frame must come back as an error status with a message (never a crash, never RXR_OK), and the context
+ * must render the valid frame again afterwards.  Built and run by tests/test_gpu_abi_negative.py (gcc -std=c11 -Wall -Werror).
+ * The reference panics on most of these inputs (index out of range, step_by(0), Option::unwrap); the boundary reports. */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "rxr.h"
+
+#define W 64u
+#define H 48u
+
+static float verts[3][4] = {{4.0f, 4.0f, 0.5f, 1.0f}, {60.0f, 6.0f, 0.5f, 1.0f}, {30.0f, 44.0f, 0.5f, 1.0f}};
+static float uvs[3][2] = {{0.0f, 0.0f}, {1.0f, 0.0f}, {0.0f, 1.0f}};
+/* (a batch without normals shades to NaN -> 0 as in the reference, and a normal along y is flipped towards the camera and meets the
+ * hemisphere term 0.5 * (n.y + 1) at 0 in the upper half of this frame: z keeps it at 0.5) */
+static float normals[3][3] = {{0.0f, 0.0f, 1.0f}, {0.0f, 0.0f, 1.0f}, {0.0f, 0.0f, 1.0f}};
+static uint32_t idx[3] = {0, 1, 2};
+static rxr_edges edges = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}, {1.0f, 1.0f, 1.0f}, 1u}; /* r = c = 1: every pixel of the box passes */
+static float verts2[4][2] = {{8.0f, 8.0f}, {24.0f, 8.0f}, {24.0f, 20.0f}, {8.0f, 20.0f}};
+static float uvs2[4][2] = {{0.0f, 0.0f}, {1.0f, 0.0f}, {1.0f, 1.0f}, {0.0f, 1.0f}};
+static uint32_t idx2[6] = {0, 1, 2, 0, 2, 3};
+static rxr_edges edges2[2] = {{{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}, {1.0f, 1.0f, 1.0f}, 1u}, {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}, {1.0f, 1.0f, 1.0f}, 1u}};
+static rxr_light light;
+static rxr_batch3d b3;
+static rxr_batch2d b2;
+static rxr_frame base;
+
+static void identity(float *m) {
+    memset(m, 0, 64);
+    m[0] = m[5] = m[10] = m[15] = 1.0f;
+}
+
+static void make_valid(void) {
+    memset(&b3, 0, sizeof b3);
+    b3.projected_vertices = &verts[0][0];
+    b3.clipped_uvs = &uvs[0][0];
+    b3.clipped_normals = &normals[0][0];
+    b3.clipped_indices = idx;
+    b3.edges = &edges;
+    b3.n_vertices = 3;
+    b3.n_triangles = 1;
+    b3.has_bounding_box = 1;
+    b3.bounding_box[0] = 4.0f; b3.bounding_box[1] = 4.0f; b3.bounding_box[2] = 56.0f; b3.bounding_box[3] = 40.0f;
+    b3.source.kind = RXR_SOURCE_PIXEL;
+    b3.source.pixel[0] = 200; b3.source.pixel[1] = 40; b3.source.pixel[2] = 90; b3.source.pixel[3] = 255;
+    b3.ambient_color[0] = b3.ambient_color[1] = b3.ambient_color[2] = 1.0f;
+    b3.shader = -1;
+    b3.list = RXR_LIST_STATIC;
+    b3.chunk = -1;
+    memset(&b2, 0, sizeof b2);
+    b2.projected_vertices = &verts2[0][0];
+    b2.uvs = &uvs2[0][0];
+    b2.indices = idx2;
+    b2.edges = edges2;
+    b2.n_vertices = 4;
+    b2.n_triangles = 2;
+    b2.has_bounding_box = 1;
+    b2.bounding_box[0] = 8.0f; b2.bounding_box[1] = 8.0f; b2.bounding_box[2] = 16.0f; b2.bounding_box[3] = 12.0f;
+    b2.mode = RXR_MODE_TRIANGLES;
+    b2.source.kind = RXR_SOURCE_PIXEL;
+    b2.source.pixel[0] = 10; b2.source.pixel[1] = 220; b2.source.pixel[2] = 30; b2.source.pixel[3] = 255;
+    b2.shader = -1;
+    b2.chunk = -1;
+    memset(&light, 0, sizeof light);
+    light.emitting = 1;
+    light.intensity = 1.0f;
+    light.end_distance = 10.0f;
+    memset(&base, 0, sizeof base);
+    base.abi_version = RXR_ABI_VERSION;
+    base.width = W;
+    base.height = H;
+    base.tile_size = 16;
+    identity(base.inverse_view);
+    identity(base.inverse_projection);
+    identity(base.view);
+    identity(base.projection);
+    base.scaled2 = 1.0f;
+    base.flags = RXR_FLAG_D2_ACTIVE | RXR_FLAG_D3_ACTIVE;
+    base.batches3d = &b3;
+    base.n_batches3d = 1;
+    base.batches2d = &b2;
+    base.n_batches2d = 1;
+}
+
+static int failures = 0;
+static uint8_t pixels[W * H * 4];
+
+/* the frame is wrong: expect an error status, a message, and no crash */
+static void expect_error(rxr_ctx *ctx, const char *what, const rxr_frame *f) {
+    int rc = rxr_rasterize(ctx, f, pixels);
+    const char *msg = rxr_last_error(ctx);
+    printf("%-44s rc=%d %s\n", what, rc, rc < 0 && msg ? msg : "");
+    if (rc >= 0 || !msg || !msg[0]) {
+        printf("  ^^^ FAILED: a malformed frame must be answered with an error status and a message\n");
+        ++failures;
+    }
+}
+
+static void expect_valid(rxr_ctx *ctx, const char *when) {
+    make_valid();
+    memset(pixels, 0, sizeof pixels);
+    int rc = rxr_rasterize(ctx, &base, pixels);
+    const uint8_t *p3 = &pixels[(20u * W + 30u) * 4u], *p2 = &pixels[(12u * W + 12u) * 4u];
+    /* the 3D fragment: the batch colour under its own ambient term only (darker than 200, 40, 90, same order); the 2D one: as is */
+    int ok = rc == RXR_OK && p3[0] > 90 && p3[0] <= 200 && p3[0] > p3[2] && p3[2] > p3[1] && p3[3] == 255 && p2[0] == 10 && p2[1] == 220 && p2[2] == 30;
+    printf("%-44s rc=%d pixel3d=%u,%u,%u,%u pixel2d=%u,%u,%u\n", when, rc, p3[0], p3[1], p3[2], p3[3], p2[0], p2[1], p2[2]);
+    if (!ok) {
+        printf("  ^^^ FAILED: the valid frame must render (%s)\n", rxr_last_error(ctx));
+        ++failures;
+    }
+}
+
+int main(void) {
+    rxr_ctx *ctx = NULL;
+    int rc = rxr_create(&ctx, 0);
+    if (rc != RXR_OK) {
+        printf("rxr_create: %d\n", rc);
+        return 2;
+    }
+    expect_valid(ctx, "valid frame");
+    rxr_frame f;
+    rxr_batch3d m3;
+    rxr_batch2d m2;
+    uint32_t bad_idx[3] = {0, 1, 3};
+    uint32_t bad_idx2[6] = {0, 1, 2, 0, 2, 4};
+#define FRAME(stmt, what) do { make_valid(); f = base; stmt; expect_error(ctx, what, &f); } while (0)
+#define BATCH3(stmt, what) do { make_valid(); f = base; m3 = b3; stmt; f.batches3d = &m3; expect_error(ctx, what, &f); } while (0)
+#define BATCH2(stmt, what) do { make_valid(); f = base; m2 = b2; stmt; f.batches2d = &m2; expect_error(ctx, what, &f); } while (0)
+    FRAME(f.abi_version = RXR_ABI_VERSION - 1u, "abi_version of an older header");
+    FRAME(f.width = 0, "width 0");
+    FRAME(f.height = 0, "height 0");
+    FRAME(f.width = 40000, "width 40000");
+    FRAME(f.tile_size = 0, "tile_size 0");
+    FRAME(f.batches3d = NULL, "n_batches3d without batches3d");
+    FRAME(f.batches2d = NULL, "n_batches2d without batches2d");
+    FRAME(f.n_lights = 2, "n_lights without lights");
+    FRAME(f.n_occluders = 1, "n_occluders without occluders");
+    FRAME(f.n_linedefs = 1, "n_linedefs without linedefs");
+    FRAME(f.n_chunks = 1, "n_chunks without chunks");
+    FRAME(f.background_kind = 9, "unknown background_kind");
+    FRAME(f.background_kind = RXR_BG_HOST_PIXELS, "host background without pixels");
+    FRAME(f.n_shader_programs = 3, "n_shader_programs beyond rxr_set_shaders");
+    FRAME(f.use_meshes = 1, "use_meshes together with batches3d");
+    BATCH3(m3.clipped_indices = NULL, "3D batch: triangles without indices");
+    BATCH3(m3.edges = NULL, "3D batch: triangles without edges");
+    BATCH3(m3.projected_vertices = NULL, "3D batch: vertices without positions");
+    BATCH3(m3.clipped_uvs = NULL, "3D batch: vertices without uvs");
+    BATCH3(m3.clipped_indices = bad_idx, "3D batch: vertex index out of range");
+    BATCH3(m3.chunk = 0, "3D batch: chunk index without chunks");
+    BATCH3((m3.source.kind = RXR_SOURCE_STATIC_TILE, m3.source.index = 5), "3D batch: tile index beyond the tile list");
+    BATCH3((m3.source.kind = RXR_SOURCE_DYNAMIC_TILE, m3.source.index = 0), "3D batch: dynamic tile without dynamic tiles");
+    BATCH3(m3.source.kind = RXR_HOST_SOURCE_ENTITY_TILE, "3D batch: a host-side-only source kind");
+    BATCH2(m2.indices = NULL, "2D batch: triangles without indices");
+    BATCH2(m2.edges = NULL, "2D batch: triangles without edges");
+    BATCH2(m2.projected_vertices = NULL, "2D batch: vertices without positions");
+    BATCH2(m2.uvs = NULL, "2D batch: vertices without uvs");
+    BATCH2(m2.indices = bad_idx2, "2D batch: vertex index out of range");
+    BATCH2(m2.mode = 9, "2D batch: unknown mode");
+    BATCH2(m2.chunk = 2, "2D batch: chunk index without chunks");
+    /* (a 2D batch whose tile index is beyond the tile list is NOT an error: the 2D loop uses tile_list.get(), rasterizer.rs:673-687) */
+    {
+        make_valid();
+        f = base;
+        m2 = b2;
+        m2.source.kind = RXR_SOURCE_STATIC_TILE;
+        m2.source.index = 1;
+        f.batches2d = &m2;
+        int r0 = rxr_rasterize(ctx, &f, pixels);
+        const uint8_t *p2 = &pixels[(12u * W + 12u) * 4u];
+        printf("%-44s rc=%d pixel2d=%u,%u,%u (the 3D fragment shows through)\n", "2D batch: tile index beyond the list: [0,0,0,0]", r0, p2[0], p2[1], p2[2]);
+        if (r0 != RXR_OK || p2[0] <= 90) ++failures;
+    }
+    /* calls in the wrong order or with wrong arguments */
+    {
+        rxr_ctx *fresh = NULL;
+        if (rxr_create(&fresh, 0) == RXR_OK) {
+            int r1 = rxr_render_rows(fresh, 0, 8), r2 = rxr_render_download(fresh, pixels), r3 = rxr_download_rows(fresh, pixels, 0, 8);
+            printf("%-44s rc=%d,%d,%d\n", "render / download before any upload", r1, r2, r3);
+            if (r1 >= 0 || r2 >= 0 || r3 >= 0) ++failures;
+            rxr_destroy(fresh);
+        } else ++failures;
+        int r4 = rxr_create(&fresh, 1000);
+        printf("%-44s rc=%d\n", "rxr_create on device 1000", r4);
+        if (r4 != RXR_ERR_NO_DEVICE) ++failures;
+        int r5 = rxr_rasterize(ctx, NULL, pixels), r6 = rxr_rasterize(ctx, &base, NULL), r7 = rxr_rasterize(NULL, &base, pixels);
+        printf("%-44s rc=%d,%d,%d\n", "NULL frame / pixels / context", r5, r6, r7);
+        if (r5 >= 0 || r6 >= 0 || r7 >= 0) ++failures;
+        make_valid();
+        if (rxr_upload_frame(ctx, &base) == RXR_OK) {
+            int r8 = rxr_render_rows(ctx, 8, 4), r9 = rxr_render_rows(ctx, 0, H + 1u), r10 = rxr_download_rows(ctx, pixels, 0, H + 1u);
+            printf("%-44s rc=%d,%d,%d\n", "row ranges: reversed / beyond the frame", r8, r9, r10);
+            if (r8 >= 0 || r9 >= 0 || r10 >= 0) ++failures;
+        } else ++failures;
+    }
+    expect_valid(ctx, "valid frame again, same context");
+    rxr_destroy(ctx);
+    printf(failures ? "FAILED: %d case(s)\n" : "ok (%d failures)\n", failures);
+    return failures ? 1 : 0;
+}
