@@ -194,6 +194,62 @@ int main(void) {
             if (r8 >= 0 || r9 >= 0 || r10 >= 0) ++failures;
         } else ++failures;
     }
+    /* the other entry points that take arrays from the caller */
+    {
+        static uint8_t texel[4] = {1, 2, 3, 255};
+        rxr_texture t_ok = {texel, 1, 1}, t_null = {NULL, 1, 1}, t_zero = {texel, 0, 1}, t_huge = {texel, 40000, 1};
+        rxr_tile tile = {&t_ok, 1};
+        int r[8];
+        tile.textures = &t_null; r[0] = rxr_set_textures(ctx, &tile, 1, NULL, 0);
+        tile.textures = &t_zero; r[1] = rxr_set_textures(ctx, &tile, 1, NULL, 0);
+        tile.textures = &t_huge; r[2] = rxr_set_textures(ctx, &tile, 1, NULL, 0);
+        tile.textures = NULL;    r[3] = rxr_set_textures(ctx, &tile, 1, NULL, 0);
+        r[4] = rxr_set_textures(ctx, NULL, 2, NULL, 0);
+        r[5] = rxr_set_textures(ctx, NULL, 0, NULL, 3);
+        tile.textures = &t_ok;   r[6] = rxr_set_textures(ctx, &tile, 1, NULL, 0);  /* (a good one: accepted) */
+        r[7] = rxr_set_textures(ctx, NULL, 0, NULL, 0);                           /* (and none at all: accepted) */
+        printf("%-44s rc=%d,%d,%d,%d,%d,%d then %d,%d\n", "rxr_set_textures: bad textures / arrays", r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7]);
+        for (int i = 0; i < 6; ++i) if (r[i] >= 0) ++failures;
+        if (r[6] != RXR_OK || r[7] != RXR_OK) ++failures;
+
+        static float mv[3][4] = {{0, 0, 0, 1}, {1, 0, 0, 1}, {0, 1, 0, 1}};
+        static float mn[3][3] = {{0, 0, 1}, {0, 0, 1}, {0, 0, 1}};
+        static uint32_t mi[3] = {0, 1, 2}, mi_bad[3] = {0, 1, 7};
+        rxr_mesh3d mesh;
+        memset(&mesh, 0, sizeof mesh);
+        mesh.vertices = &mv[0][0]; mesh.uvs = &uvs[0][0]; mesh.normals = &mn[0][0]; mesh.indices = mi;
+        mesh.n_vertices = 3; mesh.n_triangles = 1;
+        identity(mesh.transform_3d);
+        mesh.shader = -1; mesh.chunk = -1; mesh.list = RXR_LIST_STATIC; mesh.source.kind = RXR_SOURCE_PIXEL;
+        rxr_mesh3d m;
+        int q[7];
+        m = mesh; m.normals = NULL;          q[0] = rxr_set_meshes(ctx, &m, 1);
+        m = mesh; m.indices = mi_bad;        q[1] = rxr_set_meshes(ctx, &m, 1);
+        m = mesh; m.cull_mode = 5;           q[2] = rxr_set_meshes(ctx, &m, 1);
+        m = mesh; m.vertices = NULL;         q[3] = rxr_set_meshes(ctx, &m, 1);
+        m = mesh; m.indices = NULL;          q[4] = rxr_set_meshes(ctx, &m, 1);
+        q[5] = rxr_set_meshes(ctx, NULL, 2);
+        q[6] = rxr_set_meshes(ctx, &mesh, 1);                                      /* (a good one: accepted) */
+        printf("%-44s rc=%d,%d,%d,%d,%d,%d then %d\n", "rxr_set_meshes: bad meshes", q[0], q[1], q[2], q[3], q[4], q[5], q[6]);
+        for (int i = 0; i < 6; ++i) if (q[i] >= 0) ++failures;
+        if (q[6] != RXR_OK) ++failures;
+        if (rxr_set_meshes(ctx, NULL, 0) != RXR_OK) ++failures;
+
+        rxr_ctx *multi = NULL;
+        int ids_bad[2] = {0, 1000}, ids_ok[2] = {0, 0};
+        int c0 = rxr_create_multi(&multi, NULL, 2), c1 = rxr_create_multi(&multi, ids_ok, 0), c2 = rxr_create_multi(&multi, ids_bad, 2), c3 = rxr_create_multi(NULL, ids_ok, 2);
+        printf("%-44s rc=%d,%d,%d,%d\n", "rxr_create_multi: bad device lists", c0, c1, c2, c3);
+        if (c0 >= 0 || c1 >= 0 || c2 >= 0 || c3 >= 0) ++failures;
+        if (rxr_create_multi(&multi, ids_ok, 2) == RXR_OK) {   /* two logical members on one GPU render the valid frame too */
+            make_valid();
+            memset(pixels, 0, sizeof pixels);
+            int rm = rxr_rasterize(multi, &base, pixels);
+            const uint8_t *p2 = &pixels[(12u * W + 12u) * 4u];
+            printf("%-44s rc=%d pixel2d=%u,%u,%u\n", "valid frame on a 2-member context", rm, p2[0], p2[1], p2[2]);
+            if (rm != RXR_OK || p2[1] != 220) ++failures;
+            rxr_destroy(multi);
+        } else ++failures;
+    }
     expect_valid(ctx, "valid frame again, same context");
     rxr_destroy(ctx);
     printf(failures ? "FAILED: %d case(s)\n" : "ok (%d failures)\n", failures);
