@@ -23,6 +23,7 @@
 #include <mutex>
 #include <new>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #ifndef RXR_PARALLEL_MIN_WEIGHT
@@ -54,8 +55,9 @@ class Pool {
             for (size_t i = 0; i < n; ++i) fn(i);
             return;
         }
+        using Fn = typename std::remove_reference<F>::type;  // (callers pass temporaries and named lambdas alike)
         struct Thunk {
-            F *f;
+            Fn *f;
             static void call(void *self, size_t i) { (*((Thunk *)self)->f)(i); }
         } thunk{&fn};
         std::unique_lock<std::mutex> job_lock(job_mu_);  // one job at a time
