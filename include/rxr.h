@@ -24,7 +24,9 @@
 #ifndef RXR_H
 #define RXR_H
 
+#if !defined(__HIPCC_RTC__) /* (hiprtc, the run-time compiler of rxr_jit.hip, has size_t built in and no <stddef.h>) */
 #include <stddef.h>
+#endif
 #include <stdint.h>
 
 #ifdef __cplusplus

@@ -187,6 +187,7 @@ void rxr_destroy(rxr_ctx *ctx) {
                       &ctx->d_vm_code, &ctx->d_programs, &ctx->d_patterns, &ctx->d_pattern_data, &ctx->d_palette};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
+    rxr_jit_drop(ctx);
     if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
     if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -1338,7 +1339,7 @@ static int render_impl(rxr_ctx *ctx, const RenderSpec &spec, void *dev_pixels, h
         rxr_launch_bin2d_fill(&P, s);
     }
     if (timed) HIPCHK(ctx, hipEventRecord(e1, s));
-    rxr_launch_raster(&P, s);
+    if (!rxr_jit_launch(ctx, &P, s)) rxr_launch_raster(&P, s);
     if (timed) HIPCHK(ctx, hipEventRecord(e2, s));
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipEventRecord(ctx->ev_render, s));
@@ -2192,6 +2193,18 @@ int rxr_set_shaders(rxr_ctx *ctx, const rxr_shader_set *set) {
     }
     if ((rc = up(ctx->d_palette, pal.data(), pal.size() * 4)) != RXR_OK) return rc;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // the staging vectors die here
+    // opt-in: the set as straight-line kernels compiled now (rxr_jit.hip); sets with calls or PaletteIndex keep the interpreter
+    rxr_jit_drop(ctx);
+    ctx->jit_info.clear();
+    if (const char *jit = getenv("RXR_SHADER_JIT")) {
+        if (jit[0] == '1') {
+            if (ctx->programs_static) {
+                if ((rc = rxr_jit_build(ctx, fl.code, progs)) != RXR_OK) return rc;
+            } else {
+                ctx->jit_info = progs.empty() ? "not compiled: no programs" : "not compiled: a program of the set has calls, PaletteIndex or a data-dependent stack depth";
+            }
+        }
+    }
     ctx->programs = std::move(progs);
     ctx->program_field_reads = std::move(field_reads);
     ctx->n_patterns = set->n_patterns;
@@ -2226,3 +2239,49 @@ int rxr_selftest_math(rxr_ctx *ctx, uint64_t n_tuples, uint64_t seed, uint64_t m
 }
 
 }  // extern "C"
+
+// what the run-time compiler did with the last program set of this context (rxr_jit.hip); "" when it was not asked
+extern "C" const char *rxr_debug_jit_info(rxr_ctx *ctx) {
+    if (!ctx) return "";
+    if (ctx->group) return rxr_member(ctx, 0) ? rxr_member(ctx, 0)->jit_info.c_str() : "";
+    return ctx->jit_info.c_str();
+}
+
+// device-free half of the run-time compiler, for tests without a GPU: validates + flattens the set like rxr_check_shaders, generates
+// the C++ of its programs (copied to `source`, truncated to its capacity) and, with compile != 0, runs hiprtc for gfx950.
+// Returns RXR_OK, the validation status, or RXR_ERR_UNSUPPORTED with the reason in `message` when the set is not covered.
+extern "C" int rxr_debug_jit_generate(const rxr_shader_set *set, int compile, char *source, uint32_t source_capacity, char *message, uint32_t message_capacity) {
+    std::vector<uint32_t> code, reads;
+    std::vector<DevProgram> progs;
+    std::string err, gen;
+    auto say = [&](const std::string &m) {
+        if (message && message_capacity) snprintf(message, message_capacity, "%s", m.c_str());
+    };
+    say("");
+    int rc = set ? flatten_programs(set, code, progs, reads, err) : RXR_ERR_INVALID;
+    if (rc != RXR_OK) {
+        say(err);
+        return rc;
+    }
+    if (progs.empty() || !tag_static_depths(code, progs)) {
+        say("a program of the set has calls, PaletteIndex or a data-dependent stack depth");
+        return RXR_ERR_UNSUPPORTED;
+    }
+    if (!rxr_jit_generate(code, progs, gen, err)) {
+        say(err);
+        return RXR_ERR_UNSUPPORTED;
+    }
+    if (source && source_capacity) snprintf(source, source_capacity, "%s", gen.c_str());
+    if (compile) {
+        std::vector<char> obj;
+        double seconds = 0.0;
+        if (!rxr_jit_compile(gen, "gfx950", obj, seconds, err)) {
+            say(err);
+            return RXR_ERR_HIP;
+        }
+        char m[96];
+        snprintf(m, sizeof m, "compiled in %.2f s, %zu bytes", seconds, obj.size());
+        say(m);
+    }
+    return RXR_OK;
+}

@@ -91,6 +91,9 @@ struct rxr_ctx {
     bool scratch_dirty = false;      // a pre-pass was queued without its raster launch
     bool scratch2d_dirty = false;
     uint32_t min_kernel_level = 0;   // RXR_MIN_KERNEL_LEVEL (tuning)
+    // run-time compiled kernels of the current program set (rxr_jit.hip; opt-in RXR_SHADER_JIT=1), else null: the interpreter runs
+    void *jit_module = nullptr, *jit_fn = nullptr, *jit_fn_v = nullptr;
+    std::string jit_info;                // what happened to the last set ("compiled: ...", "not compiled: <why>", empty: not asked)
     bool programs_static = false;    // every program of the set has a stack depth that is a function of the pc (tag_static_depths)
     uint32_t small_mode = 2;         // RasterParams.fused_small for frames with <= RXR_STAGE_TRIS triangles;
                                      // RXR_SMALL_MODE=0|1|2 overrides it (tests / A-B runs)
@@ -159,3 +162,10 @@ int rxr_group_download(rxr_ctx *ctx, uint8_t *pixels);       // ... and ships th
 int rxr_group_render_download(rxr_ctx *ctx, uint8_t *pixels);
 int rxr_group_synchronize(rxr_ctx *ctx);
 int rxr_group_get_stats(rxr_ctx *ctx, rxr_stats *out);
+
+// rxr_jit.hip: program sets compiled at run time
+bool rxr_jit_generate(const std::vector<uint32_t> &code, const std::vector<DevProgram> &progs, std::string &src, std::string &why);
+bool rxr_jit_compile(const std::string &gen, const std::string &arch, std::vector<char> &obj, double &seconds, std::string &err);
+int rxr_jit_build(rxr_ctx *ctx, const std::vector<uint32_t> &code, const std::vector<DevProgram> &progs);
+void rxr_jit_drop(rxr_ctx *ctx);
+bool rxr_jit_launch(rxr_ctx *ctx, const RasterParams *P, hipStream_t s);

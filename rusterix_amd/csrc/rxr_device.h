@@ -3,7 +3,11 @@
 #pragma once
 #include <stdint.h>
 
+#ifdef RXR_JIT
+#include "rxr.h"  // (hiprtc: the sources are in-memory headers with plain names, rxr_jit.hip)
+#else
 #include "../../include/rxr.h"
+#endif
 
 // GPU tile = binning granule = one 256-thread workgroup.  16x16 pixels; a wave covers 16x4.
 #define RXR_TILE_W 16

@@ -25,7 +25,9 @@
 //
 // RXR_EXACT_FAST=0 compiles the plain operators instead (A/B measurements).
 #pragma once
+#ifndef RXR_JIT
 #include <hip/hip_runtime.h>
+#endif
 
 #ifndef RXR_EXACT_FAST
 #define RXR_EXACT_FAST 1

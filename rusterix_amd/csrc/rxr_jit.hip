@@ -1,0 +1,326 @@
+// rxr_jit.hip -- Rusteria program sets compiled at run time (opt-in: RXR_SHADER_JIT=1).
+//
+// Why: the interpreter (rxr_vm.h) costs about a hundred SIMD cycles per VM instruction and wave -- fetch, a tree of scalar
+// branches, the value stack in LDS -- and its state bounds the program kernels to 80 VGPRs with spills; the 1 M-triangle grid with
+// the per-batch program of BASELINE.json's configuration C5 spends more time interpreting sixteen instructions per fragment than
+// rasterising.  For a set whose stack depths are static (no calls, no PaletteIndex: what rxr_set_shaders proves with
+// tag_static_depths, the common case of colour / material programs) the jump code IS a register program: the depth before every
+// instruction is known, so stack slot k is the variable s<k>, locals and globals are variables, If / For are gotos, and a lane
+// that diverges is the compiler's business.  This file turns the SAME jump code the interpreter would run into that C++
+// (rxr_jit_generate), compiles the raster kernel around it with hiprtc (the kernel sources are embedded in the library:
+// rxr_jit_embedded.inc, written by __graft_entry__.build()), loads the code object and launches it in place of k_raster_vm*.
+// The operations are the interpreter's own expressions (rxr_jit_ops.h); parity with the interpreter and the CPU oracle is
+// tests/test_gpu_shader_jit.py.  Everything else -- validation, purity analysis, flattening, refusals -- is unchanged and runs
+// first; a set that is not eligible, or a compiler failure, leaves the interpreter in charge (the reason is kept in the context).
+#include <hip/hip_runtime.h>
+#include <hip/hiprtc.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "rxr_ctx.h"
+
+namespace {
+
+#include "rxr_jit_embedded.inc"  // rxr_jit_header_names[], rxr_jit_header_sources[], rxr_jit_n_headers
+
+uint32_t length_of(uint32_t op) {
+    switch (op) {
+        case RXR_NODE_LOAD_GLOBAL: case RXR_NODE_STORE_GLOBAL: case RXR_NODE_LOAD_LOCAL: case RXR_NODE_STORE_LOCAL:
+        case VM_GETC: case VM_SETC: case VM_JMP: case VM_JZ: case VM_FOR_COND: case VM_RETURN: case VM_FAULT: return 2;
+        case RXR_NODE_PUSH: case VM_BINC: case VM_CALL: return 4;
+        default: return 1;
+    }
+}
+
+std::string slot(int k) { return "s" + std::to_string(k); }
+std::string hexw(uint32_t w) {
+    char b[16];
+    snprintf(b, sizeof b, "0x%08xu", w);
+    return b;
+}
+std::string imm3(const std::vector<uint32_t> &code, uint32_t pc) {
+    return "mk(__uint_as_float(" + hexw(code[pc + 1]) + "), __uint_as_float(" + hexw(code[pc + 2]) + "), __uint_as_float(" + hexw(code[pc + 3]) + "))";
+}
+
+enum Arity { A_NONE, A_UN, A_BIN, A_TER };
+Arity pure_arity(uint32_t op) {
+    switch (op) {
+        case RXR_NODE_LENGTH: case RXR_NODE_LENGTH2: case RXR_NODE_LENGTH3: case RXR_NODE_ABS: case RXR_NODE_SIN: case RXR_NODE_SIN1:
+        case RXR_NODE_SIN2: case RXR_NODE_COS: case RXR_NODE_COS1: case RXR_NODE_COS2: case RXR_NODE_TAN: case RXR_NODE_ATAN:
+        case RXR_NODE_NORMALIZE: case RXR_NODE_FLOOR: case RXR_NODE_CEIL: case RXR_NODE_ROUND: case RXR_NODE_FRACT:
+        case RXR_NODE_DEGREES: case RXR_NODE_RADIANS: case RXR_NODE_SQRT: case RXR_NODE_LOG: case RXR_NODE_NOT: case RXR_NODE_NEG:
+            return A_UN;
+        case RXR_NODE_PACK2: case RXR_NODE_ADD: case RXR_NODE_SUB: case RXR_NODE_MUL: case RXR_NODE_DIV: case RXR_NODE_ATAN2:
+        case RXR_NODE_ROTATE2D: case RXR_NODE_DOT: case RXR_NODE_DOT2: case RXR_NODE_DOT3: case RXR_NODE_CROSS: case RXR_NODE_MOD:
+        case RXR_NODE_MIN: case RXR_NODE_MAX: case RXR_NODE_STEP: case RXR_NODE_POW: case RXR_NODE_EQ: case RXR_NODE_NE: case RXR_NODE_LT:
+        case RXR_NODE_LE: case RXR_NODE_GT: case RXR_NODE_GE: case RXR_NODE_AND: case RXR_NODE_OR:
+            return A_BIN;
+        case RXR_NODE_PACK3: case RXR_NODE_MIX: case RXR_NODE_SMOOTHSTEP: case RXR_NODE_CLAMP:
+            return A_TER;
+        default: return A_NONE;
+    }
+}
+const char *field_of(uint32_t op, bool &is_set) {
+    is_set = false;
+    switch (op) {
+        case RXR_NODE_UV: return "io.uv";
+        case RXR_NODE_SET_UV: is_set = true; return "io.uv";
+        case RXR_NODE_NORMAL: return "io.normal";
+        case RXR_NODE_HITPOINT: return "io.hitpoint";
+        case RXR_NODE_TIME: return "io.time";
+        case RXR_NODE_COLOR: return "io.color";
+        case RXR_NODE_SET_COLOR: is_set = true; return "io.color";
+        case RXR_NODE_ROUGHNESS: return "io.roughness";
+        case RXR_NODE_SET_ROUGHNESS: is_set = true; return "io.roughness";
+        case RXR_NODE_METALLIC: return "io.metallic";
+        case RXR_NODE_SET_METALLIC: is_set = true; return "io.metallic";
+        case RXR_NODE_EMISSIVE: return "io.emissive";
+        case RXR_NODE_SET_EMISSIVE: is_set = true; return "io.emissive";
+        case RXR_NODE_OPACITY: return "io.opacity";
+        case RXR_NODE_SET_OPACITY: is_set = true; return "io.opacity";
+        case RXR_NODE_BUMP: return "io.bump";
+        case RXR_NODE_SET_BUMP: is_set = true; return "io.bump";
+        default: return nullptr;
+    }
+}
+
+// one program's `shade`: the reachable instructions in address order, each under its label; `code` carries the static depths
+// (bits 16..23 of every reachable opcode word, tag_static_depths).  Returns false for anything this generator does not cover.
+bool generate_program(const std::vector<uint32_t> &code, const DevProgram &p, uint32_t index, std::string &out, std::string &why) {
+    out += "__device__ __forceinline__ uint32_t rxr_jit_prog_" + std::to_string(index) + "(const RasterParams &P, rxvm::IO &io) {\n";
+    out += "    using namespace rxvm;\n    (void)P;\n";
+    if (p.shade_entry == 0xFFFFFFFFu) {  // shade_index None: nothing runs
+        out += "    (void)io;\n    return 0u;\n}\n";
+        return true;
+    }
+    if (p.shade_locals > RXR_VM_LOCALS) {
+        out += "    (void)io;\n    *P.vm_fault = " + std::to_string((uint32_t)VMF_LOCALS_OVERFLOW) + "u;\n    return " + std::to_string((uint32_t)VMF_LOCALS_OVERFLOW) + "u;\n}\n";
+        return true;
+    }
+    // reachable instructions (the same walk as tag_static_depths, without its checks: it has passed)
+    std::vector<char> reach(code.size(), 0);
+    std::vector<uint32_t> work{p.shade_entry};
+    int max_depth = 0;
+    while (!work.empty()) {
+        uint32_t pc = work.back();
+        work.pop_back();
+        for (;;) {
+            if (pc >= code.size()) { why = "jump code runs past its end"; return false; }
+            if (reach[pc]) break;
+            reach[pc] = 1;
+            const uint32_t w = code[pc], op = w & 0xFFu;
+            const uint32_t len = length_of(op);
+            if (pc + len > code.size()) { why = "truncated instruction"; return false; }
+            max_depth = std::max(max_depth, (int)((w >> 16) & 0xFFu) + 1);
+            if (op == VM_ENDFN || op == VM_FAULT) break;
+            if (op == VM_JMP || op == VM_RETURN) { pc = code[pc + 1]; continue; }
+            if (op == VM_JZ || op == VM_FOR_COND) work.push_back(code[pc + 1]);
+            pc += len;
+        }
+    }
+    for (int k = 0; k <= max_depth; ++k) out += "    v3 " + slot(k) + " = splat(0.0f);\n";
+    for (uint32_t k = 0; k < p.shade_locals; ++k) out += "    v3 l" + std::to_string(k) + " = splat(0.0f);\n";
+    for (uint32_t k = 0; k < p.n_globals && k < RXR_VM_GLOBALS; ++k) out += "    v3 g" + std::to_string(k) + " = splat(0.0f);\n";
+    out += "    uint32_t fault = 0u, steps = 0u;\n    (void)steps;\n";
+    auto fail = [&](uint32_t code_) { return "{ fault = " + std::to_string(code_) + "u; goto Lend; }"; };
+    for (uint32_t pc = p.shade_entry; pc < code.size(); ++pc) {
+        if (!reach[pc]) {
+            // (unreachable words -- dead code behind a jump, or the immediates of the instruction before -- are skipped; an
+            // instruction that falls through always has a reachable successor)
+            continue;
+        }
+        const uint32_t w = code[pc], op = w & 0xFFu;
+        const int d = (int)((w >> 16) & 0xFFu);  // depth BEFORE the instruction
+        const uint32_t len = length_of(op);
+        out += "L" + std::to_string(pc) + ": ";
+        const std::string t0 = slot(d - 1), t1 = slot(d - 2), t2 = slot(d - 3), top = slot(d);
+        bool is_set = false;
+        const Arity ar = pure_arity(op);
+        if (op == RXR_NODE_CLAMP) {
+            out += "{ if (!jit_clamp_ok(" + t1 + ", " + t0 + ")) " + fail(VMF_CLAMP_BOUNDS) + " " + t2 + " = jit_ter<" + std::to_string(op) + "u>(" + t2 + ", " + t1 + ", " + t0 + "); }\n";
+        } else if (ar == A_UN) {
+            out += t0 + " = jit_un<" + std::to_string(op) + "u>(" + t0 + ");\n";
+        } else if (ar == A_BIN) {
+            out += t1 + " = jit_bin<" + std::to_string(op) + "u>(" + t1 + ", " + t0 + ");\n";
+        } else if (ar == A_TER) {
+            out += t2 + " = jit_ter<" + std::to_string(op) + "u>(" + t2 + ", " + t1 + ", " + t0 + ");\n";
+        } else if (const char *f = field_of(op, is_set)) {
+            out += is_set ? std::string(f) + " = " + t0 + ";\n" : top + " = " + f + ";\n";
+        } else {
+            switch (op) {
+                case RXR_NODE_PUSH: out += top + " = " + imm3(code, pc) + ";\n"; break;
+                case VM_BINC: out += t0 + " = jit_binc<" + std::to_string((w >> 8) & 0xFFu) + "u>(" + t0 + ", " + imm3(code, pc) + ");\n"; break;
+                case RXR_NODE_LOAD_LOCAL:
+                    out += code[pc + 1] < p.shade_locals ? top + " = l" + std::to_string(code[pc + 1]) + ";\n" : fail(VMF_LOCAL_INDEX) + "\n";
+                    break;
+                case RXR_NODE_STORE_LOCAL:
+                    out += code[pc + 1] < p.shade_locals ? "l" + std::to_string(code[pc + 1]) + " = " + t0 + ";\n" : fail(VMF_LOCAL_INDEX) + "\n";
+                    break;
+                case RXR_NODE_LOAD_GLOBAL:
+                    out += code[pc + 1] < p.n_globals ? top + " = g" + std::to_string(code[pc + 1]) + ";\n" : fail(VMF_GLOBAL_INDEX) + "\n";
+                    break;
+                case RXR_NODE_STORE_GLOBAL:
+                    out += code[pc + 1] < p.n_globals ? "g" + std::to_string(code[pc + 1]) + " = " + t0 + ";\n" : fail(VMF_GLOBAL_INDEX) + "\n";
+                    break;
+                case RXR_NODE_SWAP: out += "{ const v3 t = " + t0 + "; " + t0 + " = " + t1 + "; " + t1 + " = t; }\n"; break;
+                case VM_GETC: out += t0 + " = jit_getc(" + hexw(code[pc + 1]) + ", " + t0 + ");\n"; break;
+                case VM_SETC: out += t1 + " = jit_setc(" + hexw(code[pc + 1]) + ", " + t1 + ", " + t0 + ");\n"; break;
+                case RXR_NODE_CLEAR: case RXR_NODE_PRINT: case VM_FOR_ENTER: case VM_FOR_TRUNC: case VM_FOR_EXIT: out += ";\n"; break;  // (static depths)
+                case RXR_NODE_DUP: out += d > 0 ? top + " = " + t0 + ";\n" : std::string(";\n"); break;
+                case RXR_NODE_SET_NORMAL: out += "io.normal = jit_set_normal(" + t0 + ");\n"; break;
+                case RXR_NODE_SAMPLE: out += t1 + " = jit_sample(P, " + t1 + ", " + t0 + ");\n"; break;
+                case RXR_NODE_SAMPLE_NORMAL: out += t1 + " = jit_sample_normal(P, " + t1 + ", " + t0 + ");\n"; break;
+                case VM_JMP:
+                    if (code[pc + 1] <= pc)  // the only way back: a For loop's closing jump
+                        out += "{ if (++steps > " + std::to_string((uint32_t)RXR_VM_MAX_STEPS) + "u) " + fail(VMF_STEP_LIMIT) + " goto L" + std::to_string(code[pc + 1]) + "; }\n";
+                    else
+                        out += "goto L" + std::to_string(code[pc + 1]) + ";\n";
+                    break;
+                case VM_JZ: out += "if (!(" + t0 + ".x != 0.0f)) goto L" + std::to_string(code[pc + 1]) + ";\n"; break;
+                case VM_FOR_COND: out += "if (" + t0 + ".x == 0.0f) goto L" + std::to_string(code[pc + 1]) + ";\n"; break;
+                case VM_RETURN: case VM_ENDFN: out += "goto Lend;\n"; break;
+                case VM_FAULT: out += fail(code[pc + 1]) + "\n"; break;
+                default: why = "opcode " + std::to_string(op) + " is not covered by the run-time compiler"; return false;
+            }
+        }
+        if (op == VM_ENDFN) break;  // (the end of `shade`; what follows belongs to other functions)
+        pc += len - 1;
+    }
+    out += "Lend:\n    if (fault) *P.vm_fault = fault;\n    return fault;\n}\n";
+    return true;
+}
+
+}  // namespace
+
+// the header rxr_vm.h includes in RXR_JIT mode: one function per program and the dispatcher
+bool rxr_jit_generate(const std::vector<uint32_t> &code, const std::vector<DevProgram> &progs, std::string &src, std::string &why) {
+    src = "// generated by rxr_jit.hip from the jump code of one rxr_set_shaders call\n#pragma once\n";
+    for (size_t i = 0; i < progs.size(); ++i)
+        if (!generate_program(code, progs[i], (uint32_t)i, src, why)) return false;
+    src += "__device__ __forceinline__ uint32_t rxr_jit_shade(const RasterParams &P, uint32_t pi, rxvm::IO &io) {\n    switch (pi) {\n";
+    for (size_t i = 0; i < progs.size(); ++i) src += "        case " + std::to_string(i) + "u: return rxr_jit_prog_" + std::to_string(i) + "(P, io);\n";
+    src += "        default: return 0u;\n    }\n}\n";
+    return true;
+}
+
+namespace {
+std::mutex g_cache_mu;
+std::map<std::string, std::vector<char>> g_code_objects;  // generated source -> code object (one compilation per set and process)
+}  // namespace
+
+void rxr_jit_drop(rxr_ctx *ctx) {
+    if (ctx->jit_module) (void)hipModuleUnload((hipModule_t)ctx->jit_module);
+    ctx->jit_module = nullptr;
+    ctx->jit_fn = ctx->jit_fn_v = nullptr;
+}
+
+// generated header -> code object for `arch` ("gfx950"), through the process-wide cache; needs no device
+bool rxr_jit_compile(const std::string &gen, const std::string &arch, std::vector<char> &obj, double &seconds, std::string &err) {
+    seconds = 0.0;
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        auto it = g_code_objects.find(arch + "\n" + gen);
+        if (it != g_code_objects.end()) {
+            obj = it->second;
+            return true;
+        }
+    }
+    std::vector<const char *> names(rxr_jit_header_names, rxr_jit_header_names + rxr_jit_n_headers), sources(rxr_jit_header_sources, rxr_jit_header_sources + rxr_jit_n_headers);
+    names.push_back("rxr_jit_programs.h");
+    sources.push_back(gen.c_str());
+    hiprtcProgram prog = nullptr;
+    const char *main_src = "#define RXR_JIT 1\n#include \"rxr_kernels.hip\"\n";
+    if (hiprtcCreateProgram(&prog, main_src, "rxr_jit_main.hip", (int)names.size(), sources.data(), names.data()) != HIPRTC_SUCCESS) {
+        err = "hiprtcCreateProgram failed";
+        return false;
+    }
+    const std::string arch_opt = "--offload-arch=" + arch;
+    const char *opts[] = {arch_opt.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize"};
+    const auto t0 = std::chrono::steady_clock::now();
+    const hiprtcResult r = hiprtcCompileProgram(prog, (int)(sizeof(opts) / sizeof(opts[0])), opts);
+    seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (r != HIPRTC_SUCCESS) {
+        size_t n = 0;
+        std::string log;
+        if (hiprtcGetProgramLogSize(prog, &n) == HIPRTC_SUCCESS && n) {
+            log.resize(n);
+            (void)hiprtcGetProgramLog(prog, &log[0]);
+        }
+        (void)hiprtcDestroyProgram(&prog);
+        err = std::string(hiprtcGetErrorString(r)) + ": " + log.substr(0, 2000);
+        return false;
+    }
+    size_t n = 0;
+    if (hiprtcGetCodeSize(prog, &n) != HIPRTC_SUCCESS || n == 0) {
+        (void)hiprtcDestroyProgram(&prog);
+        err = "empty code object";
+        return false;
+    }
+    obj.resize(n);
+    (void)hiprtcGetCode(prog, obj.data());
+    (void)hiprtcDestroyProgram(&prog);
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    g_code_objects[arch + "\n" + gen] = obj;
+    return true;
+}
+
+// compiles (or finds) the kernels of the set just flattened and loads them on ctx's device; RXR_OK also when the set is simply
+// not covered or the compiler fails (the interpreter stays in charge; ctx->jit_info says why)
+int rxr_jit_build(rxr_ctx *ctx, const std::vector<uint32_t> &code, const std::vector<DevProgram> &progs) {
+    rxr_jit_drop(ctx);
+    ctx->jit_info.clear();
+    std::string gen, why;
+    if (!rxr_jit_generate(code, progs, gen, why)) {
+        ctx->jit_info = "not compiled: " + why;
+        return RXR_OK;
+    }
+    hipDeviceProp_t props;
+    std::string arch = "gfx950";
+    if (hipGetDeviceProperties(&props, ctx->device) == hipSuccess && props.gcnArchName[0]) {
+        arch = props.gcnArchName;  // "gfx950:sramecc+:xnack-"
+        arch = arch.substr(0, arch.find(':'));
+    }
+    std::vector<char> obj;
+    double seconds = 0.0;
+    if (!rxr_jit_compile(gen, arch, obj, seconds, why)) {
+        ctx->jit_info = "not compiled: " + why;
+        return RXR_OK;
+    }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipModule_t mod = nullptr;
+    hipError_t e = hipModuleLoadData(&mod, obj.data());
+    hipFunction_t fn = nullptr, fn_v = nullptr;
+    if (e == hipSuccess) e = hipModuleGetFunction(&fn, mod, "k_raster_jit");
+    if (e == hipSuccess) e = hipModuleGetFunction(&fn_v, mod, "k_raster_jit_v");
+    if (e != hipSuccess) {
+        if (mod) (void)hipModuleUnload(mod);
+        ctx->jit_info = std::string("not loaded: ") + hipGetErrorString(e);
+        return RXR_OK;
+    }
+    ctx->jit_module = mod;
+    ctx->jit_fn = fn;
+    ctx->jit_fn_v = fn_v;
+    char msg[200];
+    snprintf(msg, sizeof msg, "compiled: %zu program(s), %zu words of jump code, %zu bytes of code object, %.2f s%s", progs.size(), code.size(), obj.size(), seconds,
+             seconds == 0.0 ? " (cached)" : "");
+    ctx->jit_info = msg;
+    return RXR_OK;
+}
+
+// the raster launch of a frame whose programs are compiled; false: no compiled kernels (the caller launches the interpreter kernels)
+bool rxr_jit_launch(rxr_ctx *ctx, const RasterParams *P, hipStream_t s) {
+    if (!ctx->jit_fn || P->kernel_level < 2u) return false;
+    if (P->tiles_x * P->tiles_y == 0) return true;
+    // kernel levels 6 / 7: no program of the opaque pass decides visibility (rxr_upload_frame); 2 .. 5: one may
+    hipFunction_t fn = (hipFunction_t)(P->kernel_level >= 6u ? ctx->jit_fn : ctx->jit_fn_v);
+    RasterParams params = *P;
+    size_t size = sizeof(params);
+    void *config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &params, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+    return hipModuleLaunchKernel(fn, P->tiles_x, P->tiles_y, 1, RXR_TILE_THREADS, 1, 1, 0, s, nullptr, config) == hipSuccess;
+}

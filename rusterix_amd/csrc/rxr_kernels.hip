@@ -23,10 +23,15 @@
 // order, the surviving fragment of a pixel is therefore the one with the smallest z among the
 // alpha-255 fragments, ties broken by the smaller submission index -- an order-independent argmin,
 // so the bins need not be sorted and overdraw is never shaded.
+// RXR_JIT: this file compiled at RUN time by hiprtc (rxr_jit.hip) for one set of Rusteria programs -- only the raster kernel of
+// the program levels, with the interpreter replaced by the straight-line code generated from the set's jump code.  hiprtc brings
+// its own runtime declarations and no host headers; the pre-pass kernels and the launch functions are left out.
+#ifndef RXR_JIT
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
 #include <cstring>
+#endif
 
 #include "rxr_device.h"
 #include "rxr_exact_math.h"
@@ -642,7 +647,7 @@ __device__ __forceinline__ void shade3d_lights(const RasterParams &P, bool hit, 
     const f3 c = mk3(__shfl(F.world.x, src, 64), __shfl(F.world.y, src, 64), __shfl(F.world.z, src, 64));
     const float r = hit ? mag3(sub3(F.world, c)) : 0.0f;
     // NaN / inf world positions are not bounded by the sphere: no culling for this wave then
-    const bool can_cull = __ballot(hit && !(r < INFINITY)) == 0ull;
+    const bool can_cull = __ballot(hit && !(r < __builtin_huge_valf())) == 0ull;  // (INFINITY, without <cmath>: hiprtc)
     const float rmax = wave_max(r);
     const float rough = (X >= 2) ? F.rough : 0.5f, metal = (X >= 2) ? F.metal : 0.0f;
 
@@ -1058,6 +1063,7 @@ __device__ __forceinline__ uint32_t wave_bin_finish(uint32_t raw, uint32_t first
     return (uint32_t)__shfl((int)raw, (int)first, 64) + ((threadIdx.x & 63u) - first);
 }
 
+#ifndef RXR_JIT  // ---- the pre-pass kernels (not part of a run-time compiled program kernel) --------------------------------
 // The records leave through LDS: a thread's own 96 + 80 bytes are eleven 16-byte stores at a stride of 96 / 80 bytes across the
 // wave (every store instruction touches 64 cache lines, a sixth of each); transposed, the workgroup's 256 records are one
 // contiguous 24 KB / 20 KB block that consecutive lanes write 16 bytes at a time.
@@ -1408,6 +1414,7 @@ extern "C" __global__ void __launch_bounds__(256) k_bin2d_fill(RasterParams P) {
         }
 }
 
+#endif  // !RXR_JIT
 // =================================================================================================
 // k_raster: the tile kernel.  One workgroup per 16x16 tile, one pixel per lane.
 // Replaces the rayon tile closure, rasterizer.rs:275-556, and the tile->framebuffer copy, :559-579.
@@ -2479,6 +2486,14 @@ __device__ __forceinline__ const RasterParams &kernarg_params_early() { return *
 // in VGPR lanes (369 v_writelane / v_readlane in k_raster, 51 of them executed by every wave before its first useful
 // instruction); read in place they are scalar loads at the point of use (17 spill instructions).  Measured A-B-A-B on one
 // box: bench frame 208 -> 198 us, the 1-light frame 126 -> 117 us.
+#ifdef RXR_JIT
+// the two kernels of a run-time compiled program set: feature level 2 (programs may decide visibility) and 7 (none does)
+#ifndef RXR_JIT_WAVES_PER_SIMD
+#define RXR_JIT_WAVES_PER_SIMD 8
+#endif
+extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_JIT_WAVES_PER_SIMD) k_raster_jit_v(RasterParams) { raster_tile<false, 2, true>(kernarg_params_early()); }
+extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_JIT_WAVES_PER_SIMD) k_raster_jit(RasterParams) { raster_tile<false, 7, true>(kernarg_params_early()); }
+#else
 #ifndef RXR_RASTER_KERNARG_IN_PLACE
 #define RXR_RASTER_KERNARG_IN_PLACE 1
 #endif
@@ -2583,3 +2598,4 @@ extern "C" void rxr_launch_raster(const RasterParams *P, hipStream_t s) {
     else if (P->fused_small == 0u && (P->flags & RXR_FLAG_D3_ACTIVE) && !no_rows) hipLaunchKernelGGL(k_raster_rows, tiles, dim3(RXR_TILE_THREADS), 0, s, *P);
     else hipLaunchKernelGGL(k_raster, tiles, dim3(RXR_TILE_THREADS), 0, s, *P);
 }
+#endif  // !RXR_JIT

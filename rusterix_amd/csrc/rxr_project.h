@@ -3,7 +3,11 @@
 #pragma once
 #include <stdint.h>
 
+#ifdef RXR_JIT
+#include "rxr.h"  // (hiprtc: the sources are in-memory headers with plain names, rxr_jit.hip)
+#else
 #include "../../include/rxr.h"
+#endif
 
 // Output layout per mesh (capacity based, so that triangle ids keep the reference's submission order
 // without a cross-mesh compaction): vertices [vout_base, vout_base + n_verts + 4*n_tris),

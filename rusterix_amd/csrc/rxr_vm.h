@@ -14,7 +14,9 @@
 // sin / cos / tan / atan / atan2 / pow / ln come from the device math library and differ from the host's
 // libm by a few ulp: programs that use them are compared at +-1 per 8-bit channel.
 #pragma once
+#ifndef RXR_JIT
 #include <hip/hip_runtime.h>
+#endif
 
 #include "rxr_device.h"
 
@@ -65,6 +67,7 @@ __device__ __forceinline__ v3 pattern_sample(const RasterParams &P, const DevPat
 }
 __device__ __forceinline__ float rclampf(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
+#ifndef RXR_JIT
 // ---- the interpreter ------------------------------------------------------------------------------
 // All lanes of a wave that need a program run call shade() together.  Instruction fetch and decode are
 // wave-uniform: every step executes the instruction at the SMALLEST program counter among the lanes still
@@ -142,6 +145,7 @@ __device__ __forceinline__ uint32_t wave_min_pc(uint32_t pc, unsigned long long 
     }
 }
 
+#endif  // !RXR_JIT
 // the libm-backed opcodes, kept out of line: they are rare and their inlined bodies would set the register
 // budget of the whole interpreter
 __device__ __noinline__ v3 slow_unary(uint32_t op, v3 a) {
@@ -169,6 +173,20 @@ __device__ __noinline__ v3 slow_binary(uint32_t op, v3 a, v3 b) {
     }
 }
 
+#ifdef RXR_JIT
+// ---- a run-time compiled program set (rxr_jit.hip): no interpreter -- every program of the set is a straight-line device
+// function generated from its jump code (rxr_jit_programs.h, handed to hiprtc as an in-memory header), built from the operation
+// templates of rxr_jit_ops.h, and the three entry points of the interpreter forward to it
+}  // namespace rxvm
+#include "rxr_jit_ops.h"
+#include "rxr_jit_programs.h"
+namespace rxvm {
+template <bool SSP>
+__device__ __forceinline__ uint32_t shade_inline(const RasterParams &P, uint32_t pi, IO &io, float *) { return rxr_jit_shade(P, pi, io); }
+__device__ __forceinline__ float *stack_block() { return nullptr; }
+template <bool SSP>
+__device__ __forceinline__ uint32_t shade_call(const RasterParams &P, uint32_t pi, IO &io) { return rxr_jit_shade(P, pi, io); }
+#else
 // calls f(integral_constant<K>) for K == op, LO <= op < HI, through a balanced tree of comparisons (see shade_inline)
 template <uint32_t K>
 struct OpConst { static constexpr uint32_t value = K; };
@@ -788,5 +806,6 @@ __device__ __noinline__ uint32_t shade_call(const RasterParams &P, uint32_t pi, 
 #undef VM_TER
 #undef VM_GET
 #undef VM_SET
+#endif  // RXR_JIT
 
 }  // namespace rxvm

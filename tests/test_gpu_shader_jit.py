@@ -1,0 +1,147 @@
+"""Program sets compiled at run time (rusterix_amd/csrc/rxr_jit.hip, RXR_SHADER_JIT=1): the same jump code as straight-line device
+code instead of the interpreter.  Every frame here is rendered three ways -- CPU oracle, interpreter kernels, compiled kernels --
+and the compiled frame must EQUAL the interpreter's (same float operations in the same order) and meet the oracle within the
+interpreter's own tolerance (exact for the arithmetic opcodes, +-1 for libm).  `rxr_debug_jit_info` proves which path ran."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import rusterix_amd
+from rusterix_amd import binding as B
+from rusterix_amd import scenes
+from rusterix_amd.binding import Program
+from tests import test_gpu_shaders as S
+
+pytestmark = pytest.mark.gpu
+W, H = 192, 128
+
+
+def jit_info(product):
+    rxr = C.CDLL(rusterix_amd.lib_paths()["rxr"])
+    rxr.rxr_debug_jit_info.restype = C.c_char_p
+    rxr.rxr_debug_jit_info.argtypes = [C.c_void_p]
+    product.lib.rxh_context.restype = C.c_void_p
+    return rxr.rxr_debug_jit_info(product.lib.rxh_context()).decode()
+
+
+def grid_scene(api, programs, time=0.25, lights=False):
+    """one textured 2D rectangle per program, side by side (every program of the set runs in the same frame)"""
+    scene = api.Scene.empty()
+    n = len(programs)
+    cols = int(np.ceil(np.sqrt(n)))
+    rows = (n + cols - 1) // cols
+    cw, ch = W / cols, H / rows
+    for k, prog in enumerate(programs):
+        idx = scene.add_program(prog)
+        r = api.Batch2D.from_rectangle(float(np.float32((k % cols) * cw)), float(np.float32((k // cols) * ch)), float(np.float32(cw)), float(np.float32(ch)))
+        r.source(B.PixelSource.StaticTileIndex(0)).shader(idx)
+        scene.add_d2_static(r)
+    if lights:
+        scene.lights([B.Light(B.LIGHT_POINT).with_position((60.0, 0.0, 40.0)).with_color((1.0, 0.9, 0.8)).with_intensity(1.5)
+                      .with_start_distance(10.0).with_end_distance(120.0).compile()])
+    assets = api.Assets.default().textures([B.Tile.from_texture(scenes.noise_texture(5, 32, 32))])
+    assets.patterns(S.patterns()).patterns(S.patterns()[::-1], normal=True).palette([(0.9, 0.1, 0.2), None, (0.2, 0.3, 0.9)])
+
+    def setup():
+        return api.Rasterizer.setup(None, B.Mat4.identity(), B.Mat4.identity()).time(time)
+
+    return scenes._result(api, scene, assets, setup, W, H, 40, "jit-grid")
+
+
+def three_ways(oracle, product, monkeypatch, build, tol=0, max_off=0):
+    monkeypatch.delenv("RXR_SHADER_JIT", raising=False)
+    interp = scenes.render(build(product)).copy()
+    assert jit_info(product) == ""
+    monkeypatch.setenv("RXR_SHADER_JIT", "1")
+    got = scenes.render(build(product)).copy()
+    info = jit_info(product)
+    assert info.startswith("compiled:"), info
+    monkeypatch.delenv("RXR_SHADER_JIT", raising=False)
+    assert np.array_equal(got, interp), f"compiled and interpreted frames differ in {(got != interp).any(axis=2).sum()} pixels; first at {np.argwhere((got != interp).any(axis=2))[:3].tolist()}"
+    ref = scenes.render(build(oracle))
+    diff = np.abs(got.astype(np.int16) - ref.astype(np.int16)).max(axis=2)
+    assert (diff > tol).sum() <= max_off, f"{(diff > tol).sum()} pixels differ from the oracle by more than {tol} (max {diff.max()})"
+    return got, info
+
+
+def test_every_exact_opcode(oracle, product, monkeypatch):
+    programs = [Program([S.A + [op] + S.TO_COLOR]) for op in S.EXACT_UNARY] + [Program([S.A + S.Bv + [op] + S.TO_COLOR]) for op in S.EXACT_BINARY]
+    got, info = three_ways(oracle, product, monkeypatch, lambda api: grid_scene(api, programs))
+    assert f"{len(programs)} program(s)" in info
+    assert len(np.unique(got.reshape(-1, 4), axis=0)) > 500
+
+
+def test_libm_opcodes(oracle, product, monkeypatch):
+    programs = [Program([S.A + [op] + S.TO_COLOR]) for op in S.LIBM_UNARY]
+    programs += [Program([(S.A + [("Push", 37.0)] if op == "Rotate2D" else S.A + S.Bv) + [op] + S.TO_COLOR]) for op in S.LIBM_BINARY]
+    three_ways(oracle, product, monkeypatch, lambda api: grid_scene(api, programs), tol=S.TOLERANCE)
+
+
+def test_ternaries_swizzles_fields_patterns_loops(oracle, product, monkeypatch):
+    tern = Program([S.A + S.Bv + [("Push", 0.3, 0.6, 0.9), "Mix", ("Push", -1.0), ("Push", 1.0), "Clamp",
+                                  ("Push", 0.0), ("Push", 1.0), "UV", ("GetComponents", [0]), ("Push", 4.0), "Mul", "Smoothstep", "Mul",
+                                  "Color", "Add", "Hitpoint", ("Push", 0.001), "Mul", "Add", "Time", ("Push", 0.1), "Mul", "Add",
+                                  "Dup", ("GetComponents", [2, 0]), ("SetComponents", [1, 2]), ("Push", 0.5), "Mul", "SetColor"]])
+    pats = Program([["UV", ("Push", 8.0), "Mul", ("Push", 0.0), "Sample", "UV", ("Push", 5.0), "Mul", ("Push", 1.0), "SampleNormal", ("Push", 0.25), "Mul", "Add",
+                     "UV", ("Push", 3.0), "Mul", ("Push", 9.0), "Sample", "Add", "SetColor"]])
+    loops = Program([[("Push", 0.0), ("StoreLocal", 0), "UV", ("GetComponents", [0]), ("Push", 40.0), "Mul", "Floor", ("StoreLocal", 2),
+                      ("For", [("Push", 0.0), ("StoreLocal", 1)], [("LoadLocal", 1), ("LoadLocal", 2), "Lt"],
+                       [("LoadLocal", 1), ("Push", 1.0), "Add", ("StoreLocal", 1)],
+                       [("LoadLocal", 1), ("Push", 2.0), "Mod", ("Push", 0.0), "Eq",
+                        ("If", [("LoadLocal", 0), ("Push", 0.07), "Add", ("StoreLocal", 0)], [("LoadLocal", 0), ("Push", 0.02), "Add", ("StoreLocal", 0)]),
+                        ("Push", 5.0)]),
+                      ("LoadLocal", 0), "UV", ("GetComponents", [1]), ("Push", 4.0), "Mul", ("LoadLocal", 2), ("Push", 0.04), "Mul", "Pack3", "SetColor"]], shade_locals=3)
+    glob = Program([["UV", ("StoreGlobal", 1), ("LoadGlobal", 1), ("Push", 4.0), "Mul", "UV", "Swap", "Clear", ("Push", 0.5), "Add", "SetColor"]], globals=2)
+    early = Program([["UV", ("GetComponents", [0]), ("Push", 0.05), "Lt", ("If", [("Push", 1.0, 0.0, 0.0), "SetColor", "Return"], None), "UV", ("Push", 4.0), "Mul", "SetColor"]])
+    got, _ = three_ways(oracle, product, monkeypatch, lambda api: grid_scene(api, [tern, pats, loops, glob, early], time=0.75, lights=True))
+    assert len(np.unique(got.reshape(-1, 4), axis=0)) > 200
+
+
+def test_random_programs(oracle, product, monkeypatch):
+    programs = []
+    for seed in range(14):
+        rng = np.random.default_rng([0x52585231, 9001, seed])
+        programs.append(S.ProgramGen(rng, n_locals=int(rng.integers(3, 6)), n_functions=0, setters=["SetColor"]).program())
+    three_ways(oracle, product, monkeypatch, lambda api: grid_scene(api, programs, time=0.5), tol=S.TOLERANCE, max_off=6)
+
+
+@pytest.mark.parametrize("seed", [1, 4, 9])
+def test_random_cube_materials(oracle, product, monkeypatch, seed):
+    """3D opaque pass: colour / roughness / metallic of a compiled program feed the lighting (log2 / exp2 against libm: +-1)"""
+    rng = np.random.default_rng([0x52585231, 778, seed])
+    prog = S.ProgramGen(rng, n_locals=int(rng.integers(3, 6)), n_functions=0).program()
+    three_ways(oracle, product, monkeypatch, lambda api: S.cube_scene(api, prog), tol=S.TOLERANCE, max_off=5)
+
+
+def test_program_that_decides_visibility_and_the_opacity_pass(oracle, product, monkeypatch):
+    """SetOpacity in the opaque pass (the visibility loop runs the compiled program: k_raster_jit_v) and a program on an opacity-list batch"""
+    cut = Program([["UV", ("Push", 8.0), "Mul", "Fract", ("GetComponents", [0]), ("Push", 0.5), "Lt", ("If", [("Push", 0.0), "SetOpacity"], [("Push", 1.0), "SetOpacity"]),
+                    "Color", ("Push", 0.9), "Mul", "SetColor"]])
+    three_ways(oracle, product, monkeypatch, lambda api: S.cube_scene(api, cut), tol=S.TOLERANCE, max_off=5)
+    tint = Program([["Color", ("Push", 0.5, 1.0, 0.7), "Mul", "SetColor", ("Push", 0.6), "SetOpacity"]])
+    three_ways(oracle, product, monkeypatch, lambda api: S.cube_scene(api, tint, opacity_list=True), tol=S.TOLERANCE, max_off=5)
+
+
+def test_faults_are_reported_by_compiled_programs(product, monkeypatch):
+    monkeypatch.setenv("RXR_SHADER_JIT", "1")
+    bad = Program([["UV", ("Push", 1.0), ("Push", 0.0), "Clamp", "SetColor"]])  # clamp with min > max: the reference panics
+    with pytest.raises(B.RasterizeError) as e:
+        scenes.render(grid_scene(product, [bad]))
+    assert e.value.code == B.RXR_ERR_INVALID and "clamp" in str(e.value).lower()
+    assert jit_info(product).startswith("compiled:")
+
+
+def test_sets_with_calls_keep_the_interpreter(oracle, product, monkeypatch):
+    monkeypatch.setenv("RXR_SHADER_JIT", "1")
+    helper = [("LoadLocal", 0), ("Push", 0.5), "Mul", "Return"]
+    prog = Program([["UV", ("FunctionCall", 1, 1, 1), "SetColor"], helper])
+    got = scenes.render(grid_scene(product, [prog]))
+    assert jit_info(product).startswith("not compiled:")
+    assert np.array_equal(got, scenes.render(grid_scene(oracle, [prog])))
+
+
+def test_box_grid_with_the_configuration_c5_program(oracle, product, monkeypatch):
+    """the per-batch program of BASELINE.json's C5 on the reduced grid (binned path, row mode, Linear sampling)"""
+    build = lambda api: scenes.box_grid_scene(api, n=32, width=640, height=360, shader=True)  # noqa: E731
+    three_ways(oracle, product, monkeypatch, build, tol=0, max_off=0)
