@@ -17,6 +17,7 @@
 
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -225,7 +226,7 @@ bool rxr_jit_compile(const std::string &gen, const std::string &arch, std::vecto
     seconds = 0.0;
     {
         std::lock_guard<std::mutex> lk(g_cache_mu);
-        auto it = g_code_objects.find(arch + "\n" + gen);
+        auto it = g_code_objects.find(arch + "\n" + (getenv("RXR_JIT_FLAGS") ? getenv("RXR_JIT_FLAGS") : "") + "\n" + gen);
         if (it != g_code_objects.end()) {
             obj = it->second;
             return true;
@@ -241,9 +242,21 @@ bool rxr_jit_compile(const std::string &gen, const std::string &arch, std::vecto
         return false;
     }
     const std::string arch_opt = "--offload-arch=" + arch;
-    const char *opts[] = {arch_opt.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize"};
+    std::vector<std::string> extra;  // RXR_JIT_FLAGS: further compiler options, blank-separated (tuning runs: -DRXR_JIT_WAVES_PER_SIMD=6 ...)
+    if (const char *e = getenv("RXR_JIT_FLAGS")) {
+        std::string cur;
+        for (const char *c = e;; ++c) {
+            if (*c == ' ' || *c == 0) {
+                if (!cur.empty()) extra.push_back(cur);
+                cur.clear();
+                if (!*c) break;
+            } else cur += *c;
+        }
+    }
+    std::vector<const char *> opts = {arch_opt.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize"};
+    for (const std::string &x : extra) opts.push_back(x.c_str());
     const auto t0 = std::chrono::steady_clock::now();
-    const hiprtcResult r = hiprtcCompileProgram(prog, (int)(sizeof(opts) / sizeof(opts[0])), opts);
+    const hiprtcResult r = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
     seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (r != HIPRTC_SUCCESS) {
         size_t n = 0;
@@ -266,7 +279,7 @@ bool rxr_jit_compile(const std::string &gen, const std::string &arch, std::vecto
     (void)hiprtcGetCode(prog, obj.data());
     (void)hiprtcDestroyProgram(&prog);
     std::lock_guard<std::mutex> lk(g_cache_mu);
-    g_code_objects[arch + "\n" + gen] = obj;
+    g_code_objects[arch + "\n" + (getenv("RXR_JIT_FLAGS") ? getenv("RXR_JIT_FLAGS") : "") + "\n" + gen] = obj;
     return true;
 }
 

@@ -2489,7 +2489,7 @@ __device__ __forceinline__ const RasterParams &kernarg_params_early() { return *
 #ifdef RXR_JIT
 // the two kernels of a run-time compiled program set: feature level 2 (programs may decide visibility) and 7 (none does)
 #ifndef RXR_JIT_WAVES_PER_SIMD
-#define RXR_JIT_WAVES_PER_SIMD 8
+#define RXR_JIT_WAVES_PER_SIMD 7  // 1 M triangles with the configuration-C5 program: 8 (64 VGPRs) 695 us, 7: 666, 6: 694, 5: 763
 #endif
 extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_JIT_WAVES_PER_SIMD) k_raster_jit_v(RasterParams) { raster_tile<false, 2, true>(kernarg_params_early()); }
 extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_JIT_WAVES_PER_SIMD) k_raster_jit(RasterParams) { raster_tile<false, 7, true>(kernarg_params_early()); }

@@ -1,0 +1,63 @@
+"""The device-free half of the run-time compiler of program sets (rusterix_amd/csrc/rxr_jit.hip): code generation from the jump
+code and the hiprtc compilation for gfx950 need no GPU (`rxr_debug_jit_generate`); loading and running the kernels is
+tests/test_gpu_shader_jit.py."""
+import ctypes as C
+import re
+
+import numpy as np
+
+import rusterix_amd
+from rusterix_amd import binding as B
+from rusterix_amd import scenes
+from rusterix_amd.binding import Program
+from tests import test_shader_validation as V
+
+
+def generate(programs, compile_):
+    lib = rusterix_amd.load_rxr()
+    lib.rxr_debug_jit_generate.argtypes = [C.POINTER(V.RxrShaderSet), C.c_int, C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32]
+    keep = []
+    progs = (V.RxrProgram * len(programs))()
+    for i, p in enumerate(programs):
+        fns = (V.RxrFunction * max(len(p.functions), 1))()
+        for k, f in enumerate(p.functions):
+            arr = np.asarray(f if len(f) else [0], np.uint32)
+            keep.append(arr)
+            fns[k] = V.RxrFunction(arr.ctypes.data_as(C.POINTER(C.c_uint32)), len(f))
+        keep.append(fns)
+        progs[i] = V.RxrProgram(p.globals, p.shade_index, p.shade_locals, fns, len(p.functions))
+    s = V.RxrShaderSet(progs, len(programs), None, 0, None, 0, None, None, 0)
+    src, msg = C.create_string_buffer(1 << 20), C.create_string_buffer(4096)
+    rc = lib.rxr_debug_jit_generate(C.byref(s), compile_, src, len(src), msg, len(msg))
+    return rc, src.value.decode(), msg.value.decode()
+
+
+def test_the_configuration_c5_program_becomes_straight_line_code_and_compiles():
+    rc, src, msg = generate([scenes.box_grid_shader()], 1)
+    assert rc == 0 and msg.startswith("compiled in"), msg
+    body = src[src.index("rxr_jit_prog_0"):]
+    # stack slots are variables, the fused "Push c; op" pairs keep their constants bit for bit, the If is two gotos
+    assert "v3 s0" in body and "jit_binc<2u>(s0, mk(__uint_as_float(0x40800000u)" in body and len(re.findall(r"goto L\d", body)) == 2
+    assert "io.color = s0;" in body and "rxr_jit_shade(const RasterParams &P, uint32_t pi" in src
+
+
+def test_loops_locals_globals_and_faults_are_generated():
+    prog = Program([[("Push", 0.0), ("StoreLocal", 0),
+                     ("For", [("Push", 0.0), ("StoreLocal", 1)], [("LoadLocal", 1), ("Push", 3.0), "Lt"], [("LoadLocal", 1), ("Push", 1.0), "Add", ("StoreLocal", 1)],
+                      [("LoadLocal", 0), ("Push", 0.1), "Add", ("StoreLocal", 0)]),
+                     ("LoadLocal", 0), ("StoreGlobal", 0), ("LoadGlobal", 0), ("Push", 0.0), ("Push", 1.0), "Clamp", "SetColor"]],
+                   shade_locals=2, globals=1)
+    rc, src, msg = generate([prog, Program([[]])], 0)
+    assert rc == 0, msg
+    assert "v3 l0" in src and "v3 l1" in src and "v3 g0" in src
+    assert re.search(r"if \(\+\+steps > 1048576u\)", src), "the backward jump of a For loop counts steps like the interpreter"
+    assert "jit_clamp_ok" in src and f"fault = {8}u" in src        # VMF_CLAMP_BOUNDS
+    assert "rxr_jit_prog_1" in src
+
+
+def test_sets_with_calls_or_palette_lookups_are_left_to_the_interpreter():
+    helper = [("LoadLocal", 0), "Return"]
+    rc, _, msg = generate([Program([["UV", ("FunctionCall", 1, 1, 1), "SetColor"], helper])], 0)
+    assert rc == B.RXR_ERR_UNSUPPORTED and "calls" in msg
+    rc, _, msg = generate([Program([["UV", "PaletteIndex", "SetColor"]])], 0)
+    assert rc == B.RXR_ERR_UNSUPPORTED

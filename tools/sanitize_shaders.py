@@ -27,6 +27,30 @@ class Raw:
         self.functions, self.globals, self.shade_index, self.shade_locals = functions, n_globals, shade_index, shade_locals
 
 
+generated = 0
+
+
+def jit_generate(p):
+    import ctypes as C
+
+    import rusterix_amd
+
+    lib = rusterix_amd.load_rxr()
+    lib.rxr_debug_jit_generate.argtypes = [C.POINTER(V.RxrShaderSet), C.c_int, C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32]
+    keep = []
+    fns = (V.RxrFunction * max(len(p.functions), 1))()
+    for k, f in enumerate(p.functions):
+        arr = np.asarray(f if len(f) else [0], np.uint32)
+        keep.append(arr)
+        fns[k] = V.RxrFunction(arr.ctypes.data_as(C.POINTER(C.c_uint32)), len(f))
+    progs = (V.RxrProgram * 1)(V.RxrProgram(p.globals, p.shade_index, p.shade_locals, fns, len(p.functions)))
+    s = V.RxrShaderSet(progs, 1, None, 0, None, 0, None, None, 0)
+    src, msg = C.create_string_buffer(1 << 18), C.create_string_buffer(512)
+    rc = lib.rxr_debug_jit_generate(C.byref(s), 0, src, len(src), msg, len(msg))
+    assert rc in (0, B.RXR_ERR_UNSUPPORTED), (rc, msg.value)
+    return 1 if rc == 0 and b"rxr_jit_shade" in src.value else 0
+
+
 def tally(rc):
     counts[rc] = counts.get(rc, 0) + 1
 
@@ -36,6 +60,8 @@ for seed in range(n):
     prog = S.ProgramGen(rng, n_locals=int(rng.integers(1, 6)), n_functions=int(rng.integers(0, 3))).program()
     rc, msg, words = V.check(prog)
     tally(rc)
+    if rc == 0:  # the run-time compiler's code generator (rxr_jit.hip) on the same set, without the compile step
+        generated += jit_generate(prog)
     assert "librxr_hip_hostasan.so" in open("/proc/self/maps").read()
     fns = [list(f) for f in prog.functions]
     for _ in range(12):
@@ -66,4 +92,4 @@ for seed in range(n):
         rc, msg, words = V.check(Raw(mutated, hdr["n_globals"], hdr["shade_index"], hdr["shade_locals"]))
         tally(rc)
 names = {0: "OK", B.RXR_ERR_INVALID: "INVALID", B.RXR_ERR_UNSUPPORTED: "UNSUPPORTED"}
-print("shader boundary under sanitizers: clean;", ", ".join(f"{names.get(k, k)}: {v}" for k, v in sorted(counts.items(), reverse=True)))
+print(f"shader boundary under sanitizers: clean; run-time compiler generated code for {generated} sets;", ", ".join(f"{names.get(k, k)}: {v}" for k, v in sorted(counts.items(), reverse=True)))
