@@ -92,7 +92,8 @@ struct rxr_ctx {
     bool scratch2d_dirty = false;
     uint32_t min_kernel_level = 0;   // RXR_MIN_KERNEL_LEVEL (tuning)
     // run-time compiled kernels of the current program set (rxr_jit.hip; opt-in RXR_SHADER_JIT=1), else null: the interpreter runs
-    void *jit_module = nullptr, *jit_fn = nullptr, *jit_fn_v = nullptr;
+    void *jit_module = nullptr, *jit_fn = nullptr, *jit_fn_v = nullptr, *jit_fn_p = nullptr;
+    bool frame_needs_chunk_paths = true;  // the uploaded frame uses what feature level 1 adds (terrain / baked textures / staircase / editor paths)
     std::string jit_info;                // what happened to the last set ("compiled: ...", "not compiled: <why>", empty: not asked)
     bool programs_static = false;    // every program of the set has a stack depth that is a function of the pc (tag_static_depths)
     uint32_t small_mode = 2;         // RasterParams.fused_small for frames with <= RXR_STAGE_TRIS triangles;

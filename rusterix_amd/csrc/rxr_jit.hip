@@ -218,7 +218,7 @@ std::map<std::string, std::vector<char>> g_code_objects;  // generated source ->
 void rxr_jit_drop(rxr_ctx *ctx) {
     if (ctx->jit_module) (void)hipModuleUnload((hipModule_t)ctx->jit_module);
     ctx->jit_module = nullptr;
-    ctx->jit_fn = ctx->jit_fn_v = nullptr;
+    ctx->jit_fn = ctx->jit_fn_v = ctx->jit_fn_p = nullptr;
 }
 
 // generated header -> code object for `arch` ("gfx950"), through the process-wide cache; needs no device
@@ -308,9 +308,10 @@ int rxr_jit_build(rxr_ctx *ctx, const std::vector<uint32_t> &code, const std::ve
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipModule_t mod = nullptr;
     hipError_t e = hipModuleLoadData(&mod, obj.data());
-    hipFunction_t fn = nullptr, fn_v = nullptr;
+    hipFunction_t fn = nullptr, fn_v = nullptr, fn_p = nullptr;
     if (e == hipSuccess) e = hipModuleGetFunction(&fn, mod, "k_raster_jit");
     if (e == hipSuccess) e = hipModuleGetFunction(&fn_v, mod, "k_raster_jit_v");
+    if (e == hipSuccess) e = hipModuleGetFunction(&fn_p, mod, "k_raster_jit_p");
     if (e != hipSuccess) {
         if (mod) (void)hipModuleUnload(mod);
         ctx->jit_info = std::string("not loaded: ") + hipGetErrorString(e);
@@ -319,6 +320,7 @@ int rxr_jit_build(rxr_ctx *ctx, const std::vector<uint32_t> &code, const std::ve
     ctx->jit_module = mod;
     ctx->jit_fn = fn;
     ctx->jit_fn_v = fn_v;
+    ctx->jit_fn_p = fn_p;
     char msg[200];
     snprintf(msg, sizeof msg, "compiled: %zu program(s), %zu words of jump code, %zu bytes of code object, %.2f s%s", progs.size(), code.size(), obj.size(), seconds,
              seconds == 0.0 ? " (cached)" : "");
@@ -330,8 +332,10 @@ int rxr_jit_build(rxr_ctx *ctx, const std::vector<uint32_t> &code, const std::ve
 bool rxr_jit_launch(rxr_ctx *ctx, const RasterParams *P, hipStream_t s) {
     if (!ctx->jit_fn || P->kernel_level < 2u) return false;
     if (P->tiles_x * P->tiles_y == 0) return true;
-    // kernel levels 6 / 7: no program of the opaque pass decides visibility (rxr_upload_frame); 2 .. 5: one may
-    hipFunction_t fn = (hipFunction_t)(P->kernel_level >= 6u ? ctx->jit_fn : ctx->jit_fn_v);
+    // RasterParams.kernel_level 4 / 5 (k_raster_vm_sv / _v, template levels 6 / 7): no program of the opaque pass decides
+    // visibility (rxr_upload_frame); 2 / 3: one may
+    // ... and when the frame needs none of the chunk paths either, the kernel without them (template level 8)
+    hipFunction_t fn = (hipFunction_t)(P->kernel_level >= 4u ? (ctx->frame_needs_chunk_paths ? ctx->jit_fn : ctx->jit_fn_p) : ctx->jit_fn_v);
     RasterParams params = *P;
     size_t size = sizeof(params);
     void *config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &params, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};

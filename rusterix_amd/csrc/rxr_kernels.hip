@@ -482,6 +482,10 @@ __device__ __forceinline__ uint32_t brush_over_texel(const RasterParams &P, uint
     return out;
 }
 
+// feature level (template parameter X of the raster code, see below) -> does it carry the chunk paths of level 1 (terrain, baked shader
+// textures, opacity staircase, grid background, brush)?  Level 8 is "programs without them" (run-time compiled sets only)
+template <int X> inline constexpr bool lvl1 = X >= 1 && X != 8;
+
 // the texel switch of the raster loops (rasterizer.rs:1101-1222, :672-758); (wx, wy) is the position terrain batches sample at;
 // `world3`: the fragment's world position in the two 3D loops (terrain brush preview), nullptr in the 2D loop
 // UNIFORM: `B` is the same batch for every lane (the 2D pass walks one primitive at a time) -- its texture descriptor then
@@ -489,7 +493,7 @@ __device__ __forceinline__ uint32_t brush_over_texel(const RasterParams &P, uint
 template <int X, bool UNIFORM = false>
 __device__ __forceinline__ uint32_t batch_texel(const RasterParams &P, const DevBatch &B, float u, float v, float wx, float wy, const f3 *world3 = nullptr) {
     if (B.tex < 0) return B.pixel;
-    if constexpr (X >= 1) {
+    if constexpr (lvl1<X>) {
         if (B.flags & DB_TERRAIN) {
             uint32_t t = terrain_texel(P, B, wx, wy);
             if (P.has_brush && world3) t = brush_over_texel(P, t, *world3);
@@ -511,7 +515,9 @@ __device__ __forceinline__ uint32_t batch_texel(const RasterParams &P, const Dev
 // 6 = 4 for frames in which no program decides whether an opaque fragment is written (none of the opaque pass's programs
 // writes `opacity`): the visibility loop's alpha test is level 1's, inlined, and the loop contains no call
 // 7 = 2 for such frames (programs with calls or PaletteIndex: per-lane stack pointer)
-template <int X> struct vm_level { static constexpr bool ssp = X >= 4 && X <= 6; static constexpr bool inline_site = X == 2 || X == 4 || X == 6 || X == 7; static constexpr int out_of_line = ssp ? 5 : 3; static constexpr bool vis_programs = X < 6; };
+// 8 = programs WITHOUT the chunk paths of level 1 (run-time compiled sets only, rxr_jit.hip: a frame whose batches run programs but
+// use no terrain / baked texture / staircase / editor background gets level 0's fragment code around its compiled programs)
+template <int X> struct vm_level { static constexpr bool ssp = X >= 4 && X <= 6; static constexpr bool inline_site = X == 2 || X == 4 || X == 6 || X == 7 || X == 8; static constexpr int out_of_line = ssp ? 5 : 3; static constexpr bool vis_programs = X < 6; };
 
 // ---- the covered-fragment block of d3_rasterize after the depth test (rasterizer.rs:1062-1404) ----
 // Split in three so that the light loop runs in wave-uniform control flow (see shade3d_lights).
@@ -560,7 +566,7 @@ __device__ __forceinline__ void shade3d_begin(const RasterParams &P, const TriSh
     f3 base = mk3(srgb_to_linear_fast((float)(texel & 0xFFu) * INV_255), srgb_to_linear_fast((float)((texel >> 8) & 0xFFu) * INV_255),
                   srgb_to_linear_fast((float)((texel >> 16) & 0xFFu) * INV_255));
     F.opacity = rxm::div1_known((float)(texel >> 24), 255.0f, true);  // :1313; byte / 255 is inside the division window
-    if (X >= 1 && B.baked_plus1) {  // chunk.shader_textures: the baked texel replaces colour and alpha, no program runs (:1239-1267)
+    if (lvl1<X> && B.baked_plus1) {  // chunk.shader_textures: the baked texel replaces colour and alpha, no program runs (:1239-1267)
         const DevTexDesc &bd = P.tex[B.baked_plus1 - 1u];
         uint32_t bt = sample_texture(bd, texel_base(P, bd), u, v, P.sample_mode, B.repeat_mode);
         base = mk3(srgb_to_linear_fast((float)(bt & 0xFFu) * INV_255), srgb_to_linear_fast((float)((bt >> 8) & 0xFFu) * INV_255),
@@ -742,7 +748,7 @@ __device__ __forceinline__ uint32_t shade3d_opacity(const RasterParams &P, const
     fragment_uv(S, alpha, beta, gamma, u, v);
     // screen_to_world (:1515, :1707-1727): needed by terrain texels and by programs
     float wx = 0.0f, wy = 0.0f, wz = 0.0f;
-    if ((X >= 1 && (B.flags & DB_TERRAIN)) || (X >= 2 && B.program_plus1)) {
+    if ((lvl1<X> && (B.flags & DB_TERRAIN)) || (X >= 2 && B.program_plus1)) {
         float x_ndc = 2.0f * (fx / P.fwidth) - 1.0f;
         float y_ndc = 1.0f - 2.0f * (fy / P.fheight);
         float vx, vy, vz, vw, ww;
@@ -1581,7 +1587,7 @@ __device__ __forceinline__ void visit(const RasterParams &P, const TriSetup &S, 
     if (is_opacity != OPACITY) return;
     if (!OPACITY) {
         // surface_id[idx].is_some() && surface_id[idx] == batch.profile_id  (:1044-1048)
-        if constexpr (X >= 1) {
+        if constexpr (lvl1<X>) {
             if (S.bflags & DB_HAS_PROFILE) {
                 const int sp = front_lookup(*opf, (int)t);
                 if (sp >= 0 && (uint32_t)sp == S.profile_id) return;
@@ -1594,10 +1600,10 @@ __device__ __forceinline__ void visit(const RasterParams &P, const TriSetup &S, 
     float alpha, beta, z;
     bary_depth(S.v0x, S.v0y, S.v1x, S.v1y, S.v2x, S.v2y, S.area, S.iz0, S.iz1, S.iz2, fx, fy, alpha, beta, z);
     const float gamma = 1.0f - alpha - beta;
-    if constexpr (OPACITY && X >= 1) front_insert(vis, z, (int)t, (S.bflags & DB_HAS_PROFILE) ? (int)S.profile_id : -1, (int)(S.bflags >> DB_GROUP_SHIFT), P.staircase_overflow);
+    if constexpr (OPACITY && lvl1<X>) front_insert(vis, z, (int)t, (S.bflags & DB_HAS_PROFILE) ? (int)S.profile_id : -1, (int)(S.bflags >> DB_GROUP_SHIFT), P.staircase_overflow);
     bool take = z < vis.zmin || (z == vis.zmin && vis.best >= 0 && (int)t < vis.best);
     if (take) {
-        if (X >= 1 && !OPACITY && (S.bflags & DB_FULL_ALPHA)) {  // frames with such batches run k_raster_chunk / k_raster_vm (RasterParams.kernel_level)
+        if (lvl1<X> && !OPACITY && (S.bflags & DB_FULL_ALPHA)) {  // frames with such batches run k_raster_chunk / k_raster_vm (RasterParams.kernel_level)
             take = fragment_alpha_is_255_full<X>(P, shade, S.batch, alpha, beta, z, fx, fy);
         } else if (!OPACITY && (S.bflags & DB_ALPHA_TEST)) {
             // the fragment is only written when its encoded alpha is 255 (:1408): sample it now
@@ -2006,7 +2012,7 @@ __device__ __forceinline__ void scan_lists_rows(const RasterParams &P, Stage &st
         __syncthreads();
         // 4. the rows of the candidates' boxes, or the walk
         PHASE_MARK(1);
-        if (row_mode && rows_round<true, (RXR_ROWS_PIXEL_ITEMS != 0) && (X < 2)>(P, st, rl, n, tile_x0, tile_y0px)) {
+        if (row_mode && rows_round<true, (RXR_ROWS_PIXEL_ITEMS != 0) && (X < 2 || X == 8)>(P, st, rl, n, tile_x0, tile_y0px)) {
             PHASE_MARK(7);
             continue;
         }
@@ -2253,7 +2259,7 @@ __device__ __forceinline__ void raster_tile(const RasterParams &P) {
         if (P.background_kind == RXR_BG_VGRADIENT) {
             uint32_t i = sat_u8(rclamp(((float)py / P.fheight) * 128.0f, 0.0f, 128.0f));  // shader/vgradient.rs:11-15
             color = pack4(i, i, i, 255u);
-        } else if (X >= 1 && P.background_kind == RXR_BG_GRID) {  // (editor-only: feature level >= 1, see rxr_upload_frame)
+        } else if (lvl1<X> && P.background_kind == RXR_BG_GRID) {  // (editor-only: feature level >= 1, see rxr_upload_frame)
             color = grid_shade(P, px, py);
         } else if (P.background_kind == RXR_BG_HOST_PIXELS && in_frame) {
             color = P.bg_pixels[(size_t)py * P.width + px];
@@ -2341,7 +2347,7 @@ __device__ __forceinline__ void raster_tile(const RasterParams &P) {
         if (P.n_lights) shade3d_lights<X>(P, hit, F);  // wave-uniform call
         PHASE_MARK(3);
         color = hit ? shade3d_end<X>(F) : pack4(0u, 0u, 0u, 255u);
-        if constexpr (X >= 1) {
+        if constexpr (lvl1<X>) {
             if (P.has_brush && !hit) color = miss_brush_preview(P, px, py);  // :435-458
         }
         PHASE_MARK(4);
@@ -2488,11 +2494,18 @@ __device__ __forceinline__ const RasterParams &kernarg_params_early() { return *
 // box: bench frame 208 -> 198 us, the 1-light frame 126 -> 117 us.
 #ifdef RXR_JIT
 // the two kernels of a run-time compiled program set: feature level 2 (programs may decide visibility) and 7 (none does)
+// (1 M triangles with the configuration-C5 program, raster kernel: level 7 at 8 waves per SIMD (64 VGPRs) 656 us, 7: 676, 6: 710;
+// level 2 at 8: 695 us, 7: 666, 6: 694, 5: 763 -- the interpreter kernels take 1180 us)
 #ifndef RXR_JIT_WAVES_PER_SIMD
-#define RXR_JIT_WAVES_PER_SIMD 7  // 1 M triangles with the configuration-C5 program: 8 (64 VGPRs) 695 us, 7: 666, 6: 694, 5: 763
+#define RXR_JIT_WAVES_PER_SIMD 8
 #endif
-extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_JIT_WAVES_PER_SIMD) k_raster_jit_v(RasterParams) { raster_tile<false, 2, true>(kernarg_params_early()); }
+#ifndef RXR_JIT_V_WAVES_PER_SIMD
+#define RXR_JIT_V_WAVES_PER_SIMD 7
+#endif
+extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_JIT_V_WAVES_PER_SIMD) k_raster_jit_v(RasterParams) { raster_tile<false, 2, true>(kernarg_params_early()); }
 extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_JIT_WAVES_PER_SIMD) k_raster_jit(RasterParams) { raster_tile<false, 7, true>(kernarg_params_early()); }
+// ... and level 8: as 7 for frames that need none of level 1's chunk paths
+extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_JIT_WAVES_PER_SIMD) k_raster_jit_p(RasterParams) { raster_tile<false, 8, true>(kernarg_params_early()); }
 #else
 #ifndef RXR_RASTER_KERNARG_IN_PLACE
 #define RXR_RASTER_KERNARG_IN_PLACE 1
