@@ -92,7 +92,11 @@ struct rxr_ctx {
     bool scratch2d_dirty = false;
     uint32_t min_kernel_level = 0;   // RXR_MIN_KERNEL_LEVEL (tuning)
     // run-time compiled kernels of the current program set (rxr_jit.hip; opt-in RXR_SHADER_JIT=1), else null: the interpreter runs
-    void *jit_module = nullptr, *jit_fn = nullptr, *jit_fn_v = nullptr, *jit_fn_p = nullptr;
+    // (one module per template level 2 / 7 / 8, compiled when the first frame that needs it is launched; jit_source: the generated
+    // programs of the current set, empty when the set is not covered)
+    void *jit_module[3] = {nullptr, nullptr, nullptr}, *jit_fn[3] = {nullptr, nullptr, nullptr};
+    bool jit_failed[3] = {false, false, false};
+    std::string jit_source, jit_arch;
     bool frame_needs_chunk_paths = true;  // the uploaded frame uses what feature level 1 adds (terrain / baked textures / staircase / editor paths)
     std::string jit_info;                // what happened to the last set ("compiled: ...", "not compiled: <why>", empty: not asked)
     bool programs_static = false;    // every program of the set has a stack depth that is a function of the pc (tag_static_depths)
@@ -166,7 +170,7 @@ int rxr_group_get_stats(rxr_ctx *ctx, rxr_stats *out);
 
 // rxr_jit.hip: program sets compiled at run time
 bool rxr_jit_generate(const std::vector<uint32_t> &code, const std::vector<DevProgram> &progs, std::string &src, std::string &why);
-bool rxr_jit_compile(const std::string &gen, const std::string &arch, std::vector<char> &obj, double &seconds, std::string &err);
+bool rxr_jit_compile(const std::string &gen, const std::string &arch, int level, std::vector<char> &obj, double &seconds, std::string &err);
 int rxr_jit_build(rxr_ctx *ctx, const std::vector<uint32_t> &code, const std::vector<DevProgram> &progs);
 void rxr_jit_drop(rxr_ctx *ctx);
 bool rxr_jit_launch(rxr_ctx *ctx, const RasterParams *P, hipStream_t s);

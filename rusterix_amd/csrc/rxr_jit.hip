@@ -216,17 +216,23 @@ std::map<std::string, std::vector<char>> g_code_objects;  // generated source ->
 }  // namespace
 
 void rxr_jit_drop(rxr_ctx *ctx) {
-    if (ctx->jit_module) (void)hipModuleUnload((hipModule_t)ctx->jit_module);
-    ctx->jit_module = nullptr;
-    ctx->jit_fn = ctx->jit_fn_v = ctx->jit_fn_p = nullptr;
+    for (int k = 0; k < 3; ++k) {
+        if (ctx->jit_module[k]) (void)hipModuleUnload((hipModule_t)ctx->jit_module[k]);
+        ctx->jit_module[k] = ctx->jit_fn[k] = nullptr;
+        ctx->jit_failed[k] = false;
+    }
+    ctx->jit_source.clear();
 }
 
-// generated header -> code object for `arch` ("gfx950"), through the process-wide cache; needs no device
-bool rxr_jit_compile(const std::string &gen, const std::string &arch, std::vector<char> &obj, double &seconds, std::string &err) {
+// generated header -> code object of the raster kernel at template level `level` (2 / 7 / 8) for `arch` ("gfx950"), through the
+// process-wide cache; needs no device
+bool rxr_jit_compile(const std::string &gen, const std::string &arch, int level, std::vector<char> &obj, double &seconds, std::string &err) {
     seconds = 0.0;
+    const char *flags_env = getenv("RXR_JIT_FLAGS");  // further compiler options, blank-separated (tuning runs: -DRXR_JIT_WAVES_PER_SIMD=6 ...)
+    const std::string key = arch + "\n" + std::to_string(level) + "\n" + (flags_env ? flags_env : "") + "\n" + gen;
     {
         std::lock_guard<std::mutex> lk(g_cache_mu);
-        auto it = g_code_objects.find(arch + "\n" + (getenv("RXR_JIT_FLAGS") ? getenv("RXR_JIT_FLAGS") : "") + "\n" + gen);
+        auto it = g_code_objects.find(key);
         if (it != g_code_objects.end()) {
             obj = it->second;
             return true;
@@ -241,11 +247,11 @@ bool rxr_jit_compile(const std::string &gen, const std::string &arch, std::vecto
         err = "hiprtcCreateProgram failed";
         return false;
     }
-    const std::string arch_opt = "--offload-arch=" + arch;
-    std::vector<std::string> extra;  // RXR_JIT_FLAGS: further compiler options, blank-separated (tuning runs: -DRXR_JIT_WAVES_PER_SIMD=6 ...)
-    if (const char *e = getenv("RXR_JIT_FLAGS")) {
+    const std::string arch_opt = "--offload-arch=" + arch, level_opt = "-DRXR_JIT_LEVEL=" + std::to_string(level);
+    std::vector<std::string> extra;
+    if (flags_env) {
         std::string cur;
-        for (const char *c = e;; ++c) {
+        for (const char *c = flags_env;; ++c) {
             if (*c == ' ' || *c == 0) {
                 if (!cur.empty()) extra.push_back(cur);
                 cur.clear();
@@ -253,7 +259,7 @@ bool rxr_jit_compile(const std::string &gen, const std::string &arch, std::vecto
             } else cur += *c;
         }
     }
-    std::vector<const char *> opts = {arch_opt.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize"};
+    std::vector<const char *> opts = {arch_opt.c_str(), level_opt.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize"};
     for (const std::string &x : extra) opts.push_back(x.c_str());
     const auto t0 = std::chrono::steady_clock::now();
     const hiprtcResult r = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
@@ -279,12 +285,12 @@ bool rxr_jit_compile(const std::string &gen, const std::string &arch, std::vecto
     (void)hiprtcGetCode(prog, obj.data());
     (void)hiprtcDestroyProgram(&prog);
     std::lock_guard<std::mutex> lk(g_cache_mu);
-    g_code_objects[arch + "\n" + (getenv("RXR_JIT_FLAGS") ? getenv("RXR_JIT_FLAGS") : "") + "\n" + gen] = obj;
+    g_code_objects[key] = obj;
     return true;
 }
 
-// compiles (or finds) the kernels of the set just flattened and loads them on ctx's device; RXR_OK also when the set is simply
-// not covered or the compiler fails (the interpreter stays in charge; ctx->jit_info says why)
+// the set just flattened: generates its programs and keeps the source; the kernels are compiled per template level when the first
+// frame that needs one is launched (rxr_jit_launch).  A set the generator does not cover leaves the interpreter in charge.
 int rxr_jit_build(rxr_ctx *ctx, const std::vector<uint32_t> &code, const std::vector<DevProgram> &progs) {
     rxr_jit_drop(ctx);
     ctx->jit_info.clear();
@@ -294,50 +300,62 @@ int rxr_jit_build(rxr_ctx *ctx, const std::vector<uint32_t> &code, const std::ve
         return RXR_OK;
     }
     hipDeviceProp_t props;
-    std::string arch = "gfx950";
+    ctx->jit_arch = "gfx950";
     if (hipGetDeviceProperties(&props, ctx->device) == hipSuccess && props.gcnArchName[0]) {
-        arch = props.gcnArchName;  // "gfx950:sramecc+:xnack-"
-        arch = arch.substr(0, arch.find(':'));
+        ctx->jit_arch = props.gcnArchName;  // "gfx950:sramecc+:xnack-"
+        ctx->jit_arch = ctx->jit_arch.substr(0, ctx->jit_arch.find(':'));
     }
-    std::vector<char> obj;
-    double seconds = 0.0;
-    if (!rxr_jit_compile(gen, arch, obj, seconds, why)) {
-        ctx->jit_info = "not compiled: " + why;
-        return RXR_OK;
-    }
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    hipModule_t mod = nullptr;
-    hipError_t e = hipModuleLoadData(&mod, obj.data());
-    hipFunction_t fn = nullptr, fn_v = nullptr, fn_p = nullptr;
-    if (e == hipSuccess) e = hipModuleGetFunction(&fn, mod, "k_raster_jit");
-    if (e == hipSuccess) e = hipModuleGetFunction(&fn_v, mod, "k_raster_jit_v");
-    if (e == hipSuccess) e = hipModuleGetFunction(&fn_p, mod, "k_raster_jit_p");
-    if (e != hipSuccess) {
-        if (mod) (void)hipModuleUnload(mod);
-        ctx->jit_info = std::string("not loaded: ") + hipGetErrorString(e);
-        return RXR_OK;
-    }
-    ctx->jit_module = mod;
-    ctx->jit_fn = fn;
-    ctx->jit_fn_v = fn_v;
-    ctx->jit_fn_p = fn_p;
-    char msg[200];
-    snprintf(msg, sizeof msg, "compiled: %zu program(s), %zu words of jump code, %zu bytes of code object, %.2f s%s", progs.size(), code.size(), obj.size(), seconds,
-             seconds == 0.0 ? " (cached)" : "");
+    ctx->jit_source.swap(gen);
+    char msg[160];
+    snprintf(msg, sizeof msg, "generated: %zu program(s), %zu words of jump code", progs.size(), code.size());
     ctx->jit_info = msg;
     return RXR_OK;
 }
 
-// the raster launch of a frame whose programs are compiled; false: no compiled kernels (the caller launches the interpreter kernels)
+namespace {
+// slot 0 / 1 / 2 = template level 2 / 7 / 8
+bool ensure_level(rxr_ctx *ctx, int slot) {
+    if (ctx->jit_fn[slot]) return true;
+    if (ctx->jit_failed[slot]) return false;
+    static const int levels[3] = {2, 7, 8};
+    std::vector<char> obj;
+    double seconds = 0.0;
+    std::string err;
+    if (!rxr_jit_compile(ctx->jit_source, ctx->jit_arch, levels[slot], obj, seconds, err)) {
+        ctx->jit_failed[slot] = true;
+        ctx->jit_info = "not compiled: " + err;
+        return false;
+    }
+    hipModule_t mod = nullptr;
+    hipFunction_t fn = nullptr;
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e == hipSuccess) e = hipModuleLoadData(&mod, obj.data());
+    if (e == hipSuccess) e = hipModuleGetFunction(&fn, mod, "k_raster_jit");
+    if (e != hipSuccess) {
+        if (mod) (void)hipModuleUnload(mod);
+        ctx->jit_failed[slot] = true;
+        ctx->jit_info = std::string("not loaded: ") + hipGetErrorString(e);
+        return false;
+    }
+    ctx->jit_module[slot] = mod;
+    ctx->jit_fn[slot] = fn;
+    char msg[200];
+    snprintf(msg, sizeof msg, "compiled: template level %d, %zu bytes of code object, %.2f s%s", levels[slot], obj.size(), seconds, seconds == 0.0 ? " (cached)" : "");
+    ctx->jit_info = msg;
+    return true;
+}
+}  // namespace
+
+// the raster launch of a frame whose programs are compiled; false: no compiled kernel (the caller launches the interpreter kernels)
 bool rxr_jit_launch(rxr_ctx *ctx, const RasterParams *P, hipStream_t s) {
-    if (!ctx->jit_fn || P->kernel_level < 2u) return false;
-    if (P->tiles_x * P->tiles_y == 0) return true;
+    if (ctx->jit_source.empty() || P->kernel_level < 2u) return false;
     // RasterParams.kernel_level 4 / 5 (k_raster_vm_sv / _v, template levels 6 / 7): no program of the opaque pass decides
-    // visibility (rxr_upload_frame); 2 / 3: one may
-    // ... and when the frame needs none of the chunk paths either, the kernel without them (template level 8)
-    hipFunction_t fn = (hipFunction_t)(P->kernel_level >= 4u ? (ctx->frame_needs_chunk_paths ? ctx->jit_fn : ctx->jit_fn_p) : ctx->jit_fn_v);
+    // visibility (rxr_upload_frame); 2 / 3: one may.  When the frame needs none of the chunk paths either: template level 8.
+    const int slot = P->kernel_level >= 4u ? (ctx->frame_needs_chunk_paths ? 1 : 2) : 0;
+    if (!ensure_level(ctx, slot)) return false;
+    if (P->tiles_x * P->tiles_y == 0) return true;
     RasterParams params = *P;
     size_t size = sizeof(params);
     void *config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &params, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
-    return hipModuleLaunchKernel(fn, P->tiles_x, P->tiles_y, 1, RXR_TILE_THREADS, 1, 1, 0, s, nullptr, config) == hipSuccess;
+    return hipModuleLaunchKernel((hipFunction_t)ctx->jit_fn[slot], P->tiles_x, P->tiles_y, 1, RXR_TILE_THREADS, 1, 1, 0, s, nullptr, config) == hipSuccess;
 }

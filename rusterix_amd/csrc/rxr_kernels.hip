@@ -2493,19 +2493,17 @@ __device__ __forceinline__ const RasterParams &kernarg_params_early() { return *
 // instruction); read in place they are scalar loads at the point of use (17 spill instructions).  Measured A-B-A-B on one
 // box: bench frame 208 -> 198 us, the 1-light frame 126 -> 117 us.
 #ifdef RXR_JIT
-// the two kernels of a run-time compiled program set: feature level 2 (programs may decide visibility) and 7 (none does)
+// the kernel of a run-time compiled program set, one template level per compilation (rxr_jit.hip compiles a level when the first
+// frame that needs it is launched): 2 = a program may decide visibility, 7 = none does, 8 = 7 without the chunk paths of level 1.
 // (1 M triangles with the configuration-C5 program, raster kernel: level 7 at 8 waves per SIMD (64 VGPRs) 656 us, 7: 676, 6: 710;
-// level 2 at 8: 695 us, 7: 666, 6: 694, 5: 763 -- the interpreter kernels take 1180 us)
+// level 2 at 8: 695 us, 7: 666, 6: 694, 5: 763; level 8 at 8: 566 us -- the interpreter kernels take 1180 us)
+#ifndef RXR_JIT_LEVEL
+#define RXR_JIT_LEVEL 8
+#endif
 #ifndef RXR_JIT_WAVES_PER_SIMD
-#define RXR_JIT_WAVES_PER_SIMD 8
+#define RXR_JIT_WAVES_PER_SIMD (RXR_JIT_LEVEL == 2 ? 7 : 8)
 #endif
-#ifndef RXR_JIT_V_WAVES_PER_SIMD
-#define RXR_JIT_V_WAVES_PER_SIMD 7
-#endif
-extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_JIT_V_WAVES_PER_SIMD) k_raster_jit_v(RasterParams) { raster_tile<false, 2, true>(kernarg_params_early()); }
-extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_JIT_WAVES_PER_SIMD) k_raster_jit(RasterParams) { raster_tile<false, 7, true>(kernarg_params_early()); }
-// ... and level 8: as 7 for frames that need none of level 1's chunk paths
-extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_JIT_WAVES_PER_SIMD) k_raster_jit_p(RasterParams) { raster_tile<false, 8, true>(kernarg_params_early()); }
+extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_JIT_WAVES_PER_SIMD) k_raster_jit(RasterParams) { raster_tile<false, RXR_JIT_LEVEL, true>(kernarg_params_early()); }
 #else
 #ifndef RXR_RASTER_KERNARG_IN_PLACE
 #define RXR_RASTER_KERNARG_IN_PLACE 1
