@@ -22,13 +22,53 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "rxr_ctx.h"
 
+#include <dlfcn.h>
+
 namespace {
 
 #include "rxr_jit_embedded.inc"  // rxr_jit_header_names[], rxr_jit_header_sources[], rxr_jit_n_headers
+
+// hiprtc is looked up when the first set is compiled, not linked: the library must load (and interpret programs) on an
+// installation without the run-time compiler
+struct Rtc {
+    decltype(&hiprtcCreateProgram) CreateProgram = nullptr;
+    decltype(&hiprtcCompileProgram) CompileProgram = nullptr;
+    decltype(&hiprtcDestroyProgram) DestroyProgram = nullptr;
+    decltype(&hiprtcGetCode) GetCode = nullptr;
+    decltype(&hiprtcGetCodeSize) GetCodeSize = nullptr;
+    decltype(&hiprtcGetErrorString) GetErrorString = nullptr;
+    decltype(&hiprtcGetProgramLog) GetProgramLog = nullptr;
+    decltype(&hiprtcGetProgramLogSize) GetProgramLogSize = nullptr;
+    std::string why;
+    bool ok = false;
+};
+const Rtc &rtc() {
+    static const Rtc r = [] {
+        Rtc x;
+        void *h = nullptr;
+        for (const char *name : {"libhiprtc.so", "libhiprtc.so.7", "/opt/rocm/lib/libhiprtc.so"})
+            if ((h = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
+        if (!h) {
+            x.why = "libhiprtc.so not found";
+            return x;
+        }
+        auto sym = [&](auto &fn, const char *name) {
+            fn = reinterpret_cast<typename std::remove_reference<decltype(fn)>::type>(dlsym(h, name));
+            return fn != nullptr;
+        };
+        x.ok = sym(x.CreateProgram, "hiprtcCreateProgram") && sym(x.CompileProgram, "hiprtcCompileProgram") && sym(x.DestroyProgram, "hiprtcDestroyProgram") &&
+               sym(x.GetCode, "hiprtcGetCode") && sym(x.GetCodeSize, "hiprtcGetCodeSize") && sym(x.GetErrorString, "hiprtcGetErrorString") &&
+               sym(x.GetProgramLog, "hiprtcGetProgramLog") && sym(x.GetProgramLogSize, "hiprtcGetProgramLogSize");
+        if (!x.ok) x.why = "libhiprtc.so lacks an entry point";
+        return x;
+    }();
+    return r;
+}
 
 uint32_t length_of(uint32_t op) {
     switch (op) {
@@ -238,12 +278,17 @@ bool rxr_jit_compile(const std::string &gen, const std::string &arch, int level,
             return true;
         }
     }
+    const Rtc &R = rtc();
+    if (!R.ok) {
+        err = R.why;
+        return false;
+    }
     std::vector<const char *> names(rxr_jit_header_names, rxr_jit_header_names + rxr_jit_n_headers), sources(rxr_jit_header_sources, rxr_jit_header_sources + rxr_jit_n_headers);
     names.push_back("rxr_jit_programs.h");
     sources.push_back(gen.c_str());
     hiprtcProgram prog = nullptr;
     const char *main_src = "#define RXR_JIT 1\n#include \"rxr_kernels.hip\"\n";
-    if (hiprtcCreateProgram(&prog, main_src, "rxr_jit_main.hip", (int)names.size(), sources.data(), names.data()) != HIPRTC_SUCCESS) {
+    if (R.CreateProgram(&prog, main_src, "rxr_jit_main.hip", (int)names.size(), sources.data(), names.data()) != HIPRTC_SUCCESS) {
         err = "hiprtcCreateProgram failed";
         return false;
     }
@@ -262,28 +307,28 @@ bool rxr_jit_compile(const std::string &gen, const std::string &arch, int level,
     std::vector<const char *> opts = {arch_opt.c_str(), level_opt.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize"};
     for (const std::string &x : extra) opts.push_back(x.c_str());
     const auto t0 = std::chrono::steady_clock::now();
-    const hiprtcResult r = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
+    const hiprtcResult r = R.CompileProgram(prog, (int)opts.size(), opts.data());
     seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (r != HIPRTC_SUCCESS) {
         size_t n = 0;
         std::string log;
-        if (hiprtcGetProgramLogSize(prog, &n) == HIPRTC_SUCCESS && n) {
+        if (R.GetProgramLogSize(prog, &n) == HIPRTC_SUCCESS && n) {
             log.resize(n);
-            (void)hiprtcGetProgramLog(prog, &log[0]);
+            (void)R.GetProgramLog(prog, &log[0]);
         }
-        (void)hiprtcDestroyProgram(&prog);
-        err = std::string(hiprtcGetErrorString(r)) + ": " + log.substr(0, 2000);
+        (void)R.DestroyProgram(&prog);
+        err = std::string(R.GetErrorString(r)) + ": " + log.substr(0, 2000);
         return false;
     }
     size_t n = 0;
-    if (hiprtcGetCodeSize(prog, &n) != HIPRTC_SUCCESS || n == 0) {
-        (void)hiprtcDestroyProgram(&prog);
+    if (R.GetCodeSize(prog, &n) != HIPRTC_SUCCESS || n == 0) {
+        (void)R.DestroyProgram(&prog);
         err = "empty code object";
         return false;
     }
     obj.resize(n);
-    (void)hiprtcGetCode(prog, obj.data());
-    (void)hiprtcDestroyProgram(&prog);
+    (void)R.GetCode(prog, obj.data());
+    (void)R.DestroyProgram(&prog);
     std::lock_guard<std::mutex> lk(g_cache_mu);
     g_code_objects[key] = obj;
     return true;

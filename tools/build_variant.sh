@@ -12,6 +12,6 @@ for f in rxr_api rxr_multi rxr_kernels rxr_project rxr_selftest rxr_jit; do
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait $p; done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -pthread -o build/variants/librxr_hip_$name.so build/obj_variant_$name/*.o -L/opt/rocm/lib -lhiprtc
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -pthread -o build/variants/librxr_hip_$name.so build/obj_variant_$name/*.o -ldl
 rm -rf build/obj_variant_$name
 ls -la build/variants/librxr_hip_$name.so

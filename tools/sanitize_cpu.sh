@@ -23,7 +23,7 @@ if [ -x /opt/rocm/bin/hipcc ] && [ -f build/obj/rxr_kernels.hip.o ]; then
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -ffp-contract=off -fno-slp-vectorize -fPIC $HSAN -Iinclude -c -o $OUT/rxr_api_asan.o rusterix_amd/csrc/rxr_api.hip
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -ffp-contract=off -fno-slp-vectorize -fPIC $HSAN -Iinclude -c -o $OUT/rxr_jit_asan.o rusterix_amd/csrc/rxr_jit.hip
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -pthread $HSAN -o $OUT/librxr_hip_hostasan.so $OUT/rxr_api_asan.o $OUT/rxr_jit_asan.o \
-      build/obj/rxr_multi.hip.o build/obj/rxr_kernels.hip.o build/obj/rxr_project.hip.o build/obj/rxr_selftest.hip.o -L/opt/rocm/lib -lhiprtc
+      build/obj/rxr_multi.hip.o build/obj/rxr_kernels.hip.o build/obj/rxr_project.hip.o build/obj/rxr_selftest.hip.o -ldl
   RXR_DEVICE_SO=$PWD/$OUT/librxr_hip_hostasan.so ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 \
   LD_PRELOAD="$CRT" python3 tools/sanitize_shaders.py
 else
