@@ -2199,11 +2199,8 @@ int rxr_set_shaders(rxr_ctx *ctx, const rxr_shader_set *set) {
     ctx->jit_info.clear();
     if (const char *jit = getenv("RXR_SHADER_JIT")) {
         if (jit[0] == '1') {
-            if (ctx->programs_static) {
-                if ((rc = rxr_jit_build(ctx, fl.code, progs)) != RXR_OK) return rc;
-            } else {
-                ctx->jit_info = progs.empty() ? "not compiled: no programs" : "not compiled: a program of the set has calls, PaletteIndex or a data-dependent stack depth";
-            }
+            if (progs.empty()) ctx->jit_info = "not compiled: no programs";
+            else if ((rc = rxr_jit_build(ctx, fl.code, progs)) != RXR_OK) return rc;  // (does its own analysis: calls are covered, PaletteIndex / recursion are not)
         }
     }
     ctx->programs = std::move(progs);
@@ -2264,8 +2261,8 @@ extern "C" int rxr_debug_jit_generate(const rxr_shader_set *set, int compile, ch
         say(err);
         return rc;
     }
-    if (progs.empty() || !tag_static_depths(code, progs)) {
-        say("a program of the set has calls, PaletteIndex or a data-dependent stack depth");
+    if (progs.empty()) {
+        say("no programs");
         return RXR_ERR_UNSUPPORTED;
     }
     if (!rxr_jit_generate(code, progs, gen, err)) {

@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <string>
@@ -131,53 +132,123 @@ const char *field_of(uint32_t op, bool &is_set) {
     }
 }
 
-// one program's `shade`: the reachable instructions in address order, each under its label; `code` carries the static depths
-// (bits 16..23 of every reachable opcode word, tag_static_depths).  Returns false for anything this generator does not cover.
-bool generate_program(const std::vector<uint32_t> &code, const DevProgram &p, uint32_t index, std::string &out, std::string &why) {
-    out += "__device__ __forceinline__ uint32_t rxr_jit_prog_" + std::to_string(index) + "(const RasterParams &P, rxvm::IO &io) {\n";
-    out += "    using namespace rxvm;\n    (void)P;\n";
-    if (p.shade_entry == 0xFFFFFFFFu) {  // shade_index None: nothing runs
-        out += "    (void)io;\n    return 0u;\n}\n";
-        return true;
-    }
-    if (p.shade_locals > RXR_VM_LOCALS) {
-        out += "    (void)io;\n    *P.vm_fault = " + std::to_string((uint32_t)VMF_LOCALS_OVERFLOW) + "u;\n    return " + std::to_string((uint32_t)VMF_LOCALS_OVERFLOW) + "u;\n}\n";
-        return true;
-    }
-    // reachable instructions (the same walk as tag_static_depths, without its checks: it has passed)
-    std::vector<char> reach(code.size(), 0);
-    std::vector<uint32_t> work{p.shade_entry};
+// ---- analysis: the stack depth before every instruction of one function, RELATIVE to the depth at its entry --------------------
+// The same abstract interpretation as tag_static_depths (rxr_api.hip), with calls: a call needs its `arity` arguments on the
+// caller's own part of the stack, pops them and leaves one value.  A function that could touch the stack BELOW its entry depth --
+// Dup / Clear / Return at relative depth 0 (they look at the absolute depth: the reference shares one stack between caller and
+// callee) -- is left to the interpreter, as is recursion.  Depths live in a side table: the code words are not touched.
+struct Call {
+    uint32_t pc, target, arity, total;
+};
+struct Fn {
+    uint32_t entry = 0, arity = 0, total = 0;   // (`shade`: arity 0, total = shade_locals)
+    bool is_shade = false;
+    std::vector<int> depth;                     // per pc, -1: unreachable
     int max_depth = 0;
+    std::vector<Call> calls;
+};
+
+bool analyse(const std::vector<uint32_t> &code, Fn &f, std::string &why) {
+    struct State {
+        int depth;
+        std::vector<int> loops;
+        bool operator==(const State &o) const { return depth == o.depth && loops == o.loops; }
+    };
+    f.depth.assign(code.size(), -1);
+    std::vector<State> states(code.size());
+    std::vector<std::pair<uint32_t, State>> work{{f.entry, State{0, {}}}};
     while (!work.empty()) {
-        uint32_t pc = work.back();
+        auto [pc, st] = work.back();
         work.pop_back();
         for (;;) {
             if (pc >= code.size()) { why = "jump code runs past its end"; return false; }
-            if (reach[pc]) break;
-            reach[pc] = 1;
-            const uint32_t w = code[pc], op = w & 0xFFu;
+            const uint32_t op = code[pc] & 0xFFu;
+            if (f.depth[pc] >= 0) {
+                if (!(states[pc] == st)) { why = "two paths reach an instruction with different stacks"; return false; }
+                break;
+            }
+            if (st.depth < 0 || st.depth > 200) { why = "stack depth out of range"; return false; }
+            f.depth[pc] = st.depth;
+            states[pc] = st;
+            f.max_depth = std::max(f.max_depth, st.depth + 1);
+            if (op == VM_ENDFN) break;
             const uint32_t len = length_of(op);
             if (pc + len > code.size()) { why = "truncated instruction"; return false; }
-            max_depth = std::max(max_depth, (int)((w >> 16) & 0xFFu) + 1);
-            if (op == VM_ENDFN || op == VM_FAULT) break;
-            if (op == VM_JMP || op == VM_RETURN) { pc = code[pc + 1]; continue; }
-            if (op == VM_JZ || op == VM_FOR_COND) work.push_back(code[pc + 1]);
+            int need = 0, delta = 0;
+            bool is_set = false;
+            const Arity ar = pure_arity(op);
+            if (ar == A_UN) need = 1;
+            else if (ar == A_BIN) { need = 2; delta = -1; }
+            else if (ar == A_TER) { need = 3; delta = -2; }
+            else if (field_of(op, is_set)) { need = is_set ? 1 : 0; delta = is_set ? -1 : 1; }
+            else switch (op) {
+                case RXR_NODE_LOAD_GLOBAL: case RXR_NODE_LOAD_LOCAL: case RXR_NODE_PUSH: delta = 1; break;
+                case RXR_NODE_STORE_GLOBAL: case RXR_NODE_STORE_LOCAL: case RXR_NODE_PRINT: case RXR_NODE_SET_NORMAL: case VM_JZ: case VM_FOR_COND:
+                    need = 1; delta = -1; break;
+                case RXR_NODE_SWAP: need = 2; break;
+                case VM_GETC: case VM_BINC: need = 1; break;
+                case VM_SETC: case RXR_NODE_SAMPLE: case RXR_NODE_SAMPLE_NORMAL: need = 2; delta = -1; break;
+                case RXR_NODE_CLEAR:
+                    if (st.depth == 0 && !f.is_shade) { why = "Clear on a callee's empty stack (it would pop the caller's value)"; return false; }
+                    delta = st.depth > 0 ? -1 : 0;
+                    break;
+                case RXR_NODE_DUP:
+                    if (st.depth == 0 && !f.is_shade) { why = "Dup on a callee's empty stack (it would copy the caller's value)"; return false; }
+                    delta = st.depth > 0 ? 1 : 0;
+                    break;
+                case VM_RETURN:
+                    if (st.depth == 0 && !f.is_shade) { why = "Return on a callee's empty stack (it would pop the caller's value)"; return false; }
+                    break;
+                case VM_CALL: {
+                    const Call c{pc, code[pc + 3], code[pc + 1], code[pc + 2]};
+                    need = (int)c.arity;
+                    delta = 1 - (int)c.arity;
+                    f.calls.push_back(c);
+                    break;
+                }
+                case VM_JMP: case VM_FOR_ENTER: case VM_FOR_TRUNC: case VM_FOR_EXIT: case VM_FAULT: break;
+                default: why = "opcode " + std::to_string(op) + " is not covered by the run-time compiler"; return false;  // PaletteIndex, unknown
+            }
+            if (st.depth < need) { why = "an instruction without its operands (the interpreter reports the underflow)"; return false; }
+            State nx = st;
+            nx.depth += delta;
+            if (op == VM_FOR_ENTER) {
+                if (nx.loops.size() >= RXR_VM_LOOPS) { why = "loops nested too deeply"; return false; }
+                nx.loops.push_back(st.depth);
+            } else if (op == VM_FOR_TRUNC) {
+                if (nx.loops.empty()) { why = "loop bookkeeping"; return false; }
+                nx.depth = std::min(nx.depth, nx.loops.back());
+            } else if (op == VM_FOR_EXIT) {
+                if (nx.loops.empty()) { why = "loop bookkeeping"; return false; }
+                nx.loops.pop_back();
+            }
+            if (op == VM_FAULT || op == VM_RETURN) break;  // (Return: straight to the function's end, its value in hand)
+            if (op == VM_JMP) { pc = code[pc + 1]; st = nx; continue; }
+            if (op == VM_JZ || op == VM_FOR_COND) work.push_back({code[pc + 1], nx});
             pc += len;
+            st = nx;
         }
     }
-    for (int k = 0; k <= max_depth; ++k) out += "    v3 " + slot(k) + " = splat(0.0f);\n";
-    for (uint32_t k = 0; k < p.shade_locals; ++k) out += "    v3 l" + std::to_string(k) + " = splat(0.0f);\n";
-    for (uint32_t k = 0; k < p.n_globals && k < RXR_VM_GLOBALS; ++k) out += "    v3 g" + std::to_string(k) + " = splat(0.0f);\n";
-    out += "    uint32_t fault = 0u, steps = 0u;\n    (void)steps;\n";
-    auto fail = [&](uint32_t code_) { return "{ fault = " + std::to_string(code_) + "u; goto Lend; }"; };
-    for (uint32_t pc = p.shade_entry; pc < code.size(); ++pc) {
-        if (!reach[pc]) {
-            // (unreachable words -- dead code behind a jump, or the immediates of the instruction before -- are skipped; an
-            // instruction that falls through always has a reachable successor)
-            continue;
-        }
+    return true;
+}
+
+std::string fn_name(uint32_t prog, const Fn &f) {
+    return f.is_shade ? "rxr_jit_prog_" + std::to_string(prog)
+                      : "rxr_jit_fn_" + std::to_string(prog) + "_" + std::to_string(f.entry) + "_" + std::to_string(f.arity) + "_" + std::to_string(f.total);
+}
+
+// the body of one function: the reachable instructions in address order, each under its label
+bool emit_body(const std::vector<uint32_t> &code, const DevProgram &p, uint32_t prog, const Fn &f, std::string &out, std::string &why) {
+    const uint32_t n_locals = f.is_shade ? p.shade_locals : f.total;
+    for (int k = 0; k <= f.max_depth; ++k) out += "    v3 " + slot(k) + " = splat(0.0f);\n";
+    for (uint32_t k = 0; k < n_locals; ++k)
+        out += "    v3 l" + std::to_string(k) + " = " + (!f.is_shade && k < f.arity ? "a" + std::to_string(k) : std::string("splat(0.0f)")) + ";\n";
+    const std::string leave = f.is_shade ? "goto Lend;" : "return splat(0.0f);";
+    auto fail = [&](uint32_t code_) { return "{ fault = " + std::to_string(code_) + "u; " + leave + " }"; };
+    for (uint32_t pc = f.entry; pc < code.size(); ++pc) {
+        if (f.depth[pc] < 0) continue;  // (dead code behind a jump, or the immediates of the instruction before)
         const uint32_t w = code[pc], op = w & 0xFFu;
-        const int d = (int)((w >> 16) & 0xFFu);  // depth BEFORE the instruction
+        const int d = f.depth[pc];  // depth BEFORE the instruction, relative to the function's entry
         const uint32_t len = length_of(op);
         out += "L" + std::to_string(pc) + ": ";
         const std::string t0 = slot(d - 1), t1 = slot(d - 2), t2 = slot(d - 3), top = slot(d);
@@ -191,23 +262,23 @@ bool generate_program(const std::vector<uint32_t> &code, const DevProgram &p, ui
             out += t1 + " = jit_bin<" + std::to_string(op) + "u>(" + t1 + ", " + t0 + ");\n";
         } else if (ar == A_TER) {
             out += t2 + " = jit_ter<" + std::to_string(op) + "u>(" + t2 + ", " + t1 + ", " + t0 + ");\n";
-        } else if (const char *f = field_of(op, is_set)) {
-            out += is_set ? std::string(f) + " = " + t0 + ";\n" : top + " = " + f + ";\n";
+        } else if (const char *fld = field_of(op, is_set)) {
+            out += is_set ? std::string(fld) + " = " + t0 + ";\n" : top + " = " + fld + ";\n";
         } else {
             switch (op) {
                 case RXR_NODE_PUSH: out += top + " = " + imm3(code, pc) + ";\n"; break;
                 case VM_BINC: out += t0 + " = jit_binc<" + std::to_string((w >> 8) & 0xFFu) + "u>(" + t0 + ", " + imm3(code, pc) + ");\n"; break;
                 case RXR_NODE_LOAD_LOCAL:
-                    out += code[pc + 1] < p.shade_locals ? top + " = l" + std::to_string(code[pc + 1]) + ";\n" : fail(VMF_LOCAL_INDEX) + "\n";
+                    out += code[pc + 1] < n_locals ? top + " = l" + std::to_string(code[pc + 1]) + ";\n" : fail(VMF_LOCAL_INDEX) + "\n";
                     break;
                 case RXR_NODE_STORE_LOCAL:
-                    out += code[pc + 1] < p.shade_locals ? "l" + std::to_string(code[pc + 1]) + " = " + t0 + ";\n" : fail(VMF_LOCAL_INDEX) + "\n";
+                    out += code[pc + 1] < n_locals ? "l" + std::to_string(code[pc + 1]) + " = " + t0 + ";\n" : fail(VMF_LOCAL_INDEX) + "\n";
                     break;
                 case RXR_NODE_LOAD_GLOBAL:
-                    out += code[pc + 1] < p.n_globals ? top + " = g" + std::to_string(code[pc + 1]) + ";\n" : fail(VMF_GLOBAL_INDEX) + "\n";
+                    out += code[pc + 1] < p.n_globals ? top + " = G.g" + std::to_string(code[pc + 1]) + ";\n" : fail(VMF_GLOBAL_INDEX) + "\n";
                     break;
                 case RXR_NODE_STORE_GLOBAL:
-                    out += code[pc + 1] < p.n_globals ? "g" + std::to_string(code[pc + 1]) + " = " + t0 + ";\n" : fail(VMF_GLOBAL_INDEX) + "\n";
+                    out += code[pc + 1] < p.n_globals ? "G.g" + std::to_string(code[pc + 1]) + " = " + t0 + ";\n" : fail(VMF_GLOBAL_INDEX) + "\n";
                     break;
                 case RXR_NODE_SWAP: out += "{ const v3 t = " + t0 + "; " + t0 + " = " + t1 + "; " + t1 + " = t; }\n"; break;
                 case VM_GETC: out += t0 + " = jit_getc(" + hexw(code[pc + 1]) + ", " + t0 + ");\n"; break;
@@ -225,15 +296,122 @@ bool generate_program(const std::vector<uint32_t> &code, const DevProgram &p, ui
                     break;
                 case VM_JZ: out += "if (!(" + t0 + ".x != 0.0f)) goto L" + std::to_string(code[pc + 1]) + ";\n"; break;
                 case VM_FOR_COND: out += "if (" + t0 + ".x == 0.0f) goto L" + std::to_string(code[pc + 1]) + ";\n"; break;
-                case VM_RETURN: case VM_ENDFN: out += "goto Lend;\n"; break;
+                case VM_RETURN: out += f.is_shade ? std::string("goto Lend;\n") : "return " + t0 + ";\n"; break;  // (a callee: relative depth >= 1, analyse())
+                case VM_ENDFN:  // falling off the end: the value on top of the function's own stack, if any
+                    out += f.is_shade ? std::string("goto Lend;\n") : "return " + (d > 0 ? t0 : std::string("splat(0.0f)")) + ";\n";
+                    break;
                 case VM_FAULT: out += fail(code[pc + 1]) + "\n"; break;
+                case VM_CALL: {
+                    const uint32_t arity = code[pc + 1], total = code[pc + 2], target = code[pc + 3];
+                    if (arity > total) {  // an argument without a local to land in: the reference's index panic
+                        out += fail(VMF_LOCAL_INDEX) + "\n";
+                        break;
+                    }
+                    Fn callee;
+                    callee.entry = target; callee.arity = arity; callee.total = total;
+                    std::string args;
+                    for (uint32_t i = 0; i < arity; ++i) args += ", " + slot(d - (int)arity + (int)i);  // local i = the i-th argument pushed
+                    const std::string res = slot(d - (int)arity);
+                    out += "{ if (++steps > " + std::to_string((uint32_t)RXR_VM_MAX_STEPS) + "u) " + fail(VMF_STEP_LIMIT) + " const v3 r = " + fn_name(prog, callee) +
+                           "(P, io, G, fault, steps" + args + "); if (fault) " + leave + " " + res + " = r; }\n";
+                    break;
+                }
                 default: why = "opcode " + std::to_string(op) + " is not covered by the run-time compiler"; return false;
             }
         }
-        if (op == VM_ENDFN) break;  // (the end of `shade`; what follows belongs to other functions)
+        if (op == VM_ENDFN) break;  // (the end of this function; what follows belongs to other functions)
         pc += len - 1;
     }
-    out += "Lend:\n    if (fault) *P.vm_fault = fault;\n    return fault;\n}\n";
+    return true;
+}
+
+// one program: `shade` and every function it can reach (specialised per (entry, arity, total_locals) as the call sites name them),
+// callees before callers.  Returns false for anything the generator does not cover; the interpreter then runs the set.
+bool generate_program(const std::vector<uint32_t> &code, const DevProgram &p, uint32_t index, std::string &out, std::string &why) {
+    const std::string sig = "(const RasterParams &P, rxvm::IO &io)";
+    if (p.shade_entry == 0xFFFFFFFFu) {  // shade_index None: nothing runs
+        out += "__device__ __forceinline__ uint32_t rxr_jit_prog_" + std::to_string(index) + sig + " {\n    (void)P;\n    (void)io;\n    return 0u;\n}\n";
+        return true;
+    }
+    if (p.shade_locals > RXR_VM_LOCALS) {
+        out += "__device__ __forceinline__ uint32_t rxr_jit_prog_" + std::to_string(index) + sig + " {\n    (void)io;\n    *P.vm_fault = " +
+               std::to_string((uint32_t)VMF_LOCALS_OVERFLOW) + "u;\n    return " + std::to_string((uint32_t)VMF_LOCALS_OVERFLOW) + "u;\n}\n";
+        return true;
+    }
+    // the functions, discovered from `shade` down; `order` ends up callees-first
+    std::vector<Fn> fns;
+    std::vector<int> order, state;  // state: 0 new, 1 on the walk's stack, 2 done
+    auto find = [&](uint32_t entry, uint32_t arity, uint32_t total) {
+        for (size_t i = 0; i < fns.size(); ++i)
+            if (fns[i].entry == entry && fns[i].arity == arity && fns[i].total == total && !fns[i].is_shade) return (int)i;
+        return -1;
+    };
+    Fn shade;
+    shade.entry = p.shade_entry;
+    shade.total = p.shade_locals;
+    shade.is_shade = true;
+    fns.push_back(shade);
+    state.push_back(0);
+    // depth-first: (function, chain depth, locals and stack in use above it)
+    struct Walk { int fn; int frames; uint32_t locals; int stack; };
+    std::vector<int> path;
+    bool ok = true;
+    std::function<void(const Walk &)> visit = [&](const Walk &wk) {
+        if (!ok) return;
+        Fn &f = fns[(size_t)wk.fn];
+        if (state[(size_t)wk.fn] == 1) { ok = false; why = "recursion"; return; }
+        if (state[(size_t)wk.fn] == 0) {
+            if (!analyse(code, f, why)) { ok = false; return; }
+        }
+        // what the interpreter would refuse at run time must not be compiled away: call depth, locals, stack (checked per chain)
+        if (wk.frames > (int)RXR_VM_FRAMES) { ok = false; why = "calls nested deeper than the interpreter's frame stack"; return; }
+        if (wk.locals + (f.is_shade ? p.shade_locals : f.total) > RXR_VM_LOCALS) { ok = false; why = "more locals along a call chain than the interpreter holds"; return; }
+        if (wk.stack + f.max_depth > (int)RXR_VM_STACK) { ok = false; why = "a value stack deeper than the interpreter's"; return; }
+        const bool first = state[(size_t)wk.fn] == 0;
+        state[(size_t)wk.fn] = 1;
+        const std::vector<Call> calls = f.calls;  // (fns may grow below: no references into it across the loop)
+        const uint32_t own_locals = f.is_shade ? p.shade_locals : f.total;
+        for (const Call &c : calls) {
+            if (c.arity > c.total) continue;  // (emitted as a static fault)
+            int k = find(c.target, c.arity, c.total);
+            if (k < 0) {
+                Fn g;
+                g.entry = c.target; g.arity = c.arity; g.total = c.total;
+                fns.push_back(g);
+                state.push_back(0);
+                k = (int)fns.size() - 1;
+            }
+            const int depth_at_call = fns[(size_t)wk.fn].depth[c.pc] - (int)c.arity;
+            visit(Walk{k, wk.frames + 1, wk.locals + own_locals, wk.stack + depth_at_call});
+            if (!ok) return;
+        }
+        state[(size_t)wk.fn] = 2;
+        if (first) order.push_back(wk.fn);
+    };
+    visit(Walk{0, 0, 0u, 0});
+    if (!ok) return false;
+    // globals of the program, shared by its functions
+    out += "struct rxr_jit_globals_" + std::to_string(index) + " {\n";
+    for (uint32_t k = 0; k < p.n_globals && k < RXR_VM_GLOBALS; ++k) out += "    rxvm::v3 g" + std::to_string(k) + ";\n";
+    out += "    int unused;\n};\n";
+    for (int k : order) {
+        const Fn &f = fns[(size_t)k];
+        if (f.is_shade) {
+            out += "__device__ __forceinline__ uint32_t " + fn_name(index, f) + sig + " {\n    using namespace rxvm;\n    (void)P;\n";
+            out += "    rxr_jit_globals_" + std::to_string(index) + " G;\n    G.unused = 0;\n";
+            for (uint32_t g = 0; g < p.n_globals && g < RXR_VM_GLOBALS; ++g) out += "    G.g" + std::to_string(g) + " = splat(0.0f);\n";
+            out += "    uint32_t fault = 0u, steps = 0u;\n    (void)steps;\n";
+            if (!emit_body(code, p, index, f, out, why)) return false;
+            out += "Lend:\n    if (fault) *P.vm_fault = fault;\n    return fault;\n}\n";
+        } else {
+            out += "__device__ __forceinline__ rxvm::v3 " + fn_name(index, f) + "(const RasterParams &P, rxvm::IO &io, rxr_jit_globals_" + std::to_string(index) +
+                   " &G, uint32_t &fault, uint32_t &steps";
+            for (uint32_t a = 0; a < f.arity; ++a) out += ", rxvm::v3 a" + std::to_string(a);
+            out += ") {\n    using namespace rxvm;\n    (void)P; (void)io; (void)G; (void)steps;\n";
+            if (!emit_body(code, p, index, f, out, why)) return false;
+            out += "    return splat(0.0f);\n}\n";
+        }
+    }
     return true;
 }
 
@@ -243,7 +421,10 @@ bool generate_program(const std::vector<uint32_t> &code, const DevProgram &p, ui
 bool rxr_jit_generate(const std::vector<uint32_t> &code, const std::vector<DevProgram> &progs, std::string &src, std::string &why) {
     src = "// generated by rxr_jit.hip from the jump code of one rxr_set_shaders call\n#pragma once\n";
     for (size_t i = 0; i < progs.size(); ++i)
-        if (!generate_program(code, progs[i], (uint32_t)i, src, why)) return false;
+        if (!generate_program(code, progs[i], (uint32_t)i, src, why)) {
+            why = "program " + std::to_string(i) + ": " + why;
+            return false;
+        }
     src += "__device__ __forceinline__ uint32_t rxr_jit_shade(const RasterParams &P, uint32_t pi, rxvm::IO &io) {\n    switch (pi) {\n";
     for (size_t i = 0; i < progs.size(); ++i) src += "        case " + std::to_string(i) + "u: return rxr_jit_prog_" + std::to_string(i) + "(P, io);\n";
     src += "        default: return 0u;\n    }\n}\n";

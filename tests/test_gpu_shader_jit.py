@@ -143,13 +143,41 @@ def test_faults_are_reported_by_compiled_programs(product, monkeypatch):
     assert jit_info(product).startswith("compiled:")
 
 
-def test_sets_with_calls_keep_the_interpreter(oracle, product, monkeypatch):
+def test_functions_are_compiled_too(oracle, product, monkeypatch):
+    """FunctionCall: arguments become parameters, every callee its own straight-line function with fresh locals; Return from inside
+    an If; a callee calling a callee; globals shared between caller and callee"""
+    helper = [("LoadLocal", 0), ("Push", 0.5), "Gt", ("If", [("LoadLocal", 0), ("Push", 0.5), "Sub", "Return"], None), ("LoadLocal", 0), "Return"]
+    twice = [("LoadLocal", 0), ("FunctionCall", 1, 1, 1), ("LoadLocal", 1), ("FunctionCall", 1, 1, 1), "Add", ("StoreLocal", 2), ("LoadLocal", 2)]   # falls off its end: top of its stack
+    shade = ["UV", ("GetComponents", [1]), ("Push", 4.0), "Mul", ("FunctionCall", 1, 1, 1),
+             "UV", ("GetComponents", [0]), ("Push", 4.0), "Mul", "UV", ("GetComponents", [1]), ("Push", 2.0), "Mul", ("FunctionCall", 2, 3, 2),
+             ("Push", 0.25), "Pack3", "SetColor"]
+    with_globals = Program([["UV", ("StoreGlobal", 1), ("LoadGlobal", 1), ("Push", 4.0), "Mul", ("FunctionCall", 0, 0, 1), "Add", "SetColor"],
+                            [("LoadGlobal", 1), ("Push", 1.0), "Mul"]], globals=2)
+    got, info = three_ways(oracle, product, monkeypatch, lambda api: grid_scene(api, [Program([shade, helper, twice]), with_globals]))
+    assert len(np.unique(got.reshape(-1, 4), axis=0)) > 100
+
+
+def test_random_programs_with_functions(oracle, product, monkeypatch):
+    programs = []
+    for seed in range(12):
+        rng = np.random.default_rng([0x52585231, 9002, seed])
+        programs.append(S.ProgramGen(rng, n_locals=int(rng.integers(3, 6)), n_functions=int(rng.integers(1, 3)), setters=["SetColor"]).program())
+    three_ways(oracle, product, monkeypatch, lambda api: grid_scene(api, programs, time=0.5), tol=S.TOLERANCE, max_off=6)
+
+
+def test_recursion_and_palette_lookups_keep_the_interpreter(oracle, product, monkeypatch):
     monkeypatch.setenv("RXR_SHADER_JIT", "1")
-    helper = [("LoadLocal", 0), ("Push", 0.5), "Mul", "Return"]
-    prog = Program([["UV", ("FunctionCall", 1, 1, 1), "SetColor"], helper])
+    fact = [("LoadLocal", 0), ("Push", 1.0), "Le", ("If", [("Push", 1.0), "Return"], None),
+            ("LoadLocal", 0), ("LoadLocal", 0), ("Push", 1.0), "Sub", ("FunctionCall", 1, 1, 1), "Mul", "Return"]
+    prog = Program([["UV", ("GetComponents", [0]), ("Push", 16.0), "Mul", "Floor", ("FunctionCall", 1, 1, 1), ("Push", 0.04), "Mul", "SetColor"], fact])
     got = scenes.render(grid_scene(product, [prog]))
-    assert jit_info(product).startswith("not compiled:")
+    assert jit_info(product).startswith("not compiled:") and "recursion" in jit_info(product)
     assert np.array_equal(got, scenes.render(grid_scene(oracle, [prog])))
+    # (a missing palette slot pushes nothing: the Add then consumes the two constants -- a data-dependent stack depth)
+    pal = Program([[("Push", 0.1, 0.1, 0.1), ("Push", 0.2, 0.3, 0.4), "UV", ("GetComponents", [0]), ("Push", 12.0), "Mul", "PaletteIndex", "Add", "Clear", "UV", "SetColor"]])
+    got = scenes.render(grid_scene(product, [pal]))
+    assert jit_info(product).startswith("not compiled:")
+    assert np.array_equal(got, scenes.render(grid_scene(oracle, [pal])))
 
 
 def test_box_grid_with_the_configuration_c5_program(oracle, product, monkeypatch):

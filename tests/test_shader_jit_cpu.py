@@ -55,9 +55,13 @@ def test_loops_locals_globals_and_faults_are_generated():
     assert "rxr_jit_prog_1" in src
 
 
-def test_sets_with_calls_or_palette_lookups_are_left_to_the_interpreter():
-    helper = [("LoadLocal", 0), "Return"]
-    rc, _, msg = generate([Program([["UV", ("FunctionCall", 1, 1, 1), "SetColor"], helper])], 0)
-    assert rc == B.RXR_ERR_UNSUPPORTED and "calls" in msg
+def test_calls_become_functions_and_recursion_or_palette_lookups_are_left_to_the_interpreter():
+    helper = [("LoadLocal", 0), ("Push", 2.0), "Mul", "Return"]
+    rc, src, msg = generate([Program([["UV", ("FunctionCall", 1, 1, 1), "SetColor"], helper])], 0)
+    assert rc == 0, msg
+    assert re.search(r"rxvm::v3 rxr_jit_fn_0_\d+_1_1\(.*rxvm::v3 a0\)", src) and "v3 l0 = a0;" in src and "if (fault) goto Lend;" in src
+    fact = [("LoadLocal", 0), ("Push", 1.0), "Le", ("If", [("Push", 1.0), "Return"], None), ("LoadLocal", 0), ("LoadLocal", 0), ("Push", 1.0), "Sub", ("FunctionCall", 1, 1, 1), "Mul", "Return"]
+    rc, _, msg = generate([Program([["UV", ("FunctionCall", 1, 1, 1), "SetColor"], fact])], 0)
+    assert rc == B.RXR_ERR_UNSUPPORTED and "recursion" in msg
     rc, _, msg = generate([Program([["UV", "PaletteIndex", "SetColor"]])], 0)
     assert rc == B.RXR_ERR_UNSUPPORTED
