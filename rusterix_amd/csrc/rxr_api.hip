@@ -1136,6 +1136,7 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
     const bool editor_paths = (P.has_brush && (f->flags & RXR_FLAG_D3_ACTIVE)) || f->background_kind == RXR_BG_GRID;
     P.kernel_level = std::max(ctx->min_kernel_level, uses_programs ? 2u : ((uses_chunk_tex || editor_paths) ? 1u : 0u));
     ctx->frame_needs_chunk_paths = uses_chunk_tex || editor_paths || ctx->min_kernel_level >= 1u;  // (rxr_jit_launch: level 8 otherwise)
+    P.plain_programs = (!ctx->frame_needs_chunk_paths && !getenv("RXR_NO_PLAIN_PROGRAMS")) ? 1u : 0u;
     if (P.kernel_level == 2u && uses_programs && ctx->programs_static) P.kernel_level = 3u;  // k_raster_vm_s: wave-uniform stack pointer
     // k_raster_vm_sv: ... and no program decides whether an opaque fragment is written, so the visibility loop is the one of
     // k_raster_chunk, without a call of the interpreter in it

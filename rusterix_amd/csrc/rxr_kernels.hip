@@ -484,7 +484,7 @@ __device__ __forceinline__ uint32_t brush_over_texel(const RasterParams &P, uint
 
 // feature level (template parameter X of the raster code, see below) -> does it carry the chunk paths of level 1 (terrain, baked shader
 // textures, opacity staircase, grid background, brush)?  Level 8 is "programs without them" (run-time compiled sets only)
-template <int X> inline constexpr bool lvl1 = X >= 1 && X != 8;
+template <int X> inline constexpr bool lvl1 = X >= 1 && X != 8 && X != 9;  // (9: the interpreter's level 6 without them, k_raster_vm_p)
 
 // the texel switch of the raster loops (rasterizer.rs:1101-1222, :672-758); (wx, wy) is the position terrain batches sample at;
 // `world3`: the fragment's world position in the two 3D loops (terrain brush preview), nullptr in the 2D loop
@@ -517,7 +517,7 @@ __device__ __forceinline__ uint32_t batch_texel(const RasterParams &P, const Dev
 // 7 = 2 for such frames (programs with calls or PaletteIndex: per-lane stack pointer)
 // 8 = programs WITHOUT the chunk paths of level 1 (run-time compiled sets only, rxr_jit.hip: a frame whose batches run programs but
 // use no terrain / baked texture / staircase / editor background gets level 0's fragment code around its compiled programs)
-template <int X> struct vm_level { static constexpr bool ssp = X >= 4 && X <= 6; static constexpr bool inline_site = X == 2 || X == 4 || X == 6 || X == 7 || X == 8; static constexpr int out_of_line = ssp ? 5 : 3; static constexpr bool vis_programs = X < 6; };
+template <int X> struct vm_level { static constexpr bool ssp = (X >= 4 && X <= 6) || X == 9; static constexpr bool inline_site = X == 2 || X == 4 || X == 6 || X == 7 || X == 8 || X == 9; static constexpr int out_of_line = ssp ? 5 : 3; static constexpr bool vis_programs = X < 6; };
 
 // ---- the covered-fragment block of d3_rasterize after the depth test (rasterizer.rs:1062-1404) ----
 // Split in three so that the light loop runs in wave-uniform control flow (see shade3d_lights).
@@ -2548,6 +2548,8 @@ extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_VM_WAVES_PER_
 extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_VM_WAVES_PER_SIMD) k_raster_vm_s(RasterParams) { raster_tile<false, 4, true>(kernarg_params()); }
 // ... and without interpreter calls in the visibility loop (kernel_level 4; vm_level<6>)
 extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_VM_WAVES_PER_SIMD) k_raster_vm_sv(RasterParams) { raster_tile<false, 6, true>(kernarg_params()); }
+// level 9 = 6 without the chunk paths of level 1, for frames that use none of them (RasterParams.plain_programs, rxr_upload_frame)
+extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_VM_WAVES_PER_SIMD) k_raster_vm_p(RasterParams) { raster_tile<false, 9, true>(kernarg_params()); }
 // the per-lane stack pointer without interpreter calls in the visibility loop (kernel_level 5; vm_level<7>)
 extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_VM_WAVES_PER_SIMD) k_raster_vm_v(RasterParams) { raster_tile<false, 7, true>(kernarg_params()); }
 
@@ -2601,6 +2603,7 @@ extern "C" void rxr_launch_raster(const RasterParams *P, hipStream_t s) {
 #endif
     const bool no_rows = getenv("RXR_NO_ROWS") != nullptr;  // tuning knob: binned scenes walk every candidate per pixel (k_raster)
     if (P->kernel_level >= 5u) hipLaunchKernelGGL(k_raster_vm_v, tiles, dim3(RXR_TILE_THREADS), 0, s, *P);
+    else if (P->kernel_level == 4u && P->plain_programs) hipLaunchKernelGGL(k_raster_vm_p, tiles, dim3(RXR_TILE_THREADS), 0, s, *P);
     else if (P->kernel_level == 4u) hipLaunchKernelGGL(k_raster_vm_sv, tiles, dim3(RXR_TILE_THREADS), 0, s, *P);
     else if (P->kernel_level == 3u) hipLaunchKernelGGL(k_raster_vm_s, tiles, dim3(RXR_TILE_THREADS), 0, s, *P);
     else if (P->kernel_level == 2u) hipLaunchKernelGGL(k_raster_vm, tiles, dim3(RXR_TILE_THREADS), 0, s, *P);
