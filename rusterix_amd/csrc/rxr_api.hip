@@ -2198,8 +2198,9 @@ int rxr_set_shaders(rxr_ctx *ctx, const rxr_shader_set *set) {
     // opt-in: the set as straight-line kernels compiled now (rxr_jit.hip); sets with calls or PaletteIndex keep the interpreter
     rxr_jit_drop(ctx);
     ctx->jit_info.clear();
-    if (const char *jit = getenv("RXR_SHADER_JIT")) {
-        if (jit[0] == '1') {
+    if (const char *jit = getenv("RXR_SHADER_JIT")) {  // "1": compiled when first needed, the caller waits; "async": by a child process
+        ctx->jit_async = jit[0] == 'a';
+        if (jit[0] == '1' || jit[0] == 'a') {
             if (progs.empty()) ctx->jit_info = "not compiled: no programs";
             else if ((rc = rxr_jit_build(ctx, fl.code, progs)) != RXR_OK) return rc;  // (does its own analysis: calls are covered, PaletteIndex / recursion are not)
         }

@@ -96,6 +96,10 @@ struct rxr_ctx {
     // programs of the current set, empty when the set is not covered)
     void *jit_module[3] = {nullptr, nullptr, nullptr}, *jit_fn[3] = {nullptr, nullptr, nullptr};
     bool jit_failed[3] = {false, false, false};
+    // RXR_SHADER_JIT=async: the compilation of a level runs in a child process (rxr_jitc); the interpreter renders until it is done
+    bool jit_async = false;
+    int jit_child[3] = {0, 0, 0};          // pid, 0: none
+    std::string jit_child_src[3], jit_child_out[3];
     std::string jit_source, jit_arch;
     bool frame_needs_chunk_paths = true;  // the uploaded frame uses what feature level 1 adds (terrain / baked textures / staircase / editor paths)
     std::string jit_info;                // what happened to the last set ("compiled: ...", "not compiled: <why>", empty: not asked)

@@ -29,6 +29,13 @@
 #include "rxr_ctx.h"
 
 #include <dlfcn.h>
+#include <signal.h>
+#include <spawn.h>
+#include <sys/types.h>
+#include <sys/wait.h>
+#include <unistd.h>
+
+extern char **environ;
 
 namespace {
 
@@ -436,11 +443,98 @@ std::mutex g_cache_mu;
 std::map<std::string, std::vector<char>> g_code_objects;  // generated source -> code object (one compilation per set and process)
 }  // namespace
 
+namespace {
+// RXR_SHADER_JIT=async: a compilation in flight is a child process (rxr_jitc, next to this library) and two files in /tmp
+void abandon_child(rxr_ctx *ctx, int slot) {
+    if (ctx->jit_child[slot] > 0) {
+        (void)kill(ctx->jit_child[slot], SIGKILL);
+        int st = 0;
+        (void)waitpid(ctx->jit_child[slot], &st, 0);
+    }
+    ctx->jit_child[slot] = 0;
+    if (!ctx->jit_child_src[slot].empty()) (void)unlink(ctx->jit_child_src[slot].c_str());
+    if (!ctx->jit_child_out[slot].empty()) (void)unlink(ctx->jit_child_out[slot].c_str());
+    ctx->jit_child_src[slot].clear();
+    ctx->jit_child_out[slot].clear();
+}
+std::string sibling_path(const char *name, std::string *self = nullptr) {
+    Dl_info info;
+    if (!dladdr((const void *)&rxr_jit_generate, &info) || !info.dli_fname) return "";
+    std::string lib = info.dli_fname;
+    if (self) *self = lib;
+    const size_t slash = lib.rfind('/');
+    return (slash == std::string::npos ? std::string(".") : lib.substr(0, slash)) + "/" + name;
+}
+bool start_child(rxr_ctx *ctx, int slot, int level, std::string &err) {
+    std::string lib;
+    const std::string exe = sibling_path("rxr_jitc", &lib);
+    if (exe.empty() || access(exe.c_str(), X_OK) != 0) {
+        err = "the background compiler rxr_jitc is not next to the library";
+        return false;
+    }
+    char src_t[] = "/tmp/rxr_jit_src_XXXXXX", out_t[] = "/tmp/rxr_jit_obj_XXXXXX";
+    const int fs = mkstemp(src_t), fo = mkstemp(out_t);
+    if (fs < 0 || fo < 0) {
+        if (fs >= 0) { close(fs); unlink(src_t); }
+        if (fo >= 0) { close(fo); unlink(out_t); }
+        err = "no temporary file";
+        return false;
+    }
+    close(fo);
+    const std::string &g = ctx->jit_source;
+    const bool wrote = write(fs, g.data(), g.size()) == (ssize_t)g.size();
+    close(fs);
+    ctx->jit_child_src[slot] = src_t;
+    ctx->jit_child_out[slot] = out_t;
+    const std::string lvl = std::to_string(level);
+    char *const argv[] = {(char *)exe.c_str(), (char *)lib.c_str(), src_t, (char *)ctx->jit_arch.c_str(), (char *)lvl.c_str(), out_t, nullptr};
+    pid_t pid = 0;
+    if (!wrote || posix_spawn(&pid, exe.c_str(), nullptr, nullptr, argv, environ) != 0) {
+        abandon_child(ctx, slot);
+        err = "the background compiler could not be started";
+        return false;
+    }
+    ctx->jit_child[slot] = (int)pid;
+    return true;
+}
+}  // namespace
+
+// rxr_jitc's half: generated source file -> code object file (no device needed)
+extern "C" int rxr_debug_jit_compile_file(const char *src_path, const char *arch, int level, const char *out_path) {
+    std::string gen, err;
+    {
+        FILE *f = fopen(src_path, "rb");
+        if (!f) return RXR_ERR_INVALID;
+        char buf[65536];
+        size_t n;
+        while ((n = fread(buf, 1, sizeof buf, f)) > 0) gen.append(buf, n);
+        fclose(f);
+    }
+    std::vector<char> obj;
+    double seconds = 0.0;
+    if (!rxr_jit_compile(gen, arch, level, obj, seconds, err)) {
+        fprintf(stderr, "rxr_jitc: %s\n", err.c_str());
+        return RXR_ERR_HIP;
+    }
+    // (written under another name first: the parent must never see half a file)
+    const std::string tmp = std::string(out_path) + ".part";
+    FILE *f = fopen(tmp.c_str(), "wb");
+    if (!f) return RXR_ERR_INVALID;
+    const bool ok = fwrite(obj.data(), 1, obj.size(), f) == obj.size();
+    fclose(f);
+    if (!ok || rename(tmp.c_str(), out_path) != 0) {
+        (void)unlink(tmp.c_str());
+        return RXR_ERR_INVALID;
+    }
+    return RXR_OK;
+}
+
 void rxr_jit_drop(rxr_ctx *ctx) {
     for (int k = 0; k < 3; ++k) {
         if (ctx->jit_module[k]) (void)hipModuleUnload((hipModule_t)ctx->jit_module[k]);
         ctx->jit_module[k] = ctx->jit_fn[k] = nullptr;
         ctx->jit_failed[k] = false;
+        abandon_child(ctx, k);
     }
     ctx->jit_source.clear();
 }
@@ -547,7 +641,39 @@ bool ensure_level(rxr_ctx *ctx, int slot) {
     std::vector<char> obj;
     double seconds = 0.0;
     std::string err;
-    if (!rxr_jit_compile(ctx->jit_source, ctx->jit_arch, levels[slot], obj, seconds, err)) {
+    if (ctx->jit_async) {
+        if (ctx->jit_child[slot] == 0) {
+            if (!start_child(ctx, slot, levels[slot], err)) {
+                ctx->jit_failed[slot] = true;
+                ctx->jit_info = "not compiled: " + err;
+                return false;
+            }
+            ctx->jit_info = "compiling in the background: template level " + std::to_string(levels[slot]);
+            return false;  // (this frame and the next ones: the interpreter)
+        }
+        int st = 0;
+        const pid_t r = waitpid(ctx->jit_child[slot], &st, WNOHANG);
+        if (r == 0) return false;  // still compiling
+        ctx->jit_child[slot] = 0;
+        bool ok = r > 0 && WIFEXITED(st) && WEXITSTATUS(st) == 0;
+        if (ok) {
+            FILE *f = fopen(ctx->jit_child_out[slot].c_str(), "rb");
+            ok = f != nullptr;
+            if (f) {
+                char buf[65536];
+                size_t n;
+                while ((n = fread(buf, 1, sizeof buf, f)) > 0) obj.insert(obj.end(), buf, buf + n);
+                fclose(f);
+            }
+            ok = ok && !obj.empty();
+        }
+        abandon_child(ctx, slot);
+        if (!ok) {
+            ctx->jit_failed[slot] = true;
+            ctx->jit_info = "not compiled: the background compiler failed";
+            return false;
+        }
+    } else if (!rxr_jit_compile(ctx->jit_source, ctx->jit_arch, levels[slot], obj, seconds, err)) {
         ctx->jit_failed[slot] = true;
         ctx->jit_info = "not compiled: " + err;
         return false;

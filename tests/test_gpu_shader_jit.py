@@ -184,3 +184,35 @@ def test_box_grid_with_the_configuration_c5_program(oracle, product, monkeypatch
     """the per-batch program of BASELINE.json's C5 on the reduced grid (binned path, row mode, Linear sampling)"""
     build = lambda api: scenes.box_grid_scene(api, n=32, width=640, height=360, shader=True)  # noqa: E731
     three_ways(oracle, product, monkeypatch, build, tol=0, max_off=0)
+
+
+def test_background_compilation_switches_over_without_changing_a_pixel(product, monkeypatch):
+    """RXR_SHADER_JIT=async: the interpreter renders until the child process (rxr_jitc) has compiled the kernel, then the compiled
+    kernel does; every frame on the way is the same frame"""
+    import time
+
+    prog = Program([["UV", ("Push", 3.25), "Mul", "Fract", "Color", ("Push", 0.37, 0.91, 0.53), "Mul", "Add", "SetColor"]])
+    monkeypatch.delenv("RXR_SHADER_JIT", raising=False)
+    want = scenes.render(grid_scene(product, [prog])).copy()
+    monkeypatch.setenv("RXR_SHADER_JIT", "async")
+    cfg = grid_scene(product, [prog])
+    first = scenes.render(cfg).copy()
+    seen = [jit_info(product)]
+    assert np.array_equal(first, want)
+    assert seen[0].startswith("compiling in the background"), seen
+    deadline = time.time() + 120.0
+    while not jit_info(product).startswith("compiled:") and time.time() < deadline:
+        assert np.array_equal(scenes.render(cfg), want)
+        if jit_info(product) != seen[-1]:
+            seen.append(jit_info(product))
+        time.sleep(0.05)
+    assert jit_info(product).startswith("compiled:"), seen
+    assert np.array_equal(scenes.render(cfg), want)
+    # a set that is replaced while its compilation runs: the child is killed, nothing is left behind, the new set compiles
+    other = Program([["UV", ("Push", 5.5), "Mul", "Fract", "SetColor"]])
+    scenes.render(grid_scene(product, [other]))
+    assert jit_info(product).startswith("compiling in the background")
+    scenes.render(grid_scene(product, [prog]))     # (replaces `other` at once)
+    monkeypatch.delenv("RXR_SHADER_JIT", raising=False)
+    assert np.array_equal(scenes.render(grid_scene(product, [prog])), want)
+

@@ -65,3 +65,27 @@ def test_calls_become_functions_and_recursion_or_palette_lookups_are_left_to_the
     assert rc == B.RXR_ERR_UNSUPPORTED and "recursion" in msg
     rc, _, msg = generate([Program([["UV", "PaletteIndex", "SetColor"]])], 0)
     assert rc == B.RXR_ERR_UNSUPPORTED
+
+
+def test_the_background_compiler_is_a_process_that_turns_a_source_file_into_a_code_object(tmp_path):
+    """RXR_SHADER_JIT=async hands the generated source to rxr_jitc (a child process: it can be killed, hiprtc in a thread cannot)"""
+    import os
+    import subprocess
+
+    rc, src, msg = generate([scenes.box_grid_shader()], 0)
+    assert rc == 0, msg
+    lib = rusterix_amd.lib_paths()["rxr"]
+    exe = os.path.join(os.path.dirname(lib), "rxr_jitc")
+    assert os.access(exe, os.X_OK), "run __graft_entry__.build()"
+    source, out = tmp_path / "set.h", tmp_path / "set.co"
+    source.write_text(src)
+    pr = subprocess.run([exe, lib, str(source), "gfx950", "8", str(out)], capture_output=True, text=True, timeout=300)
+    assert pr.returncode == 0, pr.stderr
+    blob = out.read_bytes()
+    assert blob[:4] == b"\x7fELF" and len(blob) > 10000 and not (tmp_path / "set.co.part").exists()
+    # a source that does not compile: a non-zero exit status and no output file
+    source.write_text(src + "\nthis is not C++\n")
+    bad = tmp_path / "bad.co"
+    pr = subprocess.run([exe, lib, str(source), "gfx950", "8", str(bad)], capture_output=True, text=True, timeout=300)
+    assert pr.returncode != 0 and not bad.exists()
+
