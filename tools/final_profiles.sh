@@ -9,6 +9,7 @@ python3 bench.py > "$OUT/bench_line.json" 2> "$OUT/bench_line.err"
 echo "bench line done"
 python3 tools/run_configs.py --configs C2,C3,C4,C5s,C5s_shader,D2 --oracle C2,C3,C4,C5s,C5s_shader,D2 --frames 30 > "$OUT/configs.jsonl" 2> "$OUT/configs.err"
 python3 tools/run_configs.py --configs C5,C5shader --oracle C5,C5shader --frames 30 >> "$OUT/configs.jsonl" 2>> "$OUT/configs.err"
+python3 tools/run_configs.py --configs C5s_shader,C5shader --oracle C5s_shader,C5shader --frames 30 --jit 1 > "$OUT/configs_jit.jsonl" 2> "$OUT/configs_jit.err"
 echo "configs done"
 python3 tools/run_configs.py --configs C2,C3,C4,C5s,C5s_shader --oracle C2,C3,C4,C5s,C5s_shader --frames 30 --device-projection > "$OUT/configs_devproj.jsonl" 2> "$OUT/configs_devproj.err"
 python3 tools/run_configs.py --configs C5,C5shader --oracle C5 --frames 30 --device-projection >> "$OUT/configs_devproj.jsonl" 2>> "$OUT/configs_devproj.err"

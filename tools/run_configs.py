@@ -59,9 +59,13 @@ def main():
     ap.add_argument("--frames", type=int, default=30)
     ap.add_argument("--oracle", default="C2,C3,C4,C5s")
     ap.add_argument("--threads", type=int, default=0)
+    ap.add_argument("--jit", choices=["0", "1"], default=None,
+                    help="RXR_SHADER_JIT for this run: 1 = program sets compiled at run time (the caller waits), 0 = interpreted; default: the environment")
     ap.add_argument("--device-projection", action="store_true",
                     help="N1: clip_and_project + Edges on the GPU (geometry registered once, matrices per frame)")
     args = ap.parse_args()
+    if args.jit is not None:
+        os.environ["RXR_SHADER_JIT"] = args.jit
 
     prod = rusterix_amd.load()
     host = prod.lib
@@ -128,7 +132,7 @@ def main():
         t_loop_untimed = (time.perf_counter() - t0) / args.frames
         st = Stats()
         rxr.rxr_get_stats(ctx, C.byref(st))
-        rec = dict(config=name, scene=cfg.name, device_projection=bool(args.device_projection), resolution=[W, H], triangles_3d=st.n_triangles3d, bin_entries=st.n_bin_entries,
+        rec = dict(config=name, scene=cfg.name, shader_jit=os.environ.get("RXR_SHADER_JIT", "0"), device_projection=bool(args.device_projection), resolution=[W, H], triangles_3d=st.n_triangles3d, bin_entries=st.n_bin_entries,
                    scene_build_s=round(t_build, 2), upload_ms=round(t_upload * 1e3, 2),
                    setup_kernels_us=round(float(np.median(su[: n.value])), 1), raster_kernel_us=round(float(np.median(ru[: n.value])), 1),
                    frame_ms_device_resident=round(t_loop * 1e3, 4), mpix_per_s_device_resident=round(W * H / t_loop / 1e6, 1),
