@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <functional>
 #include <map>
 #include <mutex>
@@ -28,9 +29,12 @@
 
 #include "rxr_ctx.h"
 
+#include <dirent.h>
 #include <dlfcn.h>
+#include <errno.h>
 #include <signal.h>
 #include <spawn.h>
+#include <sys/stat.h>
 #include <sys/types.h>
 #include <sys/wait.h>
 #include <unistd.h>
@@ -444,18 +448,85 @@ std::map<std::string, std::vector<char>> g_code_objects;  // generated source ->
 }  // namespace
 
 namespace {
-// RXR_SHADER_JIT=async: a compilation in flight is a child process (rxr_jitc, next to this library) and two files in /tmp
-void abandon_child(rxr_ctx *ctx, int slot) {
-    if (ctx->jit_child[slot] > 0) {
-        (void)kill(ctx->jit_child[slot], SIGKILL);
-        int st = 0;
-        (void)waitpid(ctx->jit_child[slot], &st, 0);
+std::string cache_key(const std::string &arch, int level, const std::string &gen) {
+    const char *flags_env = getenv("RXR_JIT_FLAGS");  // further compiler options, blank-separated (tuning runs: -DRXR_JIT_WAVES_PER_SIMD=6 ...)
+    return arch + "\n" + std::to_string(level) + "\n" + (flags_env ? flags_env : "") + "\n" + gen;
+}
+
+// Background compilations (the default): a compilation in flight is a child process (rxr_jitc, next to this library) and two files
+// in /tmp, registered process-wide by cache key -- the contexts of a multi-device group, or two contexts with the same set, share
+// one child; at most RXR_JIT_MAX_CHILDREN run at a time (each is a few seconds of one core), the others wait their turn.
+constexpr size_t RXR_JIT_MAX_CHILDREN = 2;
+struct BgJob {
+    std::string dir, src, out;   // a directory of its own under /tmp: the child's TMPDIR too (a killed compiler leaves its temporaries there)
+    pid_t pid = 0;
+    int refs = 0;
+};
+std::mutex g_bg_mu;
+std::map<std::string, BgJob> g_bg;          // in flight
+std::map<std::string, std::string> g_bg_failed;  // key -> why (a set that failed once is not tried again)
+
+// everything in a job's directory, then the directory (a killed compiler leaves comgr-<pid>-... directories of temporaries behind)
+void remove_job_dir(const std::string &dir, int depth = 0) {
+    if (DIR *d = opendir(dir.c_str())) {
+        while (dirent *e = readdir(d)) {
+            if (!strcmp(e->d_name, ".") || !strcmp(e->d_name, "..")) continue;
+            const std::string path = dir + "/" + e->d_name;
+            if (unlink(path.c_str()) != 0 && depth < 4) remove_job_dir(path, depth + 1);
+        }
+        closedir(d);
     }
-    ctx->jit_child[slot] = 0;
-    if (!ctx->jit_child_src[slot].empty()) (void)unlink(ctx->jit_child_src[slot].c_str());
-    if (!ctx->jit_child_out[slot].empty()) (void)unlink(ctx->jit_child_out[slot].c_str());
-    ctx->jit_child_src[slot].clear();
-    ctx->jit_child_out[slot].clear();
+    (void)rmdir(dir.c_str());
+}
+// A process that was killed (or left through _exit) could not remove its jobs' directories: each directory names its owner
+// (file "owner": the pid), and the first job of a process removes the directories whose owner no longer exists.
+void sweep_stale_job_dirs() {
+    DIR *d = opendir("/tmp");
+    if (!d) return;
+    std::vector<std::string> stale;
+    while (dirent *e = readdir(d)) {
+        if (strncmp(e->d_name, "rxr_jit_", 8) != 0) continue;
+        const std::string dir = std::string("/tmp/") + e->d_name;
+        long pid = 0;
+        if (FILE *f = fopen((dir + "/owner").c_str(), "r")) {
+            if (fscanf(f, "%ld", &pid) != 1) pid = 0;
+            fclose(f);
+        }
+        if (pid > 0) {
+            if (kill((pid_t)pid, 0) != 0 && errno == ESRCH) stale.push_back(dir);
+        } else {  // no owner recorded (half removed): stale once it is older than any compilation
+            struct stat st;
+            if (stat(dir.c_str(), &st) == 0 && time(nullptr) - st.st_mtime > 600) stale.push_back(dir);
+        }
+    }
+    closedir(d);
+    for (const std::string &dir : stale) remove_job_dir(dir);
+}
+
+void finish_job_locked(std::map<std::string, BgJob>::iterator it, bool kill_it) {
+    BgJob &j = it->second;
+    if (kill_it && j.pid > 0) {
+        (void)kill(j.pid, SIGKILL);
+        int st = 0;
+        (void)waitpid(j.pid, &st, 0);
+    }
+    if (!j.dir.empty()) remove_job_dir(j.dir);
+    g_bg.erase(it);
+}
+// library unload (process exit): compilations still in flight are killed and their files removed -- plain system calls, unlike
+// joining a compiler thread
+struct BgReaper {
+    ~BgReaper() {
+        std::lock_guard<std::mutex> lk(g_bg_mu);
+        while (!g_bg.empty()) finish_job_locked(g_bg.begin(), true);
+    }
+} g_bg_reaper;
+void detach(rxr_ctx *ctx, int slot) {
+    if (ctx->jit_wait_key[slot].empty()) return;
+    std::lock_guard<std::mutex> lk(g_bg_mu);
+    auto it = g_bg.find(ctx->jit_wait_key[slot]);
+    if (it != g_bg.end() && --it->second.refs <= 0) finish_job_locked(it, true);  // nobody waits for it any more
+    ctx->jit_wait_key[slot].clear();
 }
 std::string sibling_path(const char *name, std::string *self = nullptr) {
     Dl_info info;
@@ -465,37 +536,116 @@ std::string sibling_path(const char *name, std::string *self = nullptr) {
     const size_t slash = lib.rfind('/');
     return (slash == std::string::npos ? std::string(".") : lib.substr(0, slash)) + "/" + name;
 }
-bool start_child(rxr_ctx *ctx, int slot, int level, std::string &err) {
+bool start_child_locked(const std::string &key, const std::string &gen, const std::string &arch, int level, std::string &err) {
     std::string lib;
     const std::string exe = sibling_path("rxr_jitc", &lib);
     if (exe.empty() || access(exe.c_str(), X_OK) != 0) {
         err = "the background compiler rxr_jitc is not next to the library";
         return false;
     }
-    char src_t[] = "/tmp/rxr_jit_src_XXXXXX", out_t[] = "/tmp/rxr_jit_obj_XXXXXX";
-    const int fs = mkstemp(src_t), fo = mkstemp(out_t);
-    if (fs < 0 || fo < 0) {
-        if (fs >= 0) { close(fs); unlink(src_t); }
-        if (fo >= 0) { close(fo); unlink(out_t); }
-        err = "no temporary file";
+    static bool swept = false;  // (under g_bg_mu)
+    if (!swept) {
+        swept = true;
+        sweep_stale_job_dirs();
+    }
+    char dir_t[] = "/tmp/rxr_jit_XXXXXX";
+    if (!mkdtemp(dir_t)) {
+        err = "no temporary directory";
         return false;
     }
-    close(fo);
-    const std::string &g = ctx->jit_source;
-    const bool wrote = write(fs, g.data(), g.size()) == (ssize_t)g.size();
-    close(fs);
-    ctx->jit_child_src[slot] = src_t;
-    ctx->jit_child_out[slot] = out_t;
+    const std::string dir = dir_t, src_t = dir + "/set.h", out_t = dir + "/set.co";
+    if (FILE *f = fopen((dir + "/owner").c_str(), "w")) {
+        fprintf(f, "%ld\n", (long)getpid());
+        fclose(f);
+    }
+    bool wrote = false;
+    if (FILE *f = fopen(src_t.c_str(), "wb")) {
+        wrote = fwrite(gen.data(), 1, gen.size(), f) == gen.size();
+        fclose(f);
+    }
     const std::string lvl = std::to_string(level);
-    char *const argv[] = {(char *)exe.c_str(), (char *)lib.c_str(), src_t, (char *)ctx->jit_arch.c_str(), (char *)lvl.c_str(), out_t, nullptr};
+    char *const argv[] = {(char *)exe.c_str(), (char *)lib.c_str(), (char *)src_t.c_str(), (char *)arch.c_str(), (char *)lvl.c_str(), (char *)out_t.c_str(), nullptr};
+    // the child's environment: ours, with TMPDIR pointing into the job's directory
+    std::vector<std::string> env_store;
+    for (char **e = environ; e && *e; ++e)
+        if (strncmp(*e, "TMPDIR=", 7) != 0) env_store.push_back(*e);
+    env_store.push_back("TMPDIR=" + dir);
+    std::vector<char *> envp;
+    for (std::string &e : env_store) envp.push_back((char *)e.c_str());
+    envp.push_back(nullptr);
     pid_t pid = 0;
-    if (!wrote || posix_spawn(&pid, exe.c_str(), nullptr, nullptr, argv, environ) != 0) {
-        abandon_child(ctx, slot);
+    if (!wrote || posix_spawn(&pid, exe.c_str(), nullptr, nullptr, argv, envp.data()) != 0) {
+        remove_job_dir(dir);
         err = "the background compiler could not be started";
         return false;
     }
-    ctx->jit_child[slot] = (int)pid;
+    BgJob j;
+    j.dir = dir;
+    j.src = src_t;
+    j.out = out_t;
+    j.pid = pid;
+    j.refs = 1;
+    g_bg[key] = j;
     return true;
+}
+// 1: the code object is in the cache now; 0: not yet (still compiling, or waiting for a slot); -1: failed (err)
+int poll_background(rxr_ctx *ctx, int slot, int level, std::string &err) {
+    const std::string key = cache_key(ctx->jit_arch, level, ctx->jit_source);
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        if (g_code_objects.count(key)) return 1;
+    }
+    std::lock_guard<std::mutex> lk(g_bg_mu);
+    auto failed = g_bg_failed.find(key);
+    if (failed != g_bg_failed.end()) {
+        err = failed->second;
+        ctx->jit_wait_key[slot].clear();
+        return -1;
+    }
+    auto it = g_bg.find(key);
+    if (it == g_bg.end()) {
+        // (if this context was attached, the job has ended between two polls: the cache or the failure table answered above, or it
+        // was another context's key -- start over)
+        ctx->jit_wait_key[slot].clear();
+        if (g_bg.size() >= RXR_JIT_MAX_CHILDREN) return 0;  // wait for a slot
+        if (!start_child_locked(key, ctx->jit_source, ctx->jit_arch, level, err)) {
+            g_bg_failed[key] = err;
+            return -1;
+        }
+        ctx->jit_wait_key[slot] = key;
+        return 0;
+    }
+    if (ctx->jit_wait_key[slot] != key) {  // somebody else's child compiles this very set: share it
+        ctx->jit_wait_key[slot] = key;
+        ++it->second.refs;
+    }
+    int st = 0;
+    const pid_t r = waitpid(it->second.pid, &st, WNOHANG);
+    if (r == 0) return 0;  // still compiling
+    bool ok = r > 0 && WIFEXITED(st) && WEXITSTATUS(st) == 0;
+    std::vector<char> obj;
+    if (ok) {
+        FILE *f = fopen(it->second.out.c_str(), "rb");
+        ok = f != nullptr;
+        if (f) {
+            char buf[65536];
+            size_t n;
+            while ((n = fread(buf, 1, sizeof buf, f)) > 0) obj.insert(obj.end(), buf, buf + n);
+            fclose(f);
+        }
+        ok = ok && !obj.empty();
+    }
+    it->second.pid = 0;
+    finish_job_locked(it, false);
+    ctx->jit_wait_key[slot].clear();
+    if (!ok) {
+        err = "the background compiler failed";
+        g_bg_failed[key] = err;
+        return -1;
+    }
+    std::lock_guard<std::mutex> lk2(g_cache_mu);
+    g_code_objects[key].swap(obj);
+    return 1;
 }
 }  // namespace
 
@@ -534,7 +684,7 @@ void rxr_jit_drop(rxr_ctx *ctx) {
         if (ctx->jit_module[k]) (void)hipModuleUnload((hipModule_t)ctx->jit_module[k]);
         ctx->jit_module[k] = ctx->jit_fn[k] = nullptr;
         ctx->jit_failed[k] = false;
-        abandon_child(ctx, k);
+        detach(ctx, k);
     }
     ctx->jit_source.clear();
 }
@@ -543,8 +693,8 @@ void rxr_jit_drop(rxr_ctx *ctx) {
 // process-wide cache; needs no device
 bool rxr_jit_compile(const std::string &gen, const std::string &arch, int level, std::vector<char> &obj, double &seconds, std::string &err) {
     seconds = 0.0;
-    const char *flags_env = getenv("RXR_JIT_FLAGS");  // further compiler options, blank-separated (tuning runs: -DRXR_JIT_WAVES_PER_SIMD=6 ...)
-    const std::string key = arch + "\n" + std::to_string(level) + "\n" + (flags_env ? flags_env : "") + "\n" + gen;
+    const char *flags_env = getenv("RXR_JIT_FLAGS");
+    const std::string key = cache_key(arch, level, gen);
     {
         std::lock_guard<std::mutex> lk(g_cache_mu);
         auto it = g_code_objects.find(key);
@@ -642,35 +792,19 @@ bool ensure_level(rxr_ctx *ctx, int slot) {
     double seconds = 0.0;
     std::string err;
     if (ctx->jit_async) {
-        if (ctx->jit_child[slot] == 0) {
-            if (!start_child(ctx, slot, levels[slot], err)) {
-                ctx->jit_failed[slot] = true;
-                ctx->jit_info = "not compiled: " + err;
-                return false;
-            }
-            ctx->jit_info = "compiling in the background: template level " + std::to_string(levels[slot]);
-            return false;  // (this frame and the next ones: the interpreter)
-        }
-        int st = 0;
-        const pid_t r = waitpid(ctx->jit_child[slot], &st, WNOHANG);
-        if (r == 0) return false;  // still compiling
-        ctx->jit_child[slot] = 0;
-        bool ok = r > 0 && WIFEXITED(st) && WEXITSTATUS(st) == 0;
-        if (ok) {
-            FILE *f = fopen(ctx->jit_child_out[slot].c_str(), "rb");
-            ok = f != nullptr;
-            if (f) {
-                char buf[65536];
-                size_t n;
-                while ((n = fread(buf, 1, sizeof buf, f)) > 0) obj.insert(obj.end(), buf, buf + n);
-                fclose(f);
-            }
-            ok = ok && !obj.empty();
-        }
-        abandon_child(ctx, slot);
-        if (!ok) {
+        const int st = poll_background(ctx, slot, levels[slot], err);
+        if (st < 0) {
             ctx->jit_failed[slot] = true;
-            ctx->jit_info = "not compiled: the background compiler failed";
+            ctx->jit_info = "not compiled: " + err;
+            return false;
+        }
+        if (st == 0) {  // (this frame and the next ones: the interpreter)
+            ctx->jit_info = (ctx->jit_wait_key[slot].empty() ? "waiting for a compiler slot: template level " : "compiling in the background: template level ") + std::to_string(levels[slot]);
+            return false;
+        }
+        if (!rxr_jit_compile(ctx->jit_source, ctx->jit_arch, levels[slot], obj, seconds, err)) {  // (answers from the cache)
+            ctx->jit_failed[slot] = true;
+            ctx->jit_info = "not compiled: " + err;
             return false;
         }
     } else if (!rxr_jit_compile(ctx->jit_source, ctx->jit_arch, levels[slot], obj, seconds, err)) {

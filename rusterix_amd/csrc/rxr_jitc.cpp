@@ -7,12 +7,20 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <thread>
 
 int main(int argc, char **argv) {
     if (argc != 6) {
         std::fprintf(stderr, "usage: %s <librxr_hip.so> <source> <arch> <level> <out>\n", argv[0]);
         return 2;
     }
+    // a parent that dies without dropping its job takes this process with it (a watching thread rather than PR_SET_PDEATHSIG:
+    // that signal follows the parent's spawning THREAD, and a render call may come from a pool thread that ends early)
+    const pid_t parent = getppid();
+    std::thread([parent] {
+        while (getppid() == parent) usleep(200 * 1000);
+        _Exit(6);
+    }).detach();
     void *lib = dlopen(argv[1], RTLD_NOW | RTLD_LOCAL);
     if (!lib) {
         std::fprintf(stderr, "rxr_jitc: %s\n", dlerror());
@@ -25,8 +33,7 @@ int main(int argc, char **argv) {
         return 4;
     }
     const int rc = compile(argv[2], argv[3], std::atoi(argv[4]), argv[5]);
-    (void)unlink(argv[2]);                     // the source has been read
-    if (getppid() == 1) (void)unlink(argv[5]);  // the parent is gone (it ended without dropping its context): nobody will read this
+    // (the parent removes the job's directory -- source, code object, the compiler's temporaries -- when it collects or drops the job)
     std::fflush(nullptr);
     _Exit(rc == 0 ? 0 : 5);  // (no static destructors: the process has done its one job)
 }

@@ -27,3 +27,13 @@ def product():
     import rusterix_amd
 
     return rusterix_amd.load()
+
+
+def pytest_runtest_logstart(nodeid, location):
+    """RXR_TEST_TIMESTAMPS=<file>: one line per test with its start time (to match leftovers of a run to the test that made them)."""
+    path = os.environ.get("RXR_TEST_TIMESTAMPS")
+    if path:
+        import time
+
+        with open(path, "a") as f:
+            f.write("%s %d %s\n" % (time.strftime("%H:%M:%S"), os.getpid(), nodeid))

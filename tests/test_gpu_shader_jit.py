@@ -50,14 +50,14 @@ def grid_scene(api, programs, time=0.25, lights=False):
 
 
 def three_ways(oracle, product, monkeypatch, build, tol=0, max_off=0):
-    monkeypatch.delenv("RXR_SHADER_JIT", raising=False)
+    monkeypatch.setenv("RXR_SHADER_JIT", "0")
     interp = scenes.render(build(product)).copy()
     assert jit_info(product) == ""
     monkeypatch.setenv("RXR_SHADER_JIT", "1")
     got = scenes.render(build(product)).copy()
     info = jit_info(product)
     assert info.startswith("compiled:"), info
-    monkeypatch.delenv("RXR_SHADER_JIT", raising=False)
+    monkeypatch.setenv("RXR_SHADER_JIT", "0")
     assert np.array_equal(got, interp), f"compiled and interpreted frames differ in {(got != interp).any(axis=2).sum()} pixels; first at {np.argwhere((got != interp).any(axis=2))[:3].tolist()}"
     ref = scenes.render(build(oracle))
     diff = np.abs(got.astype(np.int16) - ref.astype(np.int16)).max(axis=2)
@@ -187,14 +187,14 @@ def test_box_grid_with_the_configuration_c5_program(oracle, product, monkeypatch
 
 
 def test_background_compilation_switches_over_without_changing_a_pixel(product, monkeypatch):
-    """RXR_SHADER_JIT=async: the interpreter renders until the child process (rxr_jitc) has compiled the kernel, then the compiled
+    """the default mode (RXR_SHADER_JIT unset or "async"): the interpreter renders until the child process (rxr_jitc) has compiled the kernel, then the compiled
     kernel does; every frame on the way is the same frame"""
     import time
 
     prog = Program([["UV", ("Push", 3.25), "Mul", "Fract", "Color", ("Push", 0.37, 0.91, 0.53), "Mul", "Add", "SetColor"]])
-    monkeypatch.delenv("RXR_SHADER_JIT", raising=False)
+    monkeypatch.setenv("RXR_SHADER_JIT", "0")
     want = scenes.render(grid_scene(product, [prog])).copy()
-    monkeypatch.setenv("RXR_SHADER_JIT", "async")
+    monkeypatch.delenv("RXR_SHADER_JIT", raising=False)   # (the default IS the background mode)
     cfg = grid_scene(product, [prog])
     first = scenes.render(cfg).copy()
     seen = [jit_info(product)]
@@ -213,6 +213,6 @@ def test_background_compilation_switches_over_without_changing_a_pixel(product, 
     scenes.render(grid_scene(product, [other]))
     assert jit_info(product).startswith("compiling in the background")
     scenes.render(grid_scene(product, [prog]))     # (replaces `other` at once)
-    monkeypatch.delenv("RXR_SHADER_JIT", raising=False)
+    monkeypatch.setenv("RXR_SHADER_JIT", "0")
     assert np.array_equal(scenes.render(grid_scene(product, [prog])), want)
 

@@ -6,6 +6,8 @@ import argparse
 import ctypes as C
 import json
 import os
+
+os.environ.setdefault("RXR_SHADER_JIT", "0")  # (measurements name their mode: interpreted unless asked otherwise)
 import sys
 import time
 

@@ -5,6 +5,8 @@ wave lifetime spent in each phase (s_memtime deltas summed over waves)."""
 import argparse
 import ctypes as C
 import os
+
+os.environ.setdefault("RXR_SHADER_JIT", "0")  # (measurements name their mode: interpreted unless asked otherwise)
 import sys
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))

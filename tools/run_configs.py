@@ -64,8 +64,11 @@ def main():
     ap.add_argument("--device-projection", action="store_true",
                     help="N1: clip_and_project + Edges on the GPU (geometry registered once, matrices per frame)")
     args = ap.parse_args()
-    if args.jit is not None:
-        os.environ["RXR_SHADER_JIT"] = args.jit
+    # measurements name their mode: interpreted unless --jit 1 (the library's own default, a background compilation that switches over
+    # in mid-run, would make the numbers depend on timing)
+    os.environ["RXR_SHADER_JIT"] = args.jit if args.jit is not None else os.environ.get("RXR_SHADER_JIT", "0")
+    if os.environ["RXR_SHADER_JIT"] not in ("0", "1"):
+        os.environ["RXR_SHADER_JIT"] = "0"
 
     prod = rusterix_amd.load()
     host = prod.lib

@@ -34,6 +34,8 @@ def run(name, prog):
 P=B.Program
 run("no program", None)
 import os
+
+os.environ.setdefault("RXR_SHADER_JIT", "0")  # (measurements name their mode: interpreted unless asked otherwise)
 if os.environ.get("ONLY_NOPROG"): sys.exit(0)
 run("empty shade", P([[]]))
 run("1 op (Color SetColor)", P([["Color","SetColor"]]))
