@@ -43,13 +43,22 @@ REHEARSAL = os.environ.get("RXR_BENCH_REHEARSAL") == "1"
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 vector (FMA counted as 2)
 
-# rocprofv3 passes of this same command (3840x2160, 16 lights, 1 GPU), per k_raster launch.  NOT measured in this run: the
-# PMC passes need the profiler (tools/profile_bench.sh); the numbers are copied here from the committed summary.
-PROFILE = {
-    "source": "profiles/r02/bench_pmc_summary.json (tools/profile_bench.sh; rocprofv3 --pmc, separate passes)",
-    "write_bytes": 33177600,       # WRITE_SIZE: exactly the framebuffer (3840 * 2160 * 4)
-    "fetch_bytes_x2": 2186156,     # FETCH_SIZE with the gfx950 x2 correction
-    "valu_wave_instructions": 151602512,
+# rocprofv3 passes of this same command (3840x2160, 16 lights, 1 GPU), per raster-kernel launch, for the two light-loop modes.
+# NOT measured in this run: the PMC passes need the profiler (tools/profile_bench.sh); the numbers are copied here from the
+# committed summaries.
+PROFILES = {
+    "relaxed": {
+        "source": "profiles/r02/bench_relaxed_pmc_summary.json (tools/profile_bench.sh; rocprofv3 --pmc, separate passes; kernel k_raster_rl)",
+        "write_bytes": 33177600,       # WRITE_SIZE: exactly the framebuffer (3840 * 2160 * 4)
+        "fetch_bytes_x2": 2138097,     # FETCH_SIZE with the gfx950 x2 correction
+        "valu_wave_instructions": 124593189,
+    },
+    "exact": {
+        "source": "profiles/r02/bench_exact_pmc_summary.json (RXR_LIGHT_MATH=exact tools/profile_bench.sh; kernel k_raster)",
+        "write_bytes": 33177600,
+        "fetch_bytes_x2": 2182024,
+        "valu_wave_instructions": 151319560,
+    },
 }
 
 
@@ -253,6 +262,25 @@ def main():
             torch.cuda.synchronize()
             assert torch.equal(direct, final), "gathered frame differs from the single-launch frame"
 
+    # the same frame in the other light-loop arithmetic (rxr_set_light_math, include/rxr.h), N = 1 only: a few batches, reported
+    # beside the default mode's `value`, never as it
+    relaxed = os.environ.get("RXR_LIGHT_MATH", "exact" if host.rxh_get_light_math_exact() else "relaxed")[0] == "r"
+    other_mode = None
+    if world == 1 and not sharded and "RXR_LIGHT_MATH" not in os.environ:
+        host.rxh_set_light_math_exact(1 if relaxed else 0)
+        rc = host.rxh_rasterizer_upload(rast._h, cfg.scene._h, W, H, cfg.tile_size, cfg.assets._h)
+        if rc == 0:
+            run(args.warmup)
+            other_s = [timed_batch() for _ in range(5)]
+            check(rxr.rxr_synchronize(ctx))
+            other_dt = float(np.median(other_s))
+            other_mode = {"light_math": "exact" if relaxed else "relaxed", "ms_per_step": round(other_dt / args.steps * 1e3, 4),
+                          "mpix_s": round(W * H * args.steps / other_dt / 1e6, 2), "batches": len(other_s)}
+        host.rxh_set_light_math_exact(0 if relaxed else 1)
+        rc = host.rxh_rasterizer_upload(rast._h, cfg.scene._h, W, H, cfg.tile_size, cfg.assets._h)
+        if rc != 0:
+            raise SystemExit(f"upload failed: {rc} {host.rxh_last_error()}")
+
     fence()
     e2e = None
     if rank == 0 and not args.no_e2e:
@@ -271,6 +299,7 @@ def main():
         alg = algorithmic_bytes(W, rows_this_rank, n_verts, n_tris, tex_bytes, args.lights)
         achieved = alg / (raster_avg_us * 1e-6) / 1e9
         default_workload = (W, H, args.lights, world) == (3840, 2160, 16, 1)
+        PROFILE = PROFILES["relaxed" if relaxed else "exact"]
         out = {
             "metric": "Mpixels/s (+ ms/frame) on rasterize_map @3840x2160, 1/2/4/8 MI355X vs CPU",
             "value": round(value, 2),
@@ -297,13 +326,17 @@ def main():
                             "fence cut-outs, 2D logo rectangle; UV jitter absent in the reference snapshot",
                 "resolution": [W, H],
                 "triangles_3d": n_tris,
+                # arithmetic of the 3D light loop (rxr_set_light_math): "relaxed" = the library's default, point lights within
+                # BASELINE.json's 1-per-channel tolerance for lit 3D fragments (tests/test_gpu_light_math.py: 43 of 8 294 400
+                # pixels of this frame differ from the CPU oracle, each by 1); "exact" = correctly rounded throughout
+                "light_math": "relaxed" if relaxed else "exact",
                 "sharding": "single GPU" if world == 1 else f"interleaved 16-row stripes over {world} GPUs (one process per GPU) + RCCL {args.exchange} "
                                                            + ("to rank (frame mod N)" if args.exchange == "rotate" else "to rank 0")
                                                            + " over xGMI, pipelined with the next frame's render",
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_raster",
+                "kernel": "k_raster_rl" if relaxed else "k_raster",
                 "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
@@ -326,6 +359,8 @@ def main():
                 } if default_workload else None,
             },
         }
+        if other_mode is not None:
+            out["other_light_math"] = other_mode
         if e2e is not None:
             out.update(e2e)
         if world == 1 and not args.no_cpu:

@@ -56,6 +56,9 @@ void *rxh_context() { return context(); }
 // device-side projection on/off (rusterix::set_device_projection)
 void rxh_set_device_projection(int on) { set_device_projection(on != 0); }
 int rxh_get_device_projection() { return device_projection() ? 1 : 0; }
+// light-loop arithmetic (rusterix::set_light_math): 1 = exact, 0 = relaxed (the default)
+void rxh_set_light_math_exact(int exact) { set_light_math(exact != 0); }
+int rxh_get_light_math_exact() { return light_math_exact() ? 1 : 0; }
 
 // ---- scene ----------------------------------------------------------------------------------------
 void *rxh_scene_new() { return new Scene(); }

@@ -451,11 +451,18 @@ std::string g_error;
 uint64_t g_tex_static_gen = 0, g_tex_dynamic_gen = 0;
 uint64_t g_shaders_gen = 0, g_shader_env_gen = 0;
 bool g_device_projection = false;
+int g_light_math = RXR_LIGHT_MATH_RELAXED;  // the library's default
 uint64_t g_mesh_fingerprint = 0;
 }  // namespace
 
 void set_device_projection(bool on) { g_device_projection = on; }
 bool device_projection() { return g_device_projection; }
+void set_light_math(bool exact) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    g_light_math = exact ? RXR_LIGHT_MATH_EXACT : RXR_LIGHT_MATH_RELAXED;
+    if (g_ctx) (void)rxr_set_light_math(g_ctx, g_light_math);
+}
+bool light_math_exact() { return g_light_math == RXR_LIGHT_MATH_EXACT; }
 
 const std::string &last_error() { return g_error; }
 
@@ -508,6 +515,7 @@ rxr_ctx *context(std::string *error) {
             return nullptr;
         }
         g_device = dev;
+        (void)rxr_set_light_math(g_ctx, g_light_math);
     }
     return g_ctx;
 }

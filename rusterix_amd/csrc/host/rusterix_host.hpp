@@ -252,6 +252,10 @@ rxr_ctx *context(std::string *error = nullptr);
 // (clip_and_project, Edges::new, bounding boxes) then runs on the GPU.  Off by default.
 void set_device_projection(bool on);
 bool device_projection();
+// arithmetic of the 3D light loop (rxr_set_light_math, include/rxr.h): relaxed by default -- point lights within the 1-per-channel
+// tolerance of lit 3D fragments; exact = the reference's correctly rounded operations throughout.  Applies from the next frame on.
+void set_light_math(bool exact);
+bool light_math_exact();
 void set_device(int device);
 // more than one entry: the context becomes a multi-device one (rxr_create_multi): rasterize() then shards every frame over
 // these GPUs inside the library.  A device may be listed more than once (logical members on one GPU).

@@ -173,6 +173,16 @@ int rxr_create(rxr_ctx **out, int device_id) {
     return RXR_OK;
 }
 
+int rxr_set_light_math(rxr_ctx *ctx, int mode) {
+    if (!ctx) return fail(nullptr, RXR_ERR_INVALID, "rxr_set_light_math: ctx is NULL");
+    if (mode != RXR_LIGHT_MATH_EXACT && mode != RXR_LIGHT_MATH_RELAXED) return fail(ctx, RXR_ERR_INVALID, "rxr_set_light_math: mode must be RXR_LIGHT_MATH_EXACT or RXR_LIGHT_MATH_RELAXED");
+    if (ctx->group) {
+        for (int i = 0; i < rxr_member_count(ctx); ++i) rxr_member(ctx, i)->relaxed_lights = mode == RXR_LIGHT_MATH_RELAXED;
+    }
+    ctx->relaxed_lights = mode == RXR_LIGHT_MATH_RELAXED;
+    return RXR_OK;
+}
+
 void rxr_destroy(rxr_ctx *ctx) {
     if (!ctx) return;
     if (ctx->group) {
@@ -1137,6 +1147,13 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
     P.kernel_level = std::max(ctx->min_kernel_level, uses_programs ? 2u : ((uses_chunk_tex || editor_paths) ? 1u : 0u));
     ctx->frame_needs_chunk_paths = uses_chunk_tex || editor_paths || ctx->min_kernel_level >= 1u;  // (rxr_jit_launch: level 8 otherwise)
     P.plain_programs = (!ctx->frame_needs_chunk_paths && !getenv("RXR_NO_PLAIN_PROGRAMS")) ? 1u : 0u;
+    {
+        // RXR_LIGHT_MATH (read per frame; rxr_set_light_math sets the context's own default): "exact" -- the light loop in the
+        // reference's correctly rounded operations; "relaxed" -- point lights through rsq / rcp products, within the 1-per-channel
+        // tolerance of lit 3D fragments (shade3d_lights<X, true>; feature levels 0 and 1)
+        const char *lm = getenv("RXR_LIGHT_MATH");
+        P.relaxed_lights = lm ? (lm[0] == 'r' ? 1u : 0u) : (ctx->relaxed_lights ? 1u : 0u);
+    }
     if (P.kernel_level == 2u && uses_programs && ctx->programs_static) P.kernel_level = 3u;  // k_raster_vm_s: wave-uniform stack pointer
     // k_raster_vm_sv: ... and no program decides whether an opaque fragment is written, so the visibility loop is the one of
     // k_raster_chunk, without a call of the interpreter in it
@@ -2198,11 +2215,14 @@ int rxr_set_shaders(rxr_ctx *ctx, const rxr_shader_set *set) {
     // opt-in: the set as straight-line kernels compiled now (rxr_jit.hip); sets with calls or PaletteIndex keep the interpreter
     rxr_jit_drop(ctx);
     ctx->jit_info.clear();
-    if (const char *jit = getenv("RXR_SHADER_JIT")) {  // "1": compiled when first needed, the caller waits; "async": by a child process
-        ctx->jit_async = jit[0] == 'a';
-        if (jit[0] == '1' || jit[0] == 'a') {
-            if (progs.empty()) ctx->jit_info = "not compiled: no programs";
-            else if ((rc = rxr_jit_build(ctx, fl.code, progs)) != RXR_OK) return rc;  // (does its own analysis: calls are covered, PaletteIndex / recursion are not)
+    {
+        // RXR_SHADER_JIT: unset / "async" -- a child process compiles while the interpreter renders (the default); "1" -- compiled when
+        // first needed, the caller waits (measurements); "0" -- interpreted only
+        const char *jit = getenv("RXR_SHADER_JIT");
+        const char mode = jit ? jit[0] : 'a';
+        ctx->jit_async = mode == 'a';
+        if ((mode == '1' || mode == 'a') && !progs.empty()) {
+            if ((rc = rxr_jit_build(ctx, fl.code, progs)) != RXR_OK) return rc;  // (does its own analysis: calls are covered, PaletteIndex / recursion are not)
         }
     }
     ctx->programs = std::move(progs);

@@ -96,11 +96,11 @@ struct rxr_ctx {
     // programs of the current set, empty when the set is not covered)
     void *jit_module[3] = {nullptr, nullptr, nullptr}, *jit_fn[3] = {nullptr, nullptr, nullptr};
     bool jit_failed[3] = {false, false, false};
-    // RXR_SHADER_JIT=async: the compilation of a level runs in a child process (rxr_jitc); the interpreter renders until it is done
+    // background mode (the default): the compilation of a level runs in a child process (rxr_jitc); the interpreter renders until it is done
     bool jit_async = false;
-    int jit_child[3] = {0, 0, 0};          // pid, 0: none
-    std::string jit_child_src[3], jit_child_out[3];
+    std::string jit_wait_key[3];           // the background compilation (rxr_jit.hip registry) this context is attached to, per level
     std::string jit_source, jit_arch;
+    bool relaxed_lights = true;           // rxr_set_light_math / RXR_LIGHT_MATH: the 3D light loop in relaxed arithmetic (RasterParams.relaxed_lights)
     bool frame_needs_chunk_paths = true;  // the uploaded frame uses what feature level 1 adds (terrain / baked textures / staircase / editor paths)
     std::string jit_info;                // what happened to the last set ("compiled: ...", "not compiled: <why>", empty: not asked)
     bool programs_static = false;    // every program of the set has a stack depth that is a function of the pc (tag_static_depths)

@@ -178,6 +178,27 @@ __device__ __forceinline__ void normalize3(float x, float y, float z, float &ox,
     mag = m;
 }
 
+// RELAXED form for the light loop of lit 3D fragments (north_star: "within 1 per channel for float-interpolated 3D/lit paths"):
+// v * rsq(|v|^2) and |v|^2 * rsq(|v|^2) -- every component and the magnitude within 2 ulp of the correctly rounded values, six
+// instructions instead of twenty-five.  The same window vote as the exact form: zero, denormal, infinite and NaN magnitudes take
+// the exact path, so the special cases of both forms are the same values.
+__device__ __forceinline__ void normalize3_relaxed(float x, float y, float z, float &ox, float &oy, float &oz, float &mag) {
+    float m2 = (x * x + y * y) + z * z;
+    if (wave_all(sq_in_window(m2))) {
+        float inv = __builtin_amdgcn_rsqf(m2);
+        ox = x * inv;
+        oy = y * inv;
+        oz = z * inv;
+        mag = m2 * inv;
+        return;
+    }
+    float m = sqrtf(m2);
+    ox = x / m;
+    oy = y / m;
+    oz = z / m;
+    mag = m;
+}
+
 // The same for vectors that often have components that are exactly zero (axis-aligned surface normals): a zero
 // numerator would lose its sign in the correction steps of the chain (fma(+0, r, -0) = +0), so each quotient goes
 // through v_div_fixup_f32 -- the compiler's own last instruction, which returns a correctly signed zero for a zero

@@ -150,6 +150,12 @@ __device__ __forceinline__ f3 norm3_fast(f3 a) {
     float m;
     return norm3_fast(a, m);
 }
+// relaxed-light mode (RXR_LIGHT_MATH, shade3d_lights): within 2 ulp per component
+__device__ __forceinline__ f3 norm3_relaxed(f3 a, float &mag) {
+    f3 o;
+    rxm::normalize3_relaxed(a.x, a.y, a.z, o.x, o.y, o.z, mag);
+    return o;
+}
 // the variant for surface normals: components that are exactly zero stay on the short path
 __device__ __forceinline__ f3 norm3_z(f3 a) {
     f3 o;
@@ -355,6 +361,7 @@ __device__ __forceinline__ bool light_color_at(const rxr_light &l, f3 point, uin
 
 // rasterizer.rs:1875-1951 with emissive == 0 at every call site
 // (n_dot_l = max(dot(n, l), 0): the point-light path of the caller has the same float at hand as its Lambert term)
+template <bool RL = false>
 __device__ __forceinline__ f3 shade_fast_brdf(f3 base, float roughness, float metallic, f3 n, f3 v, f3 l, f3 radiance, float n_dot_l) {
     if (n_dot_l <= 0.0f) return mk3(0.0f, 0.0f, 0.0f);
     // Vec3::lerp(0.04, base, metallic) = mul_add(clamp01(t), b - a, a)
@@ -364,9 +371,20 @@ __device__ __forceinline__ f3 shade_fast_brdf(f3 base, float roughness, float me
     kd = scale3(kd, 1.0f - fmaxf(f0.x, fmaxf(f0.y, f0.z)));
     float a = fmaxf(roughness * roughness, 1e-4f);
     float shininess = rclamp(2.0f / a - 2.0f, 1.0f, 2048.0f);
-    f3 h = norm3_fast(add3(l, v));
-    float n_dot_h = fmaxf(dot3(n, h), 0.0f);
-    float spec_b = (n_dot_h <= 0.0f) ? 0.0f : rxm::pow_exp2_log2(n_dot_h, shininess);
+    f3 h;
+    float n_dot_h, spec_b;
+    if constexpr (RL) {
+        float hm;
+        h = norm3_relaxed(add3(l, v), hm);
+        n_dot_h = fmaxf(dot3(n, h), 0.0f);
+        // v_log_f32 / v_exp_f32 directly: where log2f / exp2f would rescale (a denormal n.h, a result below 2^-126) both forms give
+        // a specular factor below 2^-126
+        spec_b = (n_dot_h <= 0.0f) ? 0.0f : __builtin_amdgcn_exp2f(shininess * __builtin_amdgcn_logf(n_dot_h));
+    } else {
+        h = norm3_fast(add3(l, v));
+        n_dot_h = fmaxf(dot3(n, h), 0.0f);
+        spec_b = (n_dot_h <= 0.0f) ? 0.0f : rxm::pow_exp2_log2(n_dot_h, shininess);
+    }
     float n_dot_v = fmaxf(dot3(n, v), 0.0f);
     float om = 1.0f - rclamp(n_dot_v, 0.0f, 1.0f);
     float x5 = om * om * om * om * om;
@@ -644,7 +662,10 @@ __device__ __forceinline__ float wave_max(float v) {
 // sphere cannot reach the bounding sphere of the wave's fragments is one for which every lane's
 // `distance >= end_distance` test (light.rs:539, 561, 586, 636) would return None, so skipping it
 // changes nothing; the surviving lights are then evaluated in their original order.
-template <int X>
+// RL: the relaxed arithmetic of RXR_LIGHT_MATH=relaxed for POINT lights (every quantity is continuous in the fragment's position
+// there: the range test, the smoothstep and the Lambert / specular cut-offs all meet their neighbours at zero, so an error of a
+// few ulp moves a channel by at most one step); spot, area and daylight lights have hard cut-offs and stay exact in both modes.
+template <int X, bool RL = false>
 __device__ __forceinline__ void shade3d_lights(const RasterParams &P, bool hit, Frag &F) {
     const unsigned long long hitmask = __ballot(hit);
     if (hitmask == 0ull) return;
@@ -697,14 +718,16 @@ __device__ __forceinline__ void shade3d_lights(const RasterParams &P, bool hit, 
                 if (!L.emitting) continue;
                 f3 d = sub3(lp, F.world);
                 float distance;
-                ldir = norm3_fast(d, distance);
+                if constexpr (RL) ldir = norm3_relaxed(d, distance);
+                else ldir = norm3_fast(d, distance);
                 if (distance >= L.end_distance) continue;
                 float intensity = L.intensity;
                 if (!(distance <= L.start_distance)) {
                     // smoothstep_rs(end, start, distance) with the shared reciprocal
                     const float sn = distance - L.end_distance, sd = L.start_distance - L.end_distance;
                     float q;
-                    if (ss_fast && rxm::wave_all(rxm::in_window(sn))) q = rxm::div_chain(sn, sd, ss_r);
+                    if (RL && ss_fast) q = sn * ss_r;  // (|sn| < |sd| here: the product cannot leave the window upwards; below it, q -> 0 = t)
+                    else if (ss_fast && rxm::wave_all(rxm::in_window(sn))) q = rxm::div_chain(sn, sd, ss_r);
                     else q = sn / sd;
                     const float t = rclamp(q, 0.0f, 1.0f);
                     intensity = L.intensity * (t * t * (3.0f - 2.0f * t));
@@ -721,7 +744,7 @@ __device__ __forceinline__ void shade3d_lights(const RasterParams &P, bool hit, 
             } else {
                 radiance = scale3(incoming, n_dot_l);
             }
-            F.lit = add3(F.lit, shade_fast_brdf(F.base, rough, metal, F.normal, F.view_dir, ldir, radiance, n_dot_l));
+            F.lit = add3(F.lit, shade_fast_brdf<RL>(F.base, rough, metal, F.normal, F.view_dir, ldir, radiance, n_dot_l));  // (continuous for every light type)
         }
     }
 }
@@ -2212,7 +2235,7 @@ struct RowStore {
 template <>
 struct RowStore<false> {};
 
-template <bool FUSED, int X, bool ROWS = false>
+template <bool FUSED, int X, bool ROWS = false, bool RL = false>
 __device__ __forceinline__ void raster_tile(const RasterParams &P) {
     __shared__ Stage stage;
     __shared__ uint32_t s_bin[4];
@@ -2344,7 +2367,7 @@ __device__ __forceinline__ void raster_tile(const RasterParams &P) {
             shade3d_begin<X>(P, HS, vis.batch, vis.alpha, vis.beta, vis.zmin, fx, fy, F);
         }
         PHASE_MARK(2);
-        if (P.n_lights) shade3d_lights<X>(P, hit, F);  // wave-uniform call
+        if (P.n_lights) shade3d_lights<X, RL>(P, hit, F);  // wave-uniform call
         PHASE_MARK(3);
         color = hit ? shade3d_end<X>(F) : pack4(0u, 0u, 0u, 255u);
         if constexpr (lvl1<X>) {
@@ -2514,6 +2537,8 @@ extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_RASTER_WAVES_
 extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_RASTER_WAVES_PER_SIMD) k_raster(RasterParams P) { raster_tile<false, 0>(P); }
 #endif
 extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS) k_raster_fused(RasterParams) { raster_tile<true, 0>(kernarg_params_early()); }
+// RXR_LIGHT_MATH=relaxed (RasterParams.relaxed_lights): the same kernels with the relaxed light loop (shade3d_lights<X, true>)
+extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_RASTER_WAVES_PER_SIMD) k_raster_rl(RasterParams) { raster_tile<false, 0, false, true>(kernarg_params_early()); }
 // binned scenes (more than RXR_STAGE_TRIS triangles): the walk may switch to row mode per round (rows_round)
 #ifndef RXR_ROWS_WAVES_PER_SIMD
 #define RXR_ROWS_WAVES_PER_SIMD 8  // C5: unbounded (87 VGPRs, 5 waves) 797 us, 6: 718, 7: 727; with the parameter block in place 6: 654, 8: 628
@@ -2526,6 +2551,7 @@ extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_ROWS_WAVES_PE
 #else
 extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_ROWS_WAVES_PER_SIMD) k_raster_rows(RasterParams P) { raster_tile<false, 0, true>(P); }
 #endif
+extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_ROWS_WAVES_PER_SIMD) k_raster_rows_rl(RasterParams) { raster_tile<false, 0, true, true>(kernarg_params_early()); }
 // feature levels (template parameter X) so that the common kernels above carry none of the rarer paths:
 //   1  k_raster_chunk: chunk textures -- terrain texels sampled by world position, baked shader textures, and the
 //      full-fragment alpha test they need
@@ -2543,6 +2569,7 @@ __device__ __forceinline__ const RasterParams &kernarg_params() {
 #define RXR_CHUNK_WAVES_PER_SIMD 8
 #endif
 extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_CHUNK_WAVES_PER_SIMD) k_raster_chunk(RasterParams) { raster_tile<false, 1, true>(kernarg_params()); }
+extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_CHUNK_WAVES_PER_SIMD) k_raster_chunk_rl(RasterParams) { raster_tile<false, 1, true, true>(kernarg_params()); }
 extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_VM_WAVES_PER_SIMD) k_raster_vm(RasterParams) { raster_tile<false, 2, true>(kernarg_params()); }
 // the same with the wave-uniform stack pointer, for sets whose programs all have static stack depths (kernel_level 3)
 extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_VM_WAVES_PER_SIMD) k_raster_vm_s(RasterParams) { raster_tile<false, 4, true>(kernarg_params()); }
@@ -2601,15 +2628,21 @@ extern "C" void rxr_launch_raster(const RasterParams *P, hipStream_t s) {
 #else
     const dim3 tiles(P->tiles_x, P->tiles_y);  // tiles_y <= 2048 (frames of at most 32768 rows)
 #endif
+    const bool rl = P->relaxed_lights && P->n_lights && (P->flags & RXR_FLAG_D3_ACTIVE);  // (frames without a 3D light loop: one kernel for both modes)
     const bool no_rows = getenv("RXR_NO_ROWS") != nullptr;  // tuning knob: binned scenes walk every candidate per pixel (k_raster)
     if (P->kernel_level >= 5u) hipLaunchKernelGGL(k_raster_vm_v, tiles, dim3(RXR_TILE_THREADS), 0, s, *P);
     else if (P->kernel_level == 4u && P->plain_programs) hipLaunchKernelGGL(k_raster_vm_p, tiles, dim3(RXR_TILE_THREADS), 0, s, *P);
     else if (P->kernel_level == 4u) hipLaunchKernelGGL(k_raster_vm_sv, tiles, dim3(RXR_TILE_THREADS), 0, s, *P);
     else if (P->kernel_level == 3u) hipLaunchKernelGGL(k_raster_vm_s, tiles, dim3(RXR_TILE_THREADS), 0, s, *P);
     else if (P->kernel_level == 2u) hipLaunchKernelGGL(k_raster_vm, tiles, dim3(RXR_TILE_THREADS), 0, s, *P);
-    else if (P->kernel_level == 1u) hipLaunchKernelGGL(k_raster_chunk, tiles, dim3(RXR_TILE_THREADS), 0, s, *P);
-    else if (P->fused_small == 1u) hipLaunchKernelGGL(k_raster_fused, tiles, dim3(RXR_TILE_THREADS), 0, s, *P);
-    else if (P->fused_small == 0u && (P->flags & RXR_FLAG_D3_ACTIVE) && !no_rows) hipLaunchKernelGGL(k_raster_rows, tiles, dim3(RXR_TILE_THREADS), 0, s, *P);
+    else if (P->kernel_level == 1u) {
+        if (rl) hipLaunchKernelGGL(k_raster_chunk_rl, tiles, dim3(RXR_TILE_THREADS), 0, s, *P);
+        else hipLaunchKernelGGL(k_raster_chunk, tiles, dim3(RXR_TILE_THREADS), 0, s, *P);
+    } else if (P->fused_small == 1u) hipLaunchKernelGGL(k_raster_fused, tiles, dim3(RXR_TILE_THREADS), 0, s, *P);
+    else if (P->fused_small == 0u && (P->flags & RXR_FLAG_D3_ACTIVE) && !no_rows) {
+        if (rl) hipLaunchKernelGGL(k_raster_rows_rl, tiles, dim3(RXR_TILE_THREADS), 0, s, *P);
+        else hipLaunchKernelGGL(k_raster_rows, tiles, dim3(RXR_TILE_THREADS), 0, s, *P);
+    } else if (rl) hipLaunchKernelGGL(k_raster_rl, tiles, dim3(RXR_TILE_THREADS), 0, s, *P);
     else hipLaunchKernelGGL(k_raster, tiles, dim3(RXR_TILE_THREADS), 0, s, *P);
 }
 #endif  // !RXR_JIT

@@ -61,6 +61,7 @@ def rxr_abi():
         "rxr_synchronize": (i32, [vp]),
         "rxr_get_stats": (i32, [vp, C.POINTER(RxrStats)]),
         "rxr_device_framebuffer": (vp, [vp]),
+        "rxr_set_light_math": (i32, [vp, i32]),
         "rxr_profile_begin": (i32, [vp, u32]),
         "rxr_profile_stride": (i32, [vp, u32]),
         "rxr_profile_read": (i32, [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), u32, C.POINTER(u32)]),
@@ -85,6 +86,7 @@ def load():
         lib.rxh_set_device.argtypes = [ctypes.c_int]
         lib.rxh_set_devices.argtypes = [ctypes.POINTER(ctypes.c_int), ctypes.c_int]
         lib.rxh_set_device_projection.argtypes = [ctypes.c_int]
+        lib.rxh_set_light_math_exact.argtypes = [ctypes.c_int]
         lib.rxh_rasterizer_upload.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p]
         _cached = make_api(lib, "rxh_", "product")
     return _cached

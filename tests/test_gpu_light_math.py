@@ -1,0 +1,178 @@
+"""The two arithmetic modes of the 3D direct-light loop (rxr_set_light_math, include/rxr.h; shade3d_lights<X, RL> in
+rusterix_amd/csrc/rxr_kernels.hip) against the CPU oracle.
+
+Reference path: src/rasterizer.rs:1373-1391 (the light loop), src/map/light.rs:491-552 (CompiledLight::radiance_at /
+calculate_point_light), src/rasterizer.rs:1875-1951 (shade_fast_brdf).  BASELINE.json's bar for lit, float-interpolated 3D
+fragments is 1 per 8-bit channel:
+
+  * EXACT    the reference's operations correctly rounded: a frame differs from the oracle only where log2f / exp2f / acosf of
+             the two math libraries differ (a handful of pixels, by 1);
+  * RELAXED  (the library's default) point lights through v_rsq_f32 products: nothing off by more than 1, and -- because an error
+             of two ulp reaches a channel only next to a rounding boundary -- only a small fraction of the pixels off at all;
+  * frames without a 3D light loop (unlit, 2D) are the SAME frame in both modes.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import rusterix_amd
+from rusterix_amd import binding as B
+from rusterix_amd import scenes
+from tests.test_gpu_parity import _light, assert_exact, scene_2d
+
+pytestmark = pytest.mark.gpu
+
+TOLERANCE = 1  # per 8-bit channel (BASELINE.json north_star, lit 3D paths)
+
+
+@pytest.fixture()
+def light_math(product, monkeypatch):
+    monkeypatch.delenv("RXR_LIGHT_MATH", raising=False)
+
+    def choose(exact):
+        product.lib.rxh_set_light_math_exact(1 if exact else 0)
+        assert product.lib.rxh_get_light_math_exact() == (1 if exact else 0)
+
+    yield choose
+    product.lib.rxh_set_light_math_exact(0)  # the default
+
+
+def channel_diff(a, b):
+    return np.abs(a.astype(np.int16) - b.astype(np.int16)).max(axis=2)
+
+
+def lit_box_grid(api):
+    """a binned scene (k_raster_rows / k_raster_rows_rl): 24 x 24 boxes under three point lights, Linear sampling"""
+    cfg = scenes.box_grid_scene(api, n=24, width=480, height=270)
+    for pos, col in (((1.0, 1.5, 1.0), (1.0, 0.8, 0.6)), ((3.5, 1.0, 2.5), (0.4, 0.9, 1.0)), ((2.4, 0.8, 4.0), (0.9, 0.9, 0.3))):
+        cfg.scene.add_dynamic_light(B.Light(B.LIGHT_POINT).with_position(pos).with_color(col).with_intensity(1.5)
+                                    .with_start_distance(0.5).with_end_distance(4.0).compile())
+    return cfg
+
+
+def chunk_level_map(api):
+    """the map scene with the grid shader as its background: feature level 1 (k_raster_chunk / k_raster_chunk_rl)"""
+    cfg = scenes.map_scene(api, width=400, height=240, logo_size=64, n_lights=5)
+    cfg.scene.background(api.GridShader())
+    return cfg
+
+
+def mixed_light_types(api):
+    """point lights next to spot / area / daylight lights (which keep the exact arithmetic in both modes) and a flickering one"""
+    cfg = scenes.map_scene(api, width=320, height=180, logo_size=64, n_lights=2)
+    cfg.scene.lights([
+        B.Light(B.LIGHT_AMBIENT).with_color((0.1, 0.2, 0.1)).with_intensity(0.5).compile(),
+        _light(B.LIGHT_AREA, (3.0, 1.0, 12.0), normal=(0.0, 0.0, -1.0), end=6.0, start=1.0, intensity=1.5, width=2.0, height=1.0),
+        _light(B.LIGHT_DAYLIGHT, (7.0, 3.0, 10.0), normal=(0.0, -1.0, 0.0), end=12.0, start=2.0, intensity=0.8),
+    ])
+    cfg.scene.add_dynamic_light(B.Light(B.LIGHT_POINT).with_position((2.0, 1.0, 6.0)).with_color((0.9, 0.3, 0.2)).with_intensity(1.2)
+                                .with_start_distance(1.0).with_end_distance(5.0).with_flicker(0.5).compile())
+    # start == end: the smoothstep's denominator is zero (never evaluated: a fragment is either in full range or out of it)
+    cfg.scene.add_dynamic_light(B.Light(B.LIGHT_POINT).with_position((11.0, 1.0, 4.0)).with_color((0.2, 0.6, 0.9)).with_intensity(0.8)
+                                .with_start_distance(3.0).with_end_distance(3.0).compile())
+    return cfg
+
+
+SCENES = {
+    "map, 1 light": lambda api: scenes.map_scene(api, width=640, height=360, logo_size=128, n_lights=1),
+    "map, 16 lights": lambda api: scenes.map_scene(api, width=640, height=360, logo_size=128, n_lights=16),
+    "map, 4 lights, Linear": lambda api: scenes.map_scene(api, width=400, height=240, logo_size=128, n_lights=4, sample_mode=B.SAMPLE_LINEAR),
+    "teapot with a point light": lambda api: scenes.teapot_scene(api, width=480, height=270, with_light=True, logo_size=64),
+    "lit box grid (binned, row mode)": lit_box_grid,
+    "map behind the grid background (feature level 1)": chunk_level_map,
+    "mixed light types": mixed_light_types,
+}
+
+
+@pytest.mark.parametrize("name", list(SCENES))
+def test_both_modes_against_the_oracle(oracle, product, light_math, name):
+    build = SCENES[name]
+    ref = scenes.render(build(oracle)).copy()
+    light_math(True)
+    exact = scenes.render(build(product)).copy()
+    light_math(False)
+    relaxed = scenes.render(build(product)).copy()
+    n = ref.shape[0] * ref.shape[1]
+    lit_pixels = int((ref[..., :3].max(axis=2) > 0).sum())
+    assert lit_pixels > n // 10, f"{name}: the scene shows nothing"
+    d_exact, d_relaxed, d_modes = channel_diff(exact, ref), channel_diff(relaxed, ref), channel_diff(relaxed, exact)
+    assert int(d_exact.max()) <= TOLERANCE and int(d_relaxed.max()) <= TOLERANCE and int(d_modes.max()) <= TOLERANCE, \
+        f"{name}: max channel difference exact {int(d_exact.max())}, relaxed {int(d_relaxed.max())}, between the modes {int(d_modes.max())}"
+    # exact: only libm differences (pow32_fast's log2f / exp2f); relaxed: a rounding boundary has to be within ~1e-6 of the value
+    assert int((d_exact > 0).sum()) <= 2 + n // 50_000, f"{name}: exact mode, {int((d_exact > 0).sum())} of {n} pixels differ from the oracle"
+    assert int((d_relaxed > 0).sum()) <= 4 + n // 2_000, f"{name}: relaxed mode, {int((d_relaxed > 0).sum())} of {n} pixels differ from the oracle"
+    # alpha, coverage and depth are untouched by the mode
+    assert np.array_equal(relaxed[..., 3], exact[..., 3])
+
+
+def test_frames_without_a_3d_light_loop_do_not_depend_on_the_mode(oracle, product, light_math):
+    builders = {
+        "unlit textured cube": lambda api: scenes.cube_scene(api, width=320, height=240, tile_size=40, textured=True, distance=3.0, logo_size=64, rect_size=40.0),
+        "teapot, ambient only": lambda api: scenes.teapot_scene(api, width=320, height=180, logo_size=64, rect_size=40.0),
+        "2D with 2D lights": lambda api: scene_2d(api, lights=True),
+    }
+    for what, build in builders.items():
+        ref = scenes.render(build(oracle)).copy()
+        light_math(True)
+        exact = scenes.render(build(product)).copy()
+        light_math(False)
+        relaxed = scenes.render(build(product)).copy()
+        assert_exact(relaxed, exact, f"{what}: relaxed vs exact")
+        assert_exact(exact, ref, f"{what}: vs the oracle")
+
+
+def test_the_environment_overrides_the_context_mode(product, light_math, monkeypatch):
+    build = SCENES["map, 16 lights"]
+    light_math(True)
+    exact = scenes.render(build(product)).copy()
+    light_math(False)
+    relaxed = scenes.render(build(product)).copy()
+    monkeypatch.setenv("RXR_LIGHT_MATH", "exact")   # context: relaxed
+    assert_exact(scenes.render(build(product)).copy(), exact, "RXR_LIGHT_MATH=exact over a relaxed context")
+    light_math(True)
+    monkeypatch.setenv("RXR_LIGHT_MATH", "relaxed")  # context: exact
+    assert_exact(scenes.render(build(product)).copy(), relaxed, "RXR_LIGHT_MATH=relaxed over an exact context")
+
+
+def test_the_bench_frame_in_both_modes(oracle, product, light_math):
+    """BASELINE.json configs[3] at full size: the relaxed kernel really is another computation (some pixels differ from the exact
+    frame), and stays inside the tolerance with a few dozen pixels off"""
+    kw = dict(width=3840, height=2160, n_lights=16)
+    ref = scenes.render(scenes.map_scene(oracle, **kw)).copy()
+    light_math(True)
+    exact = scenes.render(scenes.map_scene(product, **kw)).copy()
+    light_math(False)
+    relaxed = scenes.render(scenes.map_scene(product, **kw)).copy()
+    d_exact, d_relaxed, d_modes = channel_diff(exact, ref), channel_diff(relaxed, ref), channel_diff(relaxed, exact)
+    assert int(d_exact.max()) <= TOLERANCE and int((d_exact > 0).sum()) <= 16
+    assert int(d_relaxed.max()) <= TOLERANCE and int((d_relaxed > 0).sum()) <= 256
+    assert 0 < int((d_modes > 0).sum()) <= 256 and int(d_modes.max()) <= TOLERANCE
+
+
+def test_an_unknown_mode_is_refused(product):
+    rxr = rusterix_amd.rxr_abi()
+    ctx = product.lib.rxh_context()
+    assert ctx, product.lib.rxh_last_error()
+    assert rxr.rxr_set_light_math(ctx, 7) == B.RXR_ERR_INVALID
+    assert b"rxr_set_light_math" in rxr.rxr_last_error(ctx)
+    assert rxr.rxr_set_light_math(None, 0) == B.RXR_ERR_INVALID
+    assert rxr.rxr_set_light_math(ctx, 1) == 0  # RXR_LIGHT_MATH_RELAXED, the default
+
+
+def test_members_of_a_multi_device_context_use_the_mode(product, light_math):
+    """three logical members on GPU 0: the frame is the single-context frame of the same mode, stripe for stripe"""
+    build = SCENES["map, 16 lights"]
+    frames = {}
+    for exact in (True, False):
+        light_math(exact)
+        product.lib.rxh_set_device(0)
+        frames[exact] = scenes.render(build(product)).copy()
+    try:
+        ids = (C.c_int * 3)(0, 0, 0)
+        for exact in (True, False):
+            product.lib.rxh_set_devices(ids, 3)
+            light_math(exact)
+            assert_exact(scenes.render(build(product)).copy(), frames[exact], f"3 members, exact={exact}")
+    finally:
+        product.lib.rxh_set_device(0)

@@ -43,7 +43,7 @@ def test_host_library_exports_builder_api():
     for sym in ["rxh_rasterizer_rasterize", "rxh_rasterizer_upload", "rxh_context", "rxh_set_device", "rxh_last_error", "rxh_scene_project",
                 "rxh_scene_add_program", "rxh_assets_set_patterns", "rxh_assets_set_palette", "rxh_chunk_set_terrain",
                 "rxh_chunk_set_terrain_batch2d", "rxh_chunk_add_shader_texture", "rxh_set_device_projection", "rxh_rasterizer_brush_preview",
-                "rxh_scene_set_background_grid"]:
+                "rxh_scene_set_background_grid", "rxh_set_light_math_exact", "rxh_get_light_math_exact"]:
         assert hasattr(api.lib, sym), sym
 
 

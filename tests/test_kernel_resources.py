@@ -39,20 +39,30 @@ def descriptor(isa, name, key):
     return int(re.search(rf"\.amdhsa_{key} (\d+)", m.group(1)).group(1))
 
 
-def test_k_raster_keeps_its_registers(isa):
-    assert descriptor(isa, "k_raster", "next_free_vgpr") <= 64          # 8 waves per SIMD
-    assert descriptor(isa, "k_raster", "private_segment_fixed_size") <= 16
-    spills = len(re.findall(r"v_(?:writelane|readlane)_b32", kernel_body(isa, "k_raster")))
+@pytest.mark.parametrize("k_raster", ["k_raster", "k_raster_rl"])  # (_rl: the relaxed light loop, RXR_LIGHT_MATH / rxr_set_light_math)
+def test_k_raster_keeps_its_registers(isa, k_raster):
+    assert descriptor(isa, k_raster, "next_free_vgpr") <= 64          # 8 waves per SIMD
+    assert descriptor(isa, k_raster, "private_segment_fixed_size") <= 16
+    spills = len(re.findall(r"v_(?:writelane|readlane)_b32", kernel_body(isa, k_raster)))
     # 17 with the parameter block read in place, 369 by value; 85 since the light records live in SGPRs (scalar loads through the
     # constant address space, 22 dwords per light): 55 of them outside every loop, none inside the 3D light loop
-    assert spills <= 100, f"{spills} SGPR spill / reload instructions in k_raster"
-    assert "v_pk_fma_f32" not in kernel_body(isa, "k_raster"), "packed f32 (SLP vectorisation) is slower on gfx950: build with -fno-slp-vectorize"
+    assert spills <= 100, f"{spills} SGPR spill / reload instructions in {k_raster}"
+    assert "v_pk_fma_f32" not in kernel_body(isa, k_raster), "packed f32 (SLP vectorisation) is slower on gfx950: build with -fno-slp-vectorize"
 
 
-def test_k_raster_rows_keeps_its_occupancy(isa):
-    assert descriptor(isa, "k_raster_rows", "next_free_vgpr") <= 64     # 8 waves per SIMD
-    assert descriptor(isa, "k_raster_rows", "private_segment_fixed_size") <= 64
-    assert descriptor(isa, "k_raster_rows", "group_segment_fixed_size") <= 20 * 1024   # 8 workgroups per CU in 160 KB
+def test_the_relaxed_light_loop_is_the_shorter_one(isa):
+    """k_raster_rl differs from k_raster in the 3D light loop only: two v_rsq_f32 normalisations instead of the exact sequences"""
+    exact, relaxed = kernel_body(isa, "k_raster"), kernel_body(isa, "k_raster_rl")
+    valu = lambda body: len(re.findall(r"^\s+v_", body, flags=re.M))
+    assert valu(relaxed) < valu(exact) - 40, (valu(exact), valu(relaxed))
+    assert relaxed.count("v_rsq_f32") >= 2
+
+
+@pytest.mark.parametrize("k_raster_rows", ["k_raster_rows", "k_raster_rows_rl"])
+def test_k_raster_rows_keeps_its_occupancy(isa, k_raster_rows):
+    assert descriptor(isa, k_raster_rows, "next_free_vgpr") <= 64     # 8 waves per SIMD
+    assert descriptor(isa, k_raster_rows, "private_segment_fixed_size") <= 64
+    assert descriptor(isa, k_raster_rows, "group_segment_fixed_size") <= 20 * 1024   # 8 workgroups per CU in 160 KB
 
 
 def test_row_mode_uses_the_lds_atomic(isa):
