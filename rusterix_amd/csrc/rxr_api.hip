@@ -1153,6 +1153,11 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
         // tolerance of lit 3D fragments (shade3d_lights<X, true>; feature levels 0 and 1)
         const char *lm = getenv("RXR_LIGHT_MATH");
         P.relaxed_lights = lm ? (lm[0] == 'r' ? 1u : 0u) : (ctx->relaxed_lights ? 1u : 0u);
+        P.rl_flip_guard = 1e-4f;
+        if (const char *fg = getenv("RXR_RL_FLIP_GUARD")) {  // tests: a large guard sends every wave down the exact normal sequences
+            const float v = (float)atof(fg);
+            if (v >= 1e-4f) P.rl_flip_guard = v;
+        }
     }
     if (P.kernel_level == 2u && uses_programs && ctx->programs_static) P.kernel_level = 3u;  // k_raster_vm_s: wave-uniform stack pointer
     // k_raster_vm_sv: ... and no program decides whether an opaque fragment is written, so the visibility loop is the one of

@@ -548,7 +548,12 @@ struct Frag {
 };
 
 // everything before the light loop: uv, world position, normal, texel, ambient terms (:1062-1370)
-template <int X>
+// RL (relaxed light mode, frames with a 3D light loop only): the view direction and the surface normal feed nothing but the lit
+// colour, so they are normalised with one v_rsq_f32 each (within 2 ulp per component) and the reference's second normalisation of
+// the already-unit normal (:1320) is skipped.  The one DECISION they take part in -- flip the normal toward the camera when
+// n.v < 0 (:1096) -- is only taken from the relaxed values when every fragment of the wave has |n.v| >= 1e-4, a hundred times
+// their error; otherwise, and for magnitudes outside the window, the wave takes the exact sequences.
+template <int X, bool RL = false>
 __device__ __forceinline__ void shade3d_begin(const RasterParams &P, const TriShade &S, uint32_t batch_id, float alpha, float beta,
                                               float z, float fx, float fy, Frag &F) {
     const DevBatch &B = P.batches3d[batch_id];
@@ -568,15 +573,35 @@ __device__ __forceinline__ void shade3d_begin(const RasterParams &P, const TriSh
     mat4_mul(P.inv_view, vx, vy, vz, vw, wx, wy, wz, ww);
     f3 world = mk3(wx, wy, wz);
     f3 cam = mk3(P.cam[0], P.cam[1], P.cam[2]);
-    f3 view_dir = norm3_fast(sub3(cam, world));
-
-    f3 normal;
-    if (B.flags & DB_HAS_NORMALS) {  // :1083-1099
-        f3 n0 = mk3(S.n0[0], S.n0[1], S.n0[2]), n1 = mk3(S.n1[0], S.n1[1], S.n1[2]), n2 = mk3(S.n2[0], S.n2[1], S.n2[2]);
-        normal = norm3_z(add3(add3(scale3(n0, alpha), scale3(n1, beta)), scale3(n2, gamma)));
-        if (dot3(normal, view_dir) < 0.0f) normal = neg3(normal);
-    } else {
-        normal = mk3(0.0f, 0.0f, 0.0f);
+    f3 view_dir, normal;
+    bool relaxed_normals = false;  // wave-uniform
+    if constexpr (RL && X < 2) {
+        const bool has_n = (B.flags & DB_HAS_NORMALS) != 0u;
+        const f3 vd = sub3(cam, world);
+        f3 ni = mk3(0.0f, 0.0f, 0.0f);
+        if (has_n) {
+            f3 n0 = mk3(S.n0[0], S.n0[1], S.n0[2]), n1 = mk3(S.n1[0], S.n1[1], S.n1[2]), n2 = mk3(S.n2[0], S.n2[1], S.n2[2]);
+            ni = add3(add3(scale3(n0, alpha), scale3(n1, beta)), scale3(n2, gamma));
+        }
+        const float vm2 = fmaf(vd.z, vd.z, fmaf(vd.y, vd.y, vd.x * vd.x)), nm2 = fmaf(ni.z, ni.z, fmaf(ni.y, ni.y, ni.x * ni.x));
+        const float vinv = __builtin_amdgcn_rsqf(vm2), ninv = __builtin_amdgcn_rsqf(nm2);
+        const float dnv = fmaf(ni.z, vd.z, fmaf(ni.y, vd.y, ni.x * vd.x)) * (vinv * ninv);
+        relaxed_normals = rxm::wave_all(rxm::sq_in_window(vm2) && (!has_n || (rxm::sq_in_window(nm2) && __builtin_fabsf(dnv) >= P.rl_flip_guard)));
+        if (relaxed_normals) {
+            view_dir = scale3(vd, vinv);
+            // (no normals: the reference normalises the zero vector, 0 / 0)
+            normal = has_n ? scale3(ni, dnv < 0.0f ? -ninv : ninv) : mk3(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
+        }
+    }
+    if (!relaxed_normals) {
+        view_dir = norm3_fast(sub3(cam, world));
+        if (B.flags & DB_HAS_NORMALS) {  // :1083-1099
+            f3 n0 = mk3(S.n0[0], S.n0[1], S.n0[2]), n1 = mk3(S.n1[0], S.n1[1], S.n1[2]), n2 = mk3(S.n2[0], S.n2[1], S.n2[2]);
+            normal = norm3_z(add3(add3(scale3(n0, alpha), scale3(n1, beta)), scale3(n2, gamma)));
+            if (dot3(normal, view_dir) < 0.0f) normal = neg3(normal);
+        } else {
+            normal = mk3(0.0f, 0.0f, 0.0f);
+        }
     }
 
     uint32_t texel = batch_texel<X>(P, B, u, v, world.x, world.z, &world);
@@ -618,7 +643,7 @@ __device__ __forceinline__ void shade3d_begin(const RasterParams &P, const TriSh
         }
     }
 
-    normal = norm3_z(normal);  // :1320
+    if (!relaxed_normals) normal = norm3_z(normal);  // :1320
 
     f3 lit = mk3(0.0f, 0.0f, 0.0f);
     float occlusion;
@@ -677,6 +702,18 @@ __device__ __forceinline__ void shade3d_lights(const RasterParams &P, bool hit, 
     const bool can_cull = __ballot(hit && !(r < __builtin_huge_valf())) == 0ull;  // (INFINITY, without <cmath>: hiprtc)
     const float rmax = wave_max(r);
     const float rough = (X >= 2) ? F.rough : 0.5f, metal = (X >= 2) ? F.metal : 0.0f;
+    // relaxed mode: the light-independent factors of shade_fast_brdf (:1875-1951) once per fragment -- diffuse weight kd, Fresnel
+    // term f, shininess -- by the reference's own operations
+    f3 rl_kd = mk3(0.0f, 0.0f, 0.0f), rl_f = rl_kd;
+    float rl_shininess = 1.0f;
+    if constexpr (RL) {
+        const float tm = rclamp(metal, 0.0f, 1.0f);
+        const f3 f0 = mk3(fmaf(tm, F.base.x - 0.04f, 0.04f), fmaf(tm, F.base.y - 0.04f, 0.04f), fmaf(tm, F.base.z - 0.04f, 0.04f));
+        rl_kd = scale3(scale3(F.base, 1.0f - metal), 1.0f - fmaxf(f0.x, fmaxf(f0.y, f0.z)));
+        rl_shininess = rclamp(2.0f / fmaxf(rough * rough, 1e-4f) - 2.0f, 1.0f, 2048.0f);
+        const float om = 1.0f - rclamp(fmaxf(dot3(F.normal, F.view_dir), 0.0f), 0.0f, 1.0f);
+        rl_f = add3(f0, scale3(sub3(mk3(1.0f, 1.0f, 1.0f), f0), om * om * om * om * om));
+    }
 
     for (uint32_t base_i = 0; base_i < P.n_lights; base_i += 64u) {
         const uint32_t mine = base_i + (uint32_t)lane;
@@ -717,17 +754,46 @@ __device__ __forceinline__ void shade3d_lights(const RasterParams &P, bool hit, 
                 // (lp - world).normalized(): |world - lp| and |lp - world| are the same float
                 if (!L.emitting) continue;
                 f3 d = sub3(lp, F.world);
+                if constexpr (RL) {
+                    // The whole point-light term in relaxed arithmetic: fused multiply-adds, one v_rsq_f32 per normalisation, the
+                    // half vector never normalised (n.h = n.(l + v) * rsq(|l + v|^2)), and the scalar factors gathered before they
+                    // meet the colour:  lit += (kd + f * spec) * (colour * flicker) * (intensity * (n.l)^2).  Every operand stays
+                    // within a few ulp of the reference's; a fragment outside the range, behind the light (n.l = 0) or without a
+                    // specular lobe contributes exactly what it contributes there: nothing.  Magnitudes outside the window (zero,
+                    // denormal, infinite, NaN) leave through the exact path below.
+                    const float m2 = fmaf(d.z, d.z, fmaf(d.y, d.y, d.x * d.x));
+                    if (rxm::wave_all(rxm::sq_in_window(m2)) && (ss_fast || L.start_distance == L.end_distance)) {
+                        const float inv = __builtin_amdgcn_rsqf(m2);
+                        const float distance = m2 * inv;
+                        if (distance >= L.end_distance) continue;
+                        float intensity = L.intensity;
+                        if (!(distance <= L.start_distance)) {
+                            const float t = __builtin_amdgcn_fmed3f((distance - L.end_distance) * ss_r, 0.0f, 1.0f);  // (finite: no NaN to keep)
+                            intensity = L.intensity * (t * t * fmaf(-2.0f, t, 3.0f));
+                        }
+                        const f3 l = scale3(d, inv);
+                        const float ndl = fmaxf(fmaf(F.normal.z, l.z, fmaf(F.normal.y, l.y, F.normal.x * l.x)), 0.0f);
+                        const f3 hu = add3(l, F.view_dir);
+                        const float hh = fmaf(hu.z, hu.z, fmaf(hu.y, hu.y, hu.x * hu.x));  // 0 (l = -v: n.h = NaN -> 0 below) or >= 1e-15
+                        const float ndh = fmaxf(fmaf(F.normal.z, hu.z, fmaf(F.normal.y, hu.y, F.normal.x * hu.x)) * __builtin_amdgcn_rsqf(hh), 0.0f);
+                        const float spec = __builtin_amdgcn_exp2f(rl_shininess * __builtin_amdgcn_logf(ndh));  // (0 for n.h = 0)
+                        const f3 cf = apply_flicker(L, 1.0f, P.hash_anim);  // wave-uniform
+                        const float s = intensity * ndl * ndl;
+                        F.lit.x = fmaf(fmaf(rl_f.x, spec, rl_kd.x), cf.x * s, F.lit.x);
+                        F.lit.y = fmaf(fmaf(rl_f.y, spec, rl_kd.y), cf.y * s, F.lit.y);
+                        F.lit.z = fmaf(fmaf(rl_f.z, spec, rl_kd.z), cf.z * s, F.lit.z);
+                        continue;
+                    }
+                }
                 float distance;
-                if constexpr (RL) ldir = norm3_relaxed(d, distance);
-                else ldir = norm3_fast(d, distance);
+                ldir = norm3_fast(d, distance);
                 if (distance >= L.end_distance) continue;
                 float intensity = L.intensity;
                 if (!(distance <= L.start_distance)) {
                     // smoothstep_rs(end, start, distance) with the shared reciprocal
                     const float sn = distance - L.end_distance, sd = L.start_distance - L.end_distance;
                     float q;
-                    if (RL && ss_fast) q = sn * ss_r;  // (|sn| < |sd| here: the product cannot leave the window upwards; below it, q -> 0 = t)
-                    else if (ss_fast && rxm::wave_all(rxm::in_window(sn))) q = rxm::div_chain(sn, sd, ss_r);
+                    if (ss_fast && rxm::wave_all(rxm::in_window(sn))) q = rxm::div_chain(sn, sd, ss_r);
                     else q = sn / sd;
                     const float t = rclamp(q, 0.0f, 1.0f);
                     intensity = L.intensity * (t * t * (3.0f - 2.0f * t));
@@ -751,12 +817,17 @@ __device__ __forceinline__ void shade3d_lights(const RasterParams &P, bool hit, 
 
 // encode (:1394-1404).  `lit += mat_emissive` (:1394): below feature level 2 no program runs and emissive is 0 -- adding it cannot
 // change the encoded byte (x + 0 == x except -0 + 0 == +0, and both encode to 0)
-template <int X>
+template <int X, bool RL = false>
 __device__ __forceinline__ uint32_t shade3d_end(const Frag &F) {
     f3 lit = F.lit;
 #if RXR_VM_EMISSIVE
     if constexpr (X >= 2) lit = add3(lit, F.emis);
 #endif
+    if constexpr (RL) {  // linear_to_srgb_fast (:26-33) with v_sqrt_f32 (1 ulp) for the correctly rounded root
+        const float sx = __builtin_amdgcn_sqrtf(lit.x), sy = __builtin_amdgcn_sqrtf(lit.y), sz = __builtin_amdgcn_sqrtf(lit.z);
+        return pack4(f32_to_u8_saturated(1.055f * sx - 0.055f * sx * sx), f32_to_u8_saturated(1.055f * sy - 0.055f * sy * sy),
+                     f32_to_u8_saturated(1.055f * sz - 0.055f * sz * sz), f32_to_u8_saturated(F.opacity));
+    }
     return pack4(f32_to_u8_saturated(linear_to_srgb_fast(lit.x)), f32_to_u8_saturated(linear_to_srgb_fast(lit.y)),
                  f32_to_u8_saturated(linear_to_srgb_fast(lit.z)), f32_to_u8_saturated(F.opacity));
 }
@@ -2364,12 +2435,12 @@ __device__ __forceinline__ void raster_tile(const RasterParams &P) {
         if (hit) {
             if constexpr (FUSED) HS = shade_store.s.shade[vis.slot];
             else if (!ROWS || hs_of != vis.best) HS = P.tri_shade[vis.best];
-            shade3d_begin<X>(P, HS, vis.batch, vis.alpha, vis.beta, vis.zmin, fx, fy, F);
+            shade3d_begin<X, RL>(P, HS, vis.batch, vis.alpha, vis.beta, vis.zmin, fx, fy, F);
         }
         PHASE_MARK(2);
         if (P.n_lights) shade3d_lights<X, RL>(P, hit, F);  // wave-uniform call
         PHASE_MARK(3);
-        color = hit ? shade3d_end<X>(F) : pack4(0u, 0u, 0u, 255u);
+        color = hit ? shade3d_end<X, RL>(F) : pack4(0u, 0u, 0u, 255u);
         if constexpr (lvl1<X>) {
             if (P.has_brush && !hit) color = miss_brush_preview(P, px, py);  // :435-458
         }

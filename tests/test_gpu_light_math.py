@@ -122,6 +122,24 @@ def test_frames_without_a_3d_light_loop_do_not_depend_on_the_mode(oracle, produc
         assert_exact(exact, ref, f"{what}: vs the oracle")
 
 
+@pytest.mark.parametrize("name", ["map, 16 lights", "lit box grid (binned, row mode)", "map behind the grid background (feature level 1)"])
+def test_the_exact_normal_sequences_inside_the_relaxed_kernels(oracle, product, light_math, monkeypatch, name):
+    """the relaxed kernels decide the normal's flip toward the camera from relaxed values only where |n.v| >= the guard (1e-4); a
+    guard of 0.99 (RXR_RL_FLIP_GUARD, a test knob) sends practically every wave down the fallback -- the exact normalisations
+    followed by the fused light term -- which must stay inside the same bars"""
+    build = SCENES[name]
+    ref = scenes.render(build(oracle)).copy()
+    light_math(False)
+    relaxed = scenes.render(build(product)).copy()
+    monkeypatch.setenv("RXR_RL_FLIP_GUARD", "0.99")
+    guarded = scenes.render(build(product)).copy()
+    n = ref.shape[0] * ref.shape[1]
+    d_ref, d_modes = channel_diff(guarded, ref), channel_diff(guarded, relaxed)
+    assert int(d_ref.max()) <= TOLERANCE and int(d_modes.max()) <= TOLERANCE
+    assert int((d_ref > 0).sum()) <= 4 + n // 2_000, f"{name}: {int((d_ref > 0).sum())} of {n} pixels differ from the oracle"
+    assert np.array_equal(guarded[..., 3], relaxed[..., 3])
+
+
 def test_the_environment_overrides_the_context_mode(product, light_math, monkeypatch):
     build = SCENES["map, 16 lights"]
     light_math(True)
