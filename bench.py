@@ -50,14 +50,14 @@ PROFILES = {
     "relaxed": {
         "source": "profiles/r02/bench_relaxed_pmc_summary.json (tools/profile_bench.sh; rocprofv3 --pmc, separate passes; kernel k_raster_rl)",
         "write_bytes": 33177600,       # WRITE_SIZE: exactly the framebuffer (3840 * 2160 * 4)
-        "fetch_bytes_x2": 2138097,     # FETCH_SIZE with the gfx950 x2 correction
-        "valu_wave_instructions": 124593189,
+        "fetch_bytes_x2": 2193990,     # FETCH_SIZE with the gfx950 x2 correction
+        "valu_wave_instructions": 94162981,
     },
     "exact": {
-        "source": "profiles/r02/bench_exact_pmc_summary.json (RXR_LIGHT_MATH=exact tools/profile_bench.sh; kernel k_raster)",
+        "source": "profiles/r02/bench_relaxed_pmc_summary.json (the same passes: bench.py times the exact mode as well; kernel k_raster)",
         "write_bytes": 33177600,
-        "fetch_bytes_x2": 2182024,
-        "valu_wave_instructions": 151319560,
+        "fetch_bytes_x2": 2185971,
+        "valu_wave_instructions": 148910581,
     },
 }
 
@@ -327,7 +327,7 @@ def main():
                 "resolution": [W, H],
                 "triangles_3d": n_tris,
                 # arithmetic of the 3D light loop (rxr_set_light_math): "relaxed" = the library's default, point lights within
-                # BASELINE.json's 1-per-channel tolerance for lit 3D fragments (tests/test_gpu_light_math.py: 43 of 8 294 400
+                # BASELINE.json's 1-per-channel tolerance for lit 3D fragments (tests/test_gpu_light_math.py: 112 of 8 294 400
                 # pixels of this frame differ from the CPU oracle, each by 1); "exact" = correctly rounded throughout
                 "light_math": "relaxed" if relaxed else "exact",
                 "sharding": "single GPU" if world == 1 else f"interleaved 16-row stripes over {world} GPUs (one process per GPU) + RCCL {args.exchange} "

@@ -429,14 +429,16 @@ int rxr_check_shaders(const rxr_shader_set *set, uint32_t *code_words, char *mes
 
 /* Arithmetic of the 3D direct-light loop (src/rasterizer.rs:1373-1391 with CompiledLight::radiance_at, src/map/light.rs:491-552,
  * and shade_fast_brdf, :1875-1951), applied from the next rxr_upload_frame on:
- *   RXR_LIGHT_MATH_RELAXED (the default)  point lights normalise their direction and the half vector with one v_rsq_f32 and divide
- *       the smoothstep by a reciprocal: every operand within 2 ulp of the reference's correctly rounded value.  Every quantity
+ *   RXR_LIGHT_MATH_RELAXED (the default)  in frames with a 3D light loop, point lights are one fused term (fused multiply-adds,
+ *       v_rsq_f32 normalisations, the smoothstep divided by a reciprocal), view direction, normal and -- without occluders -- the
+ *       world position go through reciprocals, the encode through v_sqrt_f32: every operand within a few ulp of the reference's
+ *       correctly rounded value.  Every quantity
  *       of that path is continuous in the fragment's position (range test, smoothstep, Lambert and specular cut-offs all meet
  *       zero), so a channel moves by at most one 8-bit step -- the tolerance BASELINE.json states for lit 3D fragments; measured:
- *       43 of 8 294 400 pixels of the bench frame differ from the oracle, each by 1.  Spot / area / daylight lights (hard
+ *       112 of 8 294 400 pixels of the bench frame differ from the oracle, each by 1.  Spot / area / daylight lights (hard
  *       cut-offs), unlit frames, 2D frames and frames that run Rusteria programs are computed exactly in both modes.
  *   RXR_LIGHT_MATH_EXACT  the reference's operations, correctly rounded, throughout (bit-identical to the CPU oracle up to the
- *       libm-dependent pow; 15-18 % slower on the bench frame).
+ *       libm-dependent pow; 35 % slower on the bench frame).
  * The environment variable RXR_LIGHT_MATH=exact|relaxed, when set, overrides the context's mode (read at every upload).
  * RXR_ERR_INVALID for another mode.  On a multi-device context: every member.  Nothing in the reference corresponds to it. */
 #define RXR_LIGHT_MATH_EXACT 0

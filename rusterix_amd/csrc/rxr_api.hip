@@ -1121,6 +1121,7 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
     P.n_batches3d = n_b3;
     P.n_lights = f->n_lights;
     P.n_occluders = f->n_occluders;
+    P.any_occluders = n_occ_total ? 1u : 0u;
     P.n_linedefs = f->n_linedefs;
     P.n_prims2d = (uint32_t)p2cur;
     P.binned2d = binned2d ? 1u : 0u;

@@ -226,6 +226,7 @@ struct RasterParams {
     uint32_t plain_programs;       // host only: the frame runs programs but needs none of level 1's chunk paths (k_raster_vm_p instead of k_raster_vm_sv)
     uint32_t relaxed_lights;       // host only: RXR_LIGHT_MATH=relaxed -- feature levels 0 and 1 launch the kernels whose 3D light loop uses the
                                    // relaxed arithmetic (k_raster_rl, k_raster_rows_rl, k_raster_chunk_rl; shade3d_lights<X, true>)
+    uint32_t any_occluders;        // the frame has an occluder somewhere (mapmini's or a chunk's): get_occlusion compares world positions with their boxes
     float rl_flip_guard;           // relaxed light mode: the smallest |n.v| for which the normal's flip toward the camera is decided from the
                                    // relaxed values (shade3d_begin; 1e-4, a hundred times their error; RXR_RL_FLIP_GUARD for tests)
     uint32_t *host_status;         // pinned host words (device-visible), indexed like the counters: [CNT_ENTRIES], [CNT_OVERFLOW]

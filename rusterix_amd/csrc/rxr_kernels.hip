@@ -139,6 +139,8 @@ __device__ __forceinline__ f3 neg3(f3 a) { return f3{-a.x, -a.y, -a.z}; }
 __device__ __forceinline__ float dot3(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 __device__ __forceinline__ float mag3(f3 a) { return sqrtf(dot3(a, a)); }
 __device__ __forceinline__ f3 norm3(f3 a) { return div3(a, mag3(a)); }
+// |a| within 1 ulp (v_sqrt_f32), for BOUNDS only: the light culling's sphere radii, whose test carries a relative margin of 1e-3
+__device__ __forceinline__ float mag3_bound(f3 a) { return __builtin_amdgcn_sqrtf(dot3(a, a)); }
 // same values through the shared-reciprocal sequences of rxr_exact_math.h (bit-identical; cheaper
 // unless a component is exactly zero, which sends the wave down the plain path)
 __device__ __forceinline__ f3 norm3_fast(f3 a, float &mag) {
@@ -564,11 +566,28 @@ __device__ __forceinline__ void shade3d_begin(const RasterParams &P, const TriSh
     // screen_to_world (rasterizer.rs:1707-1727)
     // fx, fy are pixel centres (0.5 .. 2^15) and the frame size is validated by rxr_upload_frame
     // (1 .. 32768): always inside the division window
-    float x_ndc = 2.0f * rxm::div1_known(fx, P.fwidth, true) - 1.0f;
-    float y_ndc = 1.0f - 2.0f * rxm::div1_known(fy, P.fheight, true);
-    float vx, vy, vz, vw;
-    mat4_mul(P.inv_proj, x_ndc, y_ndc, z, 1.0f, vx, vy, vz, vw);
-    rxm::div3_self(vx, vy, vz, vw, vx, vy, vz, vw);
+    float x_ndc, y_ndc, vx, vy, vz, vw;
+    // relaxed mode, level 0, no occluder anywhere: the world position feeds only the light loop and the view direction -- continuous
+    // uses -- so its three divisions (pixel / frame size, the perspective divide) become reciprocal products (within 2 ulp).  With
+    // an occluder in the frame its boxes are compared with the position (get_occlusion): the exact quotients then.
+    const bool relaxed_world = RL && X == 0 && !P.any_occluders;  // wave-uniform
+    if (relaxed_world) {
+        x_ndc = fmaf(fx, 2.0f * __builtin_amdgcn_rcpf(P.fwidth), -1.0f);
+        y_ndc = fmaf(fy, -2.0f * __builtin_amdgcn_rcpf(P.fheight), 1.0f);
+        mat4_mul(P.inv_proj, x_ndc, y_ndc, z, 1.0f, vx, vy, vz, vw);
+        if (rxm::wave_all(rxm::in_window(vw))) {
+            const float rw = __builtin_amdgcn_rcpf(vw);
+            vx *= rw;
+            vy *= rw;
+            vz *= rw;
+            vw = 1.0f;
+        } else rxm::div3_self(vx, vy, vz, vw, vx, vy, vz, vw);
+    } else {
+        x_ndc = 2.0f * rxm::div1_known(fx, P.fwidth, true) - 1.0f;
+        y_ndc = 1.0f - 2.0f * rxm::div1_known(fy, P.fheight, true);
+        mat4_mul(P.inv_proj, x_ndc, y_ndc, z, 1.0f, vx, vy, vz, vw);
+        rxm::div3_self(vx, vy, vz, vw, vx, vy, vz, vw);
+    }
     float wx, wy, wz, ww;
     mat4_mul(P.inv_view, vx, vy, vz, vw, wx, wy, wz, ww);
     f3 world = mk3(wx, wy, wz);
@@ -697,7 +716,7 @@ __device__ __forceinline__ void shade3d_lights(const RasterParams &P, bool hit, 
     const int lane = (int)(threadIdx.x & 63u);
     const int src = __ffsll((long long)hitmask) - 1;
     const f3 c = mk3(__shfl(F.world.x, src, 64), __shfl(F.world.y, src, 64), __shfl(F.world.z, src, 64));
-    const float r = hit ? mag3(sub3(F.world, c)) : 0.0f;
+    const float r = hit ? mag3_bound(sub3(F.world, c)) : 0.0f;
     // NaN / inf world positions are not bounded by the sphere: no culling for this wave then
     const bool can_cull = __ballot(hit && !(r < __builtin_huge_valf())) == 0ull;  // (INFINITY, without <cmath>: hiprtc)
     const float rmax = wave_max(r);
@@ -732,7 +751,7 @@ __device__ __forceinline__ void shade3d_lights(const RasterParams &P, bool hit, 
             const rxr_light &L = P.lights[mine];
             if (L.light_type == RXR_LIGHT_POINT || L.light_type == RXR_LIGHT_SPOT || L.light_type == RXR_LIGHT_AREA ||
                 L.light_type == RXR_LIGHT_DAYLIGHT) {
-                float dcl = mag3(sub3(c, mk3(L.position[0], L.position[1], L.position[2])));
+                float dcl = mag3_bound(sub3(c, mk3(L.position[0], L.position[1], L.position[2])));
                 // every fragment p of the wave has |p - L| >= dcl - rmax; the margin covers rounding
                 float margin = 1e-3f * (dcl + rmax + fabsf(L.end_distance)) + 1e-6f;
                 if (dcl - rmax > L.end_distance + margin) cand = false;

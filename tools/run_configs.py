@@ -135,7 +135,8 @@ def main():
         t_loop_untimed = (time.perf_counter() - t0) / args.frames
         st = Stats()
         rxr.rxr_get_stats(ctx, C.byref(st))
-        rec = dict(config=name, scene=cfg.name, shader_jit=os.environ.get("RXR_SHADER_JIT", "0"), device_projection=bool(args.device_projection), resolution=[W, H], triangles_3d=st.n_triangles3d, bin_entries=st.n_bin_entries,
+        light_math = os.environ.get("RXR_LIGHT_MATH", "exact" if host.rxh_get_light_math_exact() else "relaxed")
+        rec = dict(config=name, scene=cfg.name, shader_jit=os.environ.get("RXR_SHADER_JIT", "0"), light_math=light_math, device_projection=bool(args.device_projection), resolution=[W, H], triangles_3d=st.n_triangles3d, bin_entries=st.n_bin_entries,
                    scene_build_s=round(t_build, 2), upload_ms=round(t_upload * 1e3, 2),
                    setup_kernels_us=round(float(np.median(su[: n.value])), 1), raster_kernel_us=round(float(np.median(ru[: n.value])), 1),
                    frame_ms_device_resident=round(t_loop * 1e3, 4), mpix_per_s_device_resident=round(W * H / t_loop / 1e6, 1),
