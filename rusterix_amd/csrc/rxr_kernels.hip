@@ -605,7 +605,11 @@ __device__ __forceinline__ void shade3d_begin(const RasterParams &P, const TriSh
         const float vm2 = fmaf(vd.z, vd.z, fmaf(vd.y, vd.y, vd.x * vd.x)), nm2 = fmaf(ni.z, ni.z, fmaf(ni.y, ni.y, ni.x * ni.x));
         const float vinv = __builtin_amdgcn_rsqf(vm2), ninv = __builtin_amdgcn_rsqf(nm2);
         const float dnv = fmaf(ni.z, vd.z, fmaf(ni.y, vd.y, ni.x * vd.x)) * (vinv * ninv);
-        relaxed_normals = rxm::wave_all(rxm::sq_in_window(vm2) && (!has_n || (rxm::sq_in_window(nm2) && __builtin_fabsf(dnv) >= P.rl_flip_guard)));
+        // with the relaxed world position the view vector itself is off by up to an ulp of |world| -- an angle of ulp * |world| / |v|,
+        // which matters for a camera far from the origin looking at something close: the guard grows with that ratio (25x margin)
+        float guard = P.rl_flip_guard;
+        if (relaxed_world) guard = fmaf(1e-5f * vinv, __builtin_fabsf(world.x) + __builtin_fabsf(world.y) + __builtin_fabsf(world.z), guard);
+        relaxed_normals = rxm::wave_all(rxm::sq_in_window(vm2) && (!has_n || (rxm::sq_in_window(nm2) && __builtin_fabsf(dnv) >= guard)));
         if (relaxed_normals) {
             view_dir = scale3(vd, vinv);
             // (no normals: the reference normalises the zero vector, 0 / 0)
@@ -613,6 +617,14 @@ __device__ __forceinline__ void shade3d_begin(const RasterParams &P, const TriSh
         }
     }
     if (!relaxed_normals) {
+        if (relaxed_world) {  // (rare: the exact sequences want the reference's world position -- its quotients again)
+            x_ndc = 2.0f * rxm::div1_known(fx, P.fwidth, true) - 1.0f;
+            y_ndc = 1.0f - 2.0f * rxm::div1_known(fy, P.fheight, true);
+            mat4_mul(P.inv_proj, x_ndc, y_ndc, z, 1.0f, vx, vy, vz, vw);
+            rxm::div3_self(vx, vy, vz, vw, vx, vy, vz, vw);
+            mat4_mul(P.inv_view, vx, vy, vz, vw, wx, wy, wz, ww);
+            world = mk3(wx, wy, wz);
+        }
         view_dir = norm3_fast(sub3(cam, world));
         if (B.flags & DB_HAS_NORMALS) {  // :1083-1099
             f3 n0 = mk3(S.n0[0], S.n0[1], S.n0[2]), n1 = mk3(S.n1[0], S.n1[1], S.n1[2]), n2 = mk3(S.n2[0], S.n2[1], S.n2[2]);

@@ -74,6 +74,29 @@ def mixed_light_types(api):
     return cfg
 
 
+def far_from_the_origin(api):
+    """a lit, textured cube 3000 units from the origin seen from 1.6 units away: an ulp of the world position is 2.4e-4 there, the
+    view vector's angle error from a relaxed world position ~1e-4 -- the case the scale-aware flip guard of shade3d_begin is for"""
+    c = (3000.0, 1800.0, -2500.0)
+    box = (api.Batch3D.from_box(c[0] - 0.5, c[1] - 0.5, c[2] - 0.5, 1.0, 1.0, 1.0).cull_mode(B.CULL_OFF).with_computed_normals()
+           .source(B.PixelSource.StaticTileIndex(0)))
+    scene = api.Scene.from_static([], [box]).background(api.VGrayGradientShader())
+    scene.lights([B.Light(B.LIGHT_POINT).with_position((c[0] + 1.2, c[1] + 1.5, c[2] + 0.8)).with_color((1.0, 0.9, 0.7)).with_intensity(2.0)
+                  .with_start_distance(0.5).with_end_distance(6.0).compile(),
+                  B.Light(B.LIGHT_POINT).with_position((c[0] - 1.4, c[1] + 0.2, c[2] + 1.1)).with_color((0.5, 0.7, 1.0)).with_intensity(1.5)
+                  .with_start_distance(0.5).with_end_distance(5.0).compile()])
+    assets = api.Assets.default().textures([B.Tile.from_texture(scenes.logo_texture(1, 64))])
+    cam = api.D3OrbitCamera.new()
+    cam.center = c
+    cam.set_parameter_f32("distance", 1.6)
+
+    def setup():
+        v, p = cam.matrices(400.0, 300.0)
+        return api.Rasterizer.setup(None, v, p).ambient((0.3, 0.3, 0.3, 1.0))
+
+    return scenes._result(api, scene, assets, setup, 400, 300, 40, "far cube")
+
+
 SCENES = {
     "map, 1 light": lambda api: scenes.map_scene(api, width=640, height=360, logo_size=128, n_lights=1),
     "map, 16 lights": lambda api: scenes.map_scene(api, width=640, height=360, logo_size=128, n_lights=16),
@@ -82,6 +105,7 @@ SCENES = {
     "lit box grid (binned, row mode)": lit_box_grid,
     "map behind the grid background (feature level 1)": chunk_level_map,
     "mixed light types": mixed_light_types,
+    "lit cube far from the origin": far_from_the_origin,
 }
 
 
