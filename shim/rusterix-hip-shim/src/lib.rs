@@ -62,6 +62,23 @@ fn create_context() -> Option<Ctx> {
     if unsafe { rxr_create(&mut p, dev) } == RXR_OK { Some(Ctx(p)) } else { None }
 }
 
+/// Arithmetic of the 3D light loop on the device (include/rxr.h `rxr_set_light_math`): `exact = true` reproduces the CPU
+/// rasterizer's lit frames up to libm's log2f / exp2f; `false` (the library's default) stays within 1 per 8-bit channel and
+/// renders lit frames a third faster.  Applies from the next frame on; `RXR_LIGHT_MATH=exact|relaxed` in the environment
+/// overrides it.  Returns false when there is no device context (the CPU path is exact anyway).
+pub fn set_light_math(exact: bool) -> bool {
+    let mut guard = STATE.lock().unwrap();
+    let st = guard.get_or_insert_with(Caches::default);
+    if st.ctx.is_none() && !st.tried {
+        st.tried = true;
+        st.ctx = create_context();
+    }
+    match &st.ctx {
+        Some(ctx) => unsafe { rxr_set_light_math(ctx.0, if exact { RXR_LIGHT_MATH_EXACT as i32 } else { RXR_LIGHT_MATH_RELAXED as i32 }) == RXR_OK },
+        None => false,
+    }
+}
+
 fn fnv(h: &mut u64, bytes: &[u8]) {
     for b in bytes {
         *h = (*h ^ *b as u64).wrapping_mul(1099511628211);
