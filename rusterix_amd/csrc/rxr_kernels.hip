@@ -793,20 +793,22 @@ __device__ __forceinline__ void shade3d_lights(const RasterParams &P, bool hit, 
                     // specular lobe contributes exactly what it contributes there: nothing.  Magnitudes outside the window (zero,
                     // denormal, infinite, NaN) leave through the exact path below.
                     const float m2 = fmaf(d.z, d.z, fmaf(d.y, d.y, d.x * d.x));
-                    if (rxm::wave_all(rxm::sq_in_window(m2)) && (ss_fast || L.start_distance == L.end_distance)) {
+                    // (ss_fast: start - end is a window value; the fused form also wants start < end, as every real light has it)
+                    if (rxm::wave_all(rxm::sq_in_window(m2)) && ss_fast && L.start_distance < L.end_distance) {
                         const float inv = __builtin_amdgcn_rsqf(m2);
                         const float distance = m2 * inv;
-                        if (distance >= L.end_distance) continue;
-                        float intensity = L.intensity;
-                        if (!(distance <= L.start_distance)) {
-                            const float t = __builtin_amdgcn_fmed3f((distance - L.end_distance) * ss_r, 0.0f, 1.0f);  // (finite: no NaN to keep)
-                            intensity = L.intensity * (t * t * fmaf(-2.0f, t, 3.0f));
-                        }
+                        // The range test and the full-intensity test ARE the clamp of the smoothstep: beyond the end distance
+                        // t = 0 and the term below is exactly +0 added to lit; inside the start distance t = 1 and the smoothstep
+                        // is exactly 1.  No compare, no select, no divergent branch (the wave-level culling has already dropped
+                        // the lights that reach no fragment of the wave).  The clamps are output modifiers of the multiplies.
+                        const float t = __builtin_amdgcn_fmed3f((distance - L.end_distance) * ss_r, 0.0f, 1.0f);
+                        const float intensity = L.intensity * (t * t * fmaf(-2.0f, t, 3.0f));
                         const f3 l = scale3(d, inv);
-                        const float ndl = fmaxf(fmaf(F.normal.z, l.z, fmaf(F.normal.y, l.y, F.normal.x * l.x)), 0.0f);
+                        // max(n.l, 0) and max(n.h, 0) as clamps to [0, 1] (both are cosines: at most 1 + 2 ulp)
+                        const float ndl = __builtin_amdgcn_fmed3f(fmaf(F.normal.z, l.z, fmaf(F.normal.y, l.y, F.normal.x * l.x)), 0.0f, 1.0f);
                         const f3 hu = add3(l, F.view_dir);
                         const float hh = fmaf(hu.z, hu.z, fmaf(hu.y, hu.y, hu.x * hu.x));  // 0 (l = -v: n.h = NaN -> 0 below) or >= 1e-15
-                        const float ndh = fmaxf(fmaf(F.normal.z, hu.z, fmaf(F.normal.y, hu.y, F.normal.x * hu.x)) * __builtin_amdgcn_rsqf(hh), 0.0f);
+                        const float ndh = __builtin_amdgcn_fmed3f(fmaf(F.normal.z, hu.z, fmaf(F.normal.y, hu.y, F.normal.x * hu.x)) * __builtin_amdgcn_rsqf(hh), 0.0f, 1.0f);
                         const float spec = __builtin_amdgcn_exp2f(rl_shininess * __builtin_amdgcn_logf(ndh));  // (0 for n.h = 0)
                         const f3 cf = apply_flicker(L, 1.0f, P.hash_anim);  // wave-uniform
                         const float s = intensity * ndl * ndl;
