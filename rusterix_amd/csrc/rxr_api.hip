@@ -27,6 +27,7 @@ extern "C" void rxr_launch_scan(const ScanArgs *A, hipStream_t s);
 extern "C" void rxr_launch_bin2d_count(const RasterParams *P, hipStream_t s);
 extern "C" void rxr_launch_bin2d_fill(const RasterParams *P, hipStream_t s);
 extern "C" void rxr_launch_fill(const RasterParams *P, hipStream_t s);
+extern "C" void rxr_launch_blockscan(const RasterParams *P, hipStream_t s);
 extern "C" void rxr_launch_raster(const RasterParams *P, hipStream_t s);
 extern "C" void rxr_launch_selftest_math(uint64_t seed, uint32_t blocks, uint32_t iters, unsigned long long *mismatch, hipStream_t s);
 
@@ -1083,6 +1084,19 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
         if (ctx->d_counters.p != before) HIPCHK(ctx, hipMemsetAsync(ctx->d_counters.p, 0, ctx->d_counters.cap, ctx->stream));
     }
     size_t want_list = ctx->list_floor ? ctx->list_floor : std::max<size_t>(1u << 20, n_t3 * 4);
+    // mid-sized scenes: k_blockscan gives every bin its own run of slots (not with a list floor: that knob exists to make the
+    // general pipeline's lists overflow in tests)
+    ctx->blockscan_cap = RXR_BLOCKSCAN_CAP;  // (both knobs are read per upload: tests and A-B runs switch them on a live context)
+    ctx->blockscan_enabled = true;
+    if (const char *bs = getenv("RXR_BLOCKSCAN")) ctx->blockscan_enabled = bs[0] != '0';
+    if (const char *bc = getenv("RXR_BLOCKSCAN_CAP")) {  // tests: few slots per bin make ordinary meshes overflow them
+        const long v = atol(bc);
+        if (v > 0 && v <= 4096) ctx->blockscan_cap = (uint32_t)v;
+    }
+    const size_t n_blocks = (size_t)((f->width + 63u) / 64u) * ((f->height + 63u) / 64u);
+    ctx->blockscan_off = !(ctx->blockscan_enabled && !ctx->list_floor && n_t3 > RXR_STAGE_TRIS && n_t3 <= RXR_BLOCKSCAN_MAX_TRIS &&
+                           n_t3 * n_blocks <= RXR_BLOCKSCAN_MAX_WORK && (size_t)n_bins * ctx->blockscan_cap <= (64u << 20));
+    if (!ctx->blockscan_off) want_list = std::max<size_t>(want_list, (size_t)n_bins * ctx->blockscan_cap);
     if (want_list > ctx->list_capacity) {
         if ((rc = ensure(ctx, ctx->d_list, want_list * sizeof(uint32_t))) != RXR_OK) return rc;
         ctx->list_capacity = (uint32_t)std::min<size_t>(ctx->d_list.cap / sizeof(uint32_t), 0xFFFFFFF0u);
@@ -1311,7 +1325,18 @@ static int render_impl(rxr_ctx *ctx, const RenderSpec &spec, void *dev_pixels, h
         HIPCHK(ctx, hipMemsetAsync(ctx->d_bin_count.p, 0, ctx->d_bin_count.cap, s));
         HIPCHK(ctx, hipMemsetAsync(ctx->d_counters.p, 0, ctx->d_counters.cap, s));
     }
-    if (prepass) {
+    // mid-sized scenes: k_setup3d (records and boxes only) + k_blockscan; the counters are not touched (the clean set stays clean, the
+    // large list stays empty: every block of bins looks at every triangle)
+    const bool blockscan = prepass && !ctx->blockscan_off && (size_t)n_bins * ctx->blockscan_cap <= (size_t)P.list_capacity;
+    ctx->last_used_blockscan = blockscan;
+    if (blockscan) {
+        ctx->scratch_dirty = true;
+        P.blockscan_cap = ctx->blockscan_cap;
+        P.counters = (uint32_t *)ctx->d_counters.p + (size_t)ctx->parity * CNT_WORDS;
+        if (ctx->frame_uses_meshes) rxr_launch_project(&ctx->PP, s);
+        rxr_launch_setup(&P, s);
+        rxr_launch_blockscan(&P, s);
+    } else if (prepass) {
         ctx->scratch_dirty = true;
         // counter set `parity` is clean (cleared by the previous launch's k_scan); this launch's k_scan
         // clears the other set.  bin_count is clean because k_raster hands every bin back zeroed.
@@ -1525,7 +1550,7 @@ int rxr_synchronize(rxr_ctx *ctx) {
                         "four or more groups of opacity batches nest as prefix minima in one pixel: the device keeps three per pixel (surface_id, "
                         "rasterizer.rs:314-357, :1044-1048) and had to drop one; the frame may differ from the reference");
         }
-        ctx->stats.n_bin_entries = ctx->last_had_prepass ? hc[CNT_ENTRIES] : 0u;
+        ctx->stats.n_bin_entries = (ctx->last_had_prepass && !ctx->last_used_blockscan) ? hc[CNT_ENTRIES] : 0u;  // (k_blockscan does not count its entries)
         const bool over3d = hc[CNT_OVERFLOW] != 0, over2d = hc[CNT_WORDS + CNT_OVERFLOW] != 0;
         if (!over3d && !over2d) {
             float a = 0, b = 0;
@@ -1551,7 +1576,11 @@ int rxr_synchronize(rxr_ctx *ctx) {
             ctx->P.list2d_capacity = ctx->list2d_capacity;
             hc[CNT_WORDS + CNT_OVERFLOW] = hc[CNT_WORDS + HS_MAX_ENTRIES] = 0;
         }
-        if (over3d) {
+        if (over3d && ctx->last_used_blockscan) {
+            // a block of bins or a bin had more candidates than k_blockscan keeps: this frame takes the general pipeline
+            ctx->blockscan_off = true;
+            hc[CNT_OVERFLOW] = hc[HS_MAX_ENTRIES] = 0;
+        } else if (over3d) {
             const size_t seen = std::max(hc[HS_MAX_ENTRIES], hc[CNT_ENTRIES]);
             if ((rc = ensure(ctx, ctx->d_list, (seen + seen / 2 + 1024) * sizeof(uint32_t))) != RXR_OK) return rc;
             ctx->list_capacity = (uint32_t)std::min<size_t>(ctx->d_list.cap / sizeof(uint32_t), 0xFFFFFFF0u);

@@ -100,6 +100,11 @@ struct rxr_ctx {
     bool jit_async = false;
     std::string jit_wait_key[3];           // the background compilation (rxr_jit.hip registry) this context is attached to, per level
     std::string jit_source, jit_arch;
+    // mid-sized scenes: bin lists by k_blockscan (rxr_device.h RXR_BLOCKSCAN_*).  blockscan_off: the current frame overflowed a block or a
+    // bin and goes through the general pipeline (reset by the next upload); RXR_BLOCKSCAN=0 turns the mode off, RXR_BLOCKSCAN_CAP sets
+    // the slots per bin (tests)
+    bool blockscan_enabled = true, blockscan_off = false, last_used_blockscan = false;
+    uint32_t blockscan_cap = 0;           // RXR_BLOCKSCAN_CAP in effect
     bool relaxed_lights = true;           // rxr_set_light_math / RXR_LIGHT_MATH: the 3D light loop in relaxed arithmetic (RasterParams.relaxed_lights)
     bool frame_needs_chunk_paths = true;  // the uploaded frame uses what feature level 1 adds (terrain / baked textures / staircase / editor paths)
     std::string jit_info;                // what happened to the last set ("compiled: ...", "not compiled: <why>", empty: not asked)

@@ -169,6 +169,15 @@ struct DevPattern {
 enum { CNT_LARGE = 0, CNT_ENTRIES = 1, CNT_OVERFLOW = 2, CNT_TICKET = 3, CNT_WORDS = 4 };
 // bins per k_scan workgroup (256 threads x 8)
 #define RXR_SCAN_CHUNK 2048u
+// Mid-sized scenes (RXR_STAGE_TRIS < triangles <= RXR_BLOCKSCAN_MAX_TRIS, triangles x blocks <= RXR_BLOCKSCAN_MAX_WORK): the bin lists are built without atomics on global
+// memory, without a scan and without a second pass over the triangles -- k_blockscan (rxr_kernels.hip): one workgroup per block
+// of 4 x 4 bins tests every triangle's bin range against its block, keeps the hits in LDS and deals them to its 16 bins, each
+// bin owning RasterParams.blockscan_cap list slots.  A block with more than RXR_BLOCKSCAN_BLOCK_TRIS hits or a bin with more
+// than its slots raises the overflow word: the frame is then rendered again through the general pipeline.
+#define RXR_BLOCKSCAN_MAX_TRIS 16384u
+#define RXR_BLOCKSCAN_MAX_WORK (10u << 20)   // triangles x blocks of bins: phase 1 looks at every pair (~0.4 wave-instructions each)
+#define RXR_BLOCKSCAN_BLOCK_TRIS 2048u
+#define RXR_BLOCKSCAN_CAP 256u
 
 // kernel parameter block (passed by value; lives in the kernarg segment -> scalar loads)
 struct RasterParams {
@@ -226,6 +235,7 @@ struct RasterParams {
     uint32_t plain_programs;       // host only: the frame runs programs but needs none of level 1's chunk paths (k_raster_vm_p instead of k_raster_vm_sv)
     uint32_t relaxed_lights;       // host only: RXR_LIGHT_MATH=relaxed -- feature levels 0 and 1 launch the kernels whose 3D light loop uses the
                                    // relaxed arithmetic (k_raster_rl, k_raster_rows_rl, k_raster_chunk_rl; shade3d_lights<X, true>)
+    uint32_t blockscan_cap;        // != 0: this launch bins with k_blockscan (k_setup3d counts nothing); list slots per bin
     uint32_t any_occluders;        // the frame has an occluder somewhere (mapmini's or a chunk's): get_occlusion compares world positions with their boxes
     float rl_flip_guard;           // relaxed light mode: the smallest |n.v| for which the normal's flip toward the camera is decided from the
                                    // relaxed values (shade3d_begin; 1e-4, a hundred times their error; RXR_RL_FLIP_GUARD for tests)

@@ -1227,7 +1227,7 @@ __device__ __forceinline__ bool dead_slots_block(const RasterParams &P, uint32_t
 
 extern "C" __global__ void __launch_bounds__(256) k_setup3d(RasterParams P) {
     const uint32_t t0 = blockIdx.x * blockDim.x;
-    if (dead_slots_block(P, t0)) return;
+    if (!P.blockscan_cap && dead_slots_block(P, t0)) return;  // (k_blockscan reads every slot's box: dead slots get their empty box below)
     uint32_t t = t0 + threadIdx.x;
     bool live = false;
     TriSetup S = {};
@@ -1283,7 +1283,7 @@ extern "C" __global__ void __launch_bounds__(256) k_setup3d(RasterParams P) {
         }
     }
 #endif
-    if (P.fused_small) return;  // small scenes are not binned (see scan_implicit); uniform
+    if (P.fused_small || P.blockscan_cap) return;  // small scenes are not binned (see scan_implicit), mid-sized ones by k_blockscan; uniform
     uint32_t bx0 = 0, bx1 = 0, by0 = 0, by1 = 0, nb = 0;
     if (live) {
         const uint32_t min_x = S.bx & 0xFFFFu, max_x = S.bx >> 16, min_y = S.by & 0xFFFFu, max_y = S.by >> 16;
@@ -1501,6 +1501,88 @@ extern "C" __global__ void __launch_bounds__(256) k_fill(RasterParams P) {
             if (act[u] && pos < P.list_capacity) P.bin_list[pos] = owner_t[u];
         }
     }
+}
+
+// =================================================================================================
+// k_blockscan: the bin lists of a mid-sized scene in one launch (rxr_device.h RXR_BLOCKSCAN_*).  One workgroup per block of
+// 4 x 4 bins.  Phase 1: the four waves walk ALL triangles' pixel boxes (8 bytes each, dense array written by k_setup3d), 64 per
+// step, turn each into its bin range (bin_range: the same function the general pipeline's k_fill enumerates) and keep the ones
+// whose range meets the block -- id and packed range -- in LDS (one LDS atomic per wave and step).  Phase 2: every wave takes
+// four of the block's bins and deals the kept triangles into the bin's slots with ballot + popcount.  It leaves what k_scan /
+// k_fill leave: bin_count, bin_offset (+ a zero chunk base) and the list entries -- in an order that does not matter (the
+// visibility pass is an arg-min).  No global atomic, no scan, no second pass over the triangles; large triangles need no list
+// of their own (every block sees every triangle).
+// =================================================================================================
+extern "C" __global__ void __launch_bounds__(256) k_blockscan(RasterParams P) {
+    __shared__ uint32_t kept_id[RXR_BLOCKSCAN_BLOCK_TRIS];
+    __shared__ uint2 kept_rng[RXR_BLOCKSCAN_BLOCK_TRIS];
+    __shared__ uint32_t kept_n;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t blocks_x = (P.tiles_x + 3u) / 4u;
+    const uint32_t bbx = blockIdx.x % blocks_x, bby = blockIdx.x / blocks_x;
+    const uint32_t x_lo = bbx * 4u, x_hi = min(x_lo + 3u, P.tiles_x - 1u), y_lo = bby * 4u, y_hi = min(y_lo + 3u, P.tiles_y - 1u);
+    if (tid == 0) kept_n = 0u;
+    __syncthreads();
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (uint32_t t0 = 0; t0 < P.n_tris3d; t0 += 256u) {  // uniform trip count
+        const uint32_t t = t0 + tid;
+        bool hit = false;
+        uint2 rng = make_uint2(0u, 0u);
+        if (t < P.n_tris3d) {
+            const uint2 box = P.tri_box[t];
+            uint32_t bx0, bx1, l0, l1;
+            if (bin_range(P, box.x & 0xFFFFu, box.x >> 16, box.y & 0xFFFFu, box.y >> 16, bx0, bx1, l0, l1)) {
+                hit = bx0 <= x_hi && bx1 >= x_lo && l0 <= y_hi && l1 >= y_lo;
+                rng = make_uint2(bx0 | (bx1 << 16), l0 | (l1 << 16));
+            }
+        }
+        const unsigned long long m = __ballot(hit);
+        if (m) {  // wave-uniform
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&kept_n, (uint32_t)__popcll(m));
+            base = (uint32_t)__shfl((int)base, 0, 64);
+            const uint32_t pos = base + (uint32_t)__popcll(m & below);
+            if (hit && pos < RXR_BLOCKSCAN_BLOCK_TRIS) {
+                kept_id[pos] = t;
+                kept_rng[pos] = rng;
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t n_kept_all = kept_n;
+    const uint32_t n_kept = min(n_kept_all, (uint32_t)RXR_BLOCKSCAN_BLOCK_TRIS);
+    bool overflow = n_kept_all > RXR_BLOCKSCAN_BLOCK_TRIS;
+    uint32_t worst = 0;
+    for (uint32_t j = wave; j < 16u; j += 4u) {
+        const uint32_t bx = x_lo + (j & 3u), by = y_lo + (j >> 2);
+        if (bx > x_hi || by > y_hi) continue;  // wave-uniform
+        const uint32_t bin = by * P.tiles_x + bx;
+        const uint32_t first = bin * P.blockscan_cap;
+        uint32_t cnt = 0;
+        for (uint32_t k0 = 0; k0 < n_kept; k0 += 64u) {
+            const uint32_t k = k0 + lane;
+            bool in = false;
+            uint32_t id = 0;
+            if (k < n_kept) {
+                const uint2 r = kept_rng[k];
+                in = bx >= (r.x & 0xFFFFu) && bx <= (r.x >> 16) && by >= (r.y & 0xFFFFu) && by <= (r.y >> 16);
+                id = kept_id[k];
+            }
+            const unsigned long long m = __ballot(in);
+            const uint32_t pos = cnt + (uint32_t)__popcll(m & below);
+            if (in && pos < P.blockscan_cap && first + pos < P.list_capacity) P.bin_list[first + pos] = id;
+            cnt += (uint32_t)__popcll(m);
+        }
+        if (cnt > P.blockscan_cap) overflow = true;
+        worst = max(worst, cnt);
+        if (lane == 0) {
+            P.bin_count[bin] = min(cnt, P.blockscan_cap);
+            P.bin_offset[bin] = first;  // (chunk bases are zero in this mode)
+            if (bin % RXR_SCAN_CHUNK == 0u) P.chunk_base[bin / RXR_SCAN_CHUNK] = 0u;
+        }
+    }
+    if (overflow && lane == 0) P.host_status[CNT_OVERFLOW] = 1u;  // sticky; rxr_synchronize renders the frame again through the general pipeline
+    (void)worst;
 }
 
 // =================================================================================================
@@ -2718,6 +2800,11 @@ extern "C" void rxr_launch_bin2d_count(const RasterParams *P, hipStream_t s) {
 extern "C" void rxr_launch_bin2d_fill(const RasterParams *P, hipStream_t s) {
     if (P->n_prims2d == 0) return;
     hipLaunchKernelGGL(k_bin2d_fill, dim3((P->n_prims2d + 255u) / 256u), dim3(256), 0, s, *P);
+}
+extern "C" void rxr_launch_blockscan(const RasterParams *P, hipStream_t s) {
+    if (P->n_tris3d == 0 || P->tiles_x * P->tiles_y == 0) return;
+    const uint32_t blocks = ((P->tiles_x + 3u) / 4u) * ((P->tiles_y + 3u) / 4u);
+    hipLaunchKernelGGL(k_blockscan, dim3(blocks), dim3(256), 0, s, *P);
 }
 extern "C" void rxr_launch_fill(const RasterParams *P, hipStream_t s) {
     if (P->n_tris3d == 0) return;
