@@ -1051,19 +1051,23 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
     // ---- device scratch ------------------------------------------------------------------------
     uint32_t tiles_x = (f->width + RXR_TILE_W - 1) / RXR_TILE_W, tiles_y_all = (f->height + RXR_TILE_H - 1) / RXR_TILE_H;
     size_t n_bins = (size_t)tiles_x * tiles_y_all;
+    const size_t n_blocks = (size_t)((tiles_x + 3u) / 4u) * ((tiles_y_all + 3u) / 4u);  // k_blockscan's blocks of 4 x 4 bins
     if ((rc = ensure(ctx, ctx->d_tri_setup, (n_t3 ? n_t3 : 1) * sizeof(TriSetup))) != RXR_OK) return rc;
     if ((rc = ensure(ctx, ctx->d_tri_shade, (n_t3 ? n_t3 : 1) * sizeof(TriShade))) != RXR_OK) return rc;
-    if ((rc = ensure(ctx, ctx->d_tri_box, (n_t3 ? n_t3 : 1) * sizeof(uint2))) != RXR_OK) return rc;
+    const size_t n_groups = (n_t3 + RXR_BLOCKSCAN_GROUP - 1) / RXR_BLOCKSCAN_GROUP;  // (their bin-range unions live behind the boxes)
+    if ((rc = ensure(ctx, ctx->d_tri_box, ((n_t3 ? n_t3 : 1) + n_groups + 1) * sizeof(uint2))) != RXR_OK) return rc;
     const size_t n_chunks = (n_bins + RXR_SCAN_CHUNK - 1) / RXR_SCAN_CHUNK + 1;
     {
         // bin_count lives in its OWN buffer: the invariant "all-zero between launches" (k_raster hands every
         // bin back cleared) must hold for whatever frame size comes next, so nothing else may share it
         void *before = ctx->d_bin_count.p;
-        if ((rc = ensure(ctx, ctx->d_bin_count, (n_bins + 1) * sizeof(uint32_t))) != RXR_OK) return rc;
+        // (behind the bin counts: k_blockscan's group counts per block of 4 x 4 bins, zero between launches like them)
+        if ((rc = ensure(ctx, ctx->d_bin_count, (n_bins + 1 + n_blocks) * sizeof(uint32_t))) != RXR_OK) return rc;
         if (ctx->d_bin_count.p != before) HIPCHK(ctx, hipMemsetAsync(ctx->d_bin_count.p, 0, ctx->d_bin_count.cap, ctx->stream));
     }
     if ((rc = ensure(ctx, ctx->d_bins, (2 * (n_bins + 1) + 2 * n_chunks + 8) * sizeof(uint32_t))) != RXR_OK) return rc;
-    if ((rc = ensure(ctx, ctx->d_large, (n_t3 ? n_t3 : 1) * sizeof(uint32_t))) != RXR_OK) return rc;
+    // (the large list doubles as k_blockscan's per-block group lists: the two are never used by the same launch)
+    if ((rc = ensure(ctx, ctx->d_large, std::max<size_t>(n_t3 ? n_t3 : 1, n_blocks * RXR_BLOCKSCAN_BLOCK_GROUPS + n_groups + 1) * sizeof(uint32_t))) != RXR_OK) return rc;
     // 2D binning scratch (used only when the frame has more than RXR_STAGE_TRIS 2D primitives)
     const bool binned2d = p2cur > RXR_STAGE_TRIS;
     if (binned2d) {
@@ -1093,9 +1097,10 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
         const long v = atol(bc);
         if (v > 0 && v <= 4096) ctx->blockscan_cap = (uint32_t)v;
     }
-    const size_t n_blocks = (size_t)((f->width + 63u) / 64u) * ((f->height + 63u) / 64u);
-    ctx->blockscan_off = !(ctx->blockscan_enabled && !ctx->list_floor && n_t3 > RXR_STAGE_TRIS && n_t3 <= RXR_BLOCKSCAN_MAX_TRIS &&
-                           n_t3 * n_blocks <= RXR_BLOCKSCAN_MAX_WORK && (size_t)n_bins * ctx->blockscan_cap <= (64u << 20));
+    ctx->blockscan_off = !(ctx->blockscan_enabled && !ctx->list_floor && n_t3 > RXR_STAGE_TRIS &&
+                           (n_groups > RXR_BLOCKSCAN_SCATTER_GROUPS || n_groups * n_blocks <= RXR_BLOCKSCAN_MAX_WORK) &&
+                           (size_t)n_bins * ctx->blockscan_cap <= (64u << 20));
+    if (!ctx->blockscan_off && ctx->blockscan_bad_tris == n_t3 && ctx->blockscan_bad_bins == n_bins) ctx->blockscan_off = true;
     if (!ctx->blockscan_off) want_list = std::max<size_t>(want_list, (size_t)n_bins * ctx->blockscan_cap);
     if (want_list > ctx->list_capacity) {
         if ((rc = ensure(ctx, ctx->d_list, want_list * sizeof(uint32_t))) != RXR_OK) return rc;
@@ -1216,6 +1221,11 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
     P.tri_setup = (TriSetup *)ctx->d_tri_setup.p;
     P.tri_shade = (TriShade *)ctx->d_tri_shade.p;
     P.tri_box = (uint2 *)ctx->d_tri_box.p;
+    P.group_rng = P.tri_box + (n_t3 ? n_t3 : 1);
+    P.blk_cnt = (uint32_t *)ctx->d_bin_count.p + n_bins + 1;
+    P.blk_grp = (uint32_t *)ctx->d_large.p;
+    P.blockscan_scatter = n_groups > RXR_BLOCKSCAN_SCATTER_GROUPS ? 1u : 0u;
+    P.blk_wide_base = (uint32_t)(n_blocks * RXR_BLOCKSCAN_BLOCK_GROUPS);
     P.bin_count = (uint32_t *)ctx->d_bin_count.p;
     P.bin_offset = (uint32_t *)ctx->d_bins.p;
     P.bin_cursor = P.bin_offset + n_bins + 1;
@@ -1332,7 +1342,10 @@ static int render_impl(rxr_ctx *ctx, const RenderSpec &spec, void *dev_pixels, h
     if (blockscan) {
         ctx->scratch_dirty = true;
         P.blockscan_cap = ctx->blockscan_cap;
+        // (the scatter form counts its wide groups in the clean counter set and clears the other one, as k_scan does)
         P.counters = (uint32_t *)ctx->d_counters.p + (size_t)ctx->parity * CNT_WORDS;
+        P.counters_next = (uint32_t *)ctx->d_counters.p + (size_t)(ctx->parity ^ 1u) * CNT_WORDS;
+        if (P.blockscan_scatter) ctx->parity ^= 1u;
         if (ctx->frame_uses_meshes) rxr_launch_project(&ctx->PP, s);
         rxr_launch_setup(&P, s);
         rxr_launch_blockscan(&P, s);
@@ -1579,6 +1592,8 @@ int rxr_synchronize(rxr_ctx *ctx) {
         if (over3d && ctx->last_used_blockscan) {
             // a block of bins or a bin had more candidates than k_blockscan keeps: this frame takes the general pipeline
             ctx->blockscan_off = true;
+            ctx->blockscan_bad_tris = ctx->P.n_tris3d;
+            ctx->blockscan_bad_bins = (size_t)ctx->P.tiles_x * ((ctx->P.height + RXR_TILE_H - 1) / RXR_TILE_H);
             hc[CNT_OVERFLOW] = hc[HS_MAX_ENTRIES] = 0;
         } else if (over3d) {
             const size_t seen = std::max(hc[HS_MAX_ENTRIES], hc[CNT_ENTRIES]);

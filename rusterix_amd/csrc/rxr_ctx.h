@@ -104,6 +104,9 @@ struct rxr_ctx {
     // bin and goes through the general pipeline (reset by the next upload); RXR_BLOCKSCAN=0 turns the mode off, RXR_BLOCKSCAN_CAP sets
     // the slots per bin (tests)
     bool blockscan_enabled = true, blockscan_off = false, last_used_blockscan = false;
+    size_t blockscan_bad_tris = 0, blockscan_bad_bins = 0;  // the (triangles, bins) of the last frame that overflowed k_blockscan: frames of
+                                                            // the same shape do not try again (a caller that uploads every frame would pay
+                                                            // the failed attempt and the second rendering every time)
     uint32_t blockscan_cap = 0;           // RXR_BLOCKSCAN_CAP in effect
     bool relaxed_lights = true;           // rxr_set_light_math / RXR_LIGHT_MATH: the 3D light loop in relaxed arithmetic (RasterParams.relaxed_lights)
     bool frame_needs_chunk_paths = true;  // the uploaded frame uses what feature level 1 adds (terrain / baked textures / staircase / editor paths)

@@ -169,13 +169,20 @@ struct DevPattern {
 enum { CNT_LARGE = 0, CNT_ENTRIES = 1, CNT_OVERFLOW = 2, CNT_TICKET = 3, CNT_WORDS = 4 };
 // bins per k_scan workgroup (256 threads x 8)
 #define RXR_SCAN_CHUNK 2048u
-// Mid-sized scenes (RXR_STAGE_TRIS < triangles <= RXR_BLOCKSCAN_MAX_TRIS, triangles x blocks <= RXR_BLOCKSCAN_MAX_WORK): the bin lists are built without atomics on global
-// memory, without a scan and without a second pass over the triangles -- k_blockscan (rxr_kernels.hip): one workgroup per block
-// of 4 x 4 bins tests every triangle's bin range against its block, keeps the hits in LDS and deals them to its 16 bins, each
-// bin owning RasterParams.blockscan_cap list slots.  A block with more than RXR_BLOCKSCAN_BLOCK_TRIS hits or a bin with more
-// than its slots raises the overflow word: the frame is then rendered again through the general pipeline.
-#define RXR_BLOCKSCAN_MAX_TRIS 16384u
-#define RXR_BLOCKSCAN_MAX_WORK (10u << 20)   // triangles x blocks of bins: phase 1 looks at every pair (~0.4 wave-instructions each)
+// Binned scenes whose triangle order is spatially coherent (meshes: consecutive triangles are neighbours on the screen): the bin
+// lists are built without atomics on global memory, without a scan and without a second pass over all triangles -- k_blockscan
+// (rxr_kernels.hip).  k_setup3d leaves, per group of 64 consecutive triangles (a wave), the union of their bin ranges; one workgroup
+// per block of 4 x 4 bins keeps the groups whose range meets its block, then those groups' triangles whose range does (ids
+// and packed ranges in LDS), and deals them to its 16 bins, each bin owning RasterParams.blockscan_cap list slots.  A block that
+// would have to look into more than RXR_BLOCKSCAN_BLOCK_GROUPS groups or keep more than RXR_BLOCKSCAN_BLOCK_TRIS triangles, or
+// a bin with more candidates than slots, raises the overflow word: the frame is then rendered again through the general
+// pipeline (count / scan / fill), which the rest of the upload's launches use as well.
+#define RXR_BLOCKSCAN_GROUP 64u               // triangles per group = a wave of k_setup3d
+#define RXR_BLOCKSCAN_BLOCK_GROUPS 256u       // groups a block of bins looks into; more (an incoherent triangle order, a block under
+                                              // a dense cloud of small meshes) raises the overflow word
+#define RXR_BLOCKSCAN_GROUP_BLOCKS 64u        // scatter form: blocks of bins a group's range may meet; more raises the overflow word
+#define RXR_BLOCKSCAN_SCATTER_GROUPS 256u     // more groups than this: the scatter form
+#define RXR_BLOCKSCAN_MAX_WORK (48u << 20)    // groups x blocks of bins: phase 0 looks at every pair (~0.25 wave-instructions each)
 #define RXR_BLOCKSCAN_BLOCK_TRIS 2048u
 #define RXR_BLOCKSCAN_CAP 256u
 
@@ -225,6 +232,8 @@ struct RasterParams {
     // set-up outputs
     TriSetup *tri_setup;
     TriShade *tri_shade;
+    uint2 *group_rng;                  // k_blockscan: per wave of k_setup3d (64 consecutive triangles) the union of its triangles' bin ranges,
+                                       // packed like a triangle's (bx0 | bx1 << 16, l0 | l1 << 16); (1, 0) when no triangle of the group has one
     uint2 *tri_box;                    // (bx, by) of every TriSetup once more, densely: k_fill reads these 8 bytes instead of a 96-byte stride
     uint32_t *bin_count;           // tiles_x * tiles_y; all-zero between launches (k_raster clears its own bin)
     uint32_t *bin_offset;          // chunk-local exclusive scan of bin_count; add chunk_base[bin / RXR_SCAN_CHUNK]
@@ -235,6 +244,12 @@ struct RasterParams {
     uint32_t plain_programs;       // host only: the frame runs programs but needs none of level 1's chunk paths (k_raster_vm_p instead of k_raster_vm_sv)
     uint32_t relaxed_lights;       // host only: RXR_LIGHT_MATH=relaxed -- feature levels 0 and 1 launch the kernels whose 3D light loop uses the
                                    // relaxed arithmetic (k_raster_rl, k_raster_rows_rl, k_raster_chunk_rl; shade3d_lights<X, true>)
+    uint32_t blockscan_scatter;    // k_blockscan's phase 0 the other way round (many groups): every group has appended itself to the lists of the
+                                   // blocks its range meets (k_setup3d, at most RXR_BLOCKSCAN_GROUP_BLOCKS of them) instead of every block
+                                   // reading every group's range
+    uint32_t blk_wide_base;        // first slot of the list of "wide" groups (ranges over more than RXR_BLOCKSCAN_GROUP_BLOCKS blocks) in blk_grp
+    uint32_t *blk_cnt, *blk_grp;   // per block of bins: number of groups (all-zero between launches: k_blockscan hands it back) and their ids,
+                                   // RXR_BLOCKSCAN_BLOCK_GROUPS slots each
     uint32_t blockscan_cap;        // != 0: this launch bins with k_blockscan (k_setup3d counts nothing); list slots per bin
     uint32_t any_occluders;        // the frame has an occluder somewhere (mapmini's or a chunk's): get_occlusion compares world positions with their boxes
     float rl_flip_guard;           // relaxed light mode: the smallest |n.v| for which the normal's flip toward the camera is decided from the

@@ -1227,7 +1227,12 @@ __device__ __forceinline__ bool dead_slots_block(const RasterParams &P, uint32_t
 
 extern "C" __global__ void __launch_bounds__(256) k_setup3d(RasterParams P) {
     const uint32_t t0 = blockIdx.x * blockDim.x;
-    if (!P.blockscan_cap && dead_slots_block(P, t0)) return;  // (k_blockscan reads every slot's box: dead slots get their empty box below)
+    if (dead_slots_block(P, t0)) {
+        // (k_blockscan reads the boxes of listed groups only: these four groups just say that they are empty)
+        if (P.blockscan_cap && (threadIdx.x & 63u) == 0u && (blockIdx.x * 4u + (threadIdx.x >> 6)) * RXR_BLOCKSCAN_GROUP < P.n_tris3d)
+            P.group_rng[blockIdx.x * 4u + (threadIdx.x >> 6)] = make_uint2(1u, 0u);
+        return;
+    }
     uint32_t t = t0 + threadIdx.x;
     bool live = false;
     TriSetup S = {};
@@ -1247,6 +1252,8 @@ extern "C" __global__ void __launch_bounds__(256) k_setup3d(RasterParams P) {
         // the slots of an unclipped scene) only marks its records as empty
         if (!__syncthreads_or(live ? 1 : 0)) {
             if (t < P.n_tris3d) *reinterpret_cast<uint2 *>(&P.tri_setup[t].bx) = make_uint2(0u, 0u);
+            if (P.blockscan_cap && (threadIdx.x & 63u) == 0u && (blockIdx.x * 4u + (threadIdx.x >> 6)) * RXR_BLOCKSCAN_GROUP < P.n_tris3d)
+                P.group_rng[blockIdx.x * 4u + (threadIdx.x >> 6)] = make_uint2(1u, 0u);  // (empty groups)
             return;   // (nothing to bin either)
         }
         uint4 rec[6];
@@ -1283,7 +1290,42 @@ extern "C" __global__ void __launch_bounds__(256) k_setup3d(RasterParams P) {
         }
     }
 #endif
-    if (P.fused_small || P.blockscan_cap) return;  // small scenes are not binned (see scan_implicit), mid-sized ones by k_blockscan; uniform
+    if (P.blockscan_cap) {  // uniform: k_blockscan bins this launch -- every wave leaves it the union of its 64 triangles' bin ranges
+        uint32_t gx0 = 0xFFFFu, gx1 = 0u, gy0 = 0xFFFFu, gy1 = 0u;  // (empty: x0 > x1)
+        if (live) {
+            uint32_t bx0, bx1, l0, l1;
+            if (bin_range(P, S.bx & 0xFFFFu, S.bx >> 16, S.by & 0xFFFFu, S.by >> 16, bx0, bx1, l0, l1)) {
+                gx0 = bx0;
+                gx1 = bx1;
+                gy0 = l0;
+                gy1 = l1;
+            }
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            gx0 = min(gx0, (uint32_t)__shfl_xor((int)gx0, d, 64));
+            gx1 = max(gx1, (uint32_t)__shfl_xor((int)gx1, d, 64));
+            gy0 = min(gy0, (uint32_t)__shfl_xor((int)gy0, d, 64));
+            gy1 = max(gy1, (uint32_t)__shfl_xor((int)gy1, d, 64));
+        }
+        const uint32_t lane = threadIdx.x & 63u, g = blockIdx.x * 4u + (threadIdx.x >> 6);  // group = wave
+        if (g * RXR_BLOCKSCAN_GROUP >= P.n_tris3d) return;  // (wave-uniform: a wave behind the last triangle)
+        if (lane == 0u) P.group_rng[g] = gx0 <= gx1 ? make_uint2(gx0 | (gx1 << 16), gy0 | (gy1 << 16)) : make_uint2(1u, 0u);
+        if (P.blockscan_scatter && gx0 <= gx1) {  // uniform: the group appends itself to the list of every block of 4 x 4 bins its range meets
+            const uint32_t bx_lo = gx0 / 4u, by_lo = gy0 / 4u, w = gx1 / 4u - bx_lo + 1u, nbk = w * (gy1 / 4u - by_lo + 1u);
+            if (nbk > RXR_BLOCKSCAN_GROUP_BLOCKS) {
+                // a group all over the screen (triangles next to the camera): on the list every block looks through
+                // (counted in the launch's clean counter set, word CNT_TICKET: k_scan does not run in this mode)
+                if (lane == 0u) P.blk_grp[P.blk_wide_base + atomicAdd(&P.counters[CNT_TICKET], 1u)] = g;
+            } else if (lane < nbk) {  // one lane per block
+                const uint32_t b = (by_lo + lane / w) * ((P.tiles_x + 3u) / 4u) + bx_lo + lane % w;
+                const uint32_t pos = atomicAdd(&P.blk_cnt[b], 1u);
+                if (pos < RXR_BLOCKSCAN_BLOCK_GROUPS) P.blk_grp[(size_t)b * RXR_BLOCKSCAN_BLOCK_GROUPS + pos] = g;  // (else k_blockscan sees the count)
+            }
+        }
+        return;
+    }
+    if (P.fused_small) return;  // small scenes are not binned (see scan_implicit); uniform
     uint32_t bx0 = 0, bx1 = 0, by0 = 0, by1 = 0, nb = 0;
     if (live) {
         const uint32_t min_x = S.bx & 0xFFFFu, max_x = S.bx >> 16, min_y = S.by & 0xFFFFu, max_y = S.by >> 16;
@@ -1521,11 +1563,65 @@ extern "C" __global__ void __launch_bounds__(256) k_blockscan(RasterParams P) {
     const uint32_t blocks_x = (P.tiles_x + 3u) / 4u;
     const uint32_t bbx = blockIdx.x % blocks_x, bby = blockIdx.x / blocks_x;
     const uint32_t x_lo = bbx * 4u, x_hi = min(x_lo + 3u, P.tiles_x - 1u), y_lo = bby * 4u, y_hi = min(y_lo + 3u, P.tiles_y - 1u);
-    if (tid == 0) kept_n = 0u;
+    __shared__ uint32_t grp[RXR_BLOCKSCAN_BLOCK_GROUPS];
+    __shared__ uint32_t grp_n;
+    if (tid == 0) kept_n = grp_n = 0u;
     __syncthreads();
     const unsigned long long below = (1ull << lane) - 1ull;
-    for (uint32_t t0 = 0; t0 < P.n_tris3d; t0 += 256u) {  // uniform trip count
-        const uint32_t t = t0 + tid;
+    // phase 0: the groups (256 consecutive triangles, k_setup3d's workgroups) whose union of bin ranges meets this block
+    const uint32_t n_groups = (P.n_tris3d + RXR_BLOCKSCAN_GROUP - 1u) / RXR_BLOCKSCAN_GROUP;
+    if (P.blockscan_scatter) {  // uniform: the groups have listed themselves (k_setup3d); the count goes back zeroed
+        const uint32_t cnt = P.blk_cnt[blockIdx.x];
+        if (tid < min(cnt, (uint32_t)RXR_BLOCKSCAN_BLOCK_GROUPS)) grp[tid] = P.blk_grp[(size_t)blockIdx.x * RXR_BLOCKSCAN_BLOCK_GROUPS + tid];
+        __syncthreads();
+        if (tid == 0) {
+            grp_n = cnt;
+            if (cnt) P.blk_cnt[blockIdx.x] = 0u;
+        }
+        __syncthreads();
+        const uint32_t n_wide = P.counters[CNT_TICKET];
+        for (uint32_t w0 = 0; w0 < n_wide; w0 += 256u) {  // uniform trip count
+            bool hit = false;
+            uint32_t g = 0;
+            if (w0 + tid < n_wide) {
+                g = P.blk_grp[P.blk_wide_base + w0 + tid];
+                const uint2 r = P.group_rng[g];
+                hit = (r.x & 0xFFFFu) <= x_hi && (r.x >> 16) >= x_lo && (r.y & 0xFFFFu) <= y_hi && (r.y >> 16) >= y_lo;
+            }
+            const unsigned long long m = __ballot(hit);
+            if (m) {  // wave-uniform
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&grp_n, (uint32_t)__popcll(m));
+                base = (uint32_t)__shfl((int)base, 0, 64);
+                const uint32_t pos = base + (uint32_t)__popcll(m & below);
+                if (hit && pos < RXR_BLOCKSCAN_BLOCK_GROUPS) grp[pos] = g;
+            }
+        }
+        if (blockIdx.x == 0 && tid < CNT_WORDS) P.counters_next[tid] = 0u;  // (the set of the previous launch, as k_scan does)
+    } else
+    for (uint32_t g0 = 0; g0 < n_groups; g0 += 256u) {  // uniform trip count
+        const uint32_t g = g0 + tid;
+        bool hit = false;
+        if (g < n_groups) {
+            const uint2 r = P.group_rng[g];
+            hit = (r.x & 0xFFFFu) <= x_hi && (r.x >> 16) >= x_lo && (r.y & 0xFFFFu) <= y_hi && (r.y >> 16) >= y_lo;  // ((1, 0): never)
+        }
+        const unsigned long long m = __ballot(hit);
+        if (m) {  // wave-uniform
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&grp_n, (uint32_t)__popcll(m));
+            base = (uint32_t)__shfl((int)base, 0, 64);
+            const uint32_t pos = base + (uint32_t)__popcll(m & below);
+            if (hit && pos < RXR_BLOCKSCAN_BLOCK_GROUPS) grp[pos] = g;
+        }
+    }
+    __syncthreads();
+    const uint32_t n_grp_all = grp_n;
+    const uint32_t n_grp = min(n_grp_all, (uint32_t)RXR_BLOCKSCAN_BLOCK_GROUPS);
+    // phase 1: those groups' triangles whose own range meets the block (a group per wave and step)
+    for (uint32_t gi0 = 0; gi0 < n_grp; gi0 += 4u) {  // uniform trip count
+        const uint32_t gi = gi0 + wave;
+        const uint32_t t = gi < n_grp ? grp[gi] * RXR_BLOCKSCAN_GROUP + lane : 0xFFFFFFFFu;
         bool hit = false;
         uint2 rng = make_uint2(0u, 0u);
         if (t < P.n_tris3d) {
@@ -1551,7 +1647,7 @@ extern "C" __global__ void __launch_bounds__(256) k_blockscan(RasterParams P) {
     __syncthreads();
     const uint32_t n_kept_all = kept_n;
     const uint32_t n_kept = min(n_kept_all, (uint32_t)RXR_BLOCKSCAN_BLOCK_TRIS);
-    bool overflow = n_kept_all > RXR_BLOCKSCAN_BLOCK_TRIS;
+    bool overflow = n_kept_all > RXR_BLOCKSCAN_BLOCK_TRIS || n_grp_all > RXR_BLOCKSCAN_BLOCK_GROUPS;
     uint32_t worst = 0;
     for (uint32_t j = wave; j < 16u; j += 4u) {
         const uint32_t bx = x_lo + (j & 3u), by = y_lo + (j >> 2);
