@@ -1,4 +1,4 @@
-"""Mid-sized scenes (129 .. 4096 triangles): the bin lists built by k_blockscan (rusterix_amd/csrc/rxr_kernels.hip, rxr_device.h
+"""Binned scenes with a spatially coherent triangle order (meshes): the bin lists built by k_blockscan (rusterix_amd/csrc/rxr_kernels.hip, rxr_device.h
 RXR_BLOCKSCAN_*) instead of the general count / scan / fill pipeline.  The lists only have to name the same candidates per bin
 (the visibility pass is an arg-min over them: reference src/rasterizer.rs:1020-1060), so every frame must equal the general
 pipeline's frame and the oracle's byte for byte; a bin or a block of bins with more candidates than the kernel keeps must send
@@ -44,7 +44,8 @@ def test_a_full_bin_sends_the_frame_through_the_general_pipeline(oracle, product
     monkeypatch.setenv("RXR_BLOCKSCAN_CAP", str(cap))
     got = scenes.render(build(product)).copy()
     assert_exact(got, ref, f"teapot with {cap} slots per bin")
-    # a second frame through the same context: the fallback is per upload, the next one tries k_blockscan again
+    # a second frame through the same context: a frame of the same shape (triangles, bins) as one that overflowed goes straight
+    # to the general pipeline (a caller that uploads every frame must not pay the failed attempt every time)
     got2 = scenes.render(build(product)).copy()
     assert_exact(got2, ref, f"teapot with {cap} slots per bin, second frame")
 
@@ -82,3 +83,16 @@ def test_device_projected_mid_sized_scene(oracle, product):
         product.lib.rxh_set_device_projection(0)
     assert_exact(got, ref, "device-projected teapot")
     assert_exact(got2, ref, "device-projected teapot, second frame")
+
+
+def test_large_coherent_scene_takes_the_scatter_form(oracle, product, monkeypatch):
+    """more than 256 groups of 64 triangles: every group appends itself to the blocks of bins its range meets (k_setup3d), groups all
+    over the screen go to the wide list; 64 x 64 boxes = 49 152 triangles on a small frame"""
+    def build(api):
+        return scenes.box_grid_scene(api, n=64, width=1600, height=900)
+
+    ref = scenes.render(build(oracle)).copy()
+    got = scenes.render(build(product)).copy()
+    assert_exact(got, ref, "box grid 64 x 64")
+    monkeypatch.setenv("RXR_BLOCKSCAN", "0")
+    assert_exact(scenes.render(build(product)).copy(), got, "box grid 64 x 64: general pipeline vs k_blockscan")
