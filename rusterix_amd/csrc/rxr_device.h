@@ -233,7 +233,7 @@ struct RasterParams {
     TriSetup *tri_setup;
     TriShade *tri_shade;
     uint2 *group_rng;                  // k_blockscan: per wave of k_setup3d (64 consecutive triangles) the union of its triangles' bin ranges,
-                                       // packed like a triangle's (bx0 | bx1 << 16, l0 | l1 << 16); (1, 0) when no triangle of the group has one
+                                       // packed like a triangle's (bx0 | bx1 << 16, l0 | l1 << 16); (0xFFFF, 0xFFFF) -- first bin 65535, last bin 0 -- when no triangle of the group has one
     uint2 *tri_box;                    // (bx, by) of every TriSetup once more, densely: k_fill reads these 8 bytes instead of a 96-byte stride
     uint32_t *bin_count;           // tiles_x * tiles_y; all-zero between launches (k_raster clears its own bin)
     uint32_t *bin_offset;          // chunk-local exclusive scan of bin_count; add chunk_base[bin / RXR_SCAN_CHUNK]

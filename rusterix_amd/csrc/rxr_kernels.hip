@@ -1230,7 +1230,7 @@ extern "C" __global__ void __launch_bounds__(256) k_setup3d(RasterParams P) {
     if (dead_slots_block(P, t0)) {
         // (k_blockscan reads the boxes of listed groups only: these four groups just say that they are empty)
         if (P.blockscan_cap && (threadIdx.x & 63u) == 0u && (blockIdx.x * 4u + (threadIdx.x >> 6)) * RXR_BLOCKSCAN_GROUP < P.n_tris3d)
-            P.group_rng[blockIdx.x * 4u + (threadIdx.x >> 6)] = make_uint2(1u, 0u);
+            P.group_rng[blockIdx.x * 4u + (threadIdx.x >> 6)] = make_uint2(0xFFFFu, 0xFFFFu);
         return;
     }
     uint32_t t = t0 + threadIdx.x;
@@ -1253,7 +1253,7 @@ extern "C" __global__ void __launch_bounds__(256) k_setup3d(RasterParams P) {
         if (!__syncthreads_or(live ? 1 : 0)) {
             if (t < P.n_tris3d) *reinterpret_cast<uint2 *>(&P.tri_setup[t].bx) = make_uint2(0u, 0u);
             if (P.blockscan_cap && (threadIdx.x & 63u) == 0u && (blockIdx.x * 4u + (threadIdx.x >> 6)) * RXR_BLOCKSCAN_GROUP < P.n_tris3d)
-                P.group_rng[blockIdx.x * 4u + (threadIdx.x >> 6)] = make_uint2(1u, 0u);  // (empty groups)
+                P.group_rng[blockIdx.x * 4u + (threadIdx.x >> 6)] = make_uint2(0xFFFFu, 0xFFFFu);  // (empty groups)
             return;   // (nothing to bin either)
         }
         uint4 rec[6];
@@ -1310,7 +1310,7 @@ extern "C" __global__ void __launch_bounds__(256) k_setup3d(RasterParams P) {
         }
         const uint32_t lane = threadIdx.x & 63u, g = blockIdx.x * 4u + (threadIdx.x >> 6);  // group = wave
         if (g * RXR_BLOCKSCAN_GROUP >= P.n_tris3d) return;  // (wave-uniform: a wave behind the last triangle)
-        if (lane == 0u) P.group_rng[g] = gx0 <= gx1 ? make_uint2(gx0 | (gx1 << 16), gy0 | (gy1 << 16)) : make_uint2(1u, 0u);
+        if (lane == 0u) P.group_rng[g] = gx0 <= gx1 ? make_uint2(gx0 | (gx1 << 16), gy0 | (gy1 << 16)) : make_uint2(0xFFFFu, 0xFFFFu);
         if (P.blockscan_scatter && gx0 <= gx1) {  // uniform: the group appends itself to the list of every block of 4 x 4 bins its range meets
             const uint32_t bx_lo = gx0 / 4u, by_lo = gy0 / 4u, w = gx1 / 4u - bx_lo + 1u, nbk = w * (gy1 / 4u - by_lo + 1u);
             if (nbk > RXR_BLOCKSCAN_GROUP_BLOCKS) {
@@ -1604,7 +1604,7 @@ extern "C" __global__ void __launch_bounds__(256) k_blockscan(RasterParams P) {
         bool hit = false;
         if (g < n_groups) {
             const uint2 r = P.group_rng[g];
-            hit = (r.x & 0xFFFFu) <= x_hi && (r.x >> 16) >= x_lo && (r.y & 0xFFFFu) <= y_hi && (r.y >> 16) >= y_lo;  // ((1, 0): never)
+            hit = (r.x & 0xFFFFu) <= x_hi && (r.x >> 16) >= x_lo && (r.y & 0xFFFFu) <= y_hi && (r.y >> 16) >= y_lo;  // (an empty group: first bin 65535)
         }
         const unsigned long long m = __ballot(hit);
         if (m) {  // wave-uniform

@@ -70,6 +70,21 @@ def test_stripes_and_bands_of_a_mid_sized_scene(product):
     assert_exact(out, full, "three bands")
 
 
+def test_empty_groups_are_listed_nowhere(oracle, product):
+    """regression: the mark of a group without a bin range once passed the overlap test of the block at the origin; with device
+    projection the unused slots behind a mesh keep the boxes of the PREVIOUS frame, and those triangles came back in the top left
+    corner.  A 6000-triangle mesh first, then the device-projected teapot."""
+    scenes.render(scenes.small_triangle_mesh_scene(product, width=640, height=400, n_triangles=6000))
+    build = builders()["teapot 960x540"]
+    ref = scenes.render(build(oracle)).copy()
+    product.lib.rxh_set_device_projection(1)
+    try:
+        got = scenes.render(build(product)).copy()
+    finally:
+        product.lib.rxh_set_device_projection(0)
+    assert_exact(got, ref, "device-projected teapot after a larger mesh")
+
+
 def test_device_projected_mid_sized_scene(oracle, product):
     """N1 + k_blockscan: the capacity-based triangle pools leave unused slots behind every mesh; k_setup3d gives them empty boxes
     in this mode (the general pipeline skips whole workgroups of them instead)"""
