@@ -49,14 +49,14 @@ FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 vector (FMA coun
 PROFILES = {
     "relaxed": {
         "source": "profiles/r02/bench_relaxed_pmc_summary.json (tools/profile_bench.sh; rocprofv3 --pmc, separate passes; kernel k_raster_rl)",
-        "write_bytes": 33177600,       # WRITE_SIZE: exactly the framebuffer (3840 * 2160 * 4)
-        "fetch_bytes_x2": 2193990,     # FETCH_SIZE with the gfx950 x2 correction
-        "valu_wave_instructions": 94162981,
+        "write_bytes": 35545373,       # WRITE_SIZE: the framebuffer (3840 * 2160 * 4 = 33 177 600) + 2.4 MB of spill traffic (8 B of scratch per lane)
+        "fetch_bytes_x2": 2235492,     # FETCH_SIZE with the gfx950 x2 correction
+        "valu_wave_instructions": 94031796,
     },
     "exact": {
         "source": "profiles/r02/bench_relaxed_pmc_summary.json (the same passes: bench.py times the exact mode as well; kernel k_raster)",
         "write_bytes": 33177600,
-        "fetch_bytes_x2": 2185971,
+        "fetch_bytes_x2": 2154732,
         "valu_wave_instructions": 148910581,
     },
 }
