@@ -1557,7 +1557,7 @@ extern "C" __global__ void __launch_bounds__(256) k_fill(RasterParams P) {
 // =================================================================================================
 extern "C" __global__ void __launch_bounds__(256) k_blockscan(RasterParams P) {
     __shared__ uint32_t kept_id[RXR_BLOCKSCAN_BLOCK_TRIS];
-    __shared__ uint2 kept_rng[RXR_BLOCKSCAN_BLOCK_TRIS];
+    __shared__ uint8_t kept_rng[RXR_BLOCKSCAN_BLOCK_TRIS];  // the bin range clipped to the block, two bits per bound: x0 | x1 << 2 | y0 << 4 | y1 << 6
     __shared__ uint32_t kept_n;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t blocks_x = (P.tiles_x + 3u) / 4u;
@@ -1623,13 +1623,13 @@ extern "C" __global__ void __launch_bounds__(256) k_blockscan(RasterParams P) {
         const uint32_t gi = gi0 + wave;
         const uint32_t t = gi < n_grp ? grp[gi] * RXR_BLOCKSCAN_GROUP + lane : 0xFFFFFFFFu;
         bool hit = false;
-        uint2 rng = make_uint2(0u, 0u);
+        uint32_t rng = 0u;
         if (t < P.n_tris3d) {
             const uint2 box = P.tri_box[t];
             uint32_t bx0, bx1, l0, l1;
             if (bin_range(P, box.x & 0xFFFFu, box.x >> 16, box.y & 0xFFFFu, box.y >> 16, bx0, bx1, l0, l1)) {
                 hit = bx0 <= x_hi && bx1 >= x_lo && l0 <= y_hi && l1 >= y_lo;
-                rng = make_uint2(bx0 | (bx1 << 16), l0 | (l1 << 16));
+                rng = (max(bx0, x_lo) - x_lo) | ((min(bx1, x_hi) - x_lo) << 2) | ((max(l0, y_lo) - y_lo) << 4) | ((min(l1, y_hi) - y_lo) << 6);
             }
         }
         const unsigned long long m = __ballot(hit);
@@ -1640,7 +1640,7 @@ extern "C" __global__ void __launch_bounds__(256) k_blockscan(RasterParams P) {
             const uint32_t pos = base + (uint32_t)__popcll(m & below);
             if (hit && pos < RXR_BLOCKSCAN_BLOCK_TRIS) {
                 kept_id[pos] = t;
-                kept_rng[pos] = rng;
+                kept_rng[pos] = (uint8_t)rng;
             }
         }
     }
@@ -1660,8 +1660,8 @@ extern "C" __global__ void __launch_bounds__(256) k_blockscan(RasterParams P) {
             bool in = false;
             uint32_t id = 0;
             if (k < n_kept) {
-                const uint2 r = kept_rng[k];
-                in = bx >= (r.x & 0xFFFFu) && bx <= (r.x >> 16) && by >= (r.y & 0xFFFFu) && by <= (r.y >> 16);
+                const uint32_t r = kept_rng[k];
+                in = (j & 3u) >= (r & 3u) && (j & 3u) <= ((r >> 2) & 3u) && (j >> 2) >= ((r >> 4) & 3u) && (j >> 2) <= (r >> 6);
                 id = kept_id[k];
             }
             const unsigned long long m = __ballot(in);
