@@ -81,6 +81,11 @@ def parse_args():
     ap.add_argument("--exchange", choices=["gather", "allgather", "rotate"], default="gather",
                     help="N>1: gather the stripes to rank 0 (default, what the north-star asks for), all-gather them, or gather frame i "
                          "to rank i mod N (every frame still whole on one GPU, but no single GPU's links carry every frame)")
+    ap.add_argument("--comms", type=int, default=1,
+                    help="N > 1: communicators over all ranks, frame i's exchange on communicator i mod comms (with --exchange rotate the gathers of "
+                         "consecutive frames go to different roots over disjoint xGMI links and can overlap); default 1")
+    ap.add_argument("--depth", type=int, default=1,
+                    help="N > 1: frames between the start of a frame's exchange and the wait for it (depth + 1 stripe / frame buffers); default 1")
     ap.add_argument("--force-gather", action="store_true",
                     help="debug: run the stripe -> gather -> assemble path even at N=1 (never used by the driver)")
     return ap.parse_args()
@@ -178,12 +183,13 @@ def main():
     spr = D.stripes_per_rank(H, world)
     stripe_rows = spr * D.TILE_H
     # double-buffered outputs so that frame i+1 can render while frame i is being gathered
-    NBUF = 2
+    depth = max(1, args.depth)
+    NBUF = depth + 1
     sharded = world > 1 or args.force_gather
     if not sharded:
         frames = [torch.empty((H, W, 4), dtype=torch.uint8, device="cuda") for _ in range(NBUF)]
     else:
-        gather = D.StripeGather(H, W, world, rank, device="cuda", nbuf=NBUF, mode=args.exchange, host_staged=REHEARSAL)
+        gather = D.StripeGather(H, W, world, rank, device="cuda", nbuf=NBUF, mode=args.exchange, host_staged=REHEARSAL, comms=max(1, args.comms))
         frames = gather.frames  # None on ranks that do not own the frame (gather mode: only rank 0 does)
 
     def run(n):
@@ -197,10 +203,11 @@ def main():
                 # this rank's stripes -> compact band -> RCCL gather to rank 0 over xGMI -> de-interleave
                 check(rxr.rxr_render_stripes_to(ctx, rank, world, C.c_void_p(gather.band(i).data_ptr()), sptr))
                 gather.exchange_begin(i)
-                if i > 0:
-                    gather.exchange_end(i - 1)
-        if sharded and n > 0:
-            gather.exchange_end(n - 1)
+                if i >= depth:
+                    gather.exchange_end(i - depth)
+        if sharded:
+            for i in range(max(0, n - depth), n):
+                gather.exchange_end(i)
 
     def fence():
         torch.cuda.synchronize()
@@ -332,7 +339,7 @@ def main():
                 "light_math": "relaxed" if relaxed else "exact",
                 "sharding": "single GPU" if world == 1 else f"interleaved 16-row stripes over {world} GPUs (one process per GPU) + RCCL {args.exchange} "
                                                            + ("to rank (frame mod N)" if args.exchange == "rotate" else "to rank 0")
-                                                           + " over xGMI, pipelined with the next frame's render",
+                                                           + f" over xGMI, pipelined with the next frame's render ({max(1, args.comms)} communicator(s), {depth} frame(s) in flight)",
             },
             "roofline": {
                 "bound": "hbm",

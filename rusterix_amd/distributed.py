@@ -75,8 +75,18 @@ class StripeGather:
     """
 
     def __init__(self, height: int, width: int, world: int, rank: int, device, nbuf: int = 2, mode: str = "gather", root: int = 0,
-                 host_staged: bool = False):
+                 host_staged: bool = False, comms: int = 1):
         import torch
+        import torch.distributed as dist
+
+        # comms > 1: that many process groups (communicators) over all ranks, frame i's collective on group i mod comms.  One
+        # communicator runs its collectives one after the other on its own stream; with rotating roots that leaves all links but
+        # the current root's idle.  Several communicators let consecutive frames' gathers -- to DIFFERENT roots, over disjoint
+        # links -- be in flight together (the caller keeps `depth` frames between exchange_begin and exchange_end; nbuf > depth).
+        # Every rank creates the groups in the same order and issues frame i's collective on the same group: the order the
+        # backend needs.  Untested on xGMI hardware (no multi-GPU box in this build environment); opt-in.
+        assert comms >= 1
+        self.groups = [None] if comms == 1 or world == 1 else [dist.new_group(list(range(world))) for _ in range(comms)]
 
         assert mode in ("gather", "allgather", "rotate")
         self.h, self.w, self.world, self.rank, self.mode, self.root = height, width, world, rank, mode, root
@@ -126,19 +136,20 @@ class StripeGather:
             mine = self.bands[b].cpu()
             if self.mode == "allgather":
                 parts = [torch.empty_like(mine) for _ in range(self.world)]
-                dist.all_gather(parts, mine)
+                dist.all_gather(parts, mine, group=self.groups[i % len(self.groups)])
             else:
                 root = self.root_of(i)
                 parts = [torch.empty_like(mine) for _ in range(self.world)] if self.rank == root else None
-                dist.gather(mine, parts, dst=root)
+                dist.gather(mine, parts, dst=root, group=self.groups[i % len(self.groups)])
             if parts is not None:
                 for r in range(self.world):
                     self.slots[b][r].copy_(parts[r])
         elif self.mode == "allgather":
-            self._work[b] = dist.all_gather_into_tensor(self.gathered[b], self.bands[b], async_op=True)
+            self._work[b] = dist.all_gather_into_tensor(self.gathered[b], self.bands[b], group=self.groups[i % len(self.groups)], async_op=True)
         else:
             root = self.root_of(i)
-            self._work[b] = dist.gather(self.bands[b], self.slots[b] if self.rank == root else None, dst=root, async_op=True)
+            self._work[b] = dist.gather(self.bands[b], self.slots[b] if self.rank == root else None, dst=root,
+                                        group=self.groups[i % len(self.groups)], async_op=True)
 
     def exchange_end(self, i):
         b = i % self.nbuf

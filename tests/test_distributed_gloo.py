@@ -22,15 +22,15 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, frame, result_dir, mode):
+def _worker(rank, world, port, frame, result_dir, mode, comms=1, depth=1):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         h, w = frame.shape[0], frame.shape[1]
-        g = D.StripeGather(h, w, world, rank, device="cpu", mode=mode)
+        g = D.StripeGather(h, w, world, rank, device="cpu", mode=mode, comms=comms, nbuf=depth + 1)
         ok = True
-        n = 5
+        n = 5 if depth == 1 else 11
 
         def want(i):
             return np.roll(frame, i * 5, axis=1)
@@ -42,13 +42,14 @@ def _worker(rank, world, port, frame, result_dir, mode):
             else:
                 ok &= out is None
 
-        # the same pipelined loop bench.py runs: render(i); begin(i); end(i-1)
+        # the same pipelined loop bench.py runs: render(i); begin(i); end(i - depth)
         for i in range(n):
             g.band(i).copy_(torch.from_numpy(D.extract_stripes(want(i), world, rank)))
             g.exchange_begin(i)
-            if i > 0:
-                check(i - 1, g.exchange_end(i - 1))
-        check(n - 1, g.exchange_end(n - 1))
+            if i >= depth:
+                check(i - depth, g.exchange_end(i - depth))
+        for i in range(max(0, n - depth), n):
+            check(i, g.exchange_end(i))
         # and the blocking form
         g.band(0).copy_(torch.from_numpy(D.extract_stripes(frame, world, rank)))
         check(0, g.exchange(0))
@@ -72,6 +73,19 @@ def test_stripe_exchange_roundtrip(tmp_path, oracle, world, size, mode):
         assert ok, f"rank {r} assembled a wrong frame"
         owners += int(owns)
     assert owners == (world if mode in ("allgather", "rotate") else 1)
+
+
+@pytest.mark.parametrize("world,comms,depth,mode", [(2, 2, 2, "rotate"), (3, 3, 3, "rotate"), (3, 2, 2, "gather")])
+def test_several_communicators_and_a_deeper_pipeline(tmp_path, oracle, world, comms, depth, mode):
+    """frame i's collective on communicator i mod comms, `depth` frames in flight between exchange_begin and exchange_end
+    (depth + 1 buffers): every frame still arrives whole on its root"""
+    from rusterix_amd import scenes
+
+    frame = scenes.render(scenes.map_scene(oracle, width=56, height=100, logo_size=16, n_lights=1)).copy()
+    mp.spawn(_worker, args=(world, _free_port(), frame, str(tmp_path), mode, comms, depth), nprocs=world, join=True)
+    for r in range(world):
+        ok, _ = np.load(tmp_path / f"ok{r}.npy")
+        assert ok, f"rank {r} assembled a wrong frame"
 
 
 def test_partition_covers_every_row_once():

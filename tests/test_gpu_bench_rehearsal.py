@@ -13,13 +13,14 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("world,exchange", [(2, "gather"), (3, "allgather"), (3, "rotate")])
-def test_bench_runs_its_multi_rank_path(world, exchange):
+@pytest.mark.parametrize("world,exchange,extra", [(2, "gather", []), (3, "allgather", []), (3, "rotate", []),
+                                                  (3, "rotate", ["--comms", "3", "--depth", "2"])])   # several communicators, two frames in flight
+def test_bench_runs_its_multi_rank_path(world, exchange, extra):
     env = dict(os.environ, RXR_BENCH_REHEARSAL="1", RXR_BENCH_MIN_TIMED_S="0.05")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         env.pop(k, None)
     pr = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "6", "--warmup", "2", "--no-cpu",
-                         "--width", "1280", "--height", "720", "--exchange", exchange], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+                         "--width", "1280", "--height", "720", "--exchange", exchange] + extra, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert pr.returncode == 0, pr.stdout[-2000:] + pr.stderr[-4000:]
     lines = [l for l in pr.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, pr.stdout
