@@ -28,6 +28,7 @@ extern "C" void rxr_launch_bin2d_count(const RasterParams *P, hipStream_t s);
 extern "C" void rxr_launch_bin2d_fill(const RasterParams *P, hipStream_t s);
 extern "C" void rxr_launch_fill(const RasterParams *P, hipStream_t s);
 extern "C" void rxr_launch_blockscan(const RasterParams *P, hipStream_t s);
+extern "C" void rxr_launch_blockscan2d(const RasterParams *P, hipStream_t s);
 extern "C" void rxr_launch_raster(const RasterParams *P, hipStream_t s);
 extern "C" void rxr_launch_selftest_math(uint64_t seed, uint32_t blocks, uint32_t iters, unsigned long long *mismatch, hipStream_t s);
 
@@ -1077,6 +1078,15 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
         if ((rc = ensure(ctx, ctx->d_bins2d, (2 * (n_bins + 1) + 2 * n_chunks + 8) * sizeof(uint32_t))) != RXR_OK) return rc;
         if ((rc = ensure(ctx, ctx->d_large2d, p2cur * sizeof(uint32_t))) != RXR_OK) return rc;
         size_t want2d = ctx->list_floor ? ctx->list_floor : std::max<size_t>(1u << 18, p2cur * 8);
+        // k_blockscan2d: every bin its own run of RXR_BLOCKSCAN_CAP slots, lists in submission order (no sort per tile)
+        {
+            bool on = true;
+            if (const char *bs = getenv("RXR_BLOCKSCAN2D")) on = bs[0] != '0';
+            ctx->blockscan2d_off = !(on && !ctx->list_floor && p2cur * n_blocks <= RXR_BLOCKSCAN_MAX_WORK / 4u &&
+                                     (size_t)n_bins * RXR_BLOCKSCAN_CAP <= (64u << 20)) ||
+                                   (ctx->blockscan2d_bad_prims == p2cur && ctx->blockscan2d_bad_bins == n_bins);
+            if (!ctx->blockscan2d_off) want2d = std::max<size_t>(want2d, (size_t)n_bins * RXR_BLOCKSCAN_CAP);
+        }
         if (want2d > ctx->list2d_capacity) {
             if ((rc = ensure(ctx, ctx->d_list2d, want2d * sizeof(uint32_t))) != RXR_OK) return rc;
             ctx->list2d_capacity = (uint32_t)std::min<size_t>(ctx->d_list2d.cap / sizeof(uint32_t), 0xFFFFFFF0u);
@@ -1383,6 +1393,13 @@ static int render_impl(rxr_ctx *ctx, const RenderSpec &spec, void *dev_pixels, h
             HIPCHK(ctx, hipMemsetAsync((uint32_t *)ctx->d_counters.p + 2 * CNT_WORDS, 0, 2 * CNT_WORDS * sizeof(uint32_t), s));
         }
         ctx->scratch2d_dirty = true;
+        const bool blockscan2d = !ctx->blockscan2d_off && (size_t)n_bins * RXR_BLOCKSCAN_CAP <= (size_t)P.list2d_capacity;
+        ctx->last_used_blockscan2d = blockscan2d;
+        if (blockscan2d) {  // the counters stay clean (no large list, no ticket); the raster kernel skips its per-tile sort
+            P.blockscan2d_cap = RXR_BLOCKSCAN_CAP;
+            P.counters2d = (uint32_t *)ctx->d_counters.p + (size_t)(2u + ctx->parity2d) * CNT_WORDS;
+            rxr_launch_blockscan2d(&P, s);
+        } else {
         P.counters2d = (uint32_t *)ctx->d_counters.p + (size_t)(2u + ctx->parity2d) * CNT_WORDS;
         P.counters2d_next = (uint32_t *)ctx->d_counters.p + (size_t)(2u + (ctx->parity2d ^ 1u)) * CNT_WORDS;
         ctx->parity2d ^= 1u;
@@ -1400,6 +1417,7 @@ static int render_impl(rxr_ctx *ctx, const RenderSpec &spec, void *dev_pixels, h
         A.host_status = P.host_status2d;
         rxr_launch_scan(&A, s);
         rxr_launch_bin2d_fill(&P, s);
+        }
     }
     if (timed) HIPCHK(ctx, hipEventRecord(e1, s));
     if (!rxr_jit_launch(ctx, &P, s)) rxr_launch_raster(&P, s);
@@ -1581,7 +1599,13 @@ int rxr_synchronize(rxr_ctx *ctx) {
         }
         if (launches > 1u) earlier_incomplete = true;
         int rc;
-        if (over2d) {
+        if (over2d && ctx->last_used_blockscan2d) {
+            // a block of bins or a bin had more 2D primitives than k_blockscan2d keeps: count / scan / fill (and the per-tile sort) for this frame
+            ctx->blockscan2d_off = true;
+            ctx->blockscan2d_bad_prims = ctx->P.n_prims2d;
+            ctx->blockscan2d_bad_bins = (size_t)ctx->P.tiles_x * ((ctx->P.height + RXR_TILE_H - 1) / RXR_TILE_H);
+            hc[CNT_WORDS + CNT_OVERFLOW] = hc[CNT_WORDS + HS_MAX_ENTRIES] = 0;
+        } else if (over2d) {
             const size_t seen = std::max(hc[CNT_WORDS + HS_MAX_ENTRIES], hc[CNT_WORDS + CNT_ENTRIES]);
             if ((rc = ensure(ctx, ctx->d_list2d, (seen + seen / 2 + 1024) * sizeof(uint32_t))) != RXR_OK) return rc;
             ctx->list2d_capacity = (uint32_t)std::min<size_t>(ctx->d_list2d.cap / sizeof(uint32_t), 0xFFFFFFF0u);

@@ -107,6 +107,8 @@ struct rxr_ctx {
     size_t blockscan_bad_tris = 0, blockscan_bad_bins = 0;  // the (triangles, bins) of the last frame that overflowed k_blockscan: frames of
                                                             // the same shape do not try again (a caller that uploads every frame would pay
                                                             // the failed attempt and the second rendering every time)
+    bool blockscan2d_off = false, last_used_blockscan2d = false;  // the same for the 2D bins (k_blockscan2d); RXR_BLOCKSCAN2D=0 turns it off
+    size_t blockscan2d_bad_prims = 0, blockscan2d_bad_bins = 0;
     uint32_t blockscan_cap = 0;           // RXR_BLOCKSCAN_CAP in effect
     bool relaxed_lights = true;           // rxr_set_light_math / RXR_LIGHT_MATH: the 3D light loop in relaxed arithmetic (RasterParams.relaxed_lights)
     bool frame_needs_chunk_paths = true;  // the uploaded frame uses what feature level 1 adds (terrain / baked textures / staircase / editor paths)

@@ -250,6 +250,8 @@ struct RasterParams {
     uint32_t blk_wide_base;        // first slot of the list of "wide" groups (ranges over more than RXR_BLOCKSCAN_GROUP_BLOCKS blocks) in blk_grp
     uint32_t *blk_cnt, *blk_grp;   // per block of bins: number of groups (all-zero between launches: k_blockscan hands it back) and their ids,
                                    // RXR_BLOCKSCAN_BLOCK_GROUPS slots each
+    uint32_t blockscan2d_cap;      // != 0: the 2D bin lists of this launch come from k_blockscan2d -- slots per bin; the lists are SORTED by primitive
+                                   // index (submission order) and there is no list of large primitives: the raster kernel skips its per-tile sort
     uint32_t blockscan_cap;        // != 0: this launch bins with k_blockscan (k_setup3d counts nothing); list slots per bin
     uint32_t any_occluders;        // the frame has an occluder somewhere (mapmini's or a chunk's): get_occlusion compares world positions with their boxes
     float rl_flip_guard;           // relaxed light mode: the smallest |n.v| for which the normal's flip toward the camera is decided from the

@@ -1695,6 +1695,83 @@ __device__ __forceinline__ bool prim2d_bins(const RasterParams &P, const Prim2D 
 }
 }  // namespace
 
+// k_blockscan2d: the 2D bin lists without atomics, a scan or a second pass, and IN SUBMISSION ORDER -- what the ordered blending of
+// d2_rasterize needs (rasterizer.rs:876-895) and what the general pipeline restores with a bitonic sort in every tile.  One workgroup
+// per block of 4 x 4 bins walks all primitives in index order, 256 per step; the step's hits get consecutive places in LDS (wave
+// counts through LDS, ballot + popcount inside a wave), so the kept list -- and every bin's list dealt from it -- is sorted.
+// Leaves bin2d_count / bin2d_offset (+ a zero chunk base) like k_scan / k_bin2d_fill; overflow of the block (RXR_BLOCKSCAN_BLOCK_TRIS)
+// or of a bin's slots raises the 2D overflow word and the frame is rendered again through the general pipeline.
+extern "C" __global__ void __launch_bounds__(256) k_blockscan2d(RasterParams P) {
+    __shared__ uint32_t kept_id[RXR_BLOCKSCAN_BLOCK_TRIS];
+    __shared__ uint8_t kept_rng[RXR_BLOCKSCAN_BLOCK_TRIS];  // bin range clipped to the block: x0 | x1 << 2 | y0 << 4 | y1 << 6
+    __shared__ uint32_t wave_cnt[4];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t blocks_x = (P.tiles_x + 3u) / 4u;
+    const uint32_t bbx = blockIdx.x % blocks_x, bby = blockIdx.x / blocks_x;
+    const uint32_t x_lo = bbx * 4u, x_hi = min(x_lo + 3u, P.tiles_x - 1u), y_lo = bby * 4u, y_hi = min(y_lo + 3u, P.tiles_y - 1u);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    uint32_t running = 0;  // uniform: primitives kept so far
+    for (uint32_t t0 = 0; t0 < P.n_prims2d; t0 += 256u) {  // uniform trip count
+        const uint32_t t = t0 + tid;
+        bool hit = false;
+        uint32_t rng = 0u;
+        if (t < P.n_prims2d) {
+            uint32_t bx0, bx1, l0, l1;
+            if (prim2d_bins(P, P.prim2d[t], bx0, bx1, l0, l1)) {
+                hit = bx0 <= x_hi && bx1 >= x_lo && l0 <= y_hi && l1 >= y_lo;
+                rng = (max(bx0, x_lo) - x_lo) | ((min(bx1, x_hi) - x_lo) << 2) | ((max(l0, y_lo) - y_lo) << 4) | ((min(l1, y_hi) - y_lo) << 6);
+            }
+        }
+        const unsigned long long m = __ballot(hit);
+        if (lane == 0) wave_cnt[wave] = (uint32_t)__popcll(m);
+        __syncthreads();
+        uint32_t off = running, total = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < 4u; ++w) {
+            const uint32_t c = wave_cnt[w];
+            if (w < wave) off += c;
+            total += c;
+        }
+        const uint32_t pos = off + (uint32_t)__popcll(m & below);
+        if (hit && pos < RXR_BLOCKSCAN_BLOCK_TRIS) {
+            kept_id[pos] = t;
+            kept_rng[pos] = (uint8_t)rng;
+        }
+        running += total;
+        __syncthreads();  // (wave_cnt is rewritten by the next step; the last one publishes the kept list)
+    }
+    const uint32_t n_kept = min(running, (uint32_t)RXR_BLOCKSCAN_BLOCK_TRIS);
+    bool overflow = running > RXR_BLOCKSCAN_BLOCK_TRIS;
+    for (uint32_t j = wave; j < 16u; j += 4u) {
+        const uint32_t bx = x_lo + (j & 3u), by = y_lo + (j >> 2);
+        if (bx > x_hi || by > y_hi) continue;  // wave-uniform
+        const uint32_t bin = by * P.tiles_x + bx;
+        const uint32_t first = bin * P.blockscan2d_cap;
+        uint32_t cnt = 0;
+        for (uint32_t k0 = 0; k0 < n_kept; k0 += 64u) {
+            const uint32_t k = k0 + lane;
+            bool in = false;
+            uint32_t id = 0;
+            if (k < n_kept) {
+                const uint32_t r = kept_rng[k];
+                in = (j & 3u) >= (r & 3u) && (j & 3u) <= ((r >> 2) & 3u) && (j >> 2) >= ((r >> 4) & 3u) && (j >> 2) <= (r >> 6);
+                id = kept_id[k];
+            }
+            const unsigned long long m = __ballot(in);
+            const uint32_t pos = cnt + (uint32_t)__popcll(m & below);
+            if (in && pos < P.blockscan2d_cap && first + pos < P.list2d_capacity) P.bin2d_list[first + pos] = id;
+            cnt += (uint32_t)__popcll(m);
+        }
+        if (cnt > P.blockscan2d_cap) overflow = true;
+        if (lane == 0) {
+            P.bin2d_count[bin] = min(cnt, P.blockscan2d_cap);
+            P.bin2d_offset[bin] = first;
+            if (bin % RXR_SCAN_CHUNK == 0u) P.chunk2d_base[bin / RXR_SCAN_CHUNK] = 0u;
+        }
+    }
+    if (overflow && lane == 0) P.host_status2d[CNT_OVERFLOW] = 1u;
+}
+
 extern "C" __global__ void __launch_bounds__(256) k_bin2d_count(RasterParams P) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= P.n_prims2d) return;
@@ -2717,7 +2794,7 @@ __device__ __forceinline__ void raster_tile(const RasterParams &P) {
             }
             __syncthreads();
             const uint32_t c0 = s_bin[0], c1 = s_bin[1];
-            const uint32_t n_large = min(P.counters2d[CNT_LARGE], P.n_prims2d);
+            const uint32_t n_large = P.blockscan2d_cap ? 0u : min(P.counters2d[CNT_LARGE], P.n_prims2d);  // (k_blockscan2d keeps no such list)
             const uint32_t total = n_large + (c1 - c0);
             for (uint32_t base = 0; base < total; base += RXR_TILE_THREADS) {
                 const uint32_t e = base + tid;
@@ -2754,6 +2831,9 @@ __device__ __forceinline__ void raster_tile(const RasterParams &P) {
             if (n_cand > RXR_SORT2D_MAX) {
                 // more candidates than the LDS sort holds: walk every primitive in order (correct, slow)
                 color = walk_prims2d<X>(P, stage, nullptr, P.n_prims2d, true, px, py, fx, fy, color);
+            } else if (P.blockscan2d_cap) {
+                // k_blockscan2d's lists are in submission order already, and the gather above keeps the order
+                color = walk_prims2d<X>(P, stage, s_sort, n_cand, false, px, py, fx, fy, color);
             } else {
                 // bitonic sort of s_sort[0 .. n_cand) padded to the next power of two with 0xFFFFFFFF
                 uint32_t n2 = 1;
@@ -2901,6 +2981,11 @@ extern "C" void rxr_launch_blockscan(const RasterParams *P, hipStream_t s) {
     if (P->n_tris3d == 0 || P->tiles_x * P->tiles_y == 0) return;
     const uint32_t blocks = ((P->tiles_x + 3u) / 4u) * ((P->tiles_y + 3u) / 4u);
     hipLaunchKernelGGL(k_blockscan, dim3(blocks), dim3(256), 0, s, *P);
+}
+extern "C" void rxr_launch_blockscan2d(const RasterParams *P, hipStream_t s) {
+    if (P->n_prims2d == 0 || P->tiles_x * P->tiles_y == 0) return;
+    const uint32_t blocks = ((P->tiles_x + 3u) / 4u) * ((P->tiles_y + 3u) / 4u);
+    hipLaunchKernelGGL(k_blockscan2d, dim3(blocks), dim3(256), 0, s, *P);
 }
 extern "C" void rxr_launch_fill(const RasterParams *P, hipStream_t s) {
     if (P->n_tris3d == 0) return;

@@ -111,3 +111,26 @@ def test_large_coherent_scene_takes_the_scatter_form(oracle, product, monkeypatc
     assert_exact(got, ref, "box grid 64 x 64")
     monkeypatch.setenv("RXR_BLOCKSCAN", "0")
     assert_exact(scenes.render(build(product)).copy(), got, "box grid 64 x 64: general pipeline vs k_blockscan")
+
+
+# ---- the 2D bins (k_blockscan2d): lists in submission order, no per-tile sort ---------------------------------------------
+@pytest.mark.parametrize("kw", [dict(), dict(width=333, height=211, nx=17, ny=11), dict(width=1920, height=1080, nx=60, ny=34),
+                                dict(lights=False, lines=False), dict(stacked=200, nx=12, ny=8)])
+def test_2d_tile_maps_through_the_block_scan(oracle, product, monkeypatch, kw):
+    """ordered 2D blending (reference src/rasterizer.rs:876-895): the lists k_blockscan2d leaves are already in submission
+    order; the frame must equal the general pipeline's (count / scan / fill + a bitonic sort per tile) and the oracle's"""
+    ref = scenes.render(scenes.tile_map_2d_scene(oracle, **kw)).copy()
+    got = scenes.render(scenes.tile_map_2d_scene(product, **kw)).copy()
+    monkeypatch.setenv("RXR_BLOCKSCAN2D", "0")
+    general = scenes.render(scenes.tile_map_2d_scene(product, **kw)).copy()
+    assert_exact(got, general, f"2D tile map {kw}: k_blockscan2d vs the general pipeline")
+    assert_exact(got, ref, f"2D tile map {kw}: vs the oracle")
+
+
+def test_a_pile_of_2d_primitives_falls_back(oracle, product):
+    """600 rectangles stacked on one spot: more than a bin's 256 slots -> the 2D overflow word -> the general pipeline (whose tiles
+    then walk every primitive in order, as before); the second frame of the same shape goes there directly"""
+    kw = dict(stacked=600, nx=12, ny=8)
+    ref = scenes.render(scenes.tile_map_2d_scene(oracle, **kw)).copy()
+    assert_exact(scenes.render(scenes.tile_map_2d_scene(product, **kw)).copy(), ref, "stacked rectangles")
+    assert_exact(scenes.render(scenes.tile_map_2d_scene(product, **kw)).copy(), ref, "stacked rectangles, second frame")
