@@ -1084,7 +1084,7 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
             if (const char *bs = getenv("RXR_BLOCKSCAN2D")) on = bs[0] != '0';
             ctx->blockscan2d_off = !(on && !ctx->list_floor && p2cur * n_blocks <= RXR_BLOCKSCAN_MAX_WORK / 4u &&
                                      (size_t)n_bins * RXR_BLOCKSCAN_CAP <= (64u << 20)) ||
-                                   (ctx->blockscan2d_bad_prims == p2cur && ctx->blockscan2d_bad_bins == n_bins);
+                                   ctx->blockscan2d_bad.has(p2cur, n_bins);
             if (!ctx->blockscan2d_off) want2d = std::max<size_t>(want2d, (size_t)n_bins * RXR_BLOCKSCAN_CAP);
         }
         if (want2d > ctx->list2d_capacity) {
@@ -1110,7 +1110,7 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
     ctx->blockscan_off = !(ctx->blockscan_enabled && !ctx->list_floor && n_t3 > RXR_STAGE_TRIS &&
                            (n_groups > RXR_BLOCKSCAN_SCATTER_GROUPS || n_groups * n_blocks <= RXR_BLOCKSCAN_MAX_WORK) &&
                            (size_t)n_bins * ctx->blockscan_cap <= (64u << 20));
-    if (!ctx->blockscan_off && ctx->blockscan_bad_tris == n_t3 && ctx->blockscan_bad_bins == n_bins) ctx->blockscan_off = true;
+    if (!ctx->blockscan_off && ctx->blockscan_bad.has(n_t3, n_bins)) ctx->blockscan_off = true;
     if (!ctx->blockscan_off) want_list = std::max<size_t>(want_list, (size_t)n_bins * ctx->blockscan_cap);
     if (want_list > ctx->list_capacity) {
         if ((rc = ensure(ctx, ctx->d_list, want_list * sizeof(uint32_t))) != RXR_OK) return rc;
@@ -1602,8 +1602,7 @@ int rxr_synchronize(rxr_ctx *ctx) {
         if (over2d && ctx->last_used_blockscan2d) {
             // a block of bins or a bin had more 2D primitives than k_blockscan2d keeps: count / scan / fill (and the per-tile sort) for this frame
             ctx->blockscan2d_off = true;
-            ctx->blockscan2d_bad_prims = ctx->P.n_prims2d;
-            ctx->blockscan2d_bad_bins = (size_t)ctx->P.tiles_x * ((ctx->P.height + RXR_TILE_H - 1) / RXR_TILE_H);
+            ctx->blockscan2d_bad.add(ctx->P.n_prims2d, (size_t)ctx->P.tiles_x * ((ctx->P.height + RXR_TILE_H - 1) / RXR_TILE_H));
             hc[CNT_WORDS + CNT_OVERFLOW] = hc[CNT_WORDS + HS_MAX_ENTRIES] = 0;
         } else if (over2d) {
             const size_t seen = std::max(hc[CNT_WORDS + HS_MAX_ENTRIES], hc[CNT_WORDS + CNT_ENTRIES]);
@@ -1616,8 +1615,7 @@ int rxr_synchronize(rxr_ctx *ctx) {
         if (over3d && ctx->last_used_blockscan) {
             // a block of bins or a bin had more candidates than k_blockscan keeps: this frame takes the general pipeline
             ctx->blockscan_off = true;
-            ctx->blockscan_bad_tris = ctx->P.n_tris3d;
-            ctx->blockscan_bad_bins = (size_t)ctx->P.tiles_x * ((ctx->P.height + RXR_TILE_H - 1) / RXR_TILE_H);
+            ctx->blockscan_bad.add(ctx->P.n_tris3d, (size_t)ctx->P.tiles_x * ((ctx->P.height + RXR_TILE_H - 1) / RXR_TILE_H));
             hc[CNT_OVERFLOW] = hc[HS_MAX_ENTRIES] = 0;
         } else if (over3d) {
             const size_t seen = std::max(hc[HS_MAX_ENTRIES], hc[CNT_ENTRIES]);

@@ -104,11 +104,24 @@ struct rxr_ctx {
     // bin and goes through the general pipeline (reset by the next upload); RXR_BLOCKSCAN=0 turns the mode off, RXR_BLOCKSCAN_CAP sets
     // the slots per bin (tests)
     bool blockscan_enabled = true, blockscan_off = false, last_used_blockscan = false;
-    size_t blockscan_bad_tris = 0, blockscan_bad_bins = 0;  // the (triangles, bins) of the last frame that overflowed k_blockscan: frames of
-                                                            // the same shape do not try again (a caller that uploads every frame would pay
-                                                            // the failed attempt and the second rendering every time)
+    // the (primitives, bins) of the last frames that overflowed k_blockscan / k_blockscan2d (a ring of eight each): frames of such a shape
+    // do not try again -- a caller that uploads every frame would pay the failed attempt and the second rendering every time
+    struct BadShapes {
+        size_t prims[8] = {}, bins[8] = {};
+        uint32_t next = 0;
+        bool has(size_t p, size_t b) const {
+            for (int i = 0; i < 8; ++i)
+                if (prims[i] == p && bins[i] == b && p) return true;
+            return false;
+        }
+        void add(size_t p, size_t b) {
+            if (has(p, b)) return;
+            prims[next % 8u] = p;
+            bins[next % 8u] = b;
+            ++next;
+        }
+    } blockscan_bad, blockscan2d_bad;
     bool blockscan2d_off = false, last_used_blockscan2d = false;  // the same for the 2D bins (k_blockscan2d); RXR_BLOCKSCAN2D=0 turns it off
-    size_t blockscan2d_bad_prims = 0, blockscan2d_bad_bins = 0;
     uint32_t blockscan_cap = 0;           // RXR_BLOCKSCAN_CAP in effect
     bool relaxed_lights = true;           // rxr_set_light_math / RXR_LIGHT_MATH: the 3D light loop in relaxed arithmetic (RasterParams.relaxed_lights)
     bool frame_needs_chunk_paths = true;  // the uploaded frame uses what feature level 1 adds (terrain / baked textures / staircase / editor paths)
