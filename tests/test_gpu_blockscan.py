@@ -134,3 +134,24 @@ def test_a_pile_of_2d_primitives_falls_back(oracle, product):
     ref = scenes.render(scenes.tile_map_2d_scene(oracle, **kw)).copy()
     assert_exact(scenes.render(scenes.tile_map_2d_scene(product, **kw)).copy(), ref, "stacked rectangles")
     assert_exact(scenes.render(scenes.tile_map_2d_scene(product, **kw)).copy(), ref, "stacked rectangles, second frame")
+
+
+def test_scatter_form_in_interleaved_stripes(product):
+    """the scatter form of the 3D block scan with launch-local tile rows: three logical members on GPU 0 render interleaved 16-row
+    stripes of a 49 152-triangle grid (rxr_render_stripes_to inside rxr_rasterize); the frame equals the single-context frame"""
+    import ctypes as C
+
+    def build():
+        return scenes.box_grid_scene(product, n=64, width=1280, height=720)
+
+    product.lib.rxh_set_device(0)
+    ref = scenes.render(build()).copy()
+    try:
+        ids = (C.c_int * 3)(0, 0, 0)
+        product.lib.rxh_set_devices(ids, 3)
+        got = scenes.render(build()).copy()
+        got2 = scenes.render(build()).copy()
+    finally:
+        product.lib.rxh_set_device(0)
+    assert_exact(got, ref, "3 members, scatter form")
+    assert_exact(got2, ref, "3 members, scatter form, second frame")
