@@ -1686,8 +1686,13 @@ extern "C" __global__ void __launch_bounds__(256) k_blockscan(RasterParams P) {
 // primitives' pixel boxes, same scheme as the 3D bins; the lists are sorted per tile in k_raster.
 // =================================================================================================
 namespace {
+__device__ __forceinline__ bool prim2d_box_bins(const RasterParams &P, uint2 box, uint32_t &bx0, uint32_t &bx1, uint32_t &l0, uint32_t &l1);
 __device__ __forceinline__ bool prim2d_bins(const RasterParams &P, const Prim2D &R, uint32_t &bx0, uint32_t &bx1, uint32_t &l0, uint32_t &l1) {
-    uint32_t min_x = R.bx & 0xFFFFu, max_x = R.bx >> 16, min_y = R.by & 0xFFFFu, max_y = R.by >> 16;
+    return prim2d_box_bins(P, make_uint2(R.bx, R.by), bx0, bx1, l0, l1);
+}
+// (the same from the primitive's packed pixel box alone)
+__device__ __forceinline__ bool prim2d_box_bins(const RasterParams &P, uint2 box, uint32_t &bx0, uint32_t &bx1, uint32_t &l0, uint32_t &l1) {
+    uint32_t min_x = box.x & 0xFFFFu, max_x = box.x >> 16, min_y = box.y & 0xFFFFu, max_y = box.y >> 16;
     // clamp the box to the rows of this launch (bands / stripes)
     if (min_y < P.row0) min_y = P.row0;
     if (max_y > P.row1) max_y = P.row1;
@@ -1711,13 +1716,17 @@ extern "C" __global__ void __launch_bounds__(256) k_blockscan2d(RasterParams P) 
     const uint32_t x_lo = bbx * 4u, x_hi = min(x_lo + 3u, P.tiles_x - 1u), y_lo = bby * 4u, y_hi = min(y_lo + 3u, P.tiles_y - 1u);
     const unsigned long long below = (1ull << lane) - 1ull;
     uint32_t running = 0;  // uniform: primitives kept so far
+    // (a step's pixel box is requested one step ahead: the two barriers of a step would otherwise expose every load's latency)
+    uint2 box_next = tid < P.n_prims2d ? *reinterpret_cast<const uint2 *>(&P.prim2d[tid].bx) : make_uint2(0u, 0u);
     for (uint32_t t0 = 0; t0 < P.n_prims2d; t0 += 256u) {  // uniform trip count
         const uint32_t t = t0 + tid;
+        const uint2 box = box_next;
+        if (t + 256u < P.n_prims2d) box_next = *reinterpret_cast<const uint2 *>(&P.prim2d[t + 256u].bx);
         bool hit = false;
         uint32_t rng = 0u;
         if (t < P.n_prims2d) {
             uint32_t bx0, bx1, l0, l1;
-            if (prim2d_bins(P, P.prim2d[t], bx0, bx1, l0, l1)) {
+            if (prim2d_box_bins(P, box, bx0, bx1, l0, l1)) {
                 hit = bx0 <= x_hi && bx1 >= x_lo && l0 <= y_hi && l1 >= y_lo;
                 rng = (max(bx0, x_lo) - x_lo) | ((min(bx1, x_hi) - x_lo) << 2) | ((max(l0, y_lo) - y_lo) << 4) | ((min(l1, y_hi) - y_lo) << 6);
             }
