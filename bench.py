@@ -5,7 +5,11 @@
 A "step" is one full frame: triangle set-up (+ binning for larger scenes) + the tile raster kernel over every pixel,
 inputs (projected batches, textures, lights) already resident in HBM, output left in HBM.  At N > 1 the frame is sharded
 by interleaved 16-row stripes (rank r renders stripes r, r+N, ...), the compact per-rank stripe buffers are gathered to
-rank 0 with RCCL over xGMI and de-interleaved there, so one step still produces the whole frame (strong scaling).
+rank 0 with RCCL over xGMI and de-interleaved there, so one step still produces the whole frame (strong scaling).  A rank's
+share of a frame is tens of microseconds of GPU work, so at N > 1 every rank keeps --lanes frames in flight on its GPU (member
+contexts of one device, rxr_render_stripes_batch) and moves --bucket frames per collective; `value` is measured on the exchange
+BASELINE.json names (gather to rank 0), and the SAME run also times the variants that lift that exchange's link bound (rotating
+root, several communicators) under `exchange_variants`, plus every rank's render-only and exchange-only time (`per_rank`).
 
 Timing: W untimed warm-up steps, then batches of EXACTLY K steps, each bracketed by barrier + torch.cuda.synchronize()
 on both sides and timed on its own (max over ranks); batches are repeated until at least MIN_TIMED_S seconds have been
@@ -86,6 +90,12 @@ def parse_args():
                          "consecutive frames go to different roots over disjoint xGMI links and can overlap); default 1")
     ap.add_argument("--depth", type=int, default=1,
                     help="N > 1: frames between the start of a frame's exchange and the wait for it (depth + 1 stripe / frame buffers); default 1")
+    ap.add_argument("--lanes", type=int, default=0,
+                    help="frames in flight on each GPU (member contexts on one device, each with its own resident frame and scratch, frame k on lane "
+                         "k mod L): the tail of one share's launches runs under the head of the next.  Default: 2 at N > 1, 1 at N = 1")
+    ap.add_argument("--bucket", type=int, default=0,
+                    help="N > 1: frames per exchange (one rxr_render_stripes_batch call and one collective per bucket); default 4")
+    ap.add_argument("--no-variants", action="store_true", help="N > 1: skip the exchange variants and the per-rank render-only / exchange-only legs")
     ap.add_argument("--force-gather", action="store_true",
                     help="debug: run the stripe -> gather -> assemble path even at N=1 (never used by the driver)")
     return ap.parse_args()
@@ -136,6 +146,8 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but {world} rank(s) were launched (WORLD_SIZE={world})")
 
+    import datetime
+
     import torch
     import torch.distributed as dist
 
@@ -146,10 +158,12 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # (a variant that fails on one rank only would leave the others waiting in a collective: bounded)
+        tmo = datetime.timedelta(seconds=int(os.environ.get("RXR_BENCH_PG_TIMEOUT_S", "300")))
         if REHEARSAL:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=tmo)
         else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank), timeout=tmo)
     ctl = "cpu" if REHEARSAL else "cuda"  # where the control-plane tensors (timings, batch count) live
 
     import rusterix_amd
@@ -159,55 +173,118 @@ def main():
     prod = rusterix_amd.load()
     host = prod.lib
     rxr = rusterix_amd.rxr_abi()
-    host.rxh_set_device(local_rank)
+    sharded = world > 1 or args.force_gather
+    lanes = args.lanes if args.lanes > 0 else (2 if sharded else 1)
+    bucket = args.bucket if args.bucket > 0 else 4
+    if not sharded:
+        lanes = 1  # (the N = 1 `value` is the serial loop of earlier rounds: one frame at a time; two frames in flight are reported beside it)
 
+    def use_lanes(n):
+        """the process-wide context of the host mirror: a plain context on this rank's GPU, or n member contexts on it"""
+        if n > 1:
+            host.rxh_set_devices((C.c_int * n)(*([local_rank] * n)), n)
+        else:
+            host.rxh_set_device(local_rank)
+
+    use_lanes(lanes)
     W, H = args.width, args.height
     cfg = scenes.map_scene(prod, width=W, height=H, n_lights=args.lights)
     rast = cfg.setup()
-    rc = host.rxh_rasterizer_upload(rast._h, cfg.scene._h, W, H, cfg.tile_size, cfg.assets._h)
-    if rc != 0:
-        raise SystemExit(f"upload failed: {rc} {host.rxh_last_error()}")
-    ctx = host.rxh_context()
+
+    def upload():
+        rc_ = host.rxh_rasterizer_upload(rast._h, cfg.scene._h, W, H, cfg.tile_size, cfg.assets._h)
+        if rc_ != 0:
+            raise SystemExit(f"upload failed: {rc_} {host.rxh_last_error()}")
+        return host.rxh_context()
+
+    ctx = upload()           # plain context, or the handle of the lanes
+    m0 = C.c_void_p(rxr.rxr_member(ctx, 0))  # the member that renders whole frames (identity check) and carries the kernel timing
 
     def check(rc_):
         if rc_ != 0:
             raise SystemExit(f"rxr call failed: {rc_} {rxr.rxr_last_error(ctx)}")
 
-    # one explicit (non-default) stream for everything: the raster launches, the dependency of the RCCL
-    # exchange and the assemble copy.  (torch's default stream has handle 0, which the C ABI would read
-    # as "use the context's own stream" -- the collective would then not be ordered behind the render.)
-    stream = torch.cuda.Stream()
+    # explicit (non-default) streams for everything: the raster launches, the dependency of the RCCL exchange and the
+    # assemble copy.  (torch's default stream has handle 0, which the C ABI would read as "use the context's own
+    # stream" -- the collective would then not be ordered behind the render.)  Sharded runs use one stream per lane: bucket j is
+    # rendered by lane (member context) j mod L on stream j mod L, one rxr_render_stripes_batch call for its frames, and its exchange
+    # is queued on the same stream -- so the buckets of different lanes overlap on the GPU (the tail of one share's launches under
+    # the head of another's) without a single cross-stream wait between a render and its exchange.  (Handing the whole lane group
+    # to the batch call alternates the lanes per FRAME instead; its fork / join events cost ~30 us per call on this runtime:
+    # tools/share_probe.py, profiles/r03/.)
+    cstreams = [torch.cuda.Stream() for _ in range(lanes if sharded else 1)]
+    members = [C.c_void_p(rxr.rxr_member(ctx, k)) for k in range(lanes)]
+    stream = cstreams[0]
     torch.cuda.set_stream(stream)
-    assert stream.cuda_stream != 0
+    assert all(st.cuda_stream != 0 for st in cstreams)
     sptr = C.c_void_p(stream.cuda_stream)
     spr = D.stripes_per_rank(H, world)
     stripe_rows = spr * D.TILE_H
-    # double-buffered outputs so that frame i+1 can render while frame i is being gathered
+    share_bytes = stripe_rows * W * 4
     depth = max(1, args.depth)
     NBUF = depth + 1
-    sharded = world > 1 or args.force_gather
-    if not sharded:
-        frames = [torch.empty((H, W, 4), dtype=torch.uint8, device="cuda") for _ in range(NBUF)]
-    else:
-        gather = D.StripeGather(H, W, world, rank, device="cuda", nbuf=NBUF, mode=args.exchange, host_staged=REHEARSAL, comms=max(1, args.comms))
-        frames = gather.frames  # None on ranks that do not own the frame (gather mode: only rank 0 does)
+    frames = [torch.empty((H, W, 4), dtype=torch.uint8, device="cuda") for _ in range(NBUF)] if not sharded else None
+
+    # every communicator any configuration of this run uses, created once, in the same order on every rank
+    vk = min(world, 4)
+    n_groups = max(max(1, args.comms), 1 if args.no_variants else vk)
+    groups = [None] if world == 1 or n_groups == 1 else [dist.new_group(list(range(world))) for _ in range(n_groups)]
+
+    class Pipeline:
+        """One exchange configuration: --lanes frames in flight per GPU, `bk` frames per collective, `dp` exchanges between
+        begin and end, exchange i on communicator i mod `cm`."""
+
+        def __init__(self, mode, cm, dp, bk):
+            self.mode, self.cm, self.dp, self.bk = mode, cm, dp, bk
+            self.gather = D.StripeGather(H, W, world, rank, device="cuda", nbuf=dp + 1, mode=mode, host_staged=REHEARSAL, groups=groups[:max(1, cm)], bucket=bk)
+            self.free = [torch.cuda.Event() for _ in range(dp + 1)]  # buffer b's last exchange has been consumed
+            for e in self.free:
+                e.record(stream)
+            self.last = None  # (exchange index, frames in it) of the last bucket run() assembled
+
+        def render(self, j, k, st):
+            # this rank's stripes of k frames -> compact bands (frame f of the bucket at band(j)[f]), on lane j mod L
+            check(rxr.rxr_render_stripes_batch(members[j % lanes], rank, world, k, C.c_void_p(self.gather.band_ptr(j, 0)), C.c_size_t(share_bytes),
+                                               C.c_void_p(st.cuda_stream)))
+
+        def end(self, i, st):
+            self.gather.exchange_end(i)
+            self.free[i % (self.dp + 1)].record(st)
+
+        def run(self, n, do_render=True, do_exchange=True):
+            """n complete frames in buckets of bk: render bucket j -> RCCL gather over xGMI -> de-interleave on the root, software
+            pipelined (bucket j renders while bucket j - dp travels); every frame is assembled before run() returns."""
+            nb = (n + self.bk - 1) // self.bk
+            for j in range(nb):
+                k = min(self.bk, n - j * self.bk)
+                st = cstreams[j % len(cstreams)]
+                with torch.cuda.stream(st):
+                    st.wait_event(self.free[j % (self.dp + 1)])  # the bands / gather targets of this buffer are free again
+                    if do_render:
+                        self.render(j, k, st)
+                    if do_exchange:
+                        self.gather.exchange_begin(j)
+                        if j >= self.dp:
+                            self.end(j - self.dp, st)
+            if do_exchange:
+                with torch.cuda.stream(stream):
+                    for j in range(max(0, nb - self.dp), nb):
+                        self.end(j, stream)
+                self.last = (nb - 1, n - (nb - 1) * self.bk)
+
+        def describe(self):
+            return (f"interleaved 16-row stripes over {world} GPUs (one process per GPU, {lanes} frame(s) in flight per GPU) + RCCL {self.mode} "
+                    + ("to rank (exchange mod N)" if self.mode == "rotate" else "to rank 0")
+                    + f" over xGMI, {self.bk} frame(s) per collective, pipelined with the next renders ({max(1, self.cm)} communicator(s), {self.dp} exchange(s) in flight)")
+
+    pipe = Pipeline(args.exchange, max(1, args.comms), depth, bucket) if sharded else None
 
     def run(n):
-        """n complete frames.  N > 1 is software-pipelined: while frame i-1 travels to rank 0 on the RCCL
-        stream, frame i renders; every frame is gathered and assembled before run() returns."""
-        for i in range(n):
-            b = i % NBUF
-            if not sharded:
-                check(rxr.rxr_render_rows_to(ctx, 0, H, C.c_void_p(frames[b].data_ptr()), sptr))
-            else:
-                # this rank's stripes -> compact band -> RCCL gather to rank 0 over xGMI -> de-interleave
-                check(rxr.rxr_render_stripes_to(ctx, rank, world, C.c_void_p(gather.band(i).data_ptr()), sptr))
-                gather.exchange_begin(i)
-                if i >= depth:
-                    gather.exchange_end(i - depth)
         if sharded:
-            for i in range(max(0, n - depth), n):
-                gather.exchange_end(i)
+            pipe.run(n)
+        else:
+            for i in range(n):
+                check(rxr.rxr_render_rows_to(ctx, 0, H, C.c_void_p(frames[i % NBUF].data_ptr()), sptr))
 
     def fence():
         torch.cuda.synchronize()
@@ -215,18 +292,29 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed_batch():
-        """exactly args.steps steps between two fences; seconds, max over ranks"""
+    def timed(fn, n):
+        """n steps of fn between two fences; seconds, max over ranks"""
         fence()
         t0 = time.perf_counter()
-        run(args.steps)
+        fn(n)
         fence()
-        dt = time.perf_counter() - t0
+        dt_ = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=ctl)
+            t = torch.tensor([dt_], dtype=torch.float64, device=ctl)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        return dt
+            dt_ = float(t.item())
+        return dt_
+
+    def timed_batch():
+        return timed(run, args.steps)
+
+    def agree(n):
+        """rank 0's batch count on every rank"""
+        if world > 1:
+            nb_ = torch.tensor([n], dtype=torch.int64, device=ctl)
+            dist.broadcast(nb_, src=0)
+            n = int(nb_.item())
+        return n
 
     run(args.warmup)
     fence()
@@ -234,11 +322,7 @@ def main():
     # kernel durations are measured live with HIP events on the launch stream, on every PROFILE_STRIDE-th frame of the
     # timed region: three event records per frame idle the GPU for 10-25 us, a tenth of this frame
     first = timed_batch()  # sizes the run (timed like the others, not discarded)
-    n_batches = int(min(MAX_BATCHES, max(1, np.ceil(1.25 * MIN_TIMED_S / max(first, 1e-6)))))
-    if world > 1:
-        nb = torch.tensor([n_batches], dtype=torch.int64, device=ctl)
-        dist.broadcast(nb, src=0)
-        n_batches = int(nb.item())
+    n_batches = agree(int(min(MAX_BATCHES, max(1, np.ceil(1.25 * MIN_TIMED_S / max(first, 1e-6))))))
     ring = min(65536, n_batches * args.steps // PROFILE_STRIDE + args.steps + 8)
     check(rxr.rxr_profile_stride(ctx, PROFILE_STRIDE))
     check(rxr.rxr_profile_begin(ctx, ring))
@@ -247,7 +331,7 @@ def main():
     check(rxr.rxr_synchronize(ctx))
     dt = float(np.median(batch_s))
 
-    # per-launch kernel durations measured with HIP events on the launch stream during the timed region
+    # per-launch kernel durations measured with HIP events on the launch stream during the timed region (lanes: member 0's launches)
     setup_us = (C.c_float * ring)()
     raster_us = (C.c_float * ring)()
     n_prof = C.c_uint32(0)
@@ -256,23 +340,88 @@ def main():
     raster_avg_us = float(np.mean(raster_us[: n_prof.value])) if n_prof.value else float("nan")
     setup_avg_us = float(np.mean(setup_us[: n_prof.value])) if n_prof.value else float("nan")
 
-    # sanity (on the rank that owns the assembled frame): not empty, every pixel resolved
-    last_root = gather.root_of(args.steps - 1) if sharded else 0
-    if frames is not None and (not sharded or args.exchange != "rotate" or rank == last_root):
+    def check_assembled(p):
+        """on the rank that owns the last assembled frame: not empty, every pixel resolved, byte-identical to a single-launch frame
+        """
+        i_last, k_last = p.last
+        if p.gather.frames is None or (p.mode == "rotate" and rank != p.gather.root_of(i_last)):
+            return
+        fr = p.gather.frames[i_last % (p.dp + 1)]
+        final = (fr if p.bk == 1 else fr[k_last - 1])[:H]
+        assert int(final[..., 3].min().item()) == 255 and int(final[..., :3].max().item()) > 0, "benchmark frame is not a rendered frame"
+        direct = torch.empty((H, W, 4), dtype=torch.uint8, device="cuda")
+        check(rxr.rxr_render_rows_to(m0, 0, H, C.c_void_p(direct.data_ptr()), sptr))
+        check(rxr.rxr_synchronize(ctx))
+        torch.cuda.synchronize()
+        assert torch.equal(direct, final), "gathered frame differs from the single-launch frame"
+
+    if sharded:
+        check_assembled(pipe)
+    else:
         final = frames[(args.steps - 1) % NBUF][:H]
         assert int(final[..., 3].min().item()) == 255 and int(final[..., :3].max().item()) > 0, "benchmark frame is not a rendered frame"
-        if sharded:
-            # the sharded + gathered frame must be byte-identical to a single-launch frame
-            direct = torch.empty((H, W, 4), dtype=torch.uint8, device="cuda")
-            check(rxr.rxr_render_rows_to(ctx, 0, H, C.c_void_p(direct.data_ptr()), sptr))
-            check(rxr.rxr_synchronize(ctx))
-            torch.cuda.synchronize()
-            assert torch.equal(direct, final), "gathered frame differs from the single-launch frame"
+
+    def measure(fn, t_min=min(0.3, MIN_TIMED_S), n_max=200):
+        """median seconds per `steps` steps of fn over batches that add up to >= t_min seconds (the count agreed on by all ranks)"""
+        fn(args.warmup)
+        t_first = timed(fn, args.steps)
+        nb_ = agree(int(min(n_max, max(2, np.ceil(t_min / max(t_first, 1e-6))))))
+        ts = [timed(fn, args.steps) for _ in range(nb_)]
+        return float(np.median(ts)), nb_
+
+    # N > 1, the SAME run: (a) what each rank spends on rendering alone and on the exchange alone (max-over-ranks timing cannot say
+    # which of the two bounds the curve), (b) the exchange variants that lift the fixed root's link bound.  Never `value`.
+    per_rank = None
+    variants = None
+    if sharded and not args.no_variants:
+        def local_time(fn, n_rep=5):
+            fn(args.warmup)
+            ts = []
+            for _ in range(n_rep):
+                fence()
+                t0 = time.perf_counter()
+                fn(args.steps)
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t0)
+                fence()
+            return float(np.median(ts)) / args.steps * 1e3
+
+        def all_ranks(x):
+            if world == 1:
+                return [round(x, 4)]
+            t = torch.tensor([x], dtype=torch.float64, device=ctl)
+            out_ = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(out_, t)
+            return [round(float(o.item()), 4) for o in out_]
+
+        per_rank = {
+            "render_only_ms": all_ranks(local_time(lambda n: pipe.run(n, do_exchange=False))),
+            "exchange_only_ms": all_ranks(local_time(lambda n: pipe.run(n, do_render=False))),
+            "what": f"per step and rank, in rank order: this rank's stripes through {lanes} lane(s) without any exchange; the exchange "
+                    "(collective + de-interleave on the root) of already rendered stripes without any render",
+        }
+        variants = {}
+        todo = [("rotate", vk, vk, bucket), ("rotate", vk, vk, 1), ("gather", 1, 1, 1)]
+        for mode, cm, dp, bk in todo:
+            name = f"{mode}_comms{cm}_depth{dp}_bucket{bk}"
+            if (mode, cm, dp, bk) == (pipe.mode, pipe.cm, pipe.dp, pipe.bk):
+                continue
+            try:
+                pv = Pipeline(mode, cm, dp, bk)
+                sec, nb_ = measure(pv.run)
+                check(rxr.rxr_synchronize(ctx))
+                check_assembled(pv)
+                variants[name] = {"mpix_s": round(W * H * args.steps / sec / 1e6, 2), "ms_per_step": round(sec / args.steps * 1e3, 4), "batches": nb_,
+                                  "sharding": pv.describe()}
+                del pv
+            except Exception as ex:  # a variant must never cost the bench line
+                variants[name] = {"error": repr(ex)}
 
     # the same frame in the other light-loop arithmetic (rxr_set_light_math, include/rxr.h), N = 1 only: a few batches, reported
     # beside the default mode's `value`, never as it
     relaxed = os.environ.get("RXR_LIGHT_MATH", "exact" if host.rxh_get_light_math_exact() else "relaxed")[0] == "r"
     other_mode = None
+    in_flight = None
     if world == 1 and not sharded and "RXR_LIGHT_MATH" not in os.environ:
         host.rxh_set_light_math_exact(1 if relaxed else 0)
         rc = host.rxh_rasterizer_upload(rast._h, cfg.scene._h, W, H, cfg.tile_size, cfg.assets._h)
@@ -284,9 +433,41 @@ def main():
             other_mode = {"light_math": "exact" if relaxed else "relaxed", "ms_per_step": round(other_dt / args.steps * 1e3, 4),
                           "mpix_s": round(W * H * args.steps / other_dt / 1e6, 2), "batches": len(other_s)}
         host.rxh_set_light_math_exact(0 if relaxed else 1)
-        rc = host.rxh_rasterizer_upload(rast._h, cfg.scene._h, W, H, cfg.tile_size, cfg.assets._h)
-        if rc != 0:
-            raise SystemExit(f"upload failed: {rc} {host.rxh_last_error()}")
+        upload()
+    if world == 1 and not sharded:
+        # two frames in flight on the one GPU (two member contexts, frame i on lane i mod 2, each on its own stream): throughput
+        # of the same K whole frames when the tail of one frame's launches runs under the head of the next.  Reported beside
+        # `value` (the serial loop, one frame at a time, as a caller of rasterize() sees it), never as it.
+        try:
+            serial = torch.empty((H, W, 4), dtype=torch.uint8, device="cuda")  # (the buffers of the timed loop may hold the other mode's frame)
+            check(rxr.rxr_render_rows_to(ctx, 0, H, C.c_void_p(serial.data_ptr()), sptr))
+            check(rxr.rxr_synchronize(ctx))
+            torch.cuda.synchronize()
+            use_lanes(2)
+            g2 = upload()
+            mem = [C.c_void_p(rxr.rxr_member(g2, k)) for k in range(2)]
+            st2 = [torch.cuda.Stream() for _ in range(2)]
+            fb2 = [torch.empty((H, W, 4), dtype=torch.uint8, device="cuda") for _ in range(4)]
+
+            def run2(n):
+                for i in range(n):
+                    rc_ = rxr.rxr_render_rows_to(mem[i & 1], 0, H, C.c_void_p(fb2[i & 3].data_ptr()), C.c_void_p(st2[i & 1].cuda_stream))
+                    if rc_ != 0:
+                        raise RuntimeError(f"lane render failed: {rc_} {rxr.rxr_last_error(mem[i & 1])}")
+
+            sec, nb_ = measure(run2)
+            if rxr.rxr_synchronize(g2) != 0:
+                raise RuntimeError(str(rxr.rxr_last_error(g2)))
+            torch.cuda.synchronize()
+            same = bool(torch.equal(fb2[0], serial) and torch.equal(fb2[3], serial))
+            in_flight = {"lanes": 2, "ms_per_step": round(sec / args.steps * 1e3, 4), "mpix_s": round(W * H * args.steps / sec / 1e6, 2), "batches": nb_,
+                         "identical_to_serial_frame": same,
+                         "what": "the same K whole frames with two in flight on the GPU (two member contexts of one device, alternating streams)"}
+            del fb2
+        except Exception as ex:
+            in_flight = {"error": repr(ex)}
+        use_lanes(1)
+        ctx = upload()
 
     fence()
     e2e = None
@@ -305,7 +486,7 @@ def main():
         rows_this_rank = min(stripe_rows, H) if sharded else H
         alg = algorithmic_bytes(W, rows_this_rank, n_verts, n_tris, tex_bytes, args.lights)
         achieved = alg / (raster_avg_us * 1e-6) / 1e9
-        default_workload = (W, H, args.lights, world) == (3840, 2160, 16, 1)
+        default_workload = (W, H, args.lights, world) == (3840, 2160, 16, 1) and not sharded
         PROFILE = PROFILES["relaxed" if relaxed else "exact"]
         out = {
             "metric": "Mpixels/s (+ ms/frame) on rasterize_map @3840x2160, 1/2/4/8 MI355X vs CPU",
@@ -337,9 +518,8 @@ def main():
                 # BASELINE.json's 1-per-channel tolerance for lit 3D fragments (tests/test_gpu_light_math.py: 112 of 8 294 400
                 # pixels of this frame differ from the CPU oracle, each by 1); "exact" = correctly rounded throughout
                 "light_math": "relaxed" if relaxed else "exact",
-                "sharding": "single GPU" if world == 1 else f"interleaved 16-row stripes over {world} GPUs (one process per GPU) + RCCL {args.exchange} "
-                                                           + ("to rank (frame mod N)" if args.exchange == "rotate" else "to rank 0")
-                                                           + f" over xGMI, pipelined with the next frame's render ({max(1, args.comms)} communicator(s), {depth} frame(s) in flight)",
+                "sharding": "single GPU, one frame at a time" if not sharded else pipe.describe(),
+                **({"frames_in_flight_per_gpu": lanes, "frames_per_exchange": bucket} if sharded else {}),
             },
             "roofline": {
                 "bound": "hbm",
@@ -357,7 +537,8 @@ def main():
                 "kernel_avg_us": round(raster_avg_us, 2),
                 "kernel_samples": int(n_prof.value),
                 "setup_kernels_avg_us": round(setup_avg_us, 2),
-                "note": "the kernel is fp32-VALU bound, not HBM bound: algorithmic HBM traffic is ~4.5 B/pixel (DESIGN.md section 6)",
+                "note": "the kernel is fp32-VALU bound, not HBM bound: algorithmic HBM traffic is ~4.5 B/pixel (DESIGN.md section 6)"
+                        + ("; with several frames in flight the event-timed launches overlap other lanes' launches" if sharded and lanes > 1 else ""),
                 "from_profiles": {
                     "source": PROFILE["source"],
                     "write_bytes": PROFILE["write_bytes"],
@@ -368,6 +549,12 @@ def main():
         }
         if other_mode is not None:
             out["other_light_math"] = other_mode
+        if in_flight is not None:
+            out["two_frames_in_flight"] = in_flight
+        if per_rank is not None:
+            out["per_rank"] = per_rank
+        if variants is not None:
+            out["exchange_variants"] = variants
         if e2e is not None:
             out.update(e2e)
         if world == 1 and not args.no_cpu:

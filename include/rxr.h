@@ -466,6 +466,21 @@ int rxr_render_rows_to(rxr_ctx *ctx, uint32_t row0, uint32_t row1, void *dev_pix
 #define RXR_STRIPE_ROWS 16u
 int rxr_render_stripes_to(rxr_ctx *ctx, uint32_t first, uint32_t stride, void *dev_pixels, void *hip_stream);
 
+/* K frames with one host call: renders the resident frame's stripes (first, stride: as rxr_render_stripes_to) `n_frames` times;
+ * frame k's compact stripe buffer lands at dev_pixels + k * frame_stride_bytes (frame_stride_bytes >= one compact buffer), and the
+ * batch is complete on `hip_stream` (NULL: the context's own stream).  A rank's share of a small frame is tens of microseconds of
+ * GPU work -- less than the host spends on a call per frame plus a collective per frame -- so a multi-GPU host renders a bucket of
+ * frames per call and exchanges the bucket with one collective (bench.py --bucket).
+ * On a multi-device handle whose members ALL sit on one device (rxr_create_multi with the same id L times: "lanes", L frames in
+ * flight on that GPU) frame k is rendered by member k mod L on that member's own stream: every member has its own resident frame
+ * and scratch, so consecutive frames overlap on the GPU -- the tail of one launch sequence, when most of the chip is already idle,
+ * runs under the head of the next (a 1/8 share of the 4K bench frame: 31 us per frame on one stream, 17.5 us with two lanes,
+ * profiles/r03/).  The lanes' streams are forked from and joined to `hip_stream` with events.  Members on different devices:
+ * RXR_ERR_UNSUPPORTED.  Every frame of the batch is byte-identical to rxr_render_stripes_to's.  Asynchronous; rxr_synchronize
+ * waits for it.  The reference has no counterpart: it renders one frame per call (src/rasterizer.rs:185-193). */
+int rxr_render_stripes_batch(rxr_ctx *ctx, uint32_t first, uint32_t stride, uint32_t n_frames, void *dev_pixels, size_t frame_stride_bytes,
+                             void *hip_stream);
+
 /* per-launch kernel timing for the benchmark: after rxr_profile_begin(ctx, n) every render records
  * HIP events (on the stream it launches on) around its set-up kernels and its raster kernel into a
  * ring of n slots; rxr_profile_read synchronizes and returns the durations in microseconds.

@@ -1294,7 +1294,13 @@ static int render_impl(rxr_ctx *ctx, const RenderSpec &spec, void *dev_pixels, h
     HIPCHK(ctx, hipSetDevice(ctx->device));
     // every launch sequence uses the context's one set of scratch buffers (records, bins, counters): a render on another
     // stream than the previous one is ordered behind it
-    if (ctx->rendered && ctx->last_stream != s) HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_render, 0));
+    // (the event is recorded here, at the switch, on the PREVIOUS stream -- it then covers that stream's renders and whatever the
+    // caller queued behind them, a superset -- and not behind every launch sequence: an event record is a barrier packet that idles
+    // the GPU for microseconds, and a caller that stays on one stream never needs it)
+    if (ctx->rendered && ctx->last_stream != s) {
+        HIPCHK(ctx, hipEventRecord(ctx->ev_render, ctx->last_stream));
+        HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_render, 0));
+    }
     if (retry) ctx->rerenders++;
     if (!ctx->upload_ordered_on || ctx->upload_ordered_on != s) {
         if (s != ctx->stream) {
@@ -1423,7 +1429,6 @@ static int render_impl(rxr_ctx *ctx, const RenderSpec &spec, void *dev_pixels, h
     if (!rxr_jit_launch(ctx, &P, s)) rxr_launch_raster(&P, s);
     if (timed) HIPCHK(ctx, hipEventRecord(e2, s));
     HIPCHK(ctx, hipGetLastError());
-    HIPCHK(ctx, hipEventRecord(ctx->ev_render, s));
     ctx->scratch_dirty = false;  // the raster launch that hands the bins back is queued
     ctx->scratch2d_dirty = false;
     ctx->rendered = true;
@@ -1492,6 +1497,36 @@ int rxr_render_stripes_to(rxr_ctx *ctx, uint32_t first, uint32_t stride, void *d
     spec.compact = true;
     spec.external = true;
     return render_impl(ctx, spec, dev_pixels, hip_stream ? (hipStream_t)hip_stream : ctx->stream);
+}
+
+static int stripes_spec(rxr_ctx *ctx, uint32_t first, uint32_t stride, RenderSpec &spec) {
+    if (!ctx->has_frame) return fail(ctx, RXR_ERR_INVALID, "render: no frame uploaded");
+    if (stride == 0) return fail(ctx, RXR_ERR_INVALID, "rxr_render_stripes: stride 0");
+    const uint32_t n_stripes = (ctx->P.height + RXR_TILE_H - 1) / RXR_TILE_H;
+    spec.row0 = 0;
+    spec.row1 = ctx->P.height;
+    spec.tile_y0 = first;
+    spec.tile_stride = stride;
+    spec.tiles_y = first < n_stripes ? (n_stripes - first + stride - 1) / stride : 0;
+    spec.compact = true;
+    spec.external = true;
+    return RXR_OK;
+}
+
+int rxr_render_stripes_batch(rxr_ctx *ctx, uint32_t first, uint32_t stride, uint32_t n_frames, void *dev_pixels, size_t frame_stride_bytes,
+                             void *hip_stream) {
+    if (!ctx) return RXR_ERR_INVALID;
+    if (!dev_pixels) return fail(ctx, RXR_ERR_INVALID, "rxr_render_stripes_batch: dev_pixels is NULL");
+    if (ctx->group) return rxr_group_render_stripes_batch(ctx, first, stride, n_frames, dev_pixels, frame_stride_bytes, hip_stream);
+    RenderSpec spec{};
+    int rc = stripes_spec(ctx, first, stride, spec);
+    if (rc != RXR_OK) return rc;
+    if (n_frames > 1u && frame_stride_bytes < (size_t)spec.tiles_y * RXR_TILE_H * ctx->P.width * 4u)
+        return fail(ctx, RXR_ERR_INVALID, "rxr_render_stripes_batch: frame_stride_bytes is smaller than one compact stripe buffer");
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+    for (uint32_t k = 0; k < n_frames; ++k)
+        if ((rc = render_impl(ctx, spec, (uint8_t *)dev_pixels + (size_t)k * frame_stride_bytes, s)) != RXR_OK) return rc;
+    return RXR_OK;
 }
 
 int rxr_profile_begin(rxr_ctx *ctx, uint32_t max_frames) {

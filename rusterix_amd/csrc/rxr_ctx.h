@@ -160,7 +160,7 @@ struct rxr_ctx {
     hipStream_t last_stream = nullptr;
     hipStream_t upload_ordered_on = nullptr;  // stream already ordered behind the last upload
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev_upload = nullptr;
-    hipEvent_t ev_render = nullptr;     // recorded behind every render launch sequence (orders a render on ANOTHER stream behind it)
+    hipEvent_t ev_render = nullptr;     // recorded on the previous stream when a render moves to ANOTHER stream (orders it behind the earlier ones)
     hipEvent_t last_e0 = nullptr, last_e1 = nullptr, last_e2 = nullptr;
     std::vector<ProfSlot> prof;  // rxr_profile_begin ring
     size_t prof_next = 0;
@@ -194,6 +194,8 @@ int rxr_group_download(rxr_ctx *ctx, uint8_t *pixels);       // ... and ships th
 int rxr_group_render_download(rxr_ctx *ctx, uint8_t *pixels);
 int rxr_group_synchronize(rxr_ctx *ctx);
 int rxr_group_get_stats(rxr_ctx *ctx, rxr_stats *out);
+int rxr_group_render_stripes_batch(rxr_ctx *ctx, uint32_t first, uint32_t stride, uint32_t n_frames, void *dev_pixels, size_t frame_stride_bytes,
+                                   void *hip_stream);
 
 // rxr_jit.hip: program sets compiled at run time
 bool rxr_jit_generate(const std::vector<uint32_t> &code, const std::vector<DevProgram> &progs, std::string &src, std::string &why);

@@ -32,6 +32,7 @@
 #include <dirent.h>
 #include <dlfcn.h>
 #include <errno.h>
+#include <fcntl.h>
 #include <signal.h>
 #include <spawn.h>
 #include <sys/stat.h>
@@ -466,41 +467,101 @@ std::mutex g_bg_mu;
 std::map<std::string, BgJob> g_bg;          // in flight
 std::map<std::string, std::string> g_bg_failed;  // key -> why (a set that failed once is not tried again)
 
-// everything in a job's directory, then the directory (a killed compiler leaves comgr-<pid>-... directories of temporaries behind)
-void remove_job_dir(const std::string &dir, int depth = 0) {
-    if (DIR *d = opendir(dir.c_str())) {
-        while (dirent *e = readdir(d)) {
-            if (!strcmp(e->d_name, ".") || !strcmp(e->d_name, "..")) continue;
-            const std::string path = dir + "/" + e->d_name;
-            if (unlink(path.c_str()) != 0 && depth < 4) remove_job_dir(path, depth + 1);
-        }
-        closedir(d);
+// Job directories live under ONE parent that only this user can write: $XDG_RUNTIME_DIR/rxr_jit when that variable names a
+// directory of ours, else /tmp/rxr_jit-<uid>, created 0700 and checked with lstat (a real directory, ours, no group / other bits)
+// before anything is put into or removed from it.  /tmp itself is world-writable: nothing directly under it is ever examined,
+// opened or removed by name, so another user's entry (a symlink to somebody's directory, say) cannot steer the clean-up.
+std::string job_parent(std::string &err) {
+    std::string parent;
+    if (const char *xdg = getenv("XDG_RUNTIME_DIR")) {
+        struct stat st;
+        if (xdg[0] == '/' && lstat(xdg, &st) == 0 && S_ISDIR(st.st_mode) && st.st_uid == geteuid() && (st.st_mode & 077) == 0) parent = std::string(xdg) + "/rxr_jit";
     }
-    (void)rmdir(dir.c_str());
+    if (parent.empty()) parent = "/tmp/rxr_jit-" + std::to_string((unsigned long)geteuid());
+    if (mkdir(parent.c_str(), 0700) != 0 && errno != EEXIST) {
+        err = "the background compiler's directory " + parent + " cannot be created";
+        return "";
+    }
+    struct stat st;
+    if (lstat(parent.c_str(), &st) != 0 || !S_ISDIR(st.st_mode) || st.st_uid != geteuid() || (st.st_mode & 077) != 0) {
+        err = parent + " is not a private directory of this user (a real directory, owned by it, mode 0700): background compilation is off";
+        return "";
+    }
+    return parent;
+}
+// this process's PID namespace (two containers that share a /tmp each have a process 1234: a pid says nothing across them)
+unsigned long long pid_namespace() {
+    struct stat st;
+    return stat("/proc/self/ns/pid", &st) == 0 ? (unsigned long long)st.st_ino : 0ull;
+}
+// Everything below directory `name` of the open directory `at`, then the directory itself.  Walks by file descriptor
+// (openat O_DIRECTORY | O_NOFOLLOW, unlinkat): a symbolic link is removed as a link, never followed; a killed compiler leaves
+// comgr-<pid>-... directories of temporaries behind, hence the (bounded) recursion.
+void remove_tree_at(int at, const char *name, int depth = 0) {
+    const int fd = openat(at, name, O_RDONLY | O_DIRECTORY | O_NOFOLLOW | O_CLOEXEC);
+    if (fd >= 0) {
+        if (DIR *d = fdopendir(fd)) {
+            while (dirent *e = readdir(d)) {
+                if (!strcmp(e->d_name, ".") || !strcmp(e->d_name, "..")) continue;
+                if (unlinkat(fd, e->d_name, 0) != 0 && depth < 4) remove_tree_at(fd, e->d_name, depth + 1);
+            }
+            closedir(d);  // (closes fd)
+        } else {
+            close(fd);
+        }
+    }
+    (void)unlinkat(at, name, AT_REMOVEDIR);
+}
+// `dir` is a job directory this process made with mkdtemp inside job_parent()
+void remove_job_dir(const std::string &dir) {
+    const size_t slash = dir.rfind('/');
+    if (slash == std::string::npos || slash == 0) return;
+    const int pfd = open(dir.substr(0, slash).c_str(), O_RDONLY | O_DIRECTORY | O_NOFOLLOW | O_CLOEXEC);
+    if (pfd < 0) return;
+    remove_tree_at(pfd, dir.c_str() + slash + 1);
+    close(pfd);
 }
 // A process that was killed (or left through _exit) could not remove its jobs' directories: each directory names its owner
-// (file "owner": the pid), and the first job of a process removes the directories whose owner no longer exists.
-void sweep_stale_job_dirs() {
-    DIR *d = opendir("/tmp");
-    if (!d) return;
+// (file "owner": pid and PID-namespace inode), and the first job of a process removes the directories -- real directories of this
+// user inside the private parent only -- whose owner, in OUR namespace, no longer exists; a directory of another namespace or
+// without a readable owner is stale once it is an hour old (a compilation takes seconds).
+void sweep_stale_job_dirs(const std::string &parent) {
+    const int pfd = open(parent.c_str(), O_RDONLY | O_DIRECTORY | O_NOFOLLOW | O_CLOEXEC);
+    if (pfd < 0) return;
+    DIR *d = fdopendir(dup(pfd));
+    if (!d) {
+        close(pfd);
+        return;
+    }
+    const unsigned long long my_ns = pid_namespace();
     std::vector<std::string> stale;
     while (dirent *e = readdir(d)) {
-        if (strncmp(e->d_name, "rxr_jit_", 8) != 0) continue;
-        const std::string dir = std::string("/tmp/") + e->d_name;
+        if (strncmp(e->d_name, "job_", 4) != 0) continue;
+        struct stat st;
+        if (fstatat(pfd, e->d_name, &st, AT_SYMLINK_NOFOLLOW) != 0 || !S_ISDIR(st.st_mode) || st.st_uid != geteuid()) continue;
         long pid = 0;
-        if (FILE *f = fopen((dir + "/owner").c_str(), "r")) {
-            if (fscanf(f, "%ld", &pid) != 1) pid = 0;
-            fclose(f);
+        unsigned long long ns = 0;
+        const int jfd = openat(pfd, e->d_name, O_RDONLY | O_DIRECTORY | O_NOFOLLOW | O_CLOEXEC);
+        if (jfd >= 0) {
+            const int ofd = openat(jfd, "owner", O_RDONLY | O_NOFOLLOW | O_CLOEXEC);
+            if (ofd >= 0) {
+                char buf[64] = {0};
+                const ssize_t n = read(ofd, buf, sizeof buf - 1);
+                if (n <= 0 || sscanf(buf, "%ld %llu", &pid, &ns) < 1) pid = 0;
+                close(ofd);
+            }
+            close(jfd);
         }
-        if (pid > 0) {
-            if (kill((pid_t)pid, 0) != 0 && errno == ESRCH) stale.push_back(dir);
-        } else {  // no owner recorded (half removed): stale once it is older than any compilation
-            struct stat st;
-            if (stat(dir.c_str(), &st) == 0 && time(nullptr) - st.st_mtime > 600) stale.push_back(dir);
+        const bool old = time(nullptr) - st.st_mtime > 3600;
+        if (pid > 0 && ns != 0 && ns == my_ns) {
+            if (kill((pid_t)pid, 0) != 0 && errno == ESRCH) stale.push_back(e->d_name);
+        } else if (old) {
+            stale.push_back(e->d_name);
         }
     }
     closedir(d);
-    for (const std::string &dir : stale) remove_job_dir(dir);
+    for (const std::string &name : stale) remove_tree_at(pfd, name.c_str());
+    close(pfd);
 }
 
 void finish_job_locked(std::map<std::string, BgJob>::iterator it, bool kill_it) {
@@ -543,19 +604,21 @@ bool start_child_locked(const std::string &key, const std::string &gen, const st
         err = "the background compiler rxr_jitc is not next to the library";
         return false;
     }
+    const std::string parent = job_parent(err);
+    if (parent.empty()) return false;
     static bool swept = false;  // (under g_bg_mu)
     if (!swept) {
         swept = true;
-        sweep_stale_job_dirs();
+        sweep_stale_job_dirs(parent);
     }
-    char dir_t[] = "/tmp/rxr_jit_XXXXXX";
-    if (!mkdtemp(dir_t)) {
+    std::string dir_t = parent + "/job_XXXXXX";
+    if (!mkdtemp(&dir_t[0])) {
         err = "no temporary directory";
         return false;
     }
     const std::string dir = dir_t, src_t = dir + "/set.h", out_t = dir + "/set.co";
     if (FILE *f = fopen((dir + "/owner").c_str(), "w")) {
-        fprintf(f, "%ld\n", (long)getpid());
+        fprintf(f, "%ld %llu\n", (long)getpid(), pid_namespace());
         fclose(f);
     }
     bool wrote = false;

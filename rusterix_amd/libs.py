@@ -55,6 +55,7 @@ def rxr_abi():
         "rxr_render_rows": (i32, [vp, u32, u32]),
         "rxr_render_rows_to": (i32, [vp, u32, u32, vp, vp]),
         "rxr_render_stripes_to": (i32, [vp, u32, u32, vp, vp]),
+        "rxr_render_stripes_batch": (i32, [vp, u32, u32, u32, vp, C.c_size_t, vp]),
         "rxr_render_gather": (i32, [vp, i32, vp, vp]),
         "rxr_render_download": (i32, [vp, vp]),
         "rxr_download_rows": (i32, [vp, vp, u32, u32]),

@@ -22,36 +22,44 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, frame, result_dir, mode, comms=1, depth=1):
+def _worker(rank, world, port, frame, result_dir, mode, comms=1, depth=1, bucket=1):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         h, w = frame.shape[0], frame.shape[1]
-        g = D.StripeGather(h, w, world, rank, device="cpu", mode=mode, comms=comms, nbuf=depth + 1)
+        g = D.StripeGather(h, w, world, rank, device="cpu", mode=mode, comms=comms, nbuf=depth + 1, bucket=bucket)
         ok = True
         n = 5 if depth == 1 else 11
 
-        def want(i):
-            return np.roll(frame, i * 5, axis=1)
+        def want(i, k=0):  # frame k of exchange i
+            return np.roll(frame, (i * bucket + k) * 5, axis=1)
+
+        def fill(i):
+            for k in range(bucket):
+                (g.band(i) if bucket == 1 else g.band(i)[k]).copy_(torch.from_numpy(D.extract_stripes(want(i, k), world, rank)))
 
         def check(i, out):
             nonlocal ok
-            if g.owns_frame and (mode != "rotate" or rank == g.root_of(i)):  # (rotate: frame i lives on rank i mod world only)
-                ok &= out is not None and np.array_equal(out.numpy(), want(i))
+            if g.owns_frame and (mode != "rotate" or rank == g.root_of(i)):  # (rotate: exchange i lives on rank i mod world only)
+                ok &= out is not None
+                if out is not None:
+                    ok &= tuple(out.shape) == ((h, w, 4) if bucket == 1 else (bucket, h, w, 4))
+                    for k in range(bucket):
+                        ok &= np.array_equal((out if bucket == 1 else out[k]).numpy(), want(i, k))
             else:
                 ok &= out is None
 
         # the same pipelined loop bench.py runs: render(i); begin(i); end(i - depth)
         for i in range(n):
-            g.band(i).copy_(torch.from_numpy(D.extract_stripes(want(i), world, rank)))
+            fill(i)
             g.exchange_begin(i)
             if i >= depth:
                 check(i - depth, g.exchange_end(i - depth))
         for i in range(max(0, n - depth), n):
             check(i, g.exchange_end(i))
         # and the blocking form
-        g.band(0).copy_(torch.from_numpy(D.extract_stripes(frame, world, rank)))
+        fill(0)
         check(0, g.exchange(0))
         np.save(os.path.join(result_dir, f"ok{rank}.npy"), np.array([ok, g.owns_frame]))
     finally:
@@ -117,3 +125,15 @@ def test_single_process_world_one():
     g = D.StripeGather(50, 20, 1, 0, device="cpu")
     g.band(0).copy_(torch.from_numpy(D.extract_stripes(frame, 1, 0)))
     assert np.array_equal(g.exchange(0).numpy(), frame)
+
+
+@pytest.mark.parametrize("world,bucket,comms,depth,mode", [(2, 3, 1, 1, "gather"), (3, 2, 2, 2, "rotate"), (2, 4, 1, 1, "allgather")])
+def test_buckets_of_frames_per_exchange(tmp_path, oracle, world, bucket, comms, depth, mode):
+    """bucket = K: one collective moves the stripes of K frames (band(i) is [K, rows, W, 4]) and the root de-interleaves K whole frames"""
+    from rusterix_amd import scenes
+
+    frame = scenes.render(scenes.map_scene(oracle, width=56, height=90, logo_size=16, n_lights=1)).copy()
+    mp.spawn(_worker, args=(world, _free_port(), frame, str(tmp_path), mode, comms, depth, bucket), nprocs=world, join=True)
+    for r in range(world):
+        ok, _ = np.load(tmp_path / f"ok{r}.npy")
+        assert ok, f"rank {r} assembled a wrong frame"

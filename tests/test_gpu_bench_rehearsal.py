@@ -13,8 +13,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("world,exchange,extra", [(2, "gather", []), (3, "allgather", []), (3, "rotate", []),
-                                                  (3, "rotate", ["--comms", "3", "--depth", "2"])])   # several communicators, two frames in flight
+@pytest.mark.parametrize("world,exchange,extra", [(2, "gather", []), (3, "allgather", ["--no-variants"]), (3, "rotate", ["--no-variants", "--bucket", "1", "--lanes", "1"]),
+                                                  # several communicators, two exchanges in flight, three lanes, buckets of 3 (6 steps = 2 buckets)
+                                                  (3, "rotate", ["--comms", "3", "--depth", "2", "--lanes", "3", "--bucket", "3", "--no-variants"]),
+                                                  # a ragged last bucket (6 steps in buckets of 4)
+                                                  (2, "gather", ["--bucket", "4", "--no-variants"])])
 def test_bench_runs_its_multi_rank_path(world, exchange, extra):
     env = dict(os.environ, RXR_BENCH_REHEARSAL="1", RXR_BENCH_MIN_TIMED_S="0.05")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
@@ -28,3 +31,10 @@ def test_bench_runs_its_multi_rank_path(world, exchange, extra):
     assert d["n_gpus"] == world and d["rehearsal"] is True and d["steps"] == 6
     assert f"{world} GPUs" in d["config"]["sharding"] and exchange in d["config"]["sharding"]
     assert d["value"] > 0 and "e2e_ms" in d and f"{world} GPUs" in d["e2e_what"]
+    if "--no-variants" not in extra:
+        # the same run times the variants that lift the fixed root's link bound, and every rank's render-only / exchange-only legs
+        pr_, ev = d["per_rank"], d["exchange_variants"]
+        assert len(pr_["render_only_ms"]) == world and len(pr_["exchange_only_ms"]) == world and min(pr_["render_only_ms"]) > 0
+        assert any(k.startswith("rotate_") for k in ev) and all("error" not in v for v in ev.values()), ev
+        assert all(v["mpix_s"] > 0 for v in ev.values())
+        assert d["config"]["frames_in_flight_per_gpu"] == 2 and d["config"]["frames_per_exchange"] == 4
