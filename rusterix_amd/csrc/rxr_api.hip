@@ -1183,6 +1183,15 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
         // tolerance of lit 3D fragments (shade3d_lights<X, true>; feature levels 0 and 1)
         const char *lm = getenv("RXR_LIGHT_MATH");
         P.relaxed_lights = lm ? (lm[0] == 'r' ? 1u : 0u) : (ctx->relaxed_lights ? 1u : 0u);
+        // the fused point-light term multiplies where the reference branches (a light out of range contributes intensity * 0): with an
+        // infinite or NaN intensity, colour, position or range that is NaN where the reference adds nothing.  Such frames -- no real
+        // scene has them -- take the exact loop, which skips and branches like the reference (light.rs:535-552).
+        for (uint32_t i = 0; i < f->n_lights && P.relaxed_lights; ++i) {
+            const rxr_light &l = f->lights[i];
+            const float v[] = {l.intensity, l.color[0], l.color[1], l.color[2], l.position[0], l.position[1], l.position[2], l.start_distance, l.end_distance, l.flicker};
+            for (float x : v)
+                if (!(std::fabs(x) <= 3.0e38f)) P.relaxed_lights = 0u;
+        }
         P.rl_flip_guard = 1e-4f;
         if (const char *fg = getenv("RXR_RL_FLIP_GUARD")) {  // tests: a large guard sends every wave down the exact normal sequences
             const float v = (float)atof(fg);
@@ -2368,6 +2377,9 @@ int rxr_selftest_math(rxr_ctx *ctx, uint64_t n_tuples, uint64_t seed, uint64_t m
 }  // extern "C"
 
 // what the run-time compiler did with the last program set of this context (rxr_jit.hip); "" when it was not asked
+// tests: how many launch sequences rxr_synchronize has rendered again after a list overflow (a plain context or a member)
+extern "C" uint32_t rxr_debug_rerenders(rxr_ctx *ctx) { return (ctx && !ctx->group) ? ctx->rerenders : 0u; }
+
 extern "C" const char *rxr_debug_jit_info(rxr_ctx *ctx) {
     if (!ctx) return "";
     if (ctx->group) return rxr_member(ctx, 0) ? rxr_member(ctx, 0)->jit_info.c_str() : "";

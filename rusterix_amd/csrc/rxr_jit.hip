@@ -712,6 +712,15 @@ int poll_background(rxr_ctx *ctx, int slot, int level, std::string &err) {
 }
 }  // namespace
 
+// tests (no device needed): the clean-up of stale job directories under `parent`, and where this process keeps its own
+extern "C" void rxr_debug_jit_sweep(const char *parent) { sweep_stale_job_dirs(parent); }
+extern "C" int rxr_debug_jit_job_parent(char *out, uint32_t capacity) {
+    std::string err;
+    const std::string p = job_parent(err);
+    snprintf(out, capacity, "%s", p.empty() ? err.c_str() : p.c_str());
+    return p.empty() ? RXR_ERR_INVALID : RXR_OK;
+}
+
 // rxr_jitc's half: generated source file -> code object file (no device needed)
 extern "C" int rxr_debug_jit_compile_file(const char *src_path, const char *arch, int level, const char *out_path) {
     std::string gen, err;

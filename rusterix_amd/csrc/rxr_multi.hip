@@ -78,6 +78,14 @@ struct rxr_group {
     bool bands = false;        // RXR_MULTI_SHARD=bands: contiguous row bands instead of interleaved stripes (A-B runs)
     bool copy_1d = false;      // RXR_MULTI_COPY=1d: one copy per stripe instead of one strided 2-D copy per member (A-B runs)
     bool rendered = false;
+    // the destination of the last rxr_render_gather: a member whose share is rendered again by rxr_synchronize (a bin list or a block of
+    // k_blockscan overflowed) must ship it again, or the root's frame keeps the incomplete stripes
+    struct {
+        bool active = false;
+        int root = 0;
+        uint8_t *frame = nullptr;
+        std::vector<uint32_t> rerenders;  // per member, when its share was shipped
+    } gather;
 };
 
 namespace {
@@ -275,6 +283,11 @@ int rxr_render_gather(rxr_ctx *ctx, int root, void *dev_pixels, void *hip_stream
     rxr_ctx *R = g->members[root];
     uint8_t *frame = (uint8_t *)(dev_pixels ? dev_pixels : R->d_fb.p);
     hipStream_t rs = hip_stream ? (hipStream_t)hip_stream : R->stream;
+    // whatever the consumer stream has queued so far (readers of the PREVIOUS frame in this buffer) comes before the members' writes
+    HIPCHK(ctx, hipSetDevice(R->device));
+    HIPCHK(ctx, hipEventRecord(R->ev_band[5], rs));
+    g->gather.active = false;
+    g->gather.rerenders.assign(n, 0u);
     int rc = run_all(ctx, [&](uint32_t i) -> int {
         rxr_ctx *m = g->members[i];
         HIPCHK(m, hipSetDevice(m->device));
@@ -292,10 +305,12 @@ int rxr_render_gather(rxr_ctx *ctx, int root, void *dev_pixels, void *hip_stream
         }
         int r = member_render(g, sh, i);
         if (r != RXR_OK) return r;
+        g->gather.rerenders[i] = m->rerenders;
         // push over xGMI on the SOURCE device's stream (one link per source, all concurrent); same-device members copy locally
+        HIPCHK(m, hipStreamWaitEvent(m->stream, R->ev_band[5], 0));
         r = member_ship(g, sh, i, frame, hipMemcpyDeviceToDevice);
         if (r != RXR_OK) return r;
-        HIPCHK(m, hipEventRecord(m->ev_band[0], m->stream));
+        HIPCHK(m, hipEventRecord(m->ev_band[4], m->stream));
         return RXR_OK;
     });
     if (rc != RXR_OK) return rc;
@@ -303,9 +318,12 @@ int rxr_render_gather(rxr_ctx *ctx, int root, void *dev_pixels, void *hip_stream
     HIPCHK(ctx, hipSetDevice(R->device));
     for (uint32_t i = 0; i < n; ++i) {
         if ((int)i == root && !g->bands) continue;
-        hipError_t e = hipStreamWaitEvent(rs, g->members[i]->ev_band[0], 0);
+        hipError_t e = hipStreamWaitEvent(rs, g->members[i]->ev_band[4], 0);
         if (e != hipSuccess) return rxr_fail(ctx, RXR_ERR_HIP, std::string("rxr_render_gather: hipStreamWaitEvent: ") + hipGetErrorString(e));
     }
+    g->gather.active = true;
+    g->gather.root = root;
+    g->gather.frame = frame;
     g->rendered = true;
     return RXR_OK;
 }
@@ -346,6 +364,7 @@ int rxr_group_set_shaders(rxr_ctx *ctx, const rxr_shader_set *set) {
 // the (small or replicated) scene goes to every device: N uploads over N PCIe links, flattened by N host threads
 int rxr_group_upload_frame(rxr_ctx *ctx, const rxr_frame *frame) {
     ctx->group->rendered = false;
+    ctx->group->gather.active = false;
     return run_all(ctx, [&](uint32_t i) { return rxr_upload_frame(ctx->group->members[i], frame); });
 }
 
@@ -353,6 +372,7 @@ int rxr_group_render(rxr_ctx *ctx) {
     rxr_group *g = ctx->group;
     Shard sh;
     if (!shard_of(g, sh)) return rxr_fail(ctx, RXR_ERR_INVALID, "render: no frame uploaded");
+    g->gather.active = false;
     const int rc = run_all(ctx, [&](uint32_t i) { return member_render(g, sh, i); });
     if (rc == RXR_OK) g->rendered = true;
     return rc;
@@ -378,6 +398,7 @@ int rxr_group_render_download(rxr_ctx *ctx, uint8_t *pixels) {
     rxr_group *g = ctx->group;
     Shard sh;
     if (!shard_of(g, sh)) return rxr_fail(ctx, RXR_ERR_INVALID, "rxr_render_download: no frame uploaded");
+    g->gather.active = false;
     const int rc = run_all(ctx, [&](uint32_t i) -> int {
         rxr_ctx *m = g->members[i];
         int r = member_render(g, sh, i);
@@ -445,7 +466,21 @@ int rxr_group_render_stripes_batch(rxr_ctx *ctx, uint32_t first, uint32_t stride
 }
 
 int rxr_group_synchronize(rxr_ctx *ctx) {
-    return run_all(ctx, [&](uint32_t i) { return rxr_synchronize(ctx->group->members[i]); });
+    rxr_group *g = ctx->group;
+    Shard sh{};
+    const bool gathered = g->gather.active && shard_of(g, sh);
+    return run_all(ctx, [&](uint32_t i) -> int {
+        rxr_ctx *m = g->members[i];
+        int rc = rxr_synchronize(m);
+        if (rc != RXR_OK) return rc;
+        // rxr_render_gather: a share that was rendered again (its lists had overflowed) reaches the root's frame only now
+        if (gathered && !((int)i == g->gather.root && !g->bands) && m->rerenders != g->gather.rerenders[i]) {
+            g->gather.rerenders[i] = m->rerenders;
+            if ((rc = member_ship(g, sh, i, g->gather.frame, hipMemcpyDeviceToDevice)) != RXR_OK) return rc;
+            HIPCHK(m, hipStreamSynchronize(m->stream));
+        }
+        return RXR_OK;
+    });
 }
 
 int rxr_group_get_stats(rxr_ctx *ctx, rxr_stats *out) {

@@ -87,6 +87,38 @@ fn fnv(h: &mut u64, bytes: &[u8]) {
 fn fnv_usize(h: &mut u64, v: usize) {
     fnv(h, &(v as u64).to_le_bytes());
 }
+/// Content fingerprint of a buffer that is expected to stay put (static tile textures, registered meshes): its length plus 256
+/// evenly spaced 16-byte probes and both ends.  Cheap enough for every frame (4 KB read per buffer) and catches the edits the
+/// reference allows in place (`Texture::set_pixel` / `fill` on `pub data`, a reallocation at the same address): a stale texel on
+/// the GPU would otherwise render silently wrong, where the reference reads texture memory every frame.  A change that touches
+/// none of the probes is not seen -- callers that edit a resident buffer in place call `invalidate_device_caches()`.
+fn fnv_sampled(h: &mut u64, bytes: &[u8]) {
+    fnv_usize(h, bytes.len());
+    if bytes.len() <= 8192 {
+        fnv(h, bytes);
+        return;
+    }
+    let step = bytes.len() / 256;
+    for k in 0..256 {
+        let at = k * step;
+        fnv(h, &bytes[at..at + 16]);
+    }
+    fnv(h, &bytes[bytes.len() - 64..]);
+}
+fn as_bytes<T>(v: &[T]) -> &[u8] {
+    // (plain-old-data slices only: f32 / usize tuples / Vec3)
+    unsafe { std::slice::from_raw_parts(v.as_ptr() as *const u8, std::mem::size_of_val(v)) }
+}
+
+/// Forgets what the shim believes the device holds (textures, programs, registered meshes): the next frame uploads all of it
+/// again.  For callers that edit a resident texture or mesh in place in a way the sampled fingerprints cannot see.
+pub fn invalidate_device_caches() {
+    if let Some(st) = STATE.lock().unwrap().as_mut() {
+        st.textures = 0;
+        st.shaders = 0;
+        st.meshes = 0;
+    }
+}
 
 // ---- NodeOp tree -> the word stream of include/rxr.h ------------------------------------------------------------
 /// Depth-first serialisation of `Program.user_functions[i]` (rusteria/src/node/nodeop.rs:12-103): opcode = the variant's
@@ -453,17 +485,25 @@ fn device_frame(this: &Rasterizer, scene: &Scene, pixels: &mut [u8], width: usiz
         // ---- textures: assets.tile_list (static) + scene.dynamic_textures + resolved sequence tiles ----
         {
             let mut h = 1469598103934665603u64;
-            let mut mix_tile = |t: &Tile| {
+            // the fingerprint covers CONTENTS, not only addresses: static tiles by sampled probes (fnv_sampled), dynamic textures
+            // and the resolved entity / item tiles -- small, rewritten per frame by the engine -- by a full hash
+            let mut mix_tile = |t: &Tile, full: bool| {
                 fnv_usize(&mut h, t.textures.len());
                 for x in &t.textures {
                     fnv_usize(&mut h, x.data.as_ptr() as usize);
                     fnv_usize(&mut h, x.width);
                     fnv_usize(&mut h, x.height);
+                    if full {
+                        fnv_usize(&mut h, x.data.len());
+                        fnv(&mut h, &x.data);
+                    } else {
+                        fnv_sampled(&mut h, &x.data);
+                    }
                 }
             };
-            assets.tile_list.iter().for_each(&mut mix_tile);
-            scene.dynamic_textures.iter().for_each(&mut mix_tile);
-            extra_tiles.iter().for_each(|t| mix_tile(unsafe { &**t }));
+            assets.tile_list.iter().for_each(|t| mix_tile(t, false));
+            scene.dynamic_textures.iter().for_each(|t| mix_tile(t, true));
+            extra_tiles.iter().for_each(|t| mix_tile(unsafe { &**t }, true));
             if h != st.textures {
                 let mut store: Vec<Vec<rxr_texture>> = vec![];
                 let mut view = |t: &Tile| -> (usize, u32) {
@@ -499,6 +539,11 @@ fn device_frame(this: &Rasterizer, scene: &Scene, pixels: &mut [u8], width: usiz
                     fnv_usize(&mut h, v);
                 }
                 fnv(&mut h, &s.pixel);
+                // ... and what the arrays hold (sampled: a registered mesh edited in place must be registered again)
+                fnv_sampled(&mut h, as_bytes(&b.vertices));
+                fnv_sampled(&mut h, as_bytes(&b.indices));
+                fnv_sampled(&mut h, as_bytes(&b.normals));
+                fnv_sampled(&mut h, as_bytes(&b.uvs));
                 mesh_transforms.extend_from_slice(&mat4_cols(&b.transform_3d)); // per frame: moving objects need no re-registration
             }
             if h != st.meshes {

@@ -123,6 +123,41 @@ def test_render_gather_into_root_framebuffer_and_caller_buffer(product, single_a
     assert b"multi-device" in rxr.rxr_last_error(ctx)
 
 
+@pytest.mark.parametrize("force", ["RXR_LIST_CAPACITY_FLOOR", "RXR_BLOCKSCAN_CAP"])
+def test_render_gather_with_overflowing_lists_ships_the_repaired_share(product, single_again, force):
+    """rxr_render_gather + a member whose bin lists (or k_blockscan's slots) overflow: rxr_synchronize renders that member's share
+    again, and the repaired stripes must reach the root's frame as well (round-2 advisor finding: they used to stay in the member's
+    own buffer while the call returned RXR_OK)"""
+    import torch
+
+    cfg = scenes.teapot_scene(product, width=640, height=360, logo_size=64)
+    ref = single_frame(product, cfg)
+    os.environ[force] = "512" if force == "RXR_LIST_CAPACITY_FLOOR" else "2"
+    if force == "RXR_LIST_CAPACITY_FLOOR":
+        os.environ["RXR_BLOCKSCAN"] = "0"  # the general count / scan / fill pipeline, whose lists then start at 512 entries
+    try:
+        rxr, ctx = use_members(product, 3)  # fresh member contexts: they read the variables
+        r = cfg.setup()
+        assert product.lib.rxh_rasterizer_upload(r._h, cfg.scene._h, cfg.width, cfg.height, cfg.tile_size, cfg.assets._h) == 0
+    finally:
+        for k in (force, "RXR_BLOCKSCAN"):
+            os.environ.pop(k, None)
+    before = [rxr.rxr_debug_rerenders(C.c_void_p(rxr.rxr_member(ctx, i))) for i in range(3)]
+    for root, own in ((1, False), (0, True)):
+        buf = torch.full((cfg.height, cfg.width, 4), 9, dtype=torch.uint8, device="cuda") if own else None
+        torch.cuda.synchronize()
+        assert rxr.rxr_render_gather(ctx, root, C.c_void_p(buf.data_ptr()) if own else None, None) == 0, rxr.rxr_last_error(ctx)
+        assert rxr.rxr_synchronize(ctx) == 0, rxr.rxr_last_error(ctx)
+        if own:
+            out = buf.cpu().numpy()
+        else:
+            out = np.zeros((cfg.height, cfg.width, 4), np.uint8)
+            assert rxr.rxr_download_rows(rxr.rxr_member(ctx, root), out.ctypes.data, 0, cfg.height) == 0
+        assert_exact(out, ref, f"gather to member {root} with overflowing lists ({force})")
+    after = [rxr.rxr_debug_rerenders(C.c_void_p(rxr.rxr_member(ctx, i))) for i in range(3)]
+    assert any(a > b for a, b in zip(after, before)), "the test scene did not overflow anything: it tests nothing"
+
+
 def test_plain_context_gather_and_member_api(product, single_again):
     cfg = scenes.map_scene(product, width=320, height=192, logo_size=64, n_lights=1)
     ref = single_frame(product, cfg)
@@ -206,3 +241,69 @@ def test_overflow_of_an_earlier_launch_is_reported(product, single_again):
     assert rxr.rxr_render_rows_to(m0, 0, cfg.height, C.c_void_p(last.data_ptr()), None) == 0
     assert rxr.rxr_synchronize(m0) == 0, rxr.rxr_last_error(m0)
     assert_exact(first.cpu().numpy(), ref, "after the lists have grown")
+
+
+# ---- frames in flight on one device: rxr_render_stripes_batch (plain context, a lane, the lane group) --------------------------
+def _upload(product, cfg):
+    r = cfg.setup()
+    assert product.lib.rxh_rasterizer_upload(r._h, cfg.scene._h, cfg.width, cfg.height, cfg.tile_size, cfg.assets._h) == 0, product.lib.rxh_last_error()
+    return product.lib.rxh_context()
+
+
+@pytest.mark.parametrize("scene", ["map", "binned"])
+@pytest.mark.parametrize("lanes,world,frames", [(1, 8, 5), (2, 8, 5), (3, 2, 7), (2, 3, 1)])
+def test_batched_stripes_equal_full_frame(product, single_again, scene, lanes, world, frames):
+    """`test_stripes_equal_full_frame` for the batch call: every frame of a batch -- through a plain context, through ONE lane of a
+    lane group (bench.py: lanes alternate per call) and through the group handle (lanes alternate per frame, forked from and joined
+    to the caller's stream) -- holds exactly the stripes rxr_render_stripes_to renders, i.e. the single-launch frame's."""
+    import torch
+
+    from rusterix_amd import distributed as D
+
+    if scene == "map":
+        cfg = scenes.map_scene(product, width=400, height=250, logo_size=64, n_lights=3)  # 250 rows: ragged last stripe
+    else:
+        cfg = scenes.small_triangle_mesh_scene(product, width=320, height=200, n_triangles=1500)  # bin lists: scratch shared by a context's frames
+    ref = single_frame(product, cfg)
+    if lanes > 1:
+        rxr, ctx = use_members(product, lanes)
+    else:
+        product.lib.rxh_set_device(0)
+        rxr = rusterix_amd.rxr_abi()
+    ctx = _upload(product, cfg)
+    spr = D.stripes_per_rank(cfg.height, world)
+    share = spr * D.TILE_H * cfg.width * 4
+    stream = torch.cuda.Stream()
+    sp = C.c_void_p(stream.cuda_stream)
+    handles = [("handle", C.c_void_p(ctx))] + ([("lane 1", C.c_void_p(rxr.rxr_member(ctx, 1)))] if lanes > 1 else [])
+    for what, h in handles:
+        for rank in sorted({0, world - 1}):
+            want = D.extract_stripes(ref, world, rank)
+            buf = torch.full((frames, spr * D.TILE_H, cfg.width, 4), 77, dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()
+            assert rxr.rxr_render_stripes_batch(h, rank, world, frames, C.c_void_p(buf.data_ptr()), C.c_size_t(share), sp) == 0, rxr.rxr_last_error(h)
+            stream.synchronize()  # the batch is complete on the caller's stream (the join)
+            got = buf.cpu().numpy()
+            assert rxr.rxr_synchronize(C.c_void_p(ctx)) == 0, rxr.rxr_last_error(ctx)
+            for k in range(frames):
+                # rows of a ragged last stripe beyond the frame are never written
+                rows = D.stripe_rows(cfg.height, world, rank)
+                for j, (a, b) in enumerate(rows):
+                    assert np.array_equal(got[k, j * D.TILE_H:j * D.TILE_H + (b - a)], want[j * D.TILE_H:j * D.TILE_H + (b - a)]), \
+                        f"{what}, {lanes} lane(s): frame {k} of the batch, rank {rank} of {world}, local stripe {j}"
+
+
+def test_batch_call_refusals(product, single_again):
+    import torch
+
+    cfg = scenes.map_scene(product, width=160, height=96, logo_size=32, n_lights=1)
+    product.lib.rxh_set_device(0)
+    rxr = rusterix_amd.rxr_abi()
+    ctx = C.c_void_p(_upload(product, cfg))
+    buf = torch.zeros((2, 96, 160, 4), dtype=torch.uint8, device="cuda")
+    p = C.c_void_p(buf.data_ptr())
+    assert rxr.rxr_render_stripes_batch(ctx, 0, 0, 2, p, C.c_size_t(96 * 160 * 4), None) == -1 and b"stride 0" in rxr.rxr_last_error(ctx)
+    assert rxr.rxr_render_stripes_batch(ctx, 0, 1, 2, None, C.c_size_t(96 * 160 * 4), None) == -1
+    assert rxr.rxr_render_stripes_batch(ctx, 0, 1, 2, p, C.c_size_t(64), None) == -1 and b"frame_stride_bytes" in rxr.rxr_last_error(ctx)
+    assert rxr.rxr_render_stripes_batch(ctx, 0, 1, 0, p, C.c_size_t(0), None) == 0  # nothing to do
+    assert rxr.rxr_synchronize(ctx) == 0

@@ -260,8 +260,17 @@ def test_all_light_types_and_sun(oracle, product):
         return cfg
 
     got, ref = scenes.render(build(product)), scenes.render(build(oracle))
-    # acosf decides cone membership: allow a handful of cone-edge pixels to flip
-    assert_close(got, ref, "all light types", max_outliers=got.shape[0] * got.shape[1] // 2000)
+    # acosf decides cone membership (`angle > cone_angle`, light.rs:559-580: a hard cut-off, and glibc's and OCML's acosf differ in the
+    # last place): a fragment exactly on the cone's edge may fall on the other side.  Allowed: at most 8 such pixels, each of them ON
+    # that edge -- i.e. where the oracle's own frame jumps by at least as much between neighbours.  Everything else within 1.
+    diff = np.abs(got.astype(np.int16) - ref.astype(np.int16)).max(axis=2)
+    bad = np.argwhere(diff > TOLERANCE)
+    assert len(bad) <= 8, f"all light types: {len(bad)} pixels differ by more than {TOLERANCE}"
+    r = ref.astype(np.int16)
+    for y, x in bad:
+        y0, y1, x0, x1 = max(y - 1, 0), min(y + 2, r.shape[0]), max(x - 1, 0), min(x + 2, r.shape[1])
+        jump = int(np.abs(r[y0:y1, x0:x1] - r[y, x]).max())
+        assert jump * 2 >= int(diff[y, x]), f"all light types: pixel (x={x}, y={y}) is off by {int(diff[y, x])} away from any edge of the oracle's frame (jump {jump})"
 
 
 def _light(kind, pos, direction=(0.0, 0.0, -1.0), cone_angle=0.785, normal=(0.0, 1.0, 0.0), start=1.0, end=2.0, intensity=1.0,
@@ -486,8 +495,11 @@ def test_million_triangle_grid_full_size_is_bit_exact(oracle, product, shader):
     ("C4 map 3840x2160, 16 lights", scenes.map_scene, dict(width=3840, height=2160, n_lights=16), 1, 256),
 ])
 def test_baseline_configs_at_full_size(oracle, product, name, builder, kw, tol, max_differing):
-    """BASELINE.json configs[1..3] at their full sizes against the oracle: bit-exact without lights; with lights (log2 / exp2
-    from different math libraries) nothing off by more than 1 and only a handful of pixels off at all."""
+    """BASELINE.json configs[1..3] at their full sizes against the oracle: bit-exact without lights; with lights nothing off by more
+    than 1 and only a handful of pixels off at all.  The pixel counts (64 / 256) are what the library's DEFAULT light-loop mode --
+    relaxed, rxr_set_light_math -- needs: it spends BASELINE.json's 1-per-channel tolerance on v_rsq / v_rcp products and leaves 4 of
+    2 073 600 (C3) and 112 of 8 294 400 (C4) pixels one step off; exact mode, where only log2f / exp2f of the two math libraries differ,
+    leaves 0 and 1 (tests/test_gpu_light_math.py::test_the_bench_frame_in_both_modes bounds it at 16)."""
     got = scenes.render(builder(product, **kw))
     ref = scenes.render(builder(oracle, **kw))
     diff = np.abs(got.astype(np.int16) - ref.astype(np.int16)).max(axis=2)
