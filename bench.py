@@ -48,22 +48,45 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 vector (FMA counted as 2)
 
 # rocprofv3 passes of this same command (3840x2160, 16 lights, 1 GPU), per raster-kernel launch, for the two light-loop modes.
-# NOT measured in this run: the PMC passes need the profiler (tools/profile_bench.sh); the numbers are copied here from the
-# committed summaries.
-PROFILES = {
-    "relaxed": {
-        "source": "profiles/r02/bench_relaxed_pmc_summary.json (tools/profile_bench.sh; rocprofv3 --pmc, separate passes; kernel k_raster_rl)",
-        "write_bytes": 35545373,       # WRITE_SIZE: the framebuffer (3840 * 2160 * 4 = 33 177 600) + 2.4 MB of spill traffic (8 B of scratch per lane)
-        "fetch_bytes_x2": 2235492,     # FETCH_SIZE with the gfx950 x2 correction
-        "valu_wave_instructions": 94031796,
-    },
-    "exact": {
-        "source": "profiles/r02/bench_relaxed_pmc_summary.json (the same passes: bench.py times the exact mode as well; kernel k_raster)",
-        "write_bytes": 33177600,
-        "fetch_bytes_x2": 2154732,
-        "valu_wave_instructions": 148910581,
-    },
-}
+# NOT measured in this run: the PMC passes need the profiler (tools/profile_bench.sh).  The numbers are READ from the committed
+# summary -- never copied into this file -- together with the hash of the kernel source they were taken on, so that a line
+# quoting a profile of an older kernel says so (`from_profiles.stale`; tests/test_bench_profiles.py).
+PROFILE_SUMMARY = "profiles/r03/bench_pmc_summary.json"
+KERNEL_SOURCES = ["rusterix_amd/csrc/rxr_kernels.hip", "rusterix_amd/csrc/rxr_device.h", "rusterix_amd/csrc/rxr_exact_math.h"]
+
+
+def kernel_sources_sha():
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        h.update(open(os.path.join(ROOT, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def load_profiles(path=None):
+    """{"relaxed": {...}, "exact": {...}} from the committed rocprofv3 summary (k_raster_rl / k_raster of the same passes: bench.py
+    times the other mode as well), or {} when the file is missing"""
+    path = os.path.join(ROOT, path or PROFILE_SUMMARY)
+    if not os.path.exists(path):
+        return {}
+    d = json.load(open(path))
+    out = {}
+    for mode, kernel in (("relaxed", "k_raster_rl"), ("exact", "k_raster")):
+        k = d.get("kernels", {}).get(kernel)
+        if not k or "write_bytes" not in k or "fetch_bytes_x2_gfx950" not in k or "SQ_INSTS_VALU" not in k:
+            continue
+        out[mode] = {
+            "source": f"{PROFILE_SUMMARY} (tools/profile_bench.sh; rocprofv3 --pmc, separate passes; kernel {kernel})",
+            "write_bytes": int(round(k["write_bytes"])),          # WRITE_SIZE
+            "fetch_bytes_x2": int(round(k["fetch_bytes_x2_gfx950"])),  # FETCH_SIZE with the gfx950 x2 correction
+            "valu_wave_instructions": int(round(k["SQ_INSTS_VALU"])),
+            "kernel_sources_sha": d.get("kernel_sources_sha"),
+        }
+    return out
+
+
+PROFILES = load_profiles()
 
 
 def algorithmic_bytes(width, height, n_vertices, n_triangles, texture_bytes, n_lights):
@@ -95,6 +118,8 @@ def parse_args():
                          "k mod L): the tail of one share's launches runs under the head of the next.  Default: 2 at N > 1, 1 at N = 1")
     ap.add_argument("--bucket", type=int, default=0,
                     help="N > 1: frames per exchange (one rxr_render_stripes_batch call and one collective per bucket); default 4")
+    ap.add_argument("--no-in-flight", action="store_true",
+                    help="N = 1: skip the two-frames-in-flight leg (profiling runs: its overlapped launches would mix into the per-kernel averages)")
     ap.add_argument("--no-variants", action="store_true", help="N > 1: skip the exchange variants and the per-rank render-only / exchange-only legs")
     ap.add_argument("--force-gather", action="store_true",
                     help="debug: run the stripe -> gather -> assemble path even at N=1 (never used by the driver)")
@@ -434,7 +459,7 @@ def main():
                           "mpix_s": round(W * H * args.steps / other_dt / 1e6, 2), "batches": len(other_s)}
         host.rxh_set_light_math_exact(0 if relaxed else 1)
         upload()
-    if world == 1 and not sharded:
+    if world == 1 and not sharded and not args.no_in_flight:
         # two frames in flight on the one GPU (two member contexts, frame i on lane i mod 2, each on its own stream): throughput
         # of the same K whole frames when the tail of one frame's launches runs under the head of the next.  Reported beside
         # `value` (the serial loop, one frame at a time, as a caller of rasterize() sees it), never as it.
@@ -487,7 +512,8 @@ def main():
         alg = algorithmic_bytes(W, rows_this_rank, n_verts, n_tris, tex_bytes, args.lights)
         achieved = alg / (raster_avg_us * 1e-6) / 1e9
         default_workload = (W, H, args.lights, world) == (3840, 2160, 16, 1) and not sharded
-        PROFILE = PROFILES["relaxed" if relaxed else "exact"]
+        PROFILE = PROFILES.get("relaxed" if relaxed else "exact")
+        default_workload = default_workload and PROFILE is not None
         out = {
             "metric": "Mpixels/s (+ ms/frame) on rasterize_map @3840x2160, 1/2/4/8 MI355X vs CPU",
             "value": round(value, 2),
@@ -544,6 +570,9 @@ def main():
                     "write_bytes": PROFILE["write_bytes"],
                     "fetch_bytes_x2": PROFILE["fetch_bytes_x2"],
                     "valu_wave_instructions_per_launch": PROFILE["valu_wave_instructions"],
+                    # the kernel source the profile was taken on against the one this run launched
+                    "kernel_sources_sha": PROFILE["kernel_sources_sha"],
+                    "stale": PROFILE["kernel_sources_sha"] != kernel_sources_sha(),
                 } if default_workload else None,
             },
         }
@@ -656,18 +685,24 @@ def cpu_baseline(W, H, n_lights):
     small = scenes.map_scene(orc, width=W // 2, height=H // 2, n_lights=n_lights)
     small_out = np.zeros((W // 2) * (H // 2) * 4, np.uint8)
     t1 = frame(1, small, small_out)
+    value = W * H * done / dt / 1e6
+    one = (W // 2) * (H // 2) / t1 / 1e6
     return {
-        "value": round(W * H * done / dt / 1e6, 3),
+        "value": round(value, 3),
         "unit": "Mpixels/s",
         "cores": best,
         "host_cores": cores,
         "kind": "port",
         "ms_per_frame": round(dt / done * 1e3, 1),
         "thread_sweep_mpix_s": {str(t): round(W * H / s / 1e6, 2) for t, s in sweep.items()},
-        "one_thread_mpix_s": round((W // 2) * (H // 2) / t1 / 1e6, 3),
+        "one_thread_mpix_s": round(one, 3),
+        "scaling_1_to_best": round(value / one, 1),
         "sample": f"{done} full frames of the same workload ({W}x{H}, {n_lights} lights, tile_size 40) on {best} threads (the best of the sweep "
                   f"{sorted(sweep)}, one warm-up frame before); 1-thread figure: one frame at {W // 2}x{H // 2}; C++ restatement of the reference "
-                  "algorithm (-O3 -ffp-contract=off), std::thread pool over tiles, includes Scene::project",
+                  "algorithm (-O3 -ffp-contract=off), std::thread pool over tiles, includes Scene::project.  Scaling: "
+                  f"{one:.2f} Mpixel/s on 1 thread -> {value:.1f} on {best} threads = {value / one:.1f}x (of {cores} hardware threads; more threads are "
+                  "slower: the five per-tile heap allocations of rasterizer.rs:277-290, which the port keeps, serialise in the allocator).  "
+                  "Context for the GPU number, never credit",
     }
 
 

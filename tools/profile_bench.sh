@@ -8,8 +8,8 @@ EXTRA="$*"
 export TMPDIR=/tmp
 OUT=gpurun_out/$TAG
 mkdir -p "$OUT"
-KT="--steps 100 --warmup 10 --no-cpu --no-e2e $EXTRA"
-PM="--steps 20 --warmup 2 --no-cpu --no-e2e $EXTRA"
+KT="--steps 100 --warmup 10 --no-cpu --no-e2e --no-in-flight $EXTRA"
+PM="--steps 20 --warmup 2 --no-cpu --no-e2e --no-in-flight $EXTRA"
 export RXR_BENCH_MIN_TIMED_S=0.05   # the counter passes need launches, not a long timed region
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -- python3 bench.py $KT > "$OUT/kt.log" 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_INSTS_LDS \

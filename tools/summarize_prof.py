@@ -33,7 +33,13 @@ for k, cs in summary.items():
         cs["write_bytes"] = cs["WRITE_SIZE"] * 1024
     if "SQ_THREAD_CYCLES_VALU" in cs and cs.get("SQ_ACTIVE_INST_VALU"):
         cs["valu_lane_utilisation"] = cs["SQ_THREAD_CYCLES_VALU"] / (cs["SQ_ACTIVE_INST_VALU"] * 64.0)
-res = {"bench_line": json.loads(bench[-1]) if bench else None, "kernels": summary}
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+try:
+    import bench as _bench  # the hash of the kernel sources these counters were taken on (bench.py quotes it with the numbers)
+    sha = _bench.kernel_sources_sha()
+except Exception:
+    sha = None
+res = {"bench_line": json.loads(bench[-1]) if bench else None, "kernel_sources_sha": sha, "kernels": summary}
 json.dump(res, open(os.path.join(out, "pmc_summary.json"), "w"), indent=1)
 for k, cs in summary.items():
     print(k, {c: round(v, 1) for c, v in cs.items() if not c.startswith("launches")})
