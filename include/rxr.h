@@ -445,6 +445,37 @@ int rxr_check_shaders(const rxr_shader_set *set, uint32_t *code_words, char *mes
 #define RXR_LIGHT_MATH_RELAXED 1
 int rxr_set_light_math(rxr_ctx *ctx, int mode);
 
+/* Streaming hand-over for large scenes (an addition to ABI 4; optional -- rxr_upload_frame alone does the same, later).
+ * The reference projects a scene's batches in parallel (Scene::project: rayon par_iter_mut, src/scene.rs:154-200) and only then
+ * walks the tiles; with the tiles on the GPU, projecting a million triangles and THEN copying 124 MB to the device takes the host
+ * longer than the GPU needs for ten frames.  A host that projects batch by batch hands each 3D batch over as soon as its
+ * clip_and_project is done, from whatever thread did it:
+ *     rxr_stream_begin(ctx, n, vertex_capacity, triangle_capacity)   n = the frame's number of 3D batches (rxr_frame.batches3d, same
+ *                             order); capacity[i] = an upper bound of what projecting batch i can produce (vertices: n + 4 m,
+ *                             triangles: 3 m for a batch of n vertices and m triangles covers the near-plane clip, batch3d.rs:627-686).
+ *                             Waits for the previous frame's renders.
+ *     rxr_stream_batch3d(ctx, i, &projected)      thread-safe, any order; only the five arrays and the two counts are read.  The arrays
+ *                             must stay unchanged until rxr_upload_frame has returned.  Batches are retired in index order (a batch's
+ *                             place in the pools -- hence the submission order of its triangles, which breaks depth ties -- is the sum
+ *                             of its predecessors' sizes), copied into pinned memory and sent to the device in groups, while the
+ *                             host projects the batches behind them.
+ *     rxr_upload_frame(ctx, &frame)               as always, with frame.batches3d[i] naming the SAME arrays and counts: it then only
+ *                             adds what surrounds them.  If anything differs (a batch missing, other pointers, a capacity exceeded)
+ *                             the frame is handed over from scratch as if nothing had been streamed: correct either way.
+ * Measured (1 M triangles, 7680x4320, 64 host threads, profiles/r03/c5_e2e_*): the call Rasterizer::rasterize 14.5 -> x ms.
+ * Multi-device handles: RXR_ERR_UNSUPPORTED (use rxr_upload_frame). */
+int rxr_stream_begin(rxr_ctx *ctx, uint32_t n_batches3d, const uint32_t *vertex_capacity, const uint32_t *triangle_capacity);
+/* The same with a promise: EVERY array handed to rxr_stream_batch3d lies in page-locked host memory that the device can read
+ * (rxr_alloc_pinned below, hipHostMalloc, or memory registered with rxr_pin_host_buffer / hipHostRegister).  The library then
+ * copies nothing on the host: a kernel on the device pulls each group of batches straight out of the caller's arrays over PCIe
+ * into the pools.  A pointer that breaks the promise is a device page fault -- only promise what an allocator guarantees. */
+int rxr_stream_begin_pinned(rxr_ctx *ctx, uint32_t n_batches3d, const uint32_t *vertex_capacity, const uint32_t *triangle_capacity);
+/* page-locked, device-readable host memory for a host's projected arrays (NULL when there is no device or no memory: fall back to
+ * ordinary memory and rxr_stream_begin).  No context needed; free with rxr_free_pinned. */
+void *rxr_alloc_pinned(size_t bytes);
+void rxr_free_pinned(void *ptr);
+int rxr_stream_batch3d(rxr_ctx *ctx, uint32_t index, const rxr_batch3d *projected);
+
 /* validates + flattens a projected frame and copies it to HBM (replaces nothing in the reference:
  * it is the host->device hand-over).  The frame stays resident until the next upload. */
 int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *frame);

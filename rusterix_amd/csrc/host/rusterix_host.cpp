@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -11,6 +12,25 @@
 #include <mutex>
 
 namespace rusterix {
+
+void *PinnedPool::take(size_t bytes, bool &pinned) {
+    pinned = false;
+    if (bytes >= threshold) {
+        const char *pa = getenv("RXR_PINNED_ARRAYS");  // (0: ordinary memory -- tests and A-B runs)
+        if (!(pa && pa[0] == '0'))
+            if (void *p = rxr_alloc_pinned(bytes)) {
+                pinned = true;
+                return p;
+            }
+        any_unpinned() = true;
+    }
+    return malloc(bytes);
+}
+void PinnedPool::give(void *p, bool pinned) {
+    if (pinned) rxr_free_pinned(p);
+    else free(p);
+}
+
 
 namespace {
 
@@ -220,9 +240,9 @@ bool Batch3D::clip_and_project(const Mat4 &view_matrix, const Mat4 &projection_m
     }
 
     const float near_plane = 0.1f;
-    clipped_indices = indices;
-    clipped_uvs = uvs;
-    clipped_normals = normals;
+    clipped_indices.assign(indices.begin(), indices.end());
+    clipped_uvs.assign(uvs.begin(), uvs.end());
+    clipped_normals.assign(normals.begin(), normals.end());
     std::vector<uint8_t> edge_visibility(nt, 1);
     std::vector<ClipVertex> fresh;  // vertices created by clipping, appended after the originals
 
@@ -400,7 +420,21 @@ struct ProjectJobs {
 };
 }  // namespace
 
-bool Scene::project(const Mat3 *m2d, const Mat4 &view, const Mat4 &proj, float w, float h) {
+std::vector<const Batch3D *> Scene::batches3d_in_order() const {
+    std::vector<const Batch3D *> out;
+    for (const Chunk &c : chunks) {
+        for (const Batch3D &b : c.batches3d_opacity) out.push_back(&b);
+        for (const Batch3D &b : c.batches3d) out.push_back(&b);
+        for (const Batch3D &b : c.terrain_batch3d) out.push_back(&b);
+    }
+    for (const Batch3D &b : d3_static) out.push_back(&b);
+    for (const Batch3D &b : d3_dynamic) out.push_back(&b);
+    for (const Batch3D &b : d3_overlay) out.push_back(&b);
+    return out;
+}
+
+bool Scene::project(const Mat3 *m2d, const Mat4 &view, const Mat4 &proj, float w, float h,
+                    const std::function<void(size_t, const Batch3D &)> *on_projected3d) {
     ProjectJobs jobs;
     for (Chunk &c : chunks) {
         jobs.add(c.batches2d);
@@ -419,6 +453,7 @@ bool Scene::project(const Mat3 *m2d, const Mat4 &view, const Mat4 &proj, float w
     rxr_parallel::run(n3 + jobs.d2.size(), jobs.weight, [&](size_t i) {
         if (i < n3) {
             if (!jobs.d3[i]->clip_and_project(view, proj, w, h)) ok.store(false, std::memory_order_relaxed);
+            else if (on_projected3d) (*on_projected3d)(i, *jobs.d3[i]);  // (jobs.d3 is in submission order: batches3d_in_order())
         } else {
             jobs.d2[i - n3]->project(m2d);
         }
@@ -631,9 +666,61 @@ int Rasterizer::upload(Scene &scene, size_t w, size_t h, size_t tile_size, const
     const bool on_device = g_device_projection;
     if (on_device) {
         scene.project_2d(has_m2d ? &projection_matrix_2d : nullptr);  // the 3D half runs on the GPU
-    } else if (!scene.project(has_m2d ? &projection_matrix_2d : nullptr, view_matrix, projection_matrix, width, height)) {  // :210
-        g_error = "clip_and_project: batch without normals (the reference panics at batch3d.rs:605)";
-        return RXR_ERR_INVALID;
+    } else {
+        const auto tp = std::chrono::steady_clock::now();
+        // Large scenes on a plain context: every 3D batch is handed to the device as soon as it is projected (rxr_stream_batch3d) --
+        // the copy into pinned memory and the PCIe transfer of the batches that are done run under the projection of the rest.
+        // RXR_STREAM_UPLOAD=0 keeps the plain sequence (project everything, then rxr_upload_frame copies everything).
+        std::function<void(size_t, const Batch3D &)> hand_over;
+        const char *su = getenv("RXR_STREAM_UPLOAD");  // (read per frame: tests switch it)
+        const bool stream_off = su && su[0] == '0', stream_forced = su && su[0] == 'f';
+        if (!stream_off && rxr_member_count(ctx) == 1) {
+            const std::vector<const Batch3D *> order = scene.batches3d_in_order();
+            size_t elements = 0;
+            std::vector<uint32_t> cap_v(order.size()), cap_t(order.size());
+            for (size_t i = 0; i < order.size(); ++i) {
+                const size_t nv = order[i]->vertex_count(), nt = order[i]->triangle_count();
+                cap_v[i] = (uint32_t)std::min<size_t>(nv + 4 * nt, 0x7FFFFFFFu);  // the near-plane clip appends at most 4 vertices and
+                cap_t[i] = (uint32_t)std::min<size_t>(3 * nt, 0x7FFFFFFFu);       // 2 triangles per triangle (batch3d.rs:627-686)
+                elements += nv + nt;
+            }
+            // the promise of rxr_stream_begin_pinned is made when the buffers every batch projected into LAST frame are page-locked
+            // (clip_and_project refills the same vectors; the first frame of a scene, whose vectors do not exist yet, copies).  It is
+            // checked again per batch at hand-over: a vector that had to grow into ordinary memory is not handed over, and the frame
+            // then goes the plain way.
+            auto arrays_pinned = [](const Batch3D &b) {
+                return is_pinned(b.projected_vertices) && is_pinned(b.clipped_uvs) && is_pinned(b.clipped_indices) && is_pinned(b.edges) &&
+                       (b.normals.empty() || is_pinned(b.clipped_normals));
+            };
+            bool pinned = true;
+            for (size_t i = 0; i < order.size() && pinned; ++i) pinned = arrays_pinned(*order[i]);
+            const bool large = (order.size() >= 8 && elements >= (1u << 20)) || (stream_forced && order.size() >= 2);
+            const int began = !large ? RXR_ERR_UNSUPPORTED
+                              : pinned ? rxr_stream_begin_pinned(ctx, (uint32_t)order.size(), cap_v.data(), cap_t.data())
+                                       : rxr_stream_begin(ctx, (uint32_t)order.size(), cap_v.data(), cap_t.data());
+            if (began == RXR_OK) {
+                hand_over = [ctx, pinned, arrays_pinned](size_t i, const Batch3D &b) {
+                    if (pinned && b.edges.size() && !arrays_pinned(b)) return;  // (the promise does not hold for this batch: not handed over)
+                    rxr_batch3d v{};
+                    v.projected_vertices = b.projected_vertices.data();
+                    v.clipped_uvs = b.clipped_uvs.data();
+                    v.clipped_normals = b.normals.empty() ? nullptr : b.clipped_normals.data();
+                    v.clipped_indices = b.clipped_indices.data();
+                    v.edges = b.edges.data();
+                    v.n_vertices = (uint32_t)(b.projected_vertices.size() / 4);
+                    v.n_triangles = (uint32_t)b.edges.size();
+                    (void)rxr_stream_batch3d(ctx, (uint32_t)i, &v);  // (a refusal makes rxr_upload_frame hand the frame over from scratch)
+                };
+            }
+        }
+        static const bool timing0 = getenv("RXR_E2E_TIMING") != nullptr;
+        if (timing0) fprintf(stderr, "rxr_e2e_timing before project (stream set-up) %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp).count());
+        if (!scene.project(has_m2d ? &projection_matrix_2d : nullptr, view_matrix, projection_matrix, width, height, hand_over ? &hand_over : nullptr)) {  // :210
+            g_error = "clip_and_project: batch without normals (the reference panics at batch3d.rs:605)";
+            return RXR_ERR_INVALID;
+        }
+        static const bool timing = getenv("RXR_E2E_TIMING") != nullptr;
+        if (timing) fprintf(stderr, "rxr_e2e_timing project_ms=%.3f\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp).count());
     }
     for (const Chunk &c : scene.chunks)  // :219-223
         for (const CompiledLight &l : c.lights) scene.dynamic_lights.push_back(l);
@@ -885,8 +972,11 @@ int Rasterizer::rasterize(Scene &scene, uint8_t *pixels, size_t w, size_t h, siz
         g_error = "tile_size 0 (step_by(0) panics in the reference)";
         return RXR_ERR_INVALID;
     }
+    static const bool timing = getenv("RXR_E2E_TIMING") != nullptr;  // diagnostics (tools/e2e_probe.py)
+    const auto t0 = std::chrono::steady_clock::now();
     int rc = upload(scene, w, h, tile_size, assets);
     if (rc != RXR_OK) return rc;
+    if (timing) fprintf(stderr, "rxr_e2e_timing project_and_handover_ms=%.3f\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     rxr_ctx *ctx = context();
     rc = rxr_render_download(ctx, pixels);
     if (rc != RXR_OK) g_error = rxr_last_error(ctx);

@@ -15,12 +15,53 @@
 #include <cstdint>
 #include <map>
 #include <string>
+#include <functional>
+#include <new>
 #include <vector>
 
 #include "../../../include/rusterix_vek.hpp"
 #include "../../../include/rxr.h"
 
 namespace rusterix {
+
+// Allocator of the projected arrays: page-locked, device-readable memory from the device library (rxr_alloc_pinned) while that
+// works, ordinary memory otherwise (no GPU: the CPU tests project with this mirror too).  Large blocks only -- a page-locked block
+// costs a system call, and small scenes are not streamed anyway.  all_pinned() tells Rasterizer::upload whether the promise of
+// rxr_stream_begin_pinned can be made: false as soon as ONE block of at least the threshold had to come from malloc.
+struct PinnedPool {
+    static constexpr size_t threshold = 8u << 10;
+    static bool &any_unpinned() {
+        static bool v = false;
+        return v;
+    }
+    static void *take(size_t bytes, bool &pinned);
+    static void give(void *p, bool pinned);
+};
+template <class T> struct PinnedAlloc {
+    using value_type = T;
+    PinnedAlloc() = default;
+    template <class U> PinnedAlloc(const PinnedAlloc<U> &) {}
+    T *allocate(size_t n) {
+        // one header word in front of the block says where it came from
+        const size_t bytes = n * sizeof(T) + 64;
+        bool pinned = false;
+        uint8_t *raw = (uint8_t *)PinnedPool::take(bytes, pinned);
+        if (!raw) throw std::bad_alloc();
+        *(uint64_t *)raw = pinned ? 1u : 0u;
+        return (T *)(raw + 64);
+    }
+    void deallocate(T *p, size_t) {
+        uint8_t *raw = (uint8_t *)p - 64;
+        PinnedPool::give(raw, *(uint64_t *)raw != 0u);
+    }
+    template <class U> bool operator==(const PinnedAlloc<U> &) const { return true; }
+    template <class U> bool operator!=(const PinnedAlloc<U> &) const { return false; }
+};
+template <class T> using PinnedVec = std::vector<T, PinnedAlloc<T>>;
+// is the vector's CURRENT buffer page-locked?  (the allocator's header word in front of it)
+// (a vector without a buffer -- a batch that was always rejected -- has nothing the device could read: fine)
+template <class T> inline bool is_pinned(const PinnedVec<T> &v) { return v.capacity() == 0 || *(const uint64_t *)((const uint8_t *)v.data() - 64) == 1u; }
+
 
 using rvek::Mat3;
 using rvek::Mat4;
@@ -102,11 +143,13 @@ public:
     std::vector<uint32_t> indices;         // [m][3]
     std::vector<float> uvs;                // [n][2]
     std::vector<float> normals;            // [n][3] or empty
-    std::vector<float> projected_vertices; // [n'][4]
-    std::vector<uint32_t> clipped_indices; // [m'][3]
-    std::vector<float> clipped_uvs;        // [n'][2]
-    std::vector<float> clipped_normals;    // [n'][3]
-    std::vector<rxr_edges> edges;          // [m']
+    // what clip_and_project produces lives in page-locked memory when a device is there (PinnedAlloc below): the library's streaming
+    // hand-over then lets the GPU read it in place (rxr_stream_begin_pinned) instead of copying it into a staging buffer first
+    PinnedVec<float> projected_vertices;    // [n'][4]
+    PinnedVec<uint32_t> clipped_indices;    // [m'][3]
+    PinnedVec<float> clipped_uvs;           // [n'][2]
+    PinnedVec<float> clipped_normals;       // [n'][3]
+    PinnedVec<rxr_edges> edges;             // [m']
     bool has_bounding_box = false;
     Rect bounding_box;
     uint32_t repeat_mode_ = RXR_REPEAT_CLAMP_XY;
@@ -199,7 +242,12 @@ public:
     size_t add_program(Program p) { shaders.push_back(std::move(p)); shaders_generation = next_generation(); return shaders.size() - 1; }
 
     // src/scene.rs:154-200.  false where the reference panics.
-    bool project(const Mat3 *m2d, const Mat4 &view, const Mat4 &proj, float width, float height);
+    // on_projected3d (optional): called on the projecting thread right after clip_and_project of 3D batch `index` (index = the batch's
+    // position in the submission order of Rasterizer::upload's frame) -- the hook of the streaming hand-over (rxr_stream_batch3d)
+    bool project(const Mat3 *m2d, const Mat4 &view, const Mat4 &proj, float width, float height,
+                 const std::function<void(size_t index, const Batch3D &)> *on_projected3d = nullptr);
+    // the 3D batches in submission order (what project() walks and Rasterizer::upload flattens)
+    std::vector<const Batch3D *> batches3d_in_order() const;
     // the 2D half only (src/scene.rs:163-187); used when the 3D half runs on the device
     void project_2d(const Mat3 *m2d);
 };

@@ -9,7 +9,10 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <memory>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -186,6 +189,11 @@ int rxr_set_light_math(rxr_ctx *ctx, int mode) {
 }
 
 void rxr_destroy(rxr_ctx *ctx) {
+    if (ctx && !ctx->group && ctx->fstream.table) {
+        (void)hipSetDevice(ctx->device);
+        (void)hipHostFree(ctx->fstream.table);
+        ctx->fstream.table = nullptr;
+    }
     if (!ctx) return;
     if (ctx->group) {
         rxr_group_destroy(ctx);
@@ -529,6 +537,310 @@ static int resolve_source(rxr_ctx *ctx, const rxr_source &src, bool is_3d, int c
     }
 }
 
+// rxr_stream_begin_pinned: the device pulls a group of batches out of the host's own (page-locked) arrays.  One workgroup per 16 KB
+// piece; an entry's pieces are consecutive (first_piece), the workgroup finds its entry by bisection in the (pinned) table.  Sources
+// and destinations are 4-byte aligned (destinations are v0 * 12 / t0 * 12 bytes into a pool): dword copies, 256 bytes per wave
+// instruction, sixteen independent loads per lane in flight over PCIe.
+#define RXR_GATHER_PIECE 16384u
+extern "C" __global__ void __launch_bounds__(256) k_gather_host(const FrameStream::GatherEntry *entries, uint32_t n_entries, uint8_t *blob) {
+    const uint32_t piece = blockIdx.x;
+    uint32_t lo = 0, hi = n_entries;
+    while (hi - lo > 1u) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (entries[mid].first_piece <= piece) lo = mid;
+        else hi = mid;
+    }
+    const FrameStream::GatherEntry E = entries[lo];
+    const uint32_t at = (piece - E.first_piece) * RXR_GATHER_PIECE;  // byte offset of this piece inside the entry
+    const uint32_t n_bytes = min(E.bytes - at, RXR_GATHER_PIECE);
+    const uint8_t *src = (const uint8_t *)E.src + at;
+    uint8_t *dst = blob + E.dst_off + at;
+    if ((((uintptr_t)src | (uintptr_t)dst | n_bytes) & 15u) == 0u) {
+        // (workgroup-uniform) both ends 16-byte aligned -- the projected vertices always are: 1 KB per wave instruction
+        const uint32_t n16 = n_bytes >> 4;
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t i = (uint32_t)k * 256u + threadIdx.x;
+            v[k] = i < n16 ? __builtin_nontemporal_load((const u32x4 *)src + i) : (u32x4)(0u);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t i = (uint32_t)k * 256u + threadIdx.x;
+            if (i < n16) ((u32x4 *)dst)[i] = v[k];
+        }
+        return;
+    }
+    const uint32_t n_dw = n_bytes >> 2;
+    uint32_t v[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const uint32_t i = (uint32_t)k * 256u + threadIdx.x;
+        v[k] = i < n_dw ? __builtin_nontemporal_load((const uint32_t *)src + i) : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const uint32_t i = (uint32_t)k * 256u + threadIdx.x;
+        if (i < n_dw) ((uint32_t *)dst)[i] = v[k];
+    }
+}
+
+void *rxr_alloc_pinned(size_t bytes) {
+    void *p = nullptr;
+    if (rxr_device_count() <= 0 || hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return p;
+}
+void rxr_free_pinned(void *ptr) {
+    if (ptr) (void)hipHostFree(ptr);
+}
+
+// the frame blob up to the end of the projected arrays: headers, triangle bases, then the five pools (n_v vertices, n_t triangles)
+static size_t layout_prefix(size_t n_b3, size_t n_v, size_t n_t, Layout &L) {
+    size_t o = 0;
+    auto take = [&](size_t bytes) {
+        size_t at = o;
+        o = align_up(o + (bytes ? bytes : 16), 256);
+        return at;
+    };
+    L.off_b3 = take(n_b3 * sizeof(DevBatch));
+    L.off_base = take((n_b3 + 1) * sizeof(uint32_t));
+    L.off_pv = take(n_v * 16);
+    L.off_uv = take(n_v * 8);
+    L.off_nrm = take(n_v * 12);
+    L.off_idx = take(n_t * 12);
+    L.off_edges = take(n_t * sizeof(rxr_edges));
+    return o;
+}
+
+static int stream_begin(rxr_ctx *ctx, uint32_t n_batches3d, const uint32_t *vertex_capacity, const uint32_t *triangle_capacity, bool pinned);
+int rxr_stream_begin(rxr_ctx *ctx, uint32_t n_batches3d, const uint32_t *vertex_capacity, const uint32_t *triangle_capacity) {
+    return stream_begin(ctx, n_batches3d, vertex_capacity, triangle_capacity, false);
+}
+int rxr_stream_begin_pinned(rxr_ctx *ctx, uint32_t n_batches3d, const uint32_t *vertex_capacity, const uint32_t *triangle_capacity) {
+    return stream_begin(ctx, n_batches3d, vertex_capacity, triangle_capacity, true);
+}
+static int stream_begin(rxr_ctx *ctx, uint32_t n_batches3d, const uint32_t *vertex_capacity, const uint32_t *triangle_capacity, bool pinned) {
+    if (!ctx) return RXR_ERR_INVALID;
+    if (ctx->group) return fail(ctx, RXR_ERR_UNSUPPORTED, "rxr_stream_begin on a multi-device context: hand the frame over with rxr_upload_frame");
+    FrameStream &S = ctx->fstream;
+    S.active = false;
+    if (n_batches3d == 0 || !vertex_capacity || !triangle_capacity) return fail(ctx, RXR_ERR_INVALID, "rxr_stream_begin: no batches / NULL capacities");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    size_t cv = 0, ct = 0;
+    for (uint32_t i = 0; i < n_batches3d; ++i) {
+        cv += vertex_capacity[i];
+        ct += triangle_capacity[i];
+    }
+    if (cv >= (1ull << 31) || ct >= (1ull << 31)) return fail(ctx, RXR_ERR_INVALID, "rxr_stream_begin: frame too large (>= 2^31 vertices or triangles)");
+    Layout L{};
+    const size_t prefix = layout_prefix(n_batches3d, cv, ct, L);
+    // what follows the arrays in the blob (lights, 2D primitives, chunk textures ...) is only known at rxr_upload_frame: room for what
+    // the last frame needed plus a margin; a frame that needs more falls back to the plain hand-over there
+    const size_t tail_room = std::max<size_t>(16u << 20, 2 * ctx->last_blob_tail);
+    int rc;
+    // the previous frame's renders read the blob, its transfers the staging memory: nothing of that may still run
+    if ((rc = rxr_quiesce(ctx)) != RXR_OK) return rc;
+    if ((rc = ensure_stage(ctx, prefix + tail_room)) != RXR_OK) return rc;
+    if ((rc = ensure(ctx, ctx->d_frame, prefix + tail_room)) != RXR_OK) return rc;
+    S.n = n_batches3d;
+    S.rec.assign(n_batches3d, FrameStream::Rec{});
+    S.cap_v.assign(vertex_capacity, vertex_capacity + n_batches3d);
+    S.cap_t.assign(triangle_capacity, triangle_capacity + n_batches3d);
+    S.done.reset(new std::atomic<uint8_t>[n_batches3d]);
+    for (uint32_t i = 0; i < n_batches3d; ++i) S.done[i].store(0, std::memory_order_relaxed);
+    // few, large transfers (every hipMemcpyAsync costs its caller ~20 us): eight groups of consecutive batches
+    S.group_size = std::max<uint32_t>(1u, (n_batches3d + 7u) / 8u);
+    S.n_groups = (n_batches3d + S.group_size - 1u) / S.group_size;
+    S.group_left.reset(new std::atomic<uint32_t>[S.n_groups]);
+    for (uint32_t g = 0; g < S.n_groups; ++g) S.group_left[g].store(std::min(S.group_size, n_batches3d - g * S.group_size), std::memory_order_relaxed);
+    S.next = 0;
+    S.retired.store(0);
+    S.copy_next.store(0);
+    S.vcur = S.tcur = 0;
+    S.total_cap_v = cv;
+    S.total_cap_t = ct;
+    S.off_pv = L.off_pv; S.off_uv = L.off_uv; S.off_nrm = L.off_nrm; S.off_idx = L.off_idx; S.off_edges = L.off_edges;
+    S.off_after = prefix;
+    S.blob_capacity = std::min(ctx->h_stage_cap, ctx->d_frame.cap);
+    S.pinned = pinned;
+    if (pinned && S.table_cap < (size_t)n_batches3d * 5u) {
+        if (S.table) (void)hipHostFree(S.table);
+        S.table = nullptr;
+        S.table_cap = 0;
+        HIPCHK(ctx, hipHostMalloc((void **)&S.table, ((size_t)n_batches3d * 5u + 64u) * sizeof(FrameStream::GatherEntry), hipHostMallocDefault));
+        S.table_cap = (size_t)n_batches3d * 5u + 64u;
+    }
+    S.handed.store(0);
+    S.failed.store(0);
+    S.err.clear();
+    ctx->has_frame = false;
+    S.active = true;
+    if (getenv("RXR_E2E_TIMING")) fprintf(stderr, "rxr_e2e_timing stream_begin (%s)\n", pinned ? "pinned" : "copy");
+    return RXR_OK;
+}
+
+// copy mode: claims retired batches one by one, copies their arrays to their dense places in the pinned staging blob and ships a
+// group's five ranges when its last batch has landed.  Any thread; `limit` bounds the batches taken by this call.
+static bool rxr_stream_copy_some(rxr_ctx *ctx, uint32_t limit) {
+    FrameStream &S = ctx->fstream;
+    uint8_t *const st = (uint8_t *)ctx->h_stage;
+    for (uint32_t taken = 0; taken < limit; ++taken) {
+        uint32_t j = S.copy_next.load(std::memory_order_relaxed);
+        for (;;) {
+            if (j >= S.retired.load(std::memory_order_acquire)) return true;
+            if (S.copy_next.compare_exchange_weak(j, j + 1u, std::memory_order_relaxed)) break;
+        }
+        const FrameStream::Rec &Q = S.rec[j];
+        if (Q.nv) {
+            memcpy(st + S.off_pv + Q.v0 * 16, Q.pv, (size_t)Q.nv * 16);
+            memcpy(st + S.off_uv + Q.v0 * 8, Q.uv, (size_t)Q.nv * 8);
+            if (Q.nrm) memcpy(st + S.off_nrm + Q.v0 * 12, Q.nrm, (size_t)Q.nv * 12);
+        }
+        if (Q.nt) {
+            memcpy(st + S.off_idx + Q.t0 * 12, Q.idx, (size_t)Q.nt * 12);
+            memcpy(st + S.off_edges + Q.t0 * sizeof(rxr_edges), Q.edges, (size_t)Q.nt * sizeof(rxr_edges));
+        }
+        const uint32_t g = j / S.group_size;
+        if (S.group_left[g].fetch_sub(1u, std::memory_order_acq_rel) == 1u) {
+            // the group's last batch has landed in pinned memory: its five ranges go to the device
+            const FrameStream::Rec &A = S.rec[g * S.group_size], &Z = S.rec[std::min(S.n, (g + 1u) * S.group_size) - 1u];
+            const size_t v0 = A.v0, nv = Z.v0 + Z.nv - A.v0, t0 = A.t0, nt = Z.t0 + Z.nt - A.t0;
+            const struct { size_t off, bytes; } r[5] = {{S.off_pv + v0 * 16, nv * 16}, {S.off_uv + v0 * 8, nv * 8}, {S.off_nrm + v0 * 12, nv * 12},
+                                                        {S.off_idx + t0 * 12, nt * 12}, {S.off_edges + t0 * sizeof(rxr_edges), nt * sizeof(rxr_edges)}};
+            std::lock_guard<std::mutex> lk(S.ship_mu);
+            hipError_t e = hipSetDevice(ctx->device);
+            for (const auto &x : r)
+                if (x.bytes && e == hipSuccess) e = hipMemcpyAsync((uint8_t *)ctx->d_frame.p + x.off, st + x.off, x.bytes, hipMemcpyHostToDevice, ctx->stream);
+            if (e != hipSuccess) {
+                std::lock_guard<std::mutex> lk2(S.mu);
+                if (S.err.empty()) S.err = "rxr_stream_batch3d: host->device copy failed";
+                S.failed.store(1);
+                return false;
+            }
+        }
+    }
+    return true;
+}
+
+// thread-safe; never touches ctx->err (the failure is kept in the stream and reported by rxr_upload_frame's fall-back)
+int rxr_stream_batch3d(rxr_ctx *ctx, uint32_t index, const rxr_batch3d *b) {
+    if (!ctx || !b || ctx->group) return RXR_ERR_INVALID;
+    FrameStream &S = ctx->fstream;
+    if (!S.active || index >= S.n) return RXR_ERR_INVALID;
+    static const bool timing = getenv("RXR_E2E_TIMING") != nullptr;
+    struct Tick {
+        std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+        bool on;
+        uint32_t index;
+        ~Tick() {
+            if (!on) return;
+            const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+            static std::atomic<uint64_t> total{0}, worst{0}, calls{0};
+            total += (uint64_t)us;
+            uint64_t w = worst.load();
+            while ((uint64_t)us > w && !worst.compare_exchange_weak(w, (uint64_t)us)) {}
+            if (++calls % 289 == 0) fprintf(stderr, "rxr_e2e_timing stream_batch3d: %llu calls, %.1f us each on average, worst %llu us\n", (unsigned long long)calls.load(), (double)total.load() / (double)calls.load(), (unsigned long long)worst.load());
+        }
+    } tick;
+    tick.on = timing;
+    tick.index = index;
+    auto give_up = [&](const char *why) {
+        std::lock_guard<std::mutex> lk(S.mu);
+        if (S.err.empty()) S.err = why;
+        S.failed.store(1);
+        return RXR_ERR_INVALID;
+    };
+    if (S.failed.load()) return RXR_ERR_INVALID;
+    if (S.done[index].load(std::memory_order_acquire)) return give_up("rxr_stream_batch3d: batch handed over twice");
+    if (b->n_vertices > S.cap_v[index] || b->n_triangles > S.cap_t[index]) return give_up("rxr_stream_batch3d: batch exceeds the capacity announced to rxr_stream_begin");
+    if ((b->n_triangles && (!b->clipped_indices || !b->edges)) || (b->n_vertices && (!b->projected_vertices || !b->clipped_uvs)))
+        return give_up("rxr_stream_batch3d: NULL arrays");
+    {
+        uint32_t worst = 0;  // every index (the kernels trust them)
+        for (size_t t = 0; t < (size_t)b->n_triangles * 3u; ++t) worst = std::max(worst, b->clipped_indices[t]);
+        if (b->n_triangles && worst >= b->n_vertices) return give_up("batch3d: vertex index out of range");
+    }
+    if (S.pinned) {
+        // the promise is VERIFIED, array by array, first and last byte: a pointer the device cannot read would be a GPU page fault
+        // (which can take the whole node down), so it costs the caller a frame handed over the plain way instead
+        const struct { const void *p; size_t bytes; } arr[5] = {{b->projected_vertices, (size_t)b->n_vertices * 16}, {b->clipped_uvs, (size_t)b->n_vertices * 8},
+                                                                {b->clipped_normals, b->clipped_normals ? (size_t)b->n_vertices * 12 : 0},
+                                                                {b->clipped_indices, (size_t)b->n_triangles * 12}, {b->edges, (size_t)b->n_triangles * sizeof(rxr_edges)}};
+        for (const auto &x : arr) {
+            if (!x.bytes) continue;
+            hipPointerAttribute_t a0{}, a1{};
+            const hipError_t e0 = hipPointerGetAttributes(&a0, x.p), e1 = hipPointerGetAttributes(&a1, (const uint8_t *)x.p + x.bytes - 1);
+            if (e0 != hipSuccess || e1 != hipSuccess || a0.type != hipMemoryTypeHost || a1.type != hipMemoryTypeHost) {
+                (void)hipGetLastError();
+                return give_up("rxr_stream_batch3d: an array is not in page-locked, device-readable memory (the promise of rxr_stream_begin_pinned)");
+            }
+        }
+    }
+    FrameStream::Rec &R = S.rec[index];
+    R.pv = b->projected_vertices; R.uv = b->clipped_uvs; R.nrm = b->clipped_normals; R.idx = b->clipped_indices; R.edges = b->edges;
+    R.nv = b->n_vertices; R.nt = b->n_triangles;
+    S.done[index].store(1, std::memory_order_release);
+    S.handed.fetch_add(1);
+    // retire in index order: a batch's place in the pools is the sum of its predecessors' sizes
+    uint32_t first, last;
+    {
+        std::lock_guard<std::mutex> lk(S.mu);
+        first = S.next;
+        while (S.next < S.n && S.done[S.next].load(std::memory_order_acquire)) {
+            FrameStream::Rec &Q = S.rec[S.next];
+            Q.v0 = S.vcur;
+            Q.t0 = S.tcur;
+            S.vcur += Q.nv;
+            S.tcur += Q.nt;
+            ++S.next;
+        }
+        last = S.next;
+        S.retired.store(S.next, std::memory_order_release);
+    }
+    if (!S.pinned) {
+        // copy mode: a retired batch is copied by whichever caller gets to it (the thread that retires a long run must not be the
+        // one that copies all of it: the others would project on while it falls behind)
+        (void)first;
+        (void)last;
+        return rxr_stream_copy_some(ctx, 0xFFFFFFFFu) ? RXR_OK : RXR_ERR_INVALID;
+    }
+    for (uint32_t j = first; j < last; ++j) {
+        {
+            // no host copy: when the group's last batch has retired, one kernel pulls the group out of the caller's arrays
+            const uint32_t g = j / S.group_size;
+            if (S.group_left[g].fetch_sub(1u, std::memory_order_acq_rel) != 1u) continue;
+            const uint32_t b0 = g * S.group_size, b1 = std::min(S.n, (g + 1u) * S.group_size);
+            FrameStream::GatherEntry *T = S.table + (size_t)b0 * 5u;
+            uint32_t n_e = 0, piece = 0;
+            for (uint32_t k = b0; k < b1; ++k) {
+                const FrameStream::Rec &B = S.rec[k];
+                const struct { const void *src; size_t off, bytes; } r[5] = {{B.pv, S.off_pv + B.v0 * 16, (size_t)B.nv * 16}, {B.uv, S.off_uv + B.v0 * 8, (size_t)B.nv * 8},
+                                                                             {B.nrm, S.off_nrm + B.v0 * 12, B.nrm ? (size_t)B.nv * 12 : 0}, {B.idx, S.off_idx + B.t0 * 12, (size_t)B.nt * 12},
+                                                                             {B.edges, S.off_edges + B.t0 * sizeof(rxr_edges), (size_t)B.nt * sizeof(rxr_edges)}};
+                for (const auto &x : r) {
+                    if (!x.bytes) continue;
+                    T[n_e++] = FrameStream::GatherEntry{x.src, (uint64_t)x.off, (uint32_t)x.bytes, piece};
+                    piece += (uint32_t)((x.bytes + RXR_GATHER_PIECE - 1u) / RXR_GATHER_PIECE);
+                }
+            }
+            if (n_e) {
+                std::lock_guard<std::mutex> lk(S.ship_mu);
+                hipError_t e = hipSetDevice(ctx->device);
+                if (e == hipSuccess) {
+                    hipLaunchKernelGGL(k_gather_host, dim3(piece), dim3(256), 0, ctx->stream, (const FrameStream::GatherEntry *)T, n_e, (uint8_t *)ctx->d_frame.p);
+                    e = hipGetLastError();
+                }
+                if (e != hipSuccess) return give_up("rxr_stream_batch3d: the gather launch failed");
+            }
+        }
+    }
+    return RXR_OK;
+}
+
 int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
     if (!ctx) return RXR_ERR_INVALID;
     if (!f) return fail(ctx, RXR_ERR_INVALID, "rxr_upload_frame: frame is NULL");
@@ -545,6 +857,27 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
         return fail(ctx, RXR_ERR_INVALID, "rxr_upload_frame: RXR_BG_HOST_PIXELS without background_pixels");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     ctx->has_frame = false;
+    // Were this frame's 3D batches handed over while they were projected (rxr_stream_begin / rxr_stream_batch3d)?  Then their arrays
+    // are in the blob already, or on their way.  Anything that does not match -- a batch missing, other arrays than the ones streamed,
+    // a failure on the way -- and the frame takes the plain path below from scratch.
+    FrameStream &S = ctx->fstream;
+    bool streamed = S.active && !S.failed.load() && !f->use_meshes && f->n_batches3d == S.n && S.handed.load() == S.n;
+    if (S.active && streamed) {
+        std::lock_guard<std::mutex> lk(S.mu);
+        streamed = S.next == S.n;
+        for (uint32_t i = 0; i < S.n && streamed; ++i) {
+            const rxr_batch3d &b = f->batches3d[i];
+            const FrameStream::Rec &R = S.rec[i];
+            streamed = b.projected_vertices == R.pv && b.clipped_uvs == R.uv && b.clipped_normals == R.nrm && b.clipped_indices == R.idx && b.edges == R.edges &&
+                       b.n_vertices == R.nv && b.n_triangles == R.nt;
+        }
+    }
+    if (S.active && !streamed) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // (transfers of the abandoned stream still read the staging memory)
+    S.active = false;
+    static const bool e2e_timing = getenv("RXR_E2E_TIMING") != nullptr;  // diagnostics (tools/e2e_probe.py)
+    const auto ut0 = std::chrono::steady_clock::now();
+    auto ut_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ut0).count(); };
+    double ut_validated = 0, ut_quiesced = 0, ut_headers = 0, ut_arrays = 0;
 
     // ---- pass 1: validate + size ---------------------------------------------------------------
     if (f->n_shader_programs > ctx->programs.size())
@@ -588,7 +921,7 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
         n_v3 += b.n_vertices;
         n_t3 += b.n_triangles;
     }
-    {
+    if (!streamed) {  // (a streamed batch was checked when it was handed over)
         // every index of every batch (the kernels trust them): one job per batch on the host worker pool (rxr_parallel.h)
         std::atomic<bool> bad{false};
         rxr_parallel::run(f->n_batches3d, n_t3, [&](size_t i) {
@@ -660,19 +993,13 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
     auto tex_opaque = [&](int32_t tex) { return (uint32_t)tex < n_res_tex ? ctx->h_tex[tex].all_opaque != 0 : local_tex[(uint32_t)tex - n_res_tex].opaque; };
 
     Layout L{};
-    size_t o = 0;
+    // (a streamed frame's pools were laid out for the capacities announced before projection: the arrays sit densely at their front)
+    size_t o = streamed ? layout_prefix(n_b3, S.total_cap_v, S.total_cap_t, L) : layout_prefix(n_b3, n_v3, n_t3, L);
     auto take = [&](size_t bytes) {
         size_t at = o;
         o = align_up(o + (bytes ? bytes : 16), 256);
         return at;
     };
-    L.off_b3 = take(n_b3 * sizeof(DevBatch));
-    L.off_base = take((n_b3 + 1) * sizeof(uint32_t));
-    L.off_pv = take(n_v3 * 16);
-    L.off_uv = take(n_v3 * 8);
-    L.off_nrm = take(n_v3 * 12);
-    L.off_idx = take(n_t3 * 12);
-    L.off_edges = take(n_t3 * sizeof(rxr_edges));
     L.off_lights = take(f->n_lights * sizeof(rxr_light));
     L.off_occ = take(n_occ_total * sizeof(rxr_occluder));
     L.off_ld = take(f->n_linedefs * sizeof(rxr_linedef));
@@ -686,11 +1013,23 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
     L.total = o;
 
     int rc;
+    if (streamed && L.total > S.blob_capacity) {
+        // what follows the arrays does not fit the room rxr_stream_begin left: a reallocation would lose what has been shipped.  The plain
+        // path from scratch (rare: the frame's lights / 2D primitives / chunk textures more than doubled against the previous frame).
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->last_blob_tail = L.total - L.off_lights;
+        S.failed.store(1);
+        return rxr_upload_frame(ctx, f);
+    }
+    ctx->last_blob_tail = L.total - L.off_lights;
     if ((rc = ensure_stage(ctx, L.total)) != RXR_OK) return rc;
     if ((rc = ensure(ctx, ctx->d_frame, L.total)) != RXR_OK) return rc;
     // the staging blob may still be in flight from the previous upload, and the previous frame's renders -- possibly on
     // the caller's stream -- still read the frame blob and the scratch buffers
-    if ((rc = rxr_quiesce(ctx)) != RXR_OK) return rc;
+    ut_validated = ut_ms();
+    // (a streamed frame: rxr_stream_begin has waited for the previous frame; what runs now are this frame's own transfers)
+    if (!streamed && (rc = rxr_quiesce(ctx)) != RXR_OK) return rc;
+    ut_quiesced = ut_ms();
     uint8_t *st = (uint8_t *)ctx->h_stage;
 
     // texel source, program, baked texture and the flags that follow from them, for one 3D batch header
@@ -812,7 +1151,43 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
     base[f->n_batches3d] = (uint32_t)tcur;
     // the arrays themselves: independent per batch (offsets are in the headers just written), through the host worker pool --
     // 124 MB for the 1 M-triangle grid, which one thread copies in about as long as the GPU takes for forty frames
-    rxr_parallel::run(f->n_batches3d, n_v3 + n_t3, [&](size_t i) {
+    ut_headers = ut_ms();
+    // Large frames (the 1 M-triangle grid: 124 MB): the copy into pinned memory and the host->device copy are pipelined.  The
+    // batches are cut into groups of consecutive batches of ~8 MB; the workers copy batch after batch, and the calling thread ships
+    // the five array ranges of a group (vertices, uvs, normals, indices, edges: contiguous per group in each pool) as soon as the
+    // group's last batch has landed -- the PCIe transfer of group g runs under the copies of the groups behind it.  Measured
+    // (profiles/r03/c5_e2e_*): the hand-over of that frame 3.6 -> 2.x ms.  RXR_UPLOAD_PIPELINE=0 keeps one copy at the end.
+    struct ShipGroup {
+        size_t v0, v1, t0, t1;
+        std::atomic<uint32_t> left{0};
+    };
+    const size_t big_bytes = n_v3 * 36 + n_t3 * 52;
+    static const bool pipeline_off = getenv("RXR_UPLOAD_PIPELINE") && getenv("RXR_UPLOAD_PIPELINE")[0] == '0';
+    std::vector<uint32_t> group_of;
+    std::unique_ptr<ShipGroup[]> groups;
+    size_t n_groups_ship = 0;
+    if (!streamed && !use_meshes && !pipeline_off && big_bytes >= (32u << 20) && f->n_batches3d >= 8) {
+        size_t target = std::max<size_t>(8u << 20, big_bytes / 8);  // (few, large transfers: every hipMemcpyAsync costs the calling thread ~20 us)
+        if (const char *gs = getenv("RXR_UPLOAD_GROUP_MB")) target = std::max<size_t>(1u << 20, (size_t)atol(gs) << 20);
+        group_of.resize(f->n_batches3d);
+        groups.reset(new ShipGroup[f->n_batches3d]);
+        size_t acc = 0;
+        for (uint32_t i = 0; i < f->n_batches3d; ++i) {
+            if (i == 0 || acc >= target) {
+                ShipGroup &g = groups[n_groups_ship++];
+                g.v0 = g.v1 = b3[i].vert_base;
+                g.t0 = g.t1 = b3[i].tri_base;
+                acc = 0;
+            }
+            ShipGroup &g = groups[n_groups_ship - 1];
+            g.v1 += f->batches3d[i].n_vertices;
+            g.t1 += f->batches3d[i].n_triangles;
+            g.left.store(g.left.load(std::memory_order_relaxed) + 1u, std::memory_order_relaxed);
+            group_of[i] = (uint32_t)(n_groups_ship - 1);
+            acc += (size_t)f->batches3d[i].n_vertices * 36 + (size_t)f->batches3d[i].n_triangles * 52;
+        }
+    }
+    auto copy_batch = [&](size_t i) {
         const rxr_batch3d &b = f->batches3d[i];
         const size_t v0 = b3[i].vert_base, t0 = b3[i].tri_base;
         if (b.n_vertices) {
@@ -824,8 +1199,45 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
             memcpy(st + L.off_idx + t0 * 12, b.clipped_indices, (size_t)b.n_triangles * 12);
             memcpy(st + L.off_edges + t0 * sizeof(rxr_edges), b.edges, (size_t)b.n_triangles * sizeof(rxr_edges));
         }
-    });
+        if (n_groups_ship) groups[group_of[i]].left.fetch_sub(1u, std::memory_order_release);
+    };
+    bool arrays_shipped = false;  // the five pools are on their way: the final copy sends only what surrounds them
+    ctx->last_upload_streamed = streamed ? (S.pinned ? 2 : 1) : 0;
+    if (streamed) {
+        arrays_shipped = true;  // ... since rxr_stream_batch3d
+        if (!S.pinned && S.copy_next.load() < S.n) {
+            // batches retired by the last hand-over calls and not copied yet: through the pool, one claim per job
+            std::atomic<bool> ok{true};
+            rxr_parallel::run(S.n - S.copy_next.load(), n_v3 + n_t3, [&](size_t) {
+                if (!rxr_stream_copy_some(ctx, 1u)) ok.store(false);
+            });
+            if (!ok.load() || S.failed.load()) return fail(ctx, RXR_ERR_HIP, "rxr_upload_frame: " + (S.err.empty() ? std::string("a streamed batch could not be shipped") : S.err));
+        }
+    } else if (n_groups_ship) {
+        hipError_t ship_err = hipSuccess;
+        uint8_t *const dst = (uint8_t *)ctx->d_frame.p;
+        auto ship = [&]() {
+            for (size_t g = 0; g < n_groups_ship; ++g) {
+                ShipGroup &G = groups[g];
+                while (G.left.load(std::memory_order_acquire) != 0u) std::this_thread::yield();
+                const size_t nv = G.v1 - G.v0, nt = G.t1 - G.t0;
+                const struct { size_t off, bytes; } r[5] = {{L.off_pv + G.v0 * 16, nv * 16}, {L.off_uv + G.v0 * 8, nv * 8}, {L.off_nrm + G.v0 * 12, nv * 12},
+                                                            {L.off_idx + G.t0 * 12, nt * 12}, {L.off_edges + G.t0 * sizeof(rxr_edges), nt * sizeof(rxr_edges)}};
+                for (const auto &x : r)
+                    if (x.bytes && ship_err == hipSuccess) ship_err = hipMemcpyAsync(dst + x.off, st + x.off, x.bytes, hipMemcpyHostToDevice, ctx->stream);
+            }
+        };
+        arrays_shipped = rxr_parallel::run_with(f->n_batches3d, n_v3 + n_t3, copy_batch, ship);
+        if (!arrays_shipped) {  // (a pool of one thread: copy, then one transfer at the end as for small frames)
+            n_groups_ship = 0;
+            for (size_t i = 0; i < f->n_batches3d; ++i) copy_batch(i);
+        }
+        if (ship_err != hipSuccess) return fail(ctx, RXR_ERR_HIP, std::string("rxr_upload_frame: hipMemcpyAsync: ") + hipGetErrorString(ship_err));
+    } else {
+        rxr_parallel::run(f->n_batches3d, n_v3 + n_t3, copy_batch);
+    }
 
+    ut_arrays = ut_ms();
     if (use_meshes) {
         // headers of the device-projected batches + the per-frame half of DevMesh (view * model, frustum reject)
         rvek::Mat4 view{}, proj{};
@@ -1118,7 +1530,13 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
     }
     if ((rc = ensure(ctx, ctx->d_fb, (size_t)f->width * f->height * 4)) != RXR_OK) return rc;
 
-    HIPCHK(ctx, hipMemcpyAsync(ctx->d_frame.p, st, L.total, hipMemcpyHostToDevice, ctx->stream));
+    if (arrays_shipped) {
+        // the projected arrays [off_pv, off_lights) left while they were being copied; what surrounds them follows
+        HIPCHK(ctx, hipMemcpyAsync(ctx->d_frame.p, st, L.off_pv, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync((uint8_t *)ctx->d_frame.p + L.off_lights, st + L.off_lights, L.total - L.off_lights, hipMemcpyHostToDevice, ctx->stream));
+    } else {
+        HIPCHK(ctx, hipMemcpyAsync(ctx->d_frame.p, st, L.total, hipMemcpyHostToDevice, ctx->stream));
+    }
 
     // ---- parameter block -----------------------------------------------------------------------
     RasterParams &P = ctx->P;
@@ -1290,6 +1708,9 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
         P.dev_bbox = PP.bbox;
         P.mesh_live = PP.mesh_live;
     }
+    if (e2e_timing)
+        fprintf(stderr, "rxr_e2e_timing upload: validate+size %.3f, wait for the previous frame %.3f, headers %.3f, arrays (copy + ship) %.3f, rest %.3f ms\n", ut_validated,
+                ut_quiesced - ut_validated, ut_headers - ut_quiesced, ut_arrays - ut_headers, ut_ms() - ut_arrays);
     ctx->n_tris2d = (uint32_t)t2cur;
     ctx->has_frame = true;
     ctx->rendered = false;
@@ -1712,6 +2133,24 @@ int rxr_render_download(rxr_ctx *ctx, uint8_t *pixels) {
     const uint32_t H = P.height;
     static const bool no_pipeline = getenv("RXR_NO_DOWNLOAD_PIPELINE") != nullptr;  // A-B runs
     if (!no_lists || no_pipeline || (size_t)P.width * H < (1u << 22)) {
+        static const bool timing = getenv("RXR_E2E_TIMING") != nullptr;  // diagnostics (tools/e2e_probe.py): where a large frame's call goes
+        if (timing) {
+            using clk = std::chrono::steady_clock;
+            HIPCHK(ctx, hipSetDevice(ctx->device));
+            const auto t0 = clk::now();
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // the tail of the upload's host->device copies
+            const auto t1 = clk::now();
+            rc = rxr_render_rows(ctx, 0, H);
+            if (rc != RXR_OK) return rc;
+            rc = rxr_synchronize(ctx);
+            if (rc != RXR_OK) return rc;
+            const auto t2 = clk::now();
+            rc = rxr_download_rows(ctx, pixels, 0, H);
+            const auto t3 = clk::now();
+            auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+            fprintf(stderr, "rxr_e2e_timing h2d_tail_ms=%.3f kernels_ms=%.3f download_ms=%.3f\n", ms(t0, t1), ms(t1, t2), ms(t2, t3));
+            return rc;
+        }
         rc = rxr_render_rows(ctx, 0, H);
         if (rc != RXR_OK) return rc;
         return rxr_download_rows(ctx, pixels, 0, H);
@@ -2377,6 +2816,9 @@ int rxr_selftest_math(rxr_ctx *ctx, uint64_t n_tuples, uint64_t seed, uint64_t m
 }  // extern "C"
 
 // what the run-time compiler did with the last program set of this context (rxr_jit.hip); "" when it was not asked
+// tests: how the resident frame's 3D arrays arrived -- 0 plain rxr_upload_frame, 1 streamed and copied, 2 streamed out of page-locked memory
+extern "C" int rxr_debug_stream_info(rxr_ctx *ctx) { return (ctx && !ctx->group) ? ctx->last_upload_streamed : -1; }
+
 // tests: how many launch sequences rxr_synchronize has rendered again after a list overflow (a plain context or a member)
 extern "C" uint32_t rxr_debug_rerenders(rxr_ctx *ctx) { return (ctx && !ctx->group) ? ctx->rerenders : 0u; }
 

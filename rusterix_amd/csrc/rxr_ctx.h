@@ -6,6 +6,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -61,6 +64,49 @@ enum : uint32_t {
 
 struct rxr_group;
 
+// Streaming hand-over of a large frame's projected 3D batches (rxr_stream_begin / rxr_stream_batch3d, include/rxr.h): the host
+// hands batch i over from whatever thread projected it; batches are RETIRED in index order (which fixes their dense offsets in
+// the vertex / triangle pools, i.e. the submission order the depth tie-break needs), copied into the pinned staging blob by the
+// retiring thread and shipped to the device per group of consecutive batches -- all while later batches are still being projected.
+struct FrameStream {
+    bool active = false;
+    uint32_t n = 0;
+    struct Rec {
+        const float *pv, *uv, *nrm;
+        const uint32_t *idx;
+        const rxr_edges *edges;
+        uint32_t nv, nt;
+        size_t v0, t0;
+    };
+    std::vector<Rec> rec;
+    std::vector<uint32_t> cap_v, cap_t;
+    std::unique_ptr<std::atomic<uint8_t>[]> done;
+    std::unique_ptr<std::atomic<uint32_t>[]> group_left;
+    uint32_t group_size = 1, n_groups = 0;
+    std::mutex mu;       // retirement: next / vcur / tcur
+    std::mutex ship_mu;  // the HIP calls of a group's transfers
+    uint32_t next = 0;                      // batches [0, next) are retired (under mu)
+    std::atomic<uint32_t> retired{0};       // ... the same, readable without the lock
+    std::atomic<uint32_t> copy_next{0};     // copy mode: batches [0, copy_next) have been claimed for their copy into pinned memory
+    size_t vcur = 0, tcur = 0;
+    size_t total_cap_v = 0, total_cap_t = 0;
+    size_t off_pv = 0, off_uv = 0, off_nrm = 0, off_idx = 0, off_edges = 0, off_after = 0;  // the blob's layout up to the end of the edges
+    size_t blob_capacity = 0;  // staging / device blob bytes that exist without a reallocation
+    // pinned mode (rxr_stream_begin_pinned): no host copy; per group a table of (source, destination, bytes) in pinned memory and one
+    // k_gather_host launch that pulls the arrays over PCIe
+    bool pinned = false;
+    struct GatherEntry {
+        const void *src;
+        uint64_t dst_off;       // bytes from the blob's start
+        uint32_t bytes, first_piece;
+    };
+    GatherEntry *table = nullptr;   // pinned, 5 entries per batch
+    size_t table_cap = 0;
+    std::atomic<uint32_t> handed{0};
+    std::atomic<int> failed{0};
+    std::string err;     // (under mu)
+};
+
 struct rxr_ctx {
     int device = 0;
     rxr_group *group = nullptr;          // != nullptr: multi-device handle (every other member below is unused)
@@ -79,6 +125,7 @@ struct rxr_ctx {
     void *h_stage = nullptr;
     size_t h_stage_cap = 0;
     DevBuf d_frame;
+    size_t last_blob_tail = 0;       // bytes of the last frame blob behind the projected arrays (rxr_stream_begin leaves room for twice that)
     DevBuf d_tri_setup, d_tri_shade, d_tri_box, d_bin_count, d_bins, d_list, d_large, d_counters, d_fb;
     DevBuf d_bin2d_count, d_bins2d, d_list2d, d_large2d;
     DevBuf d_stripes;                // multi-device member: this device's stripes, compact (rxr_multi.hip)
@@ -145,6 +192,9 @@ struct rxr_ctx {
     std::vector<uint32_t> program_flags;        // PG_* per program (see rxr_set_shaders)
     uint32_t n_patterns = 0, n_normal_patterns = 0, n_palette = 0;
     bool frame_uses_programs = false;
+
+    FrameStream fstream;    // rxr_stream_begin .. rxr_upload_frame
+    int last_upload_streamed = 0;  // 0 plain, 1 streamed (copied), 2 streamed out of page-locked arrays
 
     bool has_frame = false;
     RasterParams P{};       // template for the resident frame (pointers resolved)

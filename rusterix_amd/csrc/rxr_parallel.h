@@ -10,9 +10,16 @@
 // Items are handed out one at a time through an atomic cursor (batches differ in size).  `weight` is the caller's estimate of the
 // total work in "elements" (vertices + triangles, or bytes / 64): below RXR_PARALLEL_MIN_WEIGHT the loop runs inline on the caller's
 // thread, so that small frames (the bench frame has 54 triangles) never pay a wake-up.
-// Threads: RXR_HOST_THREADS if set (1 = never create a thread), else min(CPUs this process may run on, 16).  Workers are created on
-// first use, sleep on a condition variable between jobs and are joined when the library is unloaded.  A forked child starts without
-// workers (pthread_atfork) and creates its own on first use.
+// Threads: RXR_HOST_THREADS if set (1 = never create a thread), else min(CPUs this process may run on, 64) -- rayon's default is
+// every logical CPU -- and never more than one per RXR_PARALLEL_MIN_WEIGHT / 4 elements of the job, so that a mid-sized frame wakes
+// a few workers and the 1 M-triangle grid all of them (measured on the 256-thread host of the GPU box, profiles/r03/c5_e2e_*: that
+// scene's Scene::project takes 10.8 / 5.5 / 3.9 / 2.5 ms on 8 / 16 / 32 / 64 threads).  Workers are created on first use, sleep on a
+// condition variable between jobs and are joined when the library is unloaded.  A forked child starts without workers
+// (pthread_atfork) and creates its own on first use.
+//
+//   rxr_parallel::run_with(n_items, weight, fn, main_fn)   the same, but the CALLING thread runs main_fn() instead of taking items:
+//   it returns when main_fn has returned and every item is done (rxr_upload_frame: the workers copy batches into pinned memory while
+//   the caller issues the host->device copies of the ranges that are complete).
 #pragma once
 #include <pthread.h>
 #include <sched.h>
@@ -45,15 +52,33 @@ class Pool {
     // fn(i) for i in [0, n), each exactly once; returns when all are done.  Not re-entrant: one job at a time per pool (callers hold
     // the library's own lock: g_mu in the host mirror, the context in rxr_upload_frame).
     template <class F> void run(size_t n, size_t weight, F &&fn) {
-        if (n == 0) return;
+        run_impl(n, weight, static_cast<F &&>(fn), (void (*)(void *)) nullptr, nullptr);
+    }
+    // the calling thread runs main_fn() while the workers take the items; false (nothing done) when the job is too small for the
+    // pool or the pool has one thread: the caller then does both itself, one after the other
+    template <class F, class M> bool run_with(size_t n, size_t weight, F &&fn, M &&main_fn) {
+        using Mn = typename std::remove_reference<M>::type;
+        struct MainThunk {
+            static void call(void *self) { (*(Mn *)self)(); }
+        };
+        return run_impl(n, weight, static_cast<F &&>(fn), &MainThunk::call, (void *)&main_fn);
+    }
+
+  private:
+    template <class F> bool run_impl(size_t n, size_t weight, F &&fn, void (*main_call)(void *), void *main_arg) {
+        if (n == 0 && !main_call) return true;
         unsigned want;
         {
             std::lock_guard<std::mutex> lk(mu_);
             want = wanted_locked();
         }
-        if (n == 1 || want <= 1 || weight < (size_t)RXR_PARALLEL_MIN_WEIGHT) {
+        // a thread per RXR_PARALLEL_MIN_WEIGHT / 4 elements at most: waking 63 workers for a job of 70 000 elements costs more than it saves
+        const size_t by_weight = weight / ((size_t)RXR_PARALLEL_MIN_WEIGHT / 4u) + 1u;
+        if (by_weight < want) want = (unsigned)by_weight;
+        if (n <= 1 || want <= 1 || weight < (size_t)RXR_PARALLEL_MIN_WEIGHT) {
+            if (main_call) return false;
             for (size_t i = 0; i < n; ++i) fn(i);
-            return;
+            return true;
         }
         using Fn = typename std::remove_reference<F>::type;  // (callers pass temporaries and named lambdas alike)
         struct Thunk {
@@ -68,15 +93,20 @@ class Pool {
             arg_ = &thunk;
             n_ = n;
             next_.store(0, std::memory_order_relaxed);
+            active_ = want - 1;   // the first `active_` workers take part in this job, the others go back to sleep at once
             busy_ = (unsigned)workers_.size();
             ++generation_;
         }
         cv_work_.notify_all();
-        drain();
+        if (main_call) main_call(main_arg);
+        else drain();
         std::unique_lock<std::mutex> lk(mu_);
         cv_done_.wait(lk, [&] { return busy_ == 0; });
         call_ = nullptr;
+        return true;
     }
+
+  public:
 
   private:
     Pool() { pthread_atfork(nullptr, nullptr, &Pool::in_child); }
@@ -97,12 +127,15 @@ class Pool {
         if (!wanted_) {
             const char *e = getenv("RXR_HOST_THREADS");
             long v = e ? atol(e) : 0;
-            wanted_ = v > 0 ? (unsigned)(v > 256 ? 256 : v) : (allowed_cpus() < 16u ? allowed_cpus() : 16u);
+            wanted_ = v > 0 ? (unsigned)(v > 256 ? 256 : v) : (allowed_cpus() < 64u ? allowed_cpus() : 64u);
         }
         return wanted_;
     }
     void start_workers_locked(unsigned n) {
-        while (workers_.size() < n) workers_.emplace_back([this, seen = generation_]() mutable { worker(seen); });
+        while (workers_.size() < n) {
+            const unsigned index = (unsigned)workers_.size();
+            workers_.emplace_back([this, index, seen = generation_]() mutable { worker(index, seen); });
+        }
     }
     void drain() {
         for (;;) {
@@ -111,15 +144,17 @@ class Pool {
             call_(arg_, i);
         }
     }
-    void worker(unsigned long long seen) {
+    void worker(unsigned index, unsigned long long seen) {
         std::unique_lock<std::mutex> lk(mu_);
         for (;;) {
             cv_work_.wait(lk, [&] { return stop_ || generation_ != seen; });
             if (stop_) return;
             seen = generation_;
-            lk.unlock();
-            drain();
-            lk.lock();
+            if (index < active_) {
+                lk.unlock();
+                drain();
+                lk.lock();
+            }
             if (--busy_ == 0) cv_done_.notify_all();
         }
     }
@@ -153,12 +188,15 @@ class Pool {
     void *arg_ = nullptr;
     size_t n_ = 0;
     std::atomic<size_t> next_{0};
-    unsigned busy_ = 0, wanted_ = 0;
+    unsigned busy_ = 0, wanted_ = 0, active_ = 0;
     unsigned long long generation_ = 0;
     bool stop_ = false;
 };
 
 template <class F> inline void run(size_t n, size_t weight, F &&fn) { Pool::get().run(n, weight, static_cast<F &&>(fn)); }
+template <class F, class M> inline bool run_with(size_t n, size_t weight, F &&fn, M &&main_fn) {
+    return Pool::get().run_with(n, weight, static_cast<F &&>(fn), static_cast<M &&>(main_fn));
+}
 inline unsigned threads() { return Pool::get().threads(); }
 
 }  // namespace rxr_parallel

@@ -57,6 +57,10 @@ def rxr_abi():
         "rxr_render_stripes_to": (i32, [vp, u32, u32, vp, vp]),
         "rxr_render_stripes_batch": (i32, [vp, u32, u32, u32, vp, C.c_size_t, vp]),
         "rxr_render_gather": (i32, [vp, i32, vp, vp]),
+        "rxr_stream_begin": (i32, [vp, u32, C.POINTER(u32), C.POINTER(u32)]),
+        "rxr_stream_batch3d": (i32, [vp, u32, vp]),
+        "rxr_debug_stream_info": (i32, [vp]),
+        "rxr_debug_rerenders": (u32, [vp]),
         "rxr_render_download": (i32, [vp, vp]),
         "rxr_download_rows": (i32, [vp, vp, u32, u32]),
         "rxr_synchronize": (i32, [vp]),

@@ -34,6 +34,40 @@ static bool sweep(unsigned salt) {
     return true;
 }
 
+// run_with: the workers take the items while the CALLER runs its own function, which consumes the items' results in order as they
+// complete (rxr_upload_frame ships a group of batches as soon as its copies have landed)
+static bool sweep_with_main(unsigned salt) {
+    for (size_t n : {size_t(2), size_t(9), size_t(300), size_t(2048)}) {
+        std::vector<std::atomic<unsigned>> done(n);
+        for (auto &d : done) d.store(0);
+        std::vector<unsigned long long> out(n, 0), seen(n, 0);
+        bool main_ran = false;
+        const bool pooled = rxr_parallel::run_with(n, n * 64, [&](size_t i) {
+            unsigned long long acc = salt;
+            for (unsigned k = 0; k < 30 + (i % 13) * 50; ++k) acc = acc * 6364136223846793005ull + i + k;
+            out[i] = acc;
+            done[i].store(1, std::memory_order_release);
+        }, [&] {
+            main_ran = true;
+            for (size_t i = 0; i < n; ++i) {
+                while (done[i].load(std::memory_order_acquire) == 0) std::this_thread::yield();
+                seen[i] = out[i];
+            }
+        });
+        if (!pooled) return false;  // (the caller made sure the pool has more than one thread and the job is heavy enough)
+        if (!main_ran) return false;
+        for (size_t i = 0; i < n; ++i) {
+            unsigned long long acc = salt;
+            for (unsigned k = 0; k < 30 + (i % 13) * 50; ++k) acc = acc * 6364136223846793005ull + i + k;
+            if (seen[i] != acc) return false;
+        }
+    }
+    // too small for the pool: nothing runs, the caller is told to do both itself
+    bool touched = false;
+    if (rxr_parallel::run_with(4, 1, [&](size_t) { touched = true; }, [&] { touched = true; }) || touched) return false;
+    return true;
+}
+
 int main(int argc, char **argv) {
     const bool with_fork = !(argc > 1 && std::string(argv[1]) == "nofork");  // (ThreadSanitizer refuses new threads after a multi-threaded fork)
     if (rxr_parallel::threads() < 2) {
@@ -44,6 +78,7 @@ int main(int argc, char **argv) {
     for (int round = 0; round < 20; ++round) {
         std::thread other([&] { if (!sweep(1000u + round)) good = false; });
         if (!sweep((unsigned)round)) good = false;
+        if (!sweep_with_main((unsigned)round + 500u)) good = false;
         other.join();
     }
     if (!good) {
