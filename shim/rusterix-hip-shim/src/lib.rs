@@ -46,6 +46,10 @@ struct Caches {
     textures: u64, // fingerprints of what the device currently holds
     shaders: u64,
     meshes: u64,
+    /// streaming hand-over (project_streaming): the repacked arrays of the frame's 3D batches, in submission order, as the device
+    /// was given them -- device_frame must name exactly these pointers again
+    stream: Vec<Repack>,
+    streamed: bool,
 }
 static STATE: Mutex<Option<Caches>> = Mutex::new(None);
 
@@ -381,6 +385,67 @@ struct Item2D<'a> {
     chunk: i32,
 }
 
+/// `Scene::project` (src/scene.rs:154-200) for large scenes, with every 3D batch handed to the device as soon as it is projected
+/// (include/rxr.h: rxr_stream_begin / rxr_stream_batch3d): the same rayon fan-out over the same batches, one job per batch, and at
+/// the end of a job the batch's arrays -- projected_vertices and clipped_uvs in place, indices / Edges / normals repacked into buffers
+/// that live until the frame has been uploaded -- go to `rxr_stream_batch3d`.  The library retires the batches in submission order,
+/// copies them into pinned memory and ships them group by group while rayon is still projecting the rest; `rxr_upload_frame` then
+/// only adds what surrounds them.  Anything the library refuses makes that later call take the frame from scratch: the result is
+/// the same either way.  (To let the device PULL the arrays instead of the library copying them, register the Vecs once with
+/// `rxr_pin_host_buffer` and call `rxr_stream_begin_pinned`: the 1 M-triangle grid's call then takes 6.4 ms instead of 8.7.)
+fn project_streaming(this: &Rasterizer, scene: &mut Scene, ctx: *mut rxr_ctx, st: &mut Caches) {
+    use rayon::prelude::*;
+    // the 2D half as Scene::project does it
+    for chunk in scene.chunks.values_mut() {
+        chunk.batches2d.par_iter_mut().for_each(|b| b.project(this.projection_matrix_2d));
+        if let Some(t) = &mut chunk.terrain_batch2d {
+            t.project(this.projection_matrix_2d);
+        }
+    }
+    scene.d2_static.par_iter_mut().for_each(|b| b.project(this.projection_matrix_2d));
+    scene.d2_dynamic.par_iter_mut().for_each(|b| b.project(this.projection_matrix_2d));
+    // the 3D batches in submission order (src/rasterizer.rs:314-405): the index the device knows them by
+    let mut order: Vec<&mut Batch3D> = vec![];
+    for chunk in scene.chunks.values_mut() {
+        order.extend(chunk.batches3d_opacity.iter_mut());
+        order.extend(chunk.batches3d.iter_mut());
+        order.extend(chunk.terrain_batch3d.iter_mut());
+    }
+    order.extend(scene.d3_static.iter_mut());
+    order.extend(scene.d3_dynamic.iter_mut());
+    order.extend(scene.d3_overlay.iter_mut());
+    // upper bounds of what the near-plane clip can produce (batch3d.rs:627-686)
+    let cap_v: Vec<u32> = order.iter().map(|b| (b.vertices.len() + 4 * b.indices.len()) as u32).collect();
+    let cap_t: Vec<u32> = order.iter().map(|b| (3 * b.indices.len()) as u32).collect();
+    st.stream.resize_with(order.len(), Repack::default);
+    st.streamed = unsafe { rxr_stream_begin(ctx, order.len() as u32, cap_v.as_ptr(), cap_t.as_ptr()) } == RXR_OK;
+    let ctx_addr = ctx as usize; // (raw pointers are not Send; the calls are thread-safe)
+    let streamed = st.streamed;
+    let (view, proj, w, h) = (this.view_matrix, this.projection_matrix, this.width, this.height);
+    order.into_par_iter().zip(st.stream.par_iter_mut()).enumerate().for_each(|(i, (b, r))| {
+        b.clip_and_project(view, proj, w, h);
+        r.indices.clear();
+        r.indices.extend(b.clipped_indices.iter().flat_map(|&(a, bb, c)| [a as u32, bb as u32, c as u32])); // usize -> u32
+        r.edges.clear();
+        r.edges.extend(b.edges.iter().map(edges_of));
+        r.normals.clear();
+        r.normals.extend(b.clipped_normals.iter().flat_map(|n| [n.x, n.y, n.z]));
+        if streamed {
+            let v = rxr_batch3d {
+                projected_vertices: b.projected_vertices.as_ptr() as *const f32,
+                clipped_uvs: b.clipped_uvs.as_ptr() as *const f32,
+                clipped_normals: if b.normals.is_empty() { std::ptr::null() } else { r.normals.as_ptr() },
+                clipped_indices: r.indices.as_ptr(),
+                edges: r.edges.as_ptr(),
+                n_vertices: b.projected_vertices.len() as u32,
+                n_triangles: b.edges.len() as u32,
+                ..unsafe { std::mem::zeroed() } // only the arrays and the counts are read
+            };
+            unsafe { rxr_stream_batch3d(ctx_addr as *mut rxr_ctx, i as u32, &v) }; // a refusal: rxr_upload_frame starts over
+        }
+    });
+}
+
 pub trait RasterizeHip {
     fn rasterize_hip(&mut self, scene: &mut Scene, pixels: &mut [u8], width: usize, height: usize, tile_size: usize, assets: &Assets);
 }
@@ -423,7 +488,15 @@ impl RasterizeHip for Rasterizer {
                 b.project(self.projection_matrix_2d);
             }
         } else {
-            scene.project(self.projection_matrix_2d, self.view_matrix, self.projection_matrix, self.width, self.height); // :210
+            // a million elements and more: project and hand over batch by batch (RXR_STREAM_UPLOAD=0: the plain sequence)
+            let elements: usize = scene.chunks.values().flat_map(|c| c.batches3d.iter().chain(&c.batches3d_opacity)).chain(&scene.d3_static).chain(&scene.d3_dynamic)
+                .map(|b| b.vertices.len() + b.indices.len()).sum();
+            st.streamed = false;
+            if elements >= (1 << 20) && unsafe { rxr_member_count(ctx) } == 1 && std::env::var("RXR_STREAM_UPLOAD").map(|v| v != "0").unwrap_or(true) {
+                project_streaming(self, scene, ctx, st);
+            } else {
+                scene.project(self.projection_matrix_2d, self.view_matrix, self.projection_matrix, self.width, self.height); // :210
+            }
         }
         let mut appended = 0usize;
         for chunk in scene.chunks.values() {
@@ -443,6 +516,34 @@ impl RasterizeHip for Rasterizer {
             self.rasterize(scene, pixels, width, height, tile_size, assets);
         }
     }
+}
+
+/// the host-projected 3D batches as the ABI sees them: arrays by pointer (the repacked ones out of `repacks`), headers from `header`
+#[allow(clippy::type_complexity)]
+fn batch3d_views(items3: &[Item3D], repacks: &[Repack], src3: &[rxr_source],
+                 header: &dyn Fn(&Item3D, rxr_source) -> (u32, rxr_source, [f32; 3], i32, u32, u32, u32, i32)) -> Vec<rxr_batch3d> {
+    items3
+        .iter()
+        .zip(repacks)
+        .zip(src3)
+        .map(|((i, r), s)| {
+            let b = i.batch;
+            let bb = b.bounding_box.unwrap_or(Rect { x: 0.0, y: 0.0, width: 0.0, height: 0.0 });
+            let (repeat_mode, source, ambient_color, shader, has_profile_id, profile_id, list, chunk) = header(i, *s);
+            rxr_batch3d {
+                projected_vertices: b.projected_vertices.as_ptr() as *const f32,
+                clipped_uvs: b.clipped_uvs.as_ptr() as *const f32,
+                clipped_normals: if b.normals.is_empty() { std::ptr::null() } else { r.normals.as_ptr() }, // :1083
+                clipped_indices: r.indices.as_ptr(),
+                edges: r.edges.as_ptr(),
+                n_vertices: b.projected_vertices.len() as u32,
+                n_triangles: b.edges.len() as u32,
+                has_bounding_box: b.bounding_box.is_some() as u32,
+                bounding_box: [bb.x, bb.y, bb.width, bb.height],
+                repeat_mode, source, ambient_color, shader, has_profile_id, profile_id, list, chunk,
+            }
+        })
+        .collect()
 }
 
 /// Everything after the host half: flatten the projected scene, keep the device's resident data current, render.  Takes the
@@ -584,6 +685,10 @@ fn device_frame(this: &Rasterizer, scene: &Scene, pixels: &mut [u8], width: usiz
                 }
                 st.meshes = h;
             }
+        } else if st.streamed && st.stream.len() == items3.len() {
+            // project_streaming repacked these batches and gave the device their addresses: the frame names the same buffers
+            repacks = std::mem::take(&mut st.stream);
+            b3 = batch3d_views(&items3, &repacks, &src3, &header);
         } else {
             repacks = items3
                 .iter()
@@ -593,28 +698,7 @@ fn device_frame(this: &Rasterizer, scene: &Scene, pixels: &mut [u8], width: usiz
                     normals: i.batch.clipped_normals.iter().flat_map(|n| [n.x, n.y, n.z]).collect(),
                 })
                 .collect();
-            b3 = items3
-                .iter()
-                .zip(&repacks)
-                .zip(&src3)
-                .map(|((i, r), s)| {
-                    let b = i.batch;
-                    let bb = b.bounding_box.unwrap_or(Rect { x: 0.0, y: 0.0, width: 0.0, height: 0.0 });
-                    let (repeat_mode, source, ambient_color, shader, has_profile_id, profile_id, list, chunk) = header(i, *s);
-                    rxr_batch3d {
-                        projected_vertices: b.projected_vertices.as_ptr() as *const f32,
-                        clipped_uvs: b.clipped_uvs.as_ptr() as *const f32,
-                        clipped_normals: if b.normals.is_empty() { std::ptr::null() } else { r.normals.as_ptr() }, // :1083
-                        clipped_indices: r.indices.as_ptr(),
-                        edges: r.edges.as_ptr(),
-                        n_vertices: b.projected_vertices.len() as u32,
-                        n_triangles: b.edges.len() as u32,
-                        has_bounding_box: b.bounding_box.is_some() as u32,
-                        bounding_box: [bb.x, bb.y, bb.width, bb.height],
-                        repeat_mode, source, ambient_color, shader, has_profile_id, profile_id, list, chunk,
-                    }
-                })
-                .collect();
+            b3 = batch3d_views(&items3, &repacks, &src3, &header);
         }
 
         // ---- 2D batches ----
