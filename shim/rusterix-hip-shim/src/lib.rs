@@ -439,7 +439,17 @@ fn project_streaming(this: &Rasterizer, scene: &mut Scene, ctx: *mut rxr_ctx, st
                 edges: r.edges.as_ptr(),
                 n_vertices: b.projected_vertices.len() as u32,
                 n_triangles: b.edges.len() as u32,
-                ..unsafe { std::mem::zeroed() } // only the arrays and the counts are read
+                // (only the arrays and the counts are read at hand-over; the header travels with rxr_upload_frame)
+                has_bounding_box: 0,
+                bounding_box: [0.0; 4],
+                repeat_mode: 0,
+                source: rxr_source { kind: RXR_SOURCE_OTHER, index: 0, pixel: [0; 4] },
+                ambient_color: [0.0; 3],
+                shader: -1,
+                has_profile_id: 0,
+                profile_id: 0,
+                list: RXR_LIST_STATIC,
+                chunk: -1,
             };
             unsafe { rxr_stream_batch3d(ctx_addr as *mut rxr_ctx, i as u32, &v) }; // a refusal: rxr_upload_frame starts over
         }
