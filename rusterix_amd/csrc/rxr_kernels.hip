@@ -2025,9 +2025,10 @@ __device__ __forceinline__ void visit(const RasterParams &P, const TriSetup &S, 
 // pixel centre and rejects r < 0.  Rounded multiplication and addition are monotone, so over the tile's
 // pixel centres r is largest at the corner that maximises a*x and b*y separately; if even that corner
 // is rejected, every pixel of the tile is.  (NaN coefficients compare false and never reject.)
-__device__ __forceinline__ bool tile_outside_edges(const float *ea, const float *eb, const float *ec, uint32_t tile_x0, uint32_t tile_y0px) {
+__device__ __forceinline__ bool tile_outside_edges(const float *ea, const float *eb, const float *ec, uint32_t tile_x0, uint32_t tile_y0px,
+                                                   uint32_t th = RXR_TILE_H) {
     const float x_lo = (float)tile_x0 + 0.5f, x_hi = (float)(tile_x0 + RXR_TILE_W - 1u) + 0.5f;
-    const float y_lo = (float)tile_y0px + 0.5f, y_hi = (float)(tile_y0px + RXR_TILE_H - 1u) + 0.5f;
+    const float y_lo = (float)tile_y0px + 0.5f, y_hi = (float)(tile_y0px + th - 1u) + 0.5f;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const float xm = ea[i] >= 0.0f ? x_hi : x_lo;
@@ -2059,14 +2060,16 @@ struct StageShade {
 // the smaller index (see the file header) -- IS the minimum of that key, so the order in which fragments arrive does
 // not matter.  After the last round every pixel's lane reads its key back and re-derives the barycentrics of the
 // winner from its record (same expressions, same floats).
-struct RowLds {
-    unsigned long long key[RXR_TILE_THREADS];
+template <uint32_t TH>
+struct RowLdsT {
+    unsigned long long key[RXR_TILE_W * TH];   // TH = 32: the pair kernels' two tiles on top of each other (raster_tile_pair)
     uint32_t row_start[RXR_STAGE_TRIS + 1];  // exclusive prefix of the staged candidates' row counts
     uint32_t red[8];                         // per-wave totals: [0..3] rows | area << 12, [4..7] candidates with rows
     uint32_t raw[RXR_STAGE_TRIS];            // scan_lists_rows: triangle id of every list entry of the round (= of every staged record)
     uint8_t slot[RXR_STAGE_TRIS];            // scan_lists_rows: staged record of candidate k (bytes: 8 workgroups per CU must fit in 160 KB)
     uint8_t chunk_owner[RXR_TILE_THREADS];   // rows_round: first owner of every 64-item chunk of the round's pixel items
 };
+using RowLds = RowLdsT<RXR_TILE_H>;
 // order-preserving map of non-NaN floats to unsigned integers
 __device__ __forceinline__ uint32_t z_order_bits(float z) {
     const uint32_t b = __float_as_uint(z);
@@ -2101,8 +2104,9 @@ __device__ __forceinline__ uint32_t z_order_bits(float z) {
 // INDIRECT: candidate k's record is st.tri[rl.slot[k] * 6] (scan_lists_rows) instead of st.tri[k * 6]
 // PIX: pixel items (above); false = one item per row with an x loop, which the interpreter kernels keep (their register budget is
 // spent on the interpreter: pixel items cost k_raster_vm_sv 3-4 % on the 1 M-triangle grid while they save k_raster_rows 9 %)
-template <bool INDIRECT, bool PIX>
-__device__ RXR_ROWS_INLINE bool rows_round(const RasterParams &P, Stage &st, RowLds &rl, uint32_t n, uint32_t tile_x0, uint32_t tile_y0px) {
+template <bool INDIRECT, bool PIX, uint32_t TH = RXR_TILE_H>
+__device__ RXR_ROWS_INLINE bool rows_round(const RasterParams &P, Stage &st, RowLdsT<TH> &rl, uint32_t n, uint32_t tile_x0, uint32_t tile_y0px) {
+    static_assert(TH == 16 || TH == 32, "the bit fields of `geo` and the exact short division hold for offsets below 512");
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     // clipped pixel box of staged candidate `tid`
     uint32_t rows = 0, area = 0, geo = 0;
@@ -2112,7 +2116,7 @@ __device__ RXR_ROWS_INLINE bool rows_round(const RasterParams &P, Stage &st, Row
         alpha_test = (R.bflags & (DB_ALPHA_TEST | DB_FULL_ALPHA)) != 0;
         if (!(R.bflags & DB_OPACITY_LIST)) {
             const uint32_t x0 = max(R.bx & 0xFFFFu, tile_x0), x1 = min(R.bx >> 16, tile_x0 + RXR_TILE_W);
-            const uint32_t y0 = max(R.by & 0xFFFFu, tile_y0px), y1 = min(R.by >> 16, tile_y0px + RXR_TILE_H);
+            const uint32_t y0 = max(R.by & 0xFFFFu, tile_y0px), y1 = min(R.by >> 16, tile_y0px + TH);
             if (x0 < x1 && y0 < y1) {
                 rows = y1 - y0;
                 area = rows * (x1 - x0);
@@ -2594,6 +2598,119 @@ __device__ __forceinline__ uint32_t walk_prims2d(const RasterParams &P, Stage &s
 #define RXR_WAVE_8X8 0
 #endif
 
+// The 2D pass of one tile (rasterizer.rs:501-553), strictly in submission order; the caller has checked that the union of the 2D
+// pixel boxes reaches the tile.  Uses the stage (and s_bin) of the workgroup: every thread of the workgroup must call it.
+template <int X>
+__device__ __forceinline__ uint32_t pass2d(const RasterParams &P, Stage &stage, uint32_t *s_bin, uint32_t *s_sort, const uint32_t sort_cap, uint32_t bin,
+                                           uint32_t tile_x0, uint32_t tile_y0px, uint32_t px, uint32_t py, float fx, float fy, uint32_t color) {
+    const uint32_t tid = threadIdx.x;
+    __syncthreads();  // the 3D pass is done with the stage
+    if (!P.binned2d) {
+        // few primitives (<= RXR_STAGE_TRIS): thread t tests primitive t's pixel box against the tile, the
+        // survivors are ballot-compacted (which keeps submission order) and only they are staged
+        const uint32_t lane = tid & 63u, wave = tid >> 6;
+        bool keep = false;
+        if (tid < P.n_prims2d) {
+            const uint2 box = *reinterpret_cast<const uint2 *>(&P.prim2d[tid].bx);
+            uint32_t min_x = box.x & 0xFFFFu, max_x = box.x >> 16, min_y = box.y & 0xFFFFu, max_y = box.y >> 16;
+            keep = !(min_x >= tile_x0 + RXR_TILE_W || max_x <= tile_x0 || min_y >= tile_y0px + RXR_TILE_H || max_y <= tile_y0px);
+        }
+        const unsigned long long m = __ballot(keep);
+        const uint32_t before = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) stage.wave_cnt[wave] = (uint32_t)__popcll(m);
+        __syncthreads();
+        uint32_t off = 0, n = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < RXR_TILE_THREADS / 64; ++w) {
+            uint32_t c = stage.wave_cnt[w];
+            if (w < wave) off += c;
+            n += c;
+        }
+        if (keep) stage.ids[off + before] = tid;
+        __syncthreads();
+        if (n) color = walk_prims2d<X>(P, stage, stage.ids, n, false, px, py, fx, fy, color);
+    } else {
+        // candidates = [large 2D primitives whose box touches the tile] ++ [this tile's bin list], gathered
+        // into LDS, sorted by primitive index (submission order), then staged and applied in order
+        const uint32_t lane = tid & 63u, wave = tid >> 6;
+        if (tid == 0) {
+            uint32_t cnt = P.bin2d_count[bin];
+            uint32_t start = P.chunk2d_base[bin / RXR_SCAN_CHUNK] + P.bin2d_offset[bin];
+            s_bin[0] = min(start, P.list2d_capacity);
+            s_bin[1] = min(start + cnt, P.list2d_capacity);
+            s_bin[2] = 0u;  // number of gathered candidates
+            if (cnt) P.bin2d_count[bin] = 0u;
+        }
+        __syncthreads();
+        const uint32_t c0 = s_bin[0], c1 = s_bin[1];
+        const uint32_t n_large = P.blockscan2d_cap ? 0u : min(P.counters2d[CNT_LARGE], P.n_prims2d);  // (k_blockscan2d keeps no such list)
+        const uint32_t total = n_large + (c1 - c0);
+        for (uint32_t base = 0; base < total; base += RXR_TILE_THREADS) {
+            const uint32_t e = base + tid;
+            uint32_t id = 0;
+            bool keep = false;
+            if (e < total) {
+                if (e < n_large) {
+                    id = min(P.large2d_list[e], P.n_prims2d - 1u);
+                    const uint2 box = *reinterpret_cast<const uint2 *>(&P.prim2d[id].bx);
+                    uint32_t min_x = box.x & 0xFFFFu, max_x = box.x >> 16, min_y = box.y & 0xFFFFu, max_y = box.y >> 16;
+                    keep = !(min_x >= tile_x0 + RXR_TILE_W || max_x <= tile_x0 || min_y >= tile_y0px + RXR_TILE_H || max_y <= tile_y0px);
+                } else {
+                    id = P.bin2d_list[c0 + (e - n_large)];
+                    keep = id < P.n_prims2d;
+                }
+            }
+            const unsigned long long m = __ballot(keep);
+            const uint32_t before = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            if (lane == 0) stage.wave_cnt[wave] = (uint32_t)__popcll(m);
+            __syncthreads();
+            uint32_t off = s_bin[2], n = 0;
+#pragma unroll
+            for (uint32_t w = 0; w < RXR_TILE_THREADS / 64; ++w) {
+                uint32_t c = stage.wave_cnt[w];
+                if (w < wave) off += c;
+                n += c;
+            }
+            if (keep && off + before < sort_cap) s_sort[off + before] = id;
+            __syncthreads();
+            if (tid == 0) s_bin[2] = min(s_bin[2] + n, sort_cap + 1u);  // MAX + 1 flags "too many"
+            __syncthreads();
+        }
+        const uint32_t n_cand = s_bin[2];
+        if (n_cand > sort_cap) {
+            // more candidates than the LDS sort holds: walk every primitive in order (correct, slow)
+            color = walk_prims2d<X>(P, stage, nullptr, P.n_prims2d, true, px, py, fx, fy, color);
+        } else if (P.blockscan2d_cap) {
+            // k_blockscan2d's lists are in submission order already, and the gather above keeps the order
+            color = walk_prims2d<X>(P, stage, s_sort, n_cand, false, px, py, fx, fy, color);
+        } else {
+            // bitonic sort of s_sort[0 .. n_cand) padded to the next power of two with 0xFFFFFFFF
+            uint32_t n2 = 1;
+            while (n2 < n_cand) n2 <<= 1;
+            for (uint32_t i2 = n_cand + tid; i2 < n2; i2 += RXR_TILE_THREADS) s_sort[i2] = 0xFFFFFFFFu;
+            __syncthreads();
+            for (uint32_t k2 = 2; k2 <= n2; k2 <<= 1) {
+                for (uint32_t j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
+                    for (uint32_t i2 = tid; i2 < n2; i2 += RXR_TILE_THREADS) {
+                        uint32_t l2 = i2 ^ j2;
+                        if (l2 > i2) {
+                            uint32_t a = s_sort[i2], b = s_sort[l2];
+                            bool up = (i2 & k2) == 0;
+                            if ((a > b) == up) {
+                                s_sort[i2] = b;
+                                s_sort[l2] = a;
+                            }
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+            color = walk_prims2d<X>(P, stage, s_sort, n_cand, false, px, py, fx, fy, color);
+        }
+    }
+    return color;
+}
+
 // LDS of the fused instantiation only
 template <bool F>
 struct ShadeStore {
@@ -2650,9 +2767,12 @@ __device__ __forceinline__ void raster_tile(const RasterParams &P) {
     PHASE_DECL;
 
     // tile initial colour: zeros | background colour | background shader (rasterizer.rs:277-308)
+    // (in 3D mode the resolve loop overwrites every pixel -- hit: shaded colour, miss: [0,0,0,255], :420-461 -- before anything reads
+    // the background, so it is not evaluated at all: a division, a clamp and a conversion per lane of every tile)
     uint32_t color = 0u;
-    if (P.flags & RXR_FLAG_HAS_BACKGROUND_COLOR) color = P.background_color;
-    if (!(P.flags & RXR_FLAG_IGNORE_BG_SHADER)) {
+    const bool bg_dead = (P.flags & RXR_FLAG_D3_ACTIVE) != 0u;  // uniform
+    if (!bg_dead && (P.flags & RXR_FLAG_HAS_BACKGROUND_COLOR)) color = P.background_color;
+    if (!bg_dead && !(P.flags & RXR_FLAG_IGNORE_BG_SHADER)) {
         if (P.background_kind == RXR_BG_VGRADIENT) {
             uint32_t i = sat_u8(rclamp(((float)py / P.fheight) * 128.0f, 0.0f, 128.0f));  // shader/vgradient.rs:11-15
             color = pack4(i, i, i, 255u);
@@ -2769,111 +2889,8 @@ __device__ __forceinline__ void raster_tile(const RasterParams &P) {
     const bool d2_here = (P.flags & RXR_FLAG_D2_ACTIVE) && P.n_prims2d && tile_x0 < P.d2_box[1] && tile_x0 + RXR_TILE_W > P.d2_box[0] &&
                          tile_y0px < P.d2_box[3] && tile_y0px + RXR_TILE_H > P.d2_box[2];
     if (d2_here) {
-        __syncthreads();  // the 3D pass is done with the stage
-        if (!P.binned2d) {
-            // few primitives (<= RXR_STAGE_TRIS): thread t tests primitive t's pixel box against the tile, the
-            // survivors are ballot-compacted (which keeps submission order) and only they are staged
-            const uint32_t lane = tid & 63u, wave = tid >> 6;
-            bool keep = false;
-            if (tid < P.n_prims2d) {
-                const uint2 box = *reinterpret_cast<const uint2 *>(&P.prim2d[tid].bx);
-                uint32_t min_x = box.x & 0xFFFFu, max_x = box.x >> 16, min_y = box.y & 0xFFFFu, max_y = box.y >> 16;
-                keep = !(min_x >= tile_x0 + RXR_TILE_W || max_x <= tile_x0 || min_y >= tile_y0px + RXR_TILE_H || max_y <= tile_y0px);
-            }
-            const unsigned long long m = __ballot(keep);
-            const uint32_t before = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-            if (lane == 0) stage.wave_cnt[wave] = (uint32_t)__popcll(m);
-            __syncthreads();
-            uint32_t off = 0, n = 0;
-#pragma unroll
-            for (uint32_t w = 0; w < RXR_TILE_THREADS / 64; ++w) {
-                uint32_t c = stage.wave_cnt[w];
-                if (w < wave) off += c;
-                n += c;
-            }
-            if (keep) stage.ids[off + before] = tid;
-            __syncthreads();
-            if (n) color = walk_prims2d<X>(P, stage, stage.ids, n, false, px, py, fx, fy, color);
-        } else {
-            // candidates = [large 2D primitives whose box touches the tile] ++ [this tile's bin list], gathered
-            // into LDS, sorted by primitive index (submission order), then staged and applied in order
-            __shared__ uint32_t s_sort[RXR_SORT2D_MAX];
-            const uint32_t lane = tid & 63u, wave = tid >> 6;
-            if (tid == 0) {
-                uint32_t cnt = P.bin2d_count[bin];
-                uint32_t start = P.chunk2d_base[bin / RXR_SCAN_CHUNK] + P.bin2d_offset[bin];
-                s_bin[0] = min(start, P.list2d_capacity);
-                s_bin[1] = min(start + cnt, P.list2d_capacity);
-                s_bin[2] = 0u;  // number of gathered candidates
-                if (cnt) P.bin2d_count[bin] = 0u;
-            }
-            __syncthreads();
-            const uint32_t c0 = s_bin[0], c1 = s_bin[1];
-            const uint32_t n_large = P.blockscan2d_cap ? 0u : min(P.counters2d[CNT_LARGE], P.n_prims2d);  // (k_blockscan2d keeps no such list)
-            const uint32_t total = n_large + (c1 - c0);
-            for (uint32_t base = 0; base < total; base += RXR_TILE_THREADS) {
-                const uint32_t e = base + tid;
-                uint32_t id = 0;
-                bool keep = false;
-                if (e < total) {
-                    if (e < n_large) {
-                        id = min(P.large2d_list[e], P.n_prims2d - 1u);
-                        const uint2 box = *reinterpret_cast<const uint2 *>(&P.prim2d[id].bx);
-                        uint32_t min_x = box.x & 0xFFFFu, max_x = box.x >> 16, min_y = box.y & 0xFFFFu, max_y = box.y >> 16;
-                        keep = !(min_x >= tile_x0 + RXR_TILE_W || max_x <= tile_x0 || min_y >= tile_y0px + RXR_TILE_H || max_y <= tile_y0px);
-                    } else {
-                        id = P.bin2d_list[c0 + (e - n_large)];
-                        keep = id < P.n_prims2d;
-                    }
-                }
-                const unsigned long long m = __ballot(keep);
-                const uint32_t before = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                if (lane == 0) stage.wave_cnt[wave] = (uint32_t)__popcll(m);
-                __syncthreads();
-                uint32_t off = s_bin[2], n = 0;
-#pragma unroll
-                for (uint32_t w = 0; w < RXR_TILE_THREADS / 64; ++w) {
-                    uint32_t c = stage.wave_cnt[w];
-                    if (w < wave) off += c;
-                    n += c;
-                }
-                if (keep && off + before < RXR_SORT2D_MAX) s_sort[off + before] = id;
-                __syncthreads();
-                if (tid == 0) s_bin[2] = min(s_bin[2] + n, (uint32_t)RXR_SORT2D_MAX + 1u);  // MAX + 1 flags "too many"
-                __syncthreads();
-            }
-            const uint32_t n_cand = s_bin[2];
-            if (n_cand > RXR_SORT2D_MAX) {
-                // more candidates than the LDS sort holds: walk every primitive in order (correct, slow)
-                color = walk_prims2d<X>(P, stage, nullptr, P.n_prims2d, true, px, py, fx, fy, color);
-            } else if (P.blockscan2d_cap) {
-                // k_blockscan2d's lists are in submission order already, and the gather above keeps the order
-                color = walk_prims2d<X>(P, stage, s_sort, n_cand, false, px, py, fx, fy, color);
-            } else {
-                // bitonic sort of s_sort[0 .. n_cand) padded to the next power of two with 0xFFFFFFFF
-                uint32_t n2 = 1;
-                while (n2 < n_cand) n2 <<= 1;
-                for (uint32_t i2 = n_cand + tid; i2 < n2; i2 += RXR_TILE_THREADS) s_sort[i2] = 0xFFFFFFFFu;
-                __syncthreads();
-                for (uint32_t k2 = 2; k2 <= n2; k2 <<= 1) {
-                    for (uint32_t j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
-                        for (uint32_t i2 = tid; i2 < n2; i2 += RXR_TILE_THREADS) {
-                            uint32_t l2 = i2 ^ j2;
-                            if (l2 > i2) {
-                                uint32_t a = s_sort[i2], b = s_sort[l2];
-                                bool up = (i2 & k2) == 0;
-                                if ((a > b) == up) {
-                                    s_sort[i2] = b;
-                                    s_sort[l2] = a;
-                                }
-                            }
-                        }
-                        __syncthreads();
-                    }
-                }
-                color = walk_prims2d<X>(P, stage, s_sort, n_cand, false, px, py, fx, fy, color);
-            }
-        }
+        __shared__ uint32_t s_sort[RXR_SORT2D_MAX];  // the gathered candidates of a binned 2D pass
+        color = pass2d<X>(P, stage, s_bin, s_sort, RXR_SORT2D_MAX, bin, tile_x0, tile_y0px, px, py, fx, fy, color);
     }
 
     PHASE_MARK(5);
@@ -2883,6 +2900,161 @@ __device__ __forceinline__ void raster_tile(const RasterParams &P) {
     }
     PHASE_MARK(6);
     PHASE_FLUSH;
+}
+
+// ---- pairs of tiles (binned scenes, feature level 0, no opacity pass) ---------------------------------------------------------------
+// A tile of a scene of small triangles spends a quarter of its instructions on what does not depend on its pixels: list bounds, the
+// staging of its ~20 candidates, the tile-level reject, the scans and the owner search of a row-mode round.  A workgroup of the pair
+// kernels takes TWO vertically adjacent tiles -- the bins stay 16 x 16, the pre-pass and the stripes of a multi-GPU launch are untouched
+// -- as one 16 x 32 tile: both bin lists are staged into the same rounds (an entry of the lower bin whose box starts above it is in the
+// upper bin's list as well and is dropped: exact, a bin lists every triangle whose box meets it), the z-buffer in LDS has 512 cells,
+// row mode runs over the boxes clipped to 32 rows, and every lane then resolves and shades its two pixels one after the other.  ALL
+// visibility goes through the z-buffer's (z, index) keys here: a round that is walked (large triangles, cut-outs) merges each lane's
+// winner into the lane's own two cells, so no per-pixel state lives in registers across the rounds.  Same fragments, same arg-min,
+// same shading code: byte-identical to the single-tile kernels (tests/test_gpu_rows.py, the full-size configurations).
+template <int X>
+__device__ __forceinline__ void scan_lists_pair(const RasterParams &P, Stage &st, RowLdsT<32> &rl, uint32_t a0, uint32_t a1, uint32_t b0, uint32_t b1,
+                                                uint32_t tile_x0, uint32_t tile_y0px, uint32_t lx, uint32_t ly) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t n_large = min(P.counters[CNT_LARGE], P.n_tris3d);
+    const uint32_t n_a = a1 - a0, total = n_large + n_a + (b1 - b0);
+    const uint32_t y_lower = tile_y0px + RXR_TILE_H;  // first row of the lower tile
+    const float4 *g4 = reinterpret_cast<const float4 *>(P.tri_setup);
+    for (uint32_t base = 0; base < total; base += RXR_STAGE_TRIS) {
+        const uint32_t m = min(total - base, (uint32_t)RXR_STAGE_TRIS);
+        // 1. ids of the round's list entries: large list, upper bin, lower bin
+        if (tid < m) {
+            const uint32_t e = base + tid;
+            rl.raw[tid] = e < n_large ? P.large_list[e] : (e < n_large + n_a ? P.bin_list[a0 + (e - n_large)] : P.bin_list[b0 + (e - n_large - n_a)]);
+        }
+        __syncthreads();
+        // 2. their records (ids outside this frame's records are never followed: clamped here, dropped in step 3)
+        for (uint32_t f = tid; f < m * 6u; f += RXR_TILE_THREADS) {
+            const uint32_t k = f / 6u, j = f - k * 6u;
+            st.tri[f] = g4[(size_t)min(rl.raw[k], P.n_tris3d - 1u) * 6u + j];
+        }
+        __syncthreads();
+        // 3. pixel box and tile-level edge reject on the LDS copies, against the 16 x 32 rectangle; survivors' slots are compacted
+        bool keep = false;
+        uint32_t id = 0;
+        if (tid < m) {
+            id = rl.raw[tid];
+            const TriSetup &R = *reinterpret_cast<const TriSetup *>(&st.tri[tid * 6u]);
+            const uint32_t min_x = R.bx & 0xFFFFu, max_x = R.bx >> 16, min_y = R.by & 0xFFFFu, max_y = R.by >> 16;
+            keep = id < P.n_tris3d && !(min_x >= tile_x0 + RXR_TILE_W || max_x <= tile_x0 || min_y >= tile_y0px + 2u * RXR_TILE_H || max_y <= tile_y0px);
+            // the lower bin's entry is the upper bin's entry too when its box begins above the lower tile
+            if (base + tid >= n_large + n_a && min_y < y_lower) keep = false;
+            if (keep && tile_outside_edges(R.ea, R.eb, R.ec, tile_x0, tile_y0px, 2u * RXR_TILE_H)) keep = false;
+        }
+        const unsigned long long mk = __ballot(keep);
+        const uint32_t before = (uint32_t)__popcll(mk & ((1ull << lane) - 1ull));
+        if (lane == 0) st.wave_cnt[wave] = (uint32_t)__popcll(mk);
+        __syncthreads();
+        uint32_t off = 0, n = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < RXR_TILE_THREADS / 64; ++w) {
+            const uint32_t c = st.wave_cnt[w];
+            if (w < wave) off += c;
+            n += c;
+        }
+        if (keep) {
+            rl.slot[off + before] = (uint8_t)tid;
+            st.ids[off + before] = id;
+        }
+        __syncthreads();
+        // 4. the pixels of the candidates' boxes (row mode), or the walk -- merged into the same keys
+        if (rows_round<true, true, 32u>(P, st, rl, n, tile_x0, tile_y0px)) continue;
+#pragma unroll 1
+        for (uint32_t h = 0; h < 2u; ++h) {
+            const uint32_t px = tile_x0 + lx, py = tile_y0px + h * RXR_TILE_H + ly;
+            const float fx = (float)px + 0.5f, fy = (float)py + 0.5f;
+            Vis vis;
+            vis.zmin = 1.0f; vis.best = -1; vis.alpha = 0.0f; vis.beta = 0.0f; vis.slot = 0; vis.batch = 0;
+            for (uint32_t k = 0; k < n; ++k) {
+                const uint32_t sl = rl.slot[k];
+                const TriSetup &S = *reinterpret_cast<const TriSetup *>(&st.tri[sl * 6u]);
+                const uint32_t t = st.ids[k];
+                visit<false, X>(P, S, &P.tri_shade[t], t, sl, px, py, fx, fy, vis, -1, nullptr);
+            }
+            if (vis.best >= 0) {  // (z < 1.0: visit starts from the cleared buffer's 1.0, :1060)
+                // this lane's own cell; the rounds are separated by barriers, so nobody else touches it now
+                const unsigned long long key = ((unsigned long long)z_order_bits(vis.zmin + 0.0f) << 32) | (uint32_t)vis.best;
+                unsigned long long *const cell = &rl.key[(h * RXR_TILE_H + ly) * RXR_TILE_W + lx];
+                if (key < *cell) *cell = key;
+            }
+        }
+        __syncthreads();  // the stage is reused by the next round
+    }
+}
+
+template <int X, bool RL>
+__device__ __forceinline__ void raster_tile_pair(const RasterParams &P) {
+    static_assert(X == 0, "the pair kernels serve feature level 0");
+    __shared__ Stage stage;
+    __shared__ uint32_t s_bin[4];
+    __shared__ RowLdsT<32> rl;
+    const uint32_t tx = blockIdx.x, ty0 = 2u * blockIdx.y, ty1 = ty0 + 1u;  // launch-local tile rows (tile_stride == 1: adjacent)
+    const bool has_lower = ty1 < P.tiles_y;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t tile_x0 = tx * RXR_TILE_W, tile_y0px = (P.tile_y0 + ty0) * RXR_TILE_H;
+    const uint32_t lx = tid & (RXR_TILE_W - 1), ly = tid / RXR_TILE_W;
+    const uint32_t bin_a = ty0 * P.tiles_x + tx, bin_b = ty1 * P.tiles_x + tx;
+    // every thread reads the (uniform) list bounds itself; the counts are handed back zeroed below
+    const uint32_t cnt_a = P.bin_count[bin_a], cnt_b = has_lower ? P.bin_count[bin_b] : 0u;
+    const uint32_t start_a = P.chunk_base[bin_a / RXR_SCAN_CHUNK] + P.bin_offset[bin_a];
+    const uint32_t start_b = has_lower ? P.chunk_base[bin_b / RXR_SCAN_CHUNK] + P.bin_offset[bin_b] : 0u;
+    const uint32_t a0 = min(start_a, P.list_capacity), a1 = min(start_a + cnt_a, P.list_capacity);
+    const uint32_t b0 = min(start_b, P.list_capacity), b1 = min(start_b + cnt_b, P.list_capacity);
+    rl.key[tid] = RXR_ZKEY_INIT;  // own cells; published by the barriers of the first staging round
+    rl.key[RXR_TILE_THREADS + tid] = RXR_ZKEY_INIT;
+    scan_lists_pair<X>(P, stage, rl, a0, a1, b0, b1, tile_x0, tile_y0px, lx, ly);
+    if (tid == 0) {  // (a non-empty list went through the barriers of a round: every thread has read the counts)
+        if (cnt_a) P.bin_count[bin_a] = 0u;
+        if (cnt_b) P.bin_count[bin_b] = 0u;
+    }
+    // The 2D pass of a tile gathers its candidates in the UPPER tile's half of the z-buffer (2 KB = 512 entries; a tile with more walks
+    // every primitive: correct, slow): each lane has read its upper winner before pass2d's first barrier, and the lower tile's half is
+    // left alone until its own iteration -- so the workgroup's LDS stays under 20 KB and eight of them fit a CU.
+    static_assert(sizeof(rl.key) / 2 >= 512 * sizeof(uint32_t), "the 2D candidate array aliases half of the z-buffer");
+#pragma unroll 1
+    for (uint32_t h = 0; h < 2u; ++h) {
+        if (h == 1u && !has_lower) break;  // (uniform)
+        const uint32_t px = tile_x0 + lx, py = tile_y0px + h * RXR_TILE_H + ly;
+        const float fx = (float)px + 0.5f, fy = (float)py + 0.5f;
+        const bool in_frame = px < P.width && py >= P.row0 && py < P.row1;
+        Vis vis;
+        vis.zmin = 1.0f; vis.best = -1; vis.alpha = 0.0f; vis.beta = 0.0f; vis.slot = 0; vis.batch = 0;
+        TriShade HS;
+        {
+            // the winner of the pixel: its records are fetched together, its barycentrics re-derived (rows_resolve)
+            const unsigned long long key = rl.key[(h * RXR_TILE_H + ly) * RXR_TILE_W + lx];
+            if (key < RXR_ZKEY_INIT) {
+                const uint32_t t = (uint32_t)key;
+                const TriSetup S = P.tri_setup[t];
+                HS = P.tri_shade[t];
+                float alpha, beta, z;
+                bary_depth(S.v0x, S.v0y, S.v1x, S.v1y, S.v2x, S.v2y, S.area, S.iz0, S.iz1, S.iz2, fx, fy, alpha, beta, z);
+                vis.zmin = z; vis.best = (int)t; vis.alpha = alpha; vis.beta = beta; vis.batch = S.batch;
+            }
+        }
+        const bool hit = vis.best >= 0;
+        Frag F;
+        F.world = F.normal = F.view_dir = F.base = F.lit = F.emis = mk3(0.0f, 0.0f, 0.0f);
+        F.opacity = 0.0f;
+        F.rough = 0.5f;
+        F.metal = 0.0f;
+        if (hit) shade3d_begin<X, RL>(P, HS, vis.batch, vis.alpha, vis.beta, vis.zmin, fx, fy, F);
+        if (P.n_lights) shade3d_lights<X, RL>(P, hit, F);  // wave-uniform call
+        uint32_t color = hit ? shade3d_end<X, RL>(F) : pack4(0u, 0u, 0u, 255u);
+        const uint32_t tile_yh = tile_y0px + h * RXR_TILE_H;
+        const bool d2_here = (P.flags & RXR_FLAG_D2_ACTIVE) && P.n_prims2d && tile_x0 < P.d2_box[1] && tile_x0 + RXR_TILE_W > P.d2_box[0] &&
+                             tile_yh < P.d2_box[3] && tile_yh + RXR_TILE_H > P.d2_box[2];
+        if (d2_here) color = pass2d<X>(P, stage, s_bin, reinterpret_cast<uint32_t *>(rl.key), 512u, h ? bin_b : bin_a, tile_x0, tile_yh, px, py, fx, fy, color);
+        if (in_frame) {
+            const int64_t row = P.compact ? (int64_t)((ty0 + h) * RXR_TILE_H + ly) : (int64_t)py - P.out_base_row;
+            P.out[(size_t)row * P.out_row_stride + px] = color;
+        }
+    }
 }
 
 __device__ __forceinline__ const RasterParams &kernarg_params_early() { return *(const RasterParams *)__builtin_amdgcn_kernarg_segment_ptr(); }
@@ -2929,6 +3101,12 @@ extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_ROWS_WAVES_PE
 extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_ROWS_WAVES_PER_SIMD) k_raster_rows(RasterParams P) { raster_tile<false, 0, true>(P); }
 #endif
 extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_ROWS_WAVES_PER_SIMD) k_raster_rows_rl(RasterParams) { raster_tile<false, 0, true, true>(kernarg_params_early()); }
+// two tiles per workgroup (raster_tile_pair): binned scenes without an opacity pass, launches whose tile rows are adjacent
+#ifndef RXR_PAIR_WAVES_PER_SIMD
+#define RXR_PAIR_WAVES_PER_SIMD 8
+#endif
+extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_PAIR_WAVES_PER_SIMD) k_raster_pair(RasterParams) { raster_tile_pair<0, false>(kernarg_params_early()); }
+extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_PAIR_WAVES_PER_SIMD) k_raster_pair_rl(RasterParams) { raster_tile_pair<0, true>(kernarg_params_early()); }
 // feature levels (template parameter X) so that the common kernels above carry none of the rarer paths:
 //   1  k_raster_chunk: chunk textures -- terrain texels sampled by world position, baked shader textures, and the
 //      full-fragment alpha test they need
@@ -3027,7 +3205,18 @@ extern "C" void rxr_launch_raster(const RasterParams *P, hipStream_t s) {
         else hipLaunchKernelGGL(k_raster_chunk, tiles, dim3(RXR_TILE_THREADS), 0, s, *P);
     } else if (P->fused_small == 1u) hipLaunchKernelGGL(k_raster_fused, tiles, dim3(RXR_TILE_THREADS), 0, s, *P);
     else if (P->fused_small == 0u && (P->flags & RXR_FLAG_D3_ACTIVE) && !no_rows) {
-        if (rl) hipLaunchKernelGGL(k_raster_rows_rl, tiles, dim3(RXR_TILE_THREADS), 0, s, *P);
+        // two tiles per workgroup (raster_tile_pair): opt-in.  Built in round 3 as the 16 x 32-tile experiment the round-2 verdict asked to
+        // repeat on a build that passes parity: it does pass (tests/test_gpu_rows.py runs it), and it LOSES -- 1 M-triangle grid 555 ->
+        // 654 us at 8 waves per SIMD (817 / 697 / 668 at 7 / 6 / 5), teapot 29 -> 46 us (profiles/r03/pair_tiles_experiment.txt): what the
+        // pair saves in per-tile instructions it pays in spills (the two shading passes share one register budget) and in a per-workgroup
+        // latency chain that is twice as long.  RXR_PAIR_TILES=1 selects it.
+        const char *pt = getenv("RXR_PAIR_TILES");  // (read per launch: the tests switch it)
+        const bool pairs_on = pt && pt[0] == '1';
+        if (pairs_on && !P->has_opacity && P->tile_stride == 1u && !RXR_XCD_GROUP) {
+            const dim3 pairs(P->tiles_x, (P->tiles_y + 1u) / 2u);
+            if (rl) hipLaunchKernelGGL(k_raster_pair_rl, pairs, dim3(RXR_TILE_THREADS), 0, s, *P);
+            else hipLaunchKernelGGL(k_raster_pair, pairs, dim3(RXR_TILE_THREADS), 0, s, *P);
+        } else if (rl) hipLaunchKernelGGL(k_raster_rows_rl, tiles, dim3(RXR_TILE_THREADS), 0, s, *P);
         else hipLaunchKernelGGL(k_raster_rows, tiles, dim3(RXR_TILE_THREADS), 0, s, *P);
     } else if (rl) hipLaunchKernelGGL(k_raster_rl, tiles, dim3(RXR_TILE_THREADS), 0, s, *P);
     else hipLaunchKernelGGL(k_raster, tiles, dim3(RXR_TILE_THREADS), 0, s, *P);

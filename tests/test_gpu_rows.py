@@ -163,3 +163,21 @@ def test_row_mode_equals_the_walk_over_many_frames(oracle, product, monkeypatch)
         got = scenes.render(cfg)
         diff = (got != ref).any(axis=2)
         assert not diff.any(), f"frame {it} ({'walk' if it % 3 == 2 else 'rows'}): {int(diff.sum())} pixels differ; first {np.argwhere(diff)[:3].tolist()}"
+
+
+@pytest.mark.parametrize("variant", ["plain", "ties", "cutout", "mixed"])
+def test_pairs_of_tiles_per_workgroup(oracle, product, monkeypatch, variant):
+    """RXR_PAIR_TILES=1: k_raster_pair -- two vertically adjacent bins per workgroup, one 512-cell z-buffer, every round (row mode or
+    walked) merged into its (z, index) keys, two pixels resolved and shaded per lane.  The round-2 verdict's 16 x 32-tile experiment
+    on a build that passes parity: it does (here: odd tile-row counts, ragged tiles, ties, cut-outs, Linear sampling, the teapot and a
+    box grid), and it is slower (profiles/r03/pair_tiles_experiment.txt), so it stays opt-in."""
+    monkeypatch.setenv("RXR_PAIR_TILES", "1")
+    for seed, (w, h) in enumerate([(203, 131), (240, 176), (97, 33)]):   # 9, 11 and 3 tile rows: the last pair is half empty
+        got = scenes.render(build(product, seed, w, h, variant))
+        ref = scenes.render(build(oracle, seed, w, h, variant))
+        diff = (got != ref).any(axis=2)
+        assert not diff.any(), f"{variant} seed {seed}: {int(diff.sum())} pixels differ; first {np.argwhere(diff)[:3].tolist()}"
+    if variant == "plain":
+        for cfg in (lambda api: scenes.teapot_scene(api, width=640, height=360, logo_size=64), lambda api: scenes.box_grid_scene(api, n=40, width=640, height=360)):
+            got, ref = scenes.render(cfg(product)), scenes.render(cfg(oracle))
+            assert np.array_equal(got, ref)
