@@ -122,7 +122,7 @@ bool to_isize32(float x, int32_t &out) {
 }
 
 struct Layout {
-    size_t off_b3, off_base, off_pv, off_uv, off_nrm, off_idx, off_edges, off_lights, off_occ, off_ld, off_chunks, off_tdesc,
+    size_t off_b3, off_base, off_pv, off_uv, off_nrm, off_idx, off_edges, off_tinfo, off_lights, off_occ, off_ld, off_chunks, off_tdesc,
         off_ltex, off_b2, off_p2, off_bg, total;
 };
 
@@ -1000,6 +1000,8 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
         o = align_up(o + (bytes ? bytes : 16), 256);
         return at;
     };
+    const bool with_tri_info = !use_meshes && n_t3 > 0 && n_t3 <= RXR_TRI_INFO_MAX;
+    L.off_tinfo = take(with_tri_info ? n_t3 * sizeof(uint2) : 0);
     L.off_lights = take(f->n_lights * sizeof(rxr_light));
     L.off_occ = take(n_occ_total * sizeof(rxr_occluder));
     L.off_ld = take(f->n_linedefs * sizeof(rxr_linedef));
@@ -1017,11 +1019,11 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
         // what follows the arrays does not fit the room rxr_stream_begin left: a reallocation would lose what has been shipped.  The plain
         // path from scratch (rare: the frame's lights / 2D primitives / chunk textures more than doubled against the previous frame).
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        ctx->last_blob_tail = L.total - L.off_lights;
+        ctx->last_blob_tail = L.total - L.off_tinfo;
         S.failed.store(1);
         return rxr_upload_frame(ctx, f);
     }
-    ctx->last_blob_tail = L.total - L.off_lights;
+    ctx->last_blob_tail = L.total - L.off_tinfo;
     if ((rc = ensure_stage(ctx, L.total)) != RXR_OK) return rc;
     if ((rc = ensure(ctx, ctx->d_frame, L.total)) != RXR_OK) return rc;
     // the staging blob may still be in flight from the previous upload, and the previous frame's renders -- possibly on
@@ -1149,6 +1151,11 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
         tcur += b.n_triangles;
     }
     base[f->n_batches3d] = (uint32_t)tcur;
+    if (with_tri_info) {  // (batch, vert_base) per triangle: k_setup3d of a small frame looks its batch up instead of searching for it
+        uint2 *ti = (uint2 *)(st + L.off_tinfo);
+        for (uint32_t i = 0; i < f->n_batches3d; ++i)
+            for (uint32_t t = 0; t < f->batches3d[i].n_triangles; ++t) ti[b3[i].tri_base + t] = make_uint2(i, b3[i].vert_base);
+    }
     // the arrays themselves: independent per batch (offsets are in the headers just written), through the host worker pool --
     // 124 MB for the 1 M-triangle grid, which one thread copies in about as long as the GPU takes for forty frames
     ut_headers = ut_ms();
@@ -1531,9 +1538,9 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
     if ((rc = ensure(ctx, ctx->d_fb, (size_t)f->width * f->height * 4)) != RXR_OK) return rc;
 
     if (arrays_shipped) {
-        // the projected arrays [off_pv, off_lights) left while they were being copied; what surrounds them follows
+        // the projected arrays [off_pv, off_tinfo) left while they were being copied; what surrounds them follows
         HIPCHK(ctx, hipMemcpyAsync(ctx->d_frame.p, st, L.off_pv, hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(ctx, hipMemcpyAsync((uint8_t *)ctx->d_frame.p + L.off_lights, st + L.off_lights, L.total - L.off_lights, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync((uint8_t *)ctx->d_frame.p + L.off_tinfo, st + L.off_tinfo, L.total - L.off_tinfo, hipMemcpyHostToDevice, ctx->stream));
     } else {
         HIPCHK(ctx, hipMemcpyAsync(ctx->d_frame.p, st, L.total, hipMemcpyHostToDevice, ctx->stream));
     }
@@ -1655,6 +1662,7 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
     P.edges = (const rxr_edges *)(d + L.off_edges);
     P.batches3d = (const DevBatch *)(d + L.off_b3);
     P.batch_tri_base = (const uint32_t *)(d + L.off_base);
+    P.tri_info = with_tri_info ? (const uint2 *)(d + L.off_tinfo) : nullptr;
     P.tri_setup = (TriSetup *)ctx->d_tri_setup.p;
     P.tri_shade = (TriShade *)ctx->d_tri_shade.p;
     P.tri_box = (uint2 *)ctx->d_tri_box.p;

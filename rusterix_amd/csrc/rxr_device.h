@@ -78,6 +78,8 @@ struct TriSetup {
 static_assert(sizeof(TriSetup) == 96, "TriSetup is staged through LDS as 6 x 16 B");
 // candidates staged per round in k_raster (LDS: RXR_STAGE_TRIS * 96 B)
 #define RXR_STAGE_TRIS 128
+// frames of at most this many triangles carry a (batch, vert_base) pair per triangle (RasterParams.tri_info)
+#define RXR_TRI_INFO_MAX 16384u
 
 // per-triangle record for shading the winning fragment.  80 B = 5 x 16 B.
 struct TriShade {
@@ -225,6 +227,9 @@ struct RasterParams {
     const rxr_edges *edges;
     const DevBatch *batches3d;
     const uint32_t *batch_tri_base;  // n_batches3d + 1 prefix array for the triangle -> batch search
+    const uint2 *tri_info;           // small frames (<= RXR_TRI_INFO_MAX triangles, host-projected): (batch, its vert_base) per triangle, written
+                                     // at upload -- k_setup3d of such a frame is one workgroup of pure latency, and the search above is five
+                                     // dependent loads of it; nullptr otherwise
     const struct DevBBox *dev_bbox;  // device-projection path: per-batch boxes accumulated on the device (else NULL)
     const uint32_t *mesh_live;       // device-projection path: per batch, the triangle slots in use (rxr_project.h); slots behind them
                                      // hold no triangle and nothing may be read from their records (else NULL)

@@ -1064,19 +1064,29 @@ __device__ __forceinline__ bool bin_range(const RasterParams &P, uint32_t min_x,
 // box (:998-1017, tile = whole width x row band).  Returns false when no pixel can be produced
 // (invisible edge, skipped batch, empty box); then only S.bx / S.by (an empty pixel box) are meaningful.
 __device__ __forceinline__ bool make_setup(const RasterParams &P, uint32_t t, TriSetup &S, TriShade &H) {
-    // triangle -> batch: largest b with base[b] <= t
+    // triangle -> batch: looked up (small frames: the table written at upload) or searched (largest b with base[b] <= t)
     uint32_t lo = 0, hi = P.n_batches3d;
-    while (hi - lo > 1) {
-        uint32_t mid = (lo + hi) >> 1;
-        if (P.batch_tri_base[mid] <= t) lo = mid;
-        else hi = mid;
+    const bool have_info = P.tri_info != nullptr;  // uniform
+    uint2 info = make_uint2(0u, 0u);
+    if (have_info) {
+        info = P.tri_info[t];
+        lo = info.x;
+    } else {
+        while (hi - lo > 1) {
+            uint32_t mid = (lo + hi) >> 1;
+            if (P.batch_tri_base[mid] <= t) lo = mid;
+            else hi = mid;
+        }
     }
     if (P.mesh_live && t - P.batch_tri_base[lo] >= P.mesh_live[lo]) {  // an unused slot of a device-projected mesh: nothing to read
         S.bx = S.by = 0u;
         return false;
     }
-    const DevBatch B = P.batches3d[lo];
+    // (with the table the index triple and the edge record do not wait for the batch header: two levels of loads instead of seven)
     const rxr_edges E = P.edges[t];
+    const uint32_t ix0 = P.idx[3 * (size_t)t + 0], ix1 = P.idx[3 * (size_t)t + 1], ix2 = P.idx[3 * (size_t)t + 2];
+    const DevBatch B = P.batches3d[lo];
+    const uint32_t vbase = have_info ? info.y : B.vert_base;
 
     // triangles that can never produce a pixel (culled / clipped away: edges.visible == false, :989-992; skipped batch;
     // batch box off screen) are known before any vertex is read: they only get an empty pixel box
@@ -1095,7 +1105,7 @@ __device__ __forceinline__ bool make_setup(const RasterParams &P, uint32_t t, Tr
         return false;
     }
 
-    uint32_t i0 = P.idx[3 * (size_t)t + 0] + B.vert_base, i1 = P.idx[3 * (size_t)t + 1] + B.vert_base, i2 = P.idx[3 * (size_t)t + 2] + B.vert_base;
+    const uint32_t i0 = ix0 + vbase, i1 = ix1 + vbase, i2 = ix2 + vbase;
     float4 v0 = P.pv[i0], v1 = P.pv[i1], v2 = P.pv[i2];
 
 #pragma unroll
@@ -2748,7 +2758,11 @@ __device__ __forceinline__ void raster_tile(const RasterParams &P) {
     const uint32_t tx = (q / G) * (8u * G) + (blockIdx.x & 7u) * G + (q % G), ty = blockIdx.y;
     if (tx >= P.tiles_x) return;  // (workgroup-uniform; the padding columns)
 #else
-    const uint32_t tx = blockIdx.x, ty = blockIdx.y;
+#ifndef RXR_FLIP_TILE_ROWS
+#define RXR_FLIP_TILE_ROWS 0
+#endif
+    // (RXR_FLIP_TILE_ROWS: dispatch the launch's bottom tile rows first -- an A-B knob for frames whose expensive tiles are at the bottom)
+    const uint32_t tx = blockIdx.x, ty = RXR_FLIP_TILE_ROWS ? gridDim.y - 1u - blockIdx.y : blockIdx.y;
 #endif
     const uint32_t bin = ty * P.tiles_x + tx;
     const uint32_t tid = threadIdx.x;
