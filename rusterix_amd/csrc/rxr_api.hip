@@ -2039,6 +2039,18 @@ int rxr_synchronize(rxr_ctx *ctx) {
         ctx->launches_since_sync = 0;
         if (!ctx->rendered) return RXR_OK;
         uint32_t *hc = ctx->h_counters;
+        if (hc[HS_VM_FAULT] == VMF_JIT_PALETTE_MISS) {
+            // not a fault of the program: a compiled set met a palette slot without a colour, where the reference pushes nothing -- only
+            // the interpreter's dynamic stack follows that.  The set runs interpreted from now on; the last launch is rendered again, an
+            // earlier one of this batch of launches was incomplete (reported like an overflow).
+            hc[HS_VM_FAULT] = 0;
+            ctx->jit_palette_miss = true;
+            ctx->jit_info = "not compiled: a PaletteIndex met a missing or empty palette slot (the interpreter follows the reference's shorter stack)";
+            if (launches > 1u) earlier_incomplete = true;
+            int rc = render_impl(ctx, ctx->last_spec, ctx->last_out, ctx->last_stream, true);
+            if (rc != RXR_OK) return rc;
+            continue;
+        }
         if (hc[HS_VM_FAULT]) {
             // a fragment's program did what makes the reference panic (rxr_vm.h, VMF_*)
             static const char *const what[] = {"", "stack underflow", "stack overflow", "local index out of range", "global index out of range",

@@ -143,6 +143,7 @@ struct rxr_ctx {
     // programs of the current set, empty when the set is not covered)
     void *jit_module[3] = {nullptr, nullptr, nullptr}, *jit_fn[3] = {nullptr, nullptr, nullptr};
     bool jit_failed[3] = {false, false, false};
+    bool jit_palette_miss = false;   // a compiled frame met a PaletteIndex without a colour: this set runs interpreted from now on (VMF_JIT_PALETTE_MISS)
     // background mode (the default): the compilation of a level runs in a child process (rxr_jitc); the interpreter renders until it is done
     bool jit_async = false;
     std::string jit_wait_key[3];           // the background compilation (rxr_jit.hip registry) this context is attached to, per level

@@ -154,6 +154,9 @@ enum { VM_BINC_ADD = 0, VM_BINC_SUB, VM_BINC_MUL, VM_BINC_DIV, VM_BINC_MIN, VM_B
 enum : uint32_t {
     VMF_STACK_UNDERFLOW = 1, VMF_STACK_OVERFLOW, VMF_LOCAL_INDEX, VMF_GLOBAL_INDEX, VMF_CALL_DEPTH, VMF_LOOP_DEPTH,
     VMF_STEP_LIMIT, VMF_CLAMP_BOUNDS, VMF_BAD_CALL, VMF_BAD_OPCODE, VMF_LOCALS_OVERFLOW,
+    // not a fault of the program: a COMPILED set met a PaletteIndex whose slot is missing or empty (the reference then pushes nothing,
+    // which only the interpreter's dynamic stack can follow) -- rxr_synchronize sends the set back to the interpreter and renders again
+    VMF_JIT_PALETTE_MISS,
 };
 struct DevProgram {
     uint32_t shade_entry;   // word offset of the shade function in vm_code; 0xFFFFFFFF: shade_index is None

@@ -200,6 +200,10 @@ bool analyse(const std::vector<uint32_t> &code, Fn &f, std::string &why) {
                 case RXR_NODE_SWAP: need = 2; break;
                 case VM_GETC: case VM_BINC: need = 1; break;
                 case VM_SETC: case RXR_NODE_SAMPLE: case RXR_NODE_SAMPLE_NORMAL: need = 2; delta = -1; break;
+                // PaletteIndex pops the index and pushes the colour -- unless the slot is missing or empty, when the reference pushes
+                // nothing (execution.rs:742-749).  Compiled as the push; a fragment that meets the other case raises
+                // VMF_JIT_PALETTE_MISS and the whole set goes back to the interpreter (rxr_synchronize), whose stack is dynamic.
+                case RXR_NODE_PALETTE_INDEX: need = 1; break;
                 case RXR_NODE_CLEAR:
                     if (st.depth == 0 && !f.is_shade) { why = "Clear on a callee's empty stack (it would pop the caller's value)"; return false; }
                     delta = st.depth > 0 ? -1 : 0;
@@ -300,6 +304,10 @@ bool emit_body(const std::vector<uint32_t> &code, const DevProgram &p, uint32_t 
                 case RXR_NODE_SET_NORMAL: out += "io.normal = jit_set_normal(" + t0 + ");\n"; break;
                 case RXR_NODE_SAMPLE: out += t1 + " = jit_sample(P, " + t1 + ", " + t0 + ");\n"; break;
                 case RXR_NODE_SAMPLE_NORMAL: out += t1 + " = jit_sample_normal(P, " + t1 + ", " + t0 + ");\n"; break;
+                case RXR_NODE_PALETTE_INDEX:
+                    out += "{ const uint32_t id = as_usize_sat(" + t0 + ".x); if (!(id < P.n_palette && P.palette[4u * id + 3u] != 0.0f)) " + fail(VMF_JIT_PALETTE_MISS) + " " + t0 +
+                           " = mk(P.palette[4u * id], P.palette[4u * id + 1u], P.palette[4u * id + 2u]); }\n";
+                    break;
                 case VM_JMP:
                     if (code[pc + 1] <= pc)  // the only way back: a For loop's closing jump
                         out += "{ if (++steps > " + std::to_string((uint32_t)RXR_VM_MAX_STEPS) + "u) " + fail(VMF_STEP_LIMIT) + " goto L" + std::to_string(code[pc + 1]) + "; }\n";
@@ -752,6 +760,7 @@ extern "C" int rxr_debug_jit_compile_file(const char *src_path, const char *arch
 }
 
 void rxr_jit_drop(rxr_ctx *ctx) {
+    ctx->jit_palette_miss = false;
     for (int k = 0; k < 3; ++k) {
         if (ctx->jit_module[k]) (void)hipModuleUnload((hipModule_t)ctx->jit_module[k]);
         ctx->jit_module[k] = ctx->jit_fn[k] = nullptr;
@@ -906,7 +915,7 @@ bool ensure_level(rxr_ctx *ctx, int slot) {
 
 // the raster launch of a frame whose programs are compiled; false: no compiled kernel (the caller launches the interpreter kernels)
 bool rxr_jit_launch(rxr_ctx *ctx, const RasterParams *P, hipStream_t s) {
-    if (ctx->jit_source.empty() || P->kernel_level < 2u) return false;
+    if (ctx->jit_source.empty() || P->kernel_level < 2u || ctx->jit_palette_miss) return false;
     // RasterParams.kernel_level 4 / 5 (k_raster_vm_sv / _v, template levels 6 / 7): no program of the opaque pass decides
     // visibility (rxr_upload_frame); 2 / 3: one may.  When the frame needs none of the chunk paths either: template level 8.
     const int slot = P->kernel_level >= 4u ? (ctx->frame_needs_chunk_paths ? 1 : 2) : 0;

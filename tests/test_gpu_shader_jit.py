@@ -216,3 +216,37 @@ def test_background_compilation_switches_over_without_changing_a_pixel(product, 
     monkeypatch.setenv("RXR_SHADER_JIT", "0")
     assert np.array_equal(scenes.render(grid_scene(product, [prog])), want)
 
+
+
+def test_palette_index_is_compiled_while_every_index_has_a_colour(oracle, product, monkeypatch):
+    """PaletteIndex -- the one opcode whose stack effect depends on data (a missing or empty slot pushes nothing,
+    rusteria/src/node/execution.rs:742-749) -- used to leave a whole set with the interpreter.  Compiled as the push: this frame only
+    ever asks for slots 0 and 2 of the palette (0.9, 0.1, 0.2), None, (0.2, 0.3, 0.9)."""
+    # (the 2D pass hands uv / 4 to the program: uv.x runs over [0, 0.25) across the rectangle)
+    prog = Program([["UV", ("GetComponents", [0]), ("Push", 7.96), "Mul", "Floor", ("Push", 2.0), "Mul", "PaletteIndex",   # 0 or 2
+                     "UV", ("GetComponents", [1]), "Mul", "Color", ("Push", 0.25), "Mul", "Add", "SetColor"]])
+    plain = Program([S.A + ["Abs"] + S.TO_COLOR])
+    got, info = three_ways(oracle, product, monkeypatch, lambda api: grid_scene(api, [prog, plain]))
+    assert "compiled:" in info
+    assert len(np.unique(got[:, : W // 2].reshape(-1, 4), axis=0)) > 50
+
+
+def test_palette_miss_sends_the_set_back_to_the_interpreter(oracle, product, monkeypatch):
+    """... and a frame that DOES meet the empty slot (index 1 in the middle third of the rectangle: nothing is pushed, the Add consumes
+    the value below instead) cannot be followed by straight-line code: the compiled kernel raises VMF_JIT_PALETTE_MISS, rxr_synchronize
+    hands the set to the interpreter and renders the frame again -- the caller sees the interpreter's frame, this time and afterwards."""
+    prog = Program([[("Push", 0.5, 0.4, 0.3), ("Push", 0.1, 0.2, 0.3), "UV", ("GetComponents", [0]), ("Push", 11.96), "Mul", "PaletteIndex", "Add", "SetColor"]])
+    build = lambda api: grid_scene(api, [prog])  # noqa: E731
+    monkeypatch.setenv("RXR_SHADER_JIT", "0")
+    interp = scenes.render(build(product)).copy()
+    monkeypatch.setenv("RXR_SHADER_JIT", "1")
+    got = scenes.render(build(product)).copy()
+    info = jit_info(product)
+    assert "PaletteIndex" in info and info.startswith("not compiled"), info
+    again = scenes.render(build(product)).copy()   # the same set, uploaded again: compiled again, misses again, falls back again
+    monkeypatch.setenv("RXR_SHADER_JIT", "0")
+    ref = scenes.render(build(oracle))
+    assert np.array_equal(got, interp) and np.array_equal(again, interp)
+    assert np.array_equal(got, ref)
+    # the three thirds differ: colour 0 + (0.1, 0.2, 0.3); nothing pushed, so the Add takes the two constants; colour 2 + (0.1, 0.2, 0.3)
+    assert len({tuple(got[H // 2, x]) for x in (W // 6, W // 2, 5 * W // 6)}) == 3

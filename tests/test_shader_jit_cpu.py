@@ -55,7 +55,7 @@ def test_loops_locals_globals_and_faults_are_generated():
     assert "rxr_jit_prog_1" in src
 
 
-def test_calls_become_functions_and_recursion_or_palette_lookups_are_left_to_the_interpreter():
+def test_calls_become_functions_recursion_is_left_to_the_interpreter_and_palette_lookups_carry_a_way_back():
     helper = [("LoadLocal", 0), ("Push", 2.0), "Mul", "Return"]
     rc, src, msg = generate([Program([["UV", ("FunctionCall", 1, 1, 1), "SetColor"], helper])], 0)
     assert rc == 0, msg
@@ -63,8 +63,11 @@ def test_calls_become_functions_and_recursion_or_palette_lookups_are_left_to_the
     fact = [("LoadLocal", 0), ("Push", 1.0), "Le", ("If", [("Push", 1.0), "Return"], None), ("LoadLocal", 0), ("LoadLocal", 0), ("Push", 1.0), "Sub", ("FunctionCall", 1, 1, 1), "Mul", "Return"]
     rc, _, msg = generate([Program([["UV", ("FunctionCall", 1, 1, 1), "SetColor"], fact])], 0)
     assert rc == B.RXR_ERR_UNSUPPORTED and "recursion" in msg
-    rc, _, msg = generate([Program([["UV", "PaletteIndex", "SetColor"]])], 0)
-    assert rc == B.RXR_ERR_UNSUPPORTED
+    # PaletteIndex (round 3): compiled as the push, with the reference's other case -- a missing or empty slot pushes nothing --
+    # raising VMF_JIT_PALETTE_MISS (12), on which rxr_synchronize hands the set back to the interpreter
+    rc, src, msg = generate([Program([["UV", "PaletteIndex", "SetColor"]])], 0)
+    assert rc == 0, msg
+    assert "P.n_palette" in src and "fault = 12u" in src and "P.palette[4u * id" in src
 
 
 def test_the_background_compiler_is_a_process_that_turns_a_source_file_into_a_code_object(tmp_path):
