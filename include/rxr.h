@@ -199,6 +199,23 @@ typedef struct rxr_batch2d {
     int32_t chunk;
 } rxr_batch2d;
 
+/* Batch2D BEFORE projection: the inputs of Batch2D::project (src/batch/batch2d.rs:373-425) -- the 2D half of the device-side
+ * projection path (rxr_set_meshes2d + rxr_frame.use_meshes bit 1): the geometry is uploaded once, every frame sends the optional
+ * Mat3 (rxr_set_projection2d), and the device applies it, accumulates the bounding box (f32::min / f32::max: NaN dropped),
+ * builds the Edges (src/edge.rs:12-24) and the clamped pixel boxes (src/rasterizer.rs:615-634, :1777-1821). */
+typedef struct rxr_mesh2d {
+    const float *vertices;            /* [n_vertices][2]                                            */
+    const uint32_t *indices;          /* [n_triangles][3]; Lines read .0/.1 only (:902)             */
+    const float *uvs;                 /* [n_vertices][2]                                            */
+    uint32_t n_vertices, n_triangles;
+    uint32_t mode;                    /* RXR_MODE_* */
+    uint32_t repeat_mode;
+    rxr_source source;
+    uint32_t receives_light;
+    int32_t shader;
+    int32_t chunk;
+} rxr_mesh2d;
+
 /* (BBox, occlusion) entry of MapMini.occluded_sectors / Chunk.occluded_sectors
  * (src/map/mini.rs:58-66, src/chunk.rs:154-161, src/map/bbox.rs:35-40) */
 typedef struct rxr_occluder {
@@ -269,7 +286,9 @@ typedef struct rxr_frame {
                                          to a program makes the call return RXR_ERR_UNSUPPORTED     */
     /* device-side projection: when use_meshes != 0 the 3D batches are the meshes
      * registered with rxr_set_meshes (batches3d must then be empty) and are projected on the device
-     * with these matrices, replacing Scene::project's 3D half (src/scene.rs:189-199) */
+     * with these matrices, replacing Scene::project's 3D half (src/scene.rs:189-199).
+     * Bit 1 (value 2, alone or with bit 0): the 2D batches are the meshes registered with rxr_set_meshes2d (batches2d must then be
+     * empty), projected on the device with the matrix of rxr_set_projection2d: Scene::project's 2D half (:163-187) */
     uint32_t use_meshes;
     float view[16];                   /* Rasterizer.view_matrix, :40                               */
     float projection[16];             /* Rasterizer.projection_matrix, :41                         */
@@ -406,6 +425,15 @@ int rxr_set_textures(rxr_ctx *ctx, const rxr_tile *static_tiles, uint32_t n_stat
  * Replaces nothing per frame: it is the one-time hand-over of what Batch3D::clip_and_project reads
  * from `self` (src/batch/batch3d.rs:482-740).  Call again only when geometry or materials change. */
 int rxr_set_meshes(rxr_ctx *ctx, const rxr_mesh3d *meshes, uint32_t n_meshes);
+
+/* The 2D half of the same: registers the object-space 2D batches of a scene (submission order, src/rasterizer.rs:503-552) for
+ * device-side projection; what Batch2D::project reads from `self` (src/batch/batch2d.rs:373-425).  Call again only when geometry
+ * or materials change.  A batch whose texture tile does not exist is refused HERE (the reference panics only when the batch is on
+ * screen: the device does not know that before it has projected it). */
+int rxr_set_meshes2d(rxr_ctx *ctx, const rxr_mesh2d *meshes, uint32_t n_meshes);
+/* the `matrix: Option<Mat3<f32>>` of Batch2D::project for the uploads that follow: nine floats in vek's column-major order
+ * (m[c * 3 + r]), or NULL for None (vertices are used as they are) */
+int rxr_set_projection2d(rxr_ctx *ctx, const float *mat3);
 
 /* debugging / tests: copies the device-projected arrays of mesh `index` (as produced for the last
  * rendered frame) back to the host in the layout of rxr_batch3d.  Any pointer may be NULL.

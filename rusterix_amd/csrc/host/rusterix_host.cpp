@@ -488,6 +488,7 @@ uint64_t g_shaders_gen = 0, g_shader_env_gen = 0;
 bool g_device_projection = false;
 int g_light_math = RXR_LIGHT_MATH_RELAXED;  // the library's default
 uint64_t g_mesh_fingerprint = 0;
+uint64_t g_mesh2d_fingerprint = 0;
 }  // namespace
 
 void set_device_projection(bool on) { g_device_projection = on; }
@@ -506,6 +507,7 @@ void drop_context_locked() {
     if (g_ctx) rxr_destroy(g_ctx);
     g_ctx = nullptr;
     g_mesh_fingerprint = 0;
+    g_mesh2d_fingerprint = 0;
     g_tex_static_gen = g_tex_dynamic_gen = 0;
     g_shaders_gen = g_shader_env_gen = 0;
 }
@@ -665,7 +667,7 @@ int Rasterizer::upload(Scene &scene, size_t w, size_t h, size_t tile_size, const
 
     const bool on_device = g_device_projection;
     if (on_device) {
-        scene.project_2d(has_m2d ? &projection_matrix_2d : nullptr);  // the 3D half runs on the GPU
+        // both halves of Scene::project run on the GPU (rxr_set_meshes / rxr_set_meshes2d below)
     } else {
         const auto tp = std::chrono::steady_clock::now();
         // Large scenes on a plain context: every 3D batch is handed to the device as soon as it is projected (rxr_stream_batch3d) --
@@ -908,6 +910,54 @@ int Rasterizer::upload(Scene &scene, size_t w, size_t h, size_t tile_size, const
     }
     for (const Batch2D &b : scene.d2_static) b2.push_back(view2d(b, -1, slots));
     for (const Batch2D &b : scene.d2_dynamic) b2.push_back(view2d(b, -1, slots));
+    if (on_device) {
+        // the 2D batches in the same order, as object-space meshes; registered again when anything Batch2D::project reads has changed
+        // (2D batches are small: the fingerprint covers their contents)
+        std::vector<rxr_mesh2d> m2;
+        uint64_t fp = 1469598103934665603ull;
+        auto mix = [&](const void *p, size_t n) {
+            const uint8_t *q = (const uint8_t *)p;
+            for (size_t i = 0; i < n; ++i) fp = (fp ^ q[i]) * 1099511628211ull;
+        };
+        auto add2 = [&](const Batch2D &b, int chunk) {
+            rxr_mesh2d m{};
+            m.vertices = b.vertices.data();
+            m.indices = b.indices.data();
+            m.uvs = b.uvs.data();
+            m.n_vertices = (uint32_t)(b.vertices.size() / 2);
+            m.n_triangles = (uint32_t)(b.indices.size() / 3);
+            m.mode = b.mode_;
+            m.repeat_mode = b.repeat_mode_;
+            m.source = slots.resolve(b.source_);
+            m.receives_light = b.receives_light_ ? 1u : 0u;
+            m.shader = b.shader_;
+            m.chunk = chunk;
+            m2.push_back(m);
+            const uint32_t meta[9] = {m.n_vertices, m.n_triangles, m.mode, m.repeat_mode, m.source.kind, m.source.index, m.receives_light, (uint32_t)m.shader, (uint32_t)m.chunk};
+            mix(meta, sizeof(meta));
+            mix(m.source.pixel, 4);
+            mix(b.vertices.data(), b.vertices.size() * 4);
+            mix(b.uvs.data(), b.uvs.size() * 4);
+            mix(b.indices.data(), b.indices.size() * 4);
+        };
+        for (size_t c = 0; c < scene.chunks.size(); ++c) {
+            for (const Batch2D &b : scene.chunks[c].batches2d) add2(b, (int)c);
+            for (const Batch2D &b : scene.chunks[c].terrain_batch2d) add2(b, (int)c);
+        }
+        for (const Batch2D &b : scene.d2_static) add2(b, -1);
+        for (const Batch2D &b : scene.d2_dynamic) add2(b, -1);
+        if (fp != g_mesh2d_fingerprint) {
+            int rc = rxr_set_meshes2d(ctx, m2.data(), (uint32_t)m2.size());
+            if (rc != RXR_OK) {
+                g_error = rxr_last_error(ctx);
+                g_mesh2d_fingerprint = 0;
+                return rc;
+            }
+            g_mesh2d_fingerprint = fp;
+        }
+        (void)rxr_set_projection2d(ctx, has_m2d ? projection_matrix_2d.m : nullptr);
+        b2.clear();
+    }
 
     std::vector<rxr_light> lights(scene.lights);
     lights.insert(lights.end(), scene.dynamic_lights.begin(), scene.dynamic_lights.end());
@@ -955,7 +1005,7 @@ int Rasterizer::upload(Scene &scene, size_t w, size_t h, size_t tile_size, const
     f.n_chunks = (uint32_t)chunks.size();
     f.n_shader_programs = (uint32_t)scene.shaders.size();
     if (on_device) {
-        f.use_meshes = 1;
+        f.use_meshes = 3;  // both halves
         memcpy(f.view, view_matrix.m, 64);
         memcpy(f.projection, projection_matrix.m, 64);
         f.mesh_transforms = mesh_transforms.empty() ? nullptr : mesh_transforms.data();

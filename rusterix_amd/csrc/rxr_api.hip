@@ -450,6 +450,122 @@ int rxr_set_meshes(rxr_ctx *ctx, const rxr_mesh3d *meshes, uint32_t n_meshes) {
     return RXR_OK;
 }
 
+// ---- the 2D half of the device-side projection (row N1): Batch2D::project's inputs, registered once ---------------------------
+extern "C" void rxr_launch_project2d(const Project2DParams *P, hipStream_t s);
+
+int rxr_set_meshes2d(rxr_ctx *ctx, const rxr_mesh2d *meshes, uint32_t n_meshes) {
+    if (!ctx) return RXR_ERR_INVALID;
+    if (n_meshes && !meshes) return fail(ctx, RXR_ERR_INVALID, "rxr_set_meshes2d: NULL mesh array");
+    if (ctx->group) return rxr_group_set_meshes2d(ctx, meshes, n_meshes);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    {
+        int qrc = rxr_quiesce(ctx);
+        if (qrc != RXR_OK) return qrc;
+    }
+    ctx->meshes2d.clear();
+    ctx->has_frame = false;
+    size_t vin = 0, prims = 0, tris = 0;
+    for (uint32_t i = 0; i < n_meshes; ++i) {
+        const rxr_mesh2d &m = meshes[i];
+        if (m.n_vertices && (!m.vertices || !m.uvs)) return fail(ctx, RXR_ERR_INVALID, "mesh2d: NULL vertex arrays");
+        if (m.n_triangles && !m.indices) return fail(ctx, RXR_ERR_INVALID, "mesh2d: NULL indices");
+        if (m.mode > RXR_MODE_LINE_LOOP) return fail(ctx, RXR_ERR_INVALID, "mesh2d: bad mode");
+        if (m.mode == RXR_MODE_TRIANGLES || m.mode == RXR_MODE_LINES)
+            for (size_t t = 0; t < (size_t)m.n_triangles * 3u; ++t) {
+                if (m.mode == RXR_MODE_LINES && (t % 3u) == 2u) continue;  // only .0/.1 are read, :902
+                if (m.indices[t] >= m.n_vertices) return fail(ctx, RXR_ERR_INVALID, "mesh2d: vertex index out of range");
+            }
+        rxr_ctx::HostMesh2D h{};
+        h.vin_base = (uint32_t)vin;
+        h.n_verts = m.n_vertices;
+        h.n_tris = m.n_triangles;
+        switch (m.mode) {
+            case RXR_MODE_TRIANGLES: h.n_prims = m.n_triangles; tris += m.n_triangles; break;
+            case RXR_MODE_LINES: h.n_prims = m.n_triangles; break;
+            case RXR_MODE_LINE_STRIP: h.n_prims = m.n_vertices ? m.n_vertices - 1 : 0; break;
+            default: h.n_prims = m.n_vertices; break;
+        }
+        h.prim_base = (uint32_t)prims;
+        h.mode = m.mode;
+        h.repeat_mode = m.repeat_mode;
+        h.receives_light = m.receives_light;
+        h.source = m.source;
+        h.shader = m.shader;
+        h.chunk = m.chunk;
+        ctx->meshes2d.push_back(h);
+        vin += m.n_vertices;
+        prims += h.n_prims;
+    }
+    if (vin >= (1ull << 31) || prims >= (1ull << 30)) return fail(ctx, RXR_ERR_INVALID, "2D meshes too large");
+    ctx->meshes2d_prims = prims;
+    ctx->meshes2d_tris = tris;
+    size_t o = 0;
+    auto take = [&](size_t bytes) {
+        size_t at = o;
+        o = align_up(o + (bytes ? bytes : 16), 256);
+        return at;
+    };
+    const size_t off_v = take(vin * 8), off_uv = take(vin * 8), off_src = take(prims * sizeof(Prim2DSrc)), off_pv = take((n_meshes + 1) * 4),
+                 off_dm = take((size_t)n_meshes * sizeof(DevMesh2D));
+    const size_t total = o;
+    int rc;
+    if ((rc = ensure_stage(ctx, total)) != RXR_OK) return rc;
+    if ((rc = ensure(ctx, ctx->d_obj2d, total)) != RXR_OK) return rc;
+    uint8_t *st = (uint8_t *)ctx->h_stage;
+    uint32_t *pv = (uint32_t *)(st + off_pv);
+    DevMesh2D *dm = (DevMesh2D *)(st + off_dm);
+    Prim2DSrc *src = (Prim2DSrc *)(st + off_src);
+    for (uint32_t i = 0; i < n_meshes; ++i) {
+        const rxr_mesh2d &m = meshes[i];
+        const rxr_ctx::HostMesh2D &h = ctx->meshes2d[i];
+        pv[i] = h.vin_base;
+        const uint8_t white[4] = {255, 255, 255, 255};
+        dm[i] = DevMesh2D{h.vin_base, h.n_verts, h.mode, pack_px(m.source.kind == RXR_SOURCE_PIXEL ? m.source.pixel : white)};  // :911-915
+        if (m.n_vertices) {
+            memcpy(st + off_v + (size_t)h.vin_base * 8, m.vertices, (size_t)m.n_vertices * 8);
+            memcpy(st + off_uv + (size_t)h.vin_base * 8, m.uvs, (size_t)m.n_vertices * 8);
+        }
+        Prim2DSrc *q = src + h.prim_base;
+        if (m.mode == RXR_MODE_TRIANGLES)
+            for (uint32_t t = 0; t < m.n_triangles; ++t) q[t] = Prim2DSrc{i, m.indices[3 * (size_t)t], m.indices[3 * (size_t)t + 1], m.indices[3 * (size_t)t + 2]};
+        else if (m.mode == RXR_MODE_LINES)
+            for (uint32_t t = 0; t < m.n_triangles; ++t) q[t] = Prim2DSrc{i, m.indices[3 * (size_t)t], m.indices[3 * (size_t)t + 1], 0u};
+        else if (m.mode == RXR_MODE_LINE_STRIP)
+            for (uint32_t k = 0; k + 1 < m.n_vertices; ++k) q[k] = Prim2DSrc{i, k, k + 1u, 0u};
+        else
+            for (uint32_t k = 0; k < m.n_vertices; ++k) q[k] = Prim2DSrc{i, k, (k + 1u) % m.n_vertices, 0u};
+    }
+    pv[n_meshes] = (uint32_t)vin;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_obj2d.p, st, total, hipMemcpyHostToDevice, ctx->stream));
+    o = 0;
+    const size_t m_bbox = take((size_t)n_meshes * sizeof(DevBBox)), m_box = take(16);
+    if ((rc = ensure(ctx, ctx->d_proj2d_misc, o)) != RXR_OK) return rc;
+    Project2DParams &PP = ctx->PP2;
+    memset(&PP, 0, sizeof(PP));
+    PP.n_meshes = n_meshes;
+    PP.n_verts = (uint32_t)vin;
+    PP.n_prims = (uint32_t)prims;
+    uint8_t *d = (uint8_t *)ctx->d_obj2d.p, *mm = (uint8_t *)ctx->d_proj2d_misc.p;
+    PP.meshes = (const DevMesh2D *)(d + off_dm);
+    PP.vin_prefix = (const uint32_t *)(d + off_pv);
+    PP.obj_verts = (const float2 *)(d + off_v);
+    PP.obj_uvs = (const float2 *)(d + off_uv);
+    PP.src = (const Prim2DSrc *)(d + off_src);
+    PP.bbox = (DevBBox *)(mm + m_bbox);
+    PP.d2_box = (uint32_t *)(mm + m_box);
+    PP.bad_line = ctx->d_host_status + HS_BAD_LINE2D;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return RXR_OK;
+}
+
+int rxr_set_projection2d(rxr_ctx *ctx, const float *mat3) {
+    if (!ctx) return RXR_ERR_INVALID;
+    if (ctx->group) return rxr_group_set_projection2d(ctx, mat3);
+    ctx->has_matrix2d = mat3 != nullptr;
+    if (mat3) memcpy(ctx->matrix2d, mat3, sizeof(ctx->matrix2d));
+    return RXR_OK;
+}
+
 int rxr_read_projected_mesh(rxr_ctx *ctx, uint32_t index, uint32_t counts[2], float *projected_vertices, float *clipped_uvs,
                             float *clipped_normals, uint32_t *clipped_indices, rxr_edges *edges, float bounding_box[5],
                             uint32_t capacity_vertices, uint32_t capacity_triangles) {
@@ -861,7 +977,7 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
     // are in the blob already, or on their way.  Anything that does not match -- a batch missing, other arrays than the ones streamed,
     // a failure on the way -- and the frame takes the plain path below from scratch.
     FrameStream &S = ctx->fstream;
-    bool streamed = S.active && !S.failed.load() && !f->use_meshes && f->n_batches3d == S.n && S.handed.load() == S.n;
+    bool streamed = S.active && !S.failed.load() && !(f->use_meshes & 1u) && f->n_batches3d == S.n && S.handed.load() == S.n;
     if (S.active && streamed) {
         std::lock_guard<std::mutex> lk(S.mu);
         streamed = S.next == S.n;
@@ -904,8 +1020,14 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
                                        // that opaque batch must not see it (rasterizer.rs:314-357; found by tools/fuzz_sweep.py)
     size_t n_v3 = 0, n_t3 = 0;
     bool has_opacity = false;
-    const bool use_meshes = f->use_meshes != 0;
+    const bool use_meshes = (f->use_meshes & 1u) != 0;     // the 3D batches are the meshes of rxr_set_meshes
+    const bool use_meshes2d = (f->use_meshes & 2u) != 0;   // the 2D batches are the meshes of rxr_set_meshes2d
+    if (f->use_meshes > 3u) return fail(ctx, RXR_ERR_INVALID, "rxr_upload_frame: use_meshes has unknown bits");
     if (use_meshes && f->n_batches3d) return fail(ctx, RXR_ERR_INVALID, "rxr_upload_frame: use_meshes with batches3d");
+    if (use_meshes2d && f->n_batches2d) return fail(ctx, RXR_ERR_INVALID, "rxr_upload_frame: use_meshes (2D) with batches2d");
+    if (use_meshes2d)
+        for (const rxr_ctx::HostMesh2D &h : ctx->meshes2d)
+            if (h.chunk >= (int32_t)f->n_chunks) return fail(ctx, RXR_ERR_INVALID, "mesh2d: chunk index out of range");
     const uint32_t n_b3 = use_meshes ? (uint32_t)ctx->meshes.size() : f->n_batches3d;
     if (use_meshes)
         for (const HostMesh &h : ctx->meshes) {
@@ -953,6 +1075,11 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
         }
         n_items += 1;
     }
+    if (use_meshes2d) {
+        n_t2 = ctx->meshes2d_tris;
+        n_l2 = ctx->meshes2d_prims - ctx->meshes2d_tris;
+    }
+    const uint32_t n_b2 = use_meshes2d ? (uint32_t)ctx->meshes2d.size() : f->n_batches2d;
     size_t n_occ_total = f->n_occluders;
     // this frame's chunk textures (terrain, baked shader textures): DevTexDesc indices after the resident ones
     struct LocalTex {
@@ -1008,7 +1135,7 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
     L.off_chunks = take(f->n_chunks * sizeof(ChunkRange));
     L.off_tdesc = take((n_res_tex + local_tex.size()) * sizeof(DevTexDesc));
     L.off_ltex = take(local_texels * 4);
-    L.off_b2 = take(f->n_batches2d * sizeof(DevBatch));
+    L.off_b2 = take(n_b2 * sizeof(DevBatch));
     L.off_p2 = take((n_t2 + n_l2) * sizeof(Prim2D));
     (void)n_items;
     L.off_bg = take(f->background_kind == RXR_BG_HOST_PIXELS ? (size_t)f->width * f->height * 4 : 0);
@@ -1366,6 +1493,38 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
         if (x >= (float)hi) return hi;
         return (uint32_t)x;
     };
+    if (use_meshes2d) {
+        // device-projected 2D batches: the headers only -- the box reject, the Edges and the Prim2D records are the device's
+        // (k_proj2d_*, rxr_project.hip); a batch that turns out to be off screen gets empty pixel boxes there
+        for (uint32_t i = 0; i < n_b2; ++i) {
+            const rxr_ctx::HostMesh2D &h = ctx->meshes2d[i];
+            DevBatch d{};
+            d.n_tris = h.n_tris;
+            d.n_verts = h.n_verts;
+            d.mode = h.mode;
+            d.repeat_mode = h.repeat_mode;
+            d.chunk = h.chunk;
+            d.flags = h.receives_light ? DB_RECEIVES_LIGHT : 0u;
+            d.program_plus1 = program_of(h.shader, h.chunk);
+            if (d.program_plus1 && ctx->programs[d.program_plus1 - 1].shade_entry == 0xFFFFFFFFu) d.program_plus1 = 0;
+            if (d.program_plus1) {
+                d.flags |= DB_HAS_PROGRAM;
+                uses_programs = true;
+                reads_2d |= ctx->program_field_reads[d.program_plus1 - 1];
+            }
+            if (h.source.kind == RXR_SOURCE_TERRAIN && h.chunk >= 0 && chunk_terrain[h.chunk] >= 0) {  // :749-751
+                d.tex = chunk_terrain[h.chunk];
+                d.flags |= DB_TERRAIN;
+                uses_chunk_tex = true;
+            } else {
+                rc = resolve_source(ctx, h.source, false, h.chunk, f->animation_frame, d.tex, d.pixel);
+                if (rc != RXR_OK) return fail(ctx, rc, "mesh2d: tile without textures (the reference panics when the batch is on screen)");
+            }
+            b2[i] = d;
+        }
+        p2cur = ctx->meshes2d_prims;
+        t2cur = ctx->meshes2d_tris;
+    }
     for (uint32_t i = 0; i < f->n_batches2d; ++i) {
         const rxr_batch2d &b = f->batches2d[i];
         DevBatch d{};
@@ -1642,13 +1801,14 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
     {
         // tiles outside the union of the 2D pixel boxes skip the 2D pass without touching memory
         uint32_t bx0 = 0xFFFFu, bx1 = 0, by0 = 0xFFFFu, by1 = 0;
-        for (size_t i = 0; i < p2cur; ++i) {
+        for (size_t i = 0; i < (use_meshes2d ? 0 : p2cur); ++i) {  // (device-projected: the records do not exist yet -- d2_box_dev below)
             uint32_t a = p2[i].bx & 0xFFFFu, b = p2[i].bx >> 16, c = p2[i].by & 0xFFFFu, d = p2[i].by >> 16;
             if (a < b && c < d) {
                 bx0 = std::min(bx0, a); bx1 = std::max(bx1, b); by0 = std::min(by0, c); by1 = std::max(by1, d);
             }
         }
         P.d2_box[0] = bx0; P.d2_box[1] = bx1; P.d2_box[2] = by0; P.d2_box[3] = by1;
+        P.d2_box_dev = use_meshes2d ? ctx->PP2.d2_box : nullptr;  // (the device builds these records: their boxes are not known here)
     }
     P.list2d_capacity = ctx->list2d_capacity;
     P.any_lights = f->n_lights ? 1u : 0u;
@@ -1700,6 +1860,15 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
     P.tex = (const DevTexDesc *)(d + L.off_tdesc);
     P.frame_texels = (const uint32_t *)(d + L.off_ltex);
     P.bg_pixels = (const uint32_t *)(d + L.off_bg);
+    ctx->frame_uses_meshes2d = use_meshes2d;
+    if (use_meshes2d) {
+        Project2DParams &PP2 = ctx->PP2;
+        PP2.has_matrix = ctx->has_matrix2d ? 1u : 0u;
+        memcpy(PP2.m, ctx->matrix2d, sizeof(PP2.m));
+        PP2.width = W;
+        PP2.height = H;
+        PP2.out = (Prim2D *)(d + L.off_p2);
+    }
     ctx->frame_uses_meshes = use_meshes;
     if (use_meshes) {
         // the raster pre-pass reads the pools the projection kernels write
@@ -1829,6 +1998,8 @@ static int render_impl(rxr_ctx *ctx, const RenderSpec &spec, void *dev_pixels, h
     // (the pinned status words are never written by the host while launches may be in flight: earlier queued k_scan
     // launches write them; rxr_synchronize clears them once the streams have drained)
     (void)n_bins;
+    // device-projected 2D batches: Batch2D::project + the Prim2D records, before anything reads them
+    if (ctx->frame_uses_meshes2d && P.tiles_y && (P.flags & RXR_FLAG_D2_ACTIVE)) rxr_launch_project2d(&ctx->PP2, s);
     // 2D binning pre-pass (many 2D primitives): count -> scan -> fill; k_raster sorts each tile's list
     const bool prepass2d = P.tiles_y && (P.flags & RXR_FLAG_D2_ACTIVE) && P.binned2d;
     if (prepass2d) {
@@ -2060,6 +2231,10 @@ int rxr_synchronize(rxr_ctx *ctx) {
             hc[HS_VM_FAULT] = 0;
             return fail(ctx, RXR_ERR_INVALID, std::string("shader program fault: ") + (code < sizeof(what) / sizeof(what[0]) ? what[code] : "?"));
         }
+        if (hc[HS_BAD_LINE2D]) {
+            hc[HS_BAD_LINE2D] = 0;
+            return fail(ctx, RXR_ERR_UNSUPPORTED, "batch2d: line end point beyond +-2^30");
+        }
         if (hc[HS_STAIRCASE]) {
             hc[HS_STAIRCASE] = 0;
             return fail(ctx, RXR_ERR_UNSUPPORTED,
@@ -2149,7 +2324,7 @@ int rxr_render_download(rxr_ctx *ctx, uint8_t *pixels) {
     // the 4 Mpixel threshold.
     const RasterParams &P = ctx->P;
     const bool d3 = (P.flags & RXR_FLAG_D3_ACTIVE) != 0;
-    const bool no_lists = !P.binned2d && (!d3 || (P.n_tris3d <= RXR_STAGE_TRIS && ctx->small_mode != 0u)) && !ctx->frame_uses_meshes;
+    const bool no_lists = !P.binned2d && (!d3 || (P.n_tris3d <= RXR_STAGE_TRIS && ctx->small_mode != 0u)) && !ctx->frame_uses_meshes && !ctx->frame_uses_meshes2d;
     const uint32_t H = P.height;
     static const bool no_pipeline = getenv("RXR_NO_DOWNLOAD_PIPELINE") != nullptr;  // A-B runs
     if (!no_lists || no_pipeline || (size_t)P.width * H < (1u << 22)) {

@@ -56,6 +56,7 @@ struct RenderSpec {
 enum : uint32_t {
     HS_VM_FAULT = 2 * CNT_WORDS,        // a non-zero VMF_* code if any fragment's program faulted
     HS_STAIRCASE = 2 * CNT_WORDS + 1,   // != 0: a pixel's opacity staircase (rxr_kernels.hip front_insert) had to drop an entry
+    HS_BAD_LINE2D = 2 * CNT_WORDS + 2,  // != 0: device-projected 2D batches: a visible segment's end point lies beyond +-2^30 (k_proj2d_prims)
     HS_WORDS = 2 * CNT_WORDS + 4,
 };
 // inside a set of CNT_WORDS host words: CNT_ENTRIES = entries of the LAST launch, CNT_OVERFLOW = sticky flag,
@@ -185,6 +186,19 @@ struct rxr_ctx {
     size_t mesh_verts_out = 0, mesh_tris_out = 0;
     size_t pp_off_meshes = 0;  // byte offset of the per-frame DevMesh array inside d_proj_misc
     bool frame_uses_meshes = false;
+    // ... and its 2D half (rxr_set_meshes2d / rxr_set_projection2d)
+    struct HostMesh2D {
+        uint32_t vin_base, n_verts, n_tris, n_prims, prim_base, mode, repeat_mode, receives_light;
+        rxr_source source;
+        int32_t shader, chunk;
+    };
+    std::vector<HostMesh2D> meshes2d;
+    DevBuf d_obj2d, d_proj2d_misc;
+    Project2DParams PP2{};
+    size_t meshes2d_prims = 0, meshes2d_tris = 0;
+    bool has_matrix2d = false;
+    float matrix2d[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    bool frame_uses_meshes2d = false;
 
     // Rusteria programs (rxr_set_shaders)
     DevBuf d_vm_code, d_programs, d_patterns, d_pattern_data, d_palette;
@@ -238,6 +252,8 @@ extern "C" int rxr_render_spec(rxr_ctx *ctx, const RenderSpec &spec, void *dev_p
 void rxr_group_destroy(rxr_ctx *ctx);
 int rxr_group_set_textures(rxr_ctx *ctx, const rxr_tile *static_tiles, uint32_t n_static, const rxr_tile *dynamic_tiles, uint32_t n_dynamic);
 int rxr_group_set_meshes(rxr_ctx *ctx, const rxr_mesh3d *meshes, uint32_t n_meshes);
+int rxr_group_set_meshes2d(rxr_ctx *ctx, const rxr_mesh2d *meshes, uint32_t n_meshes);
+int rxr_group_set_projection2d(rxr_ctx *ctx, const float *mat3);
 int rxr_group_set_shaders(rxr_ctx *ctx, const rxr_shader_set *set);
 int rxr_group_upload_frame(rxr_ctx *ctx, const rxr_frame *frame);
 int rxr_group_render(rxr_ctx *ctx);                          // every member renders its stripes (asynchronous)

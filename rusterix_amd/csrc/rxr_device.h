@@ -216,6 +216,7 @@ struct RasterParams {
     uint32_t n_tris3d, n_batches3d, n_lights, n_occluders, n_linedefs, n_prims2d, any_lights, has_opacity;
     uint32_t binned2d;             // 1: the 2D primitives were binned (n_prims2d > RXR_STAGE_TRIS); 0: implicit ordered list
     uint32_t d2_box[4];            // union of the 2D primitives' pixel boxes: min_x, max_x, min_y, max_y (max exclusive)
+    const uint32_t *d2_box_dev;    // device-projected 2D batches: the same four words, written by k_proj2d_prims (else nullptr)
     uint32_t list2d_capacity;
     uint32_t list_capacity;
     uint32_t fused_small;          // small-scene mode (whole frame <= RXR_STAGE_TRIS triangles): 0 = binned pipeline,

@@ -2608,6 +2608,19 @@ __device__ __forceinline__ uint32_t walk_prims2d(const RasterParams &P, Stage &s
 #define RXR_WAVE_8X8 0
 #endif
 
+// does the union of the 2D primitives' pixel boxes reach this tile?  The box is a launch constant (host-built Prim2D records) or, for
+// device-projected 2D batches, four words k_proj2d_prims has left in memory (a uniform load)
+__device__ __forceinline__ bool d2_box_meets(const RasterParams &P, uint32_t tile_x0, uint32_t tile_y0px) {
+    uint32_t x0, x1, y0, y1;
+    if (P.d2_box_dev) {  // uniform
+        const uint4 b = *reinterpret_cast<const uint4 *>(P.d2_box_dev);
+        x0 = b.x; x1 = b.y; y0 = b.z; y1 = b.w;
+    } else {
+        x0 = P.d2_box[0]; x1 = P.d2_box[1]; y0 = P.d2_box[2]; y1 = P.d2_box[3];
+    }
+    return tile_x0 < x1 && tile_x0 + RXR_TILE_W > x0 && tile_y0px < y1 && tile_y0px + RXR_TILE_H > y0;
+}
+
 // The 2D pass of one tile (rasterizer.rs:501-553), strictly in submission order; the caller has checked that the union of the 2D
 // pixel boxes reaches the tile.  Uses the stage (and s_bin) of the workgroup: every thread of the workgroup must call it.
 template <int X>
@@ -2900,8 +2913,7 @@ __device__ __forceinline__ void raster_tile(const RasterParams &P) {
 
     // rasterizer.rs:501-553, strictly in submission order.  Tiles that no 2D pixel box reaches skip the pass
     // (a primitive only ever writes inside its box: :636-655, :1777-1821)
-    const bool d2_here = (P.flags & RXR_FLAG_D2_ACTIVE) && P.n_prims2d && tile_x0 < P.d2_box[1] && tile_x0 + RXR_TILE_W > P.d2_box[0] &&
-                         tile_y0px < P.d2_box[3] && tile_y0px + RXR_TILE_H > P.d2_box[2];
+    const bool d2_here = (P.flags & RXR_FLAG_D2_ACTIVE) && P.n_prims2d && d2_box_meets(P, tile_x0, tile_y0px);
     if (d2_here) {
         __shared__ uint32_t s_sort[RXR_SORT2D_MAX];  // the gathered candidates of a binned 2D pass
         color = pass2d<X>(P, stage, s_bin, s_sort, RXR_SORT2D_MAX, bin, tile_x0, tile_y0px, px, py, fx, fy, color);
@@ -3061,8 +3073,7 @@ __device__ __forceinline__ void raster_tile_pair(const RasterParams &P) {
         if (P.n_lights) shade3d_lights<X, RL>(P, hit, F);  // wave-uniform call
         uint32_t color = hit ? shade3d_end<X, RL>(F) : pack4(0u, 0u, 0u, 255u);
         const uint32_t tile_yh = tile_y0px + h * RXR_TILE_H;
-        const bool d2_here = (P.flags & RXR_FLAG_D2_ACTIVE) && P.n_prims2d && tile_x0 < P.d2_box[1] && tile_x0 + RXR_TILE_W > P.d2_box[0] &&
-                             tile_yh < P.d2_box[3] && tile_yh + RXR_TILE_H > P.d2_box[2];
+        const bool d2_here = (P.flags & RXR_FLAG_D2_ACTIVE) && P.n_prims2d && d2_box_meets(P, tile_x0, tile_yh);
         if (d2_here) color = pass2d<X>(P, stage, s_bin, reinterpret_cast<uint32_t *>(rl.key), 512u, h ? bin_b : bin_a, tile_x0, tile_yh, px, py, fx, fy, color);
         if (in_frame) {
             const int64_t row = P.compact ? (int64_t)((ty0 + h) * RXR_TILE_H + ly) : (int64_t)py - P.out_base_row;

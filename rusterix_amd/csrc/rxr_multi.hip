@@ -357,6 +357,14 @@ int rxr_group_set_meshes(rxr_ctx *ctx, const rxr_mesh3d *meshes, uint32_t n_mesh
     return run_all(ctx, [&](uint32_t i) { return rxr_set_meshes(ctx->group->members[i], meshes, n_meshes); });
 }
 
+int rxr_group_set_meshes2d(rxr_ctx *ctx, const rxr_mesh2d *meshes, uint32_t n_meshes) {
+    return run_all(ctx, [&](uint32_t i) { return rxr_set_meshes2d(ctx->group->members[i], meshes, n_meshes); });
+}
+
+int rxr_group_set_projection2d(rxr_ctx *ctx, const float *mat3) {
+    return run_all(ctx, [&](uint32_t i) { return rxr_set_projection2d(ctx->group->members[i], mat3); });
+}
+
 int rxr_group_set_shaders(rxr_ctx *ctx, const rxr_shader_set *set) {
     return run_all(ctx, [&](uint32_t i) { return rxr_set_shaders(ctx->group->members[i], set); });
 }

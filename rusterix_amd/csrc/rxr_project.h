@@ -68,3 +68,27 @@ struct ProjectParams {
     uint32_t *mesh_live;          // per mesh and frame: triangle slots in use = originals + appended fans (0 for a rejected mesh);
                                   // the slots behind them are dead: k_proj_edges, k_setup3d and k_fill skip whole workgroups of them
 };
+
+// ---- the 2D half: Batch2D::project (src/batch/batch2d.rs:373-425) + the Prim2D records rxr_upload_frame builds on the host ----------
+struct DevMesh2D {
+    uint32_t vin_base, n_verts;     // into the object-space 2D pools
+    uint32_t mode;                  // RXR_MODE_*
+    uint32_t line_color;            // Lines / LineStrip / LineLoop: the packed colour of every segment (:911-915)
+};
+struct Prim2DSrc {
+    uint32_t mesh;                  // registered 2D mesh = batch index of the frame
+    uint32_t ia, ib, ic;            // mesh-local vertex indices: a triangle's three, a segment's two
+};
+struct Project2DParams {
+    uint32_t n_meshes, n_verts, n_prims, has_matrix;
+    float m[9];                     // vek column-major Mat3 (m[c * 3 + r])
+    float width, height;
+    const DevMesh2D *meshes;
+    const uint32_t *vin_prefix;     // n_meshes + 1
+    const float2 *obj_verts, *obj_uvs;
+    const Prim2DSrc *src;
+    DevBBox *bbox;                  // per mesh and frame
+    struct Prim2D *out;             // the frame blob's Prim2D records
+    uint32_t *d2_box;               // min_x, max_x, min_y, max_y of the non-empty pixel boxes (RasterParams.d2_box_dev)
+    uint32_t *bad_line;             // pinned status word: a segment end point beyond +-2^30 (the host builder refuses the frame)
+};

@@ -486,3 +486,141 @@ extern "C" void rxr_launch_project(const ProjectParams *P, hipStream_t s) {
     if (P->n_tris_in) hipLaunchKernelGGL(k_clip_emit, dim3((P->n_tris_in + 255u) / 256u), dim3(256), 0, s, *P);
     if (P->n_tris_out) hipLaunchKernelGGL(k_proj_edges, dim3((P->n_tris_out + 255u) / 256u), dim3(256), 0, s, *P);
 }
+
+// =================================================================================================
+// The 2D half (row N1): Batch2D::project on the device, and the Prim2D records of the raster kernels' 2D pass built from it
+// (what rxr_upload_frame builds on the host for host-projected batches: same expressions, same order of operations).
+// =================================================================================================
+#include "rxr_device.h"
+namespace {
+// vek Mat3 * Vec3(x, y, 1) (include/rusterix_vek.hpp): first column multiplied, the others accumulated (fused like Mat4 * Vec4)
+__device__ __forceinline__ float2 project2d(const Project2DParams &P, float2 v) {
+    if (!P.has_matrix) return v;
+    float2 o;
+    o.x = madd(P.m[6], 1.0f, madd(P.m[3], v.y, P.m[0] * v.x));
+    o.y = madd(P.m[7], 1.0f, madd(P.m[4], v.y, P.m[1] * v.x));
+    return o;
+}
+__device__ __forceinline__ float dec(uint32_t e) { return __uint_as_float((e & 0x80000000u) ? (e ^ 0x80000000u) : ~e); }
+// `x as usize` after the clamp against the screen (rasterizer.rs:631-634)
+__device__ __forceinline__ uint32_t sat_px(float x, uint32_t hi) {
+    if (!(x > 0.0f)) return 0u;
+    if (x >= (float)hi) return hi;
+    return (uint32_t)x;
+}
+// Rust `x as isize` narrowed to i32 for the Bresenham end points (:1785-1788); false beyond +-2^30
+__device__ __forceinline__ bool to_isize32(float x, int32_t &out) {
+    if (!(x == x)) {
+        out = 0;
+        return true;
+    }
+    if (x <= -1073741824.0f || x >= 1073741824.0f) return false;
+    out = (int32_t)x;
+    return true;
+}
+}  // namespace
+
+extern "C" __global__ void __launch_bounds__(256) k_proj2d_init(Project2DParams P) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < P.n_meshes) {
+        P.bbox[i].min_x = P.bbox[i].min_y = 0xFFFFFFFFu;
+        P.bbox[i].max_x = P.bbox[i].max_y = 0u;
+    }
+    if (i == 0u) {
+        P.d2_box[0] = 0xFFFFu; P.d2_box[1] = 0u; P.d2_box[2] = 0xFFFFu; P.d2_box[3] = 0u;
+    }
+}
+
+// bounding box per batch (batch2d.rs:377-403): min / max of the projected vertices with NaN dropped
+extern "C" __global__ void __launch_bounds__(256) k_proj2d_bbox(Project2DParams P) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const bool active = i < P.n_verts;
+    uint32_t m = 0;
+    float2 p = make_float2(0.0f, 0.0f);
+    if (active) {
+        m = find_mesh_wave(P.vin_prefix, P.n_meshes, i);
+        p = project2d(P, P.obj_verts[i]);
+    }
+    if (__ballot(active)) bbox_add_wave(P.bbox, m, active, p.x, p.y);
+}
+
+extern "C" __global__ void __launch_bounds__(256) k_proj2d_prims(Project2DParams P) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    uint32_t min_x = 0, max_x = 0, min_y = 0, max_y = 0;
+    if (i < P.n_prims) {
+        const Prim2DSrc s = P.src[i];
+        const DevMesh2D M = P.meshes[s.mesh];
+        // the batch-level box reject with pad 0.5 against the whole screen (rasterizer.rs:594-600): Rect {x, y, width = max - min, ..}
+        const DevBBox bb = P.bbox[s.mesh];
+        const float bx = dec(bb.min_x), by = dec(bb.min_y), bw = dec(bb.max_x) - bx, bh = dec(bb.max_y) - by;
+        const float pad = 0.5f;
+        const bool keep = bx < P.width + pad && (bx + bw) > 0.0f - pad && by < P.height + pad && (by + bh) > 0.0f - pad;
+        Prim2D T;
+        __builtin_memset(&T, 0, sizeof(T));
+        if (M.mode == RXR_MODE_TRIANGLES) {
+            const float2 v0 = project2d(P, P.obj_verts[M.vin_base + s.ia]), v1 = project2d(P, P.obj_verts[M.vin_base + s.ib]),
+                         v2 = project2d(P, P.obj_verts[M.vin_base + s.ic]);
+            // Edges::new([v0, v1, v2], [v1, v2, v0]) (batch2d.rs:413-421, edge.rs:17-21)
+            const float px[3] = {v0.x, v1.x, v2.x}, py[3] = {v0.y, v1.y, v2.y}, qx[3] = {v1.x, v2.x, v0.x}, qy[3] = {v1.y, v2.y, v0.y};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                T.ea[k] = qy[k] - py[k];
+                T.eb[k] = px[k] - qx[k];
+                T.ec[k] = qx[k] * py[k] - qy[k] * px[k];
+            }
+            T.v0x = v0.x; T.v0y = v0.y; T.v1x = v1.x; T.v1y = v1.y; T.v2x = v2.x; T.v2y = v2.y;
+            const float2 u0 = P.obj_uvs[M.vin_base + s.ia], u1 = P.obj_uvs[M.vin_base + s.ib], u2 = P.obj_uvs[M.vin_base + s.ic];
+            T.u0 = u0.x; T.v0 = u0.y; T.u1 = u1.x; T.v1 = u1.y; T.u2 = u2.x; T.v2 = u2.y;
+            T.batch_kind = (s.mesh << 2) | 1u;
+            if (keep) {
+                const float min_xf = fminf(v0.x, fminf(v1.x, v2.x)), max_xf = fmaxf(v0.x, fmaxf(v1.x, v2.x));
+                const float min_yf = fminf(v0.y, fminf(v1.y, v2.y)), max_yf = fmaxf(v0.y, fmaxf(v1.y, v2.y));
+                min_x = sat_px(fmaxf(floorf(min_xf), 0.0f), 0xFFFFu);
+                max_x = sat_px(fminf(ceilf(max_xf), P.width), 0xFFFFu);
+                min_y = sat_px(fmaxf(floorf(min_yf), 0.0f), 0xFFFFu);
+                max_y = sat_px(fminf(ceilf(max_yf), P.height), 0xFFFFu);
+            }
+        } else {
+            const float2 a = project2d(P, P.obj_verts[M.vin_base + s.ia]), b = project2d(P, P.obj_verts[M.vin_base + s.ib]);
+            int32_t x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+            const bool ok = to_isize32(a.x, x0) && to_isize32(a.y, y0) && to_isize32(b.x, x1) && to_isize32(b.y, y1);
+            if (keep && !ok) *P.bad_line = 1u;  // (the host builder refuses such a frame: RXR_ERR_UNSUPPORTED at rxr_synchronize)
+            T.v0x = __int_as_float(x0); T.v0y = __int_as_float(y0); T.v1x = __int_as_float(x1); T.v1y = __int_as_float(y1);
+            T.v2x = __uint_as_float(M.line_color);
+            T.batch_kind = (s.mesh << 2) | 2u | 1u;
+            if (keep && ok) {
+                // the walk never leaves the end-point box (the last point is not plotted, :1800)
+                const long long lx0 = min(x0, x1), lx1 = (long long)max(x0, x1) + 1, ly0 = min(y0, y1), ly1 = (long long)max(y0, y1) + 1;
+                const long long W = (long long)P.width, H = (long long)P.height;  // (whole numbers: the frame size)
+                min_x = (uint32_t)min(max(lx0, 0ll), W); max_x = (uint32_t)min(max(lx1, 0ll), W);
+                min_y = (uint32_t)min(max(ly0, 0ll), H); max_y = (uint32_t)min(max(ly1, 0ll), H);
+            }
+        }
+        if (!(min_x < max_x && min_y < max_y)) min_x = max_x = min_y = max_y = 0u;
+        T.bx = min_x | (max_x << 16);
+        T.by = min_y | (max_y << 16);
+        P.out[i] = T;
+    }
+    // union of the non-empty boxes: tiles outside it skip the 2D pass (RasterParams.d2_box_dev)
+    const bool some = min_x < max_x && min_y < max_y;
+    uint32_t a = some ? min_x : 0xFFFFu, b = some ? max_x : 0u, c = some ? min_y : 0xFFFFu, d = some ? max_y : 0u;
+#pragma unroll
+    for (int k = 32; k >= 1; k >>= 1) {
+        a = min(a, (uint32_t)__shfl_xor((int)a, k, 64));
+        b = max(b, (uint32_t)__shfl_xor((int)b, k, 64));
+        c = min(c, (uint32_t)__shfl_xor((int)c, k, 64));
+        d = max(d, (uint32_t)__shfl_xor((int)d, k, 64));
+    }
+    if ((threadIdx.x & 63u) == 0u && a < b && c < d) {
+        atomicMin(&P.d2_box[0], a);
+        atomicMax(&P.d2_box[1], b);
+        atomicMin(&P.d2_box[2], c);
+        atomicMax(&P.d2_box[3], d);
+    }
+}
+
+extern "C" void rxr_launch_project2d(const Project2DParams *P, hipStream_t s) {
+    hipLaunchKernelGGL(k_proj2d_init, dim3((P->n_meshes + 255u) / 256u + 1u), dim3(256), 0, s, *P);
+    if (P->n_verts) hipLaunchKernelGGL(k_proj2d_bbox, dim3((P->n_verts + 255u) / 256u), dim3(256), 0, s, *P);
+    if (P->n_prims) hipLaunchKernelGGL(k_proj2d_prims, dim3((P->n_prims + 255u) / 256u), dim3(256), 0, s, *P);
+}

@@ -46,6 +46,7 @@ struct Caches {
     textures: u64, // fingerprints of what the device currently holds
     shaders: u64,
     meshes: u64,
+    meshes2d: u64,
     /// streaming hand-over (project_streaming): the repacked arrays of the frame's 3D batches, in submission order, as the device
     /// was given them -- device_frame must name exactly these pointers again
     stream: Vec<Repack>,
@@ -121,6 +122,7 @@ pub fn invalidate_device_caches() {
         st.textures = 0;
         st.shaders = 0;
         st.meshes = 0;
+        st.meshes2d = 0;
     }
 }
 
@@ -485,18 +487,8 @@ impl RasterizeHip for Rasterizer {
         self.height = height as f32;
         self.hash_anim = rusterix::hash_u32(scene.animation_frame as u32); // hoisted and made `pub` by the patch (:199-208)
         if device_projection {
-            // the 3D half of Scene::project runs on the device; the 2D half stays here (src/scene.rs:163-187)
-            for chunk in scene.chunks.values_mut() {
-                for b in &mut chunk.batches2d {
-                    b.project(self.projection_matrix_2d);
-                }
-                if let Some(t) = &mut chunk.terrain_batch2d {
-                    t.project(self.projection_matrix_2d);
-                }
-            }
-            for b in scene.d2_static.iter_mut().chain(scene.d2_dynamic.iter_mut()) {
-                b.project(self.projection_matrix_2d);
-            }
+            // both halves of Scene::project run on the device: the 3D batches as rxr_set_meshes, the 2D batches as rxr_set_meshes2d
+            // with this frame's Mat3 (rxr_set_projection2d); nothing is projected here
         } else {
             // a million elements and more: project and hand over batch by batch (RXR_STREAM_UPLOAD=0: the plain sequence)
             let elements: usize = scene.chunks.values().flat_map(|c| c.batches3d.iter().chain(&c.batches3d_opacity)).chain(&scene.d3_static).chain(&scene.d3_dynamic)
@@ -711,7 +703,63 @@ fn device_frame(this: &Rasterizer, scene: &Scene, pixels: &mut [u8], width: usiz
             b3 = batch3d_views(&items3, &repacks, &src3, &header);
         }
 
-        // ---- 2D batches ----
+        // ---- 2D batches on the device (RXR_DEVICE_PROJECTION=1): object-space arrays registered when they change, the Mat3 per frame ----
+        let idx2: Vec<Vec<u32>> = if device_projection {
+            items2.iter().map(|i| i.batch.indices.iter().flat_map(|&(a, bb, c)| [a as u32, bb as u32, c as u32]).collect()).collect()
+        } else {
+            vec![]
+        };
+        if device_projection {
+            let mut h = 1469598103934665603u64;
+            for (i, s) in items2.iter().zip(&src2) {
+                let b = i.batch;
+                for v in [b.vertices.len(), b.indices.len(), b.mode as usize, b.repeat_mode as usize, s.kind as usize, s.index as usize, b.receives_light as usize,
+                          b.shader.map(|x| x + 1).unwrap_or(0), (i.chunk + 1) as usize] {
+                    fnv_usize(&mut h, v);
+                }
+                fnv(&mut h, &s.pixel);
+                fnv(&mut h, as_bytes(&b.vertices)); // 2D batches are small: the whole contents
+                fnv(&mut h, as_bytes(&b.uvs));
+                fnv(&mut h, as_bytes(&b.indices));
+            }
+            if h != st.meshes2d {
+                let m2: Vec<rxr_mesh2d> = items2
+                    .iter()
+                    .zip(&idx2)
+                    .zip(&src2)
+                    .map(|((i, ix), s)| {
+                        let b = i.batch;
+                        rxr_mesh2d {
+                            vertices: b.vertices.as_ptr() as *const f32,
+                            indices: ix.as_ptr(),
+                            uvs: b.uvs.as_ptr() as *const f32,
+                            n_vertices: b.vertices.len() as u32,
+                            n_triangles: b.indices.len() as u32,
+                            mode: b.mode as u32,
+                            repeat_mode: b.repeat_mode as u32,
+                            source: *s,
+                            receives_light: b.receives_light as u32,
+                            shader: b.shader.map(|x| x as i32).unwrap_or(-1),
+                            chunk: i.chunk,
+                        }
+                    })
+                    .collect();
+                if unsafe { rxr_set_meshes2d(ctx, m2.as_ptr(), m2.len() as u32) } != RXR_OK {
+                    st.meshes2d = 0;
+                    return false;
+                }
+                st.meshes2d = h;
+            }
+            // Option<Mat3<f32>> in vek's column-major order (cols[c][r])
+            let m3: Option<[f32; 9]> = this.projection_matrix_2d.map(|m| {
+                let c = m.into_col_array();
+                [c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], c[8]]
+            });
+            unsafe { rxr_set_projection2d(ctx, m3.as_ref().map(|a| a.as_ptr()).unwrap_or(std::ptr::null())) };
+        }
+
+        // ---- 2D batches (host-projected; none when the device projects them) ----
+        let items2: Vec<Item2D> = if device_projection { vec![] } else { items2 };
         let repacks2: Vec<Repack> = items2
             .iter()
             .map(|i| Repack {
@@ -838,7 +886,7 @@ fn device_frame(this: &Rasterizer, scene: &Scene, pixels: &mut [u8], width: usiz
             chunks: chunks.as_ptr(),
             n_chunks: chunks.len() as u32,
             n_shader_programs: scene.shaders.len() as u32,
-            use_meshes: device_projection as u32,
+            use_meshes: if device_projection { 3 } else { 0 }, // bit 0: the 3D batches, bit 1: the 2D batches are registered meshes
             view: if device_projection { mat4_cols(&this.view_matrix) } else { [0.0; 16] },
             projection: if device_projection { mat4_cols(&this.projection_matrix) } else { [0.0; 16] },
             mesh_transforms: if device_projection && !mesh_transforms.is_empty() { mesh_transforms.as_ptr() } else { std::ptr::null() },

@@ -162,3 +162,91 @@ def test_missing_normals_is_an_error(product, devproj):
     with pytest.raises(B.RasterizeError) as e:
         product.Rasterizer.setup(None, v, p).rasterize(scene, out, 64, 64, 16, product.Assets.default())
     assert e.value.code == B.RXR_ERR_INVALID
+
+
+# ---- the 2D half of row N1: Batch2D::project (src/batch/batch2d.rs:373-425) and the 2D primitive records on the device ----------------
+def _2d_cases():
+    from tests.test_gpu_parity import lines_scene, scene_2d
+
+    def with_matrix(api):
+        cfg = scene_2d(api)
+        m = B.Mat3.from_rows([[1.5, 0.0, 12.0], [0.0, 1.5, -8.0], [0.0, 0.0, 1.0]])
+
+        def setup():
+            v, p = api.D3OrbitCamera.new().matrices(float(cfg.width), float(cfg.height))
+            return api.Rasterizer.setup(m, v, p).render_mode(B.RenderMode.render_2d()).ambient((1.0, 1.0, 1.0, 1.0))
+
+        cfg.setup = setup
+        return cfg
+
+    def rotated(api):
+        cfg = lines_scene(api)
+        m = B.Mat3.from_rows([[0.8, -0.6, 40.0], [0.6, 0.8, -20.0], [0.0, 0.0, 1.0]])  # a rotation: both columns of the product matter
+
+        def setup():
+            v, p = api.D3OrbitCamera.new().matrices(float(cfg.width), float(cfg.height))
+            return api.Rasterizer.setup(m, v, p).render_mode(B.RenderMode.render_2d()).background((5, 5, 5, 255))
+
+        cfg.setup = setup
+        return cfg
+
+    return {
+        "rectangles": lambda api: scene_2d(api),
+        "rectangles, lights + linedef + occluder": lambda api: scene_2d(api, ambient=(0.5, 0.5, 0.5, 1.0), lights=True, linedef=True),
+        "rectangles, ragged frame": lambda api: scene_2d(api, width=203, height=77),
+        "rectangles under a Mat3": with_matrix,
+        "lines, strips and loops": lambda api: lines_scene(api),
+        "lines under a rotation": rotated,
+        "tile map (binned 2D pass)": lambda api: scenes.tile_map_2d_scene(api, width=640, height=400, nx=30, ny=20),
+        "tile map, stacked": lambda api: scenes.tile_map_2d_scene(api, width=400, height=250, nx=20, ny=12, stacked=3),
+        "map scene: a 2D logo over the 3D frame": lambda api: scenes.map_scene(api, width=400, height=250, logo_size=64, n_lights=2),
+    }
+
+
+@pytest.mark.parametrize("name", list(_2d_cases()))
+def test_2d_batches_projected_on_the_device(oracle, product, devproj, name):
+    """the registered object-space 2D batches + the frame's Mat3 give the frame the host-projected batches give: bit for bit (2D is
+    integer / exact), against the oracle and against the host-projected GPU frame; a second frame reuses the registration"""
+    build = _2d_cases()[name]
+    ref = scenes.render(build(oracle)).copy()
+    devproj.off()
+    host = scenes.render(build(product)).copy()
+    devproj.on()
+    cfg = build(product)
+    dev = scenes.render(cfg).copy()
+    dev2 = scenes.render(cfg).copy()
+    devproj.off()
+    lit3d = "map scene" in name   # (its 3D part is lit: +-1 against the oracle, identical between the two GPU paths)
+    assert np.array_equal(dev, host), f"{name}: device- and host-projected frames differ in {(dev != host).any(axis=2).sum()} pixels"
+    assert np.array_equal(dev2, dev)
+    if lit3d:
+        assert int(np.abs(dev.astype(np.int16) - ref.astype(np.int16)).max()) <= 1
+    else:
+        assert np.array_equal(dev, ref), f"{name}: {(dev != ref).any(axis=2).sum()} pixels differ from the oracle"
+    assert (dev[..., :3].max(axis=2) > 0).mean() > 0.02
+
+
+def test_2d_line_end_points_out_of_range_are_refused_like_on_the_host(product, devproj):
+    """a visible segment whose projected end point lies beyond +-2^30 (the Bresenham walk would not end in a frame's time): the host
+    builder refuses the frame at upload, the device sets a status word and rxr_synchronize answers RXR_ERR_UNSUPPORTED"""
+    def build(api):
+        v = np.array([[10.0, 10.0], [3.0e9, 40.0]], np.float32)
+        lines = api.Batch2D.new(v, np.array([[0, 1, 0]], np.uint32), np.zeros_like(v)).mode(B.MODE_LINES).source(B.PixelSource.Pixel((255, 0, 0, 255)))
+        scene = api.Scene.from_static([lines], [])
+
+        def setup():
+            v_, p_ = api.D3OrbitCamera.new().matrices(160.0, 96.0)
+            return api.Rasterizer.setup(None, v_, p_).render_mode(B.RenderMode.render_2d())
+
+        return scenes._result(api, scene, api.Assets.default(), setup, 160, 96, 40, "far line")
+
+    for on in (False, True):
+        (devproj.on if on else devproj.off)()
+        with pytest.raises(B.RasterizeError) as e:
+            scenes.render(build(product))
+        assert e.value.code == B.RXR_ERR_UNSUPPORTED and "2^30" in str(e.value), str(e.value)
+    devproj.off()
+    # and the context renders the next frame
+    from tests.test_gpu_parity import scene_2d
+
+    assert scenes.render(scene_2d(product)).any()
