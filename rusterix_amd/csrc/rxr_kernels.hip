@@ -1978,7 +1978,10 @@ __device__ __forceinline__ bool fragment_alpha_is_255_full(const RasterParams &P
     else return fragment_alpha_is_255_call<X>(P, shade, batch, alpha, beta, z, fx, fy);
 }
 
-template <bool OPACITY, int X>
+// ASC: the caller walks its candidates in ascending submission index from a fresh Vis, so a tie in z can never go to the candidate
+// (the reference's strict `z < z_buffer`, :1060, in submission order); LEAN: the caller recovers the winner's slot and batch from
+// vis.best after its walk (scan_implicit: slot == index, the record is still staged) -- two selects fewer per candidate
+template <bool OPACITY, int X, bool ASC = false, bool LEAN = false>
 __device__ __forceinline__ void visit(const RasterParams &P, const TriSetup &S, const TriShade *shade, uint32_t t, uint32_t slot,
                                       uint32_t px, uint32_t py, float fx, float fy, Vis &vis, int surf_profile, const Vis *opf) {
     uint32_t min_x = S.bx & 0xFFFFu, max_x = S.bx >> 16, min_y = S.by & 0xFFFFu, max_y = S.by >> 16;
@@ -2008,7 +2011,7 @@ __device__ __forceinline__ void visit(const RasterParams &P, const TriSetup &S, 
     bary_depth(S.v0x, S.v0y, S.v1x, S.v1y, S.v2x, S.v2y, S.area, S.iz0, S.iz1, S.iz2, fx, fy, alpha, beta, z);
     const float gamma = 1.0f - alpha - beta;
     if constexpr (OPACITY && lvl1<X>) front_insert(vis, z, (int)t, (S.bflags & DB_HAS_PROFILE) ? (int)S.profile_id : -1, (int)(S.bflags >> DB_GROUP_SHIFT), P.staircase_overflow);
-    bool take = z < vis.zmin || (z == vis.zmin && vis.best >= 0 && (int)t < vis.best);
+    bool take = z < vis.zmin || (!ASC && z == vis.zmin && vis.best >= 0 && (int)t < vis.best);
     if (take) {
         if (lvl1<X> && !OPACITY && (S.bflags & DB_FULL_ALPHA)) {  // frames with such batches run k_raster_chunk / k_raster_vm (RasterParams.kernel_level)
             take = fragment_alpha_is_255_full<X>(P, shade, S.batch, alpha, beta, z, fx, fy);
@@ -2027,8 +2030,29 @@ __device__ __forceinline__ void visit(const RasterParams &P, const TriSetup &S, 
     vis.best = take ? (int)t : vis.best;
     vis.alpha = take ? alpha : vis.alpha;
     vis.beta = take ? beta : vis.beta;
-    vis.slot = take ? slot : vis.slot;
-    vis.batch = take ? S.batch : vis.batch;
+    if constexpr (!LEAN) {
+        vis.slot = take ? slot : vis.slot;
+        vis.batch = take ? S.batch : vis.batch;
+    }
+}
+
+// visit() for a candidate the tile-level classification has found to be COVERING and PLAIN (tile_inside_edges below; no opacity list,
+// profile, cut-out or program-decided alpha): every pixel of the tile is inside its pixel box and passes its three edge functions, and
+// none of the per-batch rules applies -- what is left of visit() is the depth of the fragment and the strict compare.  The same
+// expressions in the same order: the same floats.
+template <bool ASC, bool LEAN>
+__device__ __forceinline__ void visit_cover(const TriSetup &S, uint32_t t, uint32_t slot, float fx, float fy, Vis &vis) {
+    float alpha, beta, z;
+    bary_depth(S.v0x, S.v0y, S.v1x, S.v1y, S.v2x, S.v2y, S.area, S.iz0, S.iz1, S.iz2, fx, fy, alpha, beta, z);
+    const bool take = z < vis.zmin || (!ASC && z == vis.zmin && vis.best >= 0 && (int)t < vis.best);
+    vis.zmin = take ? z : vis.zmin;
+    vis.best = take ? (int)t : vis.best;
+    vis.alpha = take ? alpha : vis.alpha;
+    vis.beta = take ? beta : vis.beta;
+    if constexpr (!LEAN) {
+        vis.slot = take ? slot : vis.slot;
+        vis.batch = take ? S.batch : vis.batch;
+    }
 }
 
 // Exact trivial reject of a triangle for a whole tile: Edges::evaluate computes r = (a*x + b*y) + c per
@@ -2047,6 +2071,36 @@ __device__ __forceinline__ bool tile_outside_edges(const float *ea, const float 
         if (r < 0.0f) return true;
     }
     return false;
+}
+
+// The converse: Edges::evaluate accepts EVERY pixel centre of the tile.  Over the tile r = (a*x + b*y) + c is smallest at the corner
+// that minimises a*x and b*y separately (the same monotonicity); if that corner's r -- the same expression -- is a number >= 0,
+// every other pixel's r is a number at least as large, or NaN (an overflowed product meeting an opposite infinity), and `r < 0`
+// rejects neither.  A NaN at the corner itself proves nothing: not covering.
+__device__ __forceinline__ bool tile_inside_edges(const float *ea, const float *eb, const float *ec, uint32_t tile_x0, uint32_t tile_y0px,
+                                                  uint32_t th = RXR_TILE_H) {
+    const float x_lo = (float)tile_x0 + 0.5f, x_hi = (float)(tile_x0 + RXR_TILE_W - 1u) + 0.5f;
+    const float y_lo = (float)tile_y0px + 0.5f, y_hi = (float)(tile_y0px + th - 1u) + 0.5f;
+    bool inside = true;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float xm = ea[i] >= 0.0f ? x_lo : x_hi;
+        const float ym = eb[i] >= 0.0f ? y_lo : y_hi;
+        const float r = ea[i] * xm + eb[i] * ym + ec[i];
+        inside = inside && (r >= 0.0f);
+    }
+    return inside;
+}
+#ifndef RXR_COVER_FAST
+#define RXR_COVER_FAST 1
+#endif
+#define RXR_COVER_BIT 0x80000000u
+// candidate R of the opaque pass, already known to meet the tile: covering and plain (visit_cover)?
+__device__ __forceinline__ bool covers_plainly(const TriSetup &R, uint32_t tile_x0, uint32_t tile_y0px) {
+    if (R.bflags & (DB_OPACITY_LIST | DB_HAS_PROFILE | DB_ALPHA_TEST | DB_FULL_ALPHA)) return false;
+    const uint32_t min_x = R.bx & 0xFFFFu, max_x = R.bx >> 16, min_y = R.by & 0xFFFFu, max_y = R.by >> 16;
+    if (!(min_x <= tile_x0 && max_x >= tile_x0 + RXR_TILE_W && min_y <= tile_y0px && max_y >= tile_y0px + RXR_TILE_H)) return false;
+    return tile_inside_edges(R.ea, R.eb, R.ec, tile_x0, tile_y0px);
 }
 
 // LDS staging area of one workgroup: candidate triangle records of the current round
@@ -2468,13 +2522,23 @@ __device__ __forceinline__ void scan_implicit(const RasterParams &P, Stage &st, 
         if (w < wave) off += c;
         n += c;
     }
-    if (keep) st.ids[off + before] = tid;
+    // (the survivors keep their order: the walk below is in ascending submission index)
+    bool cover = false;
+    if constexpr (!OPACITY && RXR_COVER_FAST) {
+        if (keep) cover = covers_plainly(*reinterpret_cast<const TriSetup *>(&st.tri[tid * 6u]), tile_x0, tile_y0px);
+    }
+    if (keep) st.ids[off + before] = tid | (cover ? RXR_COVER_BIT : 0u);
     __syncthreads();
     for (uint32_t k = 0; k < n; ++k) {
-        const uint32_t t = st.ids[k];
+        const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.ids[k]);  // (uniform: branches and addresses on the scalar unit)
+        const uint32_t t = e & ~RXR_COVER_BIT;
         const TriSetup &S = *reinterpret_cast<const TriSetup *>(&st.tri[t * 6u]);
-        visit<OPACITY, X>(P, S, &P.tri_shade[t], t, t, px, py, fx, fy, vis, surf_profile, opf);
+        if (e & RXR_COVER_BIT) visit_cover<true, true>(S, t, t, fx, fy, vis);
+        else visit<OPACITY, X, true, true>(P, S, &P.tri_shade[t], t, t, px, py, fx, fy, vis, surf_profile, opf);
     }
+    // (LEAN: slot == index in this path, and the winner's record is still staged)
+    vis.slot = (uint32_t)max(vis.best, 0);
+    vis.batch = reinterpret_cast<const TriSetup *>(&st.tri[vis.slot * 6u])->batch;
     __syncthreads();  // the stage is reused (second pass, 2D pass)
 }
 

@@ -90,7 +90,7 @@ class StripeGather:
     """
 
     def __init__(self, height: int, width: int, world: int, rank: int, device, nbuf: int = 2, mode: str = "gather", root: int = 0,
-                 host_staged: bool = False, comms: int = 1, bucket: int = 1, groups=None):
+                 host_staged: bool = False, comms: int = 1, bucket: int = 1, groups=None, self_collective: bool = False):
         import torch
         import torch.distributed as dist
 
@@ -101,11 +101,15 @@ class StripeGather:
         # Every rank creates the groups in the same order and issues exchange i's collective on the same group: the order the
         # backend needs.  `groups` hands in communicators made earlier (bench.py times several exchange variants in one run and
         # creates every communicator once).  Untested on xGMI hardware (no multi-GPU box in this build environment).
+        # self_collective: with world == 1 the exchange is a local copy; this flag sends it through the backend's collectives all the
+        # same (a one-rank communicator) -- the only way a one-GPU box can execute the RCCL calls of the N > 1 path at all
+        # (tests/test_gpu_rccl_self.py: two ranks on one device are refused by RCCL)
         assert comms >= 1 and bucket >= 1
+        self.self_collective = bool(self_collective) and world == 1
         if groups is not None:
             self.groups = list(groups)
         else:
-            self.groups = [None] if comms == 1 or world == 1 else [dist.new_group(list(range(world))) for _ in range(comms)]
+            self.groups = [None] if comms == 1 or (world == 1 and not self.self_collective) else [dist.new_group(list(range(world))) for _ in range(comms)]
 
         assert mode in ("gather", "allgather", "rotate")
         self.h, self.w, self.world, self.rank, self.mode, self.root = height, width, world, rank, mode, root
@@ -165,7 +169,7 @@ class StripeGather:
         import torch.distributed as dist
 
         b = i % self.nbuf
-        if self.world == 1:
+        if self.world == 1 and not self.self_collective:
             self.gathered[b][0].copy_(self._bands[b])
         elif self.host_staged:
             import torch
