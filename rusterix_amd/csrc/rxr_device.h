@@ -77,7 +77,9 @@ struct TriSetup {
 };
 static_assert(sizeof(TriSetup) == 96, "TriSetup is staged through LDS as 6 x 16 B");
 // candidates staged per round in k_raster (LDS: RXR_STAGE_TRIS * 96 B)
+#ifndef RXR_STAGE_TRIS
 #define RXR_STAGE_TRIS 128
+#endif
 // frames of at most this many triangles carry a (batch, vert_base) pair per triangle (RasterParams.tri_info)
 #define RXR_TRI_INFO_MAX 16384u
 
@@ -102,7 +104,9 @@ struct Prim2D {
 };
 static_assert(sizeof(Prim2D) == 96, "Prim2D is staged through LDS as 6 x 16 B");
 // most primitives a tile may list before k_raster falls back to walking all of them (LDS sort capacity)
+#ifndef RXR_SORT2D_MAX
 #define RXR_SORT2D_MAX 1024
+#endif
 
 // what one k_scan launch works on (the 3D bins and the 2D bins use the same kernel)
 struct ScanArgs {
