@@ -2799,6 +2799,25 @@ __device__ __forceinline__ uint32_t pass2d(const RasterParams &P, Stage &stage, 
 }
 
 // LDS of the fused instantiation only
+// Measurement knobs (0 in every product build): N useless full-rate VALU instructions per wave in front of the light loop
+// (RXR_PAD_VALU) or in front of the visibility scan (RXR_PAD_VALU_EARLY).  A kernel bound by VALU issue pays their issue cycles, one
+// bound by latency does not: profiles/r03/bench_kernel_experiments.txt.
+#ifndef RXR_PAD_VALU
+#define RXR_PAD_VALU 0
+#endif
+#ifndef RXR_PAD_VALU_EARLY
+#define RXR_PAD_VALU_EARLY 0
+#endif
+template <int N>
+__device__ __forceinline__ void valu_pad(float &carrier) {
+    if constexpr (N > 0) {
+        float pad = carrier;
+#pragma unroll
+        for (int i = 0; i < N; ++i) asm volatile("v_add_f32 %0, %0, %0" : "+v"(pad));
+        carrier = (pad != pad) ? pad : carrier;
+    }
+}
+
 template <bool F>
 struct ShadeStore {
     StageShade s;
@@ -2920,6 +2939,7 @@ __device__ __forceinline__ void raster_tile(const RasterParams &P) {
         }
         Vis vis;
         vis.zmin = 1.0f; vis.best = -1; vis.alpha = 0.0f; vis.beta = 0.0f; vis.slot = 0; vis.batch = 0;
+        valu_pad<RXR_PAD_VALU_EARLY>(vis.alpha);
         TriShade HS;     // shading record of the winner
         int hs_of = -1;  // triangle whose record HS already holds (row mode fetches it early)
         PHASE_MARK(0);
@@ -2952,6 +2972,7 @@ __device__ __forceinline__ void raster_tile(const RasterParams &P) {
             shade3d_begin<X, RL>(P, HS, vis.batch, vis.alpha, vis.beta, vis.zmin, fx, fy, F);
         }
         PHASE_MARK(2);
+        valu_pad<RXR_PAD_VALU>(F.rough);
         if (P.n_lights) shade3d_lights<X, RL>(P, hit, F);  // wave-uniform call
         PHASE_MARK(3);
         color = hit ? shade3d_end<X, RL>(F) : pack4(0u, 0u, 0u, 255u);
