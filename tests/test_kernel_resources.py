@@ -45,8 +45,10 @@ def test_k_raster_keeps_its_registers(isa, k_raster):
     assert descriptor(isa, k_raster, "private_segment_fixed_size") <= 16
     spills = len(re.findall(r"v_(?:writelane|readlane)_b32", kernel_body(isa, k_raster)))
     # 17 with the parameter block read in place, 369 by value; 85 since the light records live in SGPRs (scalar loads through the
-    # constant address space, 22 dwords per light): 55 of them outside every loop, none inside the 3D light loop
-    assert spills <= 100, f"{spills} SGPR spill / reload instructions in {k_raster}"
+    # constant address space, 22 dwords per light): 55 of them outside every loop, none inside the 3D light loop; 104 since the
+    # implicit-list walk classifies covering candidates (a scalar entry word and one more uniform branch per candidate; A-B neutral in
+    # time, profiles/r03/bench_kernel_experiments.txt)
+    assert spills <= 110, f"{spills} SGPR spill / reload instructions in {k_raster}"
     assert "v_pk_fma_f32" not in kernel_body(isa, k_raster), "packed f32 (SLP vectorisation) is slower on gfx950: build with -fno-slp-vectorize"
 
 
