@@ -97,9 +97,10 @@ def main():
         W, H = cfg.width, cfg.height
         out = np.zeros((H, W, 4), np.uint8)
         # end-to-end: Rasterizer::setup(..).rasterize(..) = host projection + upload + kernels + download
-        scenes.render(cfg, out.reshape(-1))  # warm-up (also uploads the textures)
+        for _ in range(3):  # warm-up (uploads the textures; the page-locked pools of the host mirror and the library reach their size)
+            scenes.render(cfg, out.reshape(-1))
         e2e = []
-        for _ in range(max(3, args.frames // 5)):
+        for _ in range(max(5, args.frames // 3)):
             t0 = time.perf_counter()
             scenes.render(cfg, out.reshape(-1))
             e2e.append(time.perf_counter() - t0)
