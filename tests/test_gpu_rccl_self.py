@@ -21,7 +21,10 @@ CHILD = textwrap.dedent('''
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ.setdefault("MASTER_PORT", "29631")
+    import socket
+    with socket.socket() as _s:  # a free port (the rendezvous of a one-rank group still binds one)
+        _s.bind(("127.0.0.1", 0))
+        os.environ["MASTER_PORT"] = str(_s.getsockname()[1])
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0), timeout=datetime.timedelta(seconds=120))
     import rusterix_amd

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """One-off wide sweep of the seeded scene generators of tests/ (GPU against the oracle), far more seeds than the test suite
-runs.  usage: python tools/fuzz_sweep.py [first_seed] [n_seeds]"""
+runs.  usage: python tools/fuzz_sweep.py [first_seed] [n_seeds] [--device-projection]
+--device-projection: the product projects on the device (row N1: Batch3D::clip_and_project and Batch2D::project as kernels); the
+oracle always projects on the host"""
 import os
 import sys
 
@@ -17,8 +19,15 @@ from tests import test_gpu_rows as R  # noqa: E402
 from tests import test_gpu_shaders as S  # noqa: E402
 
 prod, orc = rusterix_amd.load(), load_oracle()
-first = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
-n = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+DEVPROJ = "--device-projection" in sys.argv
+argv = [a for a in sys.argv if not a.startswith("--")]
+first = int(argv[1]) if len(argv) > 1 else 1000
+n = int(argv[2]) if len(argv) > 2 else 100
+if DEVPROJ:
+    import ctypes as C
+
+    prod.lib.rxh_set_device_projection.argtypes = [C.c_int]
+    prod.lib.rxh_set_device_projection(1)
 bad = []
 refused = []
 
@@ -66,7 +75,7 @@ for s in range(first, first + n):
         check(("tile-map-2d", s), scenes.render(scenes.tile_map_2d_scene(prod, **kw)), scenes.render(scenes.tile_map_2d_scene(orc, **kw)), 0, 0)
     if (s - first) % 20 == 19:
         print(f"... {s - first + 1} seeds, {len(bad)} failures so far", flush=True)
-print("seeds", first, "..", first + n - 1, "failures:", len(bad), "refused frames / programs:", len(refused), refused[:4])
+print("device projection" if DEVPROJ else "host projection", "seeds", first, "..", first + n - 1, "failures:", len(bad), "refused frames / programs:", len(refused), refused[:4])
 for b in bad[:20]:
     print("  ", b)
 sys.exit(1 if bad else 0)
