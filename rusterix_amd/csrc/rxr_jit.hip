@@ -148,13 +148,14 @@ const char *field_of(uint32_t op, bool &is_set) {
 // The same abstract interpretation as tag_static_depths (rxr_api.hip), with calls: a call needs its `arity` arguments on the
 // caller's own part of the stack, pops them and leaves one value.  A function that could touch the stack BELOW its entry depth --
 // Dup / Clear / Return at relative depth 0 (they look at the absolute depth: the reference shares one stack between caller and
-// callee) -- is left to the interpreter, as is recursion.  Depths live in a side table: the code words are not touched.
+// callee) -- is left to the interpreter.  (Recursion: generate_program_levels.)  Depths live in a side table: the code words are not touched.
 struct Call {
     uint32_t pc, target, arity, total;
 };
 struct Fn {
     uint32_t entry = 0, arity = 0, total = 0;   // (`shade`: arity 0, total = shade_locals)
     bool is_shade = false;
+    int level = -1;                             // recursive programs (generate_program_levels): the call depth this copy runs at, else -1
     std::vector<int> depth;                     // per pc, -1: unreachable
     int max_depth = 0;
     std::vector<Call> calls;
@@ -250,7 +251,8 @@ bool analyse(const std::vector<uint32_t> &code, Fn &f, std::string &why) {
 
 std::string fn_name(uint32_t prog, const Fn &f) {
     return f.is_shade ? "rxr_jit_prog_" + std::to_string(prog)
-                      : "rxr_jit_fn_" + std::to_string(prog) + "_" + std::to_string(f.entry) + "_" + std::to_string(f.arity) + "_" + std::to_string(f.total);
+                      : "rxr_jit_fn_" + std::to_string(prog) + "_" + std::to_string(f.entry) + "_" + std::to_string(f.arity) + "_" + std::to_string(f.total) +
+                            (f.level >= 0 ? "_L" + std::to_string(f.level) : std::string());
 }
 
 // the body of one function: the reachable instructions in address order, each under its label
@@ -332,6 +334,20 @@ bool emit_body(const std::vector<uint32_t> &code, const DevProgram &p, uint32_t 
                     std::string args;
                     for (uint32_t i = 0; i < arity; ++i) args += ", " + slot(d - (int)arity + (int)i);  // local i = the i-th argument pushed
                     const std::string res = slot(d - (int)arity);
+                    if (f.level >= 0) {
+                        // a recursive program: this copy runs with f.level frames on the interpreter's frame stack and calls the copy
+                        // one level up; the checks the acyclic form makes per call chain at generation time are the interpreter's
+                        // own here, in its order (rxr_vm.h VM_CALL): frames, steps, locals
+                        if (f.level >= (int)RXR_VM_FRAMES) {
+                            out += fail(VMF_CALL_DEPTH) + "\n";
+                            break;
+                        }
+                        callee.level = f.level + 1;
+                        out += "{ if (++steps > " + std::to_string((uint32_t)RXR_VM_MAX_STEPS) + "u) " + fail(VMF_STEP_LIMIT) + " if (lbase + " + std::to_string(n_locals + total) +
+                               "u > " + std::to_string((uint32_t)RXR_VM_LOCALS) + "u) " + fail(VMF_LOCALS_OVERFLOW) + " const v3 r = " + fn_name(prog, callee) +
+                               "(P, io, G, fault, steps, lbase + " + std::to_string(n_locals) + "u" + args + "); if (fault) " + leave + " " + res + " = r; }\n";
+                        break;
+                    }
                     out += "{ if (++steps > " + std::to_string((uint32_t)RXR_VM_MAX_STEPS) + "u) " + fail(VMF_STEP_LIMIT) + " const v3 r = " + fn_name(prog, callee) +
                            "(P, io, G, fault, steps" + args + "); if (fault) " + leave + " " + res + " = r; }\n";
                     break;
@@ -342,6 +358,91 @@ bool emit_body(const std::vector<uint32_t> &code, const DevProgram &p, uint32_t 
         if (op == VM_ENDFN) break;  // (the end of this function; what follows belongs to other functions)
         pc += len - 1;
     }
+    return true;
+}
+
+// A program whose functions call themselves (directly or around a cycle).  The interpreter bounds every call chain by its frame stack
+// (RXR_VM_FRAMES), so recursion unrolls into a FINITE acyclic program: one copy of a function per call depth it can run at, a call
+// in the copy of depth L going to the callee's copy of depth L + 1, and a call in a copy of the last depth being the fault the
+// interpreter raises there (VMF_CALL_DEPTH).  No device-side recursion, no dynamic stack: the compiler sees an acyclic call graph
+// and sizes registers and scratch as for any other program.  The locals a chain has in use depend on the path, so that check moves
+// to run time (`lbase`, the interpreter's own test); the value stack is checked here against the deepest chain through every copy.
+// The copies are real functions (noinline) when inlining them all would multiply the program (a body with two recursive call sites
+// has 2^8 paths), inlined otherwise.
+bool generate_program_levels(const std::vector<uint32_t> &code, const DevProgram &p, uint32_t index, std::string &out, std::string &why) {
+    std::vector<Fn> fns;                       // [0] = shade (level 0), then copies in discovery order
+    std::vector<int> stack_base;               // deepest value stack below the copy's own part, over every chain that reaches it
+    std::vector<double> paths;                 // number of call chains that reach the copy (for the inlining decision)
+    auto find = [&](uint32_t entry, uint32_t arity, uint32_t total, int level) {
+        for (size_t i = 1; i < fns.size(); ++i)
+            if (fns[i].entry == entry && fns[i].arity == arity && fns[i].total == total && fns[i].level == level) return (int)i;
+        return -1;
+    };
+    Fn shade;
+    shade.entry = p.shade_entry;
+    shade.total = p.shade_locals;
+    shade.is_shade = true;
+    shade.level = 0;
+    if (!analyse(code, shade, why)) return false;
+    fns.push_back(shade);
+    stack_base.push_back(0);
+    paths.push_back(1.0);
+    // level by level: every call goes exactly one level up, so when a level is processed the copies of that level are complete
+    for (int level = 0; level < (int)RXR_VM_FRAMES; ++level) {
+        const size_t n_now = fns.size();
+        for (size_t i = 0; i < n_now; ++i) {
+            if (fns[i].level != level) continue;
+            const std::vector<Call> calls = fns[i].calls;
+            for (const Call &c : calls) {
+                if (c.arity > c.total) continue;  // (emitted as a static fault)
+                int k = find(c.target, c.arity, c.total, level + 1);
+                if (k < 0) {
+                    Fn g;
+                    g.entry = c.target; g.arity = c.arity; g.total = c.total; g.level = level + 1;
+                    if (!analyse(code, g, why)) return false;
+                    fns.push_back(g);
+                    stack_base.push_back(0);
+                    paths.push_back(0.0);
+                    k = (int)fns.size() - 1;
+                    if (fns.size() > 512u) { why = "a recursive program with more than 512 function copies"; return false; }
+                }
+                stack_base[(size_t)k] = std::max(stack_base[(size_t)k], stack_base[i] + fns[i].depth[c.pc] - (int)c.arity);
+                paths[(size_t)k] += paths[i];
+            }
+        }
+    }
+    double expanded = 0.0;
+    for (size_t i = 0; i < fns.size(); ++i) {
+        if (stack_base[i] + fns[i].max_depth > (int)RXR_VM_STACK) { why = "a value stack deeper than the interpreter's"; return false; }
+        uint32_t live = 0;
+        for (int dpt : fns[i].depth) live += dpt >= 0 ? 1u : 0u;
+        expanded += paths[i] * (double)live;
+    }
+    const bool inline_all = expanded <= 1024.0;  // (VM instructions after inlining every chain)
+    out += "struct rxr_jit_globals_" + std::to_string(index) + " {\n";
+    for (uint32_t k = 0; k < p.n_globals && k < RXR_VM_GLOBALS; ++k) out += "    rxvm::v3 g" + std::to_string(k) + ";\n";
+    out += "    int unused;\n};\n";
+    // callees first: the deepest level down to shade
+    for (int level = (int)RXR_VM_FRAMES; level >= 0; --level)
+        for (size_t i = 0; i < fns.size(); ++i) {
+            const Fn &f = fns[i];
+            if (f.level != level) continue;
+            if (f.is_shade) {
+                out += "__device__ __forceinline__ uint32_t " + fn_name(index, f) + "(const RasterParams &P, rxvm::IO &io) {\n    using namespace rxvm;\n    (void)P;\n";
+                out += "    rxr_jit_globals_" + std::to_string(index) + " G;\n    G.unused = 0;\n";
+                for (uint32_t g = 0; g < p.n_globals && g < RXR_VM_GLOBALS; ++g) out += "    G.g" + std::to_string(g) + " = splat(0.0f);\n";
+                out += "    uint32_t fault = 0u, steps = 0u;\n    (void)steps;\n    const uint32_t lbase = 0u;\n    (void)lbase;\n";
+                if (!emit_body(code, p, index, f, out, why)) return false;
+                out += "Lend:\n    if (fault) *P.vm_fault = fault;\n    return fault;\n}\n";
+            } else {
+                out += std::string("__device__ ") + (inline_all ? "__forceinline__" : "__noinline__") + " rxvm::v3 " + fn_name(index, f) +
+                       "(const RasterParams &P, rxvm::IO &io, rxr_jit_globals_" + std::to_string(index) + " &G, uint32_t &fault, uint32_t &steps, const uint32_t lbase";
+                for (uint32_t a = 0; a < f.arity; ++a) out += ", rxvm::v3 a" + std::to_string(a);
+                out += ") {\n    using namespace rxvm;\n    (void)P; (void)io; (void)G; (void)steps; (void)lbase;\n";
+                if (!emit_body(code, p, index, f, out, why)) return false;
+                out += "    return splat(0.0f);\n}\n";
+            }
+        }
     return true;
 }
 
@@ -409,6 +510,7 @@ bool generate_program(const std::vector<uint32_t> &code, const DevProgram &p, ui
         if (first) order.push_back(wk.fn);
     };
     visit(Walk{0, 0, 0u, 0});
+    if (!ok && why == "recursion") return generate_program_levels(code, p, index, out, why);
     if (!ok) return false;
     // globals of the program, shared by its functions
     out += "struct rxr_jit_globals_" + std::to_string(index) + " {\n";

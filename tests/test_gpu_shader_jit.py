@@ -165,14 +165,41 @@ def test_random_programs_with_functions(oracle, product, monkeypatch):
     three_ways(oracle, product, monkeypatch, lambda api: grid_scene(api, programs, time=0.5), tol=S.TOLERANCE, max_off=6)
 
 
-def test_recursion_and_palette_lookups_keep_the_interpreter(oracle, product, monkeypatch):
+FACT = [("LoadLocal", 0), ("Push", 1.0), "Le", ("If", [("Push", 1.0), "Return"], None),
+        ("LoadLocal", 0), ("LoadLocal", 0), ("Push", 1.0), "Sub", ("FunctionCall", 1, 1, 1), "Mul", "Return"]
+
+
+def test_recursive_programs_are_compiled_as_one_copy_per_call_depth(oracle, product, monkeypatch):
+    """the interpreter bounds every call chain by its frame stack, so recursion unrolls into an acyclic program (rxr_jit.hip,
+    generate_program_levels): factorial (one recursive call site: inlined copies), Fibonacci (two call sites: 2^8 chains, real
+    functions), a mutually recursive pair with different locals"""
+    fact_prog = Program([["UV", ("GetComponents", [0]), ("Push", 24.0), "Mul", "Floor", ("FunctionCall", 1, 1, 1), ("Push", 0.004), "Mul", "SetColor"], FACT])
+    fib = [("LoadLocal", 0), ("Push", 2.0), "Lt", ("If", [("LoadLocal", 0), "Return"], None),
+           ("LoadLocal", 0), ("Push", 1.0), "Sub", ("FunctionCall", 1, 1, 1), ("LoadLocal", 0), ("Push", 2.0), "Sub", ("FunctionCall", 1, 1, 1), "Add", "Return"]
+    fib_prog = Program([["UV", ("GetComponents", [1]), ("Push", 28.0), "Mul", "Floor", ("FunctionCall", 1, 1, 1), ("Push", 0.07), "Mul", "SetColor"], fib])
+    # even(n) = n == 0 ? 1 : odd(n - 1);  odd(n) = n == 0 ? 0 : even(n - 1)   (odd keeps a second local)
+    even = [("LoadLocal", 0), ("Push", 0.0), "Eq", ("If", [("Push", 1.0), "Return"], None), ("LoadLocal", 0), ("Push", 1.0), "Sub", ("FunctionCall", 1, 2, 2), "Return"]
+    odd = [("LoadLocal", 0), ("StoreLocal", 1), ("LoadLocal", 1), ("Push", 0.0), "Eq", ("If", [("Push", 0.0), "Return"], None),
+           ("LoadLocal", 1), ("Push", 1.0), "Sub", ("FunctionCall", 1, 1, 1), "Return"]
+    parity_prog = Program([["UV", ("GetComponents", [0]), ("Push", 28.0), "Mul", "Floor", ("FunctionCall", 1, 1, 1), "UV", "Mul", "SetColor"], even, odd])
+    got, info = three_ways(oracle, product, monkeypatch, lambda api: grid_scene(api, [fact_prog, fib_prog, parity_prog]))
+    assert len(np.unique(got.reshape(-1, 4), axis=0)) > 12
+
+
+def test_recursion_beyond_the_frame_stack_faults_in_both_forms(product, monkeypatch):
+    """nine nested calls: the interpreter raises VMF_CALL_DEPTH at the ninth, the compiled form at the call site of its last copy"""
+    deep = Program([["UV", ("GetComponents", [0]), ("Push", 64.0), "Mul", "Floor", ("FunctionCall", 1, 1, 1), ("Push", 0.001), "Mul", "SetColor"], FACT])  # (uv / 4: up to 15)
+    for mode, compiled in (("0", False), ("1", True)):
+        monkeypatch.setenv("RXR_SHADER_JIT", mode)
+        with pytest.raises(B.RasterizeError) as e:
+            scenes.render(grid_scene(product, [deep]))
+        assert e.value.code == B.RXR_ERR_INVALID, str(e.value)
+        assert jit_info(product).startswith("compiled:") == compiled, jit_info(product)
+    monkeypatch.setenv("RXR_SHADER_JIT", "0")
+
+
+def test_palette_lookups_with_a_missing_slot_go_back_to_the_interpreter(oracle, product, monkeypatch):
     monkeypatch.setenv("RXR_SHADER_JIT", "1")
-    fact = [("LoadLocal", 0), ("Push", 1.0), "Le", ("If", [("Push", 1.0), "Return"], None),
-            ("LoadLocal", 0), ("LoadLocal", 0), ("Push", 1.0), "Sub", ("FunctionCall", 1, 1, 1), "Mul", "Return"]
-    prog = Program([["UV", ("GetComponents", [0]), ("Push", 16.0), "Mul", "Floor", ("FunctionCall", 1, 1, 1), ("Push", 0.04), "Mul", "SetColor"], fact])
-    got = scenes.render(grid_scene(product, [prog]))
-    assert jit_info(product).startswith("not compiled:") and "recursion" in jit_info(product)
-    assert np.array_equal(got, scenes.render(grid_scene(oracle, [prog])))
     # (a missing palette slot pushes nothing: the Add then consumes the two constants -- a data-dependent stack depth)
     pal = Program([[("Push", 0.1, 0.1, 0.1), ("Push", 0.2, 0.3, 0.4), "UV", ("GetComponents", [0]), ("Push", 12.0), "Mul", "PaletteIndex", "Add", "Clear", "UV", "SetColor"]])
     got = scenes.render(grid_scene(product, [pal]))

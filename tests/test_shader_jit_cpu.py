@@ -55,14 +55,28 @@ def test_loops_locals_globals_and_faults_are_generated():
     assert "rxr_jit_prog_1" in src
 
 
-def test_calls_become_functions_recursion_is_left_to_the_interpreter_and_palette_lookups_carry_a_way_back():
+def test_calls_become_functions_recursion_unrolls_by_call_depth_and_palette_lookups_carry_a_way_back():
     helper = [("LoadLocal", 0), ("Push", 2.0), "Mul", "Return"]
     rc, src, msg = generate([Program([["UV", ("FunctionCall", 1, 1, 1), "SetColor"], helper])], 0)
     assert rc == 0, msg
     assert re.search(r"rxvm::v3 rxr_jit_fn_0_\d+_1_1\(.*rxvm::v3 a0\)", src) and "v3 l0 = a0;" in src and "if (fault) goto Lend;" in src
     fact = [("LoadLocal", 0), ("Push", 1.0), "Le", ("If", [("Push", 1.0), "Return"], None), ("LoadLocal", 0), ("LoadLocal", 0), ("Push", 1.0), "Sub", ("FunctionCall", 1, 1, 1), "Mul", "Return"]
-    rc, _, msg = generate([Program([["UV", ("FunctionCall", 1, 1, 1), "SetColor"], fact])], 0)
-    assert rc == B.RXR_ERR_UNSUPPORTED and "recursion" in msg
+    # recursion (round 3): one copy of the function per call depth the interpreter's frame stack allows (8), a call in the last copy is
+    # the interpreter's VMF_CALL_DEPTH (5), the locals of a chain are checked at run time (`lbase`) like the interpreter's
+    rc, src, msg = generate([Program([["UV", ("FunctionCall", 1, 1, 1), "SetColor"], fact])], 0)
+    assert rc == 0, msg
+    copies = sorted(set(int(m) for m in re.findall(r"rxvm::v3 rxr_jit_fn_0_\d+_1_1_L(\d+)\(", src)))
+    assert copies == list(range(1, 9)), copies
+    last = src[src.index("_1_1_L8("):]
+    last = last[:last.index("\n}\n")]
+    assert "fault = 5u" in last and "_L9" not in src
+    assert "if (lbase + 2u > 48u)" in src and "const uint32_t lbase" in src and "__forceinline__ rxvm::v3 rxr_jit_fn_0_" in src
+    # two recursive call sites per body: 2^8 chains -- the copies become real functions instead of being inlined into each other
+    fib = [("LoadLocal", 0), ("Push", 2.0), "Lt", ("If", [("LoadLocal", 0), "Return"], None),
+           ("LoadLocal", 0), ("Push", 1.0), "Sub", ("FunctionCall", 1, 1, 1), ("LoadLocal", 0), ("Push", 2.0), "Sub", ("FunctionCall", 1, 1, 1), "Add", "Return"]
+    rc, src, msg = generate([Program([["UV", ("FunctionCall", 1, 1, 1), "SetColor"], fib])], 0)
+    assert rc == 0, msg
+    assert "__noinline__ rxvm::v3 rxr_jit_fn_0_" in src
     # PaletteIndex (round 3): compiled as the push, with the reference's other case -- a missing or empty slot pushes nothing --
     # raising VMF_JIT_PALETTE_MISS (12), on which rxr_synchronize hands the set back to the interpreter
     rc, src, msg = generate([Program([["UV", "PaletteIndex", "SetColor"]])], 0)
