@@ -186,6 +186,30 @@ def test_recursive_programs_are_compiled_as_one_copy_per_call_depth(oracle, prod
     assert len(np.unique(got.reshape(-1, 4), axis=0)) > 12
 
 
+def random_recursive_program(seed):
+    """a random program (S.ProgramGen: two helper functions) plus a self-recursive function R(n, x) -- early exit at n <= 0, a random
+    block, R(n - 1, <random>), a random combination -- called from `shade` with n = 0 .. 2 by pixel.  R may call the helpers; frames
+    stay within the interpreter's 8 and the chain's locals within its 48"""
+    rng = np.random.default_rng([0x52585231, 9003, seed])
+    gen = S.ProgramGen(rng, n_locals=3, n_functions=2, setters=["SetColor"])
+    prog = gen.program()
+    shade, helpers = gen.raw[0], gen.raw[1:]
+    gen.n_locals = gen.loadable = 3
+    gen.first_callable = 0
+    # (the counter moves to local 7 first: the random statements store to locals 0 .. 2 and loop on 3 .. 6)
+    rec = ([("LoadLocal", 0), ("StoreLocal", 7), ("LoadLocal", 7), ("Push", 0.0), "Le", ("If", gen.value(2) + ["Return"], None)] + gen.block(2) +
+           [("LoadLocal", 7), ("Push", 1.0), "Sub"] + gen.value(2) + [("FunctionCall", 2, 8, 3)] +
+           gen.value(2) + [str(rng.choice(["Add", "Mul", "Min", "Max", "Sub"])), "Return"])
+    assert shade[-1] == "SetColor"
+    call = ["UV", ("GetComponents", [0]), ("Push", 11.0), "Mul", "Fract", ("Push", 3.0), "Mul", "Floor", "UV", ("FunctionCall", 2, 8, 3), ("Push", 0.37), "Mul", "Add", "Fract"]
+    return Program([shade[:-1] + call + ["SetColor"]] + helpers + [rec], shade_locals=3 + 4)
+
+
+def test_random_recursive_programs(oracle, product, monkeypatch):
+    programs = [random_recursive_program(seed) for seed in range(10)]
+    three_ways(oracle, product, monkeypatch, lambda api: grid_scene(api, programs, time=0.5), tol=S.TOLERANCE, max_off=6)
+
+
 def test_recursion_beyond_the_frame_stack_faults_in_both_forms(product, monkeypatch):
     """nine nested calls: the interpreter raises VMF_CALL_DEPTH at the ninth, the compiled form at the call site of its last copy"""
     deep = Program([["UV", ("GetComponents", [0]), ("Push", 64.0), "Mul", "Floor", ("FunctionCall", 1, 1, 1), ("Push", 0.001), "Mul", "SetColor"], FACT])  # (uv / 4: up to 15)
