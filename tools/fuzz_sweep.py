@@ -17,6 +17,7 @@ from tests.oracle_api import load_oracle  # noqa: E402
 from tests import test_gpu_fuzz as F  # noqa: E402
 from tests import test_gpu_rows as R  # noqa: E402
 from tests import test_gpu_shaders as S  # noqa: E402
+from tests import test_gpu_shader_jit as J  # noqa: E402
 
 prod, orc = rusterix_amd.load(), load_oracle()
 DEVPROJ = "--device-projection" in sys.argv
@@ -68,6 +69,8 @@ for s in range(first, first + n):
         rng = np.random.default_rng([0x52585231, 777, s])
         prog = S.ProgramGen(rng, n_locals=int(rng.integers(3, 6)), n_functions=int(rng.integers(0, 3))).program()
         check(("program-cube", s), scenes.render(S.cube_scene(prod, prog)), scenes.render(S.cube_scene(orc, prog)), 1, 5)
+        rp = J.random_recursive_program(s)  # helpers + a self-recursive function with a random body (interpreted, or compiled per call depth)
+        check(("program-recursive", s), scenes.render(J.grid_scene(prod, [rp], time=0.5)), scenes.render(J.grid_scene(orc, [rp], time=0.5)), 1, 6)
     except Exception as e:  # a refused program (RXR_ERR_UNSUPPORTED) is not a parity failure
         refused.append((s, str(e)[:80]))
     if s % 10 == 0:
