@@ -1999,7 +1999,8 @@ static int render_impl(rxr_ctx *ctx, const RenderSpec &spec, void *dev_pixels, h
     // launches write them; rxr_synchronize clears them once the streams have drained)
     (void)n_bins;
     // device-projected 2D batches: Batch2D::project + the Prim2D records, before anything reads them
-    if (ctx->frame_uses_meshes2d && P.tiles_y && (P.flags & RXR_FLAG_D2_ACTIVE)) rxr_launch_project2d(&ctx->PP2, s);
+    // (a frame without 2D primitives never reads what they would write: no launch)
+    if (ctx->frame_uses_meshes2d && P.tiles_y && (P.flags & RXR_FLAG_D2_ACTIVE) && ctx->PP2.n_prims) rxr_launch_project2d(&ctx->PP2, s);
     // 2D binning pre-pass (many 2D primitives): count -> scan -> fill; k_raster sorts each tile's list
     const bool prepass2d = P.tiles_y && (P.flags & RXR_FLAG_D2_ACTIVE) && P.binned2d;
     if (prepass2d) {
