@@ -25,6 +25,7 @@
 
 extern "C" void rxr_launch_proj_static(const ProjectParams *P, hipStream_t s);
 extern "C" void rxr_launch_project(const ProjectParams *P, hipStream_t s);
+extern "C" void rxr_launch_proj_edges(const ProjectParams *P, hipStream_t s);
 extern "C" void rxr_launch_setup(const RasterParams *P, hipStream_t s);
 extern "C" void rxr_launch_scan(const ScanArgs *A, hipStream_t s);
 extern "C" void rxr_launch_bin2d_count(const RasterParams *P, hipStream_t s);
@@ -603,7 +604,15 @@ int rxr_read_projected_mesh(rxr_ctx *ctx, uint32_t index, uint32_t counts[2], fl
     if (clipped_uvs && nv) HIPCHK(ctx, hipMemcpy(clipped_uvs, PP.uv + M.vout_base, (size_t)nv * 8, hipMemcpyDeviceToHost));
     if (clipped_normals && nv) HIPCHK(ctx, hipMemcpy(clipped_normals, PP.nrm + 3 * (size_t)M.vout_base, (size_t)nv * 12, hipMemcpyDeviceToHost));
     if (clipped_indices && nt) HIPCHK(ctx, hipMemcpy(clipped_indices, PP.idx + 3 * (size_t)M.tout_base, (size_t)nt * 12, hipMemcpyDeviceToHost));
-    if (edges && nt) HIPCHK(ctx, hipMemcpy(edges, PP.edges + M.tout_base, (size_t)nt * sizeof(rxr_edges), hipMemcpyDeviceToHost));
+    if (edges && nt) {
+        if (PP.edges_in_setup) {  // (the frame's set-up built its records itself: the pool is filled for this call)
+            HIPCHK(ctx, hipSetDevice(ctx->device));
+            rxr_launch_proj_edges(&PP, ctx->stream);
+            HIPCHK(ctx, hipGetLastError());
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        }
+        HIPCHK(ctx, hipMemcpy(edges, PP.edges + M.tout_base, (size_t)nt * sizeof(rxr_edges), hipMemcpyDeviceToHost));
+    }
     if (bounding_box) {
         DevBBox bb{};
         HIPCHK(ctx, hipMemcpy(&bb, PP.bbox + index, sizeof(bb), hipMemcpyDeviceToHost));
@@ -1884,6 +1893,11 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
         P.edges = PP.edges;
         P.dev_bbox = PP.bbox;
         P.mesh_live = PP.mesh_live;
+        // the set-up builds the Edges records itself (k_proj_edges fused into make_setup): RXR_PROJ_FUSED_EDGES=0 keeps the pool
+        static const bool fused_edges = !(getenv("RXR_PROJ_FUSED_EDGES") && atoi(getenv("RXR_PROJ_FUSED_EDGES")) == 0);
+        PP.edges_in_setup = fused_edges ? 1u : 0u;
+        P.pm_meshes = fused_edges ? PP.meshes : nullptr;
+        P.pm_edge_vis = fused_edges ? PP.edge_vis : nullptr;
     }
     if (e2e_timing)
         fprintf(stderr, "rxr_e2e_timing upload: validate+size %.3f, wait for the previous frame %.3f, headers %.3f, arrays (copy + ship) %.3f, rest %.3f ms\n", ut_validated,

@@ -239,6 +239,8 @@ struct RasterParams {
                                      // at upload -- k_setup3d of such a frame is one workgroup of pure latency, and the search above is five
                                      // dependent loads of it; nullptr otherwise
     const struct DevBBox *dev_bbox;  // device-projection path: per-batch boxes accumulated on the device (else NULL)
+    const struct DevMesh *pm_meshes; // device-projection path, edges fused into the set-up (RXR_PROJ_FUSED_EDGES): the frame's mesh headers and
+    const uint8_t *pm_edge_vis;      // edge_visibility per original triangle -- make_setup builds the Edges record itself (else NULL: P.edges)
     const uint32_t *mesh_live;       // device-projection path: per batch, the triangle slots in use (rxr_project.h); slots behind them
                                      // hold no triangle and nothing may be read from their records (else NULL)
 

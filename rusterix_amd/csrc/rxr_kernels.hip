@@ -1083,10 +1083,21 @@ __device__ __forceinline__ bool make_setup(const RasterParams &P, uint32_t t, Tr
         return false;
     }
     // (with the table the index triple and the edge record do not wait for the batch header: two levels of loads instead of seven)
-    const rxr_edges E = P.edges[t];
+    const bool own_edges = P.pm_meshes != nullptr;  // uniform: a device-projected frame whose Edges records are built here (below)
+    rxr_edges E;
+    if (!own_edges) E = P.edges[t];
     const uint32_t ix0 = P.idx[3 * (size_t)t + 0], ix1 = P.idx[3 * (size_t)t + 1], ix2 = P.idx[3 * (size_t)t + 2];
     const DevBatch B = P.batches3d[lo];
     const uint32_t vbase = have_info ? info.y : B.vert_base;
+    if (own_edges) {
+        // k_proj_edges, fused: the slot is in use (mesh_live above), its edge_visibility is the original triangle's or, for an
+        // appended fan, true; the record is Edges::new of the projected vertices under the mesh's cull mode (edges_from_vertices,
+        // rxr_project.h -- the same function k_proj_edges calls).  40 B per slot are neither written nor read back.
+        const DevMesh &M = P.pm_meshes[lo];
+        const uint32_t local = t - P.batch_tri_base[lo];
+        const bool evis = local < M.n_tris ? P.pm_edge_vis[M.tin_base + local] != 0 : true;
+        E = edges_from_vertices(M.cull_mode, evis, P.pv[ix0 + vbase], P.pv[ix1 + vbase], P.pv[ix2 + vbase]);
+    }
 
     // triangles that can never produce a pixel (culled / clipped away: edges.visible == false, :989-992; skipped batch;
     // batch box off screen) are known before any vertex is read: they only get an empty pixel box

@@ -40,6 +40,7 @@ typedef unsigned long long AppendCount;
 struct ProjectParams {
     uint32_t n_meshes, n_verts_in, n_tris_in;  // totals over all meshes (object space)
     uint32_t n_tris_out;                       // total triangle capacity (sum of 3 * n_tris)
+    uint32_t edges_in_setup;                   // 1: k_setup3d builds the Edges records itself (RasterParams.pm_meshes): no k_proj_edges launch
     float projection[16];
     float width, height;
 
@@ -68,6 +69,44 @@ struct ProjectParams {
     uint32_t *mesh_live;          // per mesh and frame: triangle slots in use = originals + appended fans (0 for a rejected mesh);
                                   // the slots behind them are dead: k_proj_edges, k_setup3d and k_fill skip whole workgroups of them
 };
+
+#if defined(__HIPCC__) || defined(RXR_JIT)
+// Edges for one USED triangle slot of mesh M (batch3d.rs:706-739 + edge.rs:12-24) from its three projected vertices: the front-facing
+// test, the winding swap of the cull mode, Edges::new([v0,v1,v2], [v1,v2,v0]).  `evis`: edge_visibility of the slot (appended fans:
+// true, :731-732).  Shared by k_proj_edges and, for frames whose set-up builds the records itself, make_setup (rxr_kernels.hip).
+__device__ __forceinline__ rxr_edges edges_from_vertices(uint32_t cull_mode, bool evis, float4 v0, float4 v1, float4 v2) {
+    rxr_edges E;
+    // is_front_facing, :742-746
+    const bool front = ((v1.x - v0.x) * (v2.y - v0.y) - (v1.y - v0.y) * (v2.x - v0.x)) > 0.0f;
+    bool visible, swap;
+    if (cull_mode == RXR_CULL_OFF) {
+        swap = front;
+        visible = true;
+    } else if (cull_mode == RXR_CULL_FRONT) {
+        swap = false;
+        visible = !front;
+    } else {
+        swap = front;
+        visible = front;
+    }
+    if (swap) {
+        const float4 tmp = v1;
+        v1 = v2;
+        v2 = tmp;
+    }
+    // Edges::new([v0,v1,v2], [v1,v2,v0]): a = y1 - y0, b = x0 - x1, c = x1*y0 - y1*x0
+    const float px[3] = {v0.x, v1.x, v2.x}, py[3] = {v0.y, v1.y, v2.y};
+    const float qx[3] = {v1.x, v2.x, v0.x}, qy[3] = {v1.y, v2.y, v0.y};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        E.a[i] = qy[i] - py[i];
+        E.b[i] = px[i] - qx[i];
+        E.c[i] = qx[i] * py[i] - qy[i] * px[i];
+    }
+    E.visible = (evis && visible) ? 1u : 0u;
+    return E;
+}
+#endif
 
 // ---- the 2D half: Batch2D::project (src/batch/batch2d.rs:373-425) + the Prim2D records rxr_upload_frame builds on the host ----------
 struct DevMesh2D {

@@ -395,36 +395,8 @@ __device__ __forceinline__ rxr_edges edges_of_slot(const ProjectParams &P, uint3
     }
     if (!used) return E;
     const uint32_t *ix = P.idx + 3 * (size_t)s;
-    float4 v0 = P.pv[M.vout_base + ix[0]], v1 = P.pv[M.vout_base + ix[1]], v2 = P.pv[M.vout_base + ix[2]];
-    // is_front_facing, :742-746
-    bool front = ((v1.x - v0.x) * (v2.y - v0.y) - (v1.y - v0.y) * (v2.x - v0.x)) > 0.0f;
-    bool visible, swap;
-    if (M.cull_mode == RXR_CULL_OFF) {
-        swap = front;
-        visible = true;
-    } else if (M.cull_mode == RXR_CULL_FRONT) {
-        swap = false;
-        visible = !front;
-    } else {
-        swap = front;
-        visible = front;
-    }
-    if (swap) {
-        float4 tmp = v1;
-        v1 = v2;
-        v2 = tmp;
-    }
-    // Edges::new([v0,v1,v2], [v1,v2,v0]): a = y1 - y0, b = x0 - x1, c = x1*y0 - y1*x0
-    const float px[3] = {v0.x, v1.x, v2.x}, py[3] = {v0.y, v1.y, v2.y};
-    const float qx[3] = {v1.x, v2.x, v0.x}, qy[3] = {v1.y, v2.y, v0.y};
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        E.a[i] = qy[i] - py[i];
-        E.b[i] = px[i] - qx[i];
-        E.c[i] = qx[i] * py[i] - qy[i] * px[i];
-    }
-    E.visible = (evis && visible) ? 1u : 0u;
-    return E;
+    const float4 v0 = P.pv[M.vout_base + ix[0]], v1 = P.pv[M.vout_base + ix[1]], v2 = P.pv[M.vout_base + ix[2]];
+    return edges_from_vertices(M.cull_mode, evis, v0, v1, v2);
 }
 // per frame, one thread per mesh: how many of its 3 * n_tris triangle slots are in use (the pools are capacity based: an
 // unclipped scene leaves two thirds of them unused)
@@ -484,6 +456,10 @@ extern "C" void rxr_launch_project(const ProjectParams *P, hipStream_t s) {
     hipLaunchKernelGGL(k_proj_scan, dim3((nt1 + RXR_PROJ_SCAN_CHUNK - 1u) / RXR_PROJ_SCAN_CHUNK), dim3(256), 0, s, *P);
     hipLaunchKernelGGL(k_proj_live, dim3((P->n_meshes + 255u) / 256u), dim3(256), 0, s, *P);
     if (P->n_tris_in) hipLaunchKernelGGL(k_clip_emit, dim3((P->n_tris_in + 255u) / 256u), dim3(256), 0, s, *P);
+    if (P->n_tris_out && !P->edges_in_setup) hipLaunchKernelGGL(k_proj_edges, dim3((P->n_tris_out + 255u) / 256u), dim3(256), 0, s, *P);
+}
+// the Edges pool alone (rxr_read_projected_mesh on a frame whose set-up built the records itself)
+extern "C" void rxr_launch_proj_edges(const ProjectParams *P, hipStream_t s) {
     if (P->n_tris_out) hipLaunchKernelGGL(k_proj_edges, dim3((P->n_tris_out + 255u) / 256u), dim3(256), 0, s, *P);
 }
 
