@@ -10,6 +10,7 @@
 // of the depth test, so it is reproduced exactly: k_clip_count counts what each triangle emits, an
 // exclusive scan turns the counts into append offsets, k_clip_emit writes at those offsets.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include "rxr_project.h"
 
@@ -178,18 +179,21 @@ extern "C" __global__ void __launch_bounds__(256) k_proj_static(ProjectParams P)
 }
 
 // per frame: reset the per-mesh boxes to (+inf, +inf, -inf, -inf), batch3d.rs:750-753
-extern "C" __global__ void __launch_bounds__(256) k_proj_init(ProjectParams P) {
-    uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+namespace {
+__device__ __forceinline__ void proj_init_item(const ProjectParams &P, uint32_t b) {
     if (b >= P.n_meshes) return;
     DevBBox bb;
     bb.min_x = bb.min_y = enc(INFINITY);
     bb.max_x = bb.max_y = enc(-INFINITY);
     P.bbox[b] = bb;
 }
+}  // namespace
+extern "C" __global__ void __launch_bounds__(256) k_proj_init(ProjectParams P) { proj_init_item(P, blockIdx.x * blockDim.x + threadIdx.x); }
 
 // per frame: view transform (:555-560) and screen projection (:689-700) of the ORIGINAL vertices
-extern "C" __global__ void __launch_bounds__(256) k_proj_vertices(ProjectParams P) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+namespace {
+// (called by whole waves whose lanes hold consecutive items: find_mesh_wave, bbox_add_wave)
+__device__ __forceinline__ void proj_vertices_item(const ProjectParams &P, uint32_t i) {
     bool active = i < P.n_verts_in;
     uint32_t b = 0;
     float4 s = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -207,10 +211,12 @@ extern "C" __global__ void __launch_bounds__(256) k_proj_vertices(ProjectParams 
     }
     if (__ballot(active) != 0ull) bbox_add_wave(P.bbox, b, active, s.x, s.y);  // wave-uniform call
 }
+}  // namespace
+extern "C" __global__ void __launch_bounds__(256) k_proj_vertices(ProjectParams P) { proj_vertices_item(P, blockIdx.x * blockDim.x + threadIdx.x); }
 
 // per frame: what each original triangle appends (:586-681)
-extern "C" __global__ void __launch_bounds__(256) k_clip_count(ProjectParams P) {
-    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+namespace {
+__device__ __forceinline__ void clip_count_item(const ProjectParams &P, uint32_t t) {
     if (t > P.n_tris_in) return;
     if (t == P.n_tris_in) {  // sentinel: after the scan it holds the grand total
         P.append[t] = 0ull;
@@ -230,6 +236,8 @@ extern "C" __global__ void __launch_bounds__(256) k_clip_count(ProjectParams P) 
     uint32_t nt = c.nv >= 3 ? (uint32_t)(c.nv - 2) : 0u;
     P.append[t] = (AppendCount)(uint32_t)c.nv | ((AppendCount)nt << 32);
 }
+}  // namespace
+extern "C" __global__ void __launch_bounds__(256) k_clip_count(ProjectParams P) { clip_count_item(P, blockIdx.x * blockDim.x + threadIdx.x); }
 
 // exclusive scan of P.append[0 .. n_tris_in] (n_tris_in + 1 entries) in place: chunk-local prefixes,
 // chunk bases written by the workgroup that finishes last (same scheme as k_scan in rxr_kernels.hip)
@@ -303,8 +311,8 @@ __device__ __forceinline__ AppendCount prefix_at(const ProjectParams &P, uint32_
 
 // per frame: Sutherland-Hodgman against z = -0.1 for the mixed triangles, appended vertices and fan
 // triangles written at their scanned offsets (:626-686), new vertices projected (:689-700)
-extern "C" __global__ void __launch_bounds__(256) k_clip_emit(ProjectParams P) {
-    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+namespace {
+__device__ __forceinline__ void clip_emit_item(const ProjectParams &P, uint32_t t) {
     if (t >= P.n_tris_in) return;
     uint32_t b = find_mesh_wave(P.tin_prefix, P.n_meshes, t);
     const DevMesh &M = P.meshes[b];
@@ -372,6 +380,8 @@ extern "C" __global__ void __launch_bounds__(256) k_clip_emit(ProjectParams P) {
         ++ts;
     }
 }
+}  // namespace
+extern "C" __global__ void __launch_bounds__(256) k_clip_emit(ProjectParams P) { clip_emit_item(P, blockIdx.x * blockDim.x + threadIdx.x); }
 
 // per frame: Edges for every triangle slot (:706-739 + edge.rs:12-24); unused slots become invisible
 // one slot's record (all zero = unused / invisible)
@@ -400,8 +410,7 @@ __device__ __forceinline__ rxr_edges edges_of_slot(const ProjectParams &P, uint3
 }
 // per frame, one thread per mesh: how many of its 3 * n_tris triangle slots are in use (the pools are capacity based: an
 // unclipped scene leaves two thirds of them unused)
-extern "C" __global__ void __launch_bounds__(256) k_proj_live(ProjectParams P) {
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void proj_live_item(const ProjectParams &P, uint32_t b) {
     if (b >= P.n_meshes) return;
     const DevMesh &M = P.meshes[b];
     uint32_t live = 0;
@@ -410,6 +419,56 @@ extern "C" __global__ void __launch_bounds__(256) k_proj_live(ProjectParams P) {
         live = M.n_tris + (uint32_t)(tot >> 32);
     }
     P.mesh_live[b] = live;
+}
+extern "C" __global__ void __launch_bounds__(256) k_proj_live(ProjectParams P) { proj_live_item(P, blockIdx.x * blockDim.x + threadIdx.x); }
+
+// Small frames (RXR_PROJ_SMALL_MAX original vertices and triangles): every step above in ONE workgroup -- the six dependent launches
+// of rxr_launch_project cost a map or a teapot ~5 us each, several times the work in them.  The same item functions in the same
+// order; a workgroup barrier (which orders the workgroup's global-memory traffic) stands where a kernel boundary stood; the scan is
+// the workgroup's own (every item lies in chunk 0 of the prefix scheme: chunk_base[0] = 0).
+#ifndef RXR_PROJ_SMALL_MAX
+#define RXR_PROJ_SMALL_MAX 1024u
+#endif
+static_assert(RXR_PROJ_SMALL_MAX < RXR_PROJ_SCAN_CHUNK, "k_proj_small scans chunk 0 only");
+extern "C" __global__ void __launch_bounds__(256) k_proj_small(ProjectParams P) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    __shared__ AppendCount wave_tot[4];
+    for (uint32_t b = tid; b < P.n_meshes; b += 256u) proj_init_item(P, b);
+    __syncthreads();
+    // (whole waves: the loop bounds are rounded up to the workgroup, the items check their range themselves)
+    for (uint32_t i = tid; i < ((P.n_verts_in + 255u) & ~255u); i += 256u) proj_vertices_item(P, i);
+    __syncthreads();
+    for (uint32_t t = tid; t < ((P.n_tris_in + 1u + 255u) & ~255u); t += 256u) clip_count_item(P, t);
+    __syncthreads();
+    // exclusive scan of P.append[0 .. n_tris_in] in place
+    AppendCount carry = 0;
+    for (uint32_t base = 0; base < P.n_tris_in + 1u; base += 256u) {
+        const uint32_t i = base + tid;
+        const AppendCount v = i <= P.n_tris_in ? P.append[i] : 0ull;
+        AppendCount inc = v;
+#pragma unroll
+        for (uint32_t d = 1; d < 64; d <<= 1) {
+            const AppendCount o = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += o;
+        }
+        if (lane == 63u) wave_tot[wave] = inc;
+        __syncthreads();
+        AppendCount off = 0, total = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < 4; ++w) {
+            const AppendCount wt = wave_tot[w];
+            if (w < wave) off += wt;
+            total += wt;
+        }
+        if (i <= P.n_tris_in) P.append[i] = carry + off + inc - v;
+        carry += total;
+        __syncthreads();  // wave_tot is rewritten by the next round
+    }
+    if (tid == 0) P.chunk_base[0] = 0ull;
+    __syncthreads();
+    for (uint32_t b = tid; b < P.n_meshes; b += 256u) proj_live_item(P, b);
+    __syncthreads();
+    for (uint32_t t = tid; t < ((P.n_tris_in + 255u) & ~255u); t += 256u) clip_emit_item(P, t);
 }
 
 // The 40-byte records leave through LDS as the workgroup's contiguous 10 KB block (see k_setup3d in rxr_kernels.hip).
@@ -449,6 +508,12 @@ extern "C" void rxr_launch_proj_static(const ProjectParams *P, hipStream_t s) {
 }
 extern "C" void rxr_launch_project(const ProjectParams *P, hipStream_t s) {
     if (P->n_meshes == 0) return;
+    static const bool small_ok = !(getenv("RXR_PROJ_SMALL") && atoi(getenv("RXR_PROJ_SMALL")) == 0);
+    if (small_ok && P->n_verts_in <= RXR_PROJ_SMALL_MAX && P->n_tris_in < RXR_PROJ_SMALL_MAX && P->n_meshes <= RXR_PROJ_SMALL_MAX) {
+        hipLaunchKernelGGL(k_proj_small, dim3(1), dim3(256), 0, s, *P);
+        if (P->n_tris_out && !P->edges_in_setup) hipLaunchKernelGGL(k_proj_edges, dim3((P->n_tris_out + 255u) / 256u), dim3(256), 0, s, *P);
+        return;
+    }
     hipLaunchKernelGGL(k_proj_init, dim3((P->n_meshes + 255u) / 256u), dim3(256), 0, s, *P);
     if (P->n_verts_in) hipLaunchKernelGGL(k_proj_vertices, dim3((P->n_verts_in + 255u) / 256u), dim3(256), 0, s, *P);
     uint32_t nt1 = P->n_tris_in + 1u;
