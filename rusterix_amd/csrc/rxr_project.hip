@@ -561,8 +561,8 @@ __device__ __forceinline__ bool to_isize32(float x, int32_t &out) {
 }
 }  // namespace
 
-extern "C" __global__ void __launch_bounds__(256) k_proj2d_init(Project2DParams P) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+namespace {
+__device__ __forceinline__ void proj2d_init_item(const Project2DParams &P, uint32_t i) {
     if (i < P.n_meshes) {
         P.bbox[i].min_x = P.bbox[i].min_y = 0xFFFFFFFFu;
         P.bbox[i].max_x = P.bbox[i].max_y = 0u;
@@ -571,10 +571,12 @@ extern "C" __global__ void __launch_bounds__(256) k_proj2d_init(Project2DParams 
         P.d2_box[0] = 0xFFFFu; P.d2_box[1] = 0u; P.d2_box[2] = 0xFFFFu; P.d2_box[3] = 0u;
     }
 }
+}  // namespace
+extern "C" __global__ void __launch_bounds__(256) k_proj2d_init(Project2DParams P) { proj2d_init_item(P, blockIdx.x * 256u + threadIdx.x); }
 
 // bounding box per batch (batch2d.rs:377-403): min / max of the projected vertices with NaN dropped
-extern "C" __global__ void __launch_bounds__(256) k_proj2d_bbox(Project2DParams P) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+namespace {
+__device__ __forceinline__ void proj2d_bbox_item(const Project2DParams &P, uint32_t i) {  // (whole waves, consecutive items)
     const bool active = i < P.n_verts;
     uint32_t m = 0;
     float2 p = make_float2(0.0f, 0.0f);
@@ -584,9 +586,11 @@ extern "C" __global__ void __launch_bounds__(256) k_proj2d_bbox(Project2DParams 
     }
     if (__ballot(active)) bbox_add_wave(P.bbox, m, active, p.x, p.y);
 }
+}  // namespace
+extern "C" __global__ void __launch_bounds__(256) k_proj2d_bbox(Project2DParams P) { proj2d_bbox_item(P, blockIdx.x * 256u + threadIdx.x); }
 
-extern "C" __global__ void __launch_bounds__(256) k_proj2d_prims(Project2DParams P) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+namespace {
+__device__ __forceinline__ void proj2d_prims_item(const Project2DParams &P, uint32_t i) {  // (whole waves: the union box is reduced across the wave)
     uint32_t min_x = 0, max_x = 0, min_y = 0, max_y = 0;
     if (i < P.n_prims) {
         const Prim2DSrc s = P.src[i];
@@ -659,8 +663,25 @@ extern "C" __global__ void __launch_bounds__(256) k_proj2d_prims(Project2DParams
         atomicMax(&P.d2_box[3], d);
     }
 }
+}  // namespace
+extern "C" __global__ void __launch_bounds__(256) k_proj2d_prims(Project2DParams P) { proj2d_prims_item(P, blockIdx.x * 256u + threadIdx.x); }
+
+// few 2D batches (a HUD, a logo): the three steps in one workgroup, as k_proj_small
+extern "C" __global__ void __launch_bounds__(256) k_proj2d_small(Project2DParams P) {
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t i = tid; i < ((P.n_meshes + 1u + 255u) & ~255u); i += 256u) proj2d_init_item(P, i);   // (item 0 also resets the union box)
+    __syncthreads();
+    for (uint32_t i = tid; i < ((P.n_verts + 255u) & ~255u); i += 256u) proj2d_bbox_item(P, i);
+    __syncthreads();
+    for (uint32_t i = tid; i < ((P.n_prims + 255u) & ~255u); i += 256u) proj2d_prims_item(P, i);
+}
 
 extern "C" void rxr_launch_project2d(const Project2DParams *P, hipStream_t s) {
+    static const bool small_ok = !(getenv("RXR_PROJ_SMALL") && atoi(getenv("RXR_PROJ_SMALL")) == 0);
+    if (small_ok && P->n_meshes <= RXR_PROJ_SMALL_MAX && P->n_verts <= RXR_PROJ_SMALL_MAX && P->n_prims <= RXR_PROJ_SMALL_MAX) {
+        hipLaunchKernelGGL(k_proj2d_small, dim3(1), dim3(256), 0, s, *P);
+        return;
+    }
     hipLaunchKernelGGL(k_proj2d_init, dim3((P->n_meshes + 255u) / 256u + 1u), dim3(256), 0, s, *P);
     if (P->n_verts) hipLaunchKernelGGL(k_proj2d_bbox, dim3((P->n_verts + 255u) / 256u), dim3(256), 0, s, *P);
     if (P->n_prims) hipLaunchKernelGGL(k_proj2d_prims, dim3((P->n_prims + 255u) / 256u), dim3(256), 0, s, *P);
