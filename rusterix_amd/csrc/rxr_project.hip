@@ -127,6 +127,62 @@ __device__ __forceinline__ void bbox_add_wave(DevBBox *boxes, uint32_t b, bool a
     }
 }
 
+// The same one level up, for kernels whose WORKGROUPS almost always lie inside one mesh (k_proj_vertices: a mesh of the 1 M-triangle
+// grid is 27 workgroups): the four waves' partial boxes meet in LDS and ONE lane issues the atomics for every run of waves with the same
+// mesh -- a quarter of the same-line atomics that are this kernel's run time.  Must be called by every thread of the workgroup
+// (a barrier inside); `active` marks lanes that carry a vertex of mesh `b`.
+__device__ __forceinline__ void bbox_add_block(DevBBox *boxes, uint32_t b, bool active, float x, float y) {
+    __shared__ uint32_t s_part[4][5];   // per wave: mesh (0xFFFFFFFF: nothing to merge), min_x, max_x, min_y, max_y (encoded)
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const unsigned long long act = __ballot(active);
+    uint32_t mesh = 0xFFFFFFFFu, mnx = 0xFFFFFFFFu, mxx = 0u, mny = 0xFFFFFFFFu, mxy = 0u;
+    if (act) {  // wave-uniform
+        const uint32_t b0 = __shfl(b, __ffsll((long long)act) - 1, 64);
+        if (__ballot(active && b != b0) != 0ull) {  // a mesh boundary inside the wave: plain per-lane atomics
+            if (active) bbox_add(&boxes[b], x, y);
+        } else {
+            mesh = b0;
+            mnx = (active && x == x) ? enc(x) : 0xFFFFFFFFu; mxx = (active && x == x) ? enc(x) : 0u;
+            mny = (active && y == y) ? enc(y) : 0xFFFFFFFFu; mxy = (active && y == y) ? enc(y) : 0u;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                mnx = min(mnx, (uint32_t)__shfl_xor((int)mnx, d, 64));
+                mxx = max(mxx, (uint32_t)__shfl_xor((int)mxx, d, 64));
+                mny = min(mny, (uint32_t)__shfl_xor((int)mny, d, 64));
+                mxy = max(mxy, (uint32_t)__shfl_xor((int)mxy, d, 64));
+            }
+        }
+    }
+    if (lane == 0u) {
+        s_part[wave][0] = mesh; s_part[wave][1] = mnx; s_part[wave][2] = mxx; s_part[wave][3] = mny; s_part[wave][4] = mxy;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0u) {
+        uint32_t cur = 0xFFFFFFFFu, a = 0xFFFFFFFFu, c = 0u, e = 0xFFFFFFFFu, g = 0u;
+        auto flush = [&]() {
+            if (cur == 0xFFFFFFFFu) return;
+            DevBBox *bb = &boxes[cur];
+            // neutral values mean "no finite-or-infinite coordinate seen": skip them (the box keeps +-inf)
+            if (a != 0xFFFFFFFFu) atomicMin(&bb->min_x, a);
+            if (c != 0u) atomicMax(&bb->max_x, c);
+            if (e != 0xFFFFFFFFu) atomicMin(&bb->min_y, e);
+            if (g != 0u) atomicMax(&bb->max_y, g);
+        };
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const uint32_t m = s_part[w][0];
+            if (m == 0xFFFFFFFFu) continue;
+            if (m != cur) {
+                flush();
+                cur = m; a = 0xFFFFFFFFu; c = 0u; e = 0xFFFFFFFFu; g = 0u;
+            }
+            a = min(a, s_part[w][1]); c = max(c, s_part[w][2]); e = min(e, s_part[w][3]); g = max(g, s_part[w][4]);
+        }
+        flush();
+    }
+    __syncthreads();  // (s_part is rewritten by the caller's next round)
+}
+
 struct Clip {
     int nv;            // emitted vertices (0, 3 or 4)
     bool edge_vis;     // edge_visibility[triangle] (:582-618)
@@ -192,7 +248,7 @@ extern "C" __global__ void __launch_bounds__(256) k_proj_init(ProjectParams P) {
 
 // per frame: view transform (:555-560) and screen projection (:689-700) of the ORIGINAL vertices
 namespace {
-// (called by whole waves whose lanes hold consecutive items: find_mesh_wave, bbox_add_wave)
+// (called by whole workgroups whose threads hold consecutive items: find_mesh_wave, bbox_add_block)
 __device__ __forceinline__ void proj_vertices_item(const ProjectParams &P, uint32_t i) {
     bool active = i < P.n_verts_in;
     uint32_t b = 0;
@@ -209,7 +265,7 @@ __device__ __forceinline__ void proj_vertices_item(const ProjectParams &P, uint3
             P.pv[o] = s;
         }
     }
-    if (__ballot(active) != 0ull) bbox_add_wave(P.bbox, b, active, s.x, s.y);  // wave-uniform call
+    bbox_add_block(P.bbox, b, active, s.x, s.y);  // (every thread of the workgroup)
 }
 }  // namespace
 extern "C" __global__ void __launch_bounds__(256) k_proj_vertices(ProjectParams P) { proj_vertices_item(P, blockIdx.x * blockDim.x + threadIdx.x); }
