@@ -778,7 +778,12 @@ static int stream_begin(rxr_ctx *ctx, uint32_t n_batches3d, const uint32_t *vert
     S.done.reset(new std::atomic<uint8_t>[n_batches3d]);
     for (uint32_t i = 0; i < n_batches3d; ++i) S.done[i].store(0, std::memory_order_relaxed);
     // few, large transfers (every hipMemcpyAsync costs its caller ~20 us): eight groups of consecutive batches
-    S.group_size = std::max<uint32_t>(1u, (n_batches3d + 7u) / 8u);
+    static const uint32_t n_groups_wanted = []() {
+        const char *e = getenv("RXR_STREAM_GROUPS");   // (tuning: tools/e2e_probe.py)
+        const int v = e ? atoi(e) : 0;
+        return (uint32_t)(v >= 1 && v <= 256 ? v : 8);
+    }();
+    S.group_size = std::max<uint32_t>(1u, (n_batches3d + n_groups_wanted - 1u) / n_groups_wanted);
     S.n_groups = (n_batches3d + S.group_size - 1u) / S.group_size;
     S.group_left.reset(new std::atomic<uint32_t>[S.n_groups]);
     for (uint32_t g = 0; g < S.n_groups; ++g) S.group_left[g].store(std::min(S.group_size, n_batches3d - g * S.group_size), std::memory_order_relaxed);
