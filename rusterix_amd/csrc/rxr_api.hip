@@ -1304,7 +1304,8 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
     // batches are cut into groups of consecutive batches of ~8 MB; the workers copy batch after batch, and the calling thread ships
     // the five array ranges of a group (vertices, uvs, normals, indices, edges: contiguous per group in each pool) as soon as the
     // group's last batch has landed -- the PCIe transfer of group g runs under the copies of the groups behind it.  Measured
-    // (profiles/r03/c5_e2e_*): the hand-over of that frame 3.6 -> 2.x ms.  RXR_UPLOAD_PIPELINE=0 keeps one copy at the end.
+    // (profiles/r03/c5_e2e_breakdown.jsonl): the whole call 14.1 -> 10.6 ms together with the wider worker pool (the hand-over alone 2.6 ms
+    // either way on 64 threads: what the pipeline hides is the transfer, 124 MB at 50 GB/s).  RXR_UPLOAD_PIPELINE=0 keeps one copy at the end.
     struct ShipGroup {
         size_t v0, v1, t0, t1;
         std::atomic<uint32_t> left{0};
