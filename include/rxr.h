@@ -20,6 +20,11 @@
  *   - `usize` indices of the reference are u32 here (the shim asserts < 2^32).
  *   - structs carry no implicit ownership: the caller keeps every buffer alive until the call
  *     returns; the library copies what it needs.
+ *   - threads: a context (and a multi-device handle with its members) is used by one thread at a time -- the one exception is
+ *     rxr_stream_batch3d, which any number of threads may call on the same context between rxr_stream_begin and
+ *     rxr_upload_frame.  Different contexts are independent: threads that each own their contexts need no lock between them, on
+ *     one GPU or several (what the library shares process-wide, the run-time compiler's cache and job table, it guards itself;
+ *     tests/abi_threads.c).
  */
 #ifndef RXR_H
 #define RXR_H

@@ -28,6 +28,19 @@ def test_streamed_frames_equal_the_plain_upload(tmp_path):
     assert "pulled by the device" in run.stdout  # the page-locked cases ran
 
 
+def test_contexts_of_different_threads_do_not_meet(tmp_path):
+    """tests/abi_threads.c: four host threads, each with a plain and a two-member context of its own on the one GPU, render their own
+    frames at the same time (plain uploads, streamed hand-overs): every frame is the frame the main thread rendered alone"""
+    lib = rusterix_amd.lib_paths()["rxr"]
+    exe = str(tmp_path / "abi_threads")
+    cc = subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-pthread", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "abi_threads.c"),
+                         "-o", exe, "-L" + os.path.dirname(lib), "-lrxr_hip", "-Wl,-rpath," + os.path.dirname(lib)], capture_output=True, text=True)
+    assert cc.returncode == 0, cc.stderr
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0 and run.stdout.strip().endswith("ok"), run.stdout[-6000:] + run.stderr[-2000:]
+    assert run.stdout.count("40 frames, 0 failures") == 4
+
+
 @pytest.mark.parametrize("mode", ["pinned", "copy", "off"])
 def test_host_mirror_streams_a_projected_scene(oracle, product, monkeypatch, mode):
     """Rasterizer::rasterize of the host mirror hands every 3D batch over while the others are still being projected (forced here onto
