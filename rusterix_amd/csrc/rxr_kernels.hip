@@ -1155,6 +1155,23 @@ __device__ __forceinline__ bool make_setup(const RasterParams &P, uint32_t t, Tr
         for (int k = 0; k < 3; ++k) H.n0[k] = H.n1[k] = H.n2[k] = 0.0f;
     }
     H.pad[0] = H.pad[1] = 0;
+    // Bilinear sampling turns a NaN texture coordinate into NaN in EVERY channel (texture.rs:414-460: v00 + dx * (v10 - v00)), alpha
+    // included, and `NaN as u8` is 0: such a fragment is not written (:1408) even when every texel of its texture is opaque -- the one
+    // case in which a batch without DB_ALPHA_TEST needs the per-fragment test all the same.  A coordinate is NaN only when the
+    // perspective terms misbehave (a vertex on the eye plane: 1 / w = inf, uv / w = inf or NaN; 1 / w of both signs: the interpolated
+    // 1 / w can vanish; a ratio beyond 2^20 between them: the quotient can overflow), so the TRIANGLE carries the flag: it then walks
+    // with the cut-outs and its fragments are sampled in the visibility pass.  (Nearest sampling reads a texel for any coordinate.)
+    if (P.sample_mode != RXR_SAMPLE_NEAREST && B.tex >= 0 && !(S.bflags & (DB_ALPHA_TEST | DB_FULL_ALPHA | DB_OPACITY_LIST))) {
+        const float t9[9] = {H.iw0, H.iw1, H.iw2, H.u0w, H.u1w, H.u2w, H.v0w, H.v1w, H.v2w};
+        bool risky = false;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) risky = risky || !(__builtin_fabsf(t9[k]) < __builtin_huge_valf());   // inf or NaN
+        const float lo = fminf(__builtin_fabsf(H.iw0), fminf(__builtin_fabsf(H.iw1), __builtin_fabsf(H.iw2)));
+        const float hi = fmaxf(__builtin_fabsf(H.iw0), fmaxf(__builtin_fabsf(H.iw1), __builtin_fabsf(H.iw2)));
+        const bool same_sign = (H.iw0 > 0.0f && H.iw1 > 0.0f && H.iw2 > 0.0f) || (H.iw0 < 0.0f && H.iw1 < 0.0f && H.iw2 < 0.0f);
+        risky = risky || !same_sign || !(hi <= lo * 1048576.0f);
+        if (risky) S.bflags |= DB_ALPHA_TEST;
+    }
 
     // clamped pixel box, rasterizer.rs:998-1017 with the tile replaced by (whole width) x (row band)
     float min_xf = fminf(v0.x, fminf(v1.x, v2.x)), max_xf = fmaxf(v0.x, fmaxf(v1.x, v2.x));

@@ -368,10 +368,23 @@ __device__ __forceinline__ AppendCount prefix_at(const ProjectParams &P, uint32_
 // per frame: Sutherland-Hodgman against z = -0.1 for the mixed triangles, appended vertices and fan
 // triangles written at their scanned offsets (:626-686), new vertices projected (:689-700)
 namespace {
+// per mesh: how many of its 3 * n_tris triangle slots are in use (the pools are capacity based: an unclipped scene leaves two thirds
+// of them unused) -- written by the thread of the mesh's FIRST triangle in k_clip_emit (a mesh without triangles has no slots)
+__device__ __forceinline__ void proj_live_item(const ProjectParams &P, uint32_t b) {
+    if (b >= P.n_meshes) return;
+    const DevMesh &M = P.meshes[b];
+    uint32_t live = 0;
+    if (!M.rejected) {
+        const AppendCount tot = prefix_at(P, M.tin_base + M.n_tris) - prefix_at(P, M.tin_base);
+        live = M.n_tris + (uint32_t)(tot >> 32);
+    }
+    P.mesh_live[b] = live;
+}
 __device__ __forceinline__ void clip_emit_item(const ProjectParams &P, uint32_t t) {
     if (t >= P.n_tris_in) return;
     uint32_t b = find_mesh_wave(P.tin_prefix, P.n_meshes, t);
     const DevMesh &M = P.meshes[b];
+    if (t == M.tin_base) proj_live_item(P, b);
     if (M.rejected) return;
     const uint32_t *ix = P.obj_idx + 3 * (size_t)t;
     const uint32_t gi[3] = {M.vout_base + ix[0], M.vout_base + ix[1], M.vout_base + ix[2]};
@@ -464,19 +477,6 @@ __device__ __forceinline__ rxr_edges edges_of_slot(const ProjectParams &P, uint3
     const float4 v0 = P.pv[M.vout_base + ix[0]], v1 = P.pv[M.vout_base + ix[1]], v2 = P.pv[M.vout_base + ix[2]];
     return edges_from_vertices(M.cull_mode, evis, v0, v1, v2);
 }
-// per frame, one thread per mesh: how many of its 3 * n_tris triangle slots are in use (the pools are capacity based: an
-// unclipped scene leaves two thirds of them unused)
-__device__ __forceinline__ void proj_live_item(const ProjectParams &P, uint32_t b) {
-    if (b >= P.n_meshes) return;
-    const DevMesh &M = P.meshes[b];
-    uint32_t live = 0;
-    if (!M.rejected) {
-        const AppendCount tot = prefix_at(P, M.tin_base + M.n_tris) - prefix_at(P, M.tin_base);
-        live = M.n_tris + (uint32_t)(tot >> 32);
-    }
-    P.mesh_live[b] = live;
-}
-extern "C" __global__ void __launch_bounds__(256) k_proj_live(ProjectParams P) { proj_live_item(P, blockIdx.x * blockDim.x + threadIdx.x); }
 
 // Small frames (RXR_PROJ_SMALL_MAX original vertices and triangles): every step above in ONE workgroup -- the six dependent launches
 // of rxr_launch_project cost a map or a teapot ~5 us each, several times the work in them.  The same item functions in the same
@@ -522,9 +522,7 @@ extern "C" __global__ void __launch_bounds__(256) k_proj_small(ProjectParams P) 
     }
     if (tid == 0) P.chunk_base[0] = 0ull;
     __syncthreads();
-    for (uint32_t b = tid; b < P.n_meshes; b += 256u) proj_live_item(P, b);
-    __syncthreads();
-    for (uint32_t t = tid; t < ((P.n_tris_in + 255u) & ~255u); t += 256u) clip_emit_item(P, t);
+    for (uint32_t t = tid; t < ((P.n_tris_in + 255u) & ~255u); t += 256u) clip_emit_item(P, t);   // (+ the meshes' live slot counts)
 }
 
 // The 40-byte records leave through LDS as the workgroup's contiguous 10 KB block (see k_setup3d in rxr_kernels.hip).
@@ -575,7 +573,6 @@ extern "C" void rxr_launch_project(const ProjectParams *P, hipStream_t s) {
     uint32_t nt1 = P->n_tris_in + 1u;
     hipLaunchKernelGGL(k_clip_count, dim3((nt1 + 255u) / 256u), dim3(256), 0, s, *P);
     hipLaunchKernelGGL(k_proj_scan, dim3((nt1 + RXR_PROJ_SCAN_CHUNK - 1u) / RXR_PROJ_SCAN_CHUNK), dim3(256), 0, s, *P);
-    hipLaunchKernelGGL(k_proj_live, dim3((P->n_meshes + 255u) / 256u), dim3(256), 0, s, *P);
     if (P->n_tris_in) hipLaunchKernelGGL(k_clip_emit, dim3((P->n_tris_in + 255u) / 256u), dim3(256), 0, s, *P);
     if (P->n_tris_out && !P->edges_in_setup) hipLaunchKernelGGL(k_proj_edges, dim3((P->n_tris_out + 255u) / 256u), dim3(256), 0, s, *P);
 }

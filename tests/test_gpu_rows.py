@@ -91,6 +91,24 @@ def test_small_triangle_meshes(oracle, product, variant, seed):
     assert (got[..., :3].max(axis=2) > 0).mean() > 0.05, "the scene did not produce a picture"
 
 
+@pytest.mark.parametrize("device_projection", [False, True])
+def test_a_nan_texture_coordinate_under_bilinear_sampling_is_not_written(oracle, product, device_projection):
+    """Seed 48135 of the wide fuzz sweep (tools/fuzz_sweep.py, found in round 3 after ~4 000 clean seeds): a triangle with a vertex on
+    the eye plane has 1 / w = inf, its interpolated uv is NaN, and bilinear sampling turns NaN into NaN in EVERY channel -- alpha
+    included, `NaN as u8` = 0 -- so the reference does not write the fragment (rasterizer.rs:1408) although every texel of the
+    texture is opaque.  The device used to take 'all texels opaque' for 'alpha is 255' and wrote [0, 0, 0, 0] there; such triangles
+    now carry the per-fragment alpha test (make_setup, rxr_kernels.hip)."""
+    product.lib.rxh_set_device_projection.argtypes = [C.c_int]
+    product.lib.rxh_set_device_projection(1 if device_projection else 0)
+    try:
+        got = scenes.render(build(product, 48135, 203, 131, "mixed"))
+    finally:
+        product.lib.rxh_set_device_projection(0)
+    ref = scenes.render(build(oracle, 48135, 203, 131, "mixed"))
+    assert ref[107, 127].tolist() == [0, 0, 0, 255]   # (the pixel that showed it: nothing is written there)
+    assert np.array_equal(got, ref), f"{(got != ref).any(axis=2).sum()} pixels differ; first at {np.argwhere((got != ref).any(axis=2))[:3].tolist()}"
+
+
 def test_exact_ties_go_to_the_first_submission(oracle, product):
     """two identical meshes in two colours: every fragment of the second has the same z as the first's, so nothing of the
     second colour may show (rasterizer.rs:1060: `z < z_buffer` is strict) -- in row mode that is the index half of the key"""
