@@ -20,6 +20,13 @@
 #include "../include/rxr.h"
 
 namespace orc {
+// f32::min / f32::max: a NaN operand is dropped; for operands that compare EQUAL (+0.0 and -0.0) Rust documents "either may be
+// returned".  What rustc's x86-64 back end returns is fixed, though: llvm.minnum / llvm.maxnum lower to MINSS / MAXSS with the operands
+// swapped plus a select on the first operand's NaN-ness ("Max = Op1 > Op0 ? Op1 : Op0", X86ISelLowering.cpp combineFMinNumFMaxNum):
+// ties return `self`.  glibc's fmin / fmax return the OTHER operand there, the GPU's v_max_f32 always +0 -- the sign of a zero shows
+// as soon as a program divides by it (found by the fuzz sweep, seed 52871: Max(0.0, -0.0) as a divisor).
+inline float rmin(float a, float b) { return a != a ? b : (b < a ? b : a); }
+inline float rmax(float a, float b) { return a != a ? b : (b > a ? b : a); }
 namespace vm {
 
 using rvek::Vec3;
@@ -321,8 +328,8 @@ struct Execution {
                 }
                 case RXR_NODE_RADIANS: { Vec3 a = pop(); push(map(a, [](float x) { return x * (3.14159265358979323846f / 180.0f); })); break; }
                 case RXR_NODE_DEGREES: { Vec3 a = pop(); push(map(a, [](float x) { return x * 57.2957795130823208767981548141051703f; })); break; }
-                case RXR_NODE_MIN: { Vec3 b = pop(), a = pop(); push(Vec3{std::fmin(a.x, b.x), std::fmin(a.y, b.y), std::fmin(a.z, b.z)}); break; }
-                case RXR_NODE_MAX: { Vec3 b = pop(), a = pop(); push(Vec3{std::fmax(a.x, b.x), std::fmax(a.y, b.y), std::fmax(a.z, b.z)}); break; }
+                case RXR_NODE_MIN: { Vec3 b = pop(), a = pop(); push(Vec3{rmin(a.x, b.x), rmin(a.y, b.y), rmin(a.z, b.z)}); break; }   // (execution.rs:439-444: a.x.min(b.x); ties return a, rusterix_oracle.hpp)
+                case RXR_NODE_MAX: { Vec3 b = pop(), a = pop(); push(Vec3{rmax(a.x, b.x), rmax(a.y, b.y), rmax(a.z, b.z)}); break; }
                 case RXR_NODE_MIX: {  // :449-455: a + (b - a) * c
                     Vec3 c = pop(), b = pop(), a = pop();
                     push(Vec3{a.x + (b.x - a.x) * c.x, a.y + (b.y - a.y) * c.y, a.z + (b.z - a.z) * c.z});

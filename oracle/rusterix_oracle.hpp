@@ -36,8 +36,7 @@ using rvek::Vec4;
 typedef uint8_t Pixel[4];
 
 // ---- Rust numeric semantics --------------------------------------------
-inline float rmin(float a, float b) { return std::fmin(a, b); }  // f32::min: drops NaN
-inline float rmax(float a, float b) { return std::fmax(a, b); }
+// (rmin / rmax -- f32::min / f32::max with the x86-64 tie rule -- live in rusteria_vm.hpp, which the VM needs them in)
 inline float rclamp(float x, float lo, float hi) { return rvek::rclamp(x, lo, hi); }  // keeps NaN
 inline uint64_t sat_usize(float x) {  // `x as usize`
     if (!(x == x)) return 0;

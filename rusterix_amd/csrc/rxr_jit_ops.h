@@ -48,8 +48,8 @@ __device__ __forceinline__ v3 jit_bin(v3 a, v3 b) {
     else if constexpr (OP == RXR_NODE_DOT3) return mk(a.x * b.x + a.y * b.y + a.z * b.z, 0.0f, 0.0f);
     else if constexpr (OP == RXR_NODE_CROSS) return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
     else if constexpr (OP == RXR_NODE_MOD) return mk(a.x - b.x * floorf(a.x / b.x), a.y - b.y * floorf(a.y / b.y), a.z - b.z * floorf(a.z / b.z));
-    else if constexpr (OP == RXR_NODE_MIN) return mk(fminf(a.x, b.x), fminf(a.y, b.y), fminf(a.z, b.z));
-    else if constexpr (OP == RXR_NODE_MAX) return mk(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z));
+    else if constexpr (OP == RXR_NODE_MIN) return mk(rust_min(a.x, b.x), rust_min(a.y, b.y), rust_min(a.z, b.z));
+    else if constexpr (OP == RXR_NODE_MAX) return mk(rust_max(a.x, b.x), rust_max(a.y, b.y), rust_max(a.z, b.z));
     else if constexpr (OP == RXR_NODE_STEP) return mk(b.x >= a.x ? 1.0f : 0.0f, b.y >= a.y ? 1.0f : 0.0f, b.z >= a.z ? 1.0f : 0.0f);
     else if constexpr (OP == RXR_NODE_EQ) return splat(a.x == b.x ? 1.0f : 0.0f);
     else if constexpr (OP == RXR_NODE_NE) return splat(a.x != b.x ? 1.0f : 0.0f);
@@ -87,8 +87,8 @@ __device__ __forceinline__ v3 jit_binc(v3 a, v3 b) {
     else if constexpr (WHICH == VM_BINC_SUB) return mk(a.x - b.x, a.y - b.y, a.z - b.z);
     else if constexpr (WHICH == VM_BINC_MUL) return mk(a.x * b.x, a.y * b.y, a.z * b.z);
     else if constexpr (WHICH == VM_BINC_DIV) return mk(a.x / b.x, a.y / b.y, a.z / b.z);
-    else if constexpr (WHICH == VM_BINC_MIN) return mk(fminf(a.x, b.x), fminf(a.y, b.y), fminf(a.z, b.z));
-    else if constexpr (WHICH == VM_BINC_MAX) return mk(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z));
+    else if constexpr (WHICH == VM_BINC_MIN) return mk(rust_min(a.x, b.x), rust_min(a.y, b.y), rust_min(a.z, b.z));
+    else if constexpr (WHICH == VM_BINC_MAX) return mk(rust_max(a.x, b.x), rust_max(a.y, b.y), rust_max(a.z, b.z));
     else if constexpr (WHICH == VM_BINC_MOD) return mk(a.x - b.x * floorf(a.x / b.x), a.y - b.y * floorf(a.y / b.y), a.z - b.z * floorf(a.z / b.z));
     else if constexpr (WHICH == VM_BINC_LT) return splat(a.x < b.x ? 1.0f : 0.0f);
     else if constexpr (WHICH == VM_BINC_LE) return splat(a.x <= b.x ? 1.0f : 0.0f);

@@ -66,6 +66,11 @@ __device__ __forceinline__ v3 pattern_sample(const RasterParams &P, const DevPat
     return mk(p[0], p[1], p[2]);
 }
 __device__ __forceinline__ float rclampf(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
+// f32::min / f32::max as rustc's x86-64 back end compiles them (oracle/rusterix_oracle.hpp rmin / rmax): a NaN operand is dropped and
+// operands that compare equal -- +0.0 and -0.0 -- return the FIRST one.  v_min_f32 / v_max_f32 order the zeros instead; a program that
+// divides by the result sees the difference.
+__device__ __forceinline__ float rust_min(float a, float b) { return a != a ? b : (b < a ? b : a); }
+__device__ __forceinline__ float rust_max(float a, float b) { return a != a ? b : (b > a ? b : a); }
 
 #ifndef RXR_JIT
 // ---- the interpreter ------------------------------------------------------------------------------
@@ -472,8 +477,8 @@ __device__ __forceinline__ uint32_t shade_inline(const RasterParams &P, uint32_t
                         case VM_BINC_SUB: r = mk(a.x - b.x, a.y - b.y, a.z - b.z); break;
                         case VM_BINC_MUL: r = mk(a.x * b.x, a.y * b.y, a.z * b.z); break;
                         case VM_BINC_DIV: r = mk(a.x / b.x, a.y / b.y, a.z / b.z); break;
-                        case VM_BINC_MIN: r = mk(fminf(a.x, b.x), fminf(a.y, b.y), fminf(a.z, b.z)); break;
-                        case VM_BINC_MAX: r = mk(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z)); break;
+                        case VM_BINC_MIN: r = mk(rust_min(a.x, b.x), rust_min(a.y, b.y), rust_min(a.z, b.z)); break;
+                        case VM_BINC_MAX: r = mk(rust_max(a.x, b.x), rust_max(a.y, b.y), rust_max(a.z, b.z)); break;
                         case VM_BINC_MOD: r = mk(a.x - b.x * floorf(a.x / b.x), a.y - b.y * floorf(a.y / b.y), a.z - b.z * floorf(a.z / b.z)); break;
                         case VM_BINC_LT: r = splat(a.x < b.x ? 1.0f : 0.0f); break;
                         case VM_BINC_LE: r = splat(a.x <= b.x ? 1.0f : 0.0f); break;
@@ -659,8 +664,8 @@ __device__ __forceinline__ uint32_t shade_inline(const RasterParams &P, uint32_t
             case RXR_NODE_MOD: VM_BIN(mk(a.x - b.x * floorf(a.x / b.x), a.y - b.y * floorf(a.y / b.y), a.z - b.z * floorf(a.z / b.z)))
             case RXR_NODE_RADIANS: VM_UN(mk(a.x * (3.14159265358979323846f / 180.0f), a.y * (3.14159265358979323846f / 180.0f), a.z * (3.14159265358979323846f / 180.0f)))
             case RXR_NODE_DEGREES: VM_UN(mk(a.x * 57.2957795130823208767981548141051703f, a.y * 57.2957795130823208767981548141051703f, a.z * 57.2957795130823208767981548141051703f))
-            case RXR_NODE_MIN: VM_BIN(mk(fminf(a.x, b.x), fminf(a.y, b.y), fminf(a.z, b.z)))
-            case RXR_NODE_MAX: VM_BIN(mk(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z)))
+            case RXR_NODE_MIN: VM_BIN(mk(rust_min(a.x, b.x), rust_min(a.y, b.y), rust_min(a.z, b.z)))
+            case RXR_NODE_MAX: VM_BIN(mk(rust_max(a.x, b.x), rust_max(a.y, b.y), rust_max(a.z, b.z)))
             case RXR_NODE_MIX: VM_TER(mk(a.x + (b.x - a.x) * c.x, a.y + (b.y - a.y) * c.y, a.z + (b.z - a.z) * c.z))
             case RXR_NODE_SMOOTHSTEP:  // :456-474: a = edge0, b = edge1, c = x
                 if (on) {

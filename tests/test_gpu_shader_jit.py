@@ -186,6 +186,22 @@ def test_recursive_programs_are_compiled_as_one_copy_per_call_depth(oracle, prod
     assert len(np.unique(got.reshape(-1, 4), axis=0)) > 12
 
 
+def test_min_and_max_of_signed_zeros_return_the_first_operand(oracle, product, monkeypatch):
+    """f32::min / f32::max of +0.0 and -0.0 ("either may be returned" in Rust's documentation; `self` in what rustc's x86-64 back end
+    emits): the sign shows when a program divides by the result.  Found by the fuzz sweep (seed 52871): the device's v_max_f32 orders
+    the zeros, glibc's fmax returns the other operand -- oracle and device now both follow the x86 lowering.  Variables and fused
+    constants ("Push c; op"), both orders."""
+    z = lambda s: ["UV", ("GetComponents", [0]), ("Push", 0.0), "Mul", ("Push", s), "Mul"]   # a run-time zero of either sign (uv.x * 0 * (+-1))
+    programs = []
+    for op in ("Min", "Max"):
+        for sa in (1.0, -1.0):
+            for sb in (1.0, -1.0):
+                programs.append(Program([[("Push", 1.0)] + z(sa) + z(sb) + [op, "Div", ("Push", 1e-30), "Mul", ("Push", 0.5), "Add", "SetColor"]]))          # 1 / op(a, b): +-inf -> 1 or 0
+                programs.append(Program([[("Push", 1.0)] + z(sa) + [("Push", 0.0 * sb), op, "Div", ("Push", 1e-30), "Mul", ("Push", 0.5), "Add", "SetColor"]]))  # the fused-constant form
+    got, _ = three_ways(oracle, product, monkeypatch, lambda api: grid_scene(api, programs))
+    assert len(np.unique(got.reshape(-1, 4), axis=0)) >= 2   # both signs occur
+
+
 def random_recursive_program(seed):
     """a random program (S.ProgramGen: two helper functions) plus a self-recursive function R(n, x) -- early exit at n <= 0, a random
     block, R(n - 1, <random>), a random combination -- called from `shade` with n = 0 .. 2 by pixel.  R may call the helpers; frames
