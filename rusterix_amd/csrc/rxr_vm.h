@@ -69,8 +69,13 @@ __device__ __forceinline__ float rclampf(float x, float lo, float hi) { return x
 // f32::min / f32::max as rustc's x86-64 back end compiles them (oracle/rusterix_oracle.hpp rmin / rmax): a NaN operand is dropped and
 // operands that compare equal -- +0.0 and -0.0 -- return the FIRST one.  v_min_f32 / v_max_f32 order the zeros instead; a program that
 // divides by the result sees the difference.
+#ifdef RXR_TEST_PLAIN_MINMAX   // (a build that undoes the rule: tests/test_gpu_shader_edge_values.py must notice)
+__device__ __forceinline__ float rust_min(float a, float b) { return fminf(a, b); }
+__device__ __forceinline__ float rust_max(float a, float b) { return fmaxf(a, b); }
+#else
 __device__ __forceinline__ float rust_min(float a, float b) { return a != a ? b : (b < a ? b : a); }
 __device__ __forceinline__ float rust_max(float a, float b) { return a != a ? b : (b > a ? b : a); }
+#endif
 
 #ifndef RXR_JIT
 // ---- the interpreter ------------------------------------------------------------------------------
