@@ -1170,7 +1170,9 @@ __device__ __forceinline__ bool make_setup(const RasterParams &P, uint32_t t, Tr
         const float hi = fmaxf(__builtin_fabsf(H.iw0), fmaxf(__builtin_fabsf(H.iw1), __builtin_fabsf(H.iw2)));
         const bool same_sign = (H.iw0 > 0.0f && H.iw1 > 0.0f && H.iw2 > 0.0f) || (H.iw0 < 0.0f && H.iw1 < 0.0f && H.iw2 < 0.0f);
         risky = risky || !same_sign || !(hi <= lo * 1048576.0f);
+#ifndef RXR_TEST_NO_NAN_UV_RULE   // (a build that undoes the rule: tests/test_gpu_special_inputs.py and the seed in tests/test_gpu_rows.py must notice)
         if (risky) S.bflags |= DB_ALPHA_TEST;
+#endif
     }
 
     // clamped pixel box, rasterizer.rs:998-1017 with the tile replaced by (whole width) x (row band)

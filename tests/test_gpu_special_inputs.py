@@ -1,0 +1,71 @@
+"""Special values IN THE SCENE -- NaN, +-inf, +-0, a denormal, the largest float in a vertex position or a texture coordinate of one
+triangle after the other -- through the whole path (projection, clipping, set-up, visibility, sampling) against the oracle, bit for
+bit: Nearest and Linear sampling, every repeat mode, opaque and cut-out textures, host- and device-projected.  The wide fuzz sweep
+found the NaN-coordinate rule of bilinear sampling (tests/test_gpu_rows.py) after ~4 000 seeds; this builds such triangles on purpose."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from rusterix_amd import binding as B
+from rusterix_amd import scenes
+from tests.test_gpu_fuzz import random_texture
+
+pytestmark = pytest.mark.gpu
+
+SPECIALS = [float("nan"), float("inf"), float("-inf"), 0.0, -0.0, 1e-40, 3.0e38, -3.0e38]
+W, H = 208, 144
+
+
+def build(api, sample_mode, repeat_mode, cutout, seed=7):
+    rng = np.random.default_rng([0x52585231, 606, seed])
+    textures = [B.Tile([random_texture(rng, 9, 7, 0)]), B.Tile([random_texture(rng, 8, 8, 2)])]
+    assets = api.Assets.default().textures(textures)
+    scene = api.Scene.empty()
+    # a backdrop far away, so that a fragment that must NOT be written shows as the backdrop and not as the miss colour
+    back = np.array([[-9, -7, -6.0, 1], [9, -7, -6.0, 1], [9, 7, -6.0, 1], [-9, 7, -6.0, 1]], np.float32)
+    b = api.Batch3D.new(back, np.array([[0, 1, 2], [0, 2, 3]], np.uint32), np.array([[0, 0], [3, 0], [3, 3], [0, 3]], np.float32)).with_computed_normals().cull_mode(0)
+    b.source(B.PixelSource.Pixel((40, 90, 160, 255))).ambient_color((1.0, 1.0, 1.0))
+    scene.add_d3_static(b)
+    # one batch per (field, special): a triangle of ordinary size with ONE poisoned number
+    k = 0
+    for field in range(5):                       # x, y, z of vertex 1; u, v of vertex 2
+        for s in SPECIALS:
+            cx, cy = -2.6 + 0.75 * (k % 8), -1.6 + 0.8 * (k // 8)
+            v = np.array([[cx, cy, -1.0 - 0.05 * k, 1], [cx + 0.6, cy + 0.1, -1.2 - 0.05 * k, 1], [cx + 0.2, cy + 0.6, -0.9 - 0.05 * k, 1]], np.float32)
+            uv = np.array([[0.1, 0.2], [1.7, 0.3], [0.4, 1.9]], np.float32)
+            if field < 3:
+                v[1, field] = s
+            else:
+                uv[2, field - 3] = s
+            t = api.Batch3D.new(v, np.array([[0, 1, 2]], np.uint32), uv).with_computed_normals().cull_mode(0)
+            t.source(B.PixelSource.StaticTileIndex(1 if cutout else 0)).repeat_mode(repeat_mode).ambient_color((0.9, 0.8, 0.7))
+            scene.add_d3_static(t)
+            k += 1
+    cam = api.D3OrbitCamera.new()
+    cam.set_parameter_f32("distance", 3.0)
+    cam.azimuth = float(np.float32(np.pi / 2))
+    cam.elevation = 0.1
+
+    def setup():
+        v, p = cam.matrices(float(W), float(H))
+        return api.Rasterizer.setup(None, v, p).sample_mode(sample_mode).ambient((1.0, 1.0, 1.0, 1.0))
+
+    return scenes._result(api, scene, assets, setup, W, H, 40, "special-inputs")
+
+
+@pytest.mark.parametrize("device_projection", [False, True])
+@pytest.mark.parametrize("cutout", [False, True])
+@pytest.mark.parametrize("repeat_mode", [B.REPEAT_CLAMP_XY, B.REPEAT_REPEAT_XY, B.REPEAT_REPEAT_X, B.REPEAT_REPEAT_Y])
+@pytest.mark.parametrize("sample_mode", [B.SAMPLE_NEAREST, B.SAMPLE_LINEAR])
+def test_poisoned_triangles(oracle, product, sample_mode, repeat_mode, cutout, device_projection):
+    product.lib.rxh_set_device_projection.argtypes = [C.c_int]
+    product.lib.rxh_set_device_projection(1 if device_projection else 0)
+    try:
+        got = scenes.render(build(product, sample_mode, repeat_mode, cutout))
+    finally:
+        product.lib.rxh_set_device_projection(0)
+    ref = scenes.render(build(oracle, sample_mode, repeat_mode, cutout))
+    assert len(np.unique(ref.reshape(-1, 4), axis=0)) > 20   # the ordinary triangles are there
+    d = (got != ref).any(axis=2)
+    assert not d.any(), f"{int(d.sum())} pixels differ; first at {np.argwhere(d)[:3].tolist()}: device {got[tuple(np.argwhere(d)[0])].tolist()} oracle {ref[tuple(np.argwhere(d)[0])].tolist()}"
