@@ -1,0 +1,52 @@
+"""Lights with one poisoned parameter each -- NaN, +-inf, 0, a negative number, start == end, start > end, a zero-length direction -- of
+every light type, over a lit room, in both light-loop modes against the oracle: at most one 8-bit step per channel (the tolerance of
+lit 3D fragments), and not one pixel more off than with the clean light.  The relaxed loop multiplies where the reference branches;
+rxr_upload_frame sends frames with a non-finite light parameter through the exact loop, and the finite oddities (negative intensity,
+start > end) must come out of both loops the same."""
+import numpy as np
+import pytest
+
+from rusterix_amd import binding as B
+from rusterix_amd import scenes
+
+pytestmark = pytest.mark.gpu
+NAN, INF = float("nan"), float("inf")
+
+# (field, value)
+POISON = [("intensity", v) for v in (NAN, INF, -INF, 0.0, -2.0, 1e-40)] + \
+         [("start_distance", v) for v in (NAN, INF, -1.0, 5.0)] + [("end_distance", v) for v in (NAN, INF, 0.0, -3.0)] + \
+         [("position", (NAN, 1.0, 8.0)), ("position", (INF, 1.0, 8.0)), ("position", (6.0, 3.0e38, 8.0))] + \
+         [("color", (NAN, 1.0, 1.0)), ("color", (INF, 0.0, -1.0))] + [("flicker", v) for v in (NAN, INF, 0.5, -1.0)] + \
+         [("start==end", 4.0), ("start>end", 9.0)]
+TYPES = [B.LIGHT_POINT, B.LIGHT_SPOT, B.LIGHT_AREA, B.LIGHT_AMBIENT, B.LIGHT_DAYLIGHT]
+
+
+def build(api, light_type, field, value):
+    cfg = scenes.map_scene(api, width=320, height=180, n_lights=2, logo_size=16)
+    l = B.Light(light_type).with_position((7.0, 1.2, 8.0)).with_color((1.0, 0.8, 0.6)).with_intensity(1.5).with_start_distance(1.5).with_end_distance(7.0)
+    l.direction, l.normal, l.width, l.height = (0.2, -0.6, 0.7), (0.0, -1.0, 0.3), 2.0, 1.5
+    if field == "start==end":
+        l.start_distance = l.end_distance = value
+    elif field == "start>end":
+        l.start_distance, l.end_distance = value, 3.0
+    elif field is not None:
+        setattr(l, field, value)
+    cfg.scene.add_dynamic_light(l.compile())
+    return cfg
+
+
+@pytest.mark.parametrize("light_type", TYPES)
+@pytest.mark.parametrize("exact", [False, True])
+def test_poisoned_lights(oracle, product, light_type, exact):
+    product.lib.rxh_set_light_math_exact(1 if exact else 0)
+    try:
+        worst = []
+        for field, value in [(None, None)] + POISON:
+            got = scenes.render(build(product, light_type, field, value))
+            ref = scenes.render(build(oracle, light_type, field, value))
+            d = np.abs(got.astype(np.int16) - ref.astype(np.int16)).max(axis=2)
+            worst.append((int(d.max()), int((d > 0).sum()), field, value))
+            assert d.max() <= 1, f"light type {light_type}, {field} = {value}: {int((d > 1).sum())} pixels off by more than one step (max {int(d.max())}); first at {np.argwhere(d > 1)[:2].tolist()}"
+        assert max(w[1] for w in worst) <= 64, f"more pixels off by one than a clean light leaves: {sorted(worst, reverse=True)[:3]}"
+    finally:
+        product.lib.rxh_set_light_math_exact(0)
