@@ -111,11 +111,14 @@ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 uint32_t pack_px(const uint8_t p[4]) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
 
 // Rust `x as isize` narrowed to i32 for the Bresenham end points (rasterizer.rs:1785-1788);
-// coordinates beyond +-2^30 are rejected at upload (the walk would not terminate in a frame's time)
+// coordinates beyond +-2^30 are rejected at upload (the walk would not terminate in a frame's time), and so is NaN: `NaN as isize` is 0,
+// a point OUTSIDE the batch's bounding box (f32::min / max drop NaN, batch2d.rs:377-403), and the reference skips a batch for every
+// tile its box does not meet (:594-600) -- which pixels of such a segment it draws depends on its tile size (found by
+// tests/test_gpu_special_2d.py); the caller's CPU path draws it
 bool to_isize32(float x, int32_t &out) {
     if (!(x == x)) {
         out = 0;
-        return true;
+        return false;
     }
     if (x <= -1073741824.0f || x >= 1073741824.0f) return false;
     out = (int32_t)x;
@@ -1637,7 +1640,7 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
             } else {
                 for (uint32_t k = 0; k < b.n_vertices && ok; ++k) ok = push(k, (k + 1) % b.n_vertices);
             }
-            if (!ok) return fail(ctx, RXR_ERR_UNSUPPORTED, "batch2d: line end point beyond +-2^30");
+            if (!ok) return fail(ctx, RXR_ERR_UNSUPPORTED, "batch2d: line end point NaN or beyond +-2^30");
         }
     }
     if (f->background_kind == RXR_BG_HOST_PIXELS) memcpy(st + L.off_bg, f->background_pixels, (size_t)f->width * f->height * 4);
@@ -2254,7 +2257,7 @@ int rxr_synchronize(rxr_ctx *ctx) {
         }
         if (hc[HS_BAD_LINE2D]) {
             hc[HS_BAD_LINE2D] = 0;
-            return fail(ctx, RXR_ERR_UNSUPPORTED, "batch2d: line end point beyond +-2^30");
+            return fail(ctx, RXR_ERR_UNSUPPORTED, "batch2d: line end point NaN or beyond +-2^30");
         }
         if (hc[HS_STAIRCASE]) {
             hc[HS_STAIRCASE] = 0;

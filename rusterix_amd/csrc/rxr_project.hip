@@ -604,9 +604,9 @@ __device__ __forceinline__ uint32_t sat_px(float x, uint32_t hi) {
 }
 // Rust `x as isize` narrowed to i32 for the Bresenham end points (:1785-1788); false beyond +-2^30
 __device__ __forceinline__ bool to_isize32(float x, int32_t &out) {
-    if (!(x == x)) {
+    if (!(x == x)) {  // (NaN: refused like a coordinate out of range -- rxr_api.hip to_isize32 says why)
         out = 0;
-        return true;
+        return false;
     }
     if (x <= -1073741824.0f || x >= 1073741824.0f) return false;
     out = (int32_t)x;
