@@ -371,3 +371,15 @@ def test_brush_preview_on_terrain_texels_and_on_missed_pixels(oracle, product, b
 
 def test_brush_preview_with_lights_and_holes(oracle, product):
     compare(oracle, product, lambda api: terrain_scene(api, holes=True, brush=((3.0, 0.0, 5.0), 3.0, 0.4)), tol=TOLERANCE)
+
+
+NAN_, INF_ = float("nan"), float("inf")
+
+
+@pytest.mark.parametrize("brush", [((NAN_, 0.0, 4.0), 2.5, 0.5), ((4.0, INF_, 4.0), 2.5, 0.5), ((4.0, 0.0, 4.0), NAN_, 0.5), ((4.0, 0.0, 4.0), INF_, 0.5),
+                                   ((4.0, 0.0, 4.0), -1.0, 0.5), ((4.0, 0.0, 4.0), 2.5, NAN_), ((4.0, 0.0, 4.0), 2.5, INF_), ((4.0, 0.0, 4.0), 2.5, -3.0),
+                                   ((4.0, 0.0, 4.0), 1e-40, 1e-40), ((3.0e38, 0.0, -3.0e38), 3.0e38, 0.001)])
+def test_brush_preview_with_poisoned_parameters(oracle, product, brush):
+    """the brush disc with NaN / inf / negative / denormal position, radius and falloff (rasterizer.rs:1193-1212, :435-458): on terrain
+    texels and on missed pixels, bit for bit"""
+    compare(oracle, product, lambda api: terrain_scene(api, lights=False, brush=brush, under=False, opacity_terrain=True))
