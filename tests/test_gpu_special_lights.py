@@ -50,3 +50,44 @@ def test_poisoned_lights(oracle, product, light_type, exact):
         assert max(w[1] for w in worst) <= 64, f"more pixels off by one than a clean light leaves: {sorted(worst, reverse=True)[:3]}"
     finally:
         product.lib.rxh_set_light_math_exact(0)
+
+
+OCCLUSION = [((0.0, 9.0), (6.0, 15.0), NAN), ((0.0, 9.0), (6.0, 15.0), INF), ((0.0, 9.0), (6.0, 15.0), -0.5), ((0.0, 9.0), (6.0, 15.0), 0.0),
+             ((NAN, 9.0), (6.0, 15.0), 0.35), ((0.0, -INF), (INF, 15.0), 0.35), ((6.0, 15.0), (0.0, 9.0), 0.35), ((3.0, 9.0), (3.0, 9.0), 0.35)]
+LINEDEFS = [((NAN, 0.0), (6.0, 200.0)), ((6.0, -INF), (6.0, INF)), ((6.0, 8.0), (6.0, 8.0)), ((0.0, 0.0), (3.0e38, 3.0e38)), ((7.0, 0.0), (7.0, 20.0))]
+SUNS = [((NAN, -1.0, 0.2), 0.6), ((0.0, 0.0, 0.0), 0.6), ((0.3, -1.0, 0.2), NAN), ((0.3, -1.0, 0.2), INF), ((0.3, -1.0, 0.2), -1.0), ((INF, -1.0, 0.2), 0.6)]
+
+
+@pytest.mark.parametrize("exact", [False, True])
+def test_poisoned_occluders_linedefs_and_sun(oracle, product, exact):
+    """mapmini occluder boxes (NaN / inf / inverted / empty, NaN / negative occlusion), linedefs the area lights are tested against (NaN,
+    infinite, zero length), the sun's direction and day factor (NaN, zero vector, inf, negative): rasterizer.rs:1324-1365, light.rs:586-660"""
+    product.lib.rxh_set_light_math_exact(1 if exact else 0)
+    try:
+        cases = [("occluder", o) for o in OCCLUSION] + [("linedef", l) for l in LINEDEFS] + [("sun", s) for s in SUNS]
+        for kind, arg in cases:
+            def build(api):
+                cfg = scenes.map_scene(api, width=320, height=180, n_lights=3, logo_size=16)
+                al = B.Light(B.LIGHT_AREA).with_position((7.0, 1.0, 12.0)).with_color((0.9, 0.9, 1.0)).with_intensity(1.5).with_start_distance(1.0).with_end_distance(8.0)
+                al.normal, al.width, al.height, al.from_linedef = (0.0, 0.0, -1.0), 2.0, 1.0, True
+                cfg.scene.add_dynamic_light(al.compile())
+                base = cfg.setup
+
+                def setup():
+                    r = base()
+                    if kind == "occluder":
+                        r.mapmini_add_occluder(*arg)
+                    elif kind == "linedef":
+                        r.mapmini_add_linedef(*arg)
+                    else:
+                        r.sun(*arg)
+                    return r
+
+                cfg.setup = setup
+                return cfg
+
+            got, ref = scenes.render(build(product)), scenes.render(build(oracle))
+            d = np.abs(got.astype(np.int16) - ref.astype(np.int16)).max(axis=2)
+            assert d.max() <= 1 and (d > 0).sum() <= 64, f"{kind} {arg}: {int((d > 1).sum())} pixels beyond one step, {int((d > 0).sum())} differ (max {int(d.max())}); first at {np.argwhere(d > 0)[:2].tolist()}"
+    finally:
+        product.lib.rxh_set_light_math_exact(0)
