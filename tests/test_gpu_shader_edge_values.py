@@ -105,3 +105,32 @@ def test_binary_opcodes_on_special_operands(oracle, product, monkeypatch):
 
 def test_ternary_opcodes_on_special_operands(oracle, product, monkeypatch):
     run(oracle, product, monkeypatch, TERNARY, lambda n: [n], 3)
+
+
+def test_libm_opcodes_on_special_operands(oracle, product, monkeypatch):
+    """the libm-backed opcodes (glibc on the oracle's side, OCML on the device's: not bit-reproducible, judged at one step): what must
+    agree EXACTLY is the class of the result -- NaN, infinite, the sign (of a zero too): log(0) = -inf, log(-1) = NaN, pow(0, 0) = 1,
+    pow(-1, 0.5) = NaN, atan2(+-0, +-0), tan(inf) = NaN ..."""
+    monkeypatch.setenv("RXR_SHADER_JIT", "0")
+    names = [(n, 1) for n in S.LIBM_UNARY] + [(n, 2) for n in S.LIBM_BINARY]
+    programs, owner = [], []
+    for name, k in names:
+        ps = programs_for([name], k)
+        programs += ps
+        owner += [(name, v % 3) for v in range(len(ps))]
+    cols = 9
+    got = scenes.render(grid(product, programs, cols))
+    ref = scenes.render(grid(oracle, programs, cols))
+    d = np.abs(got.astype(np.int16) - ref.astype(np.int16)).max(axis=2)
+    bad_class, off = {}, {}
+    for y, x in np.argwhere(d > 0):
+        k = (y // CELL) * cols + (x // CELL)
+        name, variant = owner[k]
+        a, b = SPECIALS[(x % CELL) // 2], SPECIALS[(y % CELL) // 2]
+        if variant == 1:      # sign / NaN / inf flags
+            bad_class.setdefault(name, []).append((a, b, got[y, x].tolist(), ref[y, x].tolist()))
+        elif d[y, x] > 1:
+            off.setdefault(name, []).append((a, b, got[y, x].tolist(), ref[y, x].tolist()))
+    assert not bad_class, "libm opcodes whose result CLASS (sign, NaN, inf) differs (a, b, device, oracle): " + "; ".join(f"{n}: {v[:4]}" for n, v in bad_class.items())
+    # the value encodings wrap (fract): an ulp next to a wrap point is a full swing; a handful of such operand pairs at most
+    assert sum(len(v) for v in off.values()) <= 24, "libm opcodes off by more than one step on special operands: " + "; ".join(f"{n}: {v[:3]} ({len(v)})" for n, v in off.items())
