@@ -134,3 +134,21 @@ def test_libm_opcodes_on_special_operands(oracle, product, monkeypatch):
     assert not bad_class, "libm opcodes whose result CLASS (sign, NaN, inf) differs (a, b, device, oracle): " + "; ".join(f"{n}: {v[:4]}" for n, v in bad_class.items())
     # the value encodings wrap (fract): an ulp next to a wrap point is a full swing; a handful of such operand pairs at most
     assert sum(len(v) for v in off.values()) <= 24, "libm opcodes off by more than one step on special operands: " + "; ".join(f"{n}: {v[:3]} ({len(v)})" for n, v in off.items())
+
+
+@pytest.mark.parametrize("which", ["unary", "binary"])
+def test_compiled_opcodes_on_special_operands(oracle, product, monkeypatch, which):
+    """the same grid through the run-time compiled form of the programs (rxr_jit_ops.h: its own implementations of the opcodes): equal
+    to the interpreted frame and to the oracle"""
+    names, k = (UNARY, 1) if which == "unary" else (BINARY, 2)
+    programs = []
+    for name in names:
+        programs += programs_for([name], k)
+    cols = 9
+    monkeypatch.setenv("RXR_SHADER_JIT", "0")
+    interpreted = scenes.render(grid(product, programs, cols)).copy()
+    monkeypatch.setenv("RXR_SHADER_JIT", "1")
+    compiled = scenes.render(grid(product, programs, cols)).copy()
+    monkeypatch.setenv("RXR_SHADER_JIT", "0")
+    assert np.array_equal(compiled, interpreted), f"compiled and interpreted differ in {(compiled != interpreted).any(axis=2).sum()} pixels; first at {np.argwhere((compiled != interpreted).any(axis=2))[:3].tolist()}"
+    assert np.array_equal(compiled, scenes.render(grid(oracle, programs, cols)))
