@@ -17,9 +17,9 @@ SPECIALS = [float("nan"), float("inf"), float("-inf"), 0.0, -0.0, 1e-40, 3.0e38,
 W, H = 208, 144
 
 
-def build(api, sample_mode, repeat_mode, cutout, seed=7):
+def build(api, sample_mode, repeat_mode, cutout, seed=7, shape=(9, 7)):
     rng = np.random.default_rng([0x52585231, 606, seed])
-    textures = [B.Tile([random_texture(rng, 9, 7, 0)]), B.Tile([random_texture(rng, 8, 8, 2)])]
+    textures = [B.Tile([random_texture(rng, shape[0], shape[1], 0)]), B.Tile([random_texture(rng, shape[1], shape[0], 2)])]
     assets = api.Assets.default().textures(textures)
     scene = api.Scene.empty()
     # a backdrop far away, so that a fragment that must NOT be written shows as the backdrop and not as the miss colour
@@ -69,3 +69,15 @@ def test_poisoned_triangles(oracle, product, sample_mode, repeat_mode, cutout, d
     assert len(np.unique(ref.reshape(-1, 4), axis=0)) > 20   # the ordinary triangles are there
     d = (got != ref).any(axis=2)
     assert not d.any(), f"{int(d.sum())} pixels differ; first at {np.argwhere(d)[:3].tolist()}: device {got[tuple(np.argwhere(d)[0])].tolist()} oracle {ref[tuple(np.argwhere(d)[0])].tolist()}"
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (1, 5), (5, 1), (2, 2)])
+@pytest.mark.parametrize("sample_mode", [B.SAMPLE_NEAREST, B.SAMPLE_LINEAR])
+def test_poisoned_triangles_on_degenerate_textures(oracle, product, sample_mode, shape):
+    """the same with textures of one texel, one row, one column (x1 = min(x0 + 1, w - 1) of the bilinear taps, texture.rs:414-460)"""
+    for repeat_mode in (B.REPEAT_CLAMP_XY, B.REPEAT_REPEAT_XY):
+        for cutout in (False, True):
+            got = scenes.render(build(product, sample_mode, repeat_mode, cutout, shape=shape))
+            ref = scenes.render(build(oracle, sample_mode, repeat_mode, cutout, shape=shape))
+            d = (got != ref).any(axis=2)
+            assert not d.any(), f"texture {shape}, repeat {repeat_mode}, cutout {cutout}: {int(d.sum())} pixels differ; first at {np.argwhere(d)[:3].tolist()}"
