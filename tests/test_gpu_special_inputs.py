@@ -17,7 +17,7 @@ SPECIALS = [float("nan"), float("inf"), float("-inf"), 0.0, -0.0, 1e-40, 3.0e38,
 W, H = 208, 144
 
 
-def build(api, sample_mode, repeat_mode, cutout, seed=7, shape=(9, 7)):
+def build(api, sample_mode, repeat_mode, cutout, seed=7, shape=(9, 7), mode="plain"):
     rng = np.random.default_rng([0x52585231, 606, seed])
     textures = [B.Tile([random_texture(rng, shape[0], shape[1], 0)]), B.Tile([random_texture(rng, shape[1], shape[0], 2)])]
     assets = api.Assets.default().textures(textures)
@@ -28,6 +28,15 @@ def build(api, sample_mode, repeat_mode, cutout, seed=7, shape=(9, 7)):
     b.source(B.PixelSource.Pixel((40, 90, 160, 255))).ambient_color((1.0, 1.0, 1.0))
     scene.add_d3_static(b)
     # one batch per (field, special): a triangle of ordinary size with ONE poisoned number
+    # mode: "plain" | "opacity" (the triangles go to a chunk's opacity list: d3_rasterize_opacity and the blend) | "program" (every
+    # triangle runs a Rusteria program that reads uv and the texel) | "program_alpha" (... and writes `opacity`: the alpha of a
+    # fragment then needs the whole front half of the fragment block, DB_FULL_ALPHA)
+    chunk = scene.add_chunk() if mode == "opacity" else None
+    prog = None
+    if mode == "program":
+        prog = scene.add_program(B.Program([["Color", "UV", ("Push", 0.5), "Mul", ("Push", 0.5), "Add", "Mul", "SetColor"]]))
+    elif mode == "program_alpha":
+        prog = scene.add_program(B.Program([["Color", "SetColor", "UV", ("GetComponents", [0]), ("Push", 2.0), "Mul", "Fract", ("Push", 0.5), "Gt", "SetOpacity"]]))
     k = 0
     for field in range(5):                       # x, y, z of vertex 1; u, v of vertex 2
         for s in SPECIALS:
@@ -40,7 +49,12 @@ def build(api, sample_mode, repeat_mode, cutout, seed=7, shape=(9, 7)):
                 uv[2, field - 3] = s
             t = api.Batch3D.new(v, np.array([[0, 1, 2]], np.uint32), uv).with_computed_normals().cull_mode(0)
             t.source(B.PixelSource.StaticTileIndex(1 if cutout else 0)).repeat_mode(repeat_mode).ambient_color((0.9, 0.8, 0.7))
-            scene.add_d3_static(t)
+            if prog is not None:
+                t.shader(prog)
+            if chunk is not None:
+                chunk.add_batch3d_opacity(t)
+            else:
+                scene.add_d3_static(t)
             k += 1
     cam = api.D3OrbitCamera.new()
     cam.set_parameter_f32("distance", 3.0)
@@ -81,3 +95,16 @@ def test_poisoned_triangles_on_degenerate_textures(oracle, product, sample_mode,
             ref = scenes.render(build(oracle, sample_mode, repeat_mode, cutout, shape=shape))
             d = (got != ref).any(axis=2)
             assert not d.any(), f"texture {shape}, repeat {repeat_mode}, cutout {cutout}: {int(d.sum())} pixels differ; first at {np.argwhere(d)[:3].tolist()}"
+
+
+@pytest.mark.parametrize("mode", ["opacity", "program", "program_alpha"])
+@pytest.mark.parametrize("sample_mode", [B.SAMPLE_NEAREST, B.SAMPLE_LINEAR])
+def test_poisoned_triangles_in_the_other_passes(oracle, product, sample_mode, mode):
+    """the poisoned triangles as opacity batches (blended over the backdrop) and under Rusteria programs (uv and texel read; `opacity`
+    written: the visibility pass then runs the front half of the fragment block), cut-out and opaque textures, two repeat modes"""
+    for repeat_mode in (B.REPEAT_CLAMP_XY, B.REPEAT_REPEAT_XY):
+        for cutout in (False, True):
+            got = scenes.render(build(product, sample_mode, repeat_mode, cutout, mode=mode))
+            ref = scenes.render(build(oracle, sample_mode, repeat_mode, cutout, mode=mode))
+            d = np.abs(got.astype(np.int16) - ref.astype(np.int16)).max(axis=2)
+            assert d.max() == 0, f"{mode}, repeat {repeat_mode}, cutout {cutout}: {int((d > 0).sum())} pixels differ (max {int(d.max())}); first at {np.argwhere(d > 0)[:3].tolist()}: device {got[tuple(np.argwhere(d > 0)[0])].tolist()} oracle {ref[tuple(np.argwhere(d > 0)[0])].tolist()}"
