@@ -250,3 +250,35 @@ def test_2d_line_end_points_out_of_range_are_refused_like_on_the_host(product, d
     from tests.test_gpu_parity import scene_2d
 
     assert scenes.render(scene_2d(product)).any()
+
+
+def test_projected_arrays_of_poisoned_triangles_match_the_host_mirror(product, devproj):
+    """tests/test_gpu_special_inputs.py's scene -- one NaN / +-inf / +-0 / denormal / huge number per triangle in a position or a texture
+    coordinate -- through clip_and_project on the device: vertices, uvs, normals, indices, the Edges records and the bounding box equal
+    the host mirror's (NaN == NaN: the two sides' NaNs may differ in sign and payload)"""
+    from tests import test_gpu_special_inputs as SI
+
+    devproj.off()
+    ref_cfg = SI.build(product, B.SAMPLE_LINEAR, B.REPEAT_REPEAT_XY, False)
+    ref_cfg.setup().project(ref_cfg.scene, ref_cfg.width, ref_cfg.height)
+    devproj.on()
+    cfg = SI.build(product, B.SAMPLE_LINEAR, B.REPEAT_REPEAT_XY, False)
+    scenes.render(cfg)
+    i, compared = 0, 0
+    while True:
+        try:
+            ref = ref_cfg.scene.projected_batch3d(B.LIST_STATIC, i)
+        except IndexError:
+            break
+        nv, nt = ref["projected_vertices"].shape[0], ref["clipped_indices"].shape[0]
+        got = devproj.read(i, nv + 16, nt + 16)
+        if got["projected_vertices"].shape[0] == 0 or ref["bounding_box"][0] == 0.0 and nv == 0:
+            assert got["projected_vertices"].shape[0] == nv or ref["bounding_box"][0] == 0.0, (i, got["projected_vertices"].shape, nv)
+        else:
+            for key in ("projected_vertices", "clipped_uvs", "clipped_normals", "clipped_indices", "edges", "bounding_box"):
+                assert got[key].shape == ref[key].shape, (i, key, got[key].shape, ref[key].shape)
+                same = np.array_equal(got[key], ref[key], equal_nan=True) if got[key].dtype.kind == "f" else np.array_equal(got[key], ref[key])
+                assert same, (i, key, got[key].tolist()[:4], ref[key].tolist()[:4])
+            compared += 1
+        i += 1
+    assert i == 41 and compared >= 30, (i, compared)
