@@ -505,3 +505,28 @@ def test_baseline_configs_at_full_size(oracle, product, name, builder, kw, tol, 
     diff = np.abs(got.astype(np.int16) - ref.astype(np.int16)).max(axis=2)
     assert int(diff.max()) <= tol, f"{name}: max |diff| {int(diff.max())}"
     assert int((diff > 0).sum()) <= max_differing, f"{name}: {int((diff > 0).sum())} pixels differ"
+
+
+@pytest.mark.parametrize("size", [(1, 1), (1, 37), (37, 1), (2, 2), (15, 17), (16, 16), (17, 15), (33, 31), (4097, 3), (3, 2051)])
+@pytest.mark.parametrize("tile_size", [1, 7, 40, 5000])
+def test_degenerate_frame_and_tile_sizes(oracle, product, size, tile_size):
+    """frames of one pixel, one row, one column, just above and below the device's 16 x 16 tiles, very wide and very tall, with the
+    reference's tile_size from 1 to larger than the frame (rasterizer.rs:256-270: step_by(tile_size), the last tiles clipped): the lit
+    map (within one step), the teapot and the 2D scene (bit-exact)"""
+    w, h = size
+
+    def sized(builder, **kw):
+        def build(api):
+            cfg = builder(api, width=w, height=h, **kw)
+            cfg.tile_size = tile_size
+            return cfg
+        return build
+
+    got, ref = scenes.render(sized(scenes.map_scene, n_lights=3, logo_size=16)(product)), scenes.render(sized(scenes.map_scene, n_lights=3, logo_size=16)(oracle))
+    assert got.shape == (h, w, 4)
+    assert_close(got, ref, f"map {w}x{h} tile {tile_size}", max_outliers=0)
+    got, ref = scenes.render(sized(scene_2d)(product)), scenes.render(sized(scene_2d)(oracle))
+    assert_exact(got, ref, f"2D {w}x{h} tile {tile_size}")
+    if w * h <= 20000:
+        got, ref = scenes.render(sized(scenes.teapot_scene, logo_size=16)(product)), scenes.render(sized(scenes.teapot_scene, logo_size=16)(oracle))
+        assert_exact(got, ref, f"teapot {w}x{h} tile {tile_size}")
