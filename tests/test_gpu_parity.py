@@ -530,3 +530,17 @@ def test_degenerate_frame_and_tile_sizes(oracle, product, size, tile_size):
     if w * h <= 20000:
         got, ref = scenes.render(sized(scenes.teapot_scene, logo_size=16)(product)), scenes.render(sized(scenes.teapot_scene, logo_size=16)(oracle))
         assert_exact(got, ref, f"teapot {w}x{h} tile {tile_size}")
+
+
+@pytest.mark.parametrize("size", [(32768, 3), (3, 32768), (32768, 17)])
+def test_frames_at_the_size_limit(oracle, product, size):
+    """the largest frame edge the boundary accepts (32768: pixel boxes are 16-bit fields with an exclusive maximum), wide and tall"""
+    w, h = size
+    got = scenes.render(scenes.map_scene(product, width=w, height=h, n_lights=2, logo_size=16))
+    ref = scenes.render(scenes.map_scene(oracle, width=w, height=h, n_lights=2, logo_size=16))
+    assert_close(got, ref, f"map {w}x{h}")
+    got, ref = both(oracle, product, scene_2d, width=w, height=h)
+    assert_exact(got, ref, f"2D {w}x{h}")
+    with pytest.raises(B.RasterizeError) as e:
+        scenes.render(scene_2d(product, width=32769 if w > h else 3, height=3 if w > h else 32769))
+    assert e.value.code == B.RXR_ERR_INVALID
