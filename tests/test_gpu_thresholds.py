@@ -88,3 +88,24 @@ def test_2d_primitive_counts_around_the_binning_threshold(oracle, product, two_d
         product.lib.rxh_set_device_projection(0)
     ref = scenes.render(mesh_scene(oracle, [40], two_d))
     assert np.array_equal(got, ref), f"{two_d} rectangles: {(got != ref).any(axis=2).sum()} pixels differ"
+
+
+@pytest.mark.parametrize("n_rect", [511, 512, 513, 700])
+def test_more_2d_primitives_in_one_tile_than_the_sort_holds(oracle, product, n_rect):
+    """every rectangle covers the whole frame: each tile lists 2 * n_rect primitives -- at 1024 (RXR_SORT2D_MAX) the tile's LDS sort is
+    full and the pass walks the frame's primitives in order instead; blended in submission order either way"""
+    def build(api):
+        rng = np.random.default_rng([0x52585231, 1001, n_rect])
+        scene = api.Scene.empty()
+        for k in range(n_rect):
+            r = api.Batch2D.from_rectangle(float(-k % 3), float(-k % 2), float(W + 3), float(H + 2)).source(B.PixelSource.Pixel(tuple(int(c) for c in rng.integers(0, 256, 3)) + (int(rng.integers(1, 40)),)))
+            scene.add_d2_static(r)
+
+        def setup():
+            v, p = api.D3OrbitCamera.new().matrices(float(W), float(H))
+            return api.Rasterizer.setup(None, v, p).render_mode(B.RenderMode.render_2d()).background((9, 9, 9, 255))
+
+        return scenes._result(api, scene, api.Assets.default(), setup, W, H, 40, "2d-stack")
+
+    got, ref = scenes.render(build(product)), scenes.render(build(oracle))
+    assert np.array_equal(got, ref), f"{n_rect} stacked rectangles: {(got != ref).any(axis=2).sum()} pixels differ"
