@@ -15,7 +15,7 @@ NAN, INF = float("nan"), float("inf")
 # (field, value)
 POISON = [("intensity", v) for v in (NAN, INF, -INF, 0.0, -2.0, 1e-40)] + \
          [("start_distance", v) for v in (NAN, INF, -1.0, 5.0)] + [("end_distance", v) for v in (NAN, INF, 0.0, -3.0)] + \
-         [("position", (NAN, 1.0, 8.0)), ("position", (INF, 1.0, 8.0)), ("position", (6.0, 3.0e38, 8.0))] + \
+         [("position", (NAN, 1.0, 8.0)), ("position", (INF, 1.0, 8.0)), ("position", (6.0, 3.0e38, 8.0)), ("position", (-5.0, -0.0, 4.0e9)), ("position", (-INF, 1.0, 8.0))] + \
          [("color", (NAN, 1.0, 1.0)), ("color", (INF, 0.0, -1.0))] + [("flicker", v) for v in (NAN, INF, 0.5, -1.0)] + \
          [("start==end", 4.0), ("start>end", 9.0)]
 TYPES = [B.LIGHT_POINT, B.LIGHT_SPOT, B.LIGHT_AREA, B.LIGHT_AMBIENT, B.LIGHT_DAYLIGHT]
@@ -23,7 +23,8 @@ TYPES = [B.LIGHT_POINT, B.LIGHT_SPOT, B.LIGHT_AREA, B.LIGHT_AMBIENT, B.LIGHT_DAY
 
 def build(api, light_type, field, value):
     cfg = scenes.map_scene(api, width=320, height=180, n_lights=2, logo_size=16)
-    l = B.Light(light_type).with_position((7.0, 1.2, 8.0)).with_color((1.0, 0.8, 0.6)).with_intensity(1.5).with_start_distance(1.5).with_end_distance(7.0)
+    # (flickering: the hash of `position as u32` runs for every poisoned position too, light.rs:247-262)
+    l = B.Light(light_type).with_position((7.0, 1.2, 8.0)).with_color((1.0, 0.8, 0.6)).with_intensity(1.5).with_start_distance(1.5).with_end_distance(7.0).with_flicker(0.4)
     l.direction, l.normal, l.width, l.height = (0.2, -0.6, 0.7), (0.0, -1.0, 0.3), 2.0, 1.5
     if field == "start==end":
         l.start_distance = l.end_distance = value
