@@ -108,3 +108,64 @@ def test_poisoned_triangles_in_the_other_passes(oracle, product, sample_mode, mo
             ref = scenes.render(build(oracle, sample_mode, repeat_mode, cutout, mode=mode))
             d = np.abs(got.astype(np.int16) - ref.astype(np.int16)).max(axis=2)
             assert d.max() == 0, f"{mode}, repeat {repeat_mode}, cutout {cutout}: {int((d > 0).sum())} pixels differ (max {int(d.max())}); first at {np.argwhere(d > 0)[:3].tolist()}: device {got[tuple(np.argwhere(d > 0)[0])].tolist()} oracle {ref[tuple(np.argwhere(d > 0)[0])].tolist()}"
+
+
+def build_random(api, seed):
+    """several poisoned numbers at once, chosen by the seed: any position / w / uv entry of any vertex of ~30 triangles, random sampling
+    and repeat modes, opaque / cut-out textures, plain / opacity / program passes, a cull mode per batch"""
+    rng = np.random.default_rng([0x52585231, 1212, seed])
+    shape = [(9, 7), (1, 1), (3, 1), (8, 8)][int(rng.integers(0, 4))]
+    textures = [B.Tile([random_texture(rng, shape[0], shape[1], 0)]), B.Tile([random_texture(rng, shape[1], shape[0], int(rng.integers(1, 3)))])]
+    assets = api.Assets.default().textures(textures)
+    scene = api.Scene.empty()
+    back = np.array([[-9, -7, -6.0, 1], [9, -7, -6.0, 1], [9, 7, -6.0, 1], [-9, 7, -6.0, 1]], np.float32)
+    b = api.Batch3D.new(back, np.array([[0, 1, 2], [0, 2, 3]], np.uint32), np.array([[0, 0], [3, 0], [3, 3], [0, 3]], np.float32)).with_computed_normals().cull_mode(0)
+    b.source(B.PixelSource.Pixel((40, 90, 160, 255))).ambient_color((1.0, 1.0, 1.0))
+    scene.add_d3_static(b)
+    chunk = scene.add_chunk() if rng.random() < 0.4 else None
+    prog = scene.add_program(B.Program([["Color", "UV", ("Push", 0.5), "Mul", ("Push", 0.5), "Add", "Mul", "SetColor"]])) if rng.random() < 0.3 else None
+    pool = SPECIALS + [1e30, -1e30, 0.1, 1.0]
+    for k in range(30):
+        cx, cy = float(rng.uniform(-2.6, 2.6)), float(rng.uniform(-1.6, 1.6))
+        z = float(rng.uniform(-2.5, -0.4))
+        v = np.array([[cx, cy, z, 1], [cx + rng.uniform(0.2, 0.9), cy + rng.uniform(-0.2, 0.3), z - rng.uniform(-0.3, 0.3), 1],
+                      [cx + rng.uniform(-0.2, 0.4), cy + rng.uniform(0.3, 0.9), z + rng.uniform(-0.3, 0.3), 1]], np.float32)
+        uv = rng.uniform(-0.5, 2.0, (3, 2)).astype(np.float32)
+        for _ in range(int(rng.integers(0, 4))):
+            if rng.random() < 0.6:
+                v[int(rng.integers(0, 3)), int(rng.integers(0, 4))] = pool[int(rng.integers(0, len(pool)))]
+            else:
+                uv[int(rng.integers(0, 3)), int(rng.integers(0, 2))] = pool[int(rng.integers(0, len(pool)))]
+        t = api.Batch3D.new(v, np.array([[0, 1, 2]], np.uint32), uv).with_computed_normals().cull_mode(int(rng.integers(0, 3)))
+        t.source(B.PixelSource.StaticTileIndex(int(rng.integers(0, 2)))).repeat_mode(int(rng.integers(0, 4))).ambient_color(tuple(float(c) for c in rng.uniform(0.3, 1.0, 3)))
+        if prog is not None and rng.random() < 0.5:
+            t.shader(prog)
+        if chunk is not None and rng.random() < 0.5:
+            chunk.add_batch3d_opacity(t)
+        else:
+            scene.add_d3_static(t)
+    cam = api.D3OrbitCamera.new()
+    cam.set_parameter_f32("distance", float(rng.uniform(2.0, 4.0)))
+    cam.azimuth = float(np.float32(np.pi / 2))
+    cam.elevation = float(rng.uniform(-0.2, 0.3))
+    sample_mode = int(rng.integers(0, 2))
+
+    def setup():
+        v_, p_ = cam.matrices(float(W), float(H))
+        return api.Rasterizer.setup(None, v_, p_).sample_mode(sample_mode).ambient((1.0, 1.0, 1.0, 1.0))
+
+    return scenes._result(api, scene, assets, setup, W, H, 40, f"special-random{seed}")
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_combinations_of_poisoned_numbers(oracle, product, seed):
+    product.lib.rxh_set_device_projection.argtypes = [C.c_int]
+    for dp in (0, 1):
+        product.lib.rxh_set_device_projection(dp)
+        try:
+            got = scenes.render(build_random(product, seed))
+        finally:
+            product.lib.rxh_set_device_projection(0)
+        ref = scenes.render(build_random(oracle, seed))
+        d = (got != ref).any(axis=2)
+        assert not d.any(), f"seed {seed}, device projection {dp}: {int(d.sum())} pixels differ; first at {np.argwhere(d)[:3].tolist()}: device {got[tuple(np.argwhere(d)[0])].tolist()} oracle {ref[tuple(np.argwhere(d)[0])].tolist()}"
