@@ -126,7 +126,7 @@ bool to_isize32(float x, int32_t &out) {
 }
 
 struct Layout {
-    size_t off_b3, off_base, off_pv, off_uv, off_nrm, off_idx, off_edges, off_tinfo, off_lights, off_occ, off_ld, off_chunks, off_tdesc,
+    size_t off_b3, off_base, off_pv, off_uv, off_nrm, off_idx, off_edges, off_tinfo, off_clip3d, off_lights, off_occ, off_ld, off_chunks, off_tdesc,
         off_ltex, off_b2, off_p2, off_bg, total;
 };
 
@@ -1146,6 +1146,15 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
     };
     const bool with_tri_info = !use_meshes && n_t3 > 0 && n_t3 <= RXR_TRI_INFO_MAX;
     L.off_tinfo = take(with_tri_info ? n_t3 * sizeof(uint2) : 0);
+    // host-projected 3D batches whose bounding-box arithmetic the reference's per-tile test cannot be trusted with (rxr_device.h,
+    // rxr_ref_tile_span): per batch the pixels the reference draws it in
+    bool any_risky3d = false;
+    if (!(use_meshes & 1u))
+        for (uint32_t i = 0; i < n_b3 && !any_risky3d; ++i) {
+            const rxr_batch3d &b = f->batches3d[i];
+            any_risky3d = b.has_bounding_box && b.n_triangles > 0 && rxr_box_is_risky(b.bounding_box[0], b.bounding_box[1], b.bounding_box[2], b.bounding_box[3]);
+        }
+    L.off_clip3d = take(any_risky3d ? n_b3 * sizeof(uint4) : 0);
     L.off_lights = take(f->n_lights * sizeof(rxr_light));
     L.off_occ = take(n_occ_total * sizeof(rxr_occluder));
     L.off_ld = take(f->n_linedefs * sizeof(rxr_linedef));
@@ -1299,6 +1308,18 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
         uint2 *ti = (uint2 *)(st + L.off_tinfo);
         for (uint32_t i = 0; i < f->n_batches3d; ++i)
             for (uint32_t t = 0; t < f->batches3d[i].n_triangles; ++t) ti[b3[i].tri_base + t] = make_uint2(i, b3[i].vert_base);
+    }
+    if (any_risky3d) {
+        uint4 *clip = (uint4 *)(st + L.off_clip3d);
+        for (uint32_t i = 0; i < n_b3; ++i) {
+            const rxr_batch3d &b = f->batches3d[i];
+            uint4 c = make_uint4(0u, f->width, 0u, f->height);
+            if (b.has_bounding_box && rxr_box_is_risky(b.bounding_box[0], b.bounding_box[1], b.bounding_box[2], b.bounding_box[3])) {
+                rxr_ref_tile_span(b.bounding_box[0], b.bounding_box[2], f->width, f->tile_size, 0.0f, c.x, c.y);
+                rxr_ref_tile_span(b.bounding_box[1], b.bounding_box[3], f->height, f->tile_size, 0.0f, c.z, c.w);
+            }
+            clip[i] = c;
+        }
     }
     // the arrays themselves: independent per batch (offsets are in the headers just written), through the host worker pool --
     // 124 MB for the 1 M-triangle grid, which one thread copies in about as long as the GPU takes for forty frames
@@ -1580,6 +1601,15 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
         }
         b2[i] = d;
         if (!keep) continue;
+        // a batch whose box arithmetic the reference's per-tile test cannot be trusted with: its primitives only count inside the tiles
+        // that pass it (pad 0.5, :594-600)
+        uint32_t clip_x0 = 0, clip_x1 = f->width, clip_y0 = 0, clip_y1 = f->height;
+        const bool risky2d = rxr_box_is_risky(b.bounding_box[0], b.bounding_box[1], b.bounding_box[2], b.bounding_box[3]);
+        if (risky2d) {
+            rxr_ref_tile_span(b.bounding_box[0], b.bounding_box[2], f->width, f->tile_size, 0.5f, clip_x0, clip_x1);
+            rxr_ref_tile_span(b.bounding_box[1], b.bounding_box[3], f->height, f->tile_size, 0.5f, clip_y0, clip_y1);
+        }
+        const size_t p2_first = p2cur;
         if (b.mode == RXR_MODE_TRIANGLES) {
             for (uint32_t t = 0; t < b.n_triangles; ++t) {
                 const uint32_t *ix = b.indices + 3 * (size_t)t;
@@ -1642,6 +1672,14 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
             }
             if (!ok) return fail(ctx, RXR_ERR_UNSUPPORTED, "batch2d: line end point NaN or beyond +-2^30");
         }
+        if (risky2d)
+            for (size_t q = p2_first; q < p2cur; ++q) {
+                Prim2D &T = p2[q];
+                uint32_t x0 = std::max(T.bx & 0xFFFFu, clip_x0), x1 = std::min(T.bx >> 16, clip_x1), y0 = std::max(T.by & 0xFFFFu, clip_y0), y1 = std::min(T.by >> 16, clip_y1);
+                if (!(x0 < x1 && y0 < y1)) x0 = x1 = y0 = y1 = 0u;
+                T.bx = x0 | (x1 << 16);
+                T.by = y0 | (y1 << 16);
+            }
     }
     if (f->background_kind == RXR_BG_HOST_PIXELS) memcpy(st + L.off_bg, f->background_pixels, (size_t)f->width * f->height * 4);
 
@@ -1786,13 +1824,15 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
         const char *lm = getenv("RXR_LIGHT_MATH");
         P.relaxed_lights = lm ? (lm[0] == 'r' ? 1u : 0u) : (ctx->relaxed_lights ? 1u : 0u);
         // the fused point-light term multiplies where the reference branches (a light out of range contributes intensity * 0): with an
-        // infinite or NaN intensity, colour, position or range that is NaN where the reference adds nothing.  Such frames -- no real
-        // scene has them -- take the exact loop, which skips and branches like the reference (light.rs:535-552).
+        // infinite or NaN intensity, colour, position or range that is NaN where the reference adds nothing -- and so it is with FINITE
+        // parameters whose product overflows (colour -3e38 x flicker 3e38 = inf, times the 0 of an out-of-range fragment: found by
+        // tools/fuzz_special2.py, seed 1036).  Such frames -- no real scene has them -- take the exact loop, which skips and branches
+        // like the reference (light.rs:535-552): every factor of the fused term must stay below 1e9 in magnitude (their product below 1e36).
         for (uint32_t i = 0; i < f->n_lights && P.relaxed_lights; ++i) {
             const rxr_light &l = f->lights[i];
             const float v[] = {l.intensity, l.color[0], l.color[1], l.color[2], l.position[0], l.position[1], l.position[2], l.start_distance, l.end_distance, l.flicker};
             for (float x : v)
-                if (!(std::fabs(x) <= 3.0e38f)) P.relaxed_lights = 0u;
+                if (!(std::fabs(x) <= 1.0e9f)) P.relaxed_lights = 0u;
         }
         P.rl_flip_guard = 1e-4f;
         if (const char *fg = getenv("RXR_RL_FLIP_GUARD")) {  // tests: a large guard sends every wave down the exact normal sequences
@@ -1841,6 +1881,8 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
     P.batches3d = (const DevBatch *)(d + L.off_b3);
     P.batch_tri_base = (const uint32_t *)(d + L.off_base);
     P.tri_info = with_tri_info ? (const uint2 *)(d + L.off_tinfo) : nullptr;
+    P.batch_clip3d = any_risky3d ? (const uint4 *)(d + L.off_clip3d) : nullptr;
+    P.ref_tile = f->tile_size;
     P.tri_setup = (TriSetup *)ctx->d_tri_setup.p;
     P.tri_shade = (TriShade *)ctx->d_tri_shade.p;
     P.tri_box = (uint2 *)ctx->d_tri_box.p;
@@ -1885,6 +1927,7 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
         memcpy(PP2.m, ctx->matrix2d, sizeof(PP2.m));
         PP2.width = W;
         PP2.height = H;
+        PP2.ref_tile = f->tile_size;
         PP2.out = (Prim2D *)(d + L.off_p2);
     }
     ctx->frame_uses_meshes = use_meshes;

@@ -195,6 +195,54 @@ enum { CNT_LARGE = 0, CNT_ENTRIES = 1, CNT_OVERFLOW = 2, CNT_TICKET = 3, CNT_WOR
 #define RXR_BLOCKSCAN_BLOCK_TRIS 2048u
 #define RXR_BLOCKSCAN_CAP 256u
 
+// ---- the reference's per-tile batch box test, for batches whose box arithmetic cannot be trusted ---------------------------------
+// d3_rasterize / d2_rasterize skip a batch for every tile its bounding box does not meet (rasterizer.rs:978-983, :594-600):
+//     bbox.x < (tile.x + tile.width) as f32 + pad  &&  (bbox.x + bbox.width) > tile.x as f32 - pad        (and the same in y)
+// A primitive's pixels lie inside its batch's box, so for ordinary coordinates the test never cuts anything a primitive covers and
+// the device evaluates it once, against the whole screen.  It stops being harmless when `bbox.x + bbox.width` -- where
+// width is itself max - min, rounded -- no longer lands within half a pixel of the true maximum: a batch with a vertex at -3e38 and
+// another at +100 has x + width == 0, and the reference draws it in its leftmost tile column only.  The set of tiles that pass is an
+// interval of tile columns times an interval of tile rows, found here with the reference's own float expressions (a binary search per
+// bound: both conditions are monotone in the tile index); the device clips the pixel boxes of such a batch's primitives to it.
+// RISKY = some |coordinate| or extent is not below 2^21 (ulp 0.25: the sum then stays within half a pixel) -- or not a number.
+#if defined(__HIPCC__) || defined(RXR_JIT)
+#define RXR_HD __host__ __device__
+#else
+#define RXR_HD
+#endif
+RXR_HD inline bool rxr_box_is_risky(float x, float y, float w, float h) {
+    const float lim = 2097152.0f;
+    return !(x > -lim && x < lim && y > -lim && y < lim && w > -lim && w < lim && h > -lim && h < lim);   // (NaN: risky)
+}
+// pixels [p0, p1) of one axis in which the reference draws a batch with box [lo, lo + extent] (as it computes them): the union of the
+// tiles of size `ts` (the last one clipped to `size`, rasterizer.rs:256-270) that pass the test; p0 == p1: none
+RXR_HD inline void rxr_ref_tile_span(float lo, float extent, uint32_t size, uint32_t ts, float pad, uint32_t &p0, uint32_t &p1) {
+    p0 = p1 = 0u;
+    if (ts == 0u || size == 0u) return;
+    const uint32_t n = (size + ts - 1u) / ts;
+    const float hi = lo + extent;   // the reference's `bbox.x + bbox.width`
+    auto below = [&](uint32_t c) { const uint32_t t0 = c * ts, tw = (size - t0 < ts) ? size - t0 : ts; return lo < (float)(t0 + tw) + pad; };   // true from some column on
+    auto above = [&](uint32_t c) { return hi > (float)(c * ts) - pad; };                                                                   // true up to some column
+    if (!below(n - 1u) || !above(0u)) return;   // (also every NaN case)
+    uint32_t a = 0u, b = n - 1u;                // first column with below(c)
+    while (a < b) {
+        const uint32_t m = (a + b) >> 1;
+        if (below(m)) b = m;
+        else a = m + 1u;
+    }
+    const uint32_t first = a;
+    a = 0u, b = n - 1u;                         // last column with above(c)
+    while (a < b) {
+        const uint32_t m = (a + b + 1u) >> 1;
+        if (above(m)) a = m;
+        else b = m - 1u;
+    }
+    const uint32_t last = a;
+    if (first > last) return;
+    p0 = first * ts;
+    p1 = ((last + 1u) * ts < size) ? (last + 1u) * ts : size;
+}
+
 // kernel parameter block (passed by value; lives in the kernarg segment -> scalar loads)
 struct RasterParams {
     uint32_t width, height;
@@ -223,6 +271,9 @@ struct RasterParams {
     const uint32_t *d2_box_dev;    // device-projected 2D batches: the same four words, written by k_proj2d_prims (else nullptr)
     uint32_t list2d_capacity;
     uint32_t list_capacity;
+    uint32_t ref_tile;             // the reference's tile_size (rxr_frame.tile_size): only the batch box test of RISKY batches depends on it
+    const uint4 *batch_clip3d;     // host-projected frames with a risky 3D batch: per batch the pixels (x0, x1, y0, y1) the reference draws it in
+                                   // (rxr_ref_tile_span; ordinary batches: the whole frame); NULL otherwise.  make_setup clips the pixel boxes
     uint32_t fused_small;          // small-scene mode (whole frame <= RXR_STAGE_TRIS triangles): 0 = binned pipeline,
                                    // 1 = fully fused (k_raster_fused builds the records itself, no pre-pass launch),
                                    // 2 = implicit list (k_setup3d writes the records, no scan / fill / bins; default)

@@ -1182,6 +1182,22 @@ __device__ __forceinline__ bool make_setup(const RasterParams &P, uint32_t t, Tr
     uint32_t max_x = sat_index(fminf(ceilf(max_xf), (float)P.width), 0xFFFFu);
     uint32_t min_y = sat_index(fmaxf(floorf(min_yf), (float)P.row0), 0xFFFFu);
     uint32_t max_y = sat_index(fminf(ceilf(max_yf), (float)P.row1), 0xFFFFu);
+    // a batch whose box arithmetic the reference's per-tile test cannot be trusted with (rxr_device.h, rxr_ref_tile_span): only the
+    // pixels of the tiles that pass it
+    if (P.batch_clip3d) {   // uniform: host-projected, some batch is risky
+        const uint4 c = P.batch_clip3d[lo];
+        min_x = max(min_x, c.x); max_x = min(max_x, c.y); min_y = max(min_y, c.z); max_y = min(max_y, c.w);
+    } else if (P.dev_bbox) {   // device-projected: the box is here
+        const DevBBox bb = P.dev_bbox[lo];
+        auto dec = [](uint32_t e) { return __uint_as_float((e & 0x80000000u) ? (e ^ 0x80000000u) : ~e); };
+        const float bx = dec(bb.min_x), by = dec(bb.min_y), bw = dec(bb.max_x) - bx, bh = dec(bb.max_y) - by;
+        if (rxr_box_is_risky(bx, by, bw, bh)) {
+            uint32_t x0, x1, y0, y1;
+            rxr_ref_tile_span(bx, bw, P.width, P.ref_tile, 0.0f, x0, x1);
+            rxr_ref_tile_span(by, bh, P.height, P.ref_tile, 0.0f, y0, y1);
+            min_x = max(min_x, x0); max_x = min(max_x, x1); min_y = max(min_y, y0); max_y = min(max_y, y1);
+        }
+    }
 
     bool live = min_x < max_x && min_y < max_y;
     S.bx = live ? (min_x | (max_x << 16)) : 0u;
@@ -2645,7 +2661,9 @@ __device__ __forceinline__ uint32_t prim2d_pixel(const RasterParams &P, const Pr
                                                  uint32_t color) {
     const uint32_t min_x = T.bx & 0xFFFFu, max_x = T.bx >> 16, min_y = T.by & 0xFFFFu, max_y = T.by >> 16;
     if (T.batch_kind & 2u) {  // Bresenham segment
-        if (bresenham_hits(T, (int)px, (int)py)) color = __float_as_uint(T.v2x);
+        // (the walk never leaves its end-point box -- the box test only matters for a batch clipped to the reference's tiles,
+        // rxr_ref_tile_span: then it is smaller)
+        if (px >= min_x && px < max_x && py >= min_y && py < max_y && bresenham_hits(T, (int)px, (int)py)) color = __float_as_uint(T.v2x);
         return color;
     }
     bool in = px >= min_x && px < max_x && py >= min_y && py < max_y && (T.batch_kind & 1u);

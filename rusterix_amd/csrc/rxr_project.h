@@ -122,6 +122,7 @@ struct Project2DParams {
     uint32_t n_meshes, n_verts, n_prims, has_matrix;
     float m[9];                     // vek column-major Mat3 (m[c * 3 + r])
     float width, height;
+    uint32_t ref_tile;              // the reference's tile_size (the box test of risky batches, rxr_device.h rxr_ref_tile_span)
     const DevMesh2D *meshes;
     const uint32_t *vin_prefix;     // n_meshes + 1
     const float2 *obj_verts, *obj_uvs;

@@ -694,6 +694,12 @@ __device__ __forceinline__ void proj2d_prims_item(const Project2DParams &P, uint
                 min_y = (uint32_t)min(max(ly0, 0ll), H); max_y = (uint32_t)min(max(ly1, 0ll), H);
             }
         }
+        if (keep && rxr_box_is_risky(bx, by, bw, bh)) {   // only inside the reference's tiles that pass its batch box test (rxr_device.h)
+            uint32_t x0, x1, y0, y1;
+            rxr_ref_tile_span(bx, bw, (uint32_t)P.width, P.ref_tile, pad, x0, x1);
+            rxr_ref_tile_span(by, bh, (uint32_t)P.height, P.ref_tile, pad, y0, y1);
+            min_x = max(min_x, x0); max_x = min(max_x, x1); min_y = max(min_y, y0); max_y = min(max_y, y1);
+        }
         if (!(min_x < max_x && min_y < max_y)) min_x = max_x = min_y = max_y = 0u;
         T.bx = min_x | (max_x << 16);
         T.by = min_y | (max_y << 16);

@@ -102,3 +102,39 @@ def test_a_batch_with_an_infinite_box_is_not_drawn_at_all(oracle, product, devic
     finally:
         product.lib.rxh_set_device_projection(0)
     assert np.array_equal(got, scenes.render(build(oracle, B.SAMPLE_NEAREST, None, [-INF])))
+
+
+@pytest.mark.parametrize("device_projection", [False, True])
+@pytest.mark.parametrize("tile_size", [8, 40, 64, 300])
+@pytest.mark.parametrize("huge", [-3.0e38, 3.0e38, -1.0e12, 6.0e7, -2.5e6])
+def test_batches_with_huge_coordinates_are_drawn_in_the_reference_s_tiles_only(oracle, product, huge, tile_size, device_projection):
+    """a batch box is Rect {x: min, width: max - min}, and the reference skips the batch for every tile that `x + width` does not reach
+    (rasterizer.rs:594-600): with a vertex at -3e38 and the others on screen, `x + width` is 0 and only the leftmost tile column draws
+    the batch; with 6e7 the sum is off by a few pixels.  Which pixels that is depends on the reference's tile size -- the device clips
+    such a batch's primitives to the tiles that pass (rxr_device.h rxr_ref_tile_span; found by tools/fuzz_special2.py, seed 1048)"""
+    def build(api):
+        batches = [api.Batch2D.from_rectangle(0.0, 0.0, float(W), float(H)).source(B.PixelSource.Pixel((30, 60, 90, 255)))]
+        tris = [[[35.5, 108.6], [huge, 133.5], [35.7, 43.5]], [[huge, 61.8], [111.2, 140.1], [127.9, 8.2]], [[200.0, 20.0], [210.0, huge], [150.0, 90.0]]]
+        for k, t in enumerate(tris):
+            v = np.array(t, np.float32)
+            batches.append(api.Batch2D.new(v, np.array([[0, 1, 2]], np.uint32), np.array([[0, 0], [1, 0], [0, 1]], np.float32)).source(B.PixelSource.Pixel((250 - 60 * k, 40 + 70 * k, 120, 200))))
+        ln = np.array([[20.0, 130.0], [huge, 135.0], [100.0, 10.0]], np.float32)
+        if abs(huge) < 1.0e9:   # (segments end within +-2^30)
+            batches.append(api.Batch2D.new(ln, np.array([[0, 1, 0], [0, 2, 0]], np.uint32), np.zeros_like(ln)).mode(B.MODE_LINES).source(B.PixelSource.Pixel((255, 255, 0, 255))))
+        scene = api.Scene.from_static(batches, [])
+
+        def setup():
+            v_, p_ = api.D3OrbitCamera.new().matrices(float(W), float(H))
+            return api.Rasterizer.setup(None, v_, p_).render_mode(B.RenderMode.render_2d()).background((5, 5, 5, 255))
+
+        return scenes._result(api, scene, api.Assets.default(), setup, W, H, tile_size, "huge-2d")
+
+    product.lib.rxh_set_device_projection.argtypes = [C.c_int]
+    product.lib.rxh_set_device_projection(1 if device_projection else 0)
+    try:
+        got = scenes.render(build(product))
+    finally:
+        product.lib.rxh_set_device_projection(0)
+    ref = scenes.render(build(oracle))
+    d = (got != ref).any(axis=2)
+    assert not d.any(), f"{huge}, tile {tile_size}: {int(d.sum())} pixels differ; first at {np.argwhere(d)[:3].tolist()}"

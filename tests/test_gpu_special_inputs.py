@@ -169,3 +169,43 @@ def test_random_combinations_of_poisoned_numbers(oracle, product, seed):
         ref = scenes.render(build_random(oracle, seed))
         d = (got != ref).any(axis=2)
         assert not d.any(), f"seed {seed}, device projection {dp}: {int(d.sum())} pixels differ; first at {np.argwhere(d)[:3].tolist()}: device {got[tuple(np.argwhere(d)[0])].tolist()} oracle {ref[tuple(np.argwhere(d)[0])].tolist()}"
+
+
+@pytest.mark.parametrize("device_projection", [False, True])
+@pytest.mark.parametrize("tile_size", [8, 40, 64, 300])
+@pytest.mark.parametrize("huge", [-1.0e30, 1.0e30, -1.0e12, 1.0e7, -2.0e4])
+def test_3d_batches_with_huge_projected_coordinates_follow_the_reference_s_tiles(oracle, product, huge, tile_size, device_projection):
+    """the 3D analogue of tests/test_gpu_special_2d.py's huge-coordinate case: a triangle with one vertex far off to the side projects to
+    a finite but enormous screen coordinate; its batch's box is Rect {x: min, width: max - min} and the reference skips the batch for
+    every tile that the rounded `x + width` does not reach (rasterizer.rs:978-983) -- the device clips to the tiles that pass"""
+    def build(api):
+        scene = api.Scene.empty()
+        back = np.array([[-9, -7, -6.0, 1], [9, -7, -6.0, 1], [9, 7, -6.0, 1], [-9, 7, -6.0, 1]], np.float32)
+        b = api.Batch3D.new(back, np.array([[0, 1, 2], [0, 2, 3]], np.uint32), np.zeros((4, 2), np.float32)).with_computed_normals().cull_mode(0)
+        b.source(B.PixelSource.Pixel((40, 90, 160, 255))).ambient_color((1.0, 1.0, 1.0))
+        scene.add_d3_static(b)
+        for k, (axis, vert) in enumerate([(0, 1), (1, 2), (0, 0), (1, 1)]):
+            v = np.array([[-0.8 + 0.5 * k, -0.6, -1.0, 1], [0.1 + 0.4 * k, -0.5, -1.3, 1], [-0.3 + 0.5 * k, 0.7, -0.9, 1]], np.float32)
+            v[vert, axis] = huge
+            t = api.Batch3D.new(v, np.array([[0, 1, 2]], np.uint32), np.array([[0, 0], [1, 0], [0, 1]], np.float32)).with_computed_normals().cull_mode(0)
+            t.source(B.PixelSource.Pixel((250 - 50 * k, 60 + 40 * k, 90, 255))).ambient_color((1.0, 1.0, 1.0))
+            scene.add_d3_static(t)
+        cam = api.D3OrbitCamera.new()
+        cam.set_parameter_f32("distance", 3.0)
+        cam.azimuth = float(np.float32(np.pi / 2))
+
+        def setup():
+            v_, p_ = cam.matrices(float(W), float(H))
+            return api.Rasterizer.setup(None, v_, p_).ambient((1.0, 1.0, 1.0, 1.0))
+
+        return scenes._result(api, scene, api.Assets.default(), setup, W, H, tile_size, "huge-3d")
+
+    product.lib.rxh_set_device_projection.argtypes = [C.c_int]
+    product.lib.rxh_set_device_projection(1 if device_projection else 0)
+    try:
+        got = scenes.render(build(product))
+    finally:
+        product.lib.rxh_set_device_projection(0)
+    ref = scenes.render(build(oracle))
+    d = (got != ref).any(axis=2)
+    assert not d.any(), f"{huge}, tile {tile_size}: {int(d.sum())} pixels differ; first at {np.argwhere(d)[:3].tolist()}: device {got[tuple(np.argwhere(d)[0])].tolist()} oracle {ref[tuple(np.argwhere(d)[0])].tolist()}"

@@ -17,7 +17,7 @@ POISON = [("intensity", v) for v in (NAN, INF, -INF, 0.0, -2.0, 1e-40)] + \
          [("start_distance", v) for v in (NAN, INF, -1.0, 5.0)] + [("end_distance", v) for v in (NAN, INF, 0.0, -3.0)] + \
          [("position", (NAN, 1.0, 8.0)), ("position", (INF, 1.0, 8.0)), ("position", (6.0, 3.0e38, 8.0)), ("position", (-5.0, -0.0, 4.0e9)), ("position", (-INF, 1.0, 8.0))] + \
          [("color", (NAN, 1.0, 1.0)), ("color", (INF, 0.0, -1.0))] + [("flicker", v) for v in (NAN, INF, 0.5, -1.0)] + \
-         [("start==end", 4.0), ("start>end", 9.0)]
+         [("start==end", 4.0), ("start>end", 9.0), ("huge product", 3.0e38), ("huge product", 2.0e9)]
 TYPES = [B.LIGHT_POINT, B.LIGHT_SPOT, B.LIGHT_AREA, B.LIGHT_AMBIENT, B.LIGHT_DAYLIGHT]
 
 
@@ -30,6 +30,8 @@ def build(api, light_type, field, value):
         l.start_distance = l.end_distance = value
     elif field == "start>end":
         l.start_distance, l.end_distance = value, 3.0
+    elif field == "huge product":   # finite parameters whose product overflows: colour x flicker (x the 0 of an out-of-range fragment in the fused term)
+        l.color, l.flicker, l.end_distance = (-value, 0.5, 0.35), value, 4.0
     elif field is not None:
         setattr(l, field, value)
     cfg.scene.add_dynamic_light(l.compile())

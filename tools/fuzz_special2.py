@@ -19,7 +19,7 @@ POOL = [NAN, INF, -INF, 0.0, -0.0, -1.0, 1e-40, 3.0e38, -3.0e38, 1e30]
 prod, orc = rusterix_amd.load(), load_oracle()
 
 
-def build(api, seed):
+def build(api, seed, use_lights=True, use_2d=True, use_extras=True, log=None):
     rng = np.random.default_rng([0x52585231, 1313, seed])
     pick = lambda: POOL[int(rng.integers(0, len(POOL)))]   # noqa: E731
     cfg = scenes.map_scene(api, width=256, height=144, n_lights=int(rng.integers(1, 4)), logo_size=16)
@@ -39,7 +39,10 @@ def build(api, seed):
                 setattr(l, f, pick())
         if l.direction == (0.0, 0.0, 0.0) or l.normal == (0.0, 0.0, 0.0):
             pass   # (the zero vector normalises to NaN on both sides)
-        cfg.scene.add_dynamic_light(l.compile())
+        if use_lights:
+            cfg.scene.add_dynamic_light(l.compile())
+        if log is not None:
+            log.append(("light", t, l.position, l.color, l.intensity, l.start_distance, l.end_distance, l.flicker, l.direction, l.normal, l.width, l.height, l.cone_angle, l.from_linedef))
     for _ in range(int(rng.integers(0, 3))):
         v = rng.uniform(0, 250, (3, 2)).astype(np.float32)
         uv = rng.uniform(0, 1, (3, 2)).astype(np.float32)
@@ -47,7 +50,10 @@ def build(api, seed):
             v[int(rng.integers(0, 3)), int(rng.integers(0, 2))] = pick()
         if rng.random() < 0.5:
             uv[int(rng.integers(0, 3)), int(rng.integers(0, 2))] = pick()
-        cfg.scene.add_d2_static(api.Batch2D.new(v, np.array([[0, 1, 2]], np.uint32), uv).source(B.PixelSource.Pixel(tuple(int(c) for c in rng.integers(0, 256, 3)) + (int(rng.integers(30, 256)),))))
+        if log is not None:
+            log.append(("2d", v.tolist(), uv.tolist()))
+        if use_2d:
+          cfg.scene.add_d2_static(api.Batch2D.new(v, np.array([[0, 1, 2]], np.uint32), uv).source(B.PixelSource.Pixel(tuple(int(c) for c in rng.integers(0, 256, 3)) + (int(rng.integers(30, 256)),))))
     base = cfg.setup
     extras = []
     for _ in range(int(rng.integers(0, 3))):
@@ -76,9 +82,12 @@ def build(api, seed):
             a[int(rng.integers(0, 2))] = pick()
         extras.append(("line", tuple(a), tuple(b)))
 
+    if log is not None:
+        log.extend(extras)
+
     def setup():
         r = base()
-        for e in extras:
+        for e in (extras if use_extras else []):
             if e[0] == "occ":
                 r.mapmini_add_occluder(e[1], e[2], e[3])
             elif e[0] == "sun":
@@ -91,6 +100,8 @@ def build(api, seed):
     return cfg
 
 
+if __name__ != "__main__":
+    raise SystemExit
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 bad = []
