@@ -125,8 +125,36 @@ bool to_isize32(float x, int32_t &out) {
     return true;
 }
 
+// `x as u32` (Rust: saturating, NaN -> 0), as the device's sat_u32
+static uint32_t rust_as_u32(float x) {
+    if (!(x > 0.0f)) return 0u;
+    if (x >= 4294967296.0f) return 0xFFFFFFFFu;
+    return (uint32_t)x;
+}
+
+// The LightFast record of one light (rxr_device.h): the fragment-independent factors of the relaxed point-light term, by the
+// reference's own operations (CompiledLight::apply_flicker, light.rs:506-527; smoothstep(end, start, d), light.rs:545).
+static void light_fast_record(const rxr_light &l, uint32_t hash_anim, LightFast &out) {
+    memset(&out, 0, sizeof(out));
+    memcpy(out.pos, l.position, 12);
+    const float ssd = l.start_distance - l.end_distance;
+    const float a = std::fabs(ssd);
+    // (the window of rxr_exact_math.h: 2^-40 .. 2^40; the fused form also wants start < end, as every real light has it)
+    if (l.light_type != RXR_LIGHT_POINT || !l.emitting || !(a >= 0x1p-40f && a <= 0x1p40f) || !(l.start_distance < l.end_distance)) return;
+    float ff = 1.0f;
+    if (l.flicker > 0.0f) {
+        const uint32_t combined = hash_anim + (rust_as_u32(l.position[0]) + rust_as_u32(l.position[1]) + rust_as_u32(l.position[2])) * 100u;
+        float fv = (float)combined / 4294967296.0f;
+        fv = fv < 0.0f ? 0.0f : (fv > 1.0f ? 1.0f : fv);
+        ff = 1.0f - fv * l.flicker;
+    }
+    out.ss_r = 1.0f / ssd;
+    out.c0 = -l.end_distance * out.ss_r;
+    for (int k = 0; k < 3; ++k) out.cfi[k] = l.color[k] * l.intensity * ff;
+}
+
 struct Layout {
-    size_t off_b3, off_base, off_pv, off_uv, off_nrm, off_idx, off_edges, off_tinfo, off_clip3d, off_lights, off_occ, off_ld, off_chunks, off_tdesc,
+    size_t off_b3, off_base, off_pv, off_uv, off_nrm, off_idx, off_edges, off_tinfo, off_clip3d, off_lights, off_lights_fast, off_occ, off_ld, off_chunks, off_tdesc,
         off_ltex, off_b2, off_p2, off_bg, total;
 };
 
@@ -1156,6 +1184,7 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
         }
     L.off_clip3d = take(any_risky3d ? n_b3 * sizeof(uint4) : 0);
     L.off_lights = take(f->n_lights * sizeof(rxr_light));
+    L.off_lights_fast = take(f->n_lights * sizeof(LightFast));
     L.off_occ = take(n_occ_total * sizeof(rxr_occluder));
     L.off_ld = take(f->n_linedefs * sizeof(rxr_linedef));
     L.off_chunks = take(f->n_chunks * sizeof(ChunkRange));
@@ -1485,6 +1514,7 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
     }
 
     if (f->n_lights) memcpy(st + L.off_lights, f->lights, f->n_lights * sizeof(rxr_light));
+    for (uint32_t i = 0; i < f->n_lights; ++i) light_fast_record(f->lights[i], f->hash_anim, *reinterpret_cast<LightFast *>(st + L.off_lights_fast + i * sizeof(LightFast)));
     {
         rxr_occluder *oc = (rxr_occluder *)(st + L.off_occ);
         if (f->n_occluders) memcpy(oc, f->occluders, f->n_occluders * sizeof(rxr_occluder));
@@ -1901,6 +1931,7 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
     P.large_list = (uint32_t *)ctx->d_large.p;
     P.counters = (uint32_t *)ctx->d_counters.p;
     P.lights = (const rxr_light *)(d + L.off_lights);
+    P.lights_fast = (const LightFast *)(d + L.off_lights_fast);
     P.occluders = (const rxr_occluder *)(d + L.off_occ);
     P.linedefs = (const rxr_linedef *)(d + L.off_ld);
     P.chunks = (const ChunkRange *)(d + L.off_chunks);

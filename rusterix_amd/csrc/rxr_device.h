@@ -244,6 +244,20 @@ RXR_HD inline void rxr_ref_tile_span(float lo, float extent, uint32_t size, uint
 }
 
 // kernel parameter block (passed by value; lives in the kernarg segment -> scalar loads)
+// Per-light constants of the relaxed point-light term (shade3d_lights<X, true>; RXR_LIGHT_MATH=relaxed).  Everything in the term that
+// depends on the light and the frame but not on the fragment -- colour x intensity x flicker, the smoothstep's reciprocal
+// 1 / (start - end) and its offset -end / (start - end) -- is a function of the inputs of rxr_upload_frame (the light records and
+// hash_anim), so the host evaluates it once per frame next to the light records instead of every wave once per light in VALU
+// instructions on wave-uniform operands (gfx950's scalar unit has no float arithmetic): the loop reads this record through the
+// scalar cache.  ss_r == 0: the light is not a well-formed emitting point light (or a parameter is outside the exact-math window)
+// and takes the general path, which reads the rxr_light record itself.
+struct LightFast {
+    float pos[3];
+    float ss_r;    // 1 / (start_distance - end_distance), or 0
+    float cfi[3];  // colour * intensity * (1 - flicker value)
+    float c0;      // -end_distance * ss_r:  t = clamp(distance * ss_r + c0, 0, 1)
+};
+
 struct RasterParams {
     uint32_t width, height;
     uint32_t row0, row1;           // band of rows this launch renders
@@ -328,6 +342,7 @@ struct RasterParams {
     uint32_t *counters;
 
     const rxr_light *lights;
+    const LightFast *lights_fast;      // one per light, made by the host with the frame (rxr_upload_frame): shade3d_lights<X, true>
     const rxr_occluder *occluders;     // mapmini occluders first, then the chunks'
     const rxr_linedef *linedefs;
     const ChunkRange *chunks;

@@ -127,6 +127,20 @@ __device__ __forceinline__ T uniform_record(const T *table, uint32_t i) {
     return table[i];
 #endif
 }
+// a 32-byte record in ONE scalar load (the word-by-word form above lets the compiler fetch the fields where they are first used:
+// several dependent scalar-cache round trips when the uses sit behind one another's branches)
+template <class T>
+__device__ __forceinline__ T uniform_record_x8(const T *table, uint32_t i) {
+    static_assert(sizeof(T) == 32, "eight 32-bit fields");
+    typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+    typedef const u32x8 __attribute__((address_space(4))) *vec_ptr;
+    const u32x8 v = *(vec_ptr)(table + i);
+    T out;
+    uint32_t *dst = reinterpret_cast<uint32_t *>(&out);
+#pragma unroll
+    for (uint32_t k = 0; k < 8; ++k) dst[k] = v[k];
+    return out;
+}
 
 __device__ __forceinline__ f3 mk3(float x, float y, float z) { return f3{x, y, z}; }
 __device__ __forceinline__ f3 add3(f3 a, f3 b) { return f3{a.x + b.x, a.y + b.y, a.z + b.z}; }
@@ -727,6 +741,15 @@ __device__ __forceinline__ float wave_max(float v) {
 // RL: the relaxed arithmetic of RXR_LIGHT_MATH=relaxed for POINT lights (every quantity is continuous in the fragment's position
 // there: the range test, the smoothstep and the Lambert / specular cut-offs all meet their neighbours at zero, so an error of a
 // few ulp moves a channel by at most one step); spot, area and daylight lights have hard cut-offs and stay exact in both modes.
+#ifndef RXR_RL_POW6
+#define RXR_RL_POW6 1   // (0: exp2(6 log2 x) also below feature level 2 -- A-B measurements)
+#endif
+#ifndef RXR_RL_TABLE
+#define RXR_RL_TABLE 1  // (0: the light's constants from its rxr_light record in the loop -- A-B measurements)
+#endif
+#ifndef RXR_RL_FOLD
+#define RXR_RL_FOLD 1   // (0: the light direction formed and normalised first -- A-B measurements)
+#endif
 template <int X, bool RL = false>
 __device__ __forceinline__ void shade3d_lights(const RasterParams &P, bool hit, Frag &F) {
     const unsigned long long hitmask = __ballot(hit);
@@ -765,6 +788,11 @@ __device__ __forceinline__ void shade3d_lights(const RasterParams &P, bool hit, 
             ss_rcp = rxm::rcp_refined(ssd);
         }
         const unsigned long long ss_ok_mask = __ballot(ss_ok);
+        // lights of this step that have a LightFast record (relaxed mode): one bit per light, tested by the scalar unit in the loop
+        unsigned long long fast_mask = 0ull;
+#if RXR_RL_TABLE
+        if constexpr (RL) fast_mask = __ballot(cand && __float_as_uint(P.lights_fast[cand ? mine : 0u].ss_r) != 0u);
+#endif
         if (cand && can_cull) {
             const rxr_light &L = P.lights[mine];
             if (L.light_type == RXR_LIGHT_POINT || L.light_type == RXR_LIGHT_SPOT || L.light_type == RXR_LIGHT_AREA ||
@@ -780,9 +808,54 @@ __device__ __forceinline__ void shade3d_lights(const RasterParams &P, bool hit, 
             const int li_lane = __ffsll((long long)todo) - 1;
             const uint32_t li = base_i + (uint32_t)li_lane;
             todo &= todo - 1ull;
-            const float ss_r = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ss_rcp), li_lane));
-            const bool ss_fast = (ss_ok_mask >> li_lane) & 1ull;
+            // (read where the exact kernels have always read it; the relaxed kernels want it only behind their fast path)
+            constexpr bool table_path = RL && RXR_RL_TABLE;
+            float ss_r = 0.0f;
+            bool ss_fast = false;
+            if constexpr (!table_path) {
+                ss_r = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ss_rcp), li_lane));
+                ss_fast = (ss_ok_mask >> li_lane) & 1ull;
+            }
             if (!hit) continue;
+#if RXR_RL_TABLE
+            if constexpr (RL) {
+                // The whole point-light term in relaxed arithmetic (see the block below, which this one replaces: the same
+                // expressions) with every fragment-independent factor read from the light's LightFast record -- made by the host
+                // with the frame, fetched through the scalar cache: no VALU instruction on a wave-uniform operand is left in the loop.
+                // t = clamp((distance - end) / (start - end)) as ONE fused multiply-add, distance * ss_r + (-end * ss_r); colour,
+                // intensity and flicker arrive as one product.
+                if ((fast_mask >> li_lane) & 1ull) {
+                    const LightFast LF = uniform_record_x8(P.lights_fast, li);  // one s_load_dwordx8
+                    const f3 d = sub3(mk3(LF.pos[0], LF.pos[1], LF.pos[2]), F.world);
+                    const float m2 = fmaf(d.z, d.z, fmaf(d.y, d.y, d.x * d.x));
+                    if (rxm::wave_all(rxm::sq_in_window(m2))) {
+                        const float inv = __builtin_amdgcn_rsqf(m2);
+                        const float t = __builtin_amdgcn_fmed3f(fmaf(m2 * inv, LF.ss_r, LF.c0), 0.0f, 1.0f);
+                        const float ss = t * t * fmaf(-2.0f, t, 3.0f);
+                        const float ndl = __builtin_amdgcn_fmed3f(fmaf(F.normal.z, d.z, fmaf(F.normal.y, d.y, F.normal.x * d.x)) * inv, 0.0f, 1.0f);
+                        const f3 hu = mk3(fmaf(d.x, inv, F.view_dir.x), fmaf(d.y, inv, F.view_dir.y), fmaf(d.z, inv, F.view_dir.z));
+                        const float hh = fmaf(hu.z, hu.z, fmaf(hu.y, hu.y, hu.x * hu.x));  // 0 (l = -v: n.h = NaN -> 0 below) or >= 1e-15
+                        const float ndh = __builtin_amdgcn_fmed3f(fmaf(F.normal.z, hu.z, fmaf(F.normal.y, hu.y, F.normal.x * hu.x)) * __builtin_amdgcn_rsqf(hh), 0.0f, 1.0f);
+                        float spec;
+                        if constexpr (X < 2) {  // rough = 0.5: shininess = 6 exactly (see below)
+                            const float ndh2 = ndh * ndh;
+                            spec = ndh2 * ndh2 * ndh2;
+                        } else {
+                            spec = __builtin_amdgcn_exp2f(rl_shininess * __builtin_amdgcn_logf(ndh));  // (0 for n.h = 0)
+                        }
+                        const float s = ss * ndl * ndl;
+                        F.lit.x = fmaf(fmaf(rl_f.x, spec, rl_kd.x), LF.cfi[0] * s, F.lit.x);
+                        F.lit.y = fmaf(fmaf(rl_f.y, spec, rl_kd.y), LF.cfi[1] * s, F.lit.y);
+                        F.lit.z = fmaf(fmaf(rl_f.z, spec, rl_kd.z), LF.cfi[2] * s, F.lit.z);
+                        continue;
+                    }
+                }
+            }
+#endif
+            if constexpr (table_path) {
+                ss_r = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ss_rcp), li_lane));
+                ss_fast = (ss_ok_mask >> li_lane) & 1ull;
+            }
             const rxr_light L = uniform_record(P.lights, li);
             const f3 lp = mk3(L.position[0], L.position[1], L.position[2]);
             f3 incoming, ldir;
@@ -791,7 +864,7 @@ __device__ __forceinline__ void shade3d_lights(const RasterParams &P, bool hit, 
                 // (lp - world).normalized(): |world - lp| and |lp - world| are the same float
                 if (!L.emitting) continue;
                 f3 d = sub3(lp, F.world);
-                if constexpr (RL) {
+                if constexpr (RL && !RXR_RL_TABLE) {
                     // The whole point-light term in relaxed arithmetic: fused multiply-adds, one v_rsq_f32 per normalisation, the
                     // half vector never normalised (n.h = n.(l + v) * rsq(|l + v|^2)), and the scalar factors gathered before they
                     // meet the colour:  lit += (kd + f * spec) * (colour * flicker) * (intensity * (n.l)^2).  Every operand stays
@@ -809,13 +882,28 @@ __device__ __forceinline__ void shade3d_lights(const RasterParams &P, bool hit, 
                         // the lights that reach no fragment of the wave).  The clamps are output modifiers of the multiplies.
                         const float t = __builtin_amdgcn_fmed3f((distance - L.end_distance) * ss_r, 0.0f, 1.0f);
                         const float intensity = L.intensity * (t * t * fmaf(-2.0f, t, 3.0f));
-                        const f3 l = scale3(d, inv);
                         // max(n.l, 0) and max(n.h, 0) as clamps to [0, 1] (both are cosines: at most 1 + 2 ulp)
+#if RXR_RL_FOLD
+                        // l = d / |d| is never formed: n.l = (n.d) / |d| and l + v = d / |d| + v as one fused multiply-add per component
+                        const float ndl = __builtin_amdgcn_fmed3f(fmaf(F.normal.z, d.z, fmaf(F.normal.y, d.y, F.normal.x * d.x)) * inv, 0.0f, 1.0f);
+                        const f3 hu = mk3(fmaf(d.x, inv, F.view_dir.x), fmaf(d.y, inv, F.view_dir.y), fmaf(d.z, inv, F.view_dir.z));
+#else
+                        const f3 l = scale3(d, inv);
                         const float ndl = __builtin_amdgcn_fmed3f(fmaf(F.normal.z, l.z, fmaf(F.normal.y, l.y, F.normal.x * l.x)), 0.0f, 1.0f);
                         const f3 hu = add3(l, F.view_dir);
+#endif
                         const float hh = fmaf(hu.z, hu.z, fmaf(hu.y, hu.y, hu.x * hu.x));  // 0 (l = -v: n.h = NaN -> 0 below) or >= 1e-15
                         const float ndh = __builtin_amdgcn_fmed3f(fmaf(F.normal.z, hu.z, fmaf(F.normal.y, hu.y, F.normal.x * hu.x)) * __builtin_amdgcn_rsqf(hh), 0.0f, 1.0f);
-                        const float spec = __builtin_amdgcn_exp2f(rl_shininess * __builtin_amdgcn_logf(ndh));  // (0 for n.h = 0)
+                        // Below feature level 2 no program sets roughness: rough = 0.5, shininess = 2 / 0.25 - 2 = 6 exactly, and the
+                        // reference's powf(n.h, 6) is three multiplies (each within half an ulp: closer to powf than exp2(6 log2 x),
+                        // whose v_log_f32 error the exponent multiplies by six) instead of two quarter-rate transcendentals
+                        float spec;
+                        if constexpr (X < 2 && RXR_RL_POW6) {
+                            const float ndh2 = ndh * ndh;
+                            spec = ndh2 * ndh2 * ndh2;
+                        } else {
+                            spec = __builtin_amdgcn_exp2f(rl_shininess * __builtin_amdgcn_logf(ndh));  // (0 for n.h = 0)
+                        }
                         const f3 cf = apply_flicker(L, 1.0f, P.hash_anim);  // wave-uniform
                         const float s = intensity * ndl * ndl;
                         F.lit.x = fmaf(fmaf(rl_f.x, spec, rl_kd.x), cf.x * s, F.lit.x);

@@ -317,3 +317,17 @@ def test_palette_miss_sends_the_set_back_to_the_interpreter(oracle, product, mon
     assert np.array_equal(got, ref)
     # the three thirds differ: colour 0 + (0.1, 0.2, 0.3); nothing pushed, so the Add takes the two constants; colour 2 + (0.1, 0.2, 0.3)
     assert len({tuple(got[H // 2, x]) for x in (W // 6, W // 2, 5 * W // 6)}) == 3
+
+
+def test_the_reference_crates_own_test_programs(oracle, product, monkeypatch):
+    """`addition` and `fib` of rusteria/src/lib.rs:274-296 -- the only assertions the reference holds for code of this path -- as the NodeOp
+    lists its compiler emits (tests/test_oracle_reference_tests.py pins the oracle's Execution to their asserted values, 4.0 and
+    fib(27) = 196418.0).  Here the same two programs run on the device, interpreted and compiled, against that oracle: fib over
+    n = 0 .. 5 by pixel (the device bounds a call chain by eight frames where the reference recurses on the Rust stack)."""
+    from tests.test_oracle_reference_tests import FIB
+    addition = Program([[("Push", 2.0), ("StoreGlobal", 0), ("LoadGlobal", 0), ("Push", 2.0), "Add", ("Push", 0.125), "Mul", "SetColor"]], globals=1)
+    fib = Program([["UV", ("GetComponents", [0]), ("Push", 24.0), "Mul", "Floor", ("FunctionCall", 1, 1, 1), ("Push", 0.125), "Mul", "SetColor"], FIB])
+    got, _ = three_ways(oracle, product, monkeypatch, lambda api: grid_scene(api, [addition, fib]))
+    left = got[:, : W // 2 - 1, :3].reshape(-1, 3)
+    assert (left == left[0]).all() and 127 <= int(left[0, 0]) <= 128            # 4 * 0.125
+    assert len(np.unique(got[:, W // 2 + 1:, 0])) >= 4                           # fib(0 .. 5) / 8 = 0, 1/8, 1/8, 2/8, 3/8, 5/8
