@@ -604,9 +604,11 @@ void *rxr_device_framebuffer(rxr_ctx *ctx);
  * 0 div2, 1 div3, 2 div3_self, 3 normalize3, 4 sqrt, 5 pow, 6 div1, 7 pixel-centre/size and byte/255,
  * 8 normalize3 with exactly-zero components (surface normals), 9 sqrt over a strided sweep of its whole
  * operand window (stride and phase from the seed; the sweep covers n_tuples operands), 10 the saturating float -> u32 conversion
- * (Rust's `as` casts, one v_cvt_u32_f32) against its compare-and-select form over a strided sweep of all bit patterns.
+ * (Rust's `as` casts, one v_cvt_u32_f32) against its compare-and-select form over a strided sweep of all bit patterns,
+ * 11 the wave maximum of non-negative floats and 12 the wave's inclusive prefix sum through DPP operands against the shuffle forms
+ * (at most 64 tuples per lane each).
  * Blocking.  Nothing in the reference corresponds to it. */
-#define RXR_MATH_KINDS 11
+#define RXR_MATH_KINDS 13
 int rxr_selftest_math(rxr_ctx *ctx, uint64_t n_tuples, uint64_t seed, uint64_t mismatches[RXR_MATH_KINDS]);
 
 #ifdef __cplusplus

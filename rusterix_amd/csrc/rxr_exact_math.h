@@ -246,6 +246,44 @@ __device__ __forceinline__ uint32_t sat_u32(float x) {
 #endif
 }
 
+// Maximum over the 64 lanes of a wave of NON-NEGATIVE floats (+0, denormals, normals, +inf: their order is the order of their bit
+// patterns as unsigned integers), returned in a scalar register.  Six v_max_u32 with DPP operands -- inside each quad, across the
+// quads of a row of 16, then rows 0 -> 1 and 2 -> 3 (row_bcast:15) and rows 0..1 -> 2..3 (row_bcast:31): lane 63 holds the wave's
+// maximum -- and one v_readlane_b32, against six dependent ds_bpermute_b32 round trips through the LDS crossbar (with the index
+// arithmetic and the canonicalising v_max_f32 pairs of fmaxf: 36 VALU instructions) for the __shfl_xor butterfly.  EVERY lane of the
+// wave must be active.  A NaN or a negative operand makes the result meaningless, not undefined.  (Lanes a DPP pattern does not
+// write read 0, the identity of the unsigned maximum: the compiler can then fold the move into v_max_u32_dpp.)
+__device__ __forceinline__ float wave_max_nonneg(float v) {
+    int x = (int)__builtin_bit_cast(unsigned int, v);
+#define RXR_DPP_MAX_U32(ctrl, row_mask) \
+    x = (int)__builtin_elementwise_max((unsigned int)x, (unsigned int)__builtin_amdgcn_update_dpp(0, x, ctrl, row_mask, 0xf, false))
+    RXR_DPP_MAX_U32(0xB1, 0xf);   // quad_perm:[1,0,3,2]
+    RXR_DPP_MAX_U32(0x4E, 0xf);   // quad_perm:[2,3,0,1]
+    RXR_DPP_MAX_U32(0x141, 0xf);  // row_half_mirror
+    RXR_DPP_MAX_U32(0x140, 0xf);  // row_mirror: every lane of a row holds the row's maximum
+    RXR_DPP_MAX_U32(0x142, 0xa);  // row_bcast:15 into rows 1 and 3
+    RXR_DPP_MAX_U32(0x143, 0xc);  // row_bcast:31 into rows 2 and 3
+#undef RXR_DPP_MAX_U32
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(x, 63));
+}
+
+// Inclusive prefix sum of a 32-bit integer over the 64 lanes of a wave (EVERY lane active): four row_shr steps inside each row of 16
+// (lanes the shift leaves without a source add 0), then row 0's total into row 1 and row 2's into row 3 (row_bcast:15), then the
+// total of rows 0..1 into rows 2..3 (row_bcast:31) -- six v_add_u32 with DPP operands instead of the six dependent ds_bpermute_b32
+// round trips of the __shfl_up ladder.
+__device__ __forceinline__ unsigned int wave_inclusive_add(unsigned int v) {
+    int x = (int)v;
+#define RXR_DPP_ADD_U32(ctrl, row_mask) x += __builtin_amdgcn_update_dpp(0, x, ctrl, row_mask, 0xf, false)
+    RXR_DPP_ADD_U32(0x111, 0xf);  // row_shr:1
+    RXR_DPP_ADD_U32(0x112, 0xf);  // row_shr:2
+    RXR_DPP_ADD_U32(0x114, 0xf);  // row_shr:4
+    RXR_DPP_ADD_U32(0x118, 0xf);  // row_shr:8
+    RXR_DPP_ADD_U32(0x142, 0xa);  // row_bcast:15 into rows 1 and 3
+    RXR_DPP_ADD_U32(0x143, 0xc);  // row_bcast:31 into rows 2 and 3
+#undef RXR_DPP_ADD_U32
+    return (unsigned int)x;
+}
+
 // exp2f(k * log2f(x)) as the reference's pow32_fast computes it (rasterizer.rs:1895-1901)
 __device__ __forceinline__ float pow_exp2_log2(float x, float k) {
 #if RXR_EXACT_FAST

@@ -727,12 +727,6 @@ __device__ __forceinline__ void shade3d_begin(const RasterParams &P, const TriSh
     F.metal = metal;
 }
 
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d, 64));
-    return v;
-}
-
 // The direct-light loop (:1373-1391).  Must be called by EVERY lane of the wave (`hit` marks the lanes
 // that own a fragment).  Lights are first culled per WAVE, one light per lane: a light whose range
 // sphere cannot reach the bounding sphere of the wave's fragments is one for which every lane's
@@ -756,17 +750,28 @@ __device__ __forceinline__ void shade3d_lights(const RasterParams &P, bool hit, 
     if (hitmask == 0ull) return;
     const int lane = (int)(threadIdx.x & 63u);
     const int src = __ffsll((long long)hitmask) - 1;
-    const f3 c = mk3(__shfl(F.world.x, src, 64), __shfl(F.world.y, src, 64), __shfl(F.world.z, src, 64));
+    // (the centre through v_readlane_b32 -- `src` is a scalar -- and the radius through DPP operands: no LDS round trip in front of the loop)
+    const f3 c = mk3(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(F.world.x), src)),
+                     __int_as_float(__builtin_amdgcn_readlane(__float_as_int(F.world.y), src)),
+                     __int_as_float(__builtin_amdgcn_readlane(__float_as_int(F.world.z), src)));
     const float r = hit ? mag3_bound(sub3(F.world, c)) : 0.0f;
     // NaN / inf world positions are not bounded by the sphere: no culling for this wave then
     const bool can_cull = __ballot(hit && !(r < __builtin_huge_valf())) == 0ull;  // (INFINITY, without <cmath>: hiprtc)
-    const float rmax = wave_max(r);
+    const float rmax = rxm::wave_max_nonneg(r);  // (a magnitude, +0 for the lanes without a fragment; meaningless and unused when !can_cull)
     const float rough = (X >= 2) ? F.rough : 0.5f, metal = (X >= 2) ? F.metal : 0.0f;
     // relaxed mode: the light-independent factors of shade_fast_brdf (:1875-1951) once per fragment -- diffuse weight kd, Fresnel
     // term f, shininess -- by the reference's own operations
     f3 rl_kd = mk3(0.0f, 0.0f, 0.0f), rl_f = rl_kd;
     float rl_shininess = 1.0f;
-    if constexpr (RL) {
+    if constexpr (RL && X < 2) {
+        // no program below feature level 2: metal = 0 and the base colour is a texel's (finite), so f0 = lerp(0.04, base, 0) is 0.04
+        // in every channel -- the same floats as the general form below without its multiplications by zero
+        rl_kd = scale3(F.base, 1.0f - 0.04f);
+        rl_shininess = 6.0f;  // clamp(2 / 0.25 - 2, 1, 2048)
+        const float om = 1.0f - rclamp(fmaxf(dot3(F.normal, F.view_dir), 0.0f), 0.0f, 1.0f);
+        const float fs = 0.04f + (1.0f - 0.04f) * (om * om * om * om * om);
+        rl_f = mk3(fs, fs, fs);
+    } else if constexpr (RL) {
         const float tm = rclamp(metal, 0.0f, 1.0f);
         const f3 f0 = mk3(fmaf(tm, F.base.x - 0.04f, 0.04f), fmaf(tm, F.base.y - 0.04f, 0.04f), fmaf(tm, F.base.z - 0.04f, 0.04f));
         rl_kd = scale3(scale3(F.base, 1.0f - metal), 1.0f - fmaxf(f0.x, fmaxf(f0.y, f0.z)));
@@ -937,7 +942,11 @@ __device__ __forceinline__ void shade3d_lights(const RasterParams &P, bool hit, 
             } else {
                 radiance = scale3(incoming, n_dot_l);
             }
-            F.lit = add3(F.lit, shade_fast_brdf<RL>(F.base, rough, metal, F.normal, F.view_dir, ldir, radiance, n_dot_l));  // (continuous for every light type)
+            // (relaxed kernels: the general path is the rare one -- its light-independent factors (f0, kd, the Fresnel term) must not
+            // be hoisted in front of the loop, where every wave would pay for them: the empty asm ties them to this iteration)
+            float rough_g = rough, metal_g = metal;
+            if constexpr (table_path) asm volatile("" : "+v"(rough_g), "+v"(metal_g));
+            F.lit = add3(F.lit, shade_fast_brdf<RL>(F.base, rough_g, metal_g, F.normal, F.view_dir, ldir, radiance, n_dot_l));  // (continuous for every light type)
         }
     }
 }
@@ -2330,13 +2339,7 @@ __device__ RXR_ROWS_INLINE bool rows_round(const RasterParams &P, Stage &st, Row
     // (rows | area << 13): rows total <= 2^12, area total <= 2^16
     const uint32_t packed = PIX ? area : (rows | (area << 13));
     uint32_t inc = packed;
-    if (wave * 64u < n) {  // (wave-uniform: the waves behind the last candidate have nothing to add)
-#pragma unroll
-        for (uint32_t d = 1; d < 64; d <<= 1) {
-            const uint32_t o = __shfl_up(inc, d, 64);
-            if (lane >= d) inc += o;
-        }
-    }
+    if (wave * 64u < n) inc = rxm::wave_inclusive_add(packed);  // (wave-uniform: the waves behind the last candidate have nothing to add)
     const unsigned long long has = __ballot(rows != 0u);
     // cut-out candidates need a texel per fragment (:1408): such rounds are left to the walk, which keeps the sampling code
     // (and its registers) out of the row loop

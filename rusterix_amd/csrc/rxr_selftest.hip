@@ -65,7 +65,7 @@ __global__ void __launch_bounds__(256) k_selftest_math(uint64_t seed, uint32_t i
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t wave = gid >> 6;
     Rng g{mix64(seed ^ ((uint64_t)gid << 20))};
-    unsigned long long bad[RXR_MATH_KINDS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long bad[RXR_MATH_KINDS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (uint32_t it = 0; it < iters; ++it) {
         const uint32_t mode = (wave + it) & 3u;
         // ---- divisions sharing a denominator
@@ -160,6 +160,29 @@ __global__ void __launch_bounds__(256) k_selftest_math(uint64_t seed, uint32_t i
             const float x = __uint_as_float(bits);
             if (rxm::sat_u32(x) != rxm::sat_u32_ref(x)) bad[10]++;
         }
+    }
+    // ---- the DPP wave maximum of non-negative floats against the shuffle butterfly (outside the loop above: every lane of the wave
+    //      must be active, and a lane's loop may end early in no build of this kernel -- but the reduction must not depend on that).
+    //      Magnitudes of every exponent, +0, denormals, +inf; the maximum placed in every lane position over the tuples.
+    for (uint32_t it = 0; it < (iters < 64u ? iters : 64u); ++it) {
+        const uint32_t mode = (wave + it) & 3u;
+        float x = __builtin_fabsf(gen(g, mode, -120, 120));
+        if (x != x) x = __builtin_huge_valf();
+        if ((threadIdx.x & 63u) == ((it * 7u + wave) & 63u)) x = x * 4.0f + 1.0f;   // (a likely winner that walks through the lanes)
+        float ref = x;
+        for (int d = 32; d >= 1; d >>= 1) ref = fmaxf(ref, __shfl_xor(ref, d, 64));
+        if (!same(rxm::wave_max_nonneg(x), ref)) bad[11]++;
+        // the DPP inclusive prefix sum against the shuffle ladder: small counts (as the row-mode areas are), zeros, and full 32-bit words
+        // (the sum wraps the same way in both)
+        uint32_t c = g.next();
+        if (mode == 0) c &= 0xFFu;
+        else if (mode == 1) c = (c & 1u) ? 0u : (c >> 20);
+        uint32_t inc = c;
+        for (uint32_t d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(inc, d, 64);
+            if ((threadIdx.x & 63u) >= d) inc += o;
+        }
+        if (rxm::wave_inclusive_add(c) != inc) bad[12]++;
     }
     for (int k = 0; k < RXR_MATH_KINDS; ++k)
         if (bad[k]) atomicAdd(&mismatch[k], bad[k]);

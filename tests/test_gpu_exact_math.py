@@ -11,7 +11,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-KINDS = ["div2", "div3", "div3_self", "normalize3", "sqrt", "pow", "div1", "static", "normalize3_zeros", "sqrt_sweep", "sat_u32_cvt"]
+KINDS = ["div2", "div3", "div3_self", "normalize3", "sqrt", "pow", "div1", "static", "normalize3_zeros", "sqrt_sweep", "sat_u32_cvt", "wave_max_dpp", "wave_scan_dpp"]
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3])
