@@ -8,8 +8,10 @@
 // out of range, clamp with min > max, a For loop past 10 000 000 iterations) this throws vm::Fault,
 // which the raster loops turn into RXR_ERR_INVALID.
 //
-// PARITY UNPINNED: the reference has no tests for the VM either; pinned by the cited source text and by
-// the per-opcode known answers in tests/test_oracle_vm.py.
+// PINNED BY THE REFERENCE'S OWN TWO TESTS, otherwise unpinned: `addition` and `fib` (rusteria/src/lib.rs:274-296) are the only
+// assertions the reference holds for this VM -- tests/test_oracle_reference_tests.py runs the NodeOp lists its compiler emits for
+// them and requires 4.0 and fib(27) = 196418.0 (Push, globals, locals, Le, If / else, FunctionCall, Return, Add, Sub, recursion 27
+// deep).  Every other opcode is pinned only by the cited source text and the per-opcode known answers in tests/test_oracle_vm.py.
 #pragma once
 #include <cmath>
 #include <cstdint>
