@@ -2629,12 +2629,6 @@ __device__ __forceinline__ void scan_lists_rows(const RasterParams &P, Stage &st
     }
 }
 
-#ifndef RXR_STAGE_SHADE
-#define RXR_STAGE_SHADE 1  // (0: the winner's shading record always from HBM -- A-B measurements)
-#endif
-// scan_implicit: do the n_all set-up records (6 x 16 B) AND shading records (5 x 16 B) fit in the stage together?
-__device__ __forceinline__ bool implicit_shade_staged(uint32_t n_all) { return n_all * 11u <= (uint32_t)RXR_STAGE_TRIS * 6u; }
-static_assert(sizeof(TriShade) == 80, "TriShade is staged as 5 x 16 B");
 
 // Small-scene mode 2 ("implicit list": the whole frame has <= RXR_STAGE_TRIS triangles and k_setup3d has
 // written their records): no lists at all.  All records are copied to LDS with one round of coalesced
@@ -2647,15 +2641,6 @@ __device__ __forceinline__ void scan_implicit(const RasterParams &P, Stage &st, 
     const uint32_t n_all = min(P.n_tris3d, (uint32_t)RXR_STAGE_TRIS);
     const float4 *g4 = reinterpret_cast<const float4 *>(P.tri_setup);
     for (uint32_t f = tid; f < n_all * 6u; f += RXR_TILE_THREADS) st.tri[f] = g4[f];
-#if RXR_STAGE_SHADE
-    // frames small enough (implicit_shade_staged) also stage the SHADING records behind the set-up records, in the same round of
-    // loads: the winner's record is then an LDS read after the walk instead of the first of the shading phase's dependent global
-    // round trips (record -> batch header -> texture descriptor -> texel)
-    if (implicit_shade_staged(n_all)) {
-        const float4 *h4 = reinterpret_cast<const float4 *>(P.tri_shade);
-        for (uint32_t f = tid; f < n_all * 5u; f += RXR_TILE_THREADS) st.tri[n_all * 6u + f] = h4[f];
-    }
-#endif
     __syncthreads();
     bool keep = false;
     if (tid < n_all) {
@@ -3123,10 +3108,6 @@ __device__ __forceinline__ void raster_tile(const RasterParams &P) {
         F.metal = 0.0f;
         if (hit) {
             if constexpr (FUSED) HS = shade_store.s.shade[vis.slot];
-#if RXR_STAGE_SHADE
-            else if (P.fused_small == 2u && implicit_shade_staged(min(P.n_tris3d, (uint32_t)RXR_STAGE_TRIS)))  // (uniform)
-                HS = *reinterpret_cast<const TriShade *>(&stage.tri[min(P.n_tris3d, (uint32_t)RXR_STAGE_TRIS) * 6u + (uint32_t)vis.best * 5u]);  // (staged by the opaque pass's scan_implicit; the stage is next written behind pass2d's barrier)
-#endif
             else if (!ROWS || hs_of != vis.best) HS = P.tri_shade[vis.best];
             shade3d_begin<X, RL>(P, HS, vis.batch, vis.alpha, vis.beta, vis.zmin, fx, fy, F);
         }
