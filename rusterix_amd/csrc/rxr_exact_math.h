@@ -108,6 +108,22 @@ __device__ __forceinline__ void div2(float n0, float n1, float d, float &q0, flo
     q1 = n1 / d;
 }
 
+// div2 with the denominator's share of the work done once elsewhere (a triangle's area, by the thread that prepares its record for a
+// row-mode round): r = denominator_part(d).  The same instructions on the same operands: the same quotients.
+__device__ __forceinline__ float denominator_part(float d) { return in_window(d) ? rcp_refined(d) : 0.0f; }  // (never 0 inside the window)
+__device__ __forceinline__ void div2_pre(float n0, float n1, float d, float r, float &q0, float &q1) {
+#if RXR_EXACT_FAST
+    float lo = fminf(__builtin_fabsf(n0), __builtin_fabsf(n1)), hi = fmaxf(__builtin_fabsf(n0), __builtin_fabsf(n1));
+    if (wave_all(r != 0.0f && lo >= WIN_LO && hi <= WIN_HI)) {
+        q0 = div_chain(n0, d, r);
+        q1 = div_chain(n1, d, r);
+        return;
+    }
+#endif
+    q0 = n0 / d;
+    q1 = n1 / d;
+}
+
 __device__ __forceinline__ void div3(float n0, float n1, float n2, float d, float &q0, float &q1, float &q2) {
 #if RXR_EXACT_FAST
     float lo = __builtin_fminf(__builtin_fminf(__builtin_fabsf(n0), __builtin_fabsf(n1)), __builtin_fabsf(n2));

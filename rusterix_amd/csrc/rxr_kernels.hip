@@ -2072,15 +2072,21 @@ __device__ __forceinline__ int front_lookup(const Vis &v, int t) {
 #ifndef RXR_FAST_BARY
 #define RXR_FAST_BARY 1
 #endif
+// PRE: (pre_acx, pre_acy, pre_r) = (v2x - v0x, v2y - v0y, rxm::denominator_part(area)) -- what the expressions need of the TRIANGLE
+// alone -- computed once per candidate of a row-mode round by the thread that prepares it (rows_round) instead of by every pixel
+// item: the same operations on the same operands, so the same floats.
+template <bool PRE = false>
 __device__ __forceinline__ void bary_depth(float v0x, float v0y, float v1x, float v1y, float v2x, float v2y, float area, float iz0, float iz1, float iz2,
-                                           float fx, float fy, float &alpha, float &beta, float &z) {
+                                           float fx, float fy, float &alpha, float &beta, float &z, float pre_acx = 0.0f, float pre_acy = 0.0f,
+                                           float pre_r = 0.0f) {
     const float pcx = v2x - fx, pcy = v2y - fy;
     const float pbx = v1x - fx, pby = v1y - fy;
     const float apx = fx - v0x, apy = fy - v0y;
-    const float acx = v2x - v0x, acy = v2y - v0y;
+    const float acx = PRE ? pre_acx : v2x - v0x, acy = PRE ? pre_acy : v2y - v0y;
     const float na = pcx * pby - pcy * pbx, nb = acx * apy - acy * apx;
 #if RXR_FAST_BARY
-    rxm::div2(na, nb, area, alpha, beta);
+    if constexpr (PRE) rxm::div2_pre(na, nb, area, pre_r, alpha, beta);
+    else rxm::div2(na, nb, area, alpha, beta);
 #else
     alpha = na / area;
     beta = nb / area;
@@ -2291,6 +2297,12 @@ __device__ __forceinline__ uint32_t z_order_bits(float z) {
 #ifndef RXR_RESOLVE_INLINE
 #define RXR_RESOLVE_INLINE __forceinline__
 #endif
+#ifndef RXR_ROWS_PRE
+#define RXR_ROWS_PRE 1   // (0: every pixel item derives its triangle's own operands of bary_depth -- A-B measurements)
+#endif
+#ifndef RXR_ROWS_OWNER_DIRECT
+#define RXR_ROWS_OWNER_DIRECT 1  // (0: the chunk owners by binary search behind a barrier of their own -- A-B measurements)
+#endif
 #ifndef RXR_ROW_MODE_MAX_AREA
 #define RXR_ROW_MODE_MAX_AREA 128
 #endif
@@ -2364,12 +2376,32 @@ __device__ RXR_ROWS_INLINE bool rows_round(const RasterParams &P, Stage &st, Row
     }
     if constexpr (PIX) {
     if (tid < n) {
-        rl.row_start[tid] = before + inc - area;  // exclusive prefix of the areas
-        rl.raw[tid] = geo;                        // (the list entries' ids have moved to st.ids by now)
+        const uint32_t start = before + inc - area;  // exclusive prefix of the areas
+        rl.row_start[tid] = start;
+        rl.raw[tid] = geo;                           // (the list entries' ids have moved to st.ids by now)
+#if RXR_ROWS_PRE
+        // The round is row mode from here on: nothing reads the staged record's pixel box and flags again, and their words take what
+        // bary_depth needs of the triangle alone (its PRE form) -- once per candidate instead of once per pixel item.
+        if (area) {
+            TriSetup &W = *reinterpret_cast<TriSetup *>(&st.tri[(INDIRECT ? rl.slot[tid] : tid) * 6u]);
+            const float acx = W.v2x - W.v0x, acy = W.v2y - W.v0y, r = rxm::denominator_part(W.area);
+            W.bx = __float_as_uint(acx);
+            W.by = __float_as_uint(acy);
+            W.bflags = __float_as_uint(r);
+        }
+#endif
+        // first owner of every 64-item chunk (area_total <= 128 * 128: at most 256 chunks): item 64 c belongs to the one candidate
+        // WITH pixels whose range [start, start + area) holds it -- that candidate knows, so it writes the chunk's entry itself
+        // (usually none or one: ~20 items per candidate) instead of a binary search over the prefix by one thread per chunk behind
+        // another barrier.  Candidates without pixels in front of it share its start; the item loop steps over them as before.
+#if RXR_ROWS_OWNER_DIRECT
+        for (uint32_t c = (start + 63u) >> 6; (c << 6) < start + area; ++c) rl.chunk_owner[c] = (uint8_t)tid;
+#endif
     }
     if (tid == 0) rl.row_start[n] = area_total;
     __syncthreads();
-    // first owner of every 64-item chunk (area_total <= 128 * 128: at most 256 chunks): the largest k with row_start[k] <= chunk * 64
+#if !RXR_ROWS_OWNER_DIRECT
+    // the largest k with row_start[k] <= chunk * 64
     if (tid * 64u < area_total) {
         uint32_t lo = 0, hi = n;
         while (hi - lo > 1u) {
@@ -2380,6 +2412,7 @@ __device__ RXR_ROWS_INLINE bool rows_round(const RasterParams &P, Stage &st, Row
         rl.chunk_owner[tid] = (uint8_t)lo;
     }
     __syncthreads();
+#endif
     for (uint32_t base = 0; base < area_total; base += RXR_TILE_THREADS) {
         const uint32_t item = base + tid;
         if (item >= area_total) break;  // (no barrier inside the loop)
@@ -2399,7 +2432,12 @@ __device__ RXR_ROWS_INLINE bool rows_round(const RasterParams &P, Stage &st, Row
         if ((r0 < 0.0f) || (r1 < 0.0f) || (r2 < 0.0f)) continue;
         // barycentric_weights_3d and depth, as visit()
         float alpha, beta, z;
+#if RXR_ROWS_PRE
+        bary_depth<true>(S.v0x, S.v0y, S.v1x, S.v1y, S.v2x, S.v2y, S.area, S.iz0, S.iz1, S.iz2, fx, fy, alpha, beta, z, __uint_as_float(S.bx),
+                         __uint_as_float(S.by), __uint_as_float(S.bflags));
+#else
         bary_depth(S.v0x, S.v0y, S.v1x, S.v1y, S.v2x, S.v2y, S.area, S.iz0, S.iz1, S.iz2, fx, fy, alpha, beta, z);
+#endif
         if (!(z < 1.0f)) continue;  // never closer than the cleared buffer; also NaN
         const unsigned long long key = ((unsigned long long)z_order_bits(z + 0.0f) << 32) | t;  // -0 -> +0: they compare equal
         unsigned long long *const cell = &rl.key[ly * RXR_TILE_W + lx];

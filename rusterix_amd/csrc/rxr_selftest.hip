@@ -74,6 +74,8 @@ __global__ void __launch_bounds__(256) k_selftest_math(uint64_t seed, uint32_t i
             float a, b;
             rxm::div2(n0, n1, d, a, b);
             if (!same(a, n0 / d) || !same(b, n1 / d)) bad[0]++;
+            rxm::div2_pre(n0, n1, d, rxm::denominator_part(d), a, b);  // (the denominator's part precomputed: row mode)
+            if (!same(a, n0 / d) || !same(b, n1 / d)) bad[0]++;
         }
         {
             float a, b, c;
