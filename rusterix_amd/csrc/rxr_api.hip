@@ -137,6 +137,8 @@ static uint32_t rust_as_u32(float x) {
 static void light_fast_record(const rxr_light &l, uint32_t hash_anim, LightFast &out) {
     memset(&out, 0, sizeof(out));
     memcpy(out.pos, l.position, 12);
+    out.end_distance = l.end_distance;
+    out.cull_kind = (l.light_type == RXR_LIGHT_POINT || l.light_type == RXR_LIGHT_SPOT || l.light_type == RXR_LIGHT_AREA || l.light_type == RXR_LIGHT_DAYLIGHT) ? 1u : 0u;
     const float ssd = l.start_distance - l.end_distance;
     const float a = std::fabs(ssd);
     // (the window of rxr_exact_math.h: 2^-40 .. 2^40; the fused form also wants start < end, as every real light has it)

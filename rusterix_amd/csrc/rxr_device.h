@@ -256,7 +256,13 @@ struct LightFast {
     float ss_r;    // 1 / (start_distance - end_distance), or 0
     float cfi[3];  // colour * intensity * (1 - flicker value)
     float c0;      // -end_distance * ss_r:  t = clamp(distance * ss_r + c0, 0, 1)
+    // (the loop reads the 32 bytes above with one scalar load; the wave-level culling step in front of it reads position, ss_r and
+    // the two words below -- everything it needs of a light, in one round of loads -- for EVERY light, fast or not)
+    float end_distance;
+    uint32_t cull_kind;  // 1: a type with a range (point, spot, area, daylight) -- culled against the wave's bounding sphere
+    uint32_t pad[2];
 };
+static_assert(sizeof(LightFast) == 48, "LightFast: 32 bytes for the loop + 16 for the culling step");
 
 struct RasterParams {
     uint32_t width, height;

@@ -127,11 +127,11 @@ __device__ __forceinline__ T uniform_record(const T *table, uint32_t i) {
     return table[i];
 #endif
 }
-// a 32-byte record in ONE scalar load (the word-by-word form above lets the compiler fetch the fields where they are first used:
+// the first 32 bytes of a record in ONE scalar load (the word-by-word form above lets the compiler fetch the fields where they are first used:
 // several dependent scalar-cache round trips when the uses sit behind one another's branches)
 template <class T>
 __device__ __forceinline__ T uniform_record_x8(const T *table, uint32_t i) {
-    static_assert(sizeof(T) == 32, "eight 32-bit fields");
+    static_assert(sizeof(T) >= 32 && sizeof(T) % 4 == 0, "the first eight 32-bit fields of a record");
     typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
     typedef const u32x8 __attribute__((address_space(4))) *vec_ptr;
     const u32x8 v = *(vec_ptr)(table + i);
@@ -787,25 +787,57 @@ __device__ __forceinline__ void shade3d_lights(const RasterParams &P, bool hit, 
         // this step keeps the denominator's refined reciprocal (rxr_exact_math.h) and whether it is inside the window
         float ss_rcp = 0.0f;
         bool ss_ok = false;
-        if (cand) {
-            const float ssd = P.lights[mine].start_distance - P.lights[mine].end_distance;
-            ss_ok = rxm::in_window(ssd);
-            ss_rcp = rxm::rcp_refined(ssd);
-        }
-        const unsigned long long ss_ok_mask = __ballot(ss_ok);
+        unsigned long long ss_ok_mask = 0ull;
         // lights of this step that have a LightFast record (relaxed mode): one bit per light, tested by the scalar unit in the loop
         unsigned long long fast_mask = 0ull;
-#if RXR_RL_TABLE
-        if constexpr (RL) fast_mask = __ballot(cand && __float_as_uint(P.lights_fast[cand ? mine : 0u].ss_r) != 0u);
-#endif
-        if (cand && can_cull) {
-            const rxr_light &L = P.lights[mine];
-            if (L.light_type == RXR_LIGHT_POINT || L.light_type == RXR_LIGHT_SPOT || L.light_type == RXR_LIGHT_AREA ||
-                L.light_type == RXR_LIGHT_DAYLIGHT) {
-                float dcl = mag3_bound(sub3(c, mk3(L.position[0], L.position[1], L.position[2])));
-                // every fragment p of the wave has |p - L| >= dcl - rmax; the margin covers rounding
-                float margin = 1e-3f * (dcl + rmax + fabsf(L.end_distance)) + 1e-6f;
-                if (dcl - rmax > L.end_distance + margin) cand = false;
+        constexpr bool table_cull = RL && RXR_RL_TABLE;
+        if constexpr (table_cull) {
+            // Everything the step needs of a light -- position, range, whether its type is culled at all, whether it has a fast
+            // record -- comes from its LightFast record in ONE round of loads (the general form below reads start / end, the fast flag,
+            // the type and then position / range in four dependent round trips, each behind the previous one's branch); the
+            // smoothstep's reciprocal is only wanted by lights WITHOUT a fast record, a uniform branch no lit room takes.
+            bool fast = false;
+            if (cand) {
+                // (two 16-byte loads, each feeding a word that is needed whatever the light is: issued together, one round trip)
+                const float4 *lf4 = reinterpret_cast<const float4 *>(&P.lights_fast[mine]);
+                const float4 head = lf4[0], tail = lf4[2];
+                f3 lpos = mk3(head.x, head.y, head.z);
+                float endd = tail.x;
+                asm volatile("" : "+v"(lpos.x), "+v"(lpos.y), "+v"(lpos.z), "+v"(endd));  // (keeps the compiler from sinking the loads' other halves behind the branch below)
+                const uint32_t kind = __float_as_uint(tail.y);
+                fast = __float_as_uint(head.w) != 0u;
+                if (can_cull && kind) {
+                    float dcl = mag3_bound(sub3(c, lpos));
+                    // every fragment p of the wave has |p - L| >= dcl - rmax; the margin covers rounding
+                    float margin = 1e-3f * (dcl + rmax + fabsf(endd)) + 1e-6f;
+                    if (dcl - rmax > endd + margin) cand = false;
+                }
+            }
+            fast_mask = __ballot(cand && fast);
+            if (__ballot(cand && !fast)) {
+                if (cand && !fast) {
+                    const float ssd = P.lights[mine].start_distance - P.lights[mine].end_distance;
+                    ss_ok = rxm::in_window(ssd);
+                    ss_rcp = rxm::rcp_refined(ssd);
+                }
+                ss_ok_mask = __ballot(ss_ok);
+            }
+        } else {
+            if (cand) {
+                const float ssd = P.lights[mine].start_distance - P.lights[mine].end_distance;
+                ss_ok = rxm::in_window(ssd);
+                ss_rcp = rxm::rcp_refined(ssd);
+            }
+            ss_ok_mask = __ballot(ss_ok);
+            if (cand && can_cull) {
+                const rxr_light &L = P.lights[mine];
+                if (L.light_type == RXR_LIGHT_POINT || L.light_type == RXR_LIGHT_SPOT || L.light_type == RXR_LIGHT_AREA ||
+                    L.light_type == RXR_LIGHT_DAYLIGHT) {
+                    float dcl = mag3_bound(sub3(c, mk3(L.position[0], L.position[1], L.position[2])));
+                    // every fragment p of the wave has |p - L| >= dcl - rmax; the margin covers rounding
+                    float margin = 1e-3f * (dcl + rmax + fabsf(L.end_distance)) + 1e-6f;
+                    if (dcl - rmax > L.end_distance + margin) cand = false;
+                }
             }
         }
         unsigned long long todo = __ballot(cand);

@@ -48,7 +48,9 @@ def test_k_raster_keeps_its_registers(isa, k_raster):
     # constant address space, 22 dwords per light): 55 of them outside every loop, none inside the 3D light loop; 104 since the
     # implicit-list walk classifies covering candidates (a scalar entry word and one more uniform branch per candidate; A-B neutral in
     # time, profiles/r03/bench_kernel_experiments.txt)
-    assert spills <= 110, f"{spills} SGPR spill / reload instructions in {k_raster}"
+    # (k_raster_rl: 115 since the culling step in front of the light loop reads each light's LightFast record in one round of loads --
+    # twelve more outside every loop, none inside the light loop; A-B -0.8 % at 16 lights, -2.3 % at 4)
+    assert spills <= (120 if k_raster == "k_raster_rl" else 110), f"{spills} SGPR spill / reload instructions in {k_raster}"
     assert "v_pk_fma_f32" not in kernel_body(isa, k_raster), "packed f32 (SLP vectorisation) is slower on gfx950: build with -fno-slp-vectorize"
 
 
