@@ -479,9 +479,20 @@ __device__ __forceinline__ void fragment_uv(const TriShade &S, float alpha, floa
     rxm::div2(iu, iv, irw, u, v);
 }
 
+#ifndef RXR_DESC_ONE_LOAD
+#define RXR_DESC_ONE_LOAD 1  // (0: the texture descriptor's words fetched where they are first used -- A-B measurements)
+#endif
 // texel base of a texture: the resident pool, or this frame's chunk textures in the frame blob
 __device__ __forceinline__ const uint32_t *texel_base(const RasterParams &P, const DevTexDesc &d) {
+#if RXR_DESC_ONE_LOAD
+    // both bases as scalars, then a select: written as `c ? P.frame_texels : P.texels` the compiler selects between the two ADDRESSES
+    // inside the parameter block and loads the pointer per lane -- one more dependent round trip in front of every texel
+    const uint32_t *ft = P.frame_texels, *rt = P.texels;
+    asm volatile("" : "+v"(ft), "+v"(rt));  // ("v": the out-of-line interpreter sites receive P through vector registers)
+    return (d.all_opaque & 2u) ? ft : rt;
+#else
     return (d.all_opaque & 2u) ? P.frame_texels : P.texels;
+#endif
 }
 
 // Chunk::sample_terrain_texture(world_pos, Vec2::one()) (chunk.rs:133-151) with Texture::get_pixel (texture.rs:527-538)
@@ -532,6 +543,22 @@ template <int X> inline constexpr bool lvl1 = X >= 1 && X != 8 && X != 9;  // (9
 // comes through the scalar cache like the batch header itself (uniform_record)
 template <int X, bool UNIFORM = false>
 __device__ __forceinline__ uint32_t batch_texel(const RasterParams &P, const DevBatch &B, float u, float v, float wx, float wy, const f3 *world3 = nullptr) {
+#if RXR_DESC_ONE_LOAD
+    if constexpr (!UNIFORM && !lvl1<X>) {
+        // tex, pixel and repeat_mode are neighbours in the header: one 16-byte load instead of one word now and another, behind
+        // the descriptor's round trip, when the sampler wants the repeat mode
+        static_assert(offsetof(DevBatch, tex) == 16 && offsetof(DevBatch, pixel) == 20 && offsetof(DevBatch, repeat_mode) == 24, "one 16-byte load");
+        const uint4 hw = *reinterpret_cast<const uint4 *>(&B.tex);
+        int32_t tex = (int32_t)hw.x;
+        uint32_t pixel = hw.y, repeat = hw.z;
+        asm volatile("" : "+v"(tex), "+v"(pixel), "+v"(repeat));
+        if (tex < 0) return pixel;
+        const uint4 raw = *reinterpret_cast<const uint4 *>(&P.tex[tex]);
+        DevTexDesc d{raw.x, raw.y, raw.z, raw.w};
+        asm volatile("" : "+v"(d.offset), "+v"(d.w), "+v"(d.h), "+v"(d.all_opaque));
+        return sample_texture(d, texel_base(P, d), u, v, P.sample_mode, repeat);
+    }
+#endif
     if (B.tex < 0) return B.pixel;
     if constexpr (lvl1<X>) {
         if (B.flags & DB_TERRAIN) {
@@ -544,7 +571,16 @@ __device__ __forceinline__ uint32_t batch_texel(const RasterParams &P, const Dev
         const DevTexDesc d = uniform_record(P.tex, (uint32_t)B.tex);
         return sample_texture(d, texel_base(P, d), u, v, P.sample_mode, B.repeat_mode);
     } else {
+#if RXR_DESC_ONE_LOAD
+        // the descriptor in ONE 16-byte load: left to itself the compiler fetches its four words where they are first used --
+        // all_opaque, then w, then h and offset, three dependent round trips between the batch header and the texel
+        const uint4 raw = *reinterpret_cast<const uint4 *>(&P.tex[B.tex]);
+        DevTexDesc d{raw.x, raw.y, raw.z, raw.w};
+        asm volatile("" : "+v"(d.offset), "+v"(d.w), "+v"(d.h), "+v"(d.all_opaque));
+        static_assert(sizeof(DevTexDesc) == 16, "one 16-byte load");
+#else
         const DevTexDesc &d = P.tex[B.tex];
+#endif
         return sample_texture(d, texel_base(P, d), u, v, P.sample_mode, B.repeat_mode);
     }
 }
@@ -698,8 +734,15 @@ __device__ __forceinline__ void shade3d_begin(const RasterParams &P, const TriSh
 
     f3 lit = mk3(0.0f, 0.0f, 0.0f);
     float occlusion;
-    if (B.chunk >= 0) {
-        ChunkRange cr = P.chunks[B.chunk];
+    // the batch's ambient colour and its chunk are neighbours in the header: one 16-byte load here instead of the chunk now and the
+    // colour in a round trip of its own at the end of this function, right in front of the light loop
+    static_assert(offsetof(DevBatch, ambient) == 32 && offsetof(DevBatch, chunk) == 44, "one 16-byte load");
+    const uint4 amb_chunk = *reinterpret_cast<const uint4 *>(&B.ambient[0]);
+    float amb0 = __uint_as_float(amb_chunk.x), amb1 = __uint_as_float(amb_chunk.y), amb2 = __uint_as_float(amb_chunk.z);
+    int32_t b_chunk = (int32_t)amb_chunk.w;
+    asm volatile("" : "+v"(amb0), "+v"(amb1), "+v"(amb2), "+v"(b_chunk));
+    if (b_chunk >= 0) {
+        ChunkRange cr = P.chunks[b_chunk];
         occlusion = get_occlusion(P.occluders, cr.occ_first, cr.occ_count, world.x, world.z);
     } else {
         occlusion = get_occlusion(P.occluders, 0, P.n_occluders, world.x, world.z);
@@ -717,7 +760,7 @@ __device__ __forceinline__ void shade3d_begin(const RasterParams &P, const TriSh
         }
         lit = scale3(lit, occlusion);
     }
-    lit = add3(lit, scale3(mul3(mk3(B.ambient[0], B.ambient[1], B.ambient[2]), kd), hemi));  // :1368-1370
+    lit = add3(lit, scale3(mul3(mk3(amb0, amb1, amb2), kd), hemi));  // :1368-1370
     F.world = world;
     F.normal = normal;
     F.view_dir = view_dir;
