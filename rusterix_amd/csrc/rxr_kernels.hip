@@ -613,8 +613,10 @@ struct Frag {
 // their error; otherwise, and for magnitudes outside the window, the wave takes the exact sequences.
 template <int X, bool RL = false>
 __device__ __forceinline__ void shade3d_begin(const RasterParams &P, const TriShade &S, uint32_t batch_id, float alpha, float beta,
-                                              float z, float fx, float fy, Frag &F) {
+                                              float z, float fx, float fy, Frag &F, bool have_flags = false, uint32_t known_flags = 0u) {
     const DevBatch &B = P.batches3d[batch_id];
+    // (have_flags, wave-uniform: the caller read the flags from the winner's staged record -- no round trip to the header for them)
+    const uint32_t b_flags = have_flags ? known_flags : B.flags;
     float gamma = 1.0f - alpha - beta;
     float u, v;
     fragment_uv(S, alpha, beta, gamma, u, v);
@@ -651,7 +653,7 @@ __device__ __forceinline__ void shade3d_begin(const RasterParams &P, const TriSh
     f3 view_dir, normal;
     bool relaxed_normals = false;  // wave-uniform
     if constexpr (RL && X < 2) {
-        const bool has_n = (B.flags & DB_HAS_NORMALS) != 0u;
+        const bool has_n = (b_flags & DB_HAS_NORMALS) != 0u;
         const f3 vd = sub3(cam, world);
         f3 ni = mk3(0.0f, 0.0f, 0.0f);
         if (has_n) {
@@ -682,7 +684,7 @@ __device__ __forceinline__ void shade3d_begin(const RasterParams &P, const TriSh
             world = mk3(wx, wy, wz);
         }
         view_dir = norm3_fast(sub3(cam, world));
-        if (B.flags & DB_HAS_NORMALS) {  // :1083-1099
+        if (b_flags & DB_HAS_NORMALS) {  // :1083-1099
             f3 n0 = mk3(S.n0[0], S.n0[1], S.n0[2]), n1 = mk3(S.n1[0], S.n1[1], S.n1[2]), n2 = mk3(S.n2[0], S.n2[1], S.n2[2]);
             normal = norm3_z(add3(add3(scale3(n0, alpha), scale3(n1, beta)), scale3(n2, gamma)));
             if (dot3(normal, view_dir) < 0.0f) normal = neg3(normal);
@@ -2749,7 +2751,7 @@ __device__ __forceinline__ void scan_lists_rows(const RasterParams &P, Stage &st
 // ballot-compacted -- one global-memory latency per tile instead of three dependent ones.
 template <bool OPACITY, int X>
 __device__ __forceinline__ void scan_implicit(const RasterParams &P, Stage &st, uint32_t tile_x0, uint32_t tile_y0px, uint32_t px, uint32_t py,
-                                              float fx, float fy, Vis &vis, int surf_profile, const Vis *opf) {
+                                              float fx, float fy, Vis &vis, int surf_profile, const Vis *opf, uint32_t *win_flags = nullptr) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t n_all = min(P.n_tris3d, (uint32_t)RXR_STAGE_TRIS);
     const float4 *g4 = reinterpret_cast<const float4 *>(P.tri_setup);
@@ -2790,6 +2792,8 @@ __device__ __forceinline__ void scan_implicit(const RasterParams &P, Stage &st, 
     // (LEAN: slot == index in this path, and the winner's record is still staged)
     vis.slot = (uint32_t)max(vis.best, 0);
     vis.batch = reinterpret_cast<const TriSetup *>(&st.tri[vis.slot * 6u])->batch;
+    // (the record carries a copy of its batch's flags: the shading phase need not fetch them from the header)
+    if (win_flags) *win_flags = reinterpret_cast<const TriSetup *>(&st.tri[vis.slot * 6u])->bflags;
     __syncthreads();  // the stage is reused (second pass, 2D pass)
 }
 
@@ -3195,9 +3199,11 @@ __device__ __forceinline__ void raster_tile(const RasterParams &P) {
         valu_pad<RXR_PAD_VALU_EARLY>(vis.alpha);
         TriShade HS;     // shading record of the winner
         int hs_of = -1;  // triangle whose record HS already holds (row mode fetches it early)
+        uint32_t win_flags = 0u;  // the winner's batch flags, where the visibility pass had them at hand (scan_implicit)
+        const bool have_flags = !FUSED && P.fused_small == 2u;  // (uniform)
         PHASE_MARK(0);
         if constexpr (FUSED) scan_fused<false, X>(P, stage, shade_store.s, tile_x0, tile_y0px, px, py, fx, fy, vis, surf_profile, &op);
-        else if (P.fused_small == 2u) scan_implicit<false, X>(P, stage, tile_x0, tile_y0px, px, py, fx, fy, vis, surf_profile, &op);
+        else if (P.fused_small == 2u) scan_implicit<false, X>(P, stage, tile_x0, tile_y0px, px, py, fx, fy, vis, surf_profile, &op, &win_flags);
         else if (rows_binned) {
             // (the per-pixel surface_id of the opacity pass lives in the owning lane's registers: frames with opacity batches walk)
             if constexpr (ROWS) {
@@ -3222,7 +3228,7 @@ __device__ __forceinline__ void raster_tile(const RasterParams &P) {
         if (hit) {
             if constexpr (FUSED) HS = shade_store.s.shade[vis.slot];
             else if (!ROWS || hs_of != vis.best) HS = P.tri_shade[vis.best];
-            shade3d_begin<X, RL>(P, HS, vis.batch, vis.alpha, vis.beta, vis.zmin, fx, fy, F);
+            shade3d_begin<X, RL>(P, HS, vis.batch, vis.alpha, vis.beta, vis.zmin, fx, fy, F, have_flags, win_flags);
         }
         PHASE_MARK(2);
         valu_pad<RXR_PAD_VALU>(F.rough);
