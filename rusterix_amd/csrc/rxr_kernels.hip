@@ -547,7 +547,7 @@ __device__ __forceinline__ uint32_t batch_texel(const RasterParams &P, const Dev
     if constexpr (!UNIFORM && !lvl1<X>) {
         // tex, pixel and repeat_mode are neighbours in the header: one 16-byte load instead of one word now and another, behind
         // the descriptor's round trip, when the sampler wants the repeat mode
-        static_assert(offsetof(DevBatch, tex) == 16 && offsetof(DevBatch, pixel) == 20 && offsetof(DevBatch, repeat_mode) == 24, "one 16-byte load");
+        static_assert(__builtin_offsetof(DevBatch, tex) == 16 && __builtin_offsetof(DevBatch, pixel) == 20 && __builtin_offsetof(DevBatch, repeat_mode) == 24, "one 16-byte load");
         const uint4 hw = *reinterpret_cast<const uint4 *>(&B.tex);
         int32_t tex = (int32_t)hw.x;
         uint32_t pixel = hw.y, repeat = hw.z;
@@ -738,7 +738,7 @@ __device__ __forceinline__ void shade3d_begin(const RasterParams &P, const TriSh
     float occlusion;
     // the batch's ambient colour and its chunk are neighbours in the header: one 16-byte load here instead of the chunk now and the
     // colour in a round trip of its own at the end of this function, right in front of the light loop
-    static_assert(offsetof(DevBatch, ambient) == 32 && offsetof(DevBatch, chunk) == 44, "one 16-byte load");
+    static_assert(__builtin_offsetof(DevBatch, ambient) == 32 && __builtin_offsetof(DevBatch, chunk) == 44, "one 16-byte load");
     const uint4 amb_chunk = *reinterpret_cast<const uint4 *>(&B.ambient[0]);
     float amb0 = __uint_as_float(amb_chunk.x), amb1 = __uint_as_float(amb_chunk.y), amb2 = __uint_as_float(amb_chunk.z);
     int32_t b_chunk = (int32_t)amb_chunk.w;
