@@ -487,9 +487,12 @@ __device__ __forceinline__ const uint32_t *texel_base(const RasterParams &P, con
 #if RXR_DESC_ONE_LOAD
     // both bases as scalars, then a select: written as `c ? P.frame_texels : P.texels` the compiler selects between the two ADDRESSES
     // inside the parameter block and loads the pointer per lane -- one more dependent round trip in front of every texel
-    const uint32_t *ft = P.frame_texels, *rt = P.texels;
+    // (as integers, and back through the global address space: a pointer that has been through the asm is a FLAT pointer to the
+    // compiler, and flat loads count against the LDS counter as well)
+    unsigned long long ft = (unsigned long long)P.frame_texels, rt = (unsigned long long)P.texels;
     asm volatile("" : "+v"(ft), "+v"(rt));  // ("v": the out-of-line interpreter sites receive P through vector registers)
-    return (d.all_opaque & 2u) ? ft : rt;
+    typedef const uint32_t __attribute__((address_space(1))) *global_words;
+    return (const uint32_t *)(global_words)((d.all_opaque & 2u) ? ft : rt);
 #else
     return (d.all_opaque & 2u) ? P.frame_texels : P.texels;
 #endif
