@@ -36,7 +36,10 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PROFILE_STRIDE = int(os.environ.get("RXR_BENCH_PROFILE_STRIDE", "8"))  # every 8th frame of the timed region carries HIP events around its kernels
+# every PROFILE_STRIDE-th frame of the timed region has its kernels timed: a (start, stop) HIP event pair per DISPATCH (hipExtLaunchKernel:
+# the dispatch's own begin / end timestamps, what rocprofv3's kernel trace reports), no event record on the stream -- rounds 1-3 recorded
+# events between the launches, which idled the GPU and counted launch latency as kernel time (set-up 8.6 us against 5.3 in the trace)
+PROFILE_STRIDE = int(os.environ.get("RXR_BENCH_PROFILE_STRIDE", "4"))
 MIN_TIMED_S = float(os.environ.get("RXR_BENCH_MIN_TIMED_S", "1.0"))
 MAX_BATCHES = 5000
 # Rehearsal of the N > 1 code path on a box with ONE GPU (tests/test_gpu_bench_rehearsal.py): every rank uses GPU 0 and the exchange
@@ -46,13 +49,20 @@ MAX_BATCHES = 5000
 REHEARSAL = os.environ.get("RXR_BENCH_REHEARSAL") == "1"
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 vector (FMA counted as 2)
+N_SIMDS = 1024                 # 256 CUs x 4 SIMDs
+CLOCK_GHZ = 2.4                # MI355X_MICROARCH.md: peak engine clock
+VALU_ISSUE_CYCLES = 2          # nominal: one wave64 VALU instruction per SIMD every 2 cycles (the measured costs are higher: DESIGN.md section 6)
+XGMI_LINK_GBS = (64.0, 77.0, 153.0)  # per direction and link: what RCCL point-to-point sustains on MI300-class parts (low, high), and the link's peak
 
 # rocprofv3 passes of this same command (3840x2160, 16 lights, 1 GPU), per raster-kernel launch, for the two light-loop modes.
 # NOT measured in this run: the PMC passes need the profiler (tools/profile_bench.sh).  The numbers are READ from the committed
 # summary -- never copied into this file -- together with the hash of the kernel source they were taken on, so that a line
 # quoting a profile of an older kernel says so (`from_profiles.stale`; tests/test_bench_profiles.py).
-PROFILE_SUMMARY = "profiles/r03/bench_pmc_summary.json"
-KERNEL_SOURCES = ["rusterix_amd/csrc/rxr_kernels.hip", "rusterix_amd/csrc/rxr_device.h", "rusterix_amd/csrc/rxr_exact_math.h"]
+PROFILE_SUMMARY = "profiles/r04/bench_pmc_summary.json"
+PROFILE_KERNEL_STATS = "profiles/r04/bench_kernel_stats.csv"
+# rxr_kernels.hip and everything it includes (the advisor's round-3 finding: rxr_vm.h and rxr_project.h were missing)
+KERNEL_SOURCES = ["rusterix_amd/csrc/rxr_kernels.hip", "rusterix_amd/csrc/rxr_device.h", "rusterix_amd/csrc/rxr_exact_math.h", "rusterix_amd/csrc/rxr_project.h",
+                  "rusterix_amd/csrc/rxr_vm.h", "rusterix_amd/csrc/rxr_launch.h", "include/rxr.h", "include/rusterix_vek.hpp"]
 
 
 def kernel_sources_sha():
@@ -72,6 +82,17 @@ def load_profiles(path=None):
         return {}
     d = json.load(open(path))
     out = {}
+    # average duration per kernel in the rocprofv3 --kernel-trace --stats pass of the same command
+    traced = {}
+    stats = os.path.join(ROOT, PROFILE_KERNEL_STATS)
+    if os.path.exists(stats):
+        import csv
+
+        for row in csv.DictReader(open(stats)):
+            try:
+                traced[row["Name"].split("(")[0]] = float(row["AverageNs"]) / 1e3
+            except (KeyError, ValueError):
+                pass
     for mode, kernel in (("relaxed", "k_raster_rl"), ("exact", "k_raster")):
         k = d.get("kernels", {}).get(kernel)
         if not k or "write_bytes" not in k or "fetch_bytes_x2_gfx950" not in k or "SQ_INSTS_VALU" not in k:
@@ -81,6 +102,11 @@ def load_profiles(path=None):
             "write_bytes": int(round(k["write_bytes"])),          # WRITE_SIZE
             "fetch_bytes_x2": int(round(k["fetch_bytes_x2_gfx950"])),  # FETCH_SIZE with the gfx950 x2 correction
             "valu_wave_instructions": int(round(k["SQ_INSTS_VALU"])),
+            # fp32 flops of one launch: (add + mul + 2 fma) wave-instructions x 64 lanes x the measured lane utilisation
+            "fp32_wave_instructions": {c: int(round(k.get("SQ_INSTS_VALU_" + c + "_F32", 0))) for c in ("ADD", "MUL", "FMA")},
+            "valu_lane_utilisation": round(k["SQ_THREAD_CYCLES_VALU"] / (k["SQ_ACTIVE_INST_VALU"] * 64.0), 4) if k.get("SQ_ACTIVE_INST_VALU") else None,
+            "traced_kernel_avg_us": round(traced[kernel], 2) if kernel in traced else None,
+            "traced_setup_avg_us": round(traced["k_setup3d"], 2) if "k_setup3d" in traced else None,
             "kernel_sources_sha": d.get("kernel_sources_sha"),
         }
     return out
@@ -419,28 +445,65 @@ def main():
             dist.all_gather(out_, t)
             return [round(float(o.item()), 4) for o in out_]
 
+        # the WHOLE frame on each rank's own GPU, same run: one frame at a time on one lane (what the N = 1 `value` times) and alternating
+        # over this rank's lanes (the intra-GPU overlap the N > 1 pipeline also enjoys) -- scaling ratios against either figure can be
+        # formed from this one line (the advisor's round-3 finding: N > 1 with lanes against a serial N = 1 credits sharding with overlap)
+        whole = torch.empty((H, W, 4), dtype=torch.uint8, device="cuda")
+
+        def whole_serial(n):
+            for _ in range(n):
+                check(rxr.rxr_render_rows_to(members[0], 0, H, C.c_void_p(whole.data_ptr()), sptr))
+
+        def whole_lanes(n):
+            for i in range(n):
+                check(rxr.rxr_render_rows_to(members[i % lanes], 0, H, C.c_void_p(whole.data_ptr()), C.c_void_p(cstreams[i % len(cstreams)].cuda_stream)))
+
         per_rank = {
             "render_only_ms": all_ranks(local_time(lambda n: pipe.run(n, do_exchange=False))),
             "exchange_only_ms": all_ranks(local_time(lambda n: pipe.run(n, do_render=False))),
+            "whole_frame_serial_ms": all_ranks(local_time(whole_serial)),
+            "whole_frame_lanes_ms": all_ranks(local_time(whole_lanes)),
             "what": f"per step and rank, in rank order: this rank's stripes through {lanes} lane(s) without any exchange; the exchange "
-                    "(collective + de-interleave on the root) of already rendered stripes without any render",
+                    "(collective + de-interleave on the root) of already rendered stripes without any render; the whole frame on this rank's GPU "
+                    f"alone, one at a time and over its {lanes} lane(s)",
         }
+        del whole
+
+        def all_ok(ok):
+            """every rank's verdict on a stage, before anybody enters the next collective (a failure on one rank only would leave the others
+            waiting in it until the process-group timeout)"""
+            if world == 1:
+                return ok
+            t = torch.tensor([1 if ok else 0], dtype=torch.int64, device=ctl)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return bool(t.item())
+
         variants = {}
         todo = [("rotate", vk, vk, bucket), ("rotate", vk, vk, 1), ("gather", 1, 1, 1)]
         for mode, cm, dp, bk in todo:
             name = f"{mode}_comms{cm}_depth{dp}_bucket{bk}"
             if (mode, cm, dp, bk) == (pipe.mode, pipe.cm, pipe.dp, pipe.bk):
                 continue
+            pv, err = None, None
             try:
                 pv = Pipeline(mode, cm, dp, bk)
+            except Exception as ex:  # a variant must never cost the bench line
+                err = repr(ex)
+            if not all_ok(err is None):  # (nobody starts a collective of a configuration that some rank could not build)
+                variants[name] = {"error": err or "another rank could not build this configuration"}
+                continue
+            try:
                 sec, nb_ = measure(pv.run)
                 check(rxr.rxr_synchronize(ctx))
                 check_assembled(pv)
                 variants[name] = {"mpix_s": round(W * H * args.steps / sec / 1e6, 2), "ms_per_step": round(sec / args.steps * 1e3, 4), "batches": nb_,
                                   "sharding": pv.describe()}
-                del pv
-            except Exception as ex:  # a variant must never cost the bench line
-                variants[name] = {"error": repr(ex)}
+            except (Exception, SystemExit) as ex:
+                err = repr(ex)
+                variants[name] = {"error": err}
+            if not all_ok(err is None) and "error" not in variants[name]:
+                variants[name] = {"error": "another rank failed in this configuration", **variants[name]}
+            del pv
 
     # the same frame in the other light-loop arithmetic (rxr_set_light_math, include/rxr.h), N = 1 only: a few batches, reported
     # beside the default mode's `value`, never as it
@@ -514,10 +577,23 @@ def main():
         default_workload = (W, H, args.lights, world) == (3840, 2160, 16, 1) and not sharded
         PROFILE = PROFILES.get("relaxed" if relaxed else "exact")
         default_workload = default_workload and PROFILE is not None
+        # the compute-side rooflines of the same kernel ("state both fractions"): instruction and flop counts from the
+        # committed PMC passes, the duration measured live
+        valu_issue_frac = fp32_frac = fp32_tflops = None
+        if default_workload and raster_avg_us == raster_avg_us:
+            t_s = raster_avg_us * 1e-6
+            valu_issue_frac = PROFILE["valu_wave_instructions"] * VALU_ISSUE_CYCLES / (N_SIMDS * CLOCK_GHZ * 1e9 * t_s)
+            f = PROFILE["fp32_wave_instructions"]
+            if PROFILE["valu_lane_utilisation"] and (f["ADD"] + f["MUL"] + f["FMA"]):
+                fp32_tflops = (f["ADD"] + f["MUL"] + 2 * f["FMA"]) * 64 * PROFILE["valu_lane_utilisation"] / t_s / 1e12
+                fp32_frac = fp32_tflops / FP32_VALU_PEAK_TFLOPS
         out = {
             "metric": "Mpixels/s (+ ms/frame) on rasterize_map @3840x2160, 1/2/4/8 MI355X vs CPU",
             "value": round(value, 2),
             "unit": "Mpixels/s",
+            # inputs resident in HBM when the timed region starts, the frame left in HBM; the drop-in call into host pixels (host
+            # projection + upload + kernels + PCIe download) is `e2e_ms` below, never `value`
+            "value_semantics": "device-resident",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
@@ -554,15 +630,24 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6),
+                # the bound that binds: VALU wave-instructions x 2 cycles / (1024 SIMDs x 2.4 GHz x kernel time),
+                # and fp32 flops against the 157.3 TFLOP/s vector peak
+                "valu_issue_frac": round(valu_issue_frac, 4) if valu_issue_frac is not None else None,
+                "fp32_frac": round(fp32_frac, 4) if fp32_frac is not None else None,
+                "fp32_tflops": round(fp32_tflops, 2) if fp32_tflops is not None else None,
                 # HBM bytes of one launch from the rocprofv3 PMC passes of this same command (FETCH_SIZE with the gfx950 x2
                 # correction + WRITE_SIZE): from the committed profile, NOT measured in this run; only known for the default workload
                 "traffic": PROFILE["fetch_bytes_x2"] + PROFILE["write_bytes"] if default_workload else None,
                 "traffic_from": PROFILE["source"] if default_workload else None,
-                # measured live in this run (HIP events on the launch stream, every PROFILE_STRIDE-th frame of the timed region):
+                # measured live in this run, on every PROFILE_STRIDE-th frame of the timed region: HIP start / stop events bound to the
+                # dispatches themselves (hipExtLaunchKernel on the launch stream; no event record between the launches)
                 "algorithmic_bytes_per_launch": int(alg),
                 "kernel_avg_us": round(raster_avg_us, 2),
                 "kernel_samples": int(n_prof.value),
+                "kernel_timing": f"per-dispatch start/stop HIP events, 1 frame in {PROFILE_STRIDE}",
                 "setup_kernels_avg_us": round(setup_avg_us, 2),
+                # kernels of one step against the step (one frame at a time: they cannot exceed it; lanes overlap other lanes' launches)
+                "kernels_fit_step": bool(raster_avg_us + setup_avg_us <= ms_per_step * 1e3 * 1.005) if not (sharded and lanes > 1) else None,
                 "note": "the kernel is fp32-VALU bound, not HBM bound: algorithmic HBM traffic is ~4.5 B/pixel (DESIGN.md section 6)"
                         + ("; with several frames in flight the event-timed launches overlap other lanes' launches" if sharded and lanes > 1 else ""),
                 "from_profiles": {
@@ -570,6 +655,10 @@ def main():
                     "write_bytes": PROFILE["write_bytes"],
                     "fetch_bytes_x2": PROFILE["fetch_bytes_x2"],
                     "valu_wave_instructions_per_launch": PROFILE["valu_wave_instructions"],
+                    "fp32_wave_instructions_per_launch": PROFILE["fp32_wave_instructions"],
+                    "valu_lane_utilisation": PROFILE["valu_lane_utilisation"],
+                    "traced_kernel_avg_us": PROFILE["traced_kernel_avg_us"],
+                    "traced_setup_avg_us": PROFILE["traced_setup_avg_us"],
                     # the kernel source the profile was taken on against the one this run launched
                     "kernel_sources_sha": PROFILE["kernel_sources_sha"],
                     "stale": PROFILE["kernel_sources_sha"] != kernel_sources_sha(),
@@ -580,6 +669,28 @@ def main():
             out["other_light_math"] = other_mode
         if in_flight is not None:
             out["two_frames_in_flight"] = in_flight
+        if sharded:
+            # What bounds `value` at this N, stated in the line itself: the exchange BASELINE.json names is a gather to rank 0, whose root
+            # receives every other rank's share of EVERY frame, each over the one xGMI link from that rank.  A link is busy for
+            # share_bytes / rate per frame whatever the render side does; against a whole frame on one GPU that is a ceiling on the
+            # speed-up.  (The rotating-root variants below put a stripe set on each link once in N frames.)
+            n1 = float(np.median(per_rank["whole_frame_serial_ms"])) if per_rank else None
+            out["exchange_bound"] = {
+                "exchange": "gather to rank 0 over xGMI (BASELINE.json configs[3])",
+                "root_link_bytes_per_frame": int(share_bytes) if world > 1 else 0,
+                "link_GBps": {"rccl_low": XGMI_LINK_GBS[0], "rccl_high": XGMI_LINK_GBS[1], "peak": XGMI_LINK_GBS[2]},
+                "min_ms_per_frame": {k: round(share_bytes / (r * 1e9) * 1e3, 4) for k, r in zip(("rccl_low", "rccl_high", "peak"), XGMI_LINK_GBS)} if world > 1 else None,
+                "whole_frame_one_gpu_ms": round(n1, 4) if n1 else None,
+                "speedup_ceiling": {k: round(n1 / (share_bytes / (r * 1e9) * 1e3), 2) for k, r in zip(("rccl_low", "rccl_high", "peak"), XGMI_LINK_GBS)} if (n1 and world > 1) else None,
+                "measured_on_hardware": not REHEARSAL,
+                "note": "link rates are assumptions until a multi-GPU run exists: no round has had one (SCALE_r01..r03 skipped)",
+            }
+            if variants:
+                ok = {k: v for k, v in variants.items() if "ms_per_step" in v}
+                ok["value: " + pipe.mode + f"_comms{pipe.cm}_depth{pipe.dp}_bucket{pipe.bk}"] = {"ms_per_step": round(ms_per_step, 4)}
+                best = min(ok, key=lambda k: ok[k]["ms_per_step"])
+                out["best_variant"] = {"name": best, "ms_per_step": ok[best]["ms_per_step"], "x_vs_value": round(ms_per_step / ok[best]["ms_per_step"], 3),
+                                       "x_vs_whole_frame_one_gpu": round(n1 / ok[best]["ms_per_step"], 3) if n1 else None}
         if per_rank is not None:
             out["per_rank"] = per_rank
         if variants is not None:

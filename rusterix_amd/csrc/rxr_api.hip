@@ -23,6 +23,7 @@
 #include "rxr_ctx.h"
 #include "rxr_parallel.h"
 
+thread_local LaunchTimes *rxr_launch_times = nullptr;  // rxr_launch.h: the profiling slot of the render this thread is queueing
 extern "C" void rxr_launch_proj_static(const ProjectParams *P, hipStream_t s);
 extern "C" void rxr_launch_project(const ProjectParams *P, hipStream_t s);
 extern "C" void rxr_launch_proj_edges(const ProjectParams *P, hipStream_t s);
@@ -255,11 +256,9 @@ void rxr_destroy(rxr_ctx *ctx) {
         (void)hipStreamSynchronize(ctx->copy_stream);
         (void)hipStreamDestroy(ctx->copy_stream);
     }
-    for (ProfSlot &p : ctx->prof) {
-        (void)hipEventDestroy(p.e0);
-        (void)hipEventDestroy(p.e1);
-        (void)hipEventDestroy(p.e2);
-    }
+    for (ProfSlot &p : ctx->prof)
+        for (hipEvent_t e : p.ev)
+            if (e) (void)hipEventDestroy(e);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -2028,21 +2027,22 @@ static int render_impl(rxr_ctx *ctx, const RenderSpec &spec, void *dev_pixels, h
     P.out_base_row = (spec.external && !spec.compact) ? (int64_t)spec.row0 : 0;
     const size_t n_bins = (size_t)P.tiles_x * P.tiles_y;
 
-    // Kernel timing is opt-in (rxr_profile_begin): every event record is a barrier packet that idles the GPU for a few
-    // microseconds, which is a tenth of a 1080p frame of a small scene.  Without it rxr_stats' *_us fields stay zero.
+    // Kernel timing is opt-in (rxr_profile_begin): per-dispatch start / stop events (rxr_launch.h), no event record on the stream.
+    // Without it rxr_stats' *_us fields stay zero.
     const bool timed = !retry && !ctx->prof.empty() && (ctx->prof_calls++ % ctx->prof_stride) == 0u;  // (a re-render after a list overflow takes no profiling slot)
-    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+    ProfSlot *slot = nullptr;
     if (timed) {
-        ProfSlot &ps = ctx->prof[ctx->prof_next % ctx->prof.size()];
-        e0 = ps.e0;
-        e1 = ps.e1;
-        e2 = ps.e2;
+        slot = &ctx->prof[ctx->prof_next % ctx->prof.size()];
+        slot->n = 0;
+        slot->raster_first = RXR_PROF_MAX_KERNELS;
         ctx->prof_next++;
     }
-    ctx->last_e0 = e0;
-    ctx->last_e1 = e1;
-    ctx->last_e2 = e2;
-    if (timed) HIPCHK(ctx, hipEventRecord(e0, s));
+    ctx->last_prof = slot;
+    // (every kernel this thread launches until the guard goes takes a start / stop pair of the slot: rxr_launch.h)
+    struct TimesGuard {
+        explicit TimesGuard(ProfSlot *p) { rxr_launch_times = p; }
+        ~TimesGuard() { rxr_launch_times = nullptr; }
+    } times_guard(slot);
     // small scenes: one staging round of k_raster holds every triangle -> no set-up / binning launches at all
     const bool d3 = P.tiles_y && (P.flags & RXR_FLAG_D3_ACTIVE);
     P.fused_small = (d3 && P.n_tris3d <= RXR_STAGE_TRIS) ? ctx->small_mode : 0u;
@@ -2134,9 +2134,8 @@ static int render_impl(rxr_ctx *ctx, const RenderSpec &spec, void *dev_pixels, h
         rxr_launch_bin2d_fill(&P, s);
         }
     }
-    if (timed) HIPCHK(ctx, hipEventRecord(e1, s));
+    if (slot) slot->raster_first = slot->n;
     if (!rxr_jit_launch(ctx, &P, s)) rxr_launch_raster(&P, s);
-    if (timed) HIPCHK(ctx, hipEventRecord(e2, s));
     HIPCHK(ctx, hipGetLastError());
     ctx->scratch_dirty = false;  // the raster launch that hands the bins back is queued
     ctx->scratch2d_dirty = false;
@@ -2244,22 +2243,15 @@ int rxr_profile_begin(rxr_ctx *ctx, uint32_t max_frames) {
     HIPCHK(ctx, hipSetDevice(ctx->device));
     int rc = rxr_synchronize(ctx);
     if (rc != RXR_OK) return rc;
-    for (ProfSlot &p : ctx->prof) {
-        (void)hipEventDestroy(p.e0);
-        (void)hipEventDestroy(p.e1);
-        (void)hipEventDestroy(p.e2);
-    }
+    for (ProfSlot &p : ctx->prof)
+        for (hipEvent_t e : p.ev)
+            if (e) (void)hipEventDestroy(e);
     ctx->prof.clear();
+    ctx->last_prof = nullptr;
     ctx->prof_next = 0;
     ctx->prof_calls = 0;
     if (max_frames > 65536) max_frames = 65536;
-    for (uint32_t i = 0; i < max_frames; ++i) {
-        ProfSlot p{};
-        HIPCHK(ctx, hipEventCreate(&p.e0));
-        HIPCHK(ctx, hipEventCreate(&p.e1));
-        HIPCHK(ctx, hipEventCreate(&p.e2));
-        ctx->prof.push_back(p);
-    }
+    ctx->prof.assign(max_frames, ProfSlot{});  // (the events of a slot are created when a render first needs them: rxr_launch.h)
     return RXR_OK;
 }
 
@@ -2279,10 +2271,9 @@ int rxr_profile_read(rxr_ctx *ctx, float *setup_us, float *raster_us, uint32_t c
     uint32_t n = (uint32_t)std::min<size_t>(std::min<size_t>(ctx->prof_next, ctx->prof.size()), capacity);
     for (uint32_t i = 0; i < n; ++i) {
         float a = 0, b = 0;
-        HIPCHK(ctx, hipEventElapsedTime(&a, ctx->prof[i].e0, ctx->prof[i].e1));
-        HIPCHK(ctx, hipEventElapsedTime(&b, ctx->prof[i].e1, ctx->prof[i].e2));
-        if (setup_us) setup_us[i] = a * 1000.0f;
-        if (raster_us) raster_us[i] = b * 1000.0f;
+        if (!rxr_prof_slot_us(ctx->prof[i], &a, &b)) return fail(ctx, RXR_ERR_HIP, "rxr_profile_read: a kernel's start / stop events could not be read");
+        if (setup_us) setup_us[i] = a;
+        if (raster_us) raster_us[i] = b;
     }
     *n_out = n;
     ctx->prof_next = 0;
@@ -2345,11 +2336,10 @@ int rxr_synchronize(rxr_ctx *ctx) {
         const bool over3d = hc[CNT_OVERFLOW] != 0, over2d = hc[CNT_WORDS + CNT_OVERFLOW] != 0;
         if (!over3d && !over2d) {
             float a = 0, b = 0;
-            if (ctx->last_e0 && hipEventElapsedTime(&a, ctx->last_e0, ctx->last_e1) == hipSuccess &&
-                hipEventElapsedTime(&b, ctx->last_e1, ctx->last_e2) == hipSuccess) {
-                ctx->stats.setup_us = a * 1000.0f;
-                ctx->stats.raster_us = b * 1000.0f;
-                ctx->stats.total_us = (a + b) * 1000.0f;
+            if (ctx->last_prof && rxr_prof_slot_us(*ctx->last_prof, &a, &b)) {
+                ctx->stats.setup_us = a;
+                ctx->stats.raster_us = b;
+                ctx->stats.total_us = a + b;
             }
             if (earlier_incomplete)
                 return fail(ctx, RXR_ERR_OVERFLOW,

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "rxr_device.h"
+#include "rxr_launch.h"
 #include "rxr_project.h"
 
 struct DevBuf {
@@ -38,9 +39,8 @@ struct HostMesh {
     int32_t chunk;
 };
 
-struct ProfSlot {
-    hipEvent_t e0, e1, e2;
-};
+// one sampled render of the rxr_profile_begin ring: a (start, stop) event pair per launched kernel (rxr_launch.h)
+using ProfSlot = LaunchTimes;
 
 // one render launch sequence.  Band mode: rows [row0,row1), stride 1.  Stripe mode: every `stride`-th
 // 16-row stripe from `first`, into a compact buffer (compact) or at its place in a whole frame (!compact).
@@ -226,7 +226,7 @@ struct rxr_ctx {
     hipStream_t upload_ordered_on = nullptr;  // stream already ordered behind the last upload
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev_upload = nullptr;
     hipEvent_t ev_render = nullptr;     // recorded on the previous stream when a render moves to ANOTHER stream (orders it behind the earlier ones)
-    hipEvent_t last_e0 = nullptr, last_e1 = nullptr, last_e2 = nullptr;
+    ProfSlot *last_prof = nullptr;  // the slot of the last render, if it was sampled (rxr_get_stats)
     std::vector<ProfSlot> prof;  // rxr_profile_begin ring
     size_t prof_next = 0;
     rxr_stats stats{};
@@ -270,3 +270,16 @@ bool rxr_jit_compile(const std::string &gen, const std::string &arch, int level,
 int rxr_jit_build(rxr_ctx *ctx, const std::vector<uint32_t> &code, const std::vector<DevProgram> &progs);
 void rxr_jit_drop(rxr_ctx *ctx);
 bool rxr_jit_launch(rxr_ctx *ctx, const RasterParams *P, hipStream_t s);
+
+// kernel durations of one sampled render from its slot: the sum over its set-up kernels and the raster kernel, microseconds
+static inline bool rxr_prof_slot_us(const ProfSlot &p, float *setup_us, float *raster_us) {
+    float a = 0.0f, b = 0.0f;
+    for (uint32_t k = 0; k < p.n; ++k) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, p.ev[2u * k], p.ev[2u * k + 1u]) != hipSuccess) return false;
+        (k < p.raster_first ? a : b) += ms * 1000.0f;
+    }
+    *setup_us = a;
+    *raster_us = b;
+    return true;
+}

@@ -707,6 +707,27 @@ std::string sibling_path(const char *name, std::string *self = nullptr) {
     const size_t slash = lib.rfind('/');
     return (slash == std::string::npos ? std::string(".") : lib.substr(0, slash)) + "/" + name;
 }
+// The child's environment.  rxr_jitc compiles (hiprtc needs no device: the architecture is an argument) and must never touch the
+// GPU -- on the pool a second process on the card counts against the box's limit, and under a profiler the parent's environment
+// preloads a tool library that initialises the GPU in every process it reaches.  So: ours, minus whatever would load code into the
+// child or point a ROCm tool at it (LD_PRELOAD, LD_AUDIT, HSA_TOOLS_*, ROCP* / ROCPROFILER* / ROCTRACER* / ROCTX*, RPD*), with every
+// device hidden from both runtimes, and TMPDIR pointing into the job's directory.
+static bool child_env_dropped(const char *e) {
+    static const char *const prefixes[] = {"TMPDIR=", "LD_PRELOAD=", "LD_AUDIT=", "HSA_TOOLS_", "ROCP", "ROCTRACER", "ROCTX", "RPD",
+                                           "HIP_VISIBLE_DEVICES=", "ROCR_VISIBLE_DEVICES=", "CUDA_VISIBLE_DEVICES=", "GPU_DEVICE_ORDINAL="};
+    for (const char *p : prefixes)
+        if (strncmp(e, p, strlen(p)) == 0) return true;
+    return false;
+}
+static std::vector<std::string> child_environment(const std::string &tmpdir) {
+    std::vector<std::string> env;
+    for (char **e = environ; e && *e; ++e)
+        if (!child_env_dropped(*e)) env.push_back(*e);
+    env.push_back("TMPDIR=" + tmpdir);
+    env.push_back("HIP_VISIBLE_DEVICES=");   // (an empty list: no device for the HIP runtime ...
+    env.push_back("ROCR_VISIBLE_DEVICES=");  //  ... nor for the HSA runtime underneath)
+    return env;
+}
 bool start_child_locked(const std::string &key, const std::string &gen, const std::string &arch, int level, std::string &err) {
     std::string lib;
     const std::string exe = sibling_path("rxr_jitc", &lib);
@@ -738,11 +759,7 @@ bool start_child_locked(const std::string &key, const std::string &gen, const st
     }
     const std::string lvl = std::to_string(level);
     char *const argv[] = {(char *)exe.c_str(), (char *)lib.c_str(), (char *)src_t.c_str(), (char *)arch.c_str(), (char *)lvl.c_str(), (char *)out_t.c_str(), nullptr};
-    // the child's environment: ours, with TMPDIR pointing into the job's directory
-    std::vector<std::string> env_store;
-    for (char **e = environ; e && *e; ++e)
-        if (strncmp(*e, "TMPDIR=", 7) != 0) env_store.push_back(*e);
-    env_store.push_back("TMPDIR=" + dir);
+    std::vector<std::string> env_store = child_environment(dir);
     std::vector<char *> envp;
     for (std::string &e : env_store) envp.push_back((char *)e.c_str());
     envp.push_back(nullptr);
@@ -824,6 +841,13 @@ int poll_background(rxr_ctx *ctx, int slot, int level, std::string &err) {
 
 // tests (no device needed): the clean-up of stale job directories under `parent`, and where this process keeps its own
 extern "C" void rxr_debug_jit_sweep(const char *parent) { sweep_stale_job_dirs(parent); }
+// the environment a background compiler would be started with, one "NAME=value" per line; returns the length needed
+extern "C" int rxr_debug_jit_child_env(const char *tmpdir, char *out, uint32_t capacity) {
+    std::string text;
+    for (const std::string &e : child_environment(tmpdir ? tmpdir : "")) text += e + "\n";
+    if (out && capacity) snprintf(out, capacity, "%s", text.c_str());
+    return (int)text.size() + 1;
+}
 extern "C" int rxr_debug_jit_job_parent(char *out, uint32_t capacity) {
     std::string err;
     const std::string p = job_parent(err);
@@ -1026,5 +1050,9 @@ bool rxr_jit_launch(rxr_ctx *ctx, const RasterParams *P, hipStream_t s) {
     RasterParams params = *P;
     size_t size = sizeof(params);
     void *config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &params, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+    hipEvent_t e0, e1;
+    if (rxr_launch_times && rxr_launch_pair(&e0, &e1))  // (kernel timing, rxr_launch.h; this form takes the grid in THREADS)
+        return hipExtModuleLaunchKernel((hipFunction_t)ctx->jit_fn[slot], P->tiles_x * RXR_TILE_THREADS, P->tiles_y, 1, RXR_TILE_THREADS, 1, 1, 0, s, nullptr, config,
+                                        e0, e1, 0) == hipSuccess;
     return hipModuleLaunchKernel((hipFunction_t)ctx->jit_fn[slot], P->tiles_x, P->tiles_y, 1, RXR_TILE_THREADS, 1, 1, 0, s, nullptr, config) == hipSuccess;
 }

@@ -31,6 +31,8 @@
 
 #include <cstdlib>
 #include <cstring>
+
+#include "rxr_launch.h"
 #endif
 
 #include "rxr_device.h"
@@ -2386,6 +2388,28 @@ __device__ __forceinline__ uint32_t z_order_bits(float z) {
 #ifndef RXR_ROW_MODE_MAX_AREA
 #define RXR_ROW_MODE_MAX_AREA 128
 #endif
+// Fragment compaction (north-star: "wavefront ballot/prefix-sum for fragment compaction").  A candidate covers a third of its
+// clipped pixel box on the 1 M-triangle grid (measured on the scene: 34 candidates, 1 880 box pixels and 700 fragments per non-empty
+// tile), so with Edges::evaluate and the depth arithmetic in one pass two lanes in three sit out bary_depth -- two exact quotients, a
+// reciprocal and the ds_min_u64 -- and every box pixel pays the owner search and the decode of its item.  With RXR_ROWS_COMPACT
+//   (a) an item is a run of up to FOUR pixels of one row of a candidate's clipped box: one owner search, one decode and one fetch of the
+//       edge coefficients per run, and b*y per run instead of per pixel (the same products: the same floats);
+//   (b) the items only evaluate the edge functions.  The survivors of each of the four pixel slots are counted with one ballot and take
+//       consecutive places (mbcnt prefix) in a ring of 32-bit entries (staged record, x, y, z-buffer cell) that belongs to the WAVE:
+//       no atomic, no barrier, the ring's head and fill are wave-uniform;
+//   (c) whenever 64 entries are queued the wave runs barycentric_weights_3d, the depth and the ds_min_u64 on them with all lanes (the
+//       remainder goes last, once per round).
+// The same expressions per fragment, and the arg-min is order-independent: exact by construction.  The rings alias the 2D pass's sort
+// buffer, idle during the 3D passes: no LDS is added.  First tried with one-pixel items, a queue shared by the workgroup, an LDS add
+// per wave and pass and a barrier in front of the drain: 4 % fewer VALU instructions and 1.5 % SLOWER (profiles/r04).
+#ifndef RXR_ROWS_COMPACT
+#define RXR_ROWS_COMPACT 1
+#endif
+#ifndef RXR_ROWS_UNROLL_PX
+#define RXR_ROWS_UNROLL_PX 0  // (A-B knob: the four pixel slots of an item as straight-line code, five copies of the drain)
+#endif
+#define RXR_ROWS_RING 128u  // entries per wave: fewer than 64 left over + at most 64 from one pixel slot
+static_assert(RXR_ROWS_RING * 4u * (RXR_TILE_THREADS / 64) <= RXR_SORT2D_MAX * 4u, "the four rings live in the 2D pass's sort buffer");
 
 // One round of row mode over the `n` records staged in st (ids in st.ids).  Returns false (uniformly) without having
 // done anything when the round is better served by the pixel-parallel walk.
@@ -2403,12 +2427,13 @@ __device__ __forceinline__ uint32_t z_order_bits(float z) {
 // INDIRECT: candidate k's record is st.tri[rl.slot[k] * 6] (scan_lists_rows) instead of st.tri[k * 6]
 // PIX: pixel items (above); false = one item per row with an x loop, which the interpreter kernels keep (their register budget is
 // spent on the interpreter: pixel items cost k_raster_vm_sv 3-4 % on the 1 M-triangle grid while they save k_raster_rows 9 %)
-template <bool INDIRECT, bool PIX, uint32_t TH = RXR_TILE_H>
-__device__ RXR_ROWS_INLINE bool rows_round(const RasterParams &P, Stage &st, RowLdsT<TH> &rl, uint32_t n, uint32_t tile_x0, uint32_t tile_y0px) {
+template <bool INDIRECT, bool PIX, uint32_t TH = RXR_TILE_H, bool COMPACT = false>
+__device__ RXR_ROWS_INLINE bool rows_round(const RasterParams &P, Stage &st, RowLdsT<TH> &rl, uint32_t n, uint32_t tile_x0, uint32_t tile_y0px,
+                                           uint32_t *queue = nullptr) {
     static_assert(TH == 16 || TH == 32, "the bit fields of `geo` and the exact short division hold for offsets below 512");
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     // clipped pixel box of staged candidate `tid`
-    uint32_t rows = 0, area = 0, geo = 0;
+    uint32_t rows = 0, area = 0, geo = 0, items = 0;  // items: COMPACT's runs of up to four pixels
     bool alpha_test = false;
     if (tid < n) {
         const TriSetup &R = *reinterpret_cast<const TriSetup *>(&st.tri[(INDIRECT ? rl.slot[tid] : tid) * 6u]);
@@ -2422,14 +2447,22 @@ __device__ RXR_ROWS_INLINE bool rows_round(const RasterParams &P, Stage &st, Row
                 // decode data of the pixel items: box origin inside the tile, width, and ceil(8192 / width): for offsets
                 // below 512 and widths up to 16, (offset * that) >> 13 == offset / width exactly (checked for every pair)
                 const uint32_t w = x1 - x0;
-                geo = (x0 - tile_x0) | ((y0 - tile_y0px) << 4) | (w << 9) | (((8192u + w - 1u) / w) << 14);
+                if constexpr (COMPACT) {
+                    // (runs per row 1..4, then ceil(8192 / runs) for the same exact short division)
+                    const uint32_t segs = (w + 3u) >> 2;
+                    items = rows * segs;
+                    geo = (x0 - tile_x0) | ((y0 - tile_y0px) << 4) | (w << 9) | (segs << 14) | (((8192u + segs - 1u) / segs) << 17);
+                } else {
+                    geo = (x0 - tile_x0) | ((y0 - tile_y0px) << 4) | (w << 9) | (((8192u + w - 1u) / w) << 14);
+                }
                 static_assert(RXR_TILE_W == 16 && RXR_TILE_H <= 32, "bit fields of `geo`");
             }
         }
     }
     // inclusive scan over the workgroup of the areas (each <= 256, at most 128 candidates: below 2^15), or of
     // (rows | area << 13): rows total <= 2^12, area total <= 2^16
-    const uint32_t packed = PIX ? area : (rows | (area << 13));
+    // (COMPACT: items | area << 14: at most 128 * 64 items, the areas decide between row mode and the walk as before)
+    const uint32_t packed = COMPACT ? (items | (area << 14)) : PIX ? area : (rows | (area << 13));
     uint32_t inc = packed;
     if (wave * 64u < n) inc = rxm::wave_inclusive_add(packed);  // (wave-uniform: the waves behind the last candidate have nothing to add)
     const unsigned long long has = __ballot(rows != 0u);
@@ -2449,25 +2482,33 @@ __device__ RXR_ROWS_INLINE bool rows_round(const RasterParams &P, Stage &st, Row
         total += v;
         cands += rl.red[4u + w];
     }
-    const uint32_t rows_total = PIX ? 0u : (total & 0x1FFFu), area_total = PIX ? total : (total >> 13);
+    const uint32_t rows_total = PIX ? 0u : (total & 0x1FFFu), area_total = COMPACT ? (total >> 14) : PIX ? total : (total >> 13);
+    const uint32_t n_items = COMPACT ? (total & 0x3FFFu) : area_total;  // work items of the round
     if (cands == 0u || cands >= 0x10000u || area_total > cands * (uint32_t)RXR_ROW_MODE_MAX_AREA) {
         __syncthreads();  // rl.red is rewritten by the next round
         return false;
     }
     if constexpr (PIX) {
     if (tid < n) {
-        const uint32_t start = before + inc - area;  // exclusive prefix of the areas
-        rl.row_start[tid] = start;
-        rl.raw[tid] = geo;                           // (the list entries' ids have moved to st.ids by now)
+        const uint32_t mine = COMPACT ? items : area;
+        const uint32_t start = (COMPACT ? ((before + inc) & 0x3FFFu) : before + inc) - mine;  // exclusive prefix of the item counts
+        // (the addresses below are functions of the thread index alone: left to itself the compiler computes them once in front of the
+        // loop over the rounds and, at 64 registers, SPILLS them -- two scratch dwords per thread, 93 MB of HBM writes per 8K frame
+        // in the counters.  An index it cannot see through is recomputed per round: two instructions each.)
+        uint32_t tl = tid;
+        if constexpr (COMPACT) asm volatile("" : "+v"(tl));
+        rl.row_start[tl] = start;
+        rl.raw[tl] = geo;                            // (the list entries' ids have moved to st.ids by now)
 #if RXR_ROWS_PRE
         // The round is row mode from here on: nothing reads the staged record's pixel box and flags again, and their words take what
         // bary_depth needs of the triangle alone (its PRE form) -- once per candidate instead of once per pixel item.
         if (area) {
-            TriSetup &W = *reinterpret_cast<TriSetup *>(&st.tri[(INDIRECT ? rl.slot[tid] : tid) * 6u]);
+            TriSetup &W = *reinterpret_cast<TriSetup *>(&st.tri[(INDIRECT ? rl.slot[tl] : tl) * 6u]);
             const float acx = W.v2x - W.v0x, acy = W.v2y - W.v0y, r = rxm::denominator_part(W.area);
             W.bx = __float_as_uint(acx);
             W.by = __float_as_uint(acy);
             W.bflags = __float_as_uint(r);
+            if constexpr (COMPACT) W.profile_id = st.ids[tl];  // (row mode never reads the profile: no opacity pass ran) the queue names records
         }
 #endif
         // first owner of every 64-item chunk (area_total <= 128 * 128: at most 256 chunks): item 64 c belongs to the one candidate
@@ -2475,14 +2516,14 @@ __device__ RXR_ROWS_INLINE bool rows_round(const RasterParams &P, Stage &st, Row
         // (usually none or one: ~20 items per candidate) instead of a binary search over the prefix by one thread per chunk behind
         // another barrier.  Candidates without pixels in front of it share its start; the item loop steps over them as before.
 #if RXR_ROWS_OWNER_DIRECT
-        for (uint32_t c = (start + 63u) >> 6; (c << 6) < start + area; ++c) rl.chunk_owner[c] = (uint8_t)tid;
+        for (uint32_t c = (start + 63u) >> 6; (c << 6) < start + mine; ++c) rl.chunk_owner[c] = (uint8_t)tl;
 #endif
     }
-    if (tid == 0) rl.row_start[n] = area_total;
+    if (tid == 0) rl.row_start[n] = n_items;
     __syncthreads();
 #if !RXR_ROWS_OWNER_DIRECT
     // the largest k with row_start[k] <= chunk * 64
-    if (tid * 64u < area_total) {
+    if (tid * 64u < n_items) {
         uint32_t lo = 0, hi = n;
         while (hi - lo > 1u) {
             const uint32_t mid = (lo + hi) >> 1;
@@ -2493,6 +2534,87 @@ __device__ RXR_ROWS_INLINE bool rows_round(const RasterParams &P, Stage &st, Row
     }
     __syncthreads();
 #endif
+    if constexpr (COMPACT) {
+    static_assert(!COMPACT || RXR_ROWS_PRE, "the drain reads the PRE operands and the triangle id from the staged record");
+    uint32_t *const ring = queue + wave * RXR_ROWS_RING;
+    uint32_t head = 0, fill = 0;  // wave-uniform
+    // (c) entries [head, head + m) of this wave's ring on lanes 0 .. m-1: barycentric_weights_3d, the depth and the merge, as visit()
+    auto drain = [&](uint32_t m) {
+        if (lane < m) {
+            const uint32_t e = ring[(head + lane) & (RXR_ROWS_RING - 1u)];
+            // words 8 .. 23 of the staged record as four 16-byte reads (ds_read_b128: 64 banks, 16 lanes per LDS cycle -- the lanes of a drain
+            // hold fragments of several records 24 dwords apart; read field by field (ds_read2_b32, 32 banks) records 4 slots apart collide)
+            const float4 *const rec = &st.tri[(e & 0xFFu) * 6u];
+            const float4 q2 = rec[2], q3 = rec[3], q4 = rec[4], q5 = rec[5];
+            // q2 = (ec2, v0x, v0y, v1x)  q3 = (v1y, v2x, v2y, area)  q4 = (iz0, iz1, iz2, batch)  q5 = (PRE acx, PRE acy, PRE r, triangle id)
+            static_assert(__builtin_offsetof(TriSetup, v0x) == 36 && __builtin_offsetof(TriSetup, area) == 60 && __builtin_offsetof(TriSetup, iz0) == 64 &&
+                          __builtin_offsetof(TriSetup, bx) == 80 && __builtin_offsetof(TriSetup, profile_id) == 92, "the drain's view of a staged record");
+            const float fx = (float)((e >> 8) & 0xFFu) + ((float)tile_x0 + 0.5f), fy = (float)((e >> 16) & 0xFFu) + ((float)tile_y0px + 0.5f);  // (exact sums: the item's own fx, fy)
+            float alpha, beta, z;
+            bary_depth<true>(q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, q4.z, fx, fy, alpha, beta, z, q5.x, q5.y, q5.z);
+            if (z < 1.0f) {  // never closer than the cleared buffer; also NaN
+                const unsigned long long key = ((unsigned long long)z_order_bits(z + 0.0f) << 32) | __float_as_uint(q5.w);  // -0 -> +0: they compare equal
+                unsigned long long *const cell = &rl.key[TH == 16 ? (e >> 24) : ((e >> 16) & 0xFFu) * RXR_TILE_W + ((e >> 8) & 0xFFu)];
+                // (cells only ever decrease: a stale value is merely conservative.  A relaxed workgroup-scope atomic load, so that the
+                // read is an LDS instruction)
+                if (key < __hip_atomic_load(cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) atomicMin(cell, key);
+            }
+        }
+    };
+    for (uint32_t base = wave * 64u; base < n_items; base += RXR_TILE_THREADS) {  // (wave-uniform bounds: every lane is at the ballots)
+        const uint32_t item = base + lane;
+        uint32_t entry = 0, valid = 0;
+        float fx = 0.0f, a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, t0 = 0.0f, t1 = 0.0f, t2 = 0.0f, c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
+        if (item < n_items) {
+            uint32_t k = rl.chunk_owner[item >> 6];
+            while (rl.row_start[k + 1u] <= item) ++k;  // candidates without pixels share their successor's start; row_start[n] = n_items > item
+            const uint32_t g = rl.raw[k];
+            const uint32_t local = item - rl.row_start[k], segs = (g >> 14) & 7u;
+            const uint32_t ry = (local * (g >> 17)) >> 13, sx = local - ry * segs;
+            const uint32_t lx = (g & 15u) + 4u * sx, ly = ((g >> 4) & 31u) + ry;
+            valid = min(((g >> 9) & 31u) - 4u * sx, 4u);
+            const uint32_t sl = INDIRECT ? (uint32_t)rl.slot[k] : k;
+            const TriSetup &S = *reinterpret_cast<const TriSetup *>(&st.tri[sl * 6u]);
+            fx = (float)(tile_x0 + lx) + 0.5f;
+            const float fy = (float)(tile_y0px + ly) + 0.5f;
+            a0 = S.ea[0]; a1 = S.ea[1]; a2 = S.ea[2];
+            t0 = S.eb[0] * fy; t1 = S.eb[1] * fy; t2 = S.eb[2] * fy;
+            c0 = S.ec[0]; c1 = S.ec[1]; c2 = S.ec[2];
+            entry = sl | (lx << 8) | (ly << 16) | ((ly * RXR_TILE_W + lx) << 24);
+            static_assert(RXR_STAGE_TRIS <= 256 && RXR_TILE_W == 16 && TH <= 32, "bit fields of a ring entry");
+        }
+#if RXR_ROWS_UNROLL_PX
+#pragma unroll
+#else
+#pragma unroll 1
+#endif
+        for (uint32_t px = 0; px < 4u; ++px) {
+            // Edges::evaluate (edge.rs:28-36)
+            const float r0 = a0 * fx + t0 + c0;
+            const float r1 = a1 * fx + t1 + c1;
+            const float r2 = a2 * fx + t2 + c2;
+            const bool pass = px < valid && !((r0 < 0.0f) || (r1 < 0.0f) || (r2 < 0.0f));
+            const unsigned long long m = __ballot(pass);
+            if (m != 0ull) {  // (wave-uniform)
+                const uint32_t at = head + fill + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                if (pass) ring[at & (RXR_ROWS_RING - 1u)] = entry;
+                fill += (uint32_t)__popcll(m);
+                if (fill >= 64u) {
+                    __builtin_amdgcn_wave_barrier();  // (LDS instructions of one wave complete in order: the entries are there)
+                    drain(64u);
+                    head += 64u;
+                    fill -= 64u;
+                }
+            }
+            fx += 1.0f;               // (exact: the next pixel centre)
+            entry += 0x01000100u;     // x + 1, cell + 1
+        }
+    }
+    if (fill) {
+        __builtin_amdgcn_wave_barrier();
+        drain(fill);
+    }
+    } else {
     for (uint32_t base = 0; base < area_total; base += RXR_TILE_THREADS) {
         const uint32_t item = base + tid;
         if (item >= area_total) break;  // (no barrier inside the loop)
@@ -2525,6 +2647,7 @@ __device__ RXR_ROWS_INLINE bool rows_round(const RasterParams &P, Stage &st, Row
         // is an LDS instruction -- a `volatile` read through the generic pointer became a FLAT load with a wait for ALL memory traffic)
         if (key >= __hip_atomic_load(cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) continue;
         atomicMin(cell, key);
+    }
     }
     } else {
     if (tid < n) rl.row_start[tid] = ((before + inc) & 0x1FFFu) - rows;
@@ -2685,7 +2808,7 @@ __device__ __forceinline__ void scan_lists(const RasterParams &P, Stage &st, uin
 template <int X>
 __device__ __forceinline__ void scan_lists_rows(const RasterParams &P, Stage &st, RowLds &rl, bool row_mode, uint32_t b0, uint32_t b1,
                                                 uint32_t tile_x0, uint32_t tile_y0px, uint32_t px, uint32_t py, float fx, float fy, Vis &vis,
-                                                int surf_profile, const Vis *opf PHASE_PARAM) {
+                                                int surf_profile, const Vis *opf, uint32_t *queue PHASE_PARAM) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t n_large = min(P.counters[CNT_LARGE], P.n_tris3d);
     const uint32_t total = n_large + (b1 - b0);
@@ -2732,7 +2855,8 @@ __device__ __forceinline__ void scan_lists_rows(const RasterParams &P, Stage &st
         __syncthreads();
         // 4. the rows of the candidates' boxes, or the walk
         PHASE_MARK(1);
-        if (row_mode && rows_round<true, (RXR_ROWS_PIXEL_ITEMS != 0) && (X < 2 || X == 8)>(P, st, rl, n, tile_x0, tile_y0px)) {
+        constexpr bool pixel_items = (RXR_ROWS_PIXEL_ITEMS != 0) && (X < 2 || X == 8);
+        if (row_mode && rows_round<true, pixel_items, RXR_TILE_H, pixel_items && (RXR_ROWS_COMPACT != 0)>(P, st, rl, n, tile_x0, tile_y0px, queue)) {
             PHASE_MARK(7);
             continue;
         }
@@ -3098,6 +3222,7 @@ __device__ __forceinline__ void raster_tile(const RasterParams &P) {
     __shared__ uint32_t s_bin[4];
     __shared__ ShadeStore<FUSED> shade_store;
     __shared__ RowStore<ROWS> row_store;
+    __shared__ uint32_t s_sort[RXR_SORT2D_MAX];  // the gathered candidates of a binned 2D pass; during the 3D passes row mode's fragment queue
     // 2-D grid, no integer division in front of every tile.  Workgroups go to the eight XCDs round robin in launch order
     // (x fastest), and every XCD has its own L2: with column = blockIdx.x, horizontally adjacent tiles -- which share the records
     // of the triangles that straddle them -- always sit on different XCDs.  RXR_XCD_GROUP = G > 0 hands each XCD groups of G
@@ -3212,7 +3337,8 @@ __device__ __forceinline__ void raster_tile(const RasterParams &P) {
             if constexpr (ROWS) {
                 const bool row_mode = !P.has_opacity;
                 if (row_mode) row_store.r.key[ly * RXR_TILE_W + lx] = RXR_ZKEY_INIT;  // own cell; published by the barriers of the first staging round
-                scan_lists_rows<X>(P, stage, row_store.r, row_mode, b0, b1, tile_x0, tile_y0px, px, py, fx, fy, vis, surf_profile, &op PHASE_ARG);
+                scan_lists_rows<X>(P, stage, row_store.r, row_mode, b0, b1, tile_x0, tile_y0px, px, py, fx, fy, vis, surf_profile, &op,
+                                   s_sort PHASE_ARG);
                 if (tid == 0 && my_bin_count) P.bin_count[bin] = 0u;  // (a non-empty list went through the barriers of a round)
                 PHASE_MARK(1);
                 if (row_mode) rows_resolve(P, row_store.r, lx, ly, fx, fy, vis, HS, hs_of);  // (the last round ended with a barrier)
@@ -3262,7 +3388,6 @@ __device__ __forceinline__ void raster_tile(const RasterParams &P) {
     // (a primitive only ever writes inside its box: :636-655, :1777-1821)
     const bool d2_here = (P.flags & RXR_FLAG_D2_ACTIVE) && P.n_prims2d && d2_box_meets(P, tile_x0, tile_y0px);
     if (d2_here) {
-        __shared__ uint32_t s_sort[RXR_SORT2D_MAX];  // the gathered candidates of a binned 2D pass
         color = pass2d<X>(P, stage, s_bin, s_sort, RXR_SORT2D_MAX, bin, tile_x0, tile_y0px, px, py, fx, fy, color);
     }
 
@@ -3527,35 +3652,35 @@ extern "C" int rxr_debug_phase_read(unsigned long long *out16, int reset) {
 extern "C" void rxr_launch_setup(const RasterParams *P, hipStream_t s) {
     if (P->n_tris3d == 0) return;
     uint32_t blocks = (P->n_tris3d + 255u) / 256u;
-    hipLaunchKernelGGL(k_setup3d, dim3(blocks), dim3(256), 0, s, *P);
+    RXR_LAUNCH(k_setup3d, dim3(blocks), dim3(256), s, *P);
 }
 extern "C" void rxr_launch_scan(const ScanArgs *A, hipStream_t s) {
     uint32_t chunks = (A->n + RXR_SCAN_CHUNK - 1u) / RXR_SCAN_CHUNK;
     if (chunks == 0) chunks = 1;
-    hipLaunchKernelGGL(k_scan, dim3(chunks), dim3(256), 0, s, *A);
+    RXR_LAUNCH(k_scan, dim3(chunks), dim3(256), s, *A);
 }
 extern "C" void rxr_launch_bin2d_count(const RasterParams *P, hipStream_t s) {
     if (P->n_prims2d == 0) return;
-    hipLaunchKernelGGL(k_bin2d_count, dim3((P->n_prims2d + 255u) / 256u), dim3(256), 0, s, *P);
+    RXR_LAUNCH(k_bin2d_count, dim3((P->n_prims2d + 255u) / 256u), dim3(256), s, *P);
 }
 extern "C" void rxr_launch_bin2d_fill(const RasterParams *P, hipStream_t s) {
     if (P->n_prims2d == 0) return;
-    hipLaunchKernelGGL(k_bin2d_fill, dim3((P->n_prims2d + 255u) / 256u), dim3(256), 0, s, *P);
+    RXR_LAUNCH(k_bin2d_fill, dim3((P->n_prims2d + 255u) / 256u), dim3(256), s, *P);
 }
 extern "C" void rxr_launch_blockscan(const RasterParams *P, hipStream_t s) {
     if (P->n_tris3d == 0 || P->tiles_x * P->tiles_y == 0) return;
     const uint32_t blocks = ((P->tiles_x + 3u) / 4u) * ((P->tiles_y + 3u) / 4u);
-    hipLaunchKernelGGL(k_blockscan, dim3(blocks), dim3(256), 0, s, *P);
+    RXR_LAUNCH(k_blockscan, dim3(blocks), dim3(256), s, *P);
 }
 extern "C" void rxr_launch_blockscan2d(const RasterParams *P, hipStream_t s) {
     if (P->n_prims2d == 0 || P->tiles_x * P->tiles_y == 0) return;
     const uint32_t blocks = ((P->tiles_x + 3u) / 4u) * ((P->tiles_y + 3u) / 4u);
-    hipLaunchKernelGGL(k_blockscan2d, dim3(blocks), dim3(256), 0, s, *P);
+    RXR_LAUNCH(k_blockscan2d, dim3(blocks), dim3(256), s, *P);
 }
 extern "C" void rxr_launch_fill(const RasterParams *P, hipStream_t s) {
     if (P->n_tris3d == 0) return;
     uint32_t blocks = (P->n_tris3d + 255u) / 256u;
-    hipLaunchKernelGGL(k_fill, dim3(blocks), dim3(256), 0, s, *P);
+    RXR_LAUNCH(k_fill, dim3(blocks), dim3(256), s, *P);
 }
 extern "C" void rxr_launch_raster(const RasterParams *P, hipStream_t s) {
     if (P->tiles_x * P->tiles_y == 0) return;
@@ -3567,15 +3692,15 @@ extern "C" void rxr_launch_raster(const RasterParams *P, hipStream_t s) {
 #endif
     const bool rl = P->relaxed_lights && P->n_lights && (P->flags & RXR_FLAG_D3_ACTIVE);  // (frames without a 3D light loop: one kernel for both modes)
     const bool no_rows = getenv("RXR_NO_ROWS") != nullptr;  // tuning knob: binned scenes walk every candidate per pixel (k_raster)
-    if (P->kernel_level >= 5u) hipLaunchKernelGGL(k_raster_vm_v, tiles, dim3(RXR_TILE_THREADS), 0, s, *P);
-    else if (P->kernel_level == 4u && P->plain_programs) hipLaunchKernelGGL(k_raster_vm_p, tiles, dim3(RXR_TILE_THREADS), 0, s, *P);
-    else if (P->kernel_level == 4u) hipLaunchKernelGGL(k_raster_vm_sv, tiles, dim3(RXR_TILE_THREADS), 0, s, *P);
-    else if (P->kernel_level == 3u) hipLaunchKernelGGL(k_raster_vm_s, tiles, dim3(RXR_TILE_THREADS), 0, s, *P);
-    else if (P->kernel_level == 2u) hipLaunchKernelGGL(k_raster_vm, tiles, dim3(RXR_TILE_THREADS), 0, s, *P);
+    if (P->kernel_level >= 5u) RXR_LAUNCH(k_raster_vm_v, tiles, dim3(RXR_TILE_THREADS), s, *P);
+    else if (P->kernel_level == 4u && P->plain_programs) RXR_LAUNCH(k_raster_vm_p, tiles, dim3(RXR_TILE_THREADS), s, *P);
+    else if (P->kernel_level == 4u) RXR_LAUNCH(k_raster_vm_sv, tiles, dim3(RXR_TILE_THREADS), s, *P);
+    else if (P->kernel_level == 3u) RXR_LAUNCH(k_raster_vm_s, tiles, dim3(RXR_TILE_THREADS), s, *P);
+    else if (P->kernel_level == 2u) RXR_LAUNCH(k_raster_vm, tiles, dim3(RXR_TILE_THREADS), s, *P);
     else if (P->kernel_level == 1u) {
-        if (rl) hipLaunchKernelGGL(k_raster_chunk_rl, tiles, dim3(RXR_TILE_THREADS), 0, s, *P);
-        else hipLaunchKernelGGL(k_raster_chunk, tiles, dim3(RXR_TILE_THREADS), 0, s, *P);
-    } else if (P->fused_small == 1u) hipLaunchKernelGGL(k_raster_fused, tiles, dim3(RXR_TILE_THREADS), 0, s, *P);
+        if (rl) RXR_LAUNCH(k_raster_chunk_rl, tiles, dim3(RXR_TILE_THREADS), s, *P);
+        else RXR_LAUNCH(k_raster_chunk, tiles, dim3(RXR_TILE_THREADS), s, *P);
+    } else if (P->fused_small == 1u) RXR_LAUNCH(k_raster_fused, tiles, dim3(RXR_TILE_THREADS), s, *P);
     else if (P->fused_small == 0u && (P->flags & RXR_FLAG_D3_ACTIVE) && !no_rows) {
         // two tiles per workgroup (raster_tile_pair): opt-in.  Built in round 3 as the 16 x 32-tile experiment the round-2 verdict asked to
         // repeat on a build that passes parity: it does pass (tests/test_gpu_rows.py runs it), and it LOSES -- 1 M-triangle grid 555 ->
@@ -3586,11 +3711,11 @@ extern "C" void rxr_launch_raster(const RasterParams *P, hipStream_t s) {
         const bool pairs_on = pt && pt[0] == '1';
         if (pairs_on && !P->has_opacity && P->tile_stride == 1u && !RXR_XCD_GROUP) {
             const dim3 pairs(P->tiles_x, (P->tiles_y + 1u) / 2u);
-            if (rl) hipLaunchKernelGGL(k_raster_pair_rl, pairs, dim3(RXR_TILE_THREADS), 0, s, *P);
-            else hipLaunchKernelGGL(k_raster_pair, pairs, dim3(RXR_TILE_THREADS), 0, s, *P);
-        } else if (rl) hipLaunchKernelGGL(k_raster_rows_rl, tiles, dim3(RXR_TILE_THREADS), 0, s, *P);
-        else hipLaunchKernelGGL(k_raster_rows, tiles, dim3(RXR_TILE_THREADS), 0, s, *P);
-    } else if (rl) hipLaunchKernelGGL(k_raster_rl, tiles, dim3(RXR_TILE_THREADS), 0, s, *P);
-    else hipLaunchKernelGGL(k_raster, tiles, dim3(RXR_TILE_THREADS), 0, s, *P);
+            if (rl) RXR_LAUNCH(k_raster_pair_rl, pairs, dim3(RXR_TILE_THREADS), s, *P);
+            else RXR_LAUNCH(k_raster_pair, pairs, dim3(RXR_TILE_THREADS), s, *P);
+        } else if (rl) RXR_LAUNCH(k_raster_rows_rl, tiles, dim3(RXR_TILE_THREADS), s, *P);
+        else RXR_LAUNCH(k_raster_rows, tiles, dim3(RXR_TILE_THREADS), s, *P);
+    } else if (rl) RXR_LAUNCH(k_raster_rl, tiles, dim3(RXR_TILE_THREADS), s, *P);
+    else RXR_LAUNCH(k_raster, tiles, dim3(RXR_TILE_THREADS), s, *P);
 }
 #endif  // !RXR_JIT

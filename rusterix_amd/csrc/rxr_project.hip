@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 
+#include "rxr_launch.h"
 #include "rxr_project.h"
 
 #ifndef RXR_VEK_FUSED_MATVEC
@@ -558,27 +559,27 @@ extern "C" __global__ void __launch_bounds__(256) k_proj_edges(ProjectParams P) 
 extern "C" void rxr_launch_proj_static(const ProjectParams *P, hipStream_t s) {
     uint32_t n = P->n_verts_in > P->n_tris_in ? P->n_verts_in : P->n_tris_in;
     if (n == 0) return;
-    hipLaunchKernelGGL(k_proj_static, dim3((n + 255u) / 256u), dim3(256), 0, s, *P);
+    RXR_LAUNCH(k_proj_static, dim3((n + 255u) / 256u), dim3(256), s, *P);
 }
 extern "C" void rxr_launch_project(const ProjectParams *P, hipStream_t s) {
     if (P->n_meshes == 0) return;
     static const bool small_ok = !(getenv("RXR_PROJ_SMALL") && atoi(getenv("RXR_PROJ_SMALL")) == 0);
     if (small_ok && P->n_verts_in <= RXR_PROJ_SMALL_MAX && P->n_tris_in < RXR_PROJ_SMALL_MAX && P->n_meshes <= RXR_PROJ_SMALL_MAX) {
-        hipLaunchKernelGGL(k_proj_small, dim3(1), dim3(256), 0, s, *P);
-        if (P->n_tris_out && !P->edges_in_setup) hipLaunchKernelGGL(k_proj_edges, dim3((P->n_tris_out + 255u) / 256u), dim3(256), 0, s, *P);
+        RXR_LAUNCH(k_proj_small, dim3(1), dim3(256), s, *P);
+        if (P->n_tris_out && !P->edges_in_setup) RXR_LAUNCH(k_proj_edges, dim3((P->n_tris_out + 255u) / 256u), dim3(256), s, *P);
         return;
     }
-    hipLaunchKernelGGL(k_proj_init, dim3((P->n_meshes + 255u) / 256u), dim3(256), 0, s, *P);
-    if (P->n_verts_in) hipLaunchKernelGGL(k_proj_vertices, dim3((P->n_verts_in + 255u) / 256u), dim3(256), 0, s, *P);
+    RXR_LAUNCH(k_proj_init, dim3((P->n_meshes + 255u) / 256u), dim3(256), s, *P);
+    if (P->n_verts_in) RXR_LAUNCH(k_proj_vertices, dim3((P->n_verts_in + 255u) / 256u), dim3(256), s, *P);
     uint32_t nt1 = P->n_tris_in + 1u;
-    hipLaunchKernelGGL(k_clip_count, dim3((nt1 + 255u) / 256u), dim3(256), 0, s, *P);
-    hipLaunchKernelGGL(k_proj_scan, dim3((nt1 + RXR_PROJ_SCAN_CHUNK - 1u) / RXR_PROJ_SCAN_CHUNK), dim3(256), 0, s, *P);
-    if (P->n_tris_in) hipLaunchKernelGGL(k_clip_emit, dim3((P->n_tris_in + 255u) / 256u), dim3(256), 0, s, *P);
-    if (P->n_tris_out && !P->edges_in_setup) hipLaunchKernelGGL(k_proj_edges, dim3((P->n_tris_out + 255u) / 256u), dim3(256), 0, s, *P);
+    RXR_LAUNCH(k_clip_count, dim3((nt1 + 255u) / 256u), dim3(256), s, *P);
+    RXR_LAUNCH(k_proj_scan, dim3((nt1 + RXR_PROJ_SCAN_CHUNK - 1u) / RXR_PROJ_SCAN_CHUNK), dim3(256), s, *P);
+    if (P->n_tris_in) RXR_LAUNCH(k_clip_emit, dim3((P->n_tris_in + 255u) / 256u), dim3(256), s, *P);
+    if (P->n_tris_out && !P->edges_in_setup) RXR_LAUNCH(k_proj_edges, dim3((P->n_tris_out + 255u) / 256u), dim3(256), s, *P);
 }
 // the Edges pool alone (rxr_read_projected_mesh on a frame whose set-up built the records itself)
 extern "C" void rxr_launch_proj_edges(const ProjectParams *P, hipStream_t s) {
-    if (P->n_tris_out) hipLaunchKernelGGL(k_proj_edges, dim3((P->n_tris_out + 255u) / 256u), dim3(256), 0, s, *P);
+    if (P->n_tris_out) RXR_LAUNCH(k_proj_edges, dim3((P->n_tris_out + 255u) / 256u), dim3(256), s, *P);
 }
 
 // =================================================================================================
@@ -738,10 +739,10 @@ extern "C" __global__ void __launch_bounds__(256) k_proj2d_small(Project2DParams
 extern "C" void rxr_launch_project2d(const Project2DParams *P, hipStream_t s) {
     static const bool small_ok = !(getenv("RXR_PROJ_SMALL") && atoi(getenv("RXR_PROJ_SMALL")) == 0);
     if (small_ok && P->n_meshes <= RXR_PROJ_SMALL_MAX && P->n_verts <= RXR_PROJ_SMALL_MAX && P->n_prims <= RXR_PROJ_SMALL_MAX) {
-        hipLaunchKernelGGL(k_proj2d_small, dim3(1), dim3(256), 0, s, *P);
+        RXR_LAUNCH(k_proj2d_small, dim3(1), dim3(256), s, *P);
         return;
     }
-    hipLaunchKernelGGL(k_proj2d_init, dim3((P->n_meshes + 255u) / 256u + 1u), dim3(256), 0, s, *P);
-    if (P->n_verts) hipLaunchKernelGGL(k_proj2d_bbox, dim3((P->n_verts + 255u) / 256u), dim3(256), 0, s, *P);
-    if (P->n_prims) hipLaunchKernelGGL(k_proj2d_prims, dim3((P->n_prims + 255u) / 256u), dim3(256), 0, s, *P);
+    RXR_LAUNCH(k_proj2d_init, dim3((P->n_meshes + 255u) / 256u + 1u), dim3(256), s, *P);
+    if (P->n_verts) RXR_LAUNCH(k_proj2d_bbox, dim3((P->n_verts + 255u) / 256u), dim3(256), s, *P);
+    if (P->n_prims) RXR_LAUNCH(k_proj2d_prims, dim3((P->n_prims + 255u) / 256u), dim3(256), s, *P);
 }

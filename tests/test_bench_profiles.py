@@ -21,8 +21,26 @@ def test_the_quoted_numbers_are_the_committed_summary():
         assert prof[mode]["fetch_bytes_x2"] == round(k["FETCH_SIZE"] * 2048)   # gfx950: FETCH_SIZE counts half of a streaming read
         assert prof[mode]["valu_wave_instructions"] == round(k["SQ_INSTS_VALU"])
         assert bench.PROFILE_SUMMARY in prof[mode]["source"] and kernel in prof[mode]["source"]
+        # the compute-side rooflines of the bench line (valu_issue_frac, fp32_frac) come from the same passes
+        assert prof[mode]["fp32_wave_instructions"] == {c: round(k["SQ_INSTS_VALU_" + c + "_F32"]) for c in ("ADD", "MUL", "FMA")}
+        assert min(prof[mode]["fp32_wave_instructions"].values()) > 0
+        assert abs(prof[mode]["valu_lane_utilisation"] - k["SQ_THREAD_CYCLES_VALU"] / (k["SQ_ACTIVE_INST_VALU"] * 64.0)) < 1e-4
+        assert 0.5 < prof[mode]["valu_lane_utilisation"] <= 1.0
         # the framebuffer of the workload (3840 x 2160 x 4) is written once per launch: a summary of another workload would not fit
         assert 33177600 <= prof[mode]["write_bytes"] <= 33177600 * 1.15
+    # the kernel durations of the rocprofv3 --kernel-trace --stats pass of the same command, and the summary's own bench line: the
+    # live per-dispatch timing agrees with the trace, and set-up + raster fit inside the step (rounds 1-3 recorded events BETWEEN the
+    # launches: 121.2 us of kernels in a 115.9 us step, round-3 verdict)
+    import csv
+
+    rows = {r["Name"].split("(")[0]: r for r in csv.DictReader(open(os.path.join(ROOT, bench.PROFILE_KERNEL_STATS)))}
+    assert prof["relaxed"]["traced_kernel_avg_us"] == round(float(rows["k_raster_rl"]["AverageNs"]) / 1e3, 2)
+    assert prof["relaxed"]["traced_setup_avg_us"] == round(float(rows["k_setup3d"]["AverageNs"]) / 1e3, 2)
+    line = d["bench_line"]
+    roof = line["roofline"]
+    assert roof["kernels_fit_step"] is True and roof["kernel_avg_us"] + roof["setup_kernels_avg_us"] <= line["ms_per_step"] * 1e3 * 1.005
+    assert abs(roof["kernel_avg_us"] - prof["relaxed"]["traced_kernel_avg_us"]) <= 0.03 * prof["relaxed"]["traced_kernel_avg_us"]
+    assert line["value_semantics"] == "device-resident"
     assert bench.PROFILES == prof
     # the summary's own bench line is the workload BASELINE.json names
     assert d["bench_line"]["config"]["resolution"] == [3840, 2160] and d["bench_line"]["n_gpus"] == 1

@@ -38,3 +38,12 @@ def test_bench_runs_its_multi_rank_path(world, exchange, extra):
         assert any(k.startswith("rotate_") for k in ev) and all("error" not in v for v in ev.values()), ev
         assert all(v["mpix_s"] > 0 for v in ev.values())
         assert d["config"]["frames_in_flight_per_gpu"] == 2 and d["config"]["frames_per_exchange"] == 4
+        # the line explains itself (round-3 verdict): the root's link bound of the gather BASELINE.json names, the whole frame on one GPU in
+        # the same run (one at a time and over the lanes), and the fastest exchange of the run by name
+        eb, bv = d["exchange_bound"], d["best_variant"]
+        assert eb["root_link_bytes_per_frame"] > 0 and eb["measured_on_hardware"] is False and eb["whole_frame_one_gpu_ms"] > 0
+        assert set(eb["min_ms_per_frame"]) == set(eb["speedup_ceiling"]) == {"rccl_low", "rccl_high", "peak"}
+        assert eb["speedup_ceiling"]["rccl_low"] < eb["speedup_ceiling"]["rccl_high"] < eb["speedup_ceiling"]["peak"]
+        assert len(pr_["whole_frame_serial_ms"]) == world and len(pr_["whole_frame_lanes_ms"]) == world and min(pr_["whole_frame_lanes_ms"]) > 0
+        assert bv["ms_per_step"] > 0 and bv["x_vs_value"] >= 1.0 and (bv["name"] in ev or bv["name"].startswith("value: "))
+    assert d["value_semantics"] == "device-resident"

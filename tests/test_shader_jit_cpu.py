@@ -106,3 +106,44 @@ def test_the_background_compiler_is_a_process_that_turns_a_source_file_into_a_co
     pr = subprocess.run([exe, lib, str(source), "gfx950", "8", str(bad)], capture_output=True, text=True, timeout=300)
     assert pr.returncode != 0 and not bad.exists()
 
+
+
+def test_the_background_compiler_starts_without_a_gpu_and_without_the_parents_tool_libraries(tmp_path, monkeypatch):
+    """The compile-only child must be GPU-free by construction (round-3 verdict): under a profiler the parent's environment preloads
+    a tool library that initialises the GPU in every process it reaches.  rxr_jitc gets our environment minus LD_PRELOAD / LD_AUDIT /
+    HSA_TOOLS_* / ROCP* / ROCPROFILER* / ROCTRACER*, with every device hidden from both runtimes and TMPDIR inside the job's directory --
+    and still compiles (hiprtc needs no device: the architecture is an argument)."""
+    import os
+    import subprocess
+
+    monkeypatch.setenv("LD_PRELOAD", "/opt/rocm/lib/librocprofiler-sdk-tool.so")
+    monkeypatch.setenv("LD_AUDIT", "/nonexistent/audit.so")
+    monkeypatch.setenv("HSA_TOOLS_LIB", "/opt/rocm/lib/librocprofiler-sdk.so")
+    monkeypatch.setenv("HSA_TOOLS_REPORT_LOAD_FAILURE", "1")
+    monkeypatch.setenv("ROCPROFILER_LIBRARY_CTOR", "1")
+    monkeypatch.setenv("ROCPROF_COUNTERS", "SQ_WAVES")
+    monkeypatch.setenv("ROCP_TOOL_LIBRARIES", "/x.so")
+    monkeypatch.setenv("ROCTRACER_DOMAIN", "hip")
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0")
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "0,1")
+    monkeypatch.setenv("TMPDIR", "/somewhere/else")
+    monkeypatch.setenv("RXR_KEEP_ME", "yes")
+    lib = rusterix_amd.load_rxr()
+    lib.rxr_debug_jit_child_env.argtypes = [C.c_char_p, C.c_char_p, C.c_uint32]
+    buf = C.create_string_buffer(1 << 20)
+    assert 0 < lib.rxr_debug_jit_child_env(str(tmp_path).encode(), buf, len(buf)) <= len(buf)
+    env = dict(line.split("=", 1) for line in buf.value.decode().splitlines() if "=" in line)
+    for name in env:
+        assert not name.startswith(("LD_PRELOAD", "LD_AUDIT", "HSA_TOOLS_", "ROCP", "ROCTRACER", "ROCTX")), name
+    assert env["HIP_VISIBLE_DEVICES"] == "" and env["ROCR_VISIBLE_DEVICES"] == ""
+    assert env["TMPDIR"] == str(tmp_path) and env["RXR_KEEP_ME"] == "yes" and env["PATH"] == os.environ["PATH"]
+    # the child really works in that environment
+    rc, src, msg = generate([Program([["Color", "SetColor"]])], 0)
+    assert rc == 0, msg
+    path = rusterix_amd.lib_paths()["rxr"]
+    exe = os.path.join(os.path.dirname(path), "rxr_jitc")
+    source, out = tmp_path / "set.h", tmp_path / "set.co"
+    source.write_text(src)
+    pr = subprocess.run([exe, path, str(source), "gfx950", "8", str(out)], capture_output=True, text=True, timeout=300, env=env)
+    assert pr.returncode == 0, pr.stderr
+    assert out.read_bytes()[:4] == b"\x7fELF"
