@@ -1993,7 +1993,12 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
     return RXR_OK;
 }
 
-static int render_impl(rxr_ctx *ctx, const RenderSpec &spec, void *dev_pixels, hipStream_t s, bool retry = false) {
+// n_raster_bands > 1 (contiguous band specs only): ONE pre-pass over the spec's rows, then the raster kernel in that many launches over
+// consecutive groups of tile rows, an event of band_events recorded behind each -- the caller ships finished rows while the next ones
+// render (rxr_render_download).  The bins are those of the one pre-pass (RasterParams.bin_row0); every bin is still handed back zeroed
+// by its own tile's workgroup; the frame is byte-identical to one launch (tests/test_gpu_parity.py).
+static int render_impl(rxr_ctx *ctx, const RenderSpec &spec, void *dev_pixels, hipStream_t s, bool retry = false, uint32_t n_raster_bands = 1,
+                       hipEvent_t *band_events = nullptr, uint32_t *band_row_of = nullptr) {
     if (!ctx) return RXR_ERR_INVALID;
     if (!ctx->has_frame) return fail(ctx, RXR_ERR_INVALID, "render: no frame uploaded");
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -2135,7 +2140,23 @@ static int render_impl(rxr_ctx *ctx, const RenderSpec &spec, void *dev_pixels, h
         }
     }
     if (slot) slot->raster_first = slot->n;
-    if (!rxr_jit_launch(ctx, &P, s)) rxr_launch_raster(&P, s);
+    if (n_raster_bands > 1u && spec.tile_stride == 1u && !spec.compact) {
+        const uint32_t rows_all = P.tiles_y, first_row = P.tile_y0, r0_all = P.row0, r1_all = P.row1;
+        for (uint32_t k = 0; k < n_raster_bands; ++k) {
+            const uint32_t a = (uint32_t)((uint64_t)rows_all * k / n_raster_bands), b = (uint32_t)((uint64_t)rows_all * (k + 1u) / n_raster_bands);
+            P.bin_row0 = a;
+            P.tile_y0 = first_row + a;
+            P.tiles_y = b - a;
+            P.row0 = std::max(r0_all, (first_row + a) * (uint32_t)RXR_TILE_H);
+            P.row1 = std::min(r1_all, (first_row + b) * (uint32_t)RXR_TILE_H);
+            if (band_row_of) {
+                band_row_of[k] = P.row0;
+                band_row_of[k + 1u] = P.row1;
+            }
+            if (P.tiles_y && !rxr_jit_launch(ctx, &P, s)) rxr_launch_raster(&P, s);
+            if (band_events) HIPCHK(ctx, hipEventRecord(band_events[k], s));
+        }
+    } else if (!rxr_jit_launch(ctx, &P, s)) rxr_launch_raster(&P, s);
     HIPCHK(ctx, hipGetLastError());
     ctx->scratch_dirty = false;  // the raster launch that hands the bins back is queued
     ctx->scratch2d_dirty = false;
@@ -2407,17 +2428,18 @@ int rxr_render_download(rxr_ctx *ctx, uint8_t *pixels) {
     if (ctx->group) return rxr_group_render_download(ctx, pixels);
     if (!ctx->has_frame) return fail(ctx, RXR_ERR_INVALID, "rxr_render_download: no frame uploaded");
     int rc = RXR_OK;
-    // The download of a 4K frame over PCIe takes longer than rendering it.  Frames whose launches cannot overflow a list
-    // (small scenes: no bins at all) are rendered in bands of tile rows and every finished band travels to the caller's
-    // buffer while the next ones render; rendering in bands is byte-identical to one launch (tested).  Measured: 3840x2160
-    // 0.90 -> 0.76 ms per call; at 1920x1080 the extra launches cost more than the overlap gains (0.26 -> 0.31 ms), hence
-    // the 4 Mpixel threshold.
+    // The download of a 4K frame over PCIe takes longer than rendering it, so frames of 4 Mpixel and more are rastered in bands of tile
+    // rows and every finished band travels to the caller's buffer while the next ones render; rendering in bands is byte-identical to
+    // one launch (tested).  Measured: 3840x2160 0.90 -> 0.76 ms per call; at 1920x1080 the extra launches cost more than the overlap
+    // gains (0.26 -> 0.31 ms), hence the threshold.  Rounds 1-3 made four whole launch sequences of it and therefore served frames
+    // without a pre-pass only; since round 4 ONE pre-pass (projection, set-up, bins) is followed by four raster launches over its bins
+    // (render_impl, RasterParams.bin_row0), which serves binned and device-projected frames as well: the 8K frame of 1 M triangles
+    // downloads 133 MB in 2.4 ms behind 0.6 ms of kernels that used to come first.  A list overflow is repaired by rxr_synchronize as
+    // ever (lists grown, the whole frame rendered again); the frame is then downloaded once more.
     const RasterParams &P = ctx->P;
-    const bool d3 = (P.flags & RXR_FLAG_D3_ACTIVE) != 0;
-    const bool no_lists = !P.binned2d && (!d3 || (P.n_tris3d <= RXR_STAGE_TRIS && ctx->small_mode != 0u)) && !ctx->frame_uses_meshes && !ctx->frame_uses_meshes2d;
     const uint32_t H = P.height;
     static const bool no_pipeline = getenv("RXR_NO_DOWNLOAD_PIPELINE") != nullptr;  // A-B runs
-    if (!no_lists || no_pipeline || (size_t)P.width * H < (1u << 22)) {
+    if (no_pipeline || (size_t)P.width * H < (1u << 22)) {
         static const bool timing = getenv("RXR_E2E_TIMING") != nullptr;  // diagnostics (tools/e2e_probe.py): where a large frame's call goes
         if (timing) {
             using clk = std::chrono::steady_clock;
@@ -2441,24 +2463,25 @@ int rxr_render_download(rxr_ctx *ctx, uint8_t *pixels) {
         return rxr_download_rows(ctx, pixels, 0, H);
     }
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    const uint32_t n_bands = 4;
-    const uint32_t tile_rows = (H + RXR_TILE_H - 1) / RXR_TILE_H;
-    uint32_t row_of[n_bands + 1];
-    for (uint32_t k = 0; k <= n_bands; ++k) row_of[k] = std::min<uint32_t>(H, (uint32_t)((uint64_t)tile_rows * k / n_bands) * RXR_TILE_H);
-    row_of[n_bands] = H;
+    constexpr uint32_t n_bands = 4;
+    uint32_t row_of[n_bands + 1] = {};
+    RenderSpec spec{};
+    rc = band_spec(ctx, 0, H, false, spec);
+    if (rc != RXR_OK) return rc;
+    const uint32_t rerenders_before = ctx->rerenders;
+    rc = render_impl(ctx, spec, ctx->d_fb.p, ctx->stream, false, n_bands, ctx->ev_band, row_of);
+    if (rc != RXR_OK) return rc;
     for (uint32_t k = 0; k < n_bands; ++k) {
-        rc = rxr_render_rows(ctx, row_of[k], row_of[k + 1]);
-        if (rc != RXR_OK) return rc;
-        HIPCHK(ctx, hipEventRecord(ctx->ev_band[k], ctx->stream));
-    }
-    for (uint32_t k = 0; k < n_bands; ++k) {
+        if (row_of[k + 1] <= row_of[k]) continue;
         const size_t off = (size_t)row_of[k] * P.width * 4, bytes = (size_t)(row_of[k + 1] - row_of[k]) * P.width * 4;
-        if (!bytes) continue;
         HIPCHK(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev_band[k], 0));
         HIPCHK(ctx, hipMemcpyAsync(pixels + off, (uint8_t *)ctx->d_fb.p + off, bytes, hipMemcpyDeviceToHost, ctx->copy_stream));
     }
     HIPCHK(ctx, hipStreamSynchronize(ctx->copy_stream));
-    return rxr_synchronize(ctx);  // (program faults are reported here)
+    rc = rxr_synchronize(ctx);  // (program faults and list overflows are reported / repaired here)
+    if (rc != RXR_OK) return rc;
+    if (ctx->rerenders != rerenders_before) return rxr_download_rows(ctx, pixels, 0, H);  // the bands that travelled were incomplete
+    return RXR_OK;
 }
 
 int rxr_get_stats(rxr_ctx *ctx, rxr_stats *out) {

@@ -385,4 +385,6 @@ struct RasterParams {
     uint32_t *out;                 // framebuffer; row `row0` of the band is at out + out_row0_offset
     uint64_t out_row_stride;       // in pixels
     int64_t out_base_row;          // row index that `out` points at (0 for the context framebuffer, row0 for external)
+    uint32_t bin_row0;             // raster launches only: launch tile row l reads the bins of pre-pass row bin_row0 + l (0 unless ONE pre-pass
+                                   // over a band is followed by several raster launches over parts of it: rxr_render_download's pipeline)
 };

@@ -3245,7 +3245,7 @@ __device__ __forceinline__ void raster_tile(const RasterParams &P) {
     // (RXR_FLIP_TILE_ROWS: dispatch the launch's bottom tile rows first -- an A-B knob for frames whose expensive tiles are at the bottom)
     const uint32_t tx = blockIdx.x, ty = RXR_FLIP_TILE_ROWS ? gridDim.y - 1u - blockIdx.y : blockIdx.y;
 #endif
-    const uint32_t bin = ty * P.tiles_x + tx;
+    const uint32_t bin = (ty + P.bin_row0) * P.tiles_x + tx;
     const uint32_t tid = threadIdx.x;
     const uint32_t tile_x0 = tx * RXR_TILE_W, tile_y0px = (P.tile_y0 + ty * P.tile_stride) * RXR_TILE_H;
 #if RXR_WAVE_8X8
@@ -3496,7 +3496,7 @@ __device__ __forceinline__ void raster_tile_pair(const RasterParams &P) {
     const uint32_t tid = threadIdx.x;
     const uint32_t tile_x0 = tx * RXR_TILE_W, tile_y0px = (P.tile_y0 + ty0) * RXR_TILE_H;
     const uint32_t lx = tid & (RXR_TILE_W - 1), ly = tid / RXR_TILE_W;
-    const uint32_t bin_a = ty0 * P.tiles_x + tx, bin_b = ty1 * P.tiles_x + tx;
+    const uint32_t bin_a = (ty0 + P.bin_row0) * P.tiles_x + tx, bin_b = (ty1 + P.bin_row0) * P.tiles_x + tx;
     // every thread reads the (uniform) list bounds itself; the counts are handed back zeroed below
     const uint32_t cnt_a = P.bin_count[bin_a], cnt_b = has_lower ? P.bin_count[bin_b] : 0u;
     const uint32_t start_a = P.chunk_base[bin_a / RXR_SCAN_CHUNK] + P.bin_offset[bin_a];
