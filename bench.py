@@ -60,6 +60,7 @@ XGMI_LINK_GBS = (64.0, 77.0, 153.0)  # per direction and link: what RCCL point-t
 # quoting a profile of an older kernel says so (`from_profiles.stale`; tests/test_bench_profiles.py).
 PROFILE_SUMMARY = "profiles/r04/bench_pmc_summary.json"
 PROFILE_KERNEL_STATS = "profiles/r04/bench_kernel_stats.csv"
+PROFILE_BENCH_LINE = "profiles/r04/bench_line.json"   # the line of a plain (unprofiled) run of the build the summary was taken on
 # rxr_kernels.hip and everything it includes (the advisor's round-3 finding: rxr_vm.h and rxr_project.h were missing)
 KERNEL_SOURCES = ["rusterix_amd/csrc/rxr_kernels.hip", "rusterix_amd/csrc/rxr_device.h", "rusterix_amd/csrc/rxr_exact_math.h", "rusterix_amd/csrc/rxr_project.h",
                   "rusterix_amd/csrc/rxr_vm.h", "rusterix_amd/csrc/rxr_launch.h", "include/rxr.h", "include/rusterix_vek.hpp"]

@@ -372,9 +372,9 @@ typedef struct rxr_shader_set {
     uint32_t n_palette;
 } rxr_shader_set;
 
-/* the last rendered frame.  The *_us fields (HIP events around the kernels, microseconds) are only measured while
- * profiling is on (rxr_profile_begin with n > 0) and are 0 otherwise: an event record idles the GPU for a few
- * microseconds per kernel boundary, a tenth of a small 1080p frame. */
+/* the last rendered frame.  The *_us fields (microseconds) are only measured while profiling is on (rxr_profile_begin with n > 0)
+ * and are 0 otherwise: the sum of the set-up kernels' durations and the raster kernel's, each taken from a start / stop HIP event pair
+ * bound to the dispatch itself (see rxr_profile_begin). */
 typedef struct rxr_stats {
     float setup_us;      /* triangle set-up + binning kernels */
     float raster_us;     /* the tile raster / shade kernel    */
@@ -501,7 +501,9 @@ int rxr_set_light_math(rxr_ctx *ctx, int mode);
  * Multi-device handles: RXR_ERR_UNSUPPORTED (use rxr_upload_frame). */
 int rxr_stream_begin(rxr_ctx *ctx, uint32_t n_batches3d, const uint32_t *vertex_capacity, const uint32_t *triangle_capacity);
 /* The same with a promise: EVERY array handed to rxr_stream_batch3d lies in page-locked host memory that the device can read
- * (rxr_alloc_pinned below, hipHostMalloc, or memory registered with rxr_pin_host_buffer / hipHostRegister).  The library then
+ * (rxr_alloc_pinned below, hipHostMalloc, or memory registered with rxr_pin_host_buffer / hipHostRegister -- each array inside ONE
+ * registration; the device reads through the device address the runtime reports for it, which for registered memory need not be
+ * the host address).  The library then
  * copies nothing on the host: a kernel on the device pulls each group of batches straight out of the caller's arrays over PCIe
  * into the pools.  A pointer that breaks the promise is a device page fault -- only promise what an allocator guarantees. */
 int rxr_stream_begin_pinned(rxr_ctx *ctx, uint32_t n_batches3d, const uint32_t *vertex_capacity, const uint32_t *triangle_capacity);
@@ -521,7 +523,12 @@ int rxr_render_rows(rxr_ctx *ctx, uint32_t row0, uint32_t row1);
 /* same, but writes the band into caller-owned DEVICE memory (`dev_pixels` points at row `row0`,
  * rows are `width*4` bytes apart) on HIP stream `hip_stream` (hipStream_t; NULL means the context's own
  * non-blocking stream, NOT the legacy default stream -- pass an explicit stream to order with other work).
- * Used by the multi-GPU host, which then gathers the bands with RCCL. */
+ * Used by the multi-GPU host, which then gathers the bands with RCCL.
+ * Streams: a context has ONE set of scratch buffers, so a render on another stream than the context's previous render is ordered
+ * behind that stream -- behind the earlier render AND whatever the caller queued on that stream after it (the event is recorded at the
+ * switch, not after every render).  A caller that alternates streams must therefore not make later work of the OLD stream wait for
+ * something the NEW stream produces: that wait would be circular.  Callers that stay on one stream, and lanes (one member context per
+ * stream, rxr_create_multi), never meet the rule. */
 int rxr_render_rows_to(rxr_ctx *ctx, uint32_t row0, uint32_t row1, void *dev_pixels, void *hip_stream);
 
 /* multi-GPU sharding primitive: renders every `stride`-th stripe of RXR_STRIPE_ROWS pixel rows,
@@ -547,13 +554,15 @@ int rxr_render_stripes_to(rxr_ctx *ctx, uint32_t first, uint32_t stride, void *d
 int rxr_render_stripes_batch(rxr_ctx *ctx, uint32_t first, uint32_t stride, uint32_t n_frames, void *dev_pixels, size_t frame_stride_bytes,
                              void *hip_stream);
 
-/* per-launch kernel timing for the benchmark: after rxr_profile_begin(ctx, n) every render records
- * HIP events (on the stream it launches on) around its set-up kernels and its raster kernel into a
- * ring of n slots; rxr_profile_read synchronizes and returns the durations in microseconds.
- * rxr_profile_begin(ctx, 0) switches the event records off again (the default). */
+/* per-launch kernel timing for the benchmark: after rxr_profile_begin(ctx, n) every kernel of a render is launched with a start /
+ * stop HIP event pair of its own (hipExtLaunchKernel, on the stream the render launches on) into a ring of n slots: the runtime
+ * fills the pair with the dispatch's begin / end timestamps, the figures a profiler's kernel trace shows.  rxr_profile_read
+ * synchronizes and returns, per sampled render, the SUM of its set-up kernels' durations and its raster kernel's, in microseconds
+ * (time between kernels is in neither).  Nothing is recorded on the stream between the launches (rounds 1-3 did: each record is a
+ * barrier packet that idles the GPU for microseconds and counts launch latency as kernel time).
+ * rxr_profile_begin(ctx, 0) switches the timing off again (the default). */
 int rxr_profile_begin(rxr_ctx *ctx, uint32_t max_frames);
-/* sample every `stride`-th render only (default 1): three event records per frame cost 10-25 us of GPU idle time, so a
- * benchmark that wants its kernel durations measured live without paying that on every frame samples, e.g., 1 in 8 */
+/* sample every `stride`-th render only (default 1) */
 int rxr_profile_stride(rxr_ctx *ctx, uint32_t stride);
 int rxr_profile_read(rxr_ctx *ctx, float *setup_us, float *raster_us, uint32_t capacity, uint32_t *n_out);
 

@@ -959,8 +959,8 @@ static int d3_rasterize(const FrameCtx &fc, uint8_t *buffer, float *z_buffer, co
                 float color[4];
                 pixel_to_vec4(texel, color);
 
-                // :1226-1317.  chunk.shader_textures (baked shader textures) are not modelled: with None the
-                // reference takes the branch below
+                // :1226-1317.  No-shader defaults first (:1305-1317); a chunk's baked shader texture (chunk.shader_textures, :1226-1267) and a
+                // batch's program (:1268-1304) replace them below
                 color[0] = srgb_to_linear_fast(color[0]);
                 color[1] = srgb_to_linear_fast(color[1]);
                 color[2] = srgb_to_linear_fast(color[2]);

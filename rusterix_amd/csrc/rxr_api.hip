@@ -495,8 +495,25 @@ int rxr_set_meshes2d(rxr_ctx *ctx, const rxr_mesh2d *meshes, uint32_t n_meshes) 
         int qrc = rxr_quiesce(ctx);
         if (qrc != RXR_OK) return qrc;
     }
+    // A call that fails half way must leave an EMPTY registration, never a partial list beside the previous call's device data
+    // (round-3 advisor finding: a later frame with use_meshes bit 1 would have built batch headers from the partial list while the
+    // projection kernels still named the old mesh indices): everything that describes the registration is reset before the first check.
     ctx->meshes2d.clear();
+    ctx->meshes2d_prims = 0;
+    ctx->meshes2d_tris = 0;
+    ctx->PP2 = Project2DParams{};
     ctx->has_frame = false;
+    struct EmptyOnFailure {
+        rxr_ctx *c;
+        bool ok = false;
+        ~EmptyOnFailure() {
+            if (!ok) {
+                c->meshes2d.clear();
+                c->meshes2d_prims = c->meshes2d_tris = 0;
+                c->PP2 = Project2DParams{};
+            }
+        }
+    } registration{ctx};
     size_t vin = 0, prims = 0, tris = 0;
     for (uint32_t i = 0; i < n_meshes; ++i) {
         const rxr_mesh2d &m = meshes[i];
@@ -530,8 +547,6 @@ int rxr_set_meshes2d(rxr_ctx *ctx, const rxr_mesh2d *meshes, uint32_t n_meshes) 
         prims += h.n_prims;
     }
     if (vin >= (1ull << 31) || prims >= (1ull << 30)) return fail(ctx, RXR_ERR_INVALID, "2D meshes too large");
-    ctx->meshes2d_prims = prims;
-    ctx->meshes2d_tris = tris;
     size_t o = 0;
     auto take = [&](size_t bytes) {
         size_t at = o;
@@ -588,6 +603,9 @@ int rxr_set_meshes2d(rxr_ctx *ctx, const rxr_mesh2d *meshes, uint32_t n_meshes) 
     PP.d2_box = (uint32_t *)(mm + m_box);
     PP.bad_line = ctx->d_host_status + HS_BAD_LINE2D;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->meshes2d_prims = prims;
+    ctx->meshes2d_tris = tris;
+    registration.ok = true;
     return RXR_OK;
 }
 
@@ -926,13 +944,18 @@ int rxr_stream_batch3d(rxr_ctx *ctx, uint32_t index, const rxr_batch3d *b) {
         for (size_t t = 0; t < (size_t)b->n_triangles * 3u; ++t) worst = std::max(worst, b->clipped_indices[t]);
         if (b->n_triangles && worst >= b->n_vertices) return give_up("batch3d: vertex index out of range");
     }
+    const void *dev_ptr[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     if (S.pinned) {
         // the promise is VERIFIED, array by array, first and last byte: a pointer the device cannot read would be a GPU page fault
-        // (which can take the whole node down), so it costs the caller a frame handed over the plain way instead
+        // (which can take the whole node down), so it costs the caller a frame handed over the plain way instead.  The kernel reads
+        // through the DEVICE address the runtime reports for the array (round-3 advisor finding: for memory locked with hipHostRegister
+        // / rxr_pin_host_buffer the device's address of a page need not be the host's; hipHostMalloc / rxr_alloc_pinned memory has one
+        // address for both), and only when first and last byte lie `bytes - 1` apart there too: one registration, mapped in one piece.
         const struct { const void *p; size_t bytes; } arr[5] = {{b->projected_vertices, (size_t)b->n_vertices * 16}, {b->clipped_uvs, (size_t)b->n_vertices * 8},
                                                                 {b->clipped_normals, b->clipped_normals ? (size_t)b->n_vertices * 12 : 0},
                                                                 {b->clipped_indices, (size_t)b->n_triangles * 12}, {b->edges, (size_t)b->n_triangles * sizeof(rxr_edges)}};
-        for (const auto &x : arr) {
+        for (int i = 0; i < 5; ++i) {
+            const auto &x = arr[i];
             if (!x.bytes) continue;
             hipPointerAttribute_t a0{}, a1{};
             const hipError_t e0 = hipPointerGetAttributes(&a0, x.p), e1 = hipPointerGetAttributes(&a1, (const uint8_t *)x.p + x.bytes - 1);
@@ -940,11 +963,15 @@ int rxr_stream_batch3d(rxr_ctx *ctx, uint32_t index, const rxr_batch3d *b) {
                 (void)hipGetLastError();
                 return give_up("rxr_stream_batch3d: an array is not in page-locked, device-readable memory (the promise of rxr_stream_begin_pinned)");
             }
+            if (!a0.devicePointer || !a1.devicePointer || (const uint8_t *)a1.devicePointer - (const uint8_t *)a0.devicePointer != (ptrdiff_t)(x.bytes - 1))
+                return give_up("rxr_stream_batch3d: an array is page-locked but has no device address in one piece (registered in parts, or not mapped)");
+            dev_ptr[i] = a0.devicePointer;
         }
     }
     FrameStream::Rec &R = S.rec[index];
     R.pv = b->projected_vertices; R.uv = b->clipped_uvs; R.nrm = b->clipped_normals; R.idx = b->clipped_indices; R.edges = b->edges;
     R.nv = b->n_vertices; R.nt = b->n_triangles;
+    for (int i = 0; i < 5; ++i) R.dev[i] = dev_ptr[i];
     S.done[index].store(1, std::memory_order_release);
     S.handed.fetch_add(1);
     // retire in index order: a batch's place in the pools is the sum of its predecessors' sizes
@@ -980,9 +1007,10 @@ int rxr_stream_batch3d(rxr_ctx *ctx, uint32_t index, const rxr_batch3d *b) {
             uint32_t n_e = 0, piece = 0;
             for (uint32_t k = b0; k < b1; ++k) {
                 const FrameStream::Rec &B = S.rec[k];
-                const struct { const void *src; size_t off, bytes; } r[5] = {{B.pv, S.off_pv + B.v0 * 16, (size_t)B.nv * 16}, {B.uv, S.off_uv + B.v0 * 8, (size_t)B.nv * 8},
-                                                                             {B.nrm, S.off_nrm + B.v0 * 12, B.nrm ? (size_t)B.nv * 12 : 0}, {B.idx, S.off_idx + B.t0 * 12, (size_t)B.nt * 12},
-                                                                             {B.edges, S.off_edges + B.t0 * sizeof(rxr_edges), (size_t)B.nt * sizeof(rxr_edges)}};
+                // (sources: the arrays' DEVICE addresses, verified when the batch was handed over)
+                const struct { const void *src; size_t off, bytes; } r[5] = {{B.dev[0], S.off_pv + B.v0 * 16, (size_t)B.nv * 16}, {B.dev[1], S.off_uv + B.v0 * 8, (size_t)B.nv * 8},
+                                                                             {B.dev[2], S.off_nrm + B.v0 * 12, B.nrm ? (size_t)B.nv * 12 : 0}, {B.dev[3], S.off_idx + B.t0 * 12, (size_t)B.nt * 12},
+                                                                             {B.dev[4], S.off_edges + B.t0 * sizeof(rxr_edges), (size_t)B.nt * sizeof(rxr_edges)}};
                 for (const auto &x : r) {
                     if (!x.bytes) continue;
                     T[n_e++] = FrameStream::GatherEntry{x.src, (uint64_t)x.off, (uint32_t)x.bytes, piece};

@@ -78,6 +78,8 @@ struct FrameStream {
         const rxr_edges *edges;
         uint32_t nv, nt;
         size_t v0, t0;
+        const void *dev[5];  // pinned mode: the DEVICE addresses of pv, uv, nrm, idx, edges (hipPointerGetAttributes: for memory registered with
+                             // hipHostRegister they need not equal the host addresses; the pull kernel reads through these)
     };
     std::vector<Rec> rec;
     std::vector<uint32_t> cap_v, cap_t;

@@ -235,6 +235,39 @@ int main(void) {
         if (q[6] != RXR_OK) ++failures;
         if (rxr_set_meshes(ctx, NULL, 0) != RXR_OK) ++failures;
 
+        {
+            /* rxr_set_meshes2d: a registration that fails half way (the SECOND mesh has an index out of range) must leave an EMPTY
+             * registration, not the first mesh of the failed call beside the device data of the call before (round-3 advisor finding).  A
+             * frame that then asks for the registered 2D meshes has no 2D primitives: it renders its 3D part, or is refused -- never faults. */
+            static float v2[4][2] = {{4, 4}, {40, 4}, {40, 30}, {4, 30}}, u2[4][2] = {{0, 0}, {1, 0}, {1, 1}, {0, 1}};
+            static uint32_t i2[6] = {0, 1, 2, 0, 2, 3}, i2_bad[6] = {0, 1, 2, 0, 2, 9};
+            rxr_mesh2d two[2];
+            memset(two, 0, sizeof two);
+            for (int k = 0; k < 2; ++k) {
+                two[k].vertices = &v2[0][0]; two[k].uvs = &u2[0][0]; two[k].indices = i2;
+                two[k].n_vertices = 4; two[k].n_triangles = 2; two[k].mode = RXR_MODE_TRIANGLES;
+                two[k].source.kind = RXR_SOURCE_PIXEL; two[k].source.pixel[1] = 200; two[k].source.pixel[3] = 255;
+                two[k].shader = -1; two[k].chunk = -1;
+            }
+            const int good = rxr_set_meshes2d(ctx, two, 2);
+            two[1].indices = i2_bad;
+            const int bad = rxr_set_meshes2d(ctx, two, 2);
+            make_valid();
+            rxr_frame f = base;
+            f.use_meshes = 2;        /* the 2D batches are the registered meshes */
+            f.batches2d = NULL;
+            f.n_batches2d = 0;
+            memset(pixels, 0, sizeof pixels);
+            const int rr = rxr_rasterize(ctx, &f, pixels);
+            const uint8_t *p2 = &pixels[(12u * W + 12u) * 4u];
+            printf("%-44s rc=%d then %d; the frame after it rc=%d pixel2d=%u,%u,%u\n", "rxr_set_meshes2d: second mesh bad", good, bad, rr, p2[0], p2[1], p2[2]);
+            if (good != RXR_OK || bad >= 0) ++failures;
+            if (rr == RXR_OK && p2[1] == 200) {   /* a mesh of the FAILED registration was drawn */
+                printf("  ^^^ FAILED: the failed registration left meshes behind\n");
+                ++failures;
+            }
+            if (rxr_set_meshes2d(ctx, NULL, 0) != RXR_OK) ++failures;
+        }
         rxr_ctx *multi = NULL;
         int ids_bad[2] = {0, 1000}, ids_ok[2] = {0, 0};
         int c0 = rxr_create_multi(&multi, NULL, 2), c1 = rxr_create_multi(&multi, ids_ok, 0), c2 = rxr_create_multi(&multi, ids_bad, 2), c3 = rxr_create_multi(NULL, ids_ok, 2);

@@ -5,6 +5,7 @@
  * (a batch never handed over, one handed over twice, a capacity exceeded, a frame that names other arrays, the promise made on a
  * handle that cannot stream), must come out byte-identical: a stream the frame cannot use is abandoned, never trusted.
  * Built and run by tests/test_gpu_abi_stream.py (gcc -std=c11 -Wall -Werror -pthread). */
+#define _POSIX_C_SOURCE 200809L /* posix_memalign under -std=c11 */
 #include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -187,6 +188,43 @@ int main(void) {
                "page-locked arrays, pulled by the device (reverse order)");
         STREAM(rxr_stream_begin_pinned(ctx, NB, cap_v, cap_t), for (uint32_t b = 0; b < NB; ++b) if (b != 11) rxr_stream_batch3d(ctx, b, &batches[b]),
                "page-locked arrays, the last batch never handed over: from scratch");
+        {
+            /* ordinary memory locked afterwards (rxr_pin_host_buffer = hipHostRegister), which include/rxr.h allows under the promise as well:
+             * the device's address of such pages need not be the host's, and the pull kernel must read through the former (round-3 advisor
+             * finding).  One malloc'ed block holds every array of every batch at odd offsets. */
+            static Arrays reg[NB];
+            const size_t per = 4 * 4 * sizeof(float) + 4 * 2 * sizeof(float) + 4 * 3 * sizeof(float) + 6 * sizeof(uint32_t) + 2 * sizeof(rxr_edges);
+            const size_t bytes = ((size_t)NB * (per + 64) + 8192 + 4095) & ~(size_t)4095;
+            uint8_t *block = NULL;
+            if (posix_memalign((void **)&block, 4096, bytes) == 0 && rxr_pin_host_buffer(ctx, block, bytes) == RXR_OK) {
+                uint8_t *p = block + 272;  /* (not page-aligned) */
+                for (uint32_t b = 0; b < NB; ++b) {
+                    reg[b].pv = (float *)p; p += 4 * 4 * sizeof(float);
+                    reg[b].uv = (float *)p; p += 4 * 2 * sizeof(float);
+                    reg[b].nrm = (float *)p; p += 4 * 3 * sizeof(float);
+                    reg[b].idx = (uint32_t *)p; p += 6 * sizeof(uint32_t);
+                    reg[b].edges = (rxr_edges *)p; p += 2 * sizeof(rxr_edges) + 16;
+                    fill(&reg[b], b);
+                }
+                point_at(reg);
+                STREAM(rxr_stream_begin_pinned(ctx, NB, cap_v, cap_t), for (uint32_t b = 0; b < NB; ++b) rxr_stream_batch3d(ctx, b, &batches[b]),
+                       "malloc'ed arrays locked with rxr_pin_host_buffer, pulled by the device");
+                (void)rxr_synchronize(ctx);
+                {   /* the frame really came out of the registered block (2 = pulled by the device), not from scratch */
+                    extern int rxr_debug_stream_info(rxr_ctx *);
+                    const int mode = rxr_debug_stream_info(ctx);
+                    printf("%-72s mode=%d %s\n", "... handed over by the pull kernel", mode, mode == 2 ? "yes" : "NO");
+                    if (mode != 2) ++failures;
+                }
+                point_at(pinned);
+                memset(out, 0, sizeof out);
+                check("... and the frame that follows, from rxr_alloc_pinned arrays again", rxr_rasterize(ctx, &frame, out));
+                rxr_unpin_host_buffer(ctx, block);
+            } else {
+                printf("(hipHostRegister refused the block: the registered-memory case is skipped)\n");
+            }
+            free(block);
+        }
         point_at(arrays);
         /* the promise broken: ordinary memory handed over as page-locked.  The library verifies every array before the device may
          * touch it (a wrong pointer would be a GPU page fault): refused, and the frame is taken from scratch */
