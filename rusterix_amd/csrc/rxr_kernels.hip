@@ -2405,6 +2405,13 @@ __device__ __forceinline__ uint32_t z_order_bits(float z) {
 #ifndef RXR_ROWS_COMPACT
 #define RXR_ROWS_COMPACT 1
 #endif
+// k_blockscan's lists: this many entries of a tile's list are fetched together with its length (0: the offsets and, behind them, the ids).
+// Measured with 64 (profiles/r04/prefetch_ids_ab_c5.txt, A-B-A-B on one box): the 1 M-triangle frame 0.574 -> 0.591 ms -- more than half of
+// its tiles are empty and fetch 256 bytes of stale slots for nothing, and the others wait for the ids in the prologue instead of behind
+// the first barrier.  Off; the knob stays for scenes without empty tiles.
+#ifndef RXR_ROWS_PREFETCH_IDS
+#define RXR_ROWS_PREFETCH_IDS 0
+#endif
 #ifndef RXR_ROWS_UNROLL_PX
 #define RXR_ROWS_UNROLL_PX 0  // (A-B knob: the four pixel slots of an item as straight-line code, five copies of the drain)
 #endif
@@ -2808,15 +2815,16 @@ __device__ __forceinline__ void scan_lists(const RasterParams &P, Stage &st, uin
 template <int X>
 __device__ __forceinline__ void scan_lists_rows(const RasterParams &P, Stage &st, RowLds &rl, bool row_mode, uint32_t b0, uint32_t b1,
                                                 uint32_t tile_x0, uint32_t tile_y0px, uint32_t px, uint32_t py, float fx, float fy, Vis &vis,
-                                                int surf_profile, const Vis *opf, uint32_t *queue PHASE_PARAM) {
+                                                int surf_profile, const Vis *opf, uint32_t *queue, uint32_t pre_n PHASE_PARAM) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t n_large = min(P.counters[CNT_LARGE], P.n_tris3d);
     const uint32_t total = n_large + (b1 - b0);
     const float4 *g4 = reinterpret_cast<const float4 *>(P.tri_setup);
     for (uint32_t base = 0; base < total; base += RXR_STAGE_TRIS) {
         const uint32_t m = min(total - base, (uint32_t)RXR_STAGE_TRIS);
-        // 1. ids of the round's list entries
-        if (tid < m) {
+        // 1. ids of the round's list entries (the first pre_n entries of this tile's own list are in rl.raw already: raster_tile fetched
+        // them together with the list's length)
+        if (tid < m && !(base == 0u && n_large == 0u && tid < pre_n)) {
             const uint32_t e = base + tid;
             rl.raw[tid] = e < n_large ? P.large_list[e] : P.bin_list[b0 + (e - n_large)];
         }
@@ -3283,11 +3291,24 @@ __device__ __forceinline__ void raster_tile(const RasterParams &P) {
         uint32_t b0 = 0, b1 = 0;
         uint32_t my_bin_count = 0;
         const bool rows_binned = ROWS && P.fused_small == 0u;  // (k_raster_chunk / k_raster_vm also serve small scenes)
+        uint32_t pre_n = 0u;  // (rows_binned, k_blockscan's lists) entries at the head of this tile's list that were fetched before its length was known
         if (rows_binned) {
             // every thread reads the (uniform) list bounds itself: no LDS round trip and no barrier in front of the first
             // list fetch; the bin count is handed back zeroed after the scan, when every thread has long read it
             my_bin_count = P.bin_count[bin];
-            const uint32_t start = P.chunk_base[bin / RXR_SCAN_CHUNK] + P.bin_offset[bin];
+            uint32_t start;
+#if RXR_ROWS_PREFETCH_IDS
+            if (P.blockscan_cap) {  // (uniform) k_blockscan: bin b owns the slots [b * cap, (b + 1) * cap) -- no offsets to fetch, and the first
+                                    // entries can travel in the same round trip as the count instead of behind it: count -> ids -> records
+                                    // becomes (count, ids) -> records.  Slots behind the count hold stale ids; nothing uses them (pre_n).
+                start = bin * P.blockscan_cap;
+                if constexpr (ROWS) {  // (straight into the round's id table: nothing else has touched it yet, and no register carries them)
+                    if (tid < (uint32_t)RXR_ROWS_PREFETCH_IDS) row_store.r.raw[tid] = P.bin_list[min(start + tid, P.list_capacity - 1u)];
+                }
+                pre_n = min(min((uint32_t)RXR_ROWS_PREFETCH_IDS, P.blockscan_cap), P.list_capacity - min(start, P.list_capacity));
+            } else
+#endif
+                start = P.chunk_base[bin / RXR_SCAN_CHUNK] + P.bin_offset[bin];
             b0 = min(start, P.list_capacity);
             b1 = min(start + my_bin_count, P.list_capacity);
         } else if (!fused && P.fused_small == 0u) {  // (s_bin[0..1]: this tile's 3D list)
@@ -3338,7 +3359,7 @@ __device__ __forceinline__ void raster_tile(const RasterParams &P) {
                 const bool row_mode = !P.has_opacity;
                 if (row_mode) row_store.r.key[ly * RXR_TILE_W + lx] = RXR_ZKEY_INIT;  // own cell; published by the barriers of the first staging round
                 scan_lists_rows<X>(P, stage, row_store.r, row_mode, b0, b1, tile_x0, tile_y0px, px, py, fx, fy, vis, surf_profile, &op,
-                                   s_sort PHASE_ARG);
+                                   s_sort, pre_n PHASE_ARG);
                 if (tid == 0 && my_bin_count) P.bin_count[bin] = 0u;  // (a non-empty list went through the barriers of a round)
                 PHASE_MARK(1);
                 if (row_mode) rows_resolve(P, row_store.r, lx, ly, fx, fy, vis, HS, hs_of);  // (the last round ended with a barrier)
@@ -3393,7 +3414,16 @@ __device__ __forceinline__ void raster_tile(const RasterParams &P) {
 
     PHASE_MARK(5);
     if (in_frame) {
-        const int64_t row = P.compact ? (int64_t)(ty * RXR_TILE_H + ly) : (int64_t)py - P.out_base_row;
+        // (the row inside the tile once more from the thread index, through a value the compiler cannot see through: kept alive from the
+        // first line of the kernel to this one, `ly` was SPILLED by the 64-register kernels -- a scratch store and load per thread for a shift)
+        uint32_t tid_again = threadIdx.x;
+        asm volatile("" : "+v"(tid_again));
+#if RXR_WAVE_8X8
+        const uint32_t ly_again = (tid_again >> 7) * 8u + ((tid_again >> 3) & 7u);
+#else
+        const uint32_t ly_again = tid_again / RXR_TILE_W;
+#endif
+        const int64_t row = P.compact ? (int64_t)(ty * RXR_TILE_H + ly_again) : (int64_t)py - P.out_base_row;
         P.out[(size_t)row * P.out_row_stride + px] = color;
     }
     PHASE_MARK(6);
