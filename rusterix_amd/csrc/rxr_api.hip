@@ -35,6 +35,9 @@ extern "C" void rxr_launch_fill(const RasterParams *P, hipStream_t s);
 extern "C" void rxr_launch_blockscan(const RasterParams *P, hipStream_t s);
 extern "C" void rxr_launch_blockscan2d(const RasterParams *P, hipStream_t s);
 extern "C" void rxr_launch_raster(const RasterParams *P, hipStream_t s);
+extern "C" void rxr_launch_fill_words(uint32_t *dst, uint64_t n_words, uint32_t value, hipStream_t s);
+extern "C" void rxr_launch_fill_outside_spans(const RasterParams *P, hipStream_t s);
+extern "C" void rxr_launch_raster_grid(const RasterParams *P, uint32_t grid_x, hipStream_t s);
 extern "C" void rxr_launch_selftest_math(uint64_t seed, uint32_t blocks, uint32_t iters, unsigned long long *mismatch, hipStream_t s);
 
 namespace {
@@ -192,6 +195,7 @@ int rxr_create(rxr_ctx **out, int device_id) {
     for (hipEvent_t &ev : ctx->ev_band)
         if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
     if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_counters, HS_WORDS * sizeof(uint32_t), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_row_spans, RXR_MAX_TILE_ROWS * sizeof(uint2), hipHostMallocDefault);
     if (e != hipSuccess) {
         std::string msg = std::string("rxr_create: ") + hipGetErrorString(e);
         rxr_destroy(ctx);
@@ -245,6 +249,8 @@ void rxr_destroy(rxr_ctx *ctx) {
     rxr_jit_drop(ctx);
     if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
     if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
+    if (ctx->h_row_spans) (void)hipHostFree(ctx->h_row_spans);
+    if (ctx->d_row_spans.p) (void)hipFree(ctx->d_row_spans.p);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->ev2) (void)hipEventDestroy(ctx->ev2);
@@ -1085,6 +1091,22 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
     bool uses_programs = false, uses_chunk_tex = false;
     bool vis_programs = false;  // an opaque-pass batch whose program may write `opacity`: the visibility loop has to run it (DB_FULL_ALPHA)
     bool any_3d_visible = false, any_3d_program = false;
+    // the pixel rows in which the reference can draw anything of this frame: per kept batch the rows of the reference's own tiles that pass
+    // its batch box test (rxr_ref_tile_span: rasterizer.rs:978-983, :594-600) -- outside them a 3D frame is the miss colour
+    uint32_t content_y0 = f->height, content_y1 = 0;
+    // ... and per tile row of the frame the tile columns, from the same boxes (a frame of very many boxes gives up: span_budget)
+    const uint32_t n_tile_rows = (f->height + RXR_TILE_H - 1u) / RXR_TILE_H, n_tile_cols = (f->width + RXR_TILE_W - 1u) / RXR_TILE_W;
+    std::vector<uint32_t> span_lo(n_tile_rows, n_tile_cols), span_hi(n_tile_rows, 0u);
+    long span_budget = 400000;  // row updates
+    auto add_span = [&](uint32_t x0, uint32_t x1, uint32_t y0, uint32_t y1) {  // pixels [x0, x1) x [y0, y1)
+        if (x0 >= x1 || y0 >= y1 || span_budget < 0) return;
+        const uint32_t c0 = x0 / RXR_TILE_W, c1 = std::min((x1 + RXR_TILE_W - 1u) / RXR_TILE_W, n_tile_cols), r0 = y0 / RXR_TILE_H, r1 = std::min((y1 + RXR_TILE_H - 1u) / RXR_TILE_H, n_tile_rows);
+        span_budget -= (long)(r1 - r0);
+        for (uint32_t r = r0; r < r1 && span_budget >= 0; ++r) {
+            span_lo[r] = std::min(span_lo[r], c0);
+            span_hi[r] = std::max(span_hi[r], c1);
+        }
+    };
     // emissive (rasterizer.rs:1323, :1394): see the check behind the 3D batches below
     bool emissive_writer_3d = false;        // a visible 3D batch (either pass) runs a program that contains SetEmissive
     bool opaque_without_emissive = false;   // a visible opaque-pass 3D batch whose fragments do NOT assign emissive themselves
@@ -1346,6 +1368,17 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
         if (!keep) d.flags |= DB_SKIP;
         else {
             any_3d_visible = true;
+            {
+                uint32_t y0 = 0, y1 = 0;
+                rxr_ref_tile_span(b.bounding_box[1], b.bounding_box[3], f->height, f->tile_size, 0.0f, y0, y1);
+                if (y0 < y1) {
+                    content_y0 = std::min(content_y0, y0);
+                    content_y1 = std::max(content_y1, y1);
+                    uint32_t x0 = 0, x1 = 0;
+                    rxr_ref_tile_span(b.bounding_box[0], b.bounding_box[2], f->width, f->tile_size, 0.0f, x0, x1);
+                    add_span(x0, x1, y0, y1);
+                }
+            }
             if (d.program_plus1) uses_programs = any_3d_program = true;
             if ((d.flags & (DB_TERRAIN | DB_FULL_ALPHA)) || d.baked_plus1) uses_chunk_tex = true;
             if (b.list == RXR_LIST_CHUNK_OPACITY) {
@@ -1925,6 +1958,11 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
             }
         }
         P.d2_box[0] = bx0; P.d2_box[1] = bx1; P.d2_box[2] = by0; P.d2_box[3] = by1;
+        if (by0 < by1) {  // (the 2D pass only ever writes inside its primitives' pixel boxes)
+            content_y0 = std::min(content_y0, by0);
+            content_y1 = std::max(content_y1, std::min(by1, f->height));
+            add_span(bx0, std::min(bx1, f->width), by0, std::min(by1, f->height));
+        }
         P.d2_box_dev = use_meshes2d ? ctx->PP2.d2_box : nullptr;  // (the device builds these records: their boxes are not known here)
     }
     P.list2d_capacity = ctx->list2d_capacity;
@@ -2015,6 +2053,31 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
         fprintf(stderr, "rxr_e2e_timing upload: validate+size %.3f, wait for the previous frame %.3f, headers %.3f, arrays (copy + ship) %.3f, rest %.3f ms\n", ut_validated,
                 ut_quiesced - ut_validated, ut_headers - ut_quiesced, ut_arrays - ut_headers, ut_ms() - ut_arrays);
     ctx->n_tris2d = (uint32_t)t2cur;
+    // Known content rows: host-projected batches only (the device-projected ones have their boxes on the device), 3D mode (the miss
+    // colour is then the constant [0,0,0,255], :420-461; in 2D mode the background is evaluated per pixel), no brush preview (it paints
+    // missed pixels, :435-458).  RXR_CONTENT_ROWS=0 switches the clamp off (A-B runs, tests).
+    const bool content_clamp = !(getenv("RXR_CONTENT_ROWS") && atoi(getenv("RXR_CONTENT_ROWS")) == 0);  // (read per upload: tests switch it on a live context)
+    ctx->content_known = content_clamp && !use_meshes && !use_meshes2d && (f->flags & RXR_FLAG_D3_ACTIVE) && !P.has_brush && f->tile_size > 0;
+    ctx->content_row0 = std::min(content_y0, content_y1);
+    ctx->content_row1 = content_y1;
+    // the spans pay when they leave out a good part of the content rows' tiles (a table look-up in front of every tile otherwise buys nothing)
+    ctx->spans_active = false;
+    if (ctx->content_known && span_budget >= 0 && n_tile_rows <= RXR_MAX_TILE_ROWS && ctx->content_row0 < ctx->content_row1 &&
+        !(getenv("RXR_ROW_SPANS") && atoi(getenv("RXR_ROW_SPANS")) == 0)) {
+        const uint32_t r0 = ctx->content_row0 / RXR_TILE_H, r1 = std::min((ctx->content_row1 + RXR_TILE_H - 1u) / RXR_TILE_H, n_tile_rows);
+        size_t inside = 0;
+        for (uint32_t r = 0; r < n_tile_rows; ++r) {
+            const bool any = span_lo[r] < span_hi[r];
+            ctx->h_row_spans[r] = make_uint2(any ? span_lo[r] : 0u, any ? span_hi[r] : 0u);
+            if (r >= r0 && r < r1 && any) inside += span_hi[r] - span_lo[r];
+        }
+        if (inside * 100u <= (size_t)(r1 - r0) * n_tile_cols * 85u) {
+            int rc2;
+            if ((rc2 = ensure(ctx, ctx->d_row_spans, RXR_MAX_TILE_ROWS * sizeof(uint2))) != RXR_OK) return rc2;
+            HIPCHK(ctx, hipMemcpyAsync(ctx->d_row_spans.p, ctx->h_row_spans, n_tile_rows * sizeof(uint2), hipMemcpyHostToDevice, ctx->stream));
+            ctx->spans_active = true;
+        }
+    }
     ctx->has_frame = true;
     ctx->rendered = false;
     ctx->upload_ordered_on = nullptr;
@@ -2058,6 +2121,28 @@ static int render_impl(rxr_ctx *ctx, const RenderSpec &spec, void *dev_pixels, h
     P.out = (uint32_t *)dev_pixels;
     P.out_row_stride = P.width;
     P.out_base_row = (spec.external && !spec.compact) ? (int64_t)spec.row0 : 0;
+    // Rows that nothing of the frame can reach (ctx->content_row0 / 1) take the miss colour from a fill at memory speed; the pre-pass and
+    // the raster kernel are launched over the tile rows in between only.  A sparse frame pays for its empty tiles otherwise: a workgroup
+    // each that fetches its bin's length to learn that there is nothing to do -- on the 1 M-triangle grid (the 84 tile rows above the grid
+    // are empty) 0.575 -> 0.531 ms for the band alone (tools/band_probe.py, profiles/r04).  Contiguous bands only (not the stripe
+    // launches of a multi-GPU share).
+    uint32_t fill_a0 = 0, fill_a1 = 0, fill_b0 = 0, fill_b1 = 0;  // rows [a0, a1) above and [b0, b1) below the content
+    if (ctx->content_known && spec.tile_stride == 1u && !spec.compact && spec.row0 < spec.row1) {
+        const uint32_t c0 = std::min(std::max(ctx->content_row0 / RXR_TILE_H * RXR_TILE_H, spec.row0), spec.row1);
+        const uint32_t c1 = std::max(std::min((ctx->content_row1 + RXR_TILE_H - 1u) / RXR_TILE_H * RXR_TILE_H, spec.row1), c0);
+        fill_a0 = spec.row0; fill_a1 = c0; fill_b0 = c1; fill_b1 = spec.row1;
+        P.row0 = c0;
+        P.row1 = c1;
+        P.tile_y0 = c0 / RXR_TILE_H;
+        P.tiles_y = c1 > c0 ? (c1 + RXR_TILE_H - 1u) / RXR_TILE_H - P.tile_y0 : 0u;
+    }
+    P.row_spans = nullptr;
+    const bool use_spans = ctx->spans_active && fill_a0 < fill_b1 /* (the clamp above applied) */ && P.tiles_y;
+    auto widest_span = [&](uint32_t first_row, uint32_t n_rows) {
+        uint32_t w = 1u;
+        for (uint32_t r = first_row; r < first_row + n_rows && r < RXR_MAX_TILE_ROWS; ++r) w = std::max(w, ctx->h_row_spans[r].y - ctx->h_row_spans[r].x);
+        return w;
+    };
     const size_t n_bins = (size_t)P.tiles_x * P.tiles_y;
 
     // Kernel timing is opt-in (rxr_profile_begin): per-dispatch start / stop events (rxr_launch.h), no event record on the stream.
@@ -2076,6 +2161,14 @@ static int render_impl(rxr_ctx *ctx, const RenderSpec &spec, void *dev_pixels, h
         explicit TimesGuard(ProfSlot *p) { rxr_launch_times = p; }
         ~TimesGuard() { rxr_launch_times = nullptr; }
     } times_guard(slot);
+    for (int part = 0; part < 2; ++part) {  // the rows outside the content: the 3D miss colour [0, 0, 0, 255] (:420-461)
+        const uint32_t a = part ? fill_b0 : fill_a0, b = part ? fill_b1 : fill_a1;
+        if (a < b) rxr_launch_fill_words(P.out + (size_t)((int64_t)a - P.out_base_row) * P.out_row_stride, (uint64_t)(b - a) * P.out_row_stride, 0xFF000000u, s);
+    }
+    if (use_spans) {  // ... and, inside the content rows, the pixels to the left and right of each tile row's span
+        P.row_spans = (const uint2 *)ctx->d_row_spans.p;
+        rxr_launch_fill_outside_spans(&P, s);
+    }
     // small scenes: one staging round of k_raster holds every triangle -> no set-up / binning launches at all
     const bool d3 = P.tiles_y && (P.flags & RXR_FLAG_D3_ACTIVE);
     P.fused_small = (d3 && P.n_tris3d <= RXR_STAGE_TRIS) ? ctx->small_mode : 0u;
@@ -2169,6 +2262,8 @@ static int render_impl(rxr_ctx *ctx, const RenderSpec &spec, void *dev_pixels, h
     }
     if (slot) slot->raster_first = slot->n;
     if (n_raster_bands > 1u && spec.tile_stride == 1u && !spec.compact) {
+        if (band_row_of)
+            for (uint32_t k = 0; k <= n_raster_bands; ++k) band_row_of[k] = k ? spec.row1 : spec.row0;  // (a frame without content: one band of filled rows)
         const uint32_t rows_all = P.tiles_y, first_row = P.tile_y0, r0_all = P.row0, r1_all = P.row1;
         for (uint32_t k = 0; k < n_raster_bands; ++k) {
             const uint32_t a = (uint32_t)((uint64_t)rows_all * k / n_raster_bands), b = (uint32_t)((uint64_t)rows_all * (k + 1u) / n_raster_bands);
@@ -2177,14 +2272,14 @@ static int render_impl(rxr_ctx *ctx, const RenderSpec &spec, void *dev_pixels, h
             P.tiles_y = b - a;
             P.row0 = std::max(r0_all, (first_row + a) * (uint32_t)RXR_TILE_H);
             P.row1 = std::min(r1_all, (first_row + b) * (uint32_t)RXR_TILE_H);
-            if (band_row_of) {
-                band_row_of[k] = P.row0;
-                band_row_of[k + 1u] = P.row1;
+            if (band_row_of) {  // (the first and the last band take the filled rows above / below the content with them)
+                band_row_of[k] = k ? P.row0 : spec.row0;
+                band_row_of[k + 1u] = k + 1u < n_raster_bands ? P.row1 : spec.row1;
             }
-            if (P.tiles_y && !rxr_jit_launch(ctx, &P, s)) rxr_launch_raster(&P, s);
+            if (P.tiles_y && !rxr_jit_launch(ctx, &P, s)) rxr_launch_raster_grid(&P, use_spans ? widest_span(P.tile_y0, P.tiles_y) : 0u, s);
             if (band_events) HIPCHK(ctx, hipEventRecord(band_events[k], s));
         }
-    } else if (!rxr_jit_launch(ctx, &P, s)) rxr_launch_raster(&P, s);
+    } else if (!rxr_jit_launch(ctx, &P, s)) rxr_launch_raster_grid(&P, use_spans ? widest_span(P.tile_y0, P.tiles_y) : 0u, s);
     HIPCHK(ctx, hipGetLastError());
     ctx->scratch_dirty = false;  // the raster launch that hands the bins back is queued
     ctx->scratch2d_dirty = false;
@@ -3153,6 +3248,15 @@ int rxr_selftest_math(rxr_ctx *ctx, uint64_t n_tuples, uint64_t seed, uint64_t m
 
 // what the run-time compiler did with the last program set of this context (rxr_jit.hip); "" when it was not asked
 // tests: how the resident frame's 3D arrays arrived -- 0 plain rxr_upload_frame, 1 streamed and copied, 2 streamed out of page-locked memory
+// tests: what rxr_upload_frame found out about the resident frame's extent: out[0] = content rows known, out[1], out[2] = the rows, out[3] = row spans in use
+extern "C" int rxr_debug_content(rxr_ctx *ctx, uint32_t *out) {
+    if (!ctx || ctx->group || !out) return -1;
+    out[0] = ctx->content_known ? 1u : 0u;
+    out[1] = ctx->content_row0;
+    out[2] = ctx->content_row1;
+    out[3] = ctx->spans_active ? 1u : 0u;
+    return 0;
+}
 extern "C" int rxr_debug_stream_info(rxr_ctx *ctx) { return (ctx && !ctx->group) ? ctx->last_upload_streamed : -1; }
 
 // tests: how many launch sequences rxr_synchronize has rendered again after a list overflow (a plain context or a member)

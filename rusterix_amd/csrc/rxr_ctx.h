@@ -20,6 +20,7 @@ struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
 };
+#define RXR_MAX_TILE_ROWS 2048u   // frames of at most 32768 rows
 
 struct TileRange {
     uint32_t first, n;
@@ -214,6 +215,15 @@ struct rxr_ctx {
     int last_upload_streamed = 0;  // 0 plain, 1 streamed (copied), 2 streamed out of page-locked arrays
 
     bool has_frame = false;
+    // Rows [content_row0, content_row1) hold everything the resident frame can draw (rxr_upload_frame; content_known false: unknown, the
+    // whole frame): outside them every pixel is the 3D miss colour, which render_impl writes with a fill instead of launching tiles there
+    bool content_known = false;
+    uint32_t content_row0 = 0, content_row1 = 0;
+    // ... and per frame tile row the tile columns [x, y) it can draw in (RasterParams.row_spans): built by rxr_upload_frame from the batch
+    // boxes in page-locked memory, copied to the device and used when they leave out enough of the content rows (spans_active)
+    uint2 *h_row_spans = nullptr;    // RXR_MAX_TILE_ROWS entries, page-locked
+    DevBuf d_row_spans;
+    bool spans_active = false;
     RasterParams P{};       // template for the resident frame (pointers resolved)
     uint32_t n_tris2d = 0;
 

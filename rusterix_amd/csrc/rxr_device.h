@@ -387,4 +387,8 @@ struct RasterParams {
     int64_t out_base_row;          // row index that `out` points at (0 for the context framebuffer, row0 for external)
     uint32_t bin_row0;             // raster launches only: launch tile row l reads the bins of pre-pass row bin_row0 + l (0 unless ONE pre-pass
                                    // over a band is followed by several raster launches over parts of it: rxr_render_download's pipeline)
+    const uint2 *row_spans;        // per FRAME tile row the tile columns [x, y) that anything of the frame can reach (rxr_upload_frame, from the
+                                   // batch boxes), or NULL: the raster grid is as wide as the widest span of the launch, workgroup (bx, ty)
+                                   // takes column x + bx and leaves at once behind y; the pixels outside the spans get the miss colour from
+                                   // k_fill_outside_spans.  Contiguous, non-compact launches only.
 };

@@ -3251,7 +3251,13 @@ __device__ __forceinline__ void raster_tile(const RasterParams &P) {
 #define RXR_FLIP_TILE_ROWS 0
 #endif
     // (RXR_FLIP_TILE_ROWS: dispatch the launch's bottom tile rows first -- an A-B knob for frames whose expensive tiles are at the bottom)
-    const uint32_t tx = blockIdx.x, ty = RXR_FLIP_TILE_ROWS ? gridDim.y - 1u - blockIdx.y : blockIdx.y;
+    uint32_t tx = blockIdx.x;
+    const uint32_t ty = RXR_FLIP_TILE_ROWS ? gridDim.y - 1u - blockIdx.y : blockIdx.y;
+    if (P.row_spans) {  // (uniform; sparse frames only: see RasterParams.row_spans)
+        const uint2 span = uniform_record(P.row_spans, P.tile_y0 + ty);
+        tx += span.x;
+        if (tx >= span.y) return;  // (the whole workgroup, in front of every barrier)
+    }
 #endif
     const uint32_t bin = (ty + P.bin_row0) * P.tiles_x + tx;
     const uint32_t tid = threadIdx.x;
@@ -3678,6 +3684,44 @@ extern "C" int rxr_debug_phase_read(unsigned long long *out16, int reset) {
 }
 #endif
 
+// rows of the framebuffer that nothing of the frame can reach (render_impl, rxr_ctx::content_row0 / 1): one value, 16-byte stores
+extern "C" __global__ void __launch_bounds__(256) k_fill_words(uint32_t *dst, unsigned long long n_words, uint32_t value) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const unsigned long long head = min(n_words, (unsigned long long)(((16u - ((uintptr_t)dst & 15u)) & 15u) >> 2));  // words up to 16-byte alignment
+    const unsigned long long n16 = (n_words - head) >> 2, tail0 = head + (n16 << 2);
+    u32x4 *const d16 = reinterpret_cast<u32x4 *>(dst + head);
+    const u32x4 v = {value, value, value, value};
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256u + threadIdx.x; i < n16; i += (unsigned long long)gridDim.x * 256u) d16[i] = v;
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < head) dst[threadIdx.x] = value;
+        if (tail0 + threadIdx.x < n_words) dst[tail0 + threadIdx.x] = value;  // (fewer than four words)
+    }
+}
+
+// the pixels of a launch's rows that lie outside its rows' spans (RasterParams.row_spans): the 3D miss colour.  One workgroup per PIXEL
+// row (grid: tile rows x RXR_TILE_H -- one workgroup per tile row took 13 us for the 8K frame's 186 rows); 16-byte stores where the
+// segment's alignment allows them.
+extern "C" __global__ void __launch_bounds__(256) k_fill_outside_spans(RasterParams P) {
+    const uint32_t trow = P.tile_y0 + blockIdx.x, y = trow * RXR_TILE_H + blockIdx.y;
+    if (y < P.row0 || y >= P.row1) return;
+    const uint2 span = P.row_spans[trow];
+    const uint32_t x_lo = min(span.x * RXR_TILE_W, P.width), x_hi = min(max(span.y, span.x) * RXR_TILE_W, P.width);  // pixels [x_lo, x_hi) belong to the raster
+    uint32_t *const row = P.out + (size_t)((int64_t)y - P.out_base_row) * P.out_row_stride;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 v4 = {0xFF000000u, 0xFF000000u, 0xFF000000u, 0xFF000000u};
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {
+        uint32_t *const seg = part ? row + x_hi : row;
+        const uint32_t n = part ? P.width - x_hi : x_lo;
+        if ((((uintptr_t)seg) & 15u) == 0u) {  // (uniform) tile columns are 64 bytes wide: aligned whenever the row is
+            for (uint32_t i = threadIdx.x; i < (n >> 2); i += 256u) reinterpret_cast<u32x4 *>(seg)[i] = v4;
+            if (threadIdx.x < (n & 3u)) seg[(n & ~3u) + threadIdx.x] = 0xFF000000u;
+        } else {
+            for (uint32_t i = threadIdx.x; i < n; i += 256u) seg[i] = 0xFF000000u;
+        }
+    }
+}
+
 // ---- host-callable launchers (used by rxr_api.hip) ------------------------------------------------
 extern "C" void rxr_launch_setup(const RasterParams *P, hipStream_t s) {
     if (P->n_tris3d == 0) return;
@@ -3712,13 +3756,28 @@ extern "C" void rxr_launch_fill(const RasterParams *P, hipStream_t s) {
     uint32_t blocks = (P->n_tris3d + 255u) / 256u;
     RXR_LAUNCH(k_fill, dim3(blocks), dim3(256), s, *P);
 }
-extern "C" void rxr_launch_raster(const RasterParams *P, hipStream_t s) {
+extern "C" void rxr_launch_fill_words(uint32_t *dst, uint64_t n_words, uint32_t value, hipStream_t s) {
+    if (!n_words) return;
+    const uint64_t want = (n_words / 4u + 1023u) / 1024u;  // four 16-byte stores per thread
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(want, 1u), 8192u);
+    RXR_LAUNCH(k_fill_words, dim3(blocks), dim3(256), s, dst, (unsigned long long)n_words, value);
+}
+extern "C" void rxr_launch_fill_outside_spans(const RasterParams *P, hipStream_t s) {
+    if (!P->row_spans || !P->tiles_y) return;
+    RXR_LAUNCH(k_fill_outside_spans, dim3(P->tiles_y, RXR_TILE_H), dim3(256), s, *P);
+}
+// grid_x: workgroups per tile row (0: tiles_x; with RasterParams.row_spans the widest span of the launch's rows)
+extern "C" void rxr_launch_raster_grid(const RasterParams *P, uint32_t grid_x, hipStream_t s);
+extern "C" void rxr_launch_raster(const RasterParams *P, hipStream_t s) { rxr_launch_raster_grid(P, 0u, s); }
+extern "C" void rxr_launch_raster_grid(const RasterParams *P, uint32_t grid_x, hipStream_t s) {
     if (P->tiles_x * P->tiles_y == 0) return;
+    if (!grid_x || !P->row_spans) grid_x = P->tiles_x;
 #if RXR_XCD_GROUP
+    grid_x = P->tiles_x;  // (this tuning build's column mapping ignores the spans: every column is rastered, the fills are overwritten)
     const uint32_t pad = 8u * RXR_XCD_GROUP;
-    const dim3 tiles(pad * ((P->tiles_x + pad - 1u) / pad), P->tiles_y);  // (see raster_tile: groups of adjacent columns per XCD)
+    const dim3 tiles(pad * ((grid_x + pad - 1u) / pad), P->tiles_y);  // (see raster_tile: groups of adjacent columns per XCD)
 #else
-    const dim3 tiles(P->tiles_x, P->tiles_y);  // tiles_y <= 2048 (frames of at most 32768 rows)
+    const dim3 tiles(grid_x, P->tiles_y);  // tiles_y <= 2048 (frames of at most 32768 rows)
 #endif
     const bool rl = P->relaxed_lights && P->n_lights && (P->flags & RXR_FLAG_D3_ACTIVE);  // (frames without a 3D light loop: one kernel for both modes)
     const bool no_rows = getenv("RXR_NO_ROWS") != nullptr;  // tuning knob: binned scenes walk every candidate per pixel (k_raster)
@@ -3739,7 +3798,7 @@ extern "C" void rxr_launch_raster(const RasterParams *P, hipStream_t s) {
         // latency chain that is twice as long.  RXR_PAIR_TILES=1 selects it.
         const char *pt = getenv("RXR_PAIR_TILES");  // (read per launch: the tests switch it)
         const bool pairs_on = pt && pt[0] == '1';
-        if (pairs_on && !P->has_opacity && P->tile_stride == 1u && !RXR_XCD_GROUP) {
+        if (pairs_on && !P->has_opacity && P->tile_stride == 1u && !RXR_XCD_GROUP && !P->row_spans) {
             const dim3 pairs(P->tiles_x, (P->tiles_y + 1u) / 2u);
             if (rl) RXR_LAUNCH(k_raster_pair_rl, pairs, dim3(RXR_TILE_THREADS), s, *P);
             else RXR_LAUNCH(k_raster_pair, pairs, dim3(RXR_TILE_THREADS), s, *P);

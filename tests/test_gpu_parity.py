@@ -326,6 +326,78 @@ def test_row_bands_equal_full_frame(product):
     assert_exact(out, full, "row bands vs full frame")
 
 
+def _sparse_scene(api, kind):
+    """scenes whose content leaves whole tile rows of the frame empty (rxr_ctx::content_row0 / 1)"""
+    if kind == "grid":          # a distant box grid: a band in the middle of the frame, binned, row mode
+        cfg = scenes.box_grid_scene(api, n=16, width=640, height=480)
+        cam_far = api.D3OrbitCamera.new()
+        cam_far.center = (1.6, 0.0, 1.6)
+        cam_far.distance = 9.0
+        cfg.setup = (lambda c=cam_far: api.Rasterizer.setup(None, *c.matrices(640.0, 480.0)).sample_mode(B.SAMPLE_LINEAR).ambient((1.0, 1.0, 1.0, 1.0)))
+        return cfg
+    if kind == "cube_and_logo":  # a small cube (3D) and a 2D rectangle low in the frame: the content is the union of the two
+        return scenes.cube_scene(api, width=640, height=480, tile_size=40, textured=True, distance=12.0)
+    if kind == "nothing":       # 3D mode, every batch behind the camera's back: no content at all
+        cfg = scenes.cube_scene(api, width=333, height=211, tile_size=40, textured=True, distance=3.0, rect_size=0.0)  # (a 2D rectangle without pixels)
+        cam = api.D3OrbitCamera.new()
+        cam.center = (0.0, 500.0, 0.0)
+        cam.distance = 1.0
+        cfg.setup = lambda c=cam: api.Rasterizer.setup(None, *c.matrices(333.0, 211.0))
+        return cfg
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize("kind", ["grid", "cube_and_logo", "nothing"])
+def test_rows_without_content_are_filled_not_rastered(oracle, product, kind, monkeypatch):
+    """Rows that no batch box reaches (the rows of the reference's own tiles that pass its batch box test, rasterizer.rs:978-983) are written
+    by a fill, the pre-pass and the raster kernel run over the rows in between: the frame equals the oracle's, the frame rendered with the
+    clamp switched off (RXR_CONTENT_ROWS=0), and the frame assembled from row bands that cut through content and emptiness alike."""
+    import ctypes as C
+
+    cfg = _sparse_scene(product, kind)
+    got = scenes.render(cfg).copy()
+    ref = scenes.render(_sparse_scene(oracle, kind))
+    assert_exact(got, ref, f"sparse frame ({kind}) vs oracle")
+    hit_rows = np.nonzero((got[..., :3].max(axis=2) > 0).any(axis=1))[0]
+    if kind == "nothing":
+        assert len(hit_rows) == 0 and (got[..., 3] == 255).all()
+    else:
+        assert len(hit_rows) and (hit_rows.min() > 32 or hit_rows.max() < cfg.height - 32), "the scene leaves no rows empty: it tests nothing"
+    lib = product.lib
+    rxr = C.CDLL(__import__("rusterix_amd").lib_paths()["rxr"])
+    lib.rxh_context.restype = C.c_void_p
+    info = (C.c_uint32 * 4)()
+    assert rxr.rxr_debug_content(C.c_void_p(lib.rxh_context()), info) == 0
+    assert info[0] == 1, "the frame's content rows are not known: the test tests nothing"
+    if kind == "grid":
+        assert 0 < info[1] < info[2] < cfg.height and info[3] == 1, list(info)   # rows above and below, and columns left and right (row spans)
+    if kind == "nothing":
+        assert info[1] >= info[2], list(info)
+    monkeypatch.setenv("RXR_ROW_SPANS", "0")
+    no_spans = scenes.render(cfg).copy()
+    assert rxr.rxr_debug_content(C.c_void_p(lib.rxh_context()), info) == 0 and info[3] == 0
+    monkeypatch.delenv("RXR_ROW_SPANS")
+    assert_exact(got, no_spans, f"sparse frame ({kind}): row spans on vs off")
+    monkeypatch.setenv("RXR_CONTENT_ROWS", "0")
+    unclamped = scenes.render(cfg).copy()
+    assert rxr.rxr_debug_content(C.c_void_p(lib.rxh_context()), info) == 0 and info[0] == 0 and info[3] == 0
+    monkeypatch.delenv("RXR_CONTENT_ROWS")
+    assert_exact(got, unclamped, f"sparse frame ({kind}): clamp on vs off")
+    lib.rxh_rasterizer_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+    rxr.rxr_render_rows.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+    rxr.rxr_download_rows.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), C.c_uint32, C.c_uint32]
+    r = cfg.setup()
+    assert lib.rxh_rasterizer_upload(r._h, cfg.scene._h, cfg.width, cfg.height, cfg.tile_size, cfg.assets._h) == 0
+    ctx = lib.rxh_context()
+    out = np.full((cfg.height, cfg.width, 4), 7, np.uint8)
+    H = cfg.height
+    cuts = sorted({0, 5, H // 7, H // 3 + 1, H // 2, (2 * H) // 3 + 3, H - 9, H})
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        assert rxr.rxr_render_rows(ctx, a, b) == 0
+        assert rxr.rxr_download_rows(ctx, out.ctypes.data_as(C.POINTER(C.c_uint8)), a, b) == 0
+    assert_exact(out, got, f"sparse frame ({kind}): row bands vs whole frame")
+
+
 @pytest.mark.parametrize("world", [1, 2, 3, 8])
 def test_stripes_equal_full_frame(product, world):
     """The multi-GPU sharding primitive on ONE GPU: every rank's interleaved stripes rendered in turn
