@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define RXR_ABI_VERSION 4u
+#define RXR_ABI_VERSION 5u
 
 typedef enum rxr_status {
     RXR_OK = 0,
@@ -159,6 +159,14 @@ typedef struct rxr_batch3d {
     uint32_t has_profile_id, profile_id;
     uint32_t list;                    /* RXR_LIST_*                                                */
     int32_t chunk;                    /* index into rxr_frame.chunks, -1 for the scene-level lists */
+    /* ABI 5, optional: edges == NULL.  The Edges records are the largest array of the hand-over (40 of the 124 bytes per triangle that a
+     * frame of boxes sends over PCIe) and a function of arrays that travel anyway: the device then builds them itself from the projected
+     * vertices -- Edges::new([v0,v1,v2],[v1,v2,v0]) behind the winding swap of `cull_mode` (src/edge.rs:12-24,
+     * src/batch/batch3d.rs:706-746; the same operations in the same order: the same floats) -- and the host sends one word per
+     * triangle: edge_visible[t] != 0 iff the record's `visible` (what the host would have passed to Edges::new).  Every 3D batch of a
+     * frame takes the same form (all with `edges` or all without); rxr_stream_batch3d likewise. */
+    const uint32_t *edge_visible;     /* [n_triangles]; read only when edges == NULL               */
+    uint32_t cull_mode;               /* RXR_CULL_* of the batch; read only when edges == NULL     */
 } rxr_batch3d;
 
 /* CullMode, src/batch/mod.rs:17-26 */

@@ -55,6 +55,9 @@ void rxh_set_devices(const int *devices, int n) { set_devices(devices, n); }
 void *rxh_context() { return context(); }
 // device-side projection on/off (rusterix::set_device_projection)
 void rxh_set_device_projection(int on) { set_device_projection(on != 0); }
+// host-projected batches with (0) or without (1, the default) their Edges records across the ABI (rusterix::set_device_edges)
+void rxh_set_device_edges(int on) { set_device_edges(on != 0); }
+int rxh_get_device_edges() { return device_edges() ? 1 : 0; }
 int rxh_get_device_projection() { return device_projection() ? 1 : 0; }
 // light-loop arithmetic (rusterix::set_light_math): 1 = exact, 0 = relaxed (the default)
 void rxh_set_light_math_exact(int exact) { set_light_math(exact != 0); }

@@ -227,6 +227,7 @@ bool Batch3D::clip_and_project(const Mat4 &view_matrix, const Mat4 &projection_m
             clipped_uvs.clear();
             clipped_normals.clear();
             edges.clear();
+            edge_visible.clear();
             has_bounding_box = false;
             return true;
         }
@@ -330,6 +331,7 @@ bool Batch3D::clip_and_project(const Mat4 &view_matrix, const Mat4 &projection_m
 
     const size_t ntc = clipped_indices.size() / 3;
     edges.resize(ntc);
+    edge_visible.resize(ntc);
     for (size_t t = 0; t < ntc; ++t) {  // :706-739
         const float *v0 = &projected_vertices[4 * clipped_indices[3 * t]];
         const float *v1 = &projected_vertices[4 * clipped_indices[3 * t + 1]];
@@ -343,6 +345,7 @@ bool Batch3D::clip_and_project(const Mat4 &view_matrix, const Mat4 &projection_m
         }
         const bool ev = t < edge_visibility.size() ? edge_visibility[t] != 0 : true;
         edges[t] = swap ? triangle_edges(v0, v2, v1, ev && visible) : triangle_edges(v0, v1, v2, ev && visible);
+        edge_visible[t] = (ev && visible) ? 1u : 0u;
     }
     return true;
 }
@@ -486,6 +489,10 @@ std::string g_error;
 uint64_t g_tex_static_gen = 0, g_tex_dynamic_gen = 0;
 uint64_t g_shaders_gen = 0, g_shader_env_gen = 0;
 bool g_device_projection = false;
+bool g_device_edges = !(getenv("RXR_HOST_EDGES") && atoi(getenv("RXR_HOST_EDGES")) != 0);
+// the form this thread's current frame takes across the ABI (every 3D batch of a frame the same: rxr.h): without Edges records, unless the
+// setting says otherwise or the page-locked streaming hand-over can only be promised for the records (see Rasterizer::upload)
+thread_local bool t_frame_edgeless = true;
 int g_light_math = RXR_LIGHT_MATH_RELAXED;  // the library's default
 uint64_t g_mesh_fingerprint = 0;
 uint64_t g_mesh2d_fingerprint = 0;
@@ -493,6 +500,8 @@ uint64_t g_mesh2d_fingerprint = 0;
 
 void set_device_projection(bool on) { g_device_projection = on; }
 bool device_projection() { return g_device_projection; }
+void set_device_edges(bool on) { g_device_edges = on; }
+bool device_edges() { return g_device_edges; }
 void set_light_math(bool exact) {
     std::lock_guard<std::recursive_mutex> lk(g_mu);
     g_light_math = exact ? RXR_LIGHT_MATH_EXACT : RXR_LIGHT_MATH_RELAXED;
@@ -616,7 +625,9 @@ rxr_batch3d view3d(const Batch3D &b, uint32_t list, int chunk, const SequenceSlo
     o.clipped_uvs = b.clipped_uvs.data();
     o.clipped_normals = b.normals.empty() ? nullptr : b.clipped_normals.data();
     o.clipped_indices = b.clipped_indices.data();
-    o.edges = b.edges.data();
+    o.edges = t_frame_edgeless ? nullptr : b.edges.data();
+    o.edge_visible = b.edge_visible.data();
+    o.cull_mode = (uint32_t)b.cull_mode_;
     o.n_vertices = (uint32_t)(b.projected_vertices.size() / 4);
     o.n_triangles = (uint32_t)b.edges.size();
     o.has_bounding_box = b.has_bounding_box ? 1u : 0u;
@@ -666,6 +677,7 @@ int Rasterizer::upload(Scene &scene, size_t w, size_t h, size_t tile_size, const
     hash_anim = hash_u32((uint32_t)scene.animation_frame);  // :208
 
     const bool on_device = g_device_projection;
+    t_frame_edgeless = g_device_edges;
     if (on_device) {
         // both halves of Scene::project run on the GPU (rxr_set_meshes / rxr_set_meshes2d below)
     } else {
@@ -690,25 +702,38 @@ int Rasterizer::upload(Scene &scene, size_t w, size_t h, size_t tile_size, const
             // (clip_and_project refills the same vectors; the first frame of a scene, whose vectors do not exist yet, copies).  It is
             // checked again per batch at hand-over: a vector that had to grow into ordinary memory is not handed over, and the frame
             // then goes the plain way.
-            auto arrays_pinned = [](const Batch3D &b) {
-                return is_pinned(b.projected_vertices) && is_pinned(b.clipped_uvs) && is_pinned(b.clipped_indices) && is_pinned(b.edges) &&
-                       (b.normals.empty() || is_pinned(b.clipped_normals));
+            // (the `visible` words are a tenth of the records: in batches of fewer than 2048 triangles they stay below the size from which
+            // the vectors are page-locked at all.  The frame then promises -- and sends -- the records, as rounds 1-3 did)
+            auto arrays_pinned_with = [](const Batch3D &b, bool edgeless) {
+                return is_pinned(b.projected_vertices) && is_pinned(b.clipped_uvs) && is_pinned(b.clipped_indices) &&
+                       (edgeless ? is_pinned(b.edge_visible) : is_pinned(b.edges)) && (b.normals.empty() || is_pinned(b.clipped_normals));
             };
-            bool pinned = true;
-            for (size_t i = 0; i < order.size() && pinned; ++i) pinned = arrays_pinned(*order[i]);
+            bool pinned = true, pinned_records = true;
+            for (size_t i = 0; i < order.size() && (pinned || pinned_records); ++i) {
+                pinned = pinned && arrays_pinned_with(*order[i], t_frame_edgeless);
+                pinned_records = pinned_records && arrays_pinned_with(*order[i], false);
+            }
+            if (!pinned && pinned_records && t_frame_edgeless) {
+                t_frame_edgeless = false;
+                pinned = true;
+            }
+            const bool edgeless = t_frame_edgeless;
+            auto arrays_pinned = [arrays_pinned_with, edgeless](const Batch3D &b) { return arrays_pinned_with(b, edgeless); };
             const bool large = (order.size() >= 8 && elements >= (1u << 20)) || (stream_forced && order.size() >= 2);
             const int began = !large ? RXR_ERR_UNSUPPORTED
                               : pinned ? rxr_stream_begin_pinned(ctx, (uint32_t)order.size(), cap_v.data(), cap_t.data())
                                        : rxr_stream_begin(ctx, (uint32_t)order.size(), cap_v.data(), cap_t.data());
             if (began == RXR_OK) {
-                hand_over = [ctx, pinned, arrays_pinned](size_t i, const Batch3D &b) {
+                hand_over = [ctx, pinned, arrays_pinned, edgeless](size_t i, const Batch3D &b) {
                     if (pinned && b.edges.size() && !arrays_pinned(b)) return;  // (the promise does not hold for this batch: not handed over)
                     rxr_batch3d v{};
                     v.projected_vertices = b.projected_vertices.data();
                     v.clipped_uvs = b.clipped_uvs.data();
                     v.clipped_normals = b.normals.empty() ? nullptr : b.clipped_normals.data();
                     v.clipped_indices = b.clipped_indices.data();
-                    v.edges = b.edges.data();
+                    v.edges = edgeless ? nullptr : b.edges.data();
+                    v.edge_visible = b.edge_visible.data();
+                    v.cull_mode = (uint32_t)b.cull_mode_;
                     v.n_vertices = (uint32_t)(b.projected_vertices.size() / 4);
                     v.n_triangles = (uint32_t)b.edges.size();
                     (void)rxr_stream_batch3d(ctx, (uint32_t)i, &v);  // (a refusal makes rxr_upload_frame hand the frame over from scratch)

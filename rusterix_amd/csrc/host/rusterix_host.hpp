@@ -150,6 +150,8 @@ public:
     PinnedVec<float> clipped_uvs;           // [n'][2]
     PinnedVec<float> clipped_normals;       // [n'][3]
     PinnedVec<rxr_edges> edges;             // [m']
+    PinnedVec<uint32_t> edge_visible;       // [m']: edges[t].visible as a word -- what travels instead of `edges` when the device builds the
+                                            // records itself (device_edges(), rxr_batch3d.edges == NULL, ABI 5)
     bool has_bounding_box = false;
     Rect bounding_box;
     uint32_t repeat_mode_ = RXR_REPEAT_CLAMP_XY;
@@ -300,6 +302,11 @@ rxr_ctx *context(std::string *error = nullptr);
 // (clip_and_project, Edges::new, bounding boxes) then runs on the GPU.  Off by default.
 void set_device_projection(bool on);
 bool device_projection();
+// host-projected 3D batches cross the ABI WITHOUT their Edges records (40 of 124 bytes per triangle over PCIe): a word per triangle says
+// `visible`, the device rebuilds a / b / c from the projected vertices it receives anyway (rxr.h, ABI 5).  Default on; RXR_HOST_EDGES=1 or
+// set_device_edges(false) sends the records as rounds 1-3 did.
+void set_device_edges(bool on);
+bool device_edges();
 // arithmetic of the 3D light loop (rxr_set_light_math, include/rxr.h): relaxed by default -- point lights within the 1-per-channel
 // tolerance of lit 3D fragments; exact = the reference's correctly rounded operations throughout.  Applies from the next frame on.
 void set_light_math(bool exact);

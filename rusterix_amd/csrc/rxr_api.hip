@@ -862,6 +862,7 @@ static int stream_begin(rxr_ctx *ctx, uint32_t n_batches3d, const uint32_t *vert
     }
     S.handed.store(0);
     S.failed.store(0);
+    S.edgeless.store(-1);
     S.err.clear();
     ctx->has_frame = false;
     S.active = true;
@@ -888,7 +889,7 @@ static bool rxr_stream_copy_some(rxr_ctx *ctx, uint32_t limit) {
         }
         if (Q.nt) {
             memcpy(st + S.off_idx + Q.t0 * 12, Q.idx, (size_t)Q.nt * 12);
-            memcpy(st + S.off_edges + Q.t0 * sizeof(rxr_edges), Q.edges, (size_t)Q.nt * sizeof(rxr_edges));
+            memcpy(st + S.off_edges + Q.t0 * S.tri5(), Q.edges, (size_t)Q.nt * S.tri5());
         }
         const uint32_t g = j / S.group_size;
         if (S.group_left[g].fetch_sub(1u, std::memory_order_acq_rel) == 1u) {
@@ -896,7 +897,7 @@ static bool rxr_stream_copy_some(rxr_ctx *ctx, uint32_t limit) {
             const FrameStream::Rec &A = S.rec[g * S.group_size], &Z = S.rec[std::min(S.n, (g + 1u) * S.group_size) - 1u];
             const size_t v0 = A.v0, nv = Z.v0 + Z.nv - A.v0, t0 = A.t0, nt = Z.t0 + Z.nt - A.t0;
             const struct { size_t off, bytes; } r[5] = {{S.off_pv + v0 * 16, nv * 16}, {S.off_uv + v0 * 8, nv * 8}, {S.off_nrm + v0 * 12, nv * 12},
-                                                        {S.off_idx + t0 * 12, nt * 12}, {S.off_edges + t0 * sizeof(rxr_edges), nt * sizeof(rxr_edges)}};
+                                                        {S.off_idx + t0 * 12, nt * 12}, {S.off_edges + t0 * S.tri5(), nt * S.tri5()}};
             std::lock_guard<std::mutex> lk(S.ship_mu);
             hipError_t e = hipSetDevice(ctx->device);
             for (const auto &x : r)
@@ -943,8 +944,16 @@ int rxr_stream_batch3d(rxr_ctx *ctx, uint32_t index, const rxr_batch3d *b) {
     if (S.failed.load()) return RXR_ERR_INVALID;
     if (S.done[index].load(std::memory_order_acquire)) return give_up("rxr_stream_batch3d: batch handed over twice");
     if (b->n_vertices > S.cap_v[index] || b->n_triangles > S.cap_t[index]) return give_up("rxr_stream_batch3d: batch exceeds the capacity announced to rxr_stream_begin");
-    if ((b->n_triangles && (!b->clipped_indices || !b->edges)) || (b->n_vertices && (!b->projected_vertices || !b->clipped_uvs)))
+    if ((b->n_triangles && (!b->clipped_indices || (!b->edges && !b->edge_visible))) || (b->n_vertices && (!b->projected_vertices || !b->clipped_uvs)))
         return give_up("rxr_stream_batch3d: NULL arrays");
+    if (b->n_triangles) {  // with Edges records or without (ABI 5): one form per frame, fixed by the first batch that has triangles
+        const int form = b->edges ? 0 : 1;
+        int seen = -1;
+        if (!S.edgeless.compare_exchange_strong(seen, form) && seen != form) return give_up("rxr_stream_batch3d: batches with and without Edges records in one frame");
+        if (form == 1 && b->cull_mode > RXR_CULL_BACK) return give_up("rxr_stream_batch3d: bad cull mode");
+    }
+    const void *const fifth = b->edges ? (const void *)b->edges : (const void *)b->edge_visible;
+    const size_t fifth_bytes = (size_t)b->n_triangles * (b->edges ? sizeof(rxr_edges) : sizeof(uint32_t));
     {
         uint32_t worst = 0;  // every index (the kernels trust them)
         for (size_t t = 0; t < (size_t)b->n_triangles * 3u; ++t) worst = std::max(worst, b->clipped_indices[t]);
@@ -959,7 +968,7 @@ int rxr_stream_batch3d(rxr_ctx *ctx, uint32_t index, const rxr_batch3d *b) {
         // address for both), and only when first and last byte lie `bytes - 1` apart there too: one registration, mapped in one piece.
         const struct { const void *p; size_t bytes; } arr[5] = {{b->projected_vertices, (size_t)b->n_vertices * 16}, {b->clipped_uvs, (size_t)b->n_vertices * 8},
                                                                 {b->clipped_normals, b->clipped_normals ? (size_t)b->n_vertices * 12 : 0},
-                                                                {b->clipped_indices, (size_t)b->n_triangles * 12}, {b->edges, (size_t)b->n_triangles * sizeof(rxr_edges)}};
+                                                                {b->clipped_indices, (size_t)b->n_triangles * 12}, {fifth, fifth_bytes}};
         for (int i = 0; i < 5; ++i) {
             const auto &x = arr[i];
             if (!x.bytes) continue;
@@ -975,7 +984,7 @@ int rxr_stream_batch3d(rxr_ctx *ctx, uint32_t index, const rxr_batch3d *b) {
         }
     }
     FrameStream::Rec &R = S.rec[index];
-    R.pv = b->projected_vertices; R.uv = b->clipped_uvs; R.nrm = b->clipped_normals; R.idx = b->clipped_indices; R.edges = b->edges;
+    R.pv = b->projected_vertices; R.uv = b->clipped_uvs; R.nrm = b->clipped_normals; R.idx = b->clipped_indices; R.edges = fifth;
     R.nv = b->n_vertices; R.nt = b->n_triangles;
     for (int i = 0; i < 5; ++i) R.dev[i] = dev_ptr[i];
     S.done[index].store(1, std::memory_order_release);
@@ -1016,7 +1025,7 @@ int rxr_stream_batch3d(rxr_ctx *ctx, uint32_t index, const rxr_batch3d *b) {
                 // (sources: the arrays' DEVICE addresses, verified when the batch was handed over)
                 const struct { const void *src; size_t off, bytes; } r[5] = {{B.dev[0], S.off_pv + B.v0 * 16, (size_t)B.nv * 16}, {B.dev[1], S.off_uv + B.v0 * 8, (size_t)B.nv * 8},
                                                                              {B.dev[2], S.off_nrm + B.v0 * 12, B.nrm ? (size_t)B.nv * 12 : 0}, {B.dev[3], S.off_idx + B.t0 * 12, (size_t)B.nt * 12},
-                                                                             {B.dev[4], S.off_edges + B.t0 * sizeof(rxr_edges), (size_t)B.nt * sizeof(rxr_edges)}};
+                                                                             {B.dev[4], S.off_edges + B.t0 * S.tri5(), (size_t)B.nt * S.tri5()}};
                 for (const auto &x : r) {
                     if (!x.bytes) continue;
                     T[n_e++] = FrameStream::GatherEntry{x.src, (uint64_t)x.off, (uint32_t)x.bytes, piece};
@@ -1064,7 +1073,8 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
         for (uint32_t i = 0; i < S.n && streamed; ++i) {
             const rxr_batch3d &b = f->batches3d[i];
             const FrameStream::Rec &R = S.rec[i];
-            streamed = b.projected_vertices == R.pv && b.clipped_uvs == R.uv && b.clipped_normals == R.nrm && b.clipped_indices == R.idx && b.edges == R.edges &&
+            streamed = b.projected_vertices == R.pv && b.clipped_uvs == R.uv && b.clipped_normals == R.nrm && b.clipped_indices == R.idx &&
+                       (b.edges ? (const void *)b.edges : (const void *)b.edge_visible) == R.edges && (!b.n_triangles || (b.edges ? 0 : 1) == S.edgeless.load()) &&
                        b.n_vertices == R.nv && b.n_triangles == R.nt;
         }
     }
@@ -1091,6 +1101,7 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
     bool uses_programs = false, uses_chunk_tex = false;
     bool vis_programs = false;  // an opaque-pass batch whose program may write `opacity`: the visibility loop has to run it (DB_FULL_ALPHA)
     bool any_3d_visible = false, any_3d_program = false;
+    int edgeless3d = -1;  // ABI 5: -1 no triangles yet, 0 the batches carry Edges records, 1 they carry `edge_visible` words instead
     // the pixel rows in which the reference can draw anything of this frame: per kept batch the rows of the reference's own tiles that pass
     // its batch box test (rxr_ref_tile_span: rasterizer.rs:978-983, :594-600) -- outside them a 3D frame is the miss colour
     uint32_t content_y0 = f->height, content_y1 = 0;
@@ -1132,7 +1143,13 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
         }
     for (uint32_t i = 0; i < f->n_batches3d; ++i) {
         const rxr_batch3d &b = f->batches3d[i];
-        if (b.n_triangles && (!b.clipped_indices || !b.edges)) return fail(ctx, RXR_ERR_INVALID, "batch3d: NULL indices/edges");
+        if (b.n_triangles && (!b.clipped_indices || (!b.edges && !b.edge_visible))) return fail(ctx, RXR_ERR_INVALID, "batch3d: NULL indices/edges");
+        if (b.n_triangles) {  // ABI 5: with Edges records or without, one form per frame
+            const int form = b.edges ? 0 : 1;
+            if (edgeless3d < 0) edgeless3d = form;
+            else if (edgeless3d != form) return fail(ctx, RXR_ERR_INVALID, "batch3d: batches with and without Edges records in one frame");
+            if (form == 1 && b.cull_mode > RXR_CULL_BACK) return fail(ctx, RXR_ERR_INVALID, "batch3d: bad cull mode");
+        }
         if (b.n_vertices && (!b.projected_vertices || !b.clipped_uvs)) return fail(ctx, RXR_ERR_INVALID, "batch3d: NULL vertex arrays");
         if (b.chunk >= (int32_t)f->n_chunks) return fail(ctx, RXR_ERR_INVALID, "batch3d: chunk index out of range");
         if (b.list == RXR_LIST_CHUNK_OPACITY) has_opacity = true;
@@ -1356,6 +1373,7 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
         d.profile_id = b.profile_id;
         d.repeat_mode = b.repeat_mode;
         d.chunk = b.chunk;
+        d.mode = edgeless3d == 1 ? b.cull_mode : 0u;  // (3D batches without Edges records: the cull mode make_setup builds them under)
         if ((rc = opacity_group_of(d, b.list == RXR_LIST_CHUNK_OPACITY, b.has_profile_id != 0)) != RXR_OK) return rc;
         memcpy(d.ambient, b.ambient_color, 12);
         // batch-level box reject, rasterizer.rs:978-983, evaluated against the whole screen
@@ -1461,7 +1479,8 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
         }
         if (b.n_triangles) {
             memcpy(st + L.off_idx + t0 * 12, b.clipped_indices, (size_t)b.n_triangles * 12);
-            memcpy(st + L.off_edges + t0 * sizeof(rxr_edges), b.edges, (size_t)b.n_triangles * sizeof(rxr_edges));
+            if (edgeless3d == 1) memcpy(st + L.off_edges + t0 * sizeof(uint32_t), b.edge_visible, (size_t)b.n_triangles * sizeof(uint32_t));
+            else memcpy(st + L.off_edges + t0 * sizeof(rxr_edges), b.edges, (size_t)b.n_triangles * sizeof(rxr_edges));
         }
         if (n_groups_ship) groups[group_of[i]].left.fetch_sub(1u, std::memory_order_release);
     };
@@ -1484,9 +1503,9 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
             for (size_t g = 0; g < n_groups_ship; ++g) {
                 ShipGroup &G = groups[g];
                 while (G.left.load(std::memory_order_acquire) != 0u) std::this_thread::yield();
-                const size_t nv = G.v1 - G.v0, nt = G.t1 - G.t0;
+                const size_t nv = G.v1 - G.v0, nt = G.t1 - G.t0, tri5 = edgeless3d == 1 ? sizeof(uint32_t) : sizeof(rxr_edges);
                 const struct { size_t off, bytes; } r[5] = {{L.off_pv + G.v0 * 16, nv * 16}, {L.off_uv + G.v0 * 8, nv * 8}, {L.off_nrm + G.v0 * 12, nv * 12},
-                                                            {L.off_idx + G.t0 * 12, nt * 12}, {L.off_edges + G.t0 * sizeof(rxr_edges), nt * sizeof(rxr_edges)}};
+                                                            {L.off_idx + G.t0 * 12, nt * 12}, {L.off_edges + G.t0 * tri5, nt * tri5}};
                 for (const auto &x : r)
                     if (x.bytes && ship_err == hipSuccess) ship_err = hipMemcpyAsync(dst + x.off, st + x.off, x.bytes, hipMemcpyHostToDevice, ctx->stream);
             }
@@ -1975,6 +1994,7 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
     P.nrm = (const float *)(d + L.off_nrm);
     P.idx = (const uint32_t *)(d + L.off_idx);
     P.edges = (const rxr_edges *)(d + L.off_edges);
+    P.edge_vis3d = edgeless3d == 1 ? (const uint32_t *)(d + L.off_edges) : nullptr;  // (the same pool, a word per triangle instead of a record)
     P.batches3d = (const DevBatch *)(d + L.off_b3);
     P.batch_tri_base = (const uint32_t *)(d + L.off_base);
     P.tri_info = with_tri_info ? (const uint2 *)(d + L.off_tinfo) : nullptr;
@@ -2041,6 +2061,7 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
         P.nrm = PP.nrm;
         P.idx = PP.idx;
         P.edges = PP.edges;
+        P.edge_vis3d = nullptr;
         P.dev_bbox = PP.bbox;
         P.mesh_live = PP.mesh_live;
         // the set-up builds the Edges records itself (k_proj_edges fused into make_setup): RXR_PROJ_FUSED_EDGES=0 keeps the pool

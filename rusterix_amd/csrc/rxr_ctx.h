@@ -76,7 +76,7 @@ struct FrameStream {
     struct Rec {
         const float *pv, *uv, *nrm;
         const uint32_t *idx;
-        const rxr_edges *edges;
+        const void *edges;        // rxr_edges records, or (S.edgeless) the uint32 `visible` words
         uint32_t nv, nt;
         size_t v0, t0;
         const void *dev[5];  // pinned mode: the DEVICE addresses of pv, uv, nrm, idx, edges (hipPointerGetAttributes: for memory registered with
@@ -108,6 +108,8 @@ struct FrameStream {
     size_t table_cap = 0;
     std::atomic<uint32_t> handed{0};
     std::atomic<int> failed{0};
+    std::atomic<int> edgeless{-1};  // -1 until the first batch with triangles arrives; then 1: batches come without Edges records (ABI 5), 0: with
+    size_t tri5() const { return edgeless.load() == 1 ? sizeof(uint32_t) : sizeof(rxr_edges); }  // bytes per triangle in the fifth pool
     std::string err;     // (under mu)
 };
 

@@ -387,6 +387,9 @@ struct RasterParams {
     int64_t out_base_row;          // row index that `out` points at (0 for the context framebuffer, row0 for external)
     uint32_t bin_row0;             // raster launches only: launch tile row l reads the bins of pre-pass row bin_row0 + l (0 unless ONE pre-pass
                                    // over a band is followed by several raster launches over parts of it: rxr_render_download's pipeline)
+    const uint32_t *edge_vis3d;    // host-projected frames handed over WITHOUT Edges records (rxr_batch3d.edges == NULL, ABI 5): per triangle != 0 iff
+                                   // its record's `visible`; make_setup builds the record from the projected vertices under the batch's cull
+                                   // mode (DevBatch.mode), as it does for device-projected frames.  NULL: P.edges holds the records
     const uint2 *row_spans;        // per FRAME tile row the tile columns [x, y) that anything of the frame can reach (rxr_upload_frame, from the
                                    // batch boxes), or NULL: the raster grid is as wide as the widest span of the launch, workgroup (bx, ty)
                                    // takes column x + bx and leaves at once behind y; the pixels outside the spans get the miss colour from

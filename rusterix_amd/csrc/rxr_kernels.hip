@@ -1263,8 +1263,9 @@ __device__ __forceinline__ bool make_setup(const RasterParams &P, uint32_t t, Tr
     }
     // (with the table the index triple and the edge record do not wait for the batch header: two levels of loads instead of seven)
     const bool own_edges = P.pm_meshes != nullptr;  // uniform: a device-projected frame whose Edges records are built here (below)
+    const bool host_edgeless = P.edge_vis3d != nullptr;  // uniform: a host-projected frame handed over without its Edges records (ABI 5)
     rxr_edges E;
-    if (!own_edges) E = P.edges[t];
+    if (!own_edges && !host_edgeless) E = P.edges[t];
     const uint32_t ix0 = P.idx[3 * (size_t)t + 0], ix1 = P.idx[3 * (size_t)t + 1], ix2 = P.idx[3 * (size_t)t + 2];
     const DevBatch B = P.batches3d[lo];
     const uint32_t vbase = have_info ? info.y : B.vert_base;
@@ -1276,6 +1277,10 @@ __device__ __forceinline__ bool make_setup(const RasterParams &P, uint32_t t, Tr
         const uint32_t local = t - P.batch_tri_base[lo];
         const bool evis = local < M.n_tris ? P.pm_edge_vis[M.tin_base + local] != 0 : true;
         E = edges_from_vertices(M.cull_mode, evis, P.pv[ix0 + vbase], P.pv[ix1 + vbase], P.pv[ix2 + vbase]);
+    } else if (host_edgeless) {
+        // Edges::new of the projected vertices under the batch's cull mode: what the host computed and did not send (40 bytes per triangle
+        // that are a function of the vertices it sent).  `visible` arrives as a word per triangle.
+        E = edges_from_vertices(B.mode, P.edge_vis3d[t] != 0u, P.pv[ix0 + vbase], P.pv[ix1 + vbase], P.pv[ix2 + vbase]);
     }
 
     // triangles that can never produce a pixel (culled / clipped away: edges.visible == false, :989-992; skipped batch;

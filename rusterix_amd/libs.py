@@ -91,6 +91,7 @@ def load():
         lib.rxh_set_device.argtypes = [ctypes.c_int]
         lib.rxh_set_devices.argtypes = [ctypes.POINTER(ctypes.c_int), ctypes.c_int]
         lib.rxh_set_device_projection.argtypes = [ctypes.c_int]
+        lib.rxh_set_device_edges.argtypes = [ctypes.c_int]
         lib.rxh_set_light_math_exact.argtypes = [ctypes.c_int]
         lib.rxh_rasterizer_upload.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p]
         _cached = make_api(lib, "rxh_", "product")

@@ -373,8 +373,20 @@ fn texture_of(t: &Texture) -> rxr_texture {
 #[derive(Default)]
 struct Repack {
     indices: Vec<u32>,
-    edges: Vec<rxr_edges>,
+    /// 3D batches cross the ABI WITHOUT their Edges records (ABI 5: `edges` NULL): one word per triangle says `visible` (a public field),
+    /// the device rebuilds a / b / c from the projected vertices under `cull_mode` -- 4 instead of 40 bytes per triangle over PCIe, and
+    /// no use of the `Edges::coefficients()` accessor for 3D batches
+    edge_visible: Vec<u32>,
+    edges: Vec<rxr_edges>, // (2D batches)
     normals: Vec<f32>,
+}
+
+fn cull_of(c: &CullMode) -> u32 {
+    match c {
+        CullMode::Off => RXR_CULL_OFF,
+        CullMode::Front => RXR_CULL_FRONT,
+        CullMode::Back => RXR_CULL_BACK,
+    }
 }
 
 struct Item3D<'a> {
@@ -428,8 +440,8 @@ fn project_streaming(this: &Rasterizer, scene: &mut Scene, ctx: *mut rxr_ctx, st
         b.clip_and_project(view, proj, w, h);
         r.indices.clear();
         r.indices.extend(b.clipped_indices.iter().flat_map(|&(a, bb, c)| [a as u32, bb as u32, c as u32])); // usize -> u32
-        r.edges.clear();
-        r.edges.extend(b.edges.iter().map(edges_of));
+        r.edge_visible.clear();
+        r.edge_visible.extend(b.edges.iter().map(|e| e.visible as u32));
         r.normals.clear();
         r.normals.extend(b.clipped_normals.iter().flat_map(|n| [n.x, n.y, n.z]));
         if streamed {
@@ -438,7 +450,9 @@ fn project_streaming(this: &Rasterizer, scene: &mut Scene, ctx: *mut rxr_ctx, st
                 clipped_uvs: b.clipped_uvs.as_ptr() as *const f32,
                 clipped_normals: if b.normals.is_empty() { std::ptr::null() } else { r.normals.as_ptr() },
                 clipped_indices: r.indices.as_ptr(),
-                edges: r.edges.as_ptr(),
+                edges: std::ptr::null(),
+                edge_visible: r.edge_visible.as_ptr(),
+                cull_mode: cull_of(&b.cull_mode),
                 n_vertices: b.projected_vertices.len() as u32,
                 n_triangles: b.edges.len() as u32,
                 // (only the arrays and the counts are read at hand-over; the header travels with rxr_upload_frame)
@@ -537,7 +551,9 @@ fn batch3d_views(items3: &[Item3D], repacks: &[Repack], src3: &[rxr_source],
                 clipped_uvs: b.clipped_uvs.as_ptr() as *const f32,
                 clipped_normals: if b.normals.is_empty() { std::ptr::null() } else { r.normals.as_ptr() }, // :1083
                 clipped_indices: r.indices.as_ptr(),
-                edges: r.edges.as_ptr(),
+                edges: std::ptr::null(),
+                edge_visible: r.edge_visible.as_ptr(),
+                cull_mode: cull_of(&b.cull_mode),
                 n_vertices: b.projected_vertices.len() as u32,
                 n_triangles: b.edges.len() as u32,
                 has_bounding_box: b.bounding_box.is_some() as u32,
@@ -657,6 +673,7 @@ fn device_frame(this: &Rasterizer, scene: &Scene, pixels: &mut [u8], width: usiz
                     }
                     repacks.push(Repack {
                         indices: b.indices.iter().flat_map(|&(a, bb, c)| [a as u32, bb as u32, c as u32]).collect(),
+                        edge_visible: vec![],
                         edges: vec![],
                         normals: b.normals.iter().flat_map(|n| [n.x, n.y, n.z]).collect(),
                     });
@@ -696,7 +713,8 @@ fn device_frame(this: &Rasterizer, scene: &Scene, pixels: &mut [u8], width: usiz
                 .iter()
                 .map(|i| Repack {
                     indices: i.batch.clipped_indices.iter().flat_map(|&(a, bb, c)| [a as u32, bb as u32, c as u32]).collect(), // usize -> u32
-                    edges: i.batch.edges.iter().map(edges_of).collect(),
+                    edge_visible: i.batch.edges.iter().map(|e| e.visible as u32).collect(),
+                    edges: vec![],
                     normals: i.batch.clipped_normals.iter().flat_map(|n| [n.x, n.y, n.z]).collect(),
                 })
                 .collect();
@@ -764,6 +782,7 @@ fn device_frame(this: &Rasterizer, scene: &Scene, pixels: &mut [u8], width: usiz
             .iter()
             .map(|i| Repack {
                 indices: i.batch.indices.iter().flat_map(|&(a, bb, c)| [a as u32, bb as u32, c as u32]).collect(),
+                edge_visible: vec![],
                 edges: i.batch.edges.iter().map(edges_of).collect(),
                 normals: vec![],
             })

@@ -236,6 +236,26 @@ int main(void) {
         if (rxr_set_meshes(ctx, NULL, 0) != RXR_OK) ++failures;
 
         {
+            /* ABI 5: 3D batches without Edges records (edges == NULL, edge_visible + cull_mode instead).  Malformed variants: neither array,
+             * a cull mode that does not exist, and the two forms mixed in one frame */
+            make_valid();
+            static uint32_t vis_words[64];
+            for (int i = 0; i < 64; ++i) vis_words[i] = 1u;
+            rxr_batch3d two3[2];
+            rxr_frame f = base;
+            two3[0] = base.batches3d[0];
+            two3[1] = base.batches3d[0];
+            f.batches3d = two3;
+            f.n_batches3d = 2;
+            two3[0].edges = NULL; two3[0].edge_visible = NULL;
+            two3[1].edges = NULL; two3[1].edge_visible = NULL;
+            expect_error(ctx, "batch3d: neither edges nor edge_visible", &f);
+            two3[0].edge_visible = vis_words; two3[1].edge_visible = vis_words; two3[0].cull_mode = 7;
+            expect_error(ctx, "batch3d: edge_visible with a bad cull mode", &f);
+            two3[0].cull_mode = RXR_CULL_OFF; two3[1].edges = base.batches3d[0].edges;
+            expect_error(ctx, "batch3d: with and without Edges records", &f);
+        }
+        {
             /* rxr_set_meshes2d: a registration that fails half way (the SECOND mesh has an index out of range) must leave an EMPTY
              * registration, not the first mesh of the failed call beside the device data of the call before (round-3 advisor finding).  A
              * frame that then asks for the registered 2D meshes has no 2D primitives: it renders its 3D part, or is refused -- never faults. */

@@ -326,6 +326,42 @@ def test_row_bands_equal_full_frame(product):
     assert_exact(out, full, "row bands vs full frame")
 
 
+@pytest.mark.parametrize("cull", ["off", "back", "front"])
+def test_edges_built_on_the_device_equal_the_hosts(oracle, product, cull):
+    """ABI 5: host-projected 3D batches cross the boundary without their Edges records (rxr_batch3d.edges == NULL: one `visible` word per
+    triangle and the batch's cull mode instead of 40 bytes per triangle); the device builds the records from the projected vertices with
+    the operations of Edges::new behind the winding swap (src/edge.rs:12-24, src/batch/batch3d.rs:706-746).  The frame must equal the one
+    rendered from the host's records, bit for bit, and the oracle's -- for every cull mode (front- and back-facing triangles, swapped and
+    not), for clipped geometry (appended fan triangles) and for a large streamed scene."""
+    mode = {"off": B.CULL_OFF, "back": B.CULL_BACK, "front": B.CULL_FRONT}[cull]
+
+    def build(api, which):
+        if which == "cube":       # the camera inside the near range of a big cube: triangles cross the near plane (clipped fans)
+            box = api.Batch3D.from_box(-2.0, -2.0, -2.0, 4.0, 4.0, 4.0).cull_mode(mode).with_computed_normals().source(B.PixelSource.StaticTileIndex(0))
+            scene = api.Scene.from_static([], [box])
+            assets = api.Assets.default().textures([B.Tile.from_texture(scenes.logo_texture(1, 64))])
+            cam = api.D3OrbitCamera.new()
+            cam.set_parameter_f32("distance", 2.6)
+            return scenes._result(api, scene, assets, lambda: api.Rasterizer.setup(None, *cam.matrices(640.0, 400.0)).ambient((1.0, 1.0, 1.0, 1.0)), 640, 400, 40, "cube-near")
+        if which == "teapot":
+            cfg = scenes.teapot_scene(api, width=640, height=360, logo_size=64)
+            return cfg
+        return scenes.box_grid_scene(api, n=64, width=1280, height=720)   # 49 152 triangles in 64 batches: the streamed hand-over
+
+    for which in (["cube", "teapot", "grid"] if cull == "off" else ["cube"]):
+        ref = scenes.render(build(oracle, which))
+        assert product.lib.rxh_get_device_edges() == 1, "the default is the hand-over without Edges records"
+        got = scenes.render(build(product, which)).copy()
+        product.lib.rxh_set_device_edges(0)
+        try:
+            with_records = scenes.render(build(product, which)).copy()
+        finally:
+            product.lib.rxh_set_device_edges(1)
+        assert_exact(got, with_records, f"{which}, cull {cull}: Edges built on the device vs the host's records")
+        assert_exact(got, ref, f"{which}, cull {cull}: vs oracle")
+        assert (got[..., :3].max(axis=2) > 0).mean() > 0.02
+
+
 def _sparse_scene(api, kind):
     """scenes whose content leaves whole tile rows of the frame empty (rxr_ctx::content_row0 / 1)"""
     if kind == "grid":          # a distant box grid: a band in the middle of the frame, binned, row mode

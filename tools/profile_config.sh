@@ -7,7 +7,7 @@ TAG=$1; CFG=$2; shift 2
 export TMPDIR=/tmp
 OUT=gpurun_out/$TAG
 mkdir -p "$OUT"
-ARGS="tools/run_configs.py --configs $CFG --oracle none --frames 8 $*"
+ARGS="tools/run_configs.py --configs $CFG --oracle none --frames 8 --no-e2e $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -- python3 $ARGS > "$OUT/kt.log" 2>&1
 echo "kt done"
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_INSTS_LDS \

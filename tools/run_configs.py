@@ -61,6 +61,9 @@ def main():
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--jit", choices=["0", "1"], default=None,
                     help="RXR_SHADER_JIT for this run: 1 = program sets compiled at run time (the caller waits), 0 = interpreted; default: the environment")
+    ap.add_argument("--no-e2e", action="store_true",
+                    help="profiling runs: skip the end-to-end leg (its pipelined download rasters the frame in four bands: four shorter raster launches "
+                         "per call would mix into the per-kernel averages of the device-resident loop)")
     ap.add_argument("--device-projection", action="store_true",
                     help="N1: clip_and_project + Edges on the GPU (geometry registered once, matrices per frame)")
     args = ap.parse_args()
@@ -97,10 +100,12 @@ def main():
         W, H = cfg.width, cfg.height
         out = np.zeros((H, W, 4), np.uint8)
         # end-to-end: Rasterizer::setup(..).rasterize(..) = host projection + upload + kernels + download
+        if args.no_e2e:
+            os.environ["RXR_NO_DOWNLOAD_PIPELINE"] = "1"  # (the warm-up calls below render the frame in one launch as well)
         for _ in range(3):  # warm-up (uploads the textures; the page-locked pools of the host mirror and the library reach their size)
             scenes.render(cfg, out.reshape(-1))
         e2e = []
-        for _ in range(max(5, args.frames // 3)):
+        for _ in range(0 if args.no_e2e else max(5, args.frames // 3)):
             t0 = time.perf_counter()
             scenes.render(cfg, out.reshape(-1))
             e2e.append(time.perf_counter() - t0)
@@ -142,7 +147,8 @@ def main():
                    setup_kernels_us=round(float(np.median(su[: n.value])), 1), raster_kernel_us=round(float(np.median(ru[: n.value])), 1),
                    frame_ms_device_resident=round(t_loop * 1e3, 4), mpix_per_s_device_resident=round(W * H / t_loop / 1e6, 1),
                    frame_ms_device_resident_no_events=round(t_loop_untimed * 1e3, 4),
-                   frame_ms_end_to_end=round(float(np.median(e2e)) * 1e3, 3), mpix_per_s_end_to_end=round(W * H / float(np.median(e2e)) / 1e6, 1))
+                   frame_ms_end_to_end=round(float(np.median(e2e)) * 1e3, 3) if e2e else None,
+                   mpix_per_s_end_to_end=round(W * H / float(np.median(e2e)) / 1e6, 1) if e2e else None)
         if name in args.oracle.split(","):
             from tests.oracle_api import load_oracle
 
