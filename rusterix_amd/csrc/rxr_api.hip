@@ -2105,6 +2105,16 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
     return RXR_OK;
 }
 
+// the rows [c0, c1) of a contiguous band spec that the resident frame can draw in, rounded out to tile rows (false: not known -- all of them)
+static bool content_band(const rxr_ctx *ctx, const RenderSpec &spec, uint32_t &c0, uint32_t &c1) {
+    c0 = spec.row0;
+    c1 = spec.row1;
+    if (!(ctx->content_known && spec.tile_stride == 1u && !spec.compact && spec.row0 < spec.row1)) return false;
+    c0 = std::min(std::max(ctx->content_row0 / RXR_TILE_H * RXR_TILE_H, spec.row0), spec.row1);
+    c1 = std::max(std::min((ctx->content_row1 + RXR_TILE_H - 1u) / RXR_TILE_H * RXR_TILE_H, spec.row1), c0);
+    return true;
+}
+
 // n_raster_bands > 1 (contiguous band specs only): ONE pre-pass over the spec's rows, then the raster kernel in that many launches over
 // consecutive groups of tile rows, an event of band_events recorded behind each -- the caller ships finished rows while the next ones
 // render (rxr_render_download).  The bins are those of the one pre-pass (RasterParams.bin_row0); every bin is still handed back zeroed
@@ -2148,9 +2158,8 @@ static int render_impl(rxr_ctx *ctx, const RenderSpec &spec, void *dev_pixels, h
     // are empty) 0.575 -> 0.531 ms for the band alone (tools/band_probe.py, profiles/r04).  Contiguous bands only (not the stripe
     // launches of a multi-GPU share).
     uint32_t fill_a0 = 0, fill_a1 = 0, fill_b0 = 0, fill_b1 = 0;  // rows [a0, a1) above and [b0, b1) below the content
-    if (ctx->content_known && spec.tile_stride == 1u && !spec.compact && spec.row0 < spec.row1) {
-        const uint32_t c0 = std::min(std::max(ctx->content_row0 / RXR_TILE_H * RXR_TILE_H, spec.row0), spec.row1);
-        const uint32_t c1 = std::max(std::min((ctx->content_row1 + RXR_TILE_H - 1u) / RXR_TILE_H * RXR_TILE_H, spec.row1), c0);
+    uint32_t c0 = 0, c1 = 0;
+    if (content_band(ctx, spec, c0, c1)) {
         fill_a0 = spec.row0; fill_a1 = c0; fill_b0 = c1; fill_b1 = spec.row1;
         P.row0 = c0;
         P.row1 = c1;
@@ -2615,11 +2624,36 @@ int rxr_render_download(rxr_ctx *ctx, uint8_t *pixels) {
     const uint32_t rerenders_before = ctx->rerenders;
     rc = render_impl(ctx, spec, ctx->d_fb.p, ctx->stream, false, n_bands, ctx->ev_band, row_of);
     if (rc != RXR_OK) return rc;
+    // Rows outside the frame's content are the miss colour on the device AND need not cross PCIe: the caller's rows are written here,
+    // by the host, while the device renders and the content rows travel (the 8K frame of the box grid: 40 of 133 MB that are not
+    // downloaded; the link is what bounds this call).
+    uint32_t c0 = 0, c1 = H;
+    const bool clipped = content_band(ctx, spec, c0, c1);
     for (uint32_t k = 0; k < n_bands; ++k) {
-        if (row_of[k + 1] <= row_of[k]) continue;
-        const size_t off = (size_t)row_of[k] * P.width * 4, bytes = (size_t)(row_of[k + 1] - row_of[k]) * P.width * 4;
+        const uint32_t a = std::max(row_of[k], c0), b = std::min(row_of[k + 1], c1);
         HIPCHK(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev_band[k], 0));
+        if (b <= a) continue;
+        const size_t off = (size_t)a * P.width * 4, bytes = (size_t)(b - a) * P.width * 4;
         HIPCHK(ctx, hipMemcpyAsync(pixels + off, (uint8_t *)ctx->d_fb.p + off, bytes, hipMemcpyDeviceToHost, ctx->copy_stream));
+    }
+    if (clipped) {
+        auto fill_rows = [&](uint32_t r0, uint32_t r1) {  // [0, 0, 0, 255] per pixel (:420-461), the caller's buffer may be unaligned: bytes
+            if (r1 <= r0) return;
+            const size_t n = (size_t)(r1 - r0) * P.width;
+            uint8_t *p = pixels + (size_t)r0 * P.width * 4;
+            const size_t n_threads = n >= (4u << 20) ? 4u : 1u;  // (a few helpers for tens of megabytes; the calling thread otherwise waits anyway)
+            std::vector<std::thread> helpers;
+            auto part = [p](size_t i0, size_t i1) {
+                if (((uintptr_t)p & 3u) == 0u) std::fill((uint32_t *)p + i0, (uint32_t *)p + i1, 0xFF000000u);
+                else
+                    for (size_t i = i0; i < i1; ++i) { p[4 * i] = 0; p[4 * i + 1] = 0; p[4 * i + 2] = 0; p[4 * i + 3] = 255; }
+            };
+            for (size_t t = 1; t < n_threads; ++t) helpers.emplace_back(part, n * t / n_threads, n * (t + 1) / n_threads);
+            part(0, n / n_threads);
+            for (std::thread &th : helpers) th.join();
+        };
+        fill_rows(0, c0);
+        fill_rows(c1, H);
     }
     HIPCHK(ctx, hipStreamSynchronize(ctx->copy_stream));
     rc = rxr_synchronize(ctx);  // (program faults and list overflows are reported / repaired here)
