@@ -200,7 +200,9 @@ typedef struct rxr_batch2d {
     const float *projected_vertices;  /* [n_vertices][2] */
     const float *uvs;                 /* [n_vertices][2] */
     const uint32_t *indices;          /* [n_triangles][3]; for Lines only .0/.1 are used (:902)     */
-    const rxr_edges *edges;           /* [n_triangles]   */
+    const rxr_edges *edges;           /* [n_triangles], or NULL (ABI 5): Edges::new([v0,v1,v2],[v1,v2,v0], true) of the projected
+                                         vertices, as Batch2D::project builds them (src/batch/batch2d.rs:413-424), is then built by
+                                         the library                                                */
     uint32_t n_vertices, n_triangles;
     uint32_t has_bounding_box;
     float bounding_box[4];

@@ -649,7 +649,7 @@ rxr_batch2d view2d(const Batch2D &b, int chunk, const SequenceSlots &slots) {
     o.projected_vertices = b.projected_vertices.data();
     o.uvs = b.uvs.data();
     o.indices = b.indices.data();
-    o.edges = b.edges.data();
+    o.edges = t_frame_edgeless ? nullptr : b.edges.data();  // (ABI 5: the library builds Batch2D::project's records itself)
     o.n_vertices = (uint32_t)(b.projected_vertices.size() / 2);
     o.n_triangles = (uint32_t)(b.indices.size() / 3);
     o.has_bounding_box = b.has_bounding_box ? 1u : 0u;

@@ -1171,7 +1171,7 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
     size_t n_t2 = 0, n_l2 = 0, n_items = 0;
     for (uint32_t i = 0; i < f->n_batches2d; ++i) {
         const rxr_batch2d &b = f->batches2d[i];
-        if (b.n_triangles && (!b.indices || (b.mode == RXR_MODE_TRIANGLES && !b.edges))) return fail(ctx, RXR_ERR_INVALID, "batch2d: NULL indices/edges");
+        if (b.n_triangles && !b.indices) return fail(ctx, RXR_ERR_INVALID, "batch2d: NULL indices");  // (edges may be NULL since ABI 5: built below)
         if (b.n_vertices && (!b.projected_vertices || !b.uvs)) return fail(ctx, RXR_ERR_INVALID, "batch2d: NULL vertex arrays");
         if (b.chunk >= (int32_t)f->n_chunks) return fail(ctx, RXR_ERR_INVALID, "batch2d: chunk index out of range");
         if (b.mode > RXR_MODE_LINE_LOOP) return fail(ctx, RXR_ERR_INVALID, "batch2d: bad mode");
@@ -1724,7 +1724,20 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
         if (b.mode == RXR_MODE_TRIANGLES) {
             for (uint32_t t = 0; t < b.n_triangles; ++t) {
                 const uint32_t *ix = b.indices + 3 * (size_t)t;
-                const rxr_edges &e = b.edges[t];
+                rxr_edges built;
+                if (!b.edges) {
+                    // ABI 5: Batch2D::project's Edges::new([v0,v1,v2], [v1,v2,v0], true) (src/batch/batch2d.rs:413-424, src/edge.rs:12-24)
+                    // from the projected vertices, here on the host (this file is built -ffp-contract=off: the same floats)
+                    const float *v[3] = {b.projected_vertices + 2 * (size_t)ix[0], b.projected_vertices + 2 * (size_t)ix[1], b.projected_vertices + 2 * (size_t)ix[2]};
+                    for (int k = 0; k < 3; ++k) {
+                        const float *p = v[k], *q = v[(k + 1) % 3];
+                        built.a[k] = q[1] - p[1];
+                        built.b[k] = p[0] - q[0];
+                        built.c[k] = q[0] * p[1] - q[1] * p[0];
+                    }
+                    built.visible = 1u;
+                }
+                const rxr_edges &e = b.edges ? b.edges[t] : built;
                 Prim2D T{};
                 memcpy(T.ea, e.a, 12);
                 memcpy(T.eb, e.b, 12);

@@ -360,24 +360,19 @@ fn occluder_of(e: &(BBox, f32)) -> rxr_occluder {
     rxr_occluder { min: e.0.min.into_array(), max: e.0.max.into_array(), occlusion: e.1 }
 }
 
-fn edges_of(e: &Edges) -> rxr_edges {
-    let (a, b, c) = e.coefficients(); // accessor added by the patch in INTEGRATION.md (Edges is repr(Rust) with private fields)
-    rxr_edges { a, b, c, visible: e.visible as u32 }
-}
-
 fn texture_of(t: &Texture) -> rxr_texture {
     rxr_texture { rgba: t.data.as_ptr(), width: t.width as u32, height: t.height as u32 }
 }
 
-/// owned repacks of what cannot be passed by pointer: `usize` index triples, private `Edges`, `Vec3` normals
+/// owned repacks of what cannot be passed by pointer: `usize` index triples, the `visible` flags of the `Edges`, `Vec3` normals
 #[derive(Default)]
 struct Repack {
     indices: Vec<u32>,
     /// 3D batches cross the ABI WITHOUT their Edges records (ABI 5: `edges` NULL): one word per triangle says `visible` (a public field),
     /// the device rebuilds a / b / c from the projected vertices under `cull_mode` -- 4 instead of 40 bytes per triangle over PCIe, and
-    /// no use of the `Edges::coefficients()` accessor for 3D batches
+    /// nothing private of `Edges` is read (rounds 1-3 needed an accessor patched into the crate; 2D batches: the library builds
+    /// `Edges::new([v0,v1,v2],[v1,v2,v0], true)` itself when `rxr_batch2d.edges` is NULL)
     edge_visible: Vec<u32>,
-    edges: Vec<rxr_edges>, // (2D batches)
     normals: Vec<f32>,
 }
 
@@ -674,7 +669,6 @@ fn device_frame(this: &Rasterizer, scene: &Scene, pixels: &mut [u8], width: usiz
                     repacks.push(Repack {
                         indices: b.indices.iter().flat_map(|&(a, bb, c)| [a as u32, bb as u32, c as u32]).collect(),
                         edge_visible: vec![],
-                        edges: vec![],
                         normals: b.normals.iter().flat_map(|n| [n.x, n.y, n.z]).collect(),
                     });
                 }
@@ -714,7 +708,6 @@ fn device_frame(this: &Rasterizer, scene: &Scene, pixels: &mut [u8], width: usiz
                 .map(|i| Repack {
                     indices: i.batch.clipped_indices.iter().flat_map(|&(a, bb, c)| [a as u32, bb as u32, c as u32]).collect(), // usize -> u32
                     edge_visible: i.batch.edges.iter().map(|e| e.visible as u32).collect(),
-                    edges: vec![],
                     normals: i.batch.clipped_normals.iter().flat_map(|n| [n.x, n.y, n.z]).collect(),
                 })
                 .collect();
@@ -783,7 +776,6 @@ fn device_frame(this: &Rasterizer, scene: &Scene, pixels: &mut [u8], width: usiz
             .map(|i| Repack {
                 indices: i.batch.indices.iter().flat_map(|&(a, bb, c)| [a as u32, bb as u32, c as u32]).collect(),
                 edge_visible: vec![],
-                edges: i.batch.edges.iter().map(edges_of).collect(),
                 normals: vec![],
             })
             .collect();
@@ -798,7 +790,7 @@ fn device_frame(this: &Rasterizer, scene: &Scene, pixels: &mut [u8], width: usiz
                     projected_vertices: b.projected_vertices.as_ptr() as *const f32,
                     uvs: b.uvs.as_ptr() as *const f32,
                     indices: r.indices.as_ptr(),
-                    edges: r.edges.as_ptr(),
+                    edges: std::ptr::null(), // (ABI 5: Edges::new of the projected vertices is built by the library)
                     n_vertices: b.projected_vertices.len() as u32,
                     n_triangles: b.indices.len() as u32,
                     has_bounding_box: b.bounding_box.is_some() as u32,

@@ -153,7 +153,31 @@ int main(void) {
     BATCH3((m3.source.kind = RXR_SOURCE_DYNAMIC_TILE, m3.source.index = 0), "3D batch: dynamic tile without dynamic tiles");
     BATCH3(m3.source.kind = RXR_HOST_SOURCE_ENTITY_TILE, "3D batch: a host-side-only source kind");
     BATCH2(m2.indices = NULL, "2D batch: triangles without indices");
-    BATCH2(m2.edges = NULL, "2D batch: triangles without edges");
+    {
+        /* ABI 5: a 2D batch WITHOUT its Edges records is valid -- the library builds Edges::new([v0,v1,v2],[v1,v2,v0], true) of the projected
+         * vertices itself (src/batch/batch2d.rs:413-424).  The frame must equal the one rendered from the same records built here. */
+        static uint8_t with_null[W * H * 4], with_built[W * H * 4];
+        rxr_edges built[2];
+        static uint32_t wound[6] = {0, 2, 1, 0, 3, 2};   /* (the winding whose edge functions are >= 0 inside: edge.rs:28-36) */
+        for (int t = 0; t < 2; ++t) {
+            for (int k = 0; k < 3; ++k) {
+                const float *p = verts2[wound[3 * t + k]], *q = verts2[wound[3 * t + (k + 1) % 3]];
+                built[t].a[k] = q[1] - p[1];
+                built[t].b[k] = p[0] - q[0];
+                built[t].c[k] = q[0] * p[1] - q[1] * p[0];
+            }
+            built[t].visible = 1u;
+        }
+        make_valid(); f = base; m2 = b2; m2.edges = NULL; m2.indices = wound; f.batches2d = &m2;
+        const int r0 = rxr_rasterize(ctx, &f, with_null);
+        m2.edges = built;
+        const int r1 = rxr_rasterize(ctx, &f, with_built);
+        size_t drawn = 0;
+        for (size_t i = 0; i < sizeof with_null; i += 4) drawn += with_null[i + 1] == 220;   /* (the 2D batch's green) */
+        const int same = r0 == RXR_OK && r1 == RXR_OK && memcmp(with_null, with_built, sizeof with_null) == 0;
+        printf("%-44s rc=%d,%d %s, %zu pixels of the batch\n", "2D batch without Edges records (ABI 5)", r0, r1, same ? "identical" : "DIFFERENT", drawn);
+        if (!same || drawn == 0) ++failures;
+    }
     BATCH2(m2.projected_vertices = NULL, "2D batch: vertices without positions");
     BATCH2(m2.uvs = NULL, "2D batch: vertices without uvs");
     BATCH2(m2.indices = bad_idx2, "2D batch: vertex index out of range");
