@@ -2417,6 +2417,9 @@ __device__ __forceinline__ uint32_t z_order_bits(float z) {
 #ifndef RXR_ROWS_PREFETCH_IDS
 #define RXR_ROWS_PREFETCH_IDS 0
 #endif
+#ifndef RXR_ROWS_DIAG
+#define RXR_ROWS_DIAG 0
+#endif
 #ifndef RXR_ROWS_UNROLL_PX
 #define RXR_ROWS_UNROLL_PX 0  // (A-B knob: the four pixel slots of an item as straight-line code, five copies of the drain)
 #endif
@@ -2552,6 +2555,9 @@ __device__ RXR_ROWS_INLINE bool rows_round(const RasterParams &P, Stage &st, Row
     uint32_t head = 0, fill = 0;  // wave-uniform
     // (c) entries [head, head + m) of this wave's ring on lanes 0 .. m-1: barycentric_weights_3d, the depth and the merge, as visit()
     auto drain = [&](uint32_t m) {
+#if RXR_ROWS_DIAG == 2
+        return;  // (diagnostic build: where do the LDS bank conflicts come from?  wrong frames)
+#endif
         if (lane < m) {
             const uint32_t e = ring[(head + lane) & (RXR_ROWS_RING - 1u)];
             // words 8 .. 23 of the staged record as four 16-byte reads (ds_read_b128: 64 banks, 16 lanes per LDS cycle -- the lanes of a drain
@@ -2564,7 +2570,12 @@ __device__ RXR_ROWS_INLINE bool rows_round(const RasterParams &P, Stage &st, Row
             const float fx = (float)((e >> 8) & 0xFFu) + ((float)tile_x0 + 0.5f), fy = (float)((e >> 16) & 0xFFu) + ((float)tile_y0px + 0.5f);  // (exact sums: the item's own fx, fy)
             float alpha, beta, z;
             bary_depth<true>(q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, q4.z, fx, fy, alpha, beta, z, q5.x, q5.y, q5.z);
-            if (z < 1.0f) {  // never closer than the cleared buffer; also NaN
+#if RXR_ROWS_DIAG == 1
+            if (z == 12345.678f)  // (diagnostic build: the drain without its z-buffer traffic -- never true, but the arithmetic above stays)
+#else
+            if (z < 1.0f)  // never closer than the cleared buffer; also NaN
+#endif
+            {
                 const unsigned long long key = ((unsigned long long)z_order_bits(z + 0.0f) << 32) | __float_as_uint(q5.w);  // -0 -> +0: they compare equal
                 unsigned long long *const cell = &rl.key[TH == 16 ? (e >> 24) : ((e >> 16) & 0xFFu) * RXR_TILE_W + ((e >> 8) & 0xFFu)];
                 // (cells only ever decrease: a stale value is merely conservative.  A relaxed workgroup-scope atomic load, so that the
