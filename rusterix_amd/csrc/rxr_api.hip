@@ -23,6 +23,12 @@
 #include "rxr_ctx.h"
 #include "rxr_parallel.h"
 
+// sparse frames (rxr_ctx::content_row0 / 1, row spans): the empty tiles a clamp must save before its fill launches pay (RXR_CONTENT_MIN_TILES
+// overrides it -- the tests use small frames)
+static size_t content_min_tiles() {
+    const char *e = getenv("RXR_CONTENT_MIN_TILES");
+    return e ? (size_t)atol(e) : 8192u;
+}
 thread_local LaunchTimes *rxr_launch_times = nullptr;  // rxr_launch.h: the profiling slot of the render this thread is queueing
 extern "C" void rxr_launch_proj_static(const ProjectParams *P, hipStream_t s);
 extern "C" void rxr_launch_project(const ProjectParams *P, hipStream_t s);
@@ -38,6 +44,7 @@ extern "C" void rxr_launch_raster(const RasterParams *P, hipStream_t s);
 extern "C" void rxr_launch_fill_words(uint32_t *dst, uint64_t n_words, uint32_t value, hipStream_t s);
 extern "C" void rxr_launch_fill_outside_spans(const RasterParams *P, hipStream_t s);
 extern "C" void rxr_launch_raster_grid(const RasterParams *P, uint32_t grid_x, hipStream_t s);
+extern "C" int rxr_raster_takes_spans(const RasterParams *P);
 extern "C" void rxr_launch_selftest_math(uint64_t seed, uint32_t blocks, uint32_t iters, unsigned long long *mismatch, hipStream_t s);
 
 namespace {
@@ -2105,7 +2112,7 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
             ctx->h_row_spans[r] = make_uint2(any ? span_lo[r] : 0u, any ? span_hi[r] : 0u);
             if (r >= r0 && r < r1 && any) inside += span_hi[r] - span_lo[r];
         }
-        if (inside * 100u <= (size_t)(r1 - r0) * n_tile_cols * 85u) {
+        if (inside * 100u <= (size_t)(r1 - r0) * n_tile_cols * 85u && (size_t)(r1 - r0) * n_tile_cols - inside >= content_min_tiles()) {
             int rc2;
             if ((rc2 = ensure(ctx, ctx->d_row_spans, RXR_MAX_TILE_ROWS * sizeof(uint2))) != RXR_OK) return rc2;
             HIPCHK(ctx, hipMemcpyAsync(ctx->d_row_spans.p, ctx->h_row_spans, n_tile_rows * sizeof(uint2), hipMemcpyHostToDevice, ctx->stream));
@@ -2125,6 +2132,14 @@ static bool content_band(const rxr_ctx *ctx, const RenderSpec &spec, uint32_t &c
     if (!(ctx->content_known && spec.tile_stride == 1u && !spec.compact && spec.row0 < spec.row1)) return false;
     c0 = std::min(std::max(ctx->content_row0 / RXR_TILE_H * RXR_TILE_H, spec.row0), spec.row1);
     c1 = std::max(std::min((ctx->content_row1 + RXR_TILE_H - 1u) / RXR_TILE_H * RXR_TILE_H, spec.row1), c0);
+    // (an empty tile costs the raster launch about half a nanosecond of the chip's time, a fill launch two to three microseconds: the teapot
+    // at 1080p lost 5 us of set-up to save 3 of raster.  Fewer than content_min_tiles() empty tiles: the whole band is rastered)
+    const size_t saved_tiles = (size_t)((c0 - spec.row0) + (spec.row1 - c1)) / RXR_TILE_H * ctx->P.tiles_x;
+    if (saved_tiles < content_min_tiles()) {
+        c0 = spec.row0;
+        c1 = spec.row1;
+        return false;
+    }
     return true;
 }
 
@@ -2180,7 +2195,7 @@ static int render_impl(rxr_ctx *ctx, const RenderSpec &spec, void *dev_pixels, h
         P.tiles_y = c1 > c0 ? (c1 + RXR_TILE_H - 1u) / RXR_TILE_H - P.tile_y0 : 0u;
     }
     P.row_spans = nullptr;
-    const bool use_spans = ctx->spans_active && fill_a0 < fill_b1 /* (the clamp above applied) */ && P.tiles_y;
+    bool use_spans = ctx->spans_active && fill_a0 < fill_b1 /* (the clamp above applied) */ && P.tiles_y;
     auto widest_span = [&](uint32_t first_row, uint32_t n_rows) {
         uint32_t w = 1u;
         for (uint32_t r = first_row; r < first_row + n_rows && r < RXR_MAX_TILE_ROWS; ++r) w = std::max(w, ctx->h_row_spans[r].y - ctx->h_row_spans[r].x);
@@ -2208,10 +2223,6 @@ static int render_impl(rxr_ctx *ctx, const RenderSpec &spec, void *dev_pixels, h
         const uint32_t a = part ? fill_b0 : fill_a0, b = part ? fill_b1 : fill_a1;
         if (a < b) rxr_launch_fill_words(P.out + (size_t)((int64_t)a - P.out_base_row) * P.out_row_stride, (uint64_t)(b - a) * P.out_row_stride, 0xFF000000u, s);
     }
-    if (use_spans) {  // ... and, inside the content rows, the pixels to the left and right of each tile row's span
-        P.row_spans = (const uint2 *)ctx->d_row_spans.p;
-        rxr_launch_fill_outside_spans(&P, s);
-    }
     // small scenes: one staging round of k_raster holds every triangle -> no set-up / binning launches at all
     const bool d3 = P.tiles_y && (P.flags & RXR_FLAG_D3_ACTIVE);
     P.fused_small = (d3 && P.n_tris3d <= RXR_STAGE_TRIS) ? ctx->small_mode : 0u;
@@ -2219,6 +2230,11 @@ static int render_impl(rxr_ctx *ctx, const RenderSpec &spec, void *dev_pixels, h
     if (d3 && P.fused_small) {
         if (ctx->frame_uses_meshes) rxr_launch_project(&ctx->PP, s);
         if (P.fused_small == 2u) rxr_launch_setup(&P, s);  // records only; no counters, bins or lists are touched
+    }
+    use_spans = use_spans && rxr_raster_takes_spans(&P) != 0;  // (the kernel this launch gets must be one that looks the table up)
+    if (use_spans) {  // inside the content rows, the pixels to the left and right of each tile row's span
+        P.row_spans = (const uint2 *)ctx->d_row_spans.p;
+        rxr_launch_fill_outside_spans(&P, s);
     }
     const bool prepass = d3 && !P.fused_small;
     if (prepass && ctx->scratch_dirty) {

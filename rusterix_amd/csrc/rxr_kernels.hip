@@ -3240,7 +3240,10 @@ struct RowStore {
 template <>
 struct RowStore<false> {};
 
-template <bool FUSED, int X, bool ROWS = false, bool RL = false>
+// SPANS: the kernel looks RasterParams.row_spans up (sparse frames).  The two common level-0 kernels of binned scenes exist in both forms
+// (k_raster_rows[_rl] / ..._sp): the look-up in front of every tile cost the dense bench frame 0.6 % when every kernel carried it
+// (profiles/r04/row_spans_lookup_cost_bench.txt); the small-scene kernels never take spans, the rarer levels always check.
+template <bool FUSED, int X, bool ROWS = false, bool RL = false, bool SPANS = (X != 0)>
 __device__ __forceinline__ void raster_tile(const RasterParams &P) {
     __shared__ Stage stage;
     __shared__ uint32_t s_bin[4];
@@ -3269,10 +3272,12 @@ __device__ __forceinline__ void raster_tile(const RasterParams &P) {
     // (RXR_FLIP_TILE_ROWS: dispatch the launch's bottom tile rows first -- an A-B knob for frames whose expensive tiles are at the bottom)
     uint32_t tx = blockIdx.x;
     const uint32_t ty = RXR_FLIP_TILE_ROWS ? gridDim.y - 1u - blockIdx.y : blockIdx.y;
-    if (P.row_spans) {  // (uniform; sparse frames only: see RasterParams.row_spans)
-        const uint2 span = uniform_record(P.row_spans, P.tile_y0 + ty);
-        tx += span.x;
-        if (tx >= span.y) return;  // (the whole workgroup, in front of every barrier)
+    if constexpr (SPANS) {
+        if (P.row_spans) {  // (uniform; sparse frames only: see RasterParams.row_spans)
+            const uint2 span = uniform_record(P.row_spans, P.tile_y0 + ty);
+            tx += span.x;
+            if (tx >= span.y) return;  // (the whole workgroup, in front of every barrier)
+        }
     }
 #endif
     const uint32_t bin = (ty + P.bin_row0) * P.tiles_x + tx;
@@ -3650,6 +3655,9 @@ extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_ROWS_WAVES_PE
 extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_ROWS_WAVES_PER_SIMD) k_raster_rows(RasterParams P) { raster_tile<false, 0, true>(P); }
 #endif
 extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_ROWS_WAVES_PER_SIMD) k_raster_rows_rl(RasterParams) { raster_tile<false, 0, true, true>(kernarg_params_early()); }
+// ... and for sparse frames (RasterParams.row_spans)
+extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_ROWS_WAVES_PER_SIMD) k_raster_rows_sp(RasterParams) { raster_tile<false, 0, true, false, true>(kernarg_params_early()); }
+extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_ROWS_WAVES_PER_SIMD) k_raster_rows_rl_sp(RasterParams) { raster_tile<false, 0, true, true, true>(kernarg_params_early()); }
 // two tiles per workgroup (raster_tile_pair): binned scenes without an opacity pass, launches whose tile rows are adjacent
 #ifndef RXR_PAIR_WAVES_PER_SIMD
 #define RXR_PAIR_WAVES_PER_SIMD 8
@@ -3782,6 +3790,19 @@ extern "C" void rxr_launch_fill_outside_spans(const RasterParams *P, hipStream_t
     if (!P->row_spans || !P->tiles_y) return;
     RXR_LAUNCH(k_fill_outside_spans, dim3(P->tiles_y, RXR_TILE_H), dim3(256), s, *P);
 }
+// does the kernel rxr_launch_raster_grid would pick for this launch look RasterParams.row_spans up?  (the host asks before it narrows
+// the grid and fills outside the spans: the choice below mirrors the launcher's)
+extern "C" int rxr_raster_takes_spans(const RasterParams *P) {
+#if RXR_XCD_GROUP
+    return 0;
+#endif
+    if (P->kernel_level >= 1u) return 1;
+    if (P->fused_small != 0u || !(P->flags & RXR_FLAG_D3_ACTIVE)) return 0;   // k_raster / k_raster_rl / k_raster_fused: small scenes
+    if (getenv("RXR_NO_ROWS")) return 0;
+    const char *pt = getenv("RXR_PAIR_TILES");
+    if (pt && pt[0] == '1' && !P->has_opacity && P->tile_stride == 1u) return 0;  // (the pair kernels do not)
+    return 1;
+}
 // grid_x: workgroups per tile row (0: tiles_x; with RasterParams.row_spans the widest span of the launch's rows)
 extern "C" void rxr_launch_raster_grid(const RasterParams *P, uint32_t grid_x, hipStream_t s);
 extern "C" void rxr_launch_raster(const RasterParams *P, hipStream_t s) { rxr_launch_raster_grid(P, 0u, s); }
@@ -3814,10 +3835,13 @@ extern "C" void rxr_launch_raster_grid(const RasterParams *P, uint32_t grid_x, h
         // latency chain that is twice as long.  RXR_PAIR_TILES=1 selects it.
         const char *pt = getenv("RXR_PAIR_TILES");  // (read per launch: the tests switch it)
         const bool pairs_on = pt && pt[0] == '1';
-        if (pairs_on && !P->has_opacity && P->tile_stride == 1u && !RXR_XCD_GROUP && !P->row_spans) {
+        if (pairs_on && !P->has_opacity && P->tile_stride == 1u && !RXR_XCD_GROUP) {
             const dim3 pairs(P->tiles_x, (P->tiles_y + 1u) / 2u);
             if (rl) RXR_LAUNCH(k_raster_pair_rl, pairs, dim3(RXR_TILE_THREADS), s, *P);
             else RXR_LAUNCH(k_raster_pair, pairs, dim3(RXR_TILE_THREADS), s, *P);
+        } else if (P->row_spans) {
+            if (rl) RXR_LAUNCH(k_raster_rows_rl_sp, tiles, dim3(RXR_TILE_THREADS), s, *P);
+            else RXR_LAUNCH(k_raster_rows_sp, tiles, dim3(RXR_TILE_THREADS), s, *P);
         } else if (rl) RXR_LAUNCH(k_raster_rows_rl, tiles, dim3(RXR_TILE_THREADS), s, *P);
         else RXR_LAUNCH(k_raster_rows, tiles, dim3(RXR_TILE_THREADS), s, *P);
     } else if (rl) RXR_LAUNCH(k_raster_rl, tiles, dim3(RXR_TILE_THREADS), s, *P);

@@ -390,6 +390,7 @@ def test_rows_without_content_are_filled_not_rastered(oracle, product, kind, mon
     clamp switched off (RXR_CONTENT_ROWS=0), and the frame assembled from row bands that cut through content and emptiness alike."""
     import ctypes as C
 
+    monkeypatch.setenv("RXR_CONTENT_MIN_TILES", "0")   # (the clamps only pay from 8192 empty tiles on: these frames are small)
     cfg = _sparse_scene(product, kind)
     got = scenes.render(cfg).copy()
     ref = scenes.render(_sparse_scene(oracle, kind))
