@@ -435,6 +435,45 @@ def test_rows_without_content_are_filled_not_rastered(oracle, product, kind, mon
     assert_exact(out, got, f"sparse frame ({kind}): row bands vs whole frame")
 
 
+def test_sparse_frame_into_caller_buffers_and_stripes(product, monkeypatch):
+    """the fills of a sparse frame address the CALLER's device buffer (rxr_render_rows_to: `dev_pixels` points at row0 of the band, not at
+    row 0 of the frame), and stripe launches (a multi-GPU share) are not clamped at all: bands into separate torch buffers and the
+    de-interleaved stripes of three ranks must both give the whole frame"""
+    import ctypes as C
+
+    import torch
+
+    monkeypatch.setenv("RXR_CONTENT_MIN_TILES", "0")
+    cfg = _sparse_scene(product, "grid")
+    whole = scenes.render(cfg).copy()
+    lib = product.lib
+    rxr = __import__("rusterix_amd").rxr_abi()
+    lib.rxh_context.restype = C.c_void_p
+    r = cfg.setup()
+    assert lib.rxh_rasterizer_upload(r._h, cfg.scene._h, cfg.width, cfg.height, cfg.tile_size, cfg.assets._h) == 0
+    ctx = C.c_void_p(lib.rxh_context())
+    W, H = cfg.width, cfg.height
+    st = torch.cuda.Stream()
+    got = np.zeros((H, W, 4), np.uint8)
+    for a, b in [(0, 100), (100, 213), (213, 300), (300, H)]:
+        buf = torch.full((b - a, W, 4), 9, dtype=torch.uint8, device="cuda")
+        assert rxr.rxr_render_rows_to(ctx, a, b, C.c_void_p(buf.data_ptr()), C.c_void_p(st.cuda_stream)) == 0
+        assert rxr.rxr_synchronize(ctx) == 0
+        got[a:b] = buf.cpu().numpy()
+    assert_exact(got, whole, "sparse frame: bands into caller buffers")
+    n_stripes = (H + 15) // 16
+    out = np.zeros((n_stripes * 16, W, 4), np.uint8)
+    for rank in range(3):
+        mine = list(range(rank, n_stripes, 3))
+        buf = torch.full((len(mine) * 16, W, 4), 9, dtype=torch.uint8, device="cuda")
+        assert rxr.rxr_render_stripes_to(ctx, rank, 3, C.c_void_p(buf.data_ptr()), C.c_void_p(st.cuda_stream)) == 0
+        assert rxr.rxr_synchronize(ctx) == 0
+        h = buf.cpu().numpy()
+        for j, sidx in enumerate(mine):
+            out[sidx * 16:(sidx + 1) * 16] = h[j * 16:(j + 1) * 16]
+    assert_exact(out[:H], whole, "sparse frame: stripes of three ranks")
+
+
 @pytest.mark.parametrize("world", [1, 2, 3, 8])
 def test_stripes_equal_full_frame(product, world):
     """The multi-GPU sharding primitive on ONE GPU: every rank's interleaved stripes rendered in turn
