@@ -736,13 +736,20 @@ def end_to_end(prod, host, rxr, cfg, W, H, world):
     res = {"e2e_ms": round(ms, 4), "e2e_mpix_s": round(W * H / ms / 1e3, 1), "e2e_frames": n,
            "e2e_what": "median wall time of Rasterizer::rasterize into pageable host pixels: host Scene::project + flatten + upload + kernels + download"
                        + ("" if world == 1 else f", multi-device context over {world} GPUs (each GPU downloads its own stripes)")}
-    ctx = host.rxh_context()
-    if rxr.rxr_pin_host_buffer(ctx, out.ctypes.data, out.nbytes) == 0:
+    # ... and into page-locked pixels from the library's allocator (rxr_alloc_pinned; nothing of the malloc heap is locked: rxr.h)
+    from rusterix_amd.binding import pinned_pixels
+
+    locked, free_locked = pinned_pixels(rxr, out.nbytes)
+    if locked is not None:
+        pageable = out
         try:
+            out = locked
             ms_p, _ = median_ms()
             res["e2e_pinned_ms"] = round(ms_p, 4)
         finally:
-            rxr.rxr_unpin_host_buffer(ctx, out.ctypes.data)
+            out = pageable
+            del locked
+            free_locked()
     return res
 
 

@@ -423,7 +423,11 @@ int rxr_member_count(const rxr_ctx *ctx);
 rxr_ctx *rxr_member(rxr_ctx *ctx, int index);
 
 /* optional: page-locks the caller's pixel buffer (hipHostRegister, visible to every device) so that the downloads of
- * rxr_rasterize / rxr_render_download are direct DMA.  Unpinned buffers work too (the runtime locks them on the fly per copy). */
+ * rxr_rasterize / rxr_render_download are direct DMA.  Unpinned buffers work too (the runtime locks them on the fly per copy).
+ * Lock WHOLE PAGES of a mapping the buffer has to itself (an allocation of its own from mmap / posix_memalign(4096, ..) / a Vec with
+ * page alignment; or take the memory from rxr_alloc_pinned and lock nothing): pages in the middle of the malloc heap are shared with
+ * other allocations and reused by them after the buffer is freed, and a copy into such a page shortly after the unlock has been seen to
+ * end in a GPU memory access fault on this runtime.  Unlock before the memory is freed. */
 int rxr_pin_host_buffer(rxr_ctx *ctx, void *ptr, size_t bytes);
 int rxr_unpin_host_buffer(rxr_ctx *ctx, void *ptr);
 /* last error text for this context (or for rxr_create when ctx == NULL) */

@@ -358,6 +358,19 @@ class Program:
         self.globals = int(globals)
 
 
+def pinned_pixels(rxr, nbytes):
+    """a uint8 array of `nbytes` in page-locked, device-readable memory from the library's own allocator (rxr_alloc_pinned: nothing of
+    the malloc heap is locked) and the function that frees it; (None, None) when there is no such memory"""
+    rxr.rxr_alloc_pinned.restype = C.c_void_p
+    rxr.rxr_alloc_pinned.argtypes = [C.c_size_t]
+    rxr.rxr_free_pinned.argtypes = [C.c_void_p]
+    p = rxr.rxr_alloc_pinned(nbytes)
+    if not p:
+        return None, None
+    arr = np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(p))
+    return arr, (lambda: rxr.rxr_free_pinned(C.c_void_p(p)))
+
+
 def make_api(lib: C.CDLL, prefix: str, name: str):
     """Build Scene/Batch3D/... classes bound to `lib`'s `<prefix>*` entry points."""
 

@@ -457,6 +457,7 @@ def test_sparse_frame_into_caller_buffers_and_stripes(product, monkeypatch):
     got = np.zeros((H, W, 4), np.uint8)
     for a, b in [(0, 100), (100, 213), (213, 300), (300, H)]:
         buf = torch.full((b - a, W, 4), 9, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()   # (the fill ran on torch's default stream, the render runs on `st`: no implicit order between the two)
         assert rxr.rxr_render_rows_to(ctx, a, b, C.c_void_p(buf.data_ptr()), C.c_void_p(st.cuda_stream)) == 0
         assert rxr.rxr_synchronize(ctx) == 0
         got[a:b] = buf.cpu().numpy()
@@ -466,6 +467,7 @@ def test_sparse_frame_into_caller_buffers_and_stripes(product, monkeypatch):
     for rank in range(3):
         mine = list(range(rank, n_stripes, 3))
         buf = torch.full((len(mine) * 16, W, 4), 9, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
         assert rxr.rxr_render_stripes_to(ctx, rank, 3, C.c_void_p(buf.data_ptr()), C.c_void_p(st.cuda_stream)) == 0
         assert rxr.rxr_synchronize(ctx) == 0
         h = buf.cpu().numpy()

@@ -36,13 +36,16 @@ def main():
     cfg = config(prod, args.config)
     W, H = cfg.width, cfg.height
     out = np.zeros(W * H * 4, np.uint8)
+    if args.pinned:   # page-locked pixels from the library's allocator (nothing of the malloc heap is locked: include/rxr.h)
+        from rusterix_amd.binding import pinned_pixels
+
+        out, free_locked = pinned_pixels(rxr, W * H * 4)
+        assert out is not None
     ref = None
     for n in [int(x) for x in args.members.split(",")]:
         ids = (C.c_int * n)(*[devs[i % len(devs)] for i in range(n)])
         prod.lib.rxh_set_devices(ids, n)
         ctx = prod.lib.rxh_context()
-        if args.pinned:
-            assert rxr.rxr_pin_host_buffer(ctx, out.ctypes.data, out.nbytes) == 0
         for _ in range(3):
             scenes.render(cfg, out)
         ts = []
@@ -51,8 +54,6 @@ def main():
             t0 = time.perf_counter()
             scenes.render(cfg, out)
             ts.append(time.perf_counter() - t0)
-        if args.pinned:
-            rxr.rxr_unpin_host_buffer(ctx, out.ctypes.data)
         if ref is None:
             ref = out.copy()
         ms = float(np.median(ts)) * 1e3

@@ -54,10 +54,14 @@ def main():
     ctx = host.rxh_context()
     res["render_download_ms"] = med(lambda: rxr.rxr_render_download(ctx, out.ctypes.data))
     res["whole_call_ms"] = med(lambda: scenes.render(cfg, out))
-    rxr.rxr_pin_host_buffer(ctx, out.ctypes.data, out.nbytes)
-    res["render_download_pinned_ms"] = med(lambda: rxr.rxr_render_download(ctx, out.ctypes.data))
-    res["whole_call_pinned_ms"] = med(lambda: scenes.render(cfg, out))
-    rxr.rxr_unpin_host_buffer(ctx, out.ctypes.data)
+    from rusterix_amd.binding import pinned_pixels
+
+    locked, free_locked = pinned_pixels(rxr, out.nbytes)   # page-locked pixels from the library's allocator (nothing of the heap is locked: rxr.h)
+    if locked is not None:
+        res["render_download_pinned_ms"] = med(lambda: rxr.rxr_render_download(ctx, locked.ctypes.data))
+        res["whole_call_pinned_ms"] = med(lambda: scenes.render(cfg, locked))
+        del locked
+        free_locked()
     res["handover_ms"] = round(res["project_plus_handover_ms"] - res["project_ms"], 3)
     print(json.dumps(res), flush=True)
     if args.out:
