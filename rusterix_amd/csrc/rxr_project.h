@@ -64,7 +64,7 @@ struct ProjectParams {
     AppendCount *append;          // per original triangle: this triangle's (verts, tris) then, after the scan, the exclusive prefix
     AppendCount *chunk_tot;       // scan scratch
     AppendCount *chunk_base;
-    uint32_t *ticket;             // scan last-block ticket (cleared by the last block)
+    uint32_t *ticket;             // [0] scan last-block ticket (cleared by the last block); [1] "some triangle of the frame is clipped" (k_proj_init clears, k_clip_count raises)
     DevBBox *bbox;                // per mesh
     uint32_t *mesh_live;          // per mesh and frame: triangle slots in use = originals + appended fans (0 for a rejected mesh);
                                   // the slots behind them are dead: k_proj_edges, k_setup3d and k_fill skip whole workgroups of them

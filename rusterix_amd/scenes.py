@@ -306,8 +306,11 @@ def box_grid_shader():
     ]])
 
 
-def box_grid_scene(api, n=289, width=7680, height=4320, tile_size=40, sample_mode=B.SAMPLE_LINEAR, boxes_per_batch=None, shader=False):
-    """C5: n batches of n boxes on an n x n lattice (n=289 -> 1 002 252 triangles); `shader`: every batch runs box_grid_shader()."""
+def box_grid_scene(api, n=289, width=7680, height=4320, tile_size=40, sample_mode=B.SAMPLE_LINEAR, boxes_per_batch=None, shader=False,
+                   distance=None):
+    """C5: n batches of n boxes on an n x n lattice (n=289 -> 1 002 252 triangles); `shader`: every batch runs box_grid_shader();
+    `distance`: the orbit camera's (default: the whole lattice in view; a small one puts the camera among the boxes, across whose
+    near plane many triangles then lie)."""
     rng = _rng(200)
     spacing, size = 0.2, 0.16
     tmpl = api.Batch3D.from_box(0.0, 0.0, 0.0, size, size, size)
@@ -335,7 +338,7 @@ def box_grid_scene(api, n=289, width=7680, height=4320, tile_size=40, sample_mod
     extent = n * spacing
     cam = api.D3OrbitCamera.new()
     cam.center = (extent / 2, 0.0, extent / 2)
-    cam.distance = 45.0 * (extent / 57.8)
+    cam.distance = 45.0 * (extent / 57.8) if distance is None else distance
 
     def setup():
         v, p = cam.matrices(float(width), float(height))

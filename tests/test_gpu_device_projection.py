@@ -69,6 +69,9 @@ SCENES = [
     ("map16", scenes.map_scene, dict(width=640, height=360, logo_size=64, n_lights=16)),
     ("box_grid", scenes.box_grid_scene, dict(n=24, width=512, height=288)),
 ]
+# (appended, the slices below keep their meaning) the multi-launch pre-pass WITH clipped triangles: frames in which no triangle crosses
+# the near plane leave k_proj_scan / k_clip_emit early, this one must not
+SCENES_CLIPPED_LARGE = [("box_grid_inside", scenes.box_grid_scene, dict(n=24, width=512, height=288, distance=0.6))]
 
 
 def _panes(api, **kw):
@@ -82,7 +85,7 @@ def _panes(api, **kw):
 SCENES.append(("nested_panes", _panes, dict(k=6, second_chunk=True)))
 
 
-@pytest.mark.parametrize("name,builder,kw", SCENES, ids=[s[0] for s in SCENES])
+@pytest.mark.parametrize("name,builder,kw", SCENES + SCENES_CLIPPED_LARGE, ids=[s[0] for s in SCENES + SCENES_CLIPPED_LARGE])
 def test_frames_identical_to_host_projection(product, devproj, name, builder, kw):
     devproj.off()
     want = scenes.render(builder(product, **kw)).copy()
@@ -94,7 +97,10 @@ def test_frames_identical_to_host_projection(product, devproj, name, builder, kw
     assert np.array_equal(again, want)
 
 
-@pytest.mark.parametrize("name,builder,kw", SCENES[:4] + SCENES[5:6], ids=[s[0] for s in SCENES[:4] + SCENES[5:6]])  # (scenes of static batches only)
+_STATIC_ONLY = SCENES[:4] + SCENES[5:6] + SCENES_CLIPPED_LARGE   # (scenes of static batches only)
+
+
+@pytest.mark.parametrize("name,builder,kw", _STATIC_ONLY, ids=[s[0] for s in _STATIC_ONLY])
 def test_projected_arrays_match_host_mirror(product, devproj, name, builder, kw):
     # host mirror projection (bit-identical to the oracle: tests/test_host_and_abi.py)
     devproj.off()
