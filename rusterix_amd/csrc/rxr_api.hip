@@ -43,6 +43,8 @@ extern "C" void rxr_launch_blockscan2d(const RasterParams *P, hipStream_t s);
 extern "C" void rxr_launch_raster(const RasterParams *P, hipStream_t s);
 extern "C" void rxr_launch_fill_words(uint32_t *dst, uint64_t n_words, uint32_t value, hipStream_t s);
 extern "C" void rxr_launch_fill_outside_spans(const RasterParams *P, hipStream_t s);
+extern "C" void rxr_launch_spans_from_meshes(const RasterParams *P, uint32_t n_tile_rows, const uint32_t *d2_box, hipStream_t s);
+extern "C" uint32_t rxr_span_meshes_max(void);
 extern "C" void rxr_launch_raster_grid(const RasterParams *P, uint32_t grid_x, hipStream_t s);
 extern "C" int rxr_raster_takes_spans(const RasterParams *P);
 extern "C" void rxr_launch_selftest_math(uint64_t seed, uint32_t blocks, uint32_t iters, unsigned long long *mismatch, hipStream_t s);
@@ -2119,6 +2121,23 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
             ctx->spans_active = true;
         }
     }
+    // Device-projected 3D meshes: their boxes are made on the device, frame by frame -- the table goes there holding what is known here
+    // (the pixel box of a host-projected 2D pass) and k_spans_from_meshes completes it behind the projections (render_impl).  The grid is not narrowed
+    // (nothing here knows by how much); the workgroups outside the spans leave at once.  Large frames only: what a dense one pays is the
+    // table's kernel, a fill launch that finds nothing to fill and the look-up in front of every tile.
+    ctx->dev_spans = false;
+    if (content_clamp && use_meshes && (f->flags & RXR_FLAG_D3_ACTIVE) && !P.has_brush && f->tile_size > 0 && span_budget >= 0 &&
+        n_tile_rows <= RXR_MAX_TILE_ROWS && n_b3 && n_b3 <= rxr_span_meshes_max() && (size_t)n_tile_rows * n_tile_cols >= 4u * content_min_tiles() &&
+        !(getenv("RXR_ROW_SPANS") && atoi(getenv("RXR_ROW_SPANS")) == 0)) {
+        for (uint32_t r = 0; r < n_tile_rows; ++r) {
+            const bool any = span_lo[r] < span_hi[r];
+            ctx->h_row_spans[r] = make_uint2(any ? span_lo[r] : 0u, any ? span_hi[r] : 0u);
+        }
+        int rc2;
+        if ((rc2 = ensure(ctx, ctx->d_row_spans, RXR_MAX_TILE_ROWS * sizeof(uint2))) != RXR_OK) return rc2;
+        HIPCHK(ctx, hipMemcpyAsync(ctx->d_row_spans.p, ctx->h_row_spans, n_tile_rows * sizeof(uint2), hipMemcpyHostToDevice, ctx->stream));
+        ctx->dev_spans = true;
+    }
     ctx->has_frame = true;
     ctx->rendered = false;
     ctx->upload_ordered_on = nullptr;
@@ -2237,6 +2256,24 @@ static int render_impl(rxr_ctx *ctx, const RenderSpec &spec, void *dev_pixels, h
         rxr_launch_fill_outside_spans(&P, s);
     }
     const bool prepass = d3 && !P.fused_small;
+    // (device-projected frames: the spans are completed on the device, behind the projection -- see rxr_upload_frame)
+    const bool dev_spans = prepass && ctx->dev_spans && ctx->frame_uses_meshes && spec.tile_stride == 1u && !spec.compact && rxr_raster_takes_spans(&P) != 0;
+    // device-projected 2D batches: Batch2D::project + the Prim2D records, before anything reads them
+    // (a frame without 2D primitives never reads what they would write: no launch)
+    const bool project2d = ctx->frame_uses_meshes2d && P.tiles_y && (P.flags & RXR_FLAG_D2_ACTIVE) && ctx->PP2.n_prims;
+    bool projected2d = false;
+    auto project_meshes = [&]() {
+        rxr_launch_project(&ctx->PP, s);  // clip_and_project + Edges + boxes on the device
+        if (dev_spans) {
+            if (project2d) {  // (its union box belongs to the table)
+                rxr_launch_project2d(&ctx->PP2, s);
+                projected2d = true;
+            }
+            P.row_spans = (const uint2 *)ctx->d_row_spans.p;
+            rxr_launch_spans_from_meshes(&P, (P.height + RXR_TILE_H - 1u) / RXR_TILE_H, project2d ? ctx->PP2.d2_box : nullptr, s);
+            rxr_launch_fill_outside_spans(&P, s);
+        }
+    };
     if (prepass && ctx->scratch_dirty) {
         // a previous launch sequence was cut short: restore the all-zero invariants explicitly
         HIPCHK(ctx, hipMemsetAsync(ctx->d_bin_count.p, 0, ctx->d_bin_count.cap, s));
@@ -2253,7 +2290,7 @@ static int render_impl(rxr_ctx *ctx, const RenderSpec &spec, void *dev_pixels, h
         P.counters = (uint32_t *)ctx->d_counters.p + (size_t)ctx->parity * CNT_WORDS;
         P.counters_next = (uint32_t *)ctx->d_counters.p + (size_t)(ctx->parity ^ 1u) * CNT_WORDS;
         if (P.blockscan_scatter) ctx->parity ^= 1u;
-        if (ctx->frame_uses_meshes) rxr_launch_project(&ctx->PP, s);
+        if (ctx->frame_uses_meshes) project_meshes();
         rxr_launch_setup(&P, s);
         rxr_launch_blockscan(&P, s);
     } else if (prepass) {
@@ -2263,7 +2300,7 @@ static int render_impl(rxr_ctx *ctx, const RenderSpec &spec, void *dev_pixels, h
         P.counters = (uint32_t *)ctx->d_counters.p + (size_t)ctx->parity * CNT_WORDS;
         P.counters_next = (uint32_t *)ctx->d_counters.p + (size_t)(ctx->parity ^ 1u) * CNT_WORDS;
         ctx->parity ^= 1u;
-        if (ctx->frame_uses_meshes) rxr_launch_project(&ctx->PP, s);  // clip_and_project + Edges + boxes on the device
+        if (ctx->frame_uses_meshes) project_meshes();
         rxr_launch_setup(&P, s);
         ScanArgs A{};
         A.n = P.tiles_x * P.tiles_y;
@@ -2282,9 +2319,7 @@ static int render_impl(rxr_ctx *ctx, const RenderSpec &spec, void *dev_pixels, h
     // (the pinned status words are never written by the host while launches may be in flight: earlier queued k_scan
     // launches write them; rxr_synchronize clears them once the streams have drained)
     (void)n_bins;
-    // device-projected 2D batches: Batch2D::project + the Prim2D records, before anything reads them
-    // (a frame without 2D primitives never reads what they would write: no launch)
-    if (ctx->frame_uses_meshes2d && P.tiles_y && (P.flags & RXR_FLAG_D2_ACTIVE) && ctx->PP2.n_prims) rxr_launch_project2d(&ctx->PP2, s);
+    if (project2d && !projected2d) rxr_launch_project2d(&ctx->PP2, s);
     // 2D binning pre-pass (many 2D primitives): count -> scan -> fill; k_raster sorts each tile's list
     const bool prepass2d = P.tiles_y && (P.flags & RXR_FLAG_D2_ACTIVE) && P.binned2d;
     if (prepass2d) {
@@ -3332,14 +3367,21 @@ int rxr_selftest_math(rxr_ctx *ctx, uint64_t n_tuples, uint64_t seed, uint64_t m
 
 // what the run-time compiler did with the last program set of this context (rxr_jit.hip); "" when it was not asked
 // tests: how the resident frame's 3D arrays arrived -- 0 plain rxr_upload_frame, 1 streamed and copied, 2 streamed out of page-locked memory
-// tests: what rxr_upload_frame found out about the resident frame's extent: out[0] = content rows known, out[1], out[2] = the rows, out[3] = row spans in use
+// tests: what rxr_upload_frame found out about the resident frame's extent: out[0] = content rows known, out[1], out[2] = the rows, out[3] = row spans in use (1: from the host's boxes, 2: completed on the device)
 extern "C" int rxr_debug_content(rxr_ctx *ctx, uint32_t *out) {
     if (!ctx || ctx->group || !out) return -1;
     out[0] = ctx->content_known ? 1u : 0u;
     out[1] = ctx->content_row0;
     out[2] = ctx->content_row1;
-    out[3] = ctx->spans_active ? 1u : 0u;
+    out[3] = ctx->spans_active ? 1u : (ctx->dev_spans ? 2u : 0u);  // (2: completed on the device from the meshes' boxes)
     return 0;
+}
+// tests (host only, no device): rxr_ref_tile_span (quick == 0) / rxr_ref_tile_span_quick of n boxes [lo, lo + extent] on one axis; out: p0, p1 per box
+extern "C" void rxr_debug_tile_spans(const float *lo, const float *extent, uint32_t n, uint32_t size, uint32_t ts, float pad, int quick, uint32_t *out) {
+    for (uint32_t i = 0; i < n; ++i) {
+        if (quick) rxr_ref_tile_span_quick(lo[i], extent[i], size, ts, pad, out[2 * i], out[2 * i + 1]);
+        else rxr_ref_tile_span(lo[i], extent[i], size, ts, pad, out[2 * i], out[2 * i + 1]);
+    }
 }
 extern "C" int rxr_debug_stream_info(rxr_ctx *ctx) { return (ctx && !ctx->group) ? ctx->last_upload_streamed : -1; }
 

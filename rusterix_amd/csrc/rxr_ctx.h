@@ -226,6 +226,7 @@ struct rxr_ctx {
     uint2 *h_row_spans = nullptr;    // RXR_MAX_TILE_ROWS entries, page-locked
     DevBuf d_row_spans;
     bool spans_active = false;
+    bool dev_spans = false;          // device-projected meshes: the table is completed on the device behind the projection (k_spans_from_meshes)
     RasterParams P{};       // template for the resident frame (pointers resolved)
     uint32_t n_tris2d = 0;
 

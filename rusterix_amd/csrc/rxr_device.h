@@ -243,6 +243,37 @@ RXR_HD inline void rxr_ref_tile_span(float lo, float extent, uint32_t size, uint
     p1 = ((last + 1u) * ts < size) ? (last + 1u) * ts : size;
 }
 
+// The same interval for a box that is NOT risky, without the searches (k_spans_from_meshes runs this once per mesh and frame in a single
+// workgroup: eighteen dependent search steps were most of its 15 us): both bounds are guessed by a division and walked to the place where
+// the reference's own predicate flips -- the predicates are monotone in the tile index, so whatever the guess, the walk ends on the
+// bound the search finds (tests/test_host_and_abi.py compares the two on random and boundary boxes).  Risky boxes take the search.
+RXR_HD inline void rxr_ref_tile_span_quick(float lo, float extent, uint32_t size, uint32_t ts, float pad, uint32_t &p0, uint32_t &p1) {
+    const float lim = 2097152.0f;
+    if (!(lo > -lim && lo < lim && extent > -lim && extent < lim) || ts == 0u || size == 0u) {
+        rxr_ref_tile_span(lo, extent, size, ts, pad, p0, p1);
+        return;
+    }
+    p0 = p1 = 0u;
+    const uint32_t n = (size + ts - 1u) / ts;
+    const float hi = lo + extent;
+    auto below = [&](uint32_t c) { const uint32_t t0 = c * ts, tw = (size - t0 < ts) ? size - t0 : ts; return lo < (float)(t0 + tw) + pad; };
+    auto above = [&](uint32_t c) { return hi > (float)(c * ts) - pad; };
+    if (!below(n - 1u) || !above(0u)) return;
+    const float fts = (float)ts;
+    const float ga = (lo - pad) / fts, gb = (hi + pad) / fts;   // (|.| < 2^22: the conversions below are defined)
+    uint32_t first = ga > 0.0f ? (uint32_t)ga : 0u;
+    if (first > n - 1u) first = n - 1u;
+    while (first > 0u && below(first - 1u)) --first;
+    while (first < n - 1u && !below(first)) ++first;
+    uint32_t last = gb > 0.0f ? (uint32_t)gb : 0u;
+    if (last > n - 1u) last = n - 1u;
+    while (last < n - 1u && above(last + 1u)) ++last;
+    while (last > 0u && !above(last)) --last;
+    if (first > last) return;
+    p0 = first * ts;
+    p1 = ((last + 1u) * ts < size) ? (last + 1u) * ts : size;
+}
+
 // kernel parameter block (passed by value; lives in the kernarg segment -> scalar loads)
 // Per-light constants of the relaxed point-light term (shade3d_lights<X, true>; RXR_LIGHT_MATH=relaxed).  Everything in the term that
 // depends on the light and the frame but not on the fragment -- colour x intensity x flicker, the smoothstep's reciprocal

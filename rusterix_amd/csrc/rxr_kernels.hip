@@ -3746,7 +3746,66 @@ extern "C" __global__ void __launch_bounds__(256) k_fill_outside_spans(RasterPar
     }
 }
 
+// Device-projected frames (rxr_project.hip): the batch boxes exist on the device only, so the row spans of a sparse frame are made here --
+// RasterParams.row_spans arrives holding what the HOST knows (the pixel box of a host-projected 2D pass, or nothing) and leaves as its
+// union with the pixel box of a device-projected 2D pass (`d2_box`, k_proj2d_prims; NULL: none) and every kept mesh's box, through the
+// same arithmetic as rxr_upload_frame's for host-projected batches (the batch box reject of make_setup, then the reference's own tiles
+// that pass its box test: rxr_ref_tile_span; rasterizer.rs:978-983).  Idempotent: a second render of the same resident frame finds the
+// same table.  One workgroup per 64 tile rows; a thread per mesh reduces it to its tile rectangle and marks the workgroup's rows that
+// it crosses with LDS atomics that return nothing (a thread per ROW walking the rectangles was a chain of LDS round trips: 16 us).
+#define RXR_SPAN_MESHES_MAX 1024u
+extern "C" __global__ void __launch_bounds__(256) k_spans_from_meshes(RasterParams P, uint32_t n_tile_rows, const uint32_t *d2_box) {
+    __shared__ uint32_t s_lo[64], s_hi[64];
+    const uint32_t tid = threadIdx.x, row_base = blockIdx.x * 64u;
+    uint2 *const spans = const_cast<uint2 *>(P.row_spans);
+    if (tid < 64u) {
+        const uint32_t row = row_base + tid;
+        const uint2 base = row < n_tile_rows ? spans[row] : make_uint2(0u, 0u);
+        const bool any = base.x < base.y;
+        uint32_t lo0 = any ? base.x : 0xFFFFFFFFu, hi0 = any ? base.y : 0u;
+        if (d2_box) {  // (uniform) pixels [x0, x1) x [y0, y1), as rxr_upload_frame's add_span takes the host's
+            const uint32_t x0 = d2_box[0], x1 = min(d2_box[1], P.width), y0 = d2_box[2], y1 = min(d2_box[3], P.height);
+            if (x0 < x1 && y0 < y1 && row >= y0 / RXR_TILE_H && row < min((y1 + RXR_TILE_H - 1u) / RXR_TILE_H, n_tile_rows)) {
+                lo0 = min(lo0, x0 / RXR_TILE_W);
+                hi0 = max(hi0, min((x1 + RXR_TILE_W - 1u) / RXR_TILE_W, P.tiles_x));
+            }
+        }
+        s_lo[tid] = lo0;
+        s_hi[tid] = hi0;
+    }
+    __syncthreads();
+    auto dec = [](uint32_t e) { return __uint_as_float((e & 0x80000000u) ? (e ^ 0x80000000u) : ~e); };
+    for (uint32_t m = tid; m < P.n_batches3d; m += 256u) {
+        const DevBBox bb = P.dev_bbox[m];
+        const float bx = dec(bb.min_x), by = dec(bb.min_y), bw = dec(bb.max_x) - bx, bh = dec(bb.max_y) - by;
+        const bool keep = !(P.batches3d[m].flags & DB_SKIP) && bx < (float)P.width && (bx + bw) > 0.0f && by < (float)P.height && (by + bh) > 0.0f;
+        if (!keep) continue;
+        uint32_t x0 = 0, x1 = 0, y0 = 0, y1 = 0;
+        rxr_ref_tile_span_quick(by, bh, P.height, P.ref_tile, 0.0f, y0, y1);
+        if (y0 >= y1) continue;
+        const uint32_t r0 = max(y0 / RXR_TILE_H, row_base), r1 = min(min((y1 + RXR_TILE_H - 1u) / RXR_TILE_H, n_tile_rows), row_base + 64u);
+        if (r0 >= r1) continue;  // (none of this workgroup's rows)
+        rxr_ref_tile_span_quick(bx, bw, P.width, P.ref_tile, 0.0f, x0, x1);
+        if (x0 >= x1) continue;
+        const uint32_t c0 = x0 / RXR_TILE_W, c1 = min((x1 + RXR_TILE_W - 1u) / RXR_TILE_W, P.tiles_x);
+        for (uint32_t r = r0; r < r1; ++r) {
+            atomicMin(&s_lo[r - row_base], c0);
+            atomicMax(&s_hi[r - row_base], c1);
+        }
+    }
+    __syncthreads();
+    if (tid < 64u && row_base + tid < n_tile_rows) {
+        const uint32_t a = s_lo[tid], b = s_hi[tid];
+        spans[row_base + tid] = a < b ? make_uint2(a, b) : make_uint2(0u, 0u);
+    }
+}
+
 // ---- host-callable launchers (used by rxr_api.hip) ------------------------------------------------
+extern "C" uint32_t rxr_span_meshes_max(void) { return RXR_SPAN_MESHES_MAX; }
+extern "C" void rxr_launch_spans_from_meshes(const RasterParams *P, uint32_t n_tile_rows, const uint32_t *d2_box, hipStream_t s) {
+    if (!P->row_spans || !P->dev_bbox || !n_tile_rows || P->n_batches3d > RXR_SPAN_MESHES_MAX) return;
+    RXR_LAUNCH(k_spans_from_meshes, dim3((n_tile_rows + 63u) / 64u), dim3(256), s, *P, n_tile_rows, d2_box);
+}
 extern "C" void rxr_launch_setup(const RasterParams *P, hipStream_t s) {
     if (P->n_tris3d == 0) return;
     uint32_t blocks = (P->n_tris3d + 255u) / 256u;

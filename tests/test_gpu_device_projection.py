@@ -288,3 +288,66 @@ def test_projected_arrays_of_poisoned_triangles_match_the_host_mirror(product, d
             compared += 1
         i += 1
     assert i == 41 and compared >= 30, (i, compared)
+
+
+def _sparse_mesh_scene(api, kind):
+    """sparse frames of device-projected meshes: `grid` a distant lattice (a band in the middle of the frame, row mode), `grid_and_rect` the
+    same with a host-projected 2D rectangle low in the frame (the table's host part), `nothing` every mesh off the frame"""
+    from tests.test_gpu_parity import _sparse_scene
+
+    cfg = _sparse_scene(api, "nothing" if kind == "nothing" else "grid")
+    if kind == "grid_and_rect":
+        rect = api.Batch2D.from_rectangle(500.0, 400.0, 90.0, 60.0).source(B.PixelSource.Pixel((40, 200, 90, 255)))
+        cfg.scene.add_d2_static(rect)
+    return cfg
+
+
+@pytest.mark.parametrize("kind", ["grid", "grid_and_rect", "nothing"])
+def test_sparse_frames_take_their_row_spans_from_the_device_boxes(oracle, product, devproj, kind, monkeypatch):
+    """Device-projected meshes have their boxes on the device only: k_spans_from_meshes completes the row-span table there (the same box
+    arithmetic as rxr_upload_frame's for host-projected batches), the tiles outside it are filled, not rastered.  The frame equals the
+    oracle's, the host-projected one, the one with the spans switched off, and the one assembled from row bands."""
+    import ctypes as C
+
+    monkeypatch.setenv("RXR_CONTENT_MIN_TILES", "0")   # (the table only pays on large frames: these are small)
+    devproj.off()
+    want = scenes.render(_sparse_mesh_scene(product, kind)).copy()
+    ref = scenes.render(_sparse_mesh_scene(oracle, kind))
+    assert np.array_equal(want, ref), kind
+    devproj.on()
+    cfg = _sparse_mesh_scene(product, kind)
+    got = scenes.render(cfg).copy()
+    assert np.array_equal(got, ref), f"{kind}: {(got != ref).any(axis=2).sum()} pixels differ"
+    lib = product.lib
+    rxr = __import__("rusterix_amd").rxr_abi()
+    lib.rxh_context.restype = C.c_void_p
+    info = (C.c_uint32 * 4)()
+    assert rxr.rxr_debug_content(C.c_void_p(lib.rxh_context()), info) == 0
+    assert info[0] == 0 and info[3] == 2, list(info)     # (no rows known to the host; the table is the device's)
+    if kind != "nothing":
+        hit_cols = np.nonzero((got[..., :3].max(axis=2) > 0).any(axis=0))[0]
+        assert hit_cols.min() > 32 or hit_cols.max() < cfg.width - 32, "the scene leaves no tile columns empty: it tests nothing"
+    again = scenes.render(cfg).copy()                     # (the second frame re-uploads the host part and completes it again)
+    assert np.array_equal(again, ref)
+    monkeypatch.setenv("RXR_ROW_SPANS", "0")
+    off = scenes.render(cfg).copy()
+    assert rxr.rxr_debug_content(C.c_void_p(lib.rxh_context()), info) == 0 and info[3] == 0
+    monkeypatch.delenv("RXR_ROW_SPANS")
+    assert np.array_equal(off, ref)
+    # row bands of one resident frame (every band launch completes the table again: idempotent), then the pipelined download
+    lib.rxh_rasterizer_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+    rxr.rxr_render_rows.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+    rxr.rxr_download_rows.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), C.c_uint32, C.c_uint32]
+    r = cfg.setup()
+    assert lib.rxh_rasterizer_upload(r._h, cfg.scene._h, cfg.width, cfg.height, cfg.tile_size, cfg.assets._h) == 0
+    ctx = C.c_void_p(lib.rxh_context())
+    bands = np.zeros_like(got)
+    H = cfg.height
+    for a, b in [(0, 37), (37, H // 2 + 5), (H // 2 + 5, H)]:
+        assert rxr.rxr_render_rows(ctx, a, b) == 0
+        assert rxr.rxr_download_rows(ctx, bands.ctypes.data_as(C.POINTER(C.c_uint8)), a, b) == 0   # (full-frame layout: row r at r * width * 4)
+    assert np.array_equal(bands, ref), kind
+    rxr.rxr_render_download.argtypes = [C.c_void_p, C.POINTER(C.c_uint8)]
+    piped = np.full_like(got, 7)
+    assert rxr.rxr_render_download(ctx, piped.ctypes.data_as(C.POINTER(C.c_uint8))) == 0
+    assert np.array_equal(piped, ref), kind

@@ -175,3 +175,30 @@ def test_teapot_fixture_equals_the_reference_file(oracle):
     for api in (rusterix_amd.load(), oracle):
         g = api.Batch3D.from_obj(text).geometry()
         assert g[0].tobytes() == v.tobytes() and g[1].astype(np.uint32).tobytes() == idx.tobytes() and g[2].tobytes() == uv.tobytes()
+
+
+def test_tile_span_without_the_searches_equals_the_searched_one():
+    """rxr_device.h: rxr_ref_tile_span_quick (k_spans_from_meshes: the row spans of device-projected frames) guesses the two bounds of the
+    reference's per-tile batch box test (rasterizer.rs:978-983) and walks to where the predicate flips; rxr_ref_tile_span searches for them.
+    Same interval for every box: random ones, boxes on tile and pixel boundaries, off-screen, huge, infinite and NaN ones (host code only)."""
+    lib = rusterix_amd.load_rxr()
+    lib.rxr_debug_tile_spans.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_int, C.c_void_p]
+    lib.rxr_debug_tile_spans.restype = None
+    rng = np.random.default_rng(77)
+    f32 = np.float32
+    for size, ts in [(7680, 40), (4320, 40), (1920, 60), (1080, 64), (333, 40), (211, 7), (16, 100), (1, 1), (32768, 1), (640, 0)]:
+        edges = np.arange(0, size + 2 * max(ts, 1), max(ts, 1), dtype=np.float64)
+        near = (edges[:, None] + np.array([-1.0, -0.5, -2.0 ** -10, 0.0, 2.0 ** -10, 0.5, 1.0])[None, :]).ravel()
+        special = np.array([0.0, -0.0, -1.0, size, size - 0.5, size + 0.5, 2097151.75, 2097152.0, -2097152.0, 4.0e6, -4.0e6, 3.0e38, -3.0e38, np.inf, -np.inf, np.nan])
+        pool = np.concatenate([near, special, rng.uniform(-2.0 * size, 3.0 * size, 4000)]).astype(f32)
+        lo = rng.choice(pool, 60000).astype(f32)
+        hi = rng.choice(pool, 60000).astype(f32)
+        with np.errstate(invalid="ignore", over="ignore"):
+            extent = (hi - lo).astype(f32)     # (negative extents included: an empty or inverted box)
+        for pad in (0.0, 0.5):
+            out = [np.zeros((len(lo), 2), np.uint32) for _ in range(2)]
+            for quick in (0, 1):
+                lib.rxr_debug_tile_spans(lo.ctypes.data, extent.ctypes.data, len(lo), size, ts, f32(pad), quick, out[quick].ctypes.data)
+            bad = np.nonzero((out[0] != out[1]).any(axis=1))[0]
+            assert len(bad) == 0, (size, ts, pad, lo[bad[:3]], extent[bad[:3]], out[0][bad[:3]], out[1][bad[:3]])
+            assert (out[0][:, 0] < out[0][:, 1]).sum() > 1000 or ts == 0 or size <= 16, "hardly any box meets the frame: the test tests nothing"
