@@ -43,7 +43,7 @@ extern "C" void rxr_launch_blockscan2d(const RasterParams *P, hipStream_t s);
 extern "C" void rxr_launch_raster(const RasterParams *P, hipStream_t s);
 extern "C" void rxr_launch_fill_words(uint32_t *dst, uint64_t n_words, uint32_t value, hipStream_t s);
 extern "C" void rxr_launch_fill_outside_spans(const RasterParams *P, hipStream_t s);
-extern "C" void rxr_launch_spans_from_meshes(const RasterParams *P, uint32_t n_tile_rows, const uint32_t *d2_box, hipStream_t s);
+extern "C" void rxr_launch_spans_from_meshes(const RasterParams *P, uint32_t n_tile_rows, const uint32_t *d2_box, uint2 *host_copy, hipStream_t s);
 extern "C" uint32_t rxr_span_meshes_max(void);
 extern "C" void rxr_launch_raster_grid(const RasterParams *P, uint32_t grid_x, hipStream_t s);
 extern "C" int rxr_raster_takes_spans(const RasterParams *P);
@@ -204,7 +204,7 @@ int rxr_create(rxr_ctx **out, int device_id) {
     for (hipEvent_t &ev : ctx->ev_band)
         if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
     if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_counters, HS_WORDS * sizeof(uint32_t), hipHostMallocDefault);
-    if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_row_spans, RXR_MAX_TILE_ROWS * sizeof(uint2), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_row_spans, 2u * RXR_MAX_TILE_ROWS * sizeof(uint2), hipHostMallocDefault);  // (second half: the table as the device completed it, rxr_render_download)
     if (e != hipSuccess) {
         std::string msg = std::string("rxr_create: ") + hipGetErrorString(e);
         rxr_destroy(ctx);
@@ -2166,8 +2166,11 @@ static bool content_band(const rxr_ctx *ctx, const RenderSpec &spec, uint32_t &c
 // consecutive groups of tile rows, an event of band_events recorded behind each -- the caller ships finished rows while the next ones
 // render (rxr_render_download).  The bins are those of the one pre-pass (RasterParams.bin_row0); every bin is still handed back zeroed
 // by its own tile's workgroup; the frame is byte-identical to one launch (tests/test_gpu_parity.py).
+// spans_event (device-projected sparse frames): recorded behind k_spans_from_meshes, which then also writes the completed row-span
+// table to the second half of ctx->h_row_spans; *spans_recorded says whether that happened in this call.
 static int render_impl(rxr_ctx *ctx, const RenderSpec &spec, void *dev_pixels, hipStream_t s, bool retry = false, uint32_t n_raster_bands = 1,
-                       hipEvent_t *band_events = nullptr, uint32_t *band_row_of = nullptr) {
+                       hipEvent_t *band_events = nullptr, uint32_t *band_row_of = nullptr, hipEvent_t spans_event = nullptr,
+                       bool *spans_recorded = nullptr) {
     if (!ctx) return RXR_ERR_INVALID;
     if (!ctx->has_frame) return fail(ctx, RXR_ERR_INVALID, "render: no frame uploaded");
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -2270,7 +2273,9 @@ static int render_impl(rxr_ctx *ctx, const RenderSpec &spec, void *dev_pixels, h
                 projected2d = true;
             }
             P.row_spans = (const uint2 *)ctx->d_row_spans.p;
-            rxr_launch_spans_from_meshes(&P, (P.height + RXR_TILE_H - 1u) / RXR_TILE_H, project2d ? ctx->PP2.d2_box : nullptr, s);
+            rxr_launch_spans_from_meshes(&P, (P.height + RXR_TILE_H - 1u) / RXR_TILE_H, project2d ? ctx->PP2.d2_box : nullptr,
+                                         spans_event ? ctx->h_row_spans + RXR_MAX_TILE_ROWS : nullptr, s);
+            if (spans_event && hipEventRecord(spans_event, s) == hipSuccess && spans_recorded) *spans_recorded = true;
             rxr_launch_fill_outside_spans(&P, s);
         }
     };
@@ -2686,13 +2691,34 @@ int rxr_render_download(rxr_ctx *ctx, uint8_t *pixels) {
     rc = band_spec(ctx, 0, H, false, spec);
     if (rc != RXR_OK) return rc;
     const uint32_t rerenders_before = ctx->rerenders;
-    rc = render_impl(ctx, spec, ctx->d_fb.p, ctx->stream, false, n_bands, ctx->ev_band, row_of);
+    bool spans_back = false;
+    rc = render_impl(ctx, spec, ctx->d_fb.p, ctx->stream, false, n_bands, ctx->ev_band, row_of, ctx->ev_band[7], &spans_back);
     if (rc != RXR_OK) return rc;
     // Rows outside the frame's content are the miss colour on the device AND need not cross PCIe: the caller's rows are written here,
     // by the host, while the device renders and the content rows travel (the 8K frame of the box grid: 40 of 133 MB that are not
     // downloaded; the link is what bounds this call).
     uint32_t c0 = 0, c1 = H;
-    const bool clipped = content_band(ctx, spec, c0, c1);
+    bool clipped = content_band(ctx, spec, c0, c1);
+    if (spans_back) {
+        // device-projected meshes: the content is known once the projection has run -- the device hands its row-span table back a
+        // fraction of a millisecond into the frame (k_spans_from_meshes writes a copy into page-locked memory, an event behind it),
+        // long before the first band is rastered; this thread would only wait for the bands otherwise
+        HIPCHK(ctx, hipEventSynchronize(ctx->ev_band[7]));
+        const uint2 *back = ctx->h_row_spans + RXR_MAX_TILE_ROWS;
+        const uint32_t n_rows = (H + RXR_TILE_H - 1u) / RXR_TILE_H;
+        uint32_t r0 = n_rows, r1 = 0;
+        for (uint32_t r = 0; r < n_rows; ++r)
+            if (back[r].x < back[r].y) {
+                r0 = std::min(r0, r);
+                r1 = r + 1u;
+            }
+        const uint32_t d0 = r0 < r1 ? r0 * RXR_TILE_H : 0u, d1 = r0 < r1 ? std::min(r1 * (uint32_t)RXR_TILE_H, H) : 0u;
+        if ((size_t)(d0 + (H - d1)) / RXR_TILE_H * P.tiles_x >= content_min_tiles()) {  // (as content_band: a few rows are not worth the fills)
+            c0 = d0;
+            c1 = d1;
+            clipped = true;
+        }
+    }
     for (uint32_t k = 0; k < n_bands; ++k) {
         const uint32_t a = std::max(row_of[k], c0), b = std::min(row_of[k + 1], c1);
         HIPCHK(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev_band[k], 0));

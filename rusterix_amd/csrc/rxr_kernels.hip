@@ -3754,7 +3754,7 @@ extern "C" __global__ void __launch_bounds__(256) k_fill_outside_spans(RasterPar
 // same table.  One workgroup per 64 tile rows; a thread per mesh reduces it to its tile rectangle and marks the workgroup's rows that
 // it crosses with LDS atomics that return nothing (a thread per ROW walking the rectangles was a chain of LDS round trips: 16 us).
 #define RXR_SPAN_MESHES_MAX 1024u
-extern "C" __global__ void __launch_bounds__(256) k_spans_from_meshes(RasterParams P, uint32_t n_tile_rows, const uint32_t *d2_box) {
+extern "C" __global__ void __launch_bounds__(256) k_spans_from_meshes(RasterParams P, uint32_t n_tile_rows, const uint32_t *d2_box, uint2 *host_copy) {
     __shared__ uint32_t s_lo[64], s_hi[64];
     const uint32_t tid = threadIdx.x, row_base = blockIdx.x * 64u;
     uint2 *const spans = const_cast<uint2 *>(P.row_spans);
@@ -3796,15 +3796,17 @@ extern "C" __global__ void __launch_bounds__(256) k_spans_from_meshes(RasterPara
     __syncthreads();
     if (tid < 64u && row_base + tid < n_tile_rows) {
         const uint32_t a = s_lo[tid], b = s_hi[tid];
-        spans[row_base + tid] = a < b ? make_uint2(a, b) : make_uint2(0u, 0u);
+        const uint2 v = a < b ? make_uint2(a, b) : make_uint2(0u, 0u);
+        spans[row_base + tid] = v;
+        if (host_copy) host_copy[row_base + tid] = v;  // (page-locked host memory: rxr_render_download learns which rows need not cross PCIe)
     }
 }
 
 // ---- host-callable launchers (used by rxr_api.hip) ------------------------------------------------
 extern "C" uint32_t rxr_span_meshes_max(void) { return RXR_SPAN_MESHES_MAX; }
-extern "C" void rxr_launch_spans_from_meshes(const RasterParams *P, uint32_t n_tile_rows, const uint32_t *d2_box, hipStream_t s) {
-    if (!P->row_spans || !P->dev_bbox || !n_tile_rows || P->n_batches3d > RXR_SPAN_MESHES_MAX) return;
-    RXR_LAUNCH(k_spans_from_meshes, dim3((n_tile_rows + 63u) / 64u), dim3(256), s, *P, n_tile_rows, d2_box);
+extern "C" void rxr_launch_spans_from_meshes(const RasterParams *P, uint32_t n_tile_rows, const uint32_t *d2_box, uint2 *host_copy, hipStream_t s) {
+    if (!P->row_spans || !P->dev_bbox || !n_tile_rows) return;
+    RXR_LAUNCH(k_spans_from_meshes, dim3((n_tile_rows + 63u) / 64u), dim3(256), s, *P, n_tile_rows, d2_box, host_copy);
 }
 extern "C" void rxr_launch_setup(const RasterParams *P, hipStream_t s) {
     if (P->n_tris3d == 0) return;

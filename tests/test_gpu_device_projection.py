@@ -351,3 +351,42 @@ def test_sparse_frames_take_their_row_spans_from_the_device_boxes(oracle, produc
     piped = np.full_like(got, 7)
     assert rxr.rxr_render_download(ctx, piped.ctypes.data_as(C.POINTER(C.c_uint8))) == 0
     assert np.array_equal(piped, ref), kind
+
+
+def test_pipelined_download_of_a_sparse_device_projected_frame(product, devproj, monkeypatch):
+    """rxr_render_download on a frame of 4 Mpixel and more whose meshes are projected on the device: the bands are rastered behind ONE
+    pre-pass, k_spans_from_meshes hands the completed row-span table back to the host (page-locked memory + an event), the rows that
+    nothing reaches are written by the host instead of crossing PCIe.  Equal to render_rows + download_rows, to the host-projected
+    frame, and to itself on a second call."""
+    import ctypes as C
+
+    monkeypatch.setenv("RXR_CONTENT_MIN_TILES", "0")
+    kw = dict(n=40, width=2304, height=1832, distance=22.0)   # 19 200 triangles in the middle of the frame: binned, row mode
+    devproj.off()
+    want = scenes.render(scenes.box_grid_scene(product, **kw)).copy()
+    hit_rows = np.nonzero((want[..., :3].max(axis=2) > 0).any(axis=1))[0]
+    assert len(hit_rows) and hit_rows.min() > 200 and hit_rows.max() < 1832 - 200, "the scene leaves no rows empty: it tests nothing"
+    devproj.on()
+    cfg = scenes.box_grid_scene(product, **kw)
+    piped = np.full_like(want, 7)
+    piped[...] = scenes.render(cfg)                 # Rasterizer::rasterize -> rxr_render_download
+    assert np.array_equal(piped, want), f"{(piped != want).any(axis=2).sum()} pixels differ"
+    lib = product.lib
+    rxr = __import__("rusterix_amd").rxr_abi()
+    lib.rxh_context.restype = C.c_void_p
+    info = (C.c_uint32 * 4)()
+    assert rxr.rxr_debug_content(C.c_void_p(lib.rxh_context()), info) == 0 and info[3] == 2, list(info)
+    lib.rxh_rasterizer_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+    rxr.rxr_render_rows.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+    rxr.rxr_download_rows.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), C.c_uint32, C.c_uint32]
+    rxr.rxr_render_download.argtypes = [C.c_void_p, C.POINTER(C.c_uint8)]
+    r = cfg.setup()
+    assert lib.rxh_rasterizer_upload(r._h, cfg.scene._h, cfg.width, cfg.height, cfg.tile_size, cfg.assets._h) == 0
+    ctx = C.c_void_p(lib.rxh_context())
+    single = np.zeros_like(want)
+    assert rxr.rxr_render_rows(ctx, 0, cfg.height) == 0
+    assert rxr.rxr_download_rows(ctx, single.ctypes.data_as(C.POINTER(C.c_uint8)), 0, cfg.height) == 0
+    assert np.array_equal(single, want)
+    again = np.full_like(want, 9)                   # (every byte of the caller's buffer is written: by the link or by the host)
+    assert rxr.rxr_render_download(ctx, again.ctypes.data_as(C.POINTER(C.c_uint8))) == 0
+    assert np.array_equal(again, want)
