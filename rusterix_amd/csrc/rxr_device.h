@@ -88,7 +88,7 @@ struct TriShade {
     float iw0, iw1, iw2;                     // 1.0 / v.w
     float u0w, u1w, u2w, v0w, v1w, v2w;      // uv / w (rasterizer.rs:1062-1067)
     float n0[3], n1[3], n2[3];
-    uint32_t pad[2];
+    uint32_t pad[2];                         // the batch's texture descriptor, packed (rxr_kernels.hip TS_DESC_VALID), or zeros
 };
 
 // 2D primitive in submission order (flattened on the host at upload): a triangle of a Triangles batch

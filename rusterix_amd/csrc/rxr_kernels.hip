@@ -35,6 +35,12 @@
 #include "rxr_launch.h"
 #endif
 
+// 1: TriShade's two spare words carry the batch's texture descriptor (make_setup, shade3d_begin); 0: A-B runs
+#ifndef RXR_DESC_IN_TRISHADE
+#define RXR_DESC_IN_TRISHADE 1
+#endif
+#define TS_DESC_VALID 0x80000000u
+
 #include "rxr_device.h"
 #include "rxr_exact_math.h"
 #include "rxr_project.h"
@@ -698,14 +704,23 @@ __device__ __forceinline__ void shade3d_begin(const RasterParams &P, const TriSh
         }
     }
 
-    uint32_t texel = batch_texel<X>(P, B, u, v, world.x, world.z, &world);
+    uint32_t texel;
+    bool desc_in_record = false;  // wave-uniform
+#if RXR_DESC_IN_TRISHADE
+    if constexpr (!lvl1<X>) desc_in_record = rxm::wave_all((S.pad[1] & TS_DESC_VALID) != 0u);
+#endif
+    if (desc_in_record) {  // (make_setup: the descriptor as the record carries it -- the same sampler on the same words)
+        const uint32_t p0 = S.pad[0], p1 = S.pad[1];
+        const DevTexDesc d{p0, p1 & 0x1FFFu, (p1 >> 13) & 0x1FFFu, (p1 >> 28) & 3u};
+        texel = sample_texture(d, texel_base(P, d), u, v, P.sample_mode, (p1 >> 26) & 3u);
+    } else texel = batch_texel<X>(P, B, u, v, world.x, world.z, &world);
     const float INV_255 = 1.0f / 255.0f;  // lib.rs:52
     f3 base = mk3(srgb_to_linear_fast((float)(texel & 0xFFu) * INV_255), srgb_to_linear_fast((float)((texel >> 8) & 0xFFu) * INV_255),
                   srgb_to_linear_fast((float)((texel >> 16) & 0xFFu) * INV_255));
     F.opacity = rxm::div1_known((float)(texel >> 24), 255.0f, true);  // :1313; byte / 255 is inside the division window
     if (lvl1<X> && B.baked_plus1) {  // chunk.shader_textures: the baked texel replaces colour and alpha, no program runs (:1239-1267)
-        const DevTexDesc &bd = P.tex[B.baked_plus1 - 1u];
-        uint32_t bt = sample_texture(bd, texel_base(P, bd), u, v, P.sample_mode, B.repeat_mode);
+        const DevTexDesc &baked = P.tex[B.baked_plus1 - 1u];
+        uint32_t bt = sample_texture(baked, texel_base(P, baked), u, v, P.sample_mode, B.repeat_mode);
         base = mk3(srgb_to_linear_fast((float)(bt & 0xFFu) * INV_255), srgb_to_linear_fast((float)((bt >> 8) & 0xFFu) * INV_255),
                    srgb_to_linear_fast((float)((bt >> 16) & 0xFFu) * INV_255));
         F.opacity = (float)(bt >> 24) * INV_255;  // execution.opacity.x = color.w of pixel_to_vec4 (:1262)
@@ -1339,6 +1354,20 @@ __device__ __forceinline__ bool make_setup(const RasterParams &P, uint32_t t, Tr
         for (int k = 0; k < 3; ++k) H.n0[k] = H.n1[k] = H.n2[k] = 0.0f;
     }
     H.pad[0] = H.pad[1] = 0;
+#if RXR_DESC_IN_TRISHADE
+    // The batch's texture descriptor rides in the record's two spare words (TS_DESC_VALID | w | h << 13 | repeat mode << 26 | the
+    // descriptor's two flag bits << 28; the texel offset in the other word): the shading pass goes from the winner's record -- whose
+    // load it has long issued -- straight to the texels, instead of batch header -> descriptor -> texels: two dependent round trips
+    // fewer in front of every texel (shade3d_begin).  Plain textures of at most 8191 x 8191 texels; everything else (constant pixels,
+    // terrain, larger textures) leaves the words zero and takes the header's way.
+    if (B.tex >= 0 && !(B.flags & DB_TERRAIN) && B.repeat_mode < 4u) {
+        const DevTexDesc d = P.tex[B.tex];
+        if (d.w - 1u < 8191u && d.h - 1u < 8191u) {
+            H.pad[0] = d.offset;
+            H.pad[1] = TS_DESC_VALID | d.w | (d.h << 13) | (B.repeat_mode << 26) | ((d.all_opaque & 3u) << 28);
+        }
+    }
+#endif
     // Bilinear sampling turns a NaN texture coordinate into NaN in EVERY channel (texture.rs:414-460: v00 + dx * (v10 - v00)), alpha
     // included, and `NaN as u8` is 0: such a fragment is not written (:1408) even when every texel of its texture is opaque -- the one
     // case in which a batch without DB_ALPHA_TEST needs the per-fragment test all the same.  A coordinate is NaN only when the
@@ -3395,6 +3424,15 @@ __device__ __forceinline__ void raster_tile(const RasterParams &P) {
         } else scan_lists<false, X>(P, stage, b0, b1, tile_x0, tile_y0px, px, py, fx, fy, vis, surf_profile, &op);
 
         PHASE_MARK(1);
+        // The opacity layer's colour and depth wait in LDS while the fragment is shaded (each thread its own two words of s_sort: the
+        // 2D pass has not begun, and row mode -- whose fragment queue lives there -- does not run in frames with an opacity pass): the
+        // shading code sits at the kernel's 64 registers, and values that are live across it without being used in it are what the
+        // compiler sends to scratch memory (4 bytes per pixel and frame for the colour alone, in frames that have no opacity pass at all).
+        static_assert(RXR_SORT2D_MAX >= 2 * RXR_TILE_THREADS, "two words per thread");
+        if (P.has_opacity) {  // (uniform)
+            s_sort[tid] = op_color;
+            s_sort[RXR_TILE_THREADS + tid] = __float_as_uint(op.best >= 0 ? op.zmin : 1.0f);
+        }
         // resolve (rasterizer.rs:409-497): hit -> shaded colour; miss -> [0,0,0,255]
         const bool hit = vis.best >= 0;
         Frag F;
@@ -3416,8 +3454,9 @@ __device__ __forceinline__ void raster_tile(const RasterParams &P) {
             if (P.has_brush && !hit) color = miss_brush_preview(P, px, py);  // :435-458
         }
         PHASE_MARK(4);
-        if (op.best >= 0 && op.zmin < 1.0f && vis.zmin > op.zmin) {  // :464-495
-            uint32_t src = op_color;
+        const float op_z = P.has_opacity ? __uint_as_float(s_sort[RXR_TILE_THREADS + tid]) : 1.0f;  // (1.0: no opacity fragment here)
+        if (op_z < 1.0f && vis.zmin > op_z) {  // :464-495
+            uint32_t src = s_sort[tid];
             float src_r = (float)(src & 0xFFu), src_g = (float)((src >> 8) & 0xFFu), src_b = (float)((src >> 16) & 0xFFu);
             float src_a = byte_over_255(src >> 24);
             float dst_r = (float)(color & 0xFFu), dst_g = (float)((color >> 8) & 0xFFu), dst_b = (float)((color >> 16) & 0xFFu);

@@ -319,7 +319,7 @@ def test_sparse_frames_take_their_row_spans_from_the_device_boxes(oracle, produc
     got = scenes.render(cfg).copy()
     assert np.array_equal(got, ref), f"{kind}: {(got != ref).any(axis=2).sum()} pixels differ"
     lib = product.lib
-    rxr = __import__("rusterix_amd").rxr_abi()
+    rxr = C.CDLL(__import__("rusterix_amd").lib_paths()["rxr"])   # (a handle of its own: the argtypes set below stay here)
     lib.rxh_context.restype = C.c_void_p
     info = (C.c_uint32 * 4)()
     assert rxr.rxr_debug_content(C.c_void_p(lib.rxh_context()), info) == 0
@@ -372,7 +372,7 @@ def test_pipelined_download_of_a_sparse_device_projected_frame(product, devproj,
     piped[...] = scenes.render(cfg)                 # Rasterizer::rasterize -> rxr_render_download
     assert np.array_equal(piped, want), f"{(piped != want).any(axis=2).sum()} pixels differ"
     lib = product.lib
-    rxr = __import__("rusterix_amd").rxr_abi()
+    rxr = C.CDLL(__import__("rusterix_amd").lib_paths()["rxr"])   # (a handle of its own: the argtypes set below stay here)
     lib.rxh_context.restype = C.c_void_p
     info = (C.c_uint32 * 4)()
     assert rxr.rxr_debug_content(C.c_void_p(lib.rxh_context()), info) == 0 and info[3] == 2, list(info)
