@@ -2241,10 +2241,6 @@ static int render_impl(rxr_ctx *ctx, const RenderSpec &spec, void *dev_pixels, h
         explicit TimesGuard(ProfSlot *p) { rxr_launch_times = p; }
         ~TimesGuard() { rxr_launch_times = nullptr; }
     } times_guard(slot);
-    for (int part = 0; part < 2; ++part) {  // the rows outside the content: the 3D miss colour [0, 0, 0, 255] (:420-461)
-        const uint32_t a = part ? fill_b0 : fill_a0, b = part ? fill_b1 : fill_a1;
-        if (a < b) rxr_launch_fill_words(P.out + (size_t)((int64_t)a - P.out_base_row) * P.out_row_stride, (uint64_t)(b - a) * P.out_row_stride, 0xFF000000u, s);
-    }
     // small scenes: one staging round of k_raster holds every triangle -> no set-up / binning launches at all
     const bool d3 = P.tiles_y && (P.flags & RXR_FLAG_D3_ACTIVE);
     P.fused_small = (d3 && P.n_tris3d <= RXR_STAGE_TRIS) ? ctx->small_mode : 0u;
@@ -2254,9 +2250,21 @@ static int render_impl(rxr_ctx *ctx, const RenderSpec &spec, void *dev_pixels, h
         if (P.fused_small == 2u) rxr_launch_setup(&P, s);  // records only; no counters, bins or lists are touched
     }
     use_spans = use_spans && rxr_raster_takes_spans(&P) != 0;  // (the kernel this launch gets must be one that looks the table up)
-    if (use_spans) {  // inside the content rows, the pixels to the left and right of each tile row's span
+    if (use_spans) {
+        // the pixels to the left and right of each tile row's span, and -- in the same launch: their spans are empty -- the rows above
+        // and below the content (one launch of 13 us where two fills of whole rows and one of row ends took 16 and two more gaps)
         P.row_spans = (const uint2 *)ctx->d_row_spans.p;
-        rxr_launch_fill_outside_spans(&P, s);
+        RasterParams Pf = P;
+        Pf.row0 = spec.row0;
+        Pf.row1 = spec.row1;
+        Pf.tile_y0 = spec.tile_y0;
+        Pf.tiles_y = spec.tiles_y;
+        rxr_launch_fill_outside_spans(&Pf, s);
+    } else {
+        for (int part = 0; part < 2; ++part) {  // the rows outside the content: the 3D miss colour [0, 0, 0, 255] (:420-461)
+            const uint32_t a = part ? fill_b0 : fill_a0, b = part ? fill_b1 : fill_a1;
+            if (a < b) rxr_launch_fill_words(P.out + (size_t)((int64_t)a - P.out_base_row) * P.out_row_stride, (uint64_t)(b - a) * P.out_row_stride, 0xFF000000u, s);
+        }
     }
     const bool prepass = d3 && !P.fused_small;
     // (device-projected frames: the spans are completed on the device, behind the projection -- see rxr_upload_frame)
