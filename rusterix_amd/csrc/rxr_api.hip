@@ -2727,31 +2727,110 @@ int rxr_render_download(rxr_ctx *ctx, uint8_t *pixels) {
             clipped = true;
         }
     }
+    // ... and inside the content rows the columns outside the tile rows' spans (host-projected frames: the table of rxr_upload_frame;
+    // device-projected ones: the table the device has just handed back) are the miss colour as well: each band travels as two strips of
+    // hipMemcpy2DAsync over the union of its tile rows' spans, the host writes what lies to the left and right.  Strips, not tile rows:
+    // a 2D copy costs about 13 us of its own (tools/microbench/copy2d.hip: 91 MB of whole rows 1.64 ms; the same trapezoid in 4 / 24 /
+    // 93 strips 1.18 / 1.33 / 2.05 ms).
+    struct Rect {
+        uint32_t r0, r1, x0, x1;  // pixel rows [r0, r1), pixel columns [x0, x1)
+    };
+    std::vector<Rect> fills, copies;
+    const uint32_t W = P.width;
+    if (clipped) {
+        fills.push_back({0u, c0, 0u, W});
+        fills.push_back({c1, H, 0u, W});
+    }
+    const uint2 *table = nullptr;
+    if (clipped) table = spans_back ? ctx->h_row_spans + RXR_MAX_TILE_ROWS : (ctx->spans_active ? ctx->h_row_spans : nullptr);
+    if (getenv("RXR_NO_COLUMN_TRIM")) table = nullptr;  // A-B runs, tests (read per call)
+    constexpr uint32_t n_sub = 2;
+    size_t trimmed_px = 0;
     for (uint32_t k = 0; k < n_bands; ++k) {
         const uint32_t a = std::max(row_of[k], c0), b = std::min(row_of[k + 1], c1);
-        HIPCHK(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev_band[k], 0));
         if (b <= a) continue;
-        const size_t off = (size_t)a * P.width * 4, bytes = (size_t)(b - a) * P.width * 4;
-        HIPCHK(ctx, hipMemcpyAsync(pixels + off, (uint8_t *)ctx->d_fb.p + off, bytes, hipMemcpyDeviceToHost, ctx->copy_stream));
+        const uint32_t ta = a / RXR_TILE_H, tb = (b + RXR_TILE_H - 1u) / RXR_TILE_H;   // tile rows of the band
+        for (uint32_t j = 0; j < (table ? n_sub : 1u); ++j) {
+            const uint32_t t0 = table ? ta + (tb - ta) * j / n_sub : ta, t1 = table ? ta + (tb - ta) * (j + 1u) / n_sub : tb;
+            const uint32_t r0 = std::max(a, t0 * (uint32_t)RXR_TILE_H), r1 = std::min(b, t1 * (uint32_t)RXR_TILE_H);
+            if (r1 <= r0) continue;
+            uint32_t x0 = 0u, x1 = W;
+            if (table) {
+                uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+                for (uint32_t t = t0; t < t1 && t < RXR_MAX_TILE_ROWS; ++t)
+                    if (table[t].x < table[t].y) {
+                        lo = std::min(lo, table[t].x);
+                        hi = std::max(hi, table[t].y);
+                    }
+                if (lo >= hi) {  // nothing in these rows at all
+                    fills.push_back({r0, r1, 0u, W});
+                    trimmed_px += (size_t)(r1 - r0) * W;
+                    continue;
+                }
+                x0 = std::min(lo * (uint32_t)RXR_TILE_W, W);
+                x1 = std::min(hi * (uint32_t)RXR_TILE_W, W);
+                if ((size_t)(x1 - x0) * 10u >= (size_t)W * 9u) {  // (nearly the whole width: one contiguous copy is cheaper than a strided one)
+                    x0 = 0u;
+                    x1 = W;
+                }
+                trimmed_px += (size_t)(r1 - r0) * (W - (x1 - x0));
+            }
+            copies.push_back({r0, r1, x0, x1});
+        }
     }
-    if (clipped) {
-        auto fill_rows = [&](uint32_t r0, uint32_t r1) {  // [0, 0, 0, 255] per pixel (:420-461), the caller's buffer may be unaligned: bytes
-            if (r1 <= r0) return;
-            const size_t n = (size_t)(r1 - r0) * P.width;
-            uint8_t *p = pixels + (size_t)r0 * P.width * 4;
-            const size_t n_threads = n >= (4u << 20) ? 4u : 1u;  // (a few helpers for tens of megabytes; the calling thread otherwise waits anyway)
-            std::vector<std::thread> helpers;
-            auto part = [p](size_t i0, size_t i1) {
-                if (((uintptr_t)p & 3u) == 0u) std::fill((uint32_t *)p + i0, (uint32_t *)p + i1, 0xFF000000u);
-                else
-                    for (size_t i = i0; i < i1; ++i) { p[4 * i] = 0; p[4 * i + 1] = 0; p[4 * i + 2] = 0; p[4 * i + 3] = 255; }
-            };
-            for (size_t t = 1; t < n_threads; ++t) helpers.emplace_back(part, n * t / n_threads, n * (t + 1) / n_threads);
-            part(0, n / n_threads);
-            for (std::thread &th : helpers) th.join();
+    if (table && trimmed_px < content_min_tiles() * (size_t)(RXR_TILE_W * RXR_TILE_H)) {  // (8 MB by default) not worth the strided copies and the fills: whole rows, as without a table
+        copies.clear();
+        fills.resize(clipped ? 2u : 0u);
+        for (uint32_t k = 0; k < n_bands; ++k) {
+            const uint32_t a = std::max(row_of[k], c0), b = std::min(row_of[k + 1], c1);
+            if (b > a) copies.push_back({a, b, 0u, W});
+        }
+    }
+    {
+        size_t ci = 0;
+        for (uint32_t k = 0; k < n_bands; ++k) {
+            HIPCHK(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev_band[k], 0));
+            for (; ci < copies.size() && copies[ci].r0 < row_of[k + 1]; ++ci) {  // (ascending rows; every strip lies inside one band)
+                const Rect &c = copies[ci];
+                const size_t off = ((size_t)c.r0 * W + c.x0) * 4;
+                if (c.x0 == 0u && c.x1 == W) {
+                    HIPCHK(ctx, hipMemcpyAsync(pixels + off, (uint8_t *)ctx->d_fb.p + off, (size_t)(c.r1 - c.r0) * W * 4, hipMemcpyDeviceToHost, ctx->copy_stream));
+                } else {
+                    HIPCHK(ctx, hipMemcpy2DAsync(pixels + off, (size_t)W * 4, (uint8_t *)ctx->d_fb.p + off, (size_t)W * 4, (size_t)(c.x1 - c.x0) * 4, c.r1 - c.r0,
+                                                 hipMemcpyDeviceToHost, ctx->copy_stream));
+                    fills.push_back({c.r0, c.r1, 0u, c.x0});
+                    fills.push_back({c.r0, c.r1, c.x1, W});
+                }
+            }
+        }
+    }
+    {
+        // [0, 0, 0, 255] per pixel (:420-461), written by this thread and a few helpers while the device renders and the link is busy; the
+        // caller's buffer may be unaligned: bytes then.  Rows are dealt round robin.
+        size_t n_px = 0;
+        for (const Rect &f : fills) n_px += f.r1 > f.r0 && f.x1 > f.x0 ? (size_t)(f.r1 - f.r0) * (f.x1 - f.x0) : 0u;
+        const uint32_t n_threads = n_px >= (12u << 20) ? 8u : (n_px >= (4u << 20) ? 4u : 1u);
+        auto part = [&fills, pixels, W](uint32_t me, uint32_t of) {
+            const bool aligned = ((uintptr_t)pixels & 3u) == 0u;
+            uint32_t turn = 0;
+            for (const Rect &f : fills) {
+                if (f.r1 <= f.r0 || f.x1 <= f.x0) continue;
+                for (uint32_t r = f.r0; r < f.r1; ++r, ++turn) {
+                    if (turn % of != me) continue;
+                    uint8_t *p = pixels + ((size_t)r * W + f.x0) * 4;
+                    const size_t n = f.x1 - f.x0;
+                    if (aligned) std::fill((uint32_t *)p, (uint32_t *)p + n, 0xFF000000u);
+                    else
+                        for (size_t i = 0; i < n; ++i) { p[4 * i] = 0; p[4 * i + 1] = 0; p[4 * i + 2] = 0; p[4 * i + 3] = 255; }
+                }
+            }
         };
-        fill_rows(0, c0);
-        fill_rows(c1, H);
+        if (n_px) {
+            std::vector<std::thread> helpers;
+            for (uint32_t t = 1; t < n_threads; ++t) helpers.emplace_back(part, t, n_threads);
+            part(0u, n_threads);
+            for (std::thread &th : helpers) th.join();
+        }
     }
     HIPCHK(ctx, hipStreamSynchronize(ctx->copy_stream));
     rc = rxr_synchronize(ctx);  // (program faults and list overflows are reported / repaired here)

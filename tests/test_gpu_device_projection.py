@@ -390,3 +390,14 @@ def test_pipelined_download_of_a_sparse_device_projected_frame(product, devproj,
     again = np.full_like(want, 9)                   # (every byte of the caller's buffer is written: by the link or by the host)
     assert rxr.rxr_render_download(ctx, again.ctypes.data_as(C.POINTER(C.c_uint8))) == 0
     assert np.array_equal(again, want)
+    # ... also when the columns outside the spans travel with the rows (RXR_NO_COLUMN_TRIM), and into an unaligned buffer (the host's
+    # fills then write bytes)
+    monkeypatch.setenv("RXR_NO_COLUMN_TRIM", "1")
+    whole_rows = np.full_like(want, 5)
+    assert rxr.rxr_render_download(ctx, whole_rows.ctypes.data_as(C.POINTER(C.c_uint8))) == 0
+    assert np.array_equal(whole_rows, want)
+    monkeypatch.delenv("RXR_NO_COLUMN_TRIM")
+    raw = np.full(want.size + 8, 3, np.uint8)
+    odd = raw[1:1 + want.size]
+    assert rxr.rxr_render_download(ctx, odd.ctypes.data_as(C.POINTER(C.c_uint8))) == 0
+    assert np.array_equal(odd.reshape(want.shape), want) and raw[0] == 3 and (raw[1 + want.size:] == 3).all()
