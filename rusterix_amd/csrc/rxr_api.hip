@@ -2786,6 +2786,38 @@ int rxr_render_download(rxr_ctx *ctx, uint8_t *pixels) {
             if (b > a) copies.push_back({a, b, 0u, W});
         }
     }
+    for (const Rect &c : copies)
+        if (!(c.x0 == 0u && c.x1 == W)) {
+            fills.push_back({c.r0, c.r1, 0u, c.x0});
+            fills.push_back({c.r0, c.r1, c.x1, W});
+        }
+    // [0, 0, 0, 255] per pixel (:420-461), written by helper threads while the device renders and the link is busy (they start BEFORE the
+    // copies are queued: a copy into pageable memory keeps the calling thread until it has landed); the caller's buffer may be unaligned:
+    // bytes then.  Rows are dealt round robin.
+    size_t n_px = 0;
+    for (const Rect &f : fills) n_px += f.r1 > f.r0 && f.x1 > f.x0 ? (size_t)(f.r1 - f.r0) * (f.x1 - f.x0) : 0u;
+    const uint32_t n_threads = n_px >= (12u << 20) ? 8u : (n_px >= (4u << 20) ? 4u : (n_px ? 1u : 0u));
+    auto part = [&fills, pixels, W](uint32_t me, uint32_t of) {
+        const bool aligned = ((uintptr_t)pixels & 3u) == 0u;
+        uint32_t turn = 0;
+        for (const Rect &f : fills) {
+            if (f.r1 <= f.r0 || f.x1 <= f.x0) continue;
+            for (uint32_t r = f.r0; r < f.r1; ++r, ++turn) {
+                if (turn % of != me) continue;
+                uint8_t *p = pixels + ((size_t)r * W + f.x0) * 4;
+                const size_t n = f.x1 - f.x0;
+                if (aligned) std::fill((uint32_t *)p, (uint32_t *)p + n, 0xFF000000u);
+                else
+                    for (size_t i = 0; i < n; ++i) { p[4 * i] = 0; p[4 * i + 1] = 0; p[4 * i + 2] = 0; p[4 * i + 3] = 255; }
+            }
+        }
+    };
+    std::vector<std::thread> helpers;
+    for (uint32_t t = 0; t < n_threads; ++t) helpers.emplace_back(part, t, n_threads);
+    struct JoinAll {  // (every return path below, errors included, waits for the helpers: they write the caller's buffer)
+        std::vector<std::thread> &h;
+        ~JoinAll() { for (std::thread &th : h) if (th.joinable()) th.join(); }
+    } join_all{helpers};
     {
         size_t ci = 0;
         for (uint32_t k = 0; k < n_bands; ++k) {
@@ -2798,40 +2830,11 @@ int rxr_render_download(rxr_ctx *ctx, uint8_t *pixels) {
                 } else {
                     HIPCHK(ctx, hipMemcpy2DAsync(pixels + off, (size_t)W * 4, (uint8_t *)ctx->d_fb.p + off, (size_t)W * 4, (size_t)(c.x1 - c.x0) * 4, c.r1 - c.r0,
                                                  hipMemcpyDeviceToHost, ctx->copy_stream));
-                    fills.push_back({c.r0, c.r1, 0u, c.x0});
-                    fills.push_back({c.r0, c.r1, c.x1, W});
                 }
             }
         }
     }
-    {
-        // [0, 0, 0, 255] per pixel (:420-461), written by this thread and a few helpers while the device renders and the link is busy; the
-        // caller's buffer may be unaligned: bytes then.  Rows are dealt round robin.
-        size_t n_px = 0;
-        for (const Rect &f : fills) n_px += f.r1 > f.r0 && f.x1 > f.x0 ? (size_t)(f.r1 - f.r0) * (f.x1 - f.x0) : 0u;
-        const uint32_t n_threads = n_px >= (12u << 20) ? 8u : (n_px >= (4u << 20) ? 4u : 1u);
-        auto part = [&fills, pixels, W](uint32_t me, uint32_t of) {
-            const bool aligned = ((uintptr_t)pixels & 3u) == 0u;
-            uint32_t turn = 0;
-            for (const Rect &f : fills) {
-                if (f.r1 <= f.r0 || f.x1 <= f.x0) continue;
-                for (uint32_t r = f.r0; r < f.r1; ++r, ++turn) {
-                    if (turn % of != me) continue;
-                    uint8_t *p = pixels + ((size_t)r * W + f.x0) * 4;
-                    const size_t n = f.x1 - f.x0;
-                    if (aligned) std::fill((uint32_t *)p, (uint32_t *)p + n, 0xFF000000u);
-                    else
-                        for (size_t i = 0; i < n; ++i) { p[4 * i] = 0; p[4 * i + 1] = 0; p[4 * i + 2] = 0; p[4 * i + 3] = 255; }
-                }
-            }
-        };
-        if (n_px) {
-            std::vector<std::thread> helpers;
-            for (uint32_t t = 1; t < n_threads; ++t) helpers.emplace_back(part, t, n_threads);
-            part(0u, n_threads);
-            for (std::thread &th : helpers) th.join();
-        }
-    }
+    for (std::thread &th : helpers) th.join();  // (before anything below can write the same bytes again: the repaired frame's download)
     HIPCHK(ctx, hipStreamSynchronize(ctx->copy_stream));
     rc = rxr_synchronize(ctx);  // (program faults and list overflows are reported / repaired here)
     if (rc != RXR_OK) return rc;
