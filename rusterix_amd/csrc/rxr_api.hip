@@ -2813,7 +2813,14 @@ int rxr_render_download(rxr_ctx *ctx, uint8_t *pixels) {
         }
     };
     std::vector<std::thread> helpers;
-    for (uint32_t t = 0; t < n_threads; ++t) helpers.emplace_back(part, t, n_threads);
+    helpers.reserve(n_threads);
+    for (uint32_t t = 0; t < n_threads; ++t) {
+        try {
+            helpers.emplace_back(part, t, n_threads);
+        } catch (...) {  // (no thread to be had: this share is written here and now -- nothing may leave through the C ABI)
+            part(t, n_threads);
+        }
+    }
     struct JoinAll {  // (every return path below, errors included, waits for the helpers: they write the caller's buffer)
         std::vector<std::thread> &h;
         ~JoinAll() { for (std::thread &th : h) if (th.joinable()) th.join(); }
