@@ -15,6 +15,8 @@
 #include <hip/hip_runtime.h>
 #include <hip/hiprtc.h>
 
+#include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -599,6 +601,171 @@ std::string job_parent(std::string &err) {
     }
     return parent;
 }
+// ---- the code objects on disk ----------------------------------------------------------------------------------------------
+// A compilation takes seconds, during which the interpreter renders; the same set in the NEXT process would wait for the same seconds
+// again.  Code objects are therefore also kept in a directory of this user -- RXR_JIT_CACHE_DIR (an absolute path), else
+// $XDG_CACHE_HOME/rusterix_amd/jit, else $HOME/.cache/rusterix_amd/jit; RXR_JIT_CACHE=0 switches it off -- under the rules of the job
+// directories: created 0700, a real directory owned by this user without group / other write bits (checked with lstat before every
+// use), files opened through the directory's descriptor with O_NOFOLLOW, regular files of this user only, written under a temporary
+// name and renamed.  A file holds the COMPLETE key material in front of the code object -- generated source, architecture, template
+// level, extra flags, a hash of the kernel sources this library embeds and the HIP version it was built with and runs on -- and is
+// only used when that material is byte-identical: the 128-bit file name merely finds it.  At most 64 files, the oldest go first.
+uint64_t fnv1a64(const void *data, size_t n, uint64_t h) {
+    const unsigned char *p = (const unsigned char *)data;
+    for (size_t i = 0; i < n; ++i) {
+        h ^= p[i];
+        h *= 0x100000001B3ull;
+    }
+    return h;
+}
+const std::string &disk_build_id() {
+    static const std::string id = [] {
+        uint64_t a = 0xCBF29CE484222325ull, b = 0x84222325CBF29CE4ull;
+        for (int i = 0; i < rxr_jit_n_headers; ++i) {
+            a = fnv1a64(rxr_jit_header_names[i], strlen(rxr_jit_header_names[i]) + 1, a);
+            a = fnv1a64(rxr_jit_header_sources[i], strlen(rxr_jit_header_sources[i]) + 1, a);
+            b = fnv1a64(rxr_jit_header_sources[i], strlen(rxr_jit_header_sources[i]) + 1, b * 31u + 7u);
+        }
+        int rt = 0;
+        (void)hipRuntimeGetVersion(&rt);  // (no device needed)
+        char buf[128];
+        snprintf(buf, sizeof buf, "sources %016llx%016llx hip-built %d.%d.%d hip-runtime %d", (unsigned long long)a, (unsigned long long)b, HIP_VERSION_MAJOR,
+                 HIP_VERSION_MINOR, HIP_VERSION_PATCH, rt);
+        return std::string(buf);
+    }();
+    return id;
+}
+bool private_dir(const std::string &path) {
+    struct stat st;
+    return lstat(path.c_str(), &st) == 0 && S_ISDIR(st.st_mode) && st.st_uid == geteuid() && (st.st_mode & 022) == 0;
+}
+// "" = no cache (switched off, no usable place)
+std::string disk_cache_dir() {
+    if (const char *off = getenv("RXR_JIT_CACHE")) {
+        if (off[0] == '0') return "";
+    }
+    std::vector<std::string> chain;  // directories to create if missing, outermost first; the last one is the cache
+    if (const char *d = getenv("RXR_JIT_CACHE_DIR")) {
+        if (d[0] != '/') return "";
+        chain = {d};
+    } else {
+        std::string base;
+        const char *xdg = getenv("XDG_CACHE_HOME"), *home = getenv("HOME");
+        if (xdg && xdg[0] == '/') base = xdg;
+        else if (home && home[0] == '/') base = std::string(home) + "/.cache";
+        else return "";
+        chain = {base, base + "/rusterix_amd", base + "/rusterix_amd/jit"};
+    }
+    for (const std::string &c : chain)
+        if (mkdir(c.c_str(), 0700) != 0 && errno != EEXIST) return "";
+    return private_dir(chain.back()) ? chain.back() : "";
+}
+std::string disk_material(const std::string &key) { return "rxr-jit-cache-1\n" + disk_build_id() + "\n" + key; }
+std::string disk_name(const std::string &material) {
+    char buf[48];
+    snprintf(buf, sizeof buf, "%016llx%016llx.rxrco", (unsigned long long)fnv1a64(material.data(), material.size(), 0xCBF29CE484222325ull),
+             (unsigned long long)fnv1a64(material.data(), material.size(), 0x9E3779B97F4A7C15ull));
+    return buf;
+}
+constexpr char DISK_MAGIC[8] = {'R', 'X', 'R', 'J', 'I', 'T', '0', '1'};
+bool disk_get(const std::string &key, std::vector<char> &obj) {
+    const std::string dir = disk_cache_dir();
+    if (dir.empty()) return false;
+    const std::string material = disk_material(key);
+    const int dfd = open(dir.c_str(), O_RDONLY | O_DIRECTORY | O_NOFOLLOW | O_CLOEXEC);
+    if (dfd < 0) return false;
+    const int fd = openat(dfd, disk_name(material).c_str(), O_RDONLY | O_NOFOLLOW | O_CLOEXEC);
+    bool ok = false;
+    if (fd >= 0) {
+        struct stat st;
+        const size_t head = sizeof DISK_MAGIC + sizeof(uint64_t) + material.size();
+        if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_uid == geteuid() && (st.st_mode & 022) == 0 && (size_t)st.st_size > head &&
+            (size_t)st.st_size < head + (256u << 20)) {
+            std::vector<char> all((size_t)st.st_size);
+            size_t got = 0;
+            while (got < all.size()) {
+                const ssize_t n = read(fd, all.data() + got, all.size() - got);
+                if (n <= 0) break;
+                got += (size_t)n;
+            }
+            uint64_t mlen = 0;
+            if (got == all.size() && memcmp(all.data(), DISK_MAGIC, sizeof DISK_MAGIC) == 0) {
+                memcpy(&mlen, all.data() + sizeof DISK_MAGIC, sizeof mlen);
+                if (mlen == material.size() && memcmp(all.data() + sizeof DISK_MAGIC + sizeof mlen, material.data(), material.size()) == 0) {
+                    obj.assign(all.begin() + head, all.end());
+                    ok = !obj.empty();
+                    (void)futimens(fd, nullptr);  // (recently used: the pruning below removes the oldest)
+                }
+            }
+        }
+        close(fd);
+    }
+    close(dfd);
+    return ok;
+}
+void disk_put(const std::string &key, const std::vector<char> &obj) {
+    const std::string dir = disk_cache_dir();
+    if (dir.empty() || obj.empty()) return;
+    const std::string material = disk_material(key), name = disk_name(material);
+    const int dfd = open(dir.c_str(), O_RDONLY | O_DIRECTORY | O_NOFOLLOW | O_CLOEXEC);
+    if (dfd < 0) return;
+    static std::atomic<unsigned> counter{0};
+    char tmp[96];
+    snprintf(tmp, sizeof tmp, "%.40s.tmp-%ld-%u", name.c_str(), (long)getpid(), counter.fetch_add(1u));
+    const int fd = openat(dfd, tmp, O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW | O_CLOEXEC, 0600);
+    if (fd >= 0) {
+        const uint64_t mlen = material.size();
+        auto put = [&](const void *p, size_t n) {
+            const char *c = (const char *)p;
+            while (n) {
+                const ssize_t w = write(fd, c, n);
+                if (w <= 0) return false;
+                c += w;
+                n -= (size_t)w;
+            }
+            return true;
+        };
+        const bool ok = put(DISK_MAGIC, sizeof DISK_MAGIC) && put(&mlen, sizeof mlen) && put(material.data(), material.size()) && put(obj.data(), obj.size());
+        close(fd);
+        if (!ok || renameat(dfd, tmp, dfd, name.c_str()) != 0) (void)unlinkat(dfd, tmp, 0);
+    }
+    // at most 64 code objects (and no temporary of a writer that died an hour ago)
+    if (DIR *d = fdopendir(dup(dfd))) {
+        std::vector<std::pair<time_t, std::string>> files;
+        const time_t now = time(nullptr);
+        while (dirent *e = readdir(d)) {
+            const size_t len = strlen(e->d_name);
+            struct stat st;
+            if (fstatat(dfd, e->d_name, &st, AT_SYMLINK_NOFOLLOW) != 0 || !S_ISREG(st.st_mode) || st.st_uid != geteuid()) continue;
+            if (len > 6 && !strcmp(e->d_name + len - 6, ".rxrco")) files.push_back({st.st_mtime, e->d_name});
+            else if (strstr(e->d_name, ".rxrco.tmp-") && now - st.st_mtime > 3600) (void)unlinkat(dfd, e->d_name, 0);
+        }
+        closedir(d);
+        if (files.size() > 64u) {
+            std::sort(files.begin(), files.end());
+            for (size_t i = 0; i + 64u < files.size(); ++i) (void)unlinkat(dfd, files[i].second.c_str(), 0);
+        }
+    }
+    close(dfd);
+}
+// memory first, then the disk (what is found there moves into memory)
+bool cached_object(const std::string &key, std::vector<char> *obj) {
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        auto it = g_code_objects.find(key);
+        if (it != g_code_objects.end()) {
+            if (obj) *obj = it->second;
+            return true;
+        }
+    }
+    std::vector<char> from_disk;
+    if (!disk_get(key, from_disk)) return false;
+    if (obj) *obj = from_disk;
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    g_code_objects[key].swap(from_disk);
+    return true;
+}
+
 // this process's PID namespace (two containers that share a /tmp each have a process 1234: a pid says nothing across them)
 unsigned long long pid_namespace() {
     struct stat st;
@@ -781,10 +948,7 @@ bool start_child_locked(const std::string &key, const std::string &gen, const st
 // 1: the code object is in the cache now; 0: not yet (still compiling, or waiting for a slot); -1: failed (err)
 int poll_background(rxr_ctx *ctx, int slot, int level, std::string &err) {
     const std::string key = cache_key(ctx->jit_arch, level, ctx->jit_source);
-    {
-        std::lock_guard<std::mutex> lk(g_cache_mu);
-        if (g_code_objects.count(key)) return 1;
-    }
+    if (cached_object(key, nullptr)) return 1;  // (this process's, or an earlier process's on disk: no child then)
     std::lock_guard<std::mutex> lk(g_bg_mu);
     auto failed = g_bg_failed.find(key);
     if (failed != g_bg_failed.end()) {
@@ -902,14 +1066,7 @@ bool rxr_jit_compile(const std::string &gen, const std::string &arch, int level,
     seconds = 0.0;
     const char *flags_env = getenv("RXR_JIT_FLAGS");
     const std::string key = cache_key(arch, level, gen);
-    {
-        std::lock_guard<std::mutex> lk(g_cache_mu);
-        auto it = g_code_objects.find(key);
-        if (it != g_code_objects.end()) {
-            obj = it->second;
-            return true;
-        }
-    }
+    if (cached_object(key, &obj)) return true;
     const Rtc &R = rtc();
     if (!R.ok) {
         err = R.why;
@@ -961,6 +1118,7 @@ bool rxr_jit_compile(const std::string &gen, const std::string &arch, int level,
     obj.resize(n);
     (void)R.GetCode(prog, obj.data());
     (void)R.DestroyProgram(&prog);
+    disk_put(key, obj);  // (the background child comes through here: the next process finds what it compiled)
     std::lock_guard<std::mutex> lk(g_cache_mu);
     g_code_objects[key] = obj;
     return true;

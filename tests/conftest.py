@@ -7,6 +7,9 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# compiled program sets are also kept on disk between processes (rxr_jit.hip): the tests want every run to start from nothing
+# (tests/test_shader_jit_cpu.py switches the cache on, in a directory of its own)
+os.environ.setdefault("RXR_JIT_CACHE", "0")
 
 
 def pytest_configure(config):

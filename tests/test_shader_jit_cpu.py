@@ -107,6 +107,61 @@ def test_the_background_compiler_is_a_process_that_turns_a_source_file_into_a_co
     assert pr.returncode != 0 and not bad.exists()
 
 
+def test_code_objects_outlive_the_process_that_compiled_them(tmp_path):
+    """Compiled sets are kept on disk (rxr_jit.hip: RXR_JIT_CACHE_DIR / $XDG_CACHE_HOME / $HOME/.cache, RXR_JIT_CACHE=0 = off): the same set
+    in the NEXT process is answered from the file -- the identical code object, in a fraction of the compile time -- and a file that was
+    tampered with, a cache directory that others may write to, or a different set are not."""
+    import os
+    import subprocess
+    import time
+
+    rc, src, msg = generate([Program([["Color", ("Push", 0.5), "Mul", "SetColor"]])], 0)
+    assert rc == 0, msg
+    lib = rusterix_amd.lib_paths()["rxr"]
+    exe = os.path.join(os.path.dirname(lib), "rxr_jitc")
+    cache = tmp_path / "cache"
+    source = tmp_path / "set.h"
+    source.write_text(src)
+    env = dict(os.environ, RXR_JIT_CACHE="1", RXR_JIT_CACHE_DIR=str(cache))
+
+    def run(out, **more):
+        t0 = time.time()
+        pr = subprocess.run([exe, lib, str(source), "gfx950", "8", str(out)], capture_output=True, text=True, timeout=300, env=dict(env, **more))
+        assert pr.returncode == 0, pr.stderr
+        return time.time() - t0, out.read_bytes()
+
+    t_first, first = run(tmp_path / "a.co")
+    files = [f for f in os.listdir(cache) if f.endswith(".rxrco")]
+    assert len(files) == 1 and (os.stat(cache).st_mode & 0o777) == 0o700 and (os.stat(cache / files[0]).st_mode & 0o777) == 0o600
+    assert not [f for f in os.listdir(cache) if ".tmp-" in f]
+    t_again, again = run(tmp_path / "b.co")
+    assert again == first and t_again < max(1.0, t_first / 3), (t_first, t_again)       # (from the file: no compilation)
+    # a different set: its own entry
+    source.write_text(src.replace("0.5", "0.25") if "0.5" in src else src + "\n// other\n")
+    _, other = run(tmp_path / "c.co")
+    assert len([f for f in os.listdir(cache) if f.endswith(".rxrco")]) == 2
+    source.write_text(src)
+    # a tampered file (one byte of the key material in front of the code object changed): not used, compiled again and replaced
+    path = cache / files[0]
+    blob = bytearray(path.read_bytes())
+    blob[40] ^= 1
+    path.write_bytes(bytes(blob))
+    t_fixed, fixed = run(tmp_path / "d.co")
+    assert fixed == first and t_fixed > t_again * 2, (t_again, t_fixed)
+    assert path.read_bytes()[:8] == b"RXRJIT01" and path.read_bytes() != bytes(blob)
+    # a directory that group / others may write to is not trusted: nothing is read from it, nothing written to it
+    loose = tmp_path / "loose"
+    loose.mkdir()
+    os.chmod(loose, 0o777)
+    t_loose, out_loose = run(tmp_path / "e.co", RXR_JIT_CACHE_DIR=str(loose))
+    assert out_loose == first and os.listdir(loose) == [] and t_loose > t_again * 2
+    # switched off: the directory stays as it is
+    before = sorted(os.listdir(cache))
+    os.remove(path)
+    run(tmp_path / "f.co", RXR_JIT_CACHE="0")
+    assert sorted(os.listdir(cache)) == sorted(set(before) - {files[0]})
+
+
 
 def test_the_background_compiler_starts_without_a_gpu_and_without_the_parents_tool_libraries(tmp_path, monkeypatch):
     """The compile-only child must be GPU-free by construction (round-3 verdict): under a profiler the parent's environment preloads
