@@ -488,7 +488,8 @@ std::vector<int> g_devices;  // more than one entry: rxr_create_multi
 std::string g_error;
 uint64_t g_tex_static_gen = 0, g_tex_dynamic_gen = 0;
 uint64_t g_shaders_gen = 0, g_shader_env_gen = 0;
-bool g_device_projection = false;
+// (RXR_DEVICE_PROJECTION=1 in the environment makes device projection the initial choice, as in the Rust shim: shim/.../lib.rs)
+bool g_device_projection = [] { const char *e = getenv("RXR_DEVICE_PROJECTION"); return e && e[0] == '1'; }();
 bool g_device_edges = !(getenv("RXR_HOST_EDGES") && atoi(getenv("RXR_HOST_EDGES")) != 0);
 // the form this thread's current frame takes across the ABI (every 3D batch of a frame the same: rxr.h): without Edges records, unless the
 // setting says otherwise or the page-locked streaming hand-over can only be promised for the records (see Rasterizer::upload)
