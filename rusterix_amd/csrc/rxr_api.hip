@@ -2741,8 +2741,9 @@ int rxr_render_download(rxr_ctx *ctx, uint8_t *pixels) {
         fills.push_back({0u, c0, 0u, W});
         fills.push_back({c1, H, 0u, W});
     }
-    const uint2 *table = nullptr;
-    if (clipped) table = spans_back ? ctx->h_row_spans + RXR_MAX_TILE_ROWS : (ctx->spans_active ? ctx->h_row_spans : nullptr);
+    // (the table says where anything CAN be drawn whether or not the launches above used it: a frame whose content reaches from the
+    // first row to the last is not clamped in rows, but its row ends are still the miss colour)
+    const uint2 *table = spans_back ? ctx->h_row_spans + RXR_MAX_TILE_ROWS : (ctx->spans_active && ctx->content_known ? ctx->h_row_spans : nullptr);
     if (getenv("RXR_NO_COLUMN_TRIM")) table = nullptr;  // A-B runs, tests (read per call)
     constexpr uint32_t n_sub = 2;
     size_t trimmed_px = 0;
@@ -2812,6 +2813,9 @@ int rxr_render_download(rxr_ctx *ctx, uint8_t *pixels) {
             }
         }
     };
+    ctx->last_download_bytes = 0;
+    for (const Rect &c : copies) ctx->last_download_bytes += (uint64_t)(c.r1 - c.r0) * (c.x1 - c.x0) * 4u;
+    ctx->last_host_fill_bytes = (uint64_t)n_px * 4u;
     std::vector<std::thread> helpers;
     helpers.reserve(n_threads);
     for (uint32_t t = 0; t < n_threads; ++t) {
@@ -3505,6 +3509,13 @@ extern "C" void rxr_debug_tile_spans(const float *lo, const float *extent, uint3
         if (quick) rxr_ref_tile_span_quick(lo[i], extent[i], size, ts, pad, out[2 * i], out[2 * i + 1]);
         else rxr_ref_tile_span(lo[i], extent[i], size, ts, pad, out[2 * i], out[2 * i + 1]);
     }
+}
+// tests: what the last banded rxr_render_download sent over PCIe and what the host wrote itself (bytes)
+extern "C" int rxr_debug_download_bytes(rxr_ctx *ctx, uint64_t *out2) {
+    if (!ctx || ctx->group || !out2) return -1;
+    out2[0] = ctx->last_download_bytes;
+    out2[1] = ctx->last_host_fill_bytes;
+    return 0;
 }
 extern "C" int rxr_debug_stream_info(rxr_ctx *ctx) { return (ctx && !ctx->group) ? ctx->last_upload_streamed : -1; }
 

@@ -227,6 +227,7 @@ struct rxr_ctx {
     DevBuf d_row_spans;
     bool spans_active = false;
     bool dev_spans = false;          // device-projected meshes: the table is completed on the device behind the projection (k_spans_from_meshes)
+    uint64_t last_download_bytes = 0, last_host_fill_bytes = 0;  // the last banded rxr_render_download: over PCIe / written by the host (tests)
     RasterParams P{};       // template for the resident frame (pointers resolved)
     uint32_t n_tris2d = 0;
 

@@ -390,6 +390,9 @@ def test_pipelined_download_of_a_sparse_device_projected_frame(product, devproj,
     again = np.full_like(want, 9)                   # (every byte of the caller's buffer is written: by the link or by the host)
     assert rxr.rxr_render_download(ctx, again.ctypes.data_as(C.POINTER(C.c_uint8))) == 0
     assert np.array_equal(again, want)
+    sent = (C.c_uint64 * 2)()
+    assert rxr.rxr_debug_download_bytes(ctx, sent) == 0
+    assert sent[0] + sent[1] == want.nbytes and 0 < sent[0] < 0.5 * want.nbytes, list(sent)
     # ... also when the columns outside the spans travel with the rows (RXR_NO_COLUMN_TRIM), and into an unaligned buffer (the host's
     # fills then write bytes)
     monkeypatch.setenv("RXR_NO_COLUMN_TRIM", "1")
@@ -401,3 +404,67 @@ def test_pipelined_download_of_a_sparse_device_projected_frame(product, devproj,
     odd = raw[1:1 + want.size]
     assert rxr.rxr_render_download(ctx, odd.ctypes.data_as(C.POINTER(C.c_uint8))) == 0
     assert np.array_equal(odd.reshape(want.shape), want) and raw[0] == 3 and (raw[1 + want.size:] == 3).all()
+
+
+def _column_scene(api, width=2304, height=1832):
+    """a column of 240 small boxes (y = -7 .. 3) from below the bottom edge of the frame to above its top edge: content in EVERY tile row, in a fifth
+    of the tile columns -- no rows to clamp, only row ends"""
+    tmpl = api.Batch3D.from_box(0.0, 0.0, 0.0, 0.1, 0.1, 0.1)
+    tv, ti, tuv, _ = tmpl.geometry()
+    rng = np.random.default_rng(5)
+    scene = api.Scene.empty()
+    for b in range(4):
+        vs, is_, uvs = [], [], []
+        for k in range(60):
+            v = tv.copy()
+            v[:, 0] += np.float32(rng.uniform(-0.25, 0.25))
+            v[:, 1] += np.float32(-7.0 + (10.0 / 240.0) * (b * 60 + k))   # (the orbit camera looks down: the column has to start far below)
+            v[:, 2] += np.float32(rng.uniform(-0.25, 0.25))
+            vs.append(v)
+            is_.append(ti + np.uint32(24 * k))
+            uvs.append(tuv)
+        batch = api.Batch3D.new(np.concatenate(vs), np.concatenate(is_), np.concatenate(uvs))
+        scene.add_d3_static(batch.source(B.PixelSource.StaticTileIndex(b % 2)).repeat_mode(B.REPEAT_REPEAT_XY).with_computed_normals())
+    assets = api.Assets.default().textures([B.Tile.from_texture(scenes.noise_texture(300 + k)) for k in range(2)])
+    cam = api.D3OrbitCamera.new()
+    cam.center = (0.0, 0.0, 0.0)
+    cam.distance = 3.0
+
+    def setup():
+        v, p = cam.matrices(float(width), float(height))
+        return api.Rasterizer.setup(None, v, p).ambient((1.0, 1.0, 1.0, 1.0))
+
+    return scenes._result(api, scene, assets, setup, width, height, 40, "column")
+
+
+@pytest.mark.parametrize("device_projected", [False, True])
+def test_pipelined_download_trims_row_ends_of_a_frame_without_empty_rows(oracle, product, devproj, device_projected, monkeypatch):
+    """content in every tile row but in few tile columns: nothing to clamp in rows, yet only the strips inside the row spans cross PCIe and
+    the host writes the row ends -- equal to the oracle's frame and to the download of whole rows, in both projection modes"""
+    import ctypes as C
+
+    monkeypatch.setenv("RXR_CONTENT_MIN_TILES", "0")
+    ref = scenes.render(_column_scene(oracle))
+    hit = got_cols = (ref[..., :3].max(axis=2) > 0)
+    rows_hit = hit.any(axis=1)
+    assert rows_hit[:16].any() and rows_hit[-16:].any(), "the column does not reach the first and the last tile row: the test tests nothing"
+    assert got_cols.any(axis=0).mean() < 0.5
+    (devproj.on if device_projected else devproj.off)()
+    cfg = _column_scene(product)
+    piped = np.full_like(ref, 7)
+    piped[...] = scenes.render(cfg)
+    assert np.array_equal(piped, ref), f"{(piped != ref).any(axis=2).sum()} pixels differ"
+    rxr = C.CDLL(__import__("rusterix_amd").lib_paths()["rxr"])
+    product.lib.rxh_context.restype = C.c_void_p
+    info = (C.c_uint32 * 4)()
+    assert rxr.rxr_debug_content(C.c_void_p(product.lib.rxh_context()), info) == 0
+    assert info[3] == (2 if device_projected else 1), list(info)
+    sent = (C.c_uint64 * 2)()
+    assert rxr.rxr_debug_download_bytes(C.c_void_p(product.lib.rxh_context()), sent) == 0
+    assert sent[0] + sent[1] == ref.nbytes and sent[0] < 0.6 * ref.nbytes, list(sent)   # (the strips: a part of every row)
+    monkeypatch.setenv("RXR_NO_COLUMN_TRIM", "1")
+    whole = np.full_like(ref, 9)
+    whole[...] = scenes.render(cfg)
+    assert np.array_equal(whole, ref)
+    assert rxr.rxr_debug_download_bytes(C.c_void_p(product.lib.rxh_context()), sent) == 0
+    assert sent[0] == ref.nbytes and sent[1] == 0, list(sent)                          # (no empty rows: everything travels)
