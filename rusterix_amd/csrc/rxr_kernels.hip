@@ -2908,7 +2908,10 @@ __device__ __forceinline__ void scan_lists_rows(const RasterParams &P, Stage &st
         __syncthreads();
         // 4. the rows of the candidates' boxes, or the walk
         PHASE_MARK(1);
-        constexpr bool pixel_items = (RXR_ROWS_PIXEL_ITEMS != 0) && (X < 2 || X == 8);
+#ifndef RXR_ROWS_PIXEL_ITEMS_VM
+#define RXR_ROWS_PIXEL_ITEMS_VM 1   // (0: the interpreter kernel of plain program sets keeps row items, as until the end of round 4 -- A-B runs)
+#endif
+        constexpr bool pixel_items = (RXR_ROWS_PIXEL_ITEMS != 0) && (X < 2 || X == 8 || ((X == 9 || X == 6 || X == 7) && RXR_ROWS_PIXEL_ITEMS_VM != 0));
         if (row_mode && rows_round<true, pixel_items, RXR_TILE_H, pixel_items && (RXR_ROWS_COMPACT != 0)>(P, st, rl, n, tile_x0, tile_y0px, queue)) {
             PHASE_MARK(7);
             continue;
