@@ -2469,8 +2469,10 @@ static_assert(RXR_ROWS_RING * 4u * (RXR_TILE_THREADS / 64) <= RXR_SORT2D_MAX * 4
 #define RXR_ROWS_PIXEL_ITEMS 1
 #endif
 // INDIRECT: candidate k's record is st.tri[rl.slot[k] * 6] (scan_lists_rows) instead of st.tri[k * 6]
-// PIX: pixel items (above); false = one item per row with an x loop, which the interpreter kernels keep (their register budget is
-// spent on the interpreter: pixel items cost k_raster_vm_sv 3-4 % on the 1 M-triangle grid while they save k_raster_rows 9 %)
+// PIX: pixel items (above); false = one item per row with an x loop, which the interpreter kernels with programs in their visibility
+// loop keep (levels 2 - 5).  The others (6 / 7 / 9) take pixel items WITH the compaction since the end of round 4: pixel items alone had
+// cost k_raster_vm_sv 3-4 % on the 1 M-triangle grid in round 3 (its register budget is spent on the interpreter); as 4-pixel runs with
+// the per-wave rings they save k_raster_vm_p 7 % and k_raster_vm_sv 6 % (scan_lists_rows, RXR_ROWS_PIXEL_ITEMS_VM)
 template <bool INDIRECT, bool PIX, uint32_t TH = RXR_TILE_H, bool COMPACT = false>
 __device__ RXR_ROWS_INLINE bool rows_round(const RasterParams &P, Stage &st, RowLdsT<TH> &rl, uint32_t n, uint32_t tile_x0, uint32_t tile_y0px,
                                            uint32_t *queue = nullptr) {
