@@ -3433,8 +3433,10 @@ __device__ __forceinline__ void raster_tile(const RasterParams &P) {
         // 2D pass has not begun, and row mode -- whose fragment queue lives there -- does not run in frames with an opacity pass): the
         // shading code sits at the kernel's 64 registers, and values that are live across it without being used in it are what the
         // compiler sends to scratch memory (4 bytes per pixel and frame for the colour alone, in frames that have no opacity pass at all).
+        // (not in the level-1 kernels: k_raster_chunk[_rl] answered with MORE scratch -- 6 -> 20 spill instructions -- and ran 1.4 % slower)
         static_assert(RXR_SORT2D_MAX >= 2 * RXR_TILE_THREADS, "two words per thread");
-        if (P.has_opacity) {  // (uniform)
+        constexpr bool PARK_OPACITY = X != 1;
+        if (PARK_OPACITY && P.has_opacity) {  // (uniform)
             s_sort[tid] = op_color;
             s_sort[RXR_TILE_THREADS + tid] = __float_as_uint(op.best >= 0 ? op.zmin : 1.0f);
         }
@@ -3459,9 +3461,14 @@ __device__ __forceinline__ void raster_tile(const RasterParams &P) {
             if (P.has_brush && !hit) color = miss_brush_preview(P, px, py);  // :435-458
         }
         PHASE_MARK(4);
-        const float op_z = P.has_opacity ? __uint_as_float(s_sort[RXR_TILE_THREADS + tid]) : 1.0f;  // (1.0: no opacity fragment here)
+        float op_z = 1.0f;  // (1.0: no opacity fragment here)
+        if constexpr (PARK_OPACITY) {
+            if (P.has_opacity) op_z = __uint_as_float(s_sort[RXR_TILE_THREADS + tid]);
+        } else {
+            if (op.best >= 0) op_z = op.zmin;
+        }
         if (op_z < 1.0f && vis.zmin > op_z) {  // :464-495
-            uint32_t src = s_sort[tid];
+            uint32_t src = PARK_OPACITY ? s_sort[tid] : op_color;
             float src_r = (float)(src & 0xFFu), src_g = (float)((src >> 8) & 0xFFu), src_b = (float)((src >> 16) & 0xFFu);
             float src_a = byte_over_255(src >> 24);
             float dst_r = (float)(color & 0xFFu), dst_g = (float)((color >> 8) & 0xFFu), dst_b = (float)((color >> 16) & 0xFFu);
