@@ -2419,8 +2419,13 @@ __device__ __forceinline__ uint32_t z_order_bits(float z) {
 #ifndef RXR_ROWS_OWNER_DIRECT
 #define RXR_ROWS_OWNER_DIRECT 1  // (0: the chunk owners by binary search behind a barrier of their own -- A-B measurements)
 #endif
+// A round goes to the pixel-parallel walk when its candidates' clipped boxes average more than this many pixels (a whole tile is 256: at 256
+// no round of candidates without cut-outs does).  128 until the end of round 4, chosen when row mode still ran every box pixel through
+// bary_depth; with the fragment compaction row mode also wins on LARGE triangles -- A-B-A-B 128 against 256: the teapot 25.2 -> 24.6 us,
+// the reduced box grid 43.8 -> 41.5, the lattice seen from among its boxes (tools/run_configs.py near:0.8 / 2 / 4) 71.8 -> 68.4 / 66.5 ->
+// 62.8 / 55.9 -> 52.4, the 1 M-triangle grid unchanged; 64: 475-487 us there against 411-425 (profiles/r04/row_mode_area_threshold_abab.txt)
 #ifndef RXR_ROW_MODE_MAX_AREA
-#define RXR_ROW_MODE_MAX_AREA 128
+#define RXR_ROW_MODE_MAX_AREA 256
 #endif
 // Fragment compaction (north-star: "wavefront ballot/prefix-sum for fragment compaction").  A candidate covers a third of its
 // clipped pixel box on the 1 M-triangle grid (measured on the scene: 34 candidates, 1 880 box pixels and 700 fragments per non-empty

@@ -48,6 +48,8 @@ def config(api, name):
                 "m20": ["Color"] + ["Color", "Mul"] * 20 + ["SetColor"]}[kind]
         scenes.box_grid_shader = lambda: B.Program([body])
         return scenes.box_grid_scene(api, n=96, width=1920, height=1080, shader=True)
+    if name.startswith("near:"):  # the box lattice seen from among its boxes: binned scenes of LARGE triangles (row mode's other end); near:<distance>
+        return scenes.box_grid_scene(api, n=48, width=1920, height=1080, distance=float(name.split(":", 1)[1]))
     if name == "D2":  # 2D tile map: 60 x 34 textured / translucent rectangles + overlays + lines, render_2d mode
         return scenes.tile_map_2d_scene(api, width=1920, height=1080, nx=60, ny=34)
     raise SystemExit(f"unknown config {name}")
