@@ -2488,7 +2488,9 @@ __device__ RXR_ROWS_INLINE bool rows_round(const RasterParams &P, Stage &st, Row
     bool alpha_test = false;
     if (tid < n) {
         const TriSetup &R = *reinterpret_cast<const TriSetup *>(&st.tri[(INDIRECT ? rl.slot[tid] : tid) * 6u]);
-        alpha_test = (R.bflags & (DB_ALPHA_TEST | DB_FULL_ALPHA)) != 0;
+        // (a candidate with a profile id in a frame with an opacity pass: its fragments are skipped where the opacity layer carries the same id
+        // -- a per-pixel question the drain does not ask; such rounds are left to the walk as well)
+        alpha_test = (R.bflags & (DB_ALPHA_TEST | DB_FULL_ALPHA)) != 0 || (P.has_opacity && (R.bflags & DB_HAS_PROFILE));
         if (!(R.bflags & DB_OPACITY_LIST)) {
             const uint32_t x0 = max(R.bx & 0xFFFFu, tile_x0), x1 = min(R.bx >> 16, tile_x0 + RXR_TILE_W);
             const uint32_t y0 = max(R.by & 0xFFFFu, tile_y0px), y1 = min(R.by >> 16, tile_y0px + TH);
@@ -2559,7 +2561,7 @@ __device__ RXR_ROWS_INLINE bool rows_round(const RasterParams &P, Stage &st, Row
             W.bx = __float_as_uint(acx);
             W.by = __float_as_uint(acy);
             W.bflags = __float_as_uint(r);
-            if constexpr (COMPACT) W.profile_id = st.ids[tl];  // (row mode never reads the profile: no opacity pass ran) the queue names records
+            if constexpr (COMPACT) W.profile_id = st.ids[tl];  // (row mode never reads the profile: no candidate of the round has one that matters) the queue names records
         }
 #endif
         // first owner of every 64-item chunk (area_total <= 128 * 128: at most 256 chunks): item 64 c belongs to the one candidate
@@ -2823,7 +2825,10 @@ __device__ __forceinline__ void scan_lists(const RasterParams &P, Stage &st, uin
             }
             if (keep) {
                 const TriSetup &R = P.tri_setup[id];
-                if (tile_outside_edges(R.ea, R.eb, R.ec, tile_x0, tile_y0px)) keep = false;
+                // (the opacity pass only ever takes candidates of the opacity lists -- visit() -- : the others need not be staged and walked
+                // by every pixel to find that out)
+                if (OPACITY && !(R.bflags & DB_OPACITY_LIST)) keep = false;
+                else if (tile_outside_edges(R.ea, R.eb, R.ec, tile_x0, tile_y0px)) keep = false;
             }
         }
         // 2. compaction
@@ -3422,7 +3427,10 @@ __device__ __forceinline__ void raster_tile(const RasterParams &P) {
         else if (rows_binned) {
             // (the per-pixel surface_id of the opacity pass lives in the owning lane's registers: frames with opacity batches walk)
             if constexpr (ROWS) {
-                const bool row_mode = !P.has_opacity;
+                // (until the end of round 4 a frame with an opacity pass walked every round: ONE translucent pane made the reduced box grid's
+                // raster kernel 3.6 times slower.  The opacity pass only matters to opaque candidates that carry a profile id (the
+                // surface_id rule, :1044-1048): rounds with such a candidate walk, like rounds with cut-outs -- rows_round)
+                const bool row_mode = true;
                 if (row_mode) row_store.r.key[ly * RXR_TILE_W + lx] = RXR_ZKEY_INIT;  // own cell; published by the barriers of the first staging round
                 scan_lists_rows<X>(P, stage, row_store.r, row_mode, b0, b1, tile_x0, tile_y0px, px, py, fx, fy, vis, surf_profile, &op,
                                    s_sort, pre_n PHASE_ARG);

@@ -383,3 +383,33 @@ def test_brush_preview_with_poisoned_parameters(oracle, product, brush):
     """the brush disc with NaN / inf / negative / denormal position, radius and falloff (rasterizer.rs:1193-1212, :435-458): on terrain
     texels and on missed pixels, bit for bit"""
     compare(oracle, product, lambda api: terrain_scene(api, lights=False, brush=brush, under=False, opacity_terrain=True))
+
+
+def binned_grid_with_panes_scene(api, profiled, second_chunk):
+    """A BINNED frame (a 20 x 20 box lattice: 4800 triangles, row mode) with an opacity pass: translucent panes in a chunk's opacity list
+    in front of the lattice.  `profiled`: every third lattice batch carries the first pane's profile id (its fragments are skipped where
+    that pane is the opacity layer, rasterizer.rs:1044-1048) -- rounds of candidates with such a batch walk, the others take row mode;
+    `second_chunk`: a second chunk with a pane of its own (the exact prefix order: feature level 1)."""
+    cfg = scenes.box_grid_scene(api, n=20, width=640, height=360, profile_every=3 if profiled else 0, profile_id=10)
+    scene = cfg.scene
+    chunk = scene.add_chunk()
+    chunk.add_batch3d_opacity(api.Batch3D.from_box(1.2, 0.2, 1.0, 1.6, 1.2, 0.02).with_computed_normals()
+                              .source(B.PixelSource.Pixel((90, 160, 250, 120))).profile_id(10))
+    chunk.add_batch3d_opacity(api.Batch3D.from_box(2.0, 0.0, 2.4, 1.0, 1.5, 0.02).with_computed_normals()
+                              .source(B.PixelSource.Pixel((250, 120, 60, 90))).profile_id(11))
+    if second_chunk:
+        c2 = scene.add_chunk()
+        c2.add_batch3d_opacity(api.Batch3D.from_box(0.4, 0.1, 3.0, 1.4, 1.0, 0.02).with_computed_normals().source(B.PixelSource.Pixel((60, 250, 90, 140))).profile_id(10))
+        c2.add_batch3d(api.Batch3D.from_box(0.2, 0.0, 3.4, 2.0, 0.8, 0.05).with_computed_normals().source(B.PixelSource.Pixel((200, 200, 40, 255))).profile_id(10))
+    return cfg
+
+
+@pytest.mark.parametrize("profiled,second_chunk", [(False, False), (True, False), (True, True)])
+def test_opacity_pass_over_a_binned_frame_in_row_mode(oracle, product, profiled, second_chunk):
+    """since the end of round 4 a frame with an opacity pass keeps row mode for its rounds of candidates without a profile id (before, one
+    translucent pane made a binned frame's raster kernel 3.6 times slower) and the opacity pass stages candidates of the opacity lists
+    only: the frame must equal the oracle's byte for byte -- the panes blended over the lattice, the profiled batches cut out behind
+    the pane with their id"""
+    got = compare(oracle, product, lambda api: binned_grid_with_panes_scene(api, profiled, second_chunk))
+    plain = scenes.render(scenes.box_grid_scene(product, n=20, width=640, height=360))
+    assert (got != plain).any(axis=2).mean() > 0.02, "the panes change nothing: the test tests nothing"

@@ -50,6 +50,12 @@ def config(api, name):
         return scenes.box_grid_scene(api, n=96, width=1920, height=1080, shader=True)
     if name.startswith("near:"):  # the box lattice seen from among its boxes: binned scenes of LARGE triangles (row mode's other end); near:<distance>
         return scenes.box_grid_scene(api, n=48, width=1920, height=1080, distance=float(name.split(":", 1)[1]))
+    if name == "C5s_pane":  # the reduced box grid + ONE small translucent pane in a chunk's opacity list: an opacity pass in a binned frame
+        cfg = scenes.box_grid_scene(api, n=96, width=1920, height=1080)
+        chunk = cfg.scene.add_chunk()
+        chunk.add_batch3d_opacity(api.Batch3D.from_box(9.0, 1.0, 9.0, 1.2, 1.2, 0.02).with_computed_normals()
+                                  .source(B.PixelSource.Pixel((90, 160, 250, 120))).profile_id(10))
+        return cfg
     if name == "D2":  # 2D tile map: 60 x 34 textured / translucent rectangles + overlays + lines, render_2d mode
         return scenes.tile_map_2d_scene(api, width=1920, height=1080, nx=60, ny=34)
     raise SystemExit(f"unknown config {name}")
