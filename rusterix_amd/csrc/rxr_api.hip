@@ -2009,6 +2009,17 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
     P.list2d_capacity = ctx->list2d_capacity;
     P.any_lights = f->n_lights ? 1u : 0u;
     P.has_opacity = has_opacity ? 1u : 0u;
+    {
+        // frames in which row mode has to work around some candidates (rxr_kernels.hip SPLITR): a kept batch of the opaque pass whose
+        // fragments need their texel's alpha, or -- under an opacity pass -- one that carries a profile id
+        bool split = false;
+        const DevBatch *hb = (const DevBatch *)(st + L.off_b3);
+        for (uint32_t i = 0; i < n_b3 && !split; ++i) {
+            if (hb[i].flags & (DB_SKIP | DB_OPACITY_LIST)) continue;
+            split = (hb[i].flags & (DB_ALPHA_TEST | DB_FULL_ALPHA)) != 0 || (has_opacity && (hb[i].flags & DB_HAS_PROFILE));
+        }
+        P.split_rounds = ((split && !getenv("RXR_NO_SPLIT_ROUNDS")) || getenv("RXR_FORCE_SPLIT_ROUNDS")) ? 1u : 0u;   // (the variables: A-B runs, tests)
+    }
     P.list_capacity = ctx->list_capacity;
     uint8_t *d = (uint8_t *)ctx->d_frame.p;
     P.pv = (const float4 *)(d + L.off_pv);

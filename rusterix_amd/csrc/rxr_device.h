@@ -425,4 +425,7 @@ struct RasterParams {
                                    // batch boxes), or NULL: the raster grid is as wide as the widest span of the launch, workgroup (bx, ty)
                                    // takes column x + bx and leaves at once behind y; the pixels outside the spans get the miss colour from
                                    // k_fill_outside_spans.  Contiguous, non-compact launches only.
+    uint32_t split_rounds;         // some kept opaque-pass batch is a cut-out (DB_ALPHA_TEST / DB_FULL_ALPHA) or, under an opacity pass, carries a
+                                   // profile id: k_raster_rows_cut[_rl] (rxr_upload_frame)
+    uint32_t pad_tail;
 };

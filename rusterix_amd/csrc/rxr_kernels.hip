@@ -2397,6 +2397,7 @@ struct RowLdsT {
     uint32_t raw[RXR_STAGE_TRIS];            // scan_lists_rows: triangle id of every list entry of the round (= of every staged record)
     uint8_t slot[RXR_STAGE_TRIS];            // scan_lists_rows: staged record of candidate k (bytes: 8 workgroups per CU must fit in 160 KB)
     uint8_t chunk_owner[RXR_TILE_THREADS];   // rows_round: first owner of every 64-item chunk of the round's pixel items
+    uint32_t cut[4];                         // rows_round<.., SPLIT>: the round's candidates that the caller has to walk (cut-outs, profiled ones), a bit per candidate
 };
 using RowLds = RowLdsT<RXR_TILE_H>;
 // order-preserving map of non-NaN floats to unsigned integers
@@ -2478,8 +2479,14 @@ static_assert(RXR_ROWS_RING * 4u * (RXR_TILE_THREADS / 64) <= RXR_SORT2D_MAX * 4
 // loop keep (levels 2 - 5).  The others (6 / 7 / 9) take pixel items WITH the compaction since the end of round 4: pixel items alone had
 // cost k_raster_vm_sv 3-4 % on the 1 M-triangle grid in round 3 (its register budget is spent on the interpreter); as 4-pixel runs with
 // the per-wave rings they save k_raster_vm_p 7 % and k_raster_vm_sv 6 % (scan_lists_rows, RXR_ROWS_PIXEL_ITEMS_VM)
-template <bool INDIRECT, bool PIX, uint32_t TH = RXR_TILE_H, bool COMPACT = false>
-__device__ RXR_ROWS_INLINE bool rows_round(const RasterParams &P, Stage &st, RowLdsT<TH> &rl, uint32_t n, uint32_t tile_x0, uint32_t tile_y0px,
+// SPLIT: a round that holds candidates row mode cannot take -- cut-outs, whose fragments need a texel (:1408); candidates with a profile id
+// in a frame with an opacity pass (:1044-1048) -- still runs in row mode for all the others; the ones left over are named in rl.cut and
+// the caller walks them (scan_lists_rows).  Without SPLIT such a round is refused as a whole (returns false), as until the end of round
+// 4 everywhere: two batches with a fence texture among the 96 of the reduced box grid made its raster kernel 2.4 times slower, one in
+// eight 3.2 times.
+// Returns 0 (refused), 1 (done) or -- SPLIT only -- 2 (done, and rl.cut names candidates that are left to walk).
+template <bool INDIRECT, bool PIX, uint32_t TH = RXR_TILE_H, bool COMPACT = false, bool SPLIT = false>
+__device__ RXR_ROWS_INLINE uint32_t rows_round(const RasterParams &P, Stage &st, RowLdsT<TH> &rl, uint32_t n, uint32_t tile_x0, uint32_t tile_y0px,
                                            uint32_t *queue = nullptr) {
     static_assert(TH == 16 || TH == 32, "the bit fields of `geo` and the exact short division hold for offsets below 512");
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -2494,7 +2501,9 @@ __device__ RXR_ROWS_INLINE bool rows_round(const RasterParams &P, Stage &st, Row
         if (!(R.bflags & DB_OPACITY_LIST)) {
             const uint32_t x0 = max(R.bx & 0xFFFFu, tile_x0), x1 = min(R.bx >> 16, tile_x0 + RXR_TILE_W);
             const uint32_t y0 = max(R.by & 0xFFFFu, tile_y0px), y1 = min(R.by >> 16, tile_y0px + TH);
-            if (x0 < x1 && y0 < y1) {
+            if (SPLIT && alpha_test) {
+                alpha_test = x0 < x1 && y0 < y1;   // (left over for the caller's walk -- if its box meets the tile at all; no row items)
+            } else if (x0 < x1 && y0 < y1) {
                 rows = y1 - y0;
                 area = rows * (x1 - x0);
                 // decode data of the pixel items: box origin inside the tile, width, and ceil(8192 / width): for offsets
@@ -2510,6 +2519,8 @@ __device__ RXR_ROWS_INLINE bool rows_round(const RasterParams &P, Stage &st, Row
                 }
                 static_assert(RXR_TILE_W == 16 && RXR_TILE_H <= 32, "bit fields of `geo`");
             }
+        } else if (SPLIT) {
+            alpha_test = false;   // (a candidate of the opacity lists: nothing for the opaque pass, neither in rows nor in the walk)
         }
     }
     // inclusive scan over the workgroup of the areas (each <= 256, at most 128 candidates: below 2^15), or of
@@ -2521,10 +2532,16 @@ __device__ RXR_ROWS_INLINE bool rows_round(const RasterParams &P, Stage &st, Row
     const unsigned long long has = __ballot(rows != 0u);
     // cut-out candidates need a texel per fragment (:1408): such rounds are left to the walk, which keeps the sampling code
     // (and its registers) out of the row loop
-    const unsigned long long cutout = __ballot(rows != 0u && alpha_test);
+    const unsigned long long cutout = SPLIT ? __ballot(alpha_test && tid < n) : __ballot(rows != 0u && alpha_test);
     if (lane == 63u) {
         rl.red[wave] = inc;
-        rl.red[4u + wave] = cutout ? 0x10000u : (uint32_t)__popcll(has);
+        rl.red[4u + wave] = (cutout ? 0x10000u : 0u) + ((!SPLIT && cutout) ? 0u : (uint32_t)__popcll(has));  // (bit 16 and up: waves with such candidates)
+        if constexpr (SPLIT) {
+            if (wave < 2u) {
+                rl.cut[2u * wave] = (uint32_t)cutout;
+                rl.cut[2u * wave + 1u] = (uint32_t)(cutout >> 32);
+            }
+        }
     }
     __syncthreads();
     uint32_t before = 0, total = 0, cands = 0;
@@ -2537,9 +2554,11 @@ __device__ RXR_ROWS_INLINE bool rows_round(const RasterParams &P, Stage &st, Row
     }
     const uint32_t rows_total = PIX ? 0u : (total & 0x1FFFu), area_total = COMPACT ? (total >> 14) : PIX ? total : (total >> 13);
     const uint32_t n_items = COMPACT ? (total & 0x3FFFu) : area_total;  // work items of the round
+    const bool leftovers = SPLIT && cands >= 0x10000u;
+    if constexpr (SPLIT) cands &= 0xFFFFu;
     if (cands == 0u || cands >= 0x10000u || area_total > cands * (uint32_t)RXR_ROW_MODE_MAX_AREA) {
         __syncthreads();  // rl.red is rewritten by the next round
-        return false;
+        return 0u;
     }
     if constexpr (PIX) {
     if (tid < n) {
@@ -2759,7 +2778,7 @@ __device__ RXR_ROWS_INLINE bool rows_round(const RasterParams &P, Stage &st, Row
     }
     }
     __syncthreads();  // the stage and rl are reused by the next round
-    return true;
+    return leftovers ? 2u : 1u;
 }
 
 // after the last round: this lane's pixel takes the z-buffer's winner if it beats what the pixel-parallel rounds found
@@ -2869,7 +2888,10 @@ __device__ __forceinline__ void scan_lists(const RasterParams &P, Stage &st, uin
 // of all list entries of the round go to LDS as soon as their ids are known, the tile-level reject runs on the LDS copies
 // and compacts slot numbers instead of moving records -- one global round trip fewer than scan_lists (which reads the
 // edges from HBM for the reject and the records again for staging).  The round is then handed to rows_round or walked.
-template <int X>
+// SPLITR (k_raster_rows_cut*: frames with cut-out or profiled batches, RasterParams.split_rounds): rounds run in row mode around the
+// candidates row mode cannot take (rows_round SPLIT) instead of being walked as a whole.  A variant of its own, not a branch: compiled into
+// the plain kernels the few extra lines cost the 1 M-triangle grid 2-9 % through register allocation alone (profiles/r04/HISTORY).
+template <int X, bool SPLITR = false>
 __device__ __forceinline__ void scan_lists_rows(const RasterParams &P, Stage &st, RowLds &rl, bool row_mode, uint32_t b0, uint32_t b1,
                                                 uint32_t tile_x0, uint32_t tile_y0px, uint32_t px, uint32_t py, float fx, float fy, Vis &vis,
                                                 int surf_profile, const Vis *opf, uint32_t *queue, uint32_t pre_n PHASE_PARAM) {
@@ -2924,18 +2946,50 @@ __device__ __forceinline__ void scan_lists_rows(const RasterParams &P, Stage &st
 #define RXR_ROWS_PIXEL_ITEMS_VM 1   // (0: the interpreter kernel of plain program sets keeps row items, as until the end of round 4 -- A-B runs)
 #endif
         constexpr bool pixel_items = (RXR_ROWS_PIXEL_ITEMS != 0) && (X < 2 || X == 8 || ((X == 9 || X == 6 || X == 7) && RXR_ROWS_PIXEL_ITEMS_VM != 0));
-        if (row_mode && rows_round<true, pixel_items, RXR_TILE_H, pixel_items && (RXR_ROWS_COMPACT != 0)>(P, st, rl, n, tile_x0, tile_y0px, queue)) {
-            PHASE_MARK(7);
-            continue;
+        if constexpr (SPLITR) {
+            // the candidates every pixel walks: all of the round when row mode refuses it (0), else the ones row mode left over (2: cut-outs;
+            // profiled ones under an opacity pass -- rows_round SPLIT wrote their bits in front of its barriers; their records are untouched)
+            unsigned long long walk_lo = n >= 64u ? ~0ull : ((1ull << n) - 1ull), walk_hi = n > 64u ? (n >= 128u ? ~0ull : ((1ull << (n - 64u)) - 1ull)) : 0ull;
+            const uint32_t rows_ret = row_mode ? rows_round<true, pixel_items, RXR_TILE_H, pixel_items && (RXR_ROWS_COMPACT != 0), pixel_items>(P, st, rl, n, tile_x0, tile_y0px, queue) : 0u;
+            if (rows_ret) {
+                walk_lo = walk_hi = 0ull;
+                if (pixel_items && rows_ret == 2u) {  // (uniform)
+                    const uint32_t c0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)rl.cut[0]), c1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)rl.cut[1]);
+                    const uint32_t c2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)rl.cut[2]), c3 = (uint32_t)__builtin_amdgcn_readfirstlane((int)rl.cut[3]);
+                    walk_lo = (unsigned long long)c0 | ((unsigned long long)c1 << 32);
+                    walk_hi = (unsigned long long)c2 | ((unsigned long long)c3 << 32);
+                }
+                PHASE_MARK(7);
+            }
+            if (walk_lo | walk_hi) {  // (uniform over the workgroup)
+                for (uint32_t h = 0; h < 2u; ++h) {
+                    for (unsigned long long m = h ? walk_hi : walk_lo; m; m &= m - 1ull) {
+                        const uint32_t k = h * 64u + (uint32_t)__builtin_ctzll(m);
+                        const uint32_t sl = rl.slot[k];
+                        const TriSetup &S = *reinterpret_cast<const TriSetup *>(&st.tri[sl * 6u]);
+                        const uint32_t t = st.ids[k];
+                        visit<false, X>(P, S, &P.tri_shade[t], t, sl, px, py, fx, fy, vis, surf_profile, opf);
+                    }
+                }
+                __syncthreads();  // the stage is reused by the next round
+            } else if (!rows_ret) {
+                __syncthreads();
+            }
+            PHASE_MARK(10);
+        } else {
+            if (row_mode && rows_round<true, pixel_items, RXR_TILE_H, pixel_items && (RXR_ROWS_COMPACT != 0)>(P, st, rl, n, tile_x0, tile_y0px, queue)) {
+                PHASE_MARK(7);
+                continue;
+            }
+            for (uint32_t k = 0; k < n; ++k) {
+                const uint32_t sl = rl.slot[k];
+                const TriSetup &S = *reinterpret_cast<const TriSetup *>(&st.tri[sl * 6u]);
+                const uint32_t t = st.ids[k];
+                visit<false, X>(P, S, &P.tri_shade[t], t, sl, px, py, fx, fy, vis, surf_profile, opf);
+            }
+            __syncthreads();  // the stage is reused by the next round
+            PHASE_MARK(10);
         }
-        for (uint32_t k = 0; k < n; ++k) {
-            const uint32_t sl = rl.slot[k];
-            const TriSetup &S = *reinterpret_cast<const TriSetup *>(&st.tri[sl * 6u]);
-            const uint32_t t = st.ids[k];
-            visit<false, X>(P, S, &P.tri_shade[t], t, sl, px, py, fx, fy, vis, surf_profile, opf);
-        }
-        __syncthreads();  // the stage is reused by the next round
-        PHASE_MARK(10);
     }
 }
 
@@ -3287,7 +3341,7 @@ struct RowStore<false> {};
 // SPANS: the kernel looks RasterParams.row_spans up (sparse frames).  The two common level-0 kernels of binned scenes exist in both forms
 // (k_raster_rows[_rl] / ..._sp): the look-up in front of every tile cost the dense bench frame 0.6 % when every kernel carried it
 // (profiles/r04/row_spans_lookup_cost_bench.txt); the small-scene kernels never take spans, the rarer levels always check.
-template <bool FUSED, int X, bool ROWS = false, bool RL = false, bool SPANS = (X != 0)>
+template <bool FUSED, int X, bool ROWS = false, bool RL = false, bool SPANS = (X != 0), bool SPLITR = false>
 __device__ __forceinline__ void raster_tile(const RasterParams &P) {
     __shared__ Stage stage;
     __shared__ uint32_t s_bin[4];
@@ -3432,7 +3486,7 @@ __device__ __forceinline__ void raster_tile(const RasterParams &P) {
                 // surface_id rule, :1044-1048): rounds with such a candidate walk, like rounds with cut-outs -- rows_round)
                 const bool row_mode = true;
                 if (row_mode) row_store.r.key[ly * RXR_TILE_W + lx] = RXR_ZKEY_INIT;  // own cell; published by the barriers of the first staging round
-                scan_lists_rows<X>(P, stage, row_store.r, row_mode, b0, b1, tile_x0, tile_y0px, px, py, fx, fy, vis, surf_profile, &op,
+                scan_lists_rows<X, SPLITR>(P, stage, row_store.r, row_mode, b0, b1, tile_x0, tile_y0px, px, py, fx, fy, vis, surf_profile, &op,
                                    s_sort, pre_n PHASE_ARG);
                 if (tid == 0 && my_bin_count) P.bin_count[bin] = 0u;  // (a non-empty list went through the barriers of a round)
                 PHASE_MARK(1);
@@ -3722,6 +3776,11 @@ extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_ROWS_WAVES_PE
 // ... and for sparse frames (RasterParams.row_spans)
 extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_ROWS_WAVES_PER_SIMD) k_raster_rows_sp(RasterParams) { raster_tile<false, 0, true, false, true>(kernarg_params_early()); }
 extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_ROWS_WAVES_PER_SIMD) k_raster_rows_rl_sp(RasterParams) { raster_tile<false, 0, true, true, true>(kernarg_params_early()); }
+// ... and for frames with cut-out batches (texel alpha) or, under an opacity pass, batches with a profile id (RasterParams.split_rounds):
+// rounds in row mode AROUND such candidates (scan_lists_rows SPLITR) -- two batches with a fence texture among the 96 of the reduced box
+// grid: 98.5 -> 72 us, one in eight: 131 -> 79 us; kernels of their own so that the plain ones stay what they are
+extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_ROWS_WAVES_PER_SIMD) k_raster_rows_cut(RasterParams) { raster_tile<false, 0, true, false, true, true>(kernarg_params_early()); }
+extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_ROWS_WAVES_PER_SIMD) k_raster_rows_cut_rl(RasterParams) { raster_tile<false, 0, true, true, true, true>(kernarg_params_early()); }
 // two tiles per workgroup (raster_tile_pair): binned scenes without an opacity pass, launches whose tile rows are adjacent
 #ifndef RXR_PAIR_WAVES_PER_SIMD
 #define RXR_PAIR_WAVES_PER_SIMD 8
@@ -3964,6 +4023,9 @@ extern "C" void rxr_launch_raster_grid(const RasterParams *P, uint32_t grid_x, h
             const dim3 pairs(P->tiles_x, (P->tiles_y + 1u) / 2u);
             if (rl) RXR_LAUNCH(k_raster_pair_rl, pairs, dim3(RXR_TILE_THREADS), s, *P);
             else RXR_LAUNCH(k_raster_pair, pairs, dim3(RXR_TILE_THREADS), s, *P);
+        } else if (P->split_rounds) {  // (these two look the row spans up themselves when there are any: SPANS)
+            if (rl) RXR_LAUNCH(k_raster_rows_cut_rl, tiles, dim3(RXR_TILE_THREADS), s, *P);
+            else RXR_LAUNCH(k_raster_rows_cut, tiles, dim3(RXR_TILE_THREADS), s, *P);
         } else if (P->row_spans) {
             if (rl) RXR_LAUNCH(k_raster_rows_rl_sp, tiles, dim3(RXR_TILE_THREADS), s, *P);
             else RXR_LAUNCH(k_raster_rows_sp, tiles, dim3(RXR_TILE_THREADS), s, *P);

@@ -307,10 +307,11 @@ def box_grid_shader():
 
 
 def box_grid_scene(api, n=289, width=7680, height=4320, tile_size=40, sample_mode=B.SAMPLE_LINEAR, boxes_per_batch=None, shader=False,
-                   distance=None, profile_every=0, profile_id=10):
+                   distance=None, profile_every=0, profile_id=10, cutout_every=0):
     """C5: n batches of n boxes on an n x n lattice (n=289 -> 1 002 252 triangles); `shader`: every batch runs box_grid_shader();
     `distance`: the orbit camera's (default: the whole lattice in view; a small one puts the camera among the boxes, across whose
-    near plane many triangles then lie); `profile_every` = k > 0: every k-th batch carries `profile_id` (what an opacity pass cuts out)."""
+    near plane many triangles then lie); `profile_every` = k > 0: every k-th batch carries `profile_id` (what an opacity pass cuts out);
+    `cutout_every` = k > 0: every k-th batch takes a texture with holes (texel alpha 0: fragments that are not written, rasterizer.rs:1408)."""
     rng = _rng(200)
     spacing, size = 0.2, 0.16
     tmpl = api.Batch3D.from_box(0.0, 0.0, 0.0, size, size, size)
@@ -330,13 +331,14 @@ def box_grid_scene(api, n=289, width=7680, height=4320, tile_size=40, sample_mod
             is_.append(ti + np.uint32(24 * bx))
             uvs.append(tuv)
         b = api.Batch3D.new(np.concatenate(vs), np.concatenate(is_), np.concatenate(uvs))
-        b = (b.source(B.PixelSource.StaticTileIndex(bz % 16)).repeat_mode(B.REPEAT_REPEAT_XY).with_computed_normals())
+        tile = 16 if (cutout_every and bz % cutout_every == 0) else bz % 16
+        b = (b.source(B.PixelSource.StaticTileIndex(tile)).repeat_mode(B.REPEAT_REPEAT_XY).with_computed_normals())
         if shader_index is not None:
             b.shader(shader_index)
         if profile_every and bz % profile_every == 0:
             b.profile_id(profile_id)
         scene.add_d3_static(b)
-    assets = api.Assets.default().textures([B.Tile.from_texture(noise_texture(300 + k)) for k in range(16)])
+    assets = api.Assets.default().textures([B.Tile.from_texture(noise_texture(300 + k)) for k in range(16)] + [B.Tile.from_texture(fence_texture(7))])
     extent = n * spacing
     cam = api.D3OrbitCamera.new()
     cam.center = (extent / 2, 0.0, extent / 2)

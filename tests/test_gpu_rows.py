@@ -199,3 +199,30 @@ def test_pairs_of_tiles_per_workgroup(oracle, product, monkeypatch, variant):
         for cfg in (lambda api: scenes.teapot_scene(api, width=640, height=360, logo_size=64), lambda api: scenes.box_grid_scene(api, n=40, width=640, height=360)):
             got, ref = scenes.render(cfg(product)), scenes.render(cfg(oracle))
             assert np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("cutout_every,with_pane", [(3, False), (2, False), (7, True)])
+def test_rounds_run_in_row_mode_around_cut_out_and_profiled_candidates(oracle, product, cutout_every, with_pane, monkeypatch):
+    """Binned frames in which some batches are textured with holes (texel alpha 0: fragments that are not written, rasterizer.rs:1408) or --
+    under an opacity pass -- carry a profile id: k_raster_rows_cut* runs every round in row mode for the plain candidates and walks only
+    the others (scan_lists_rows SPLITR; before, one such candidate sent the whole round to the walk).  The frame equals the oracle's and
+    the one rendered with the plain kernels (RXR_NO_SPLIT_ROUNDS), byte for byte; holes show what lies behind them."""
+    from rusterix_amd import binding as B
+
+    def build(api):
+        cfg = scenes.box_grid_scene(api, n=20, width=640, height=360, cutout_every=cutout_every, profile_every=5 if with_pane else 0, profile_id=10)
+        if with_pane:
+            chunk = cfg.scene.add_chunk()
+            chunk.add_batch3d_opacity(api.Batch3D.from_box(1.2, 0.2, 1.0, 1.6, 1.2, 0.02).with_computed_normals()
+                                      .source(B.PixelSource.Pixel((90, 160, 250, 120))).profile_id(10))
+        return cfg
+
+    ref = scenes.render(build(oracle)).copy()
+    got = scenes.render(build(product)).copy()
+    assert np.array_equal(got, ref), f"{(got != ref).any(axis=2).sum()} pixels differ from the oracle"
+    monkeypatch.setenv("RXR_NO_SPLIT_ROUNDS", "1")
+    plain_kernels = scenes.render(build(product)).copy()
+    assert np.array_equal(plain_kernels, ref)
+    monkeypatch.delenv("RXR_NO_SPLIT_ROUNDS")
+    solid = scenes.render(scenes.box_grid_scene(product, n=20, width=640, height=360))
+    assert (got != solid).any(axis=2).mean() > 0.01, "the holes change nothing: the test tests nothing"

@@ -56,6 +56,8 @@ def config(api, name):
         chunk.add_batch3d_opacity(api.Batch3D.from_box(9.0, 1.0, 9.0, 1.2, 1.2, 0.02).with_computed_normals()
                                   .source(B.PixelSource.Pixel((90, 160, 250, 120))).profile_id(10))
         return cfg
+    if name.startswith("C5s_cutout:"):  # the reduced box grid with every k-th batch textured with holes (a fence): cut-out candidates in binned rounds
+        return scenes.box_grid_scene(api, n=96, width=1920, height=1080, cutout_every=int(name.split(":", 1)[1]))
     if name == "D2":  # 2D tile map: 60 x 34 textured / translucent rectangles + overlays + lines, render_2d mode
         return scenes.tile_map_2d_scene(api, width=1920, height=1080, nx=60, ny=34)
     raise SystemExit(f"unknown config {name}")
