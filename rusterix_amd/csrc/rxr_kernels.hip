@@ -3805,6 +3805,9 @@ __device__ __forceinline__ const RasterParams &kernarg_params() {
 #endif
 extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_CHUNK_WAVES_PER_SIMD) k_raster_chunk(RasterParams) { raster_tile<false, 1, true>(kernarg_params()); }
 extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_CHUNK_WAVES_PER_SIMD) k_raster_chunk_rl(RasterParams) { raster_tile<false, 1, true, true>(kernarg_params()); }
+// ... and with rounds in row mode around cut-out / profiled candidates (RasterParams.split_rounds), as k_raster_rows_cut*
+extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_CHUNK_WAVES_PER_SIMD) k_raster_chunk_cut(RasterParams) { raster_tile<false, 1, true, false, true, true>(kernarg_params()); }
+extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_CHUNK_WAVES_PER_SIMD) k_raster_chunk_cut_rl(RasterParams) { raster_tile<false, 1, true, true, true, true>(kernarg_params()); }
 extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_VM_WAVES_PER_SIMD) k_raster_vm(RasterParams) { raster_tile<false, 2, true>(kernarg_params()); }
 // the same with the wave-uniform stack pointer, for sets whose programs all have static stack depths (kernel_level 3)
 extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_VM_WAVES_PER_SIMD) k_raster_vm_s(RasterParams) { raster_tile<false, 4, true>(kernarg_params()); }
@@ -4008,7 +4011,10 @@ extern "C" void rxr_launch_raster_grid(const RasterParams *P, uint32_t grid_x, h
     else if (P->kernel_level == 3u) RXR_LAUNCH(k_raster_vm_s, tiles, dim3(RXR_TILE_THREADS), s, *P);
     else if (P->kernel_level == 2u) RXR_LAUNCH(k_raster_vm, tiles, dim3(RXR_TILE_THREADS), s, *P);
     else if (P->kernel_level == 1u) {
-        if (rl) RXR_LAUNCH(k_raster_chunk_rl, tiles, dim3(RXR_TILE_THREADS), s, *P);
+        const bool cut = P->split_rounds && P->fused_small == 0u && (P->flags & RXR_FLAG_D3_ACTIVE);  // (binned frames: the others never reach scan_lists_rows)
+        if (cut && rl) RXR_LAUNCH(k_raster_chunk_cut_rl, tiles, dim3(RXR_TILE_THREADS), s, *P);
+        else if (cut) RXR_LAUNCH(k_raster_chunk_cut, tiles, dim3(RXR_TILE_THREADS), s, *P);
+        else if (rl) RXR_LAUNCH(k_raster_chunk_rl, tiles, dim3(RXR_TILE_THREADS), s, *P);
         else RXR_LAUNCH(k_raster_chunk, tiles, dim3(RXR_TILE_THREADS), s, *P);
     } else if (P->fused_small == 1u) RXR_LAUNCH(k_raster_fused, tiles, dim3(RXR_TILE_THREADS), s, *P);
     else if (P->fused_small == 0u && (P->flags & RXR_FLAG_D3_ACTIVE) && !no_rows) {
