@@ -707,7 +707,7 @@ __device__ __forceinline__ void shade3d_begin(const RasterParams &P, const TriSh
     uint32_t texel;
     bool desc_in_record = false;  // wave-uniform
 #if RXR_DESC_IN_TRISHADE
-    if constexpr (!lvl1<X>) desc_in_record = rxm::wave_all((S.pad[1] & TS_DESC_VALID) != 0u);
+    if constexpr (!lvl1<X> || X == 1) desc_in_record = rxm::wave_all((S.pad[1] & TS_DESC_VALID) != 0u);  // (terrain batches leave the words zero: make_setup)
 #endif
     if (desc_in_record) {  // (make_setup: the descriptor as the record carries it -- the same sampler on the same words)
         const uint32_t p0 = S.pad[0], p1 = S.pad[1];
