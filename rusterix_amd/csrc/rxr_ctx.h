@@ -148,6 +148,7 @@ struct rxr_ctx {
     // (one module per template level 2 / 7 / 8, compiled when the first frame that needs it is launched; jit_source: the generated
     // programs of the current set, empty when the set is not covered)
     void *jit_module[3] = {nullptr, nullptr, nullptr}, *jit_fn[3] = {nullptr, nullptr, nullptr};
+    void *jit_fn_cut[3] = {nullptr, nullptr, nullptr};   // k_raster_jit_cut of the same module (levels 7 / 8), or null
     bool jit_failed[3] = {false, false, false};
     bool jit_palette_miss = false;   // a compiled frame met a PaletteIndex without a colour: this set runs interpreted from now on (VMF_JIT_PALETTE_MISS)
     // background mode (the default): the compilation of a level runs in a child process (rxr_jitc); the interpreter renders until it is done

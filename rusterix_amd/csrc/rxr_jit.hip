@@ -1053,7 +1053,7 @@ void rxr_jit_drop(rxr_ctx *ctx) {
     ctx->jit_palette_miss = false;
     for (int k = 0; k < 3; ++k) {
         if (ctx->jit_module[k]) (void)hipModuleUnload((hipModule_t)ctx->jit_module[k]);
-        ctx->jit_module[k] = ctx->jit_fn[k] = nullptr;
+        ctx->jit_module[k] = ctx->jit_fn[k] = ctx->jit_fn_cut[k] = nullptr;
         ctx->jit_failed[k] = false;
         detach(ctx, k);
     }
@@ -1190,6 +1190,12 @@ bool ensure_level(rxr_ctx *ctx, int slot) {
     }
     ctx->jit_module[slot] = mod;
     ctx->jit_fn[slot] = fn;
+    hipFunction_t fn_cut = nullptr;
+    ctx->jit_fn_cut[slot] = nullptr;
+    if (levels[slot] != 2) {  // (template level 2 has none)
+        if (hipModuleGetFunction(&fn_cut, mod, "k_raster_jit_cut") == hipSuccess) ctx->jit_fn_cut[slot] = (void *)fn_cut;
+        else (void)hipGetLastError();   // (a code object of an older build in the disk cache: the plain kernel serves; the error must not stay behind)
+    }
     char msg[200];
     snprintf(msg, sizeof msg, "compiled: template level %d, %zu bytes of code object, %.2f s%s", levels[slot], obj.size(), seconds, seconds == 0.0 ? " (cached)" : "");
     ctx->jit_info = msg;
@@ -1208,9 +1214,12 @@ bool rxr_jit_launch(rxr_ctx *ctx, const RasterParams *P, hipStream_t s) {
     RasterParams params = *P;
     size_t size = sizeof(params);
     void *config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &params, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+    // (frames with cut-out or profiled batches: rounds in row mode around them -- binned frames only, the others never reach that code)
+    const bool cut = P->split_rounds && ctx->jit_fn_cut[slot] && P->fused_small == 0u && (P->flags & RXR_FLAG_D3_ACTIVE);
+    const hipFunction_t kernel = (hipFunction_t)(cut ? ctx->jit_fn_cut[slot] : ctx->jit_fn[slot]);
     hipEvent_t e0, e1;
     if (rxr_launch_times && rxr_launch_pair(&e0, &e1))  // (kernel timing, rxr_launch.h; this form takes the grid in THREADS)
-        return hipExtModuleLaunchKernel((hipFunction_t)ctx->jit_fn[slot], P->tiles_x * RXR_TILE_THREADS, P->tiles_y, 1, RXR_TILE_THREADS, 1, 1, 0, s, nullptr, config,
+        return hipExtModuleLaunchKernel(kernel, P->tiles_x * RXR_TILE_THREADS, P->tiles_y, 1, RXR_TILE_THREADS, 1, 1, 0, s, nullptr, config,
                                         e0, e1, 0) == hipSuccess;
-    return hipModuleLaunchKernel((hipFunction_t)ctx->jit_fn[slot], P->tiles_x, P->tiles_y, 1, RXR_TILE_THREADS, 1, 1, 0, s, nullptr, config) == hipSuccess;
+    return hipModuleLaunchKernel(kernel, P->tiles_x, P->tiles_y, 1, RXR_TILE_THREADS, 1, 1, 0, s, nullptr, config) == hipSuccess;
 }

@@ -3748,6 +3748,10 @@ __device__ __forceinline__ const RasterParams &kernarg_params_early() { return *
 #define RXR_JIT_WAVES_PER_SIMD (RXR_JIT_LEVEL == 2 ? 7 : 8)
 #endif
 extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_JIT_WAVES_PER_SIMD) k_raster_jit(RasterParams) { raster_tile<false, RXR_JIT_LEVEL, true>(kernarg_params_early()); }
+#if RXR_JIT_LEVEL != 2
+// ... and for frames with cut-out or profiled batches (RasterParams.split_rounds), as k_raster_rows_cut: the same code object carries both
+extern "C" __global__ void __launch_bounds__(RXR_TILE_THREADS, RXR_JIT_WAVES_PER_SIMD) k_raster_jit_cut(RasterParams) { raster_tile<false, RXR_JIT_LEVEL, true, false, true, true>(kernarg_params_early()); }
+#endif
 #else
 #ifndef RXR_RASTER_KERNARG_IN_PLACE
 #define RXR_RASTER_KERNARG_IN_PLACE 1

@@ -331,3 +331,18 @@ def test_the_reference_crates_own_test_programs(oracle, product, monkeypatch):
     left = got[:, : W // 2 - 1, :3].reshape(-1, 3)
     assert (left == left[0]).all() and 127 <= int(left[0, 0]) <= 128            # 4 * 0.125
     assert len(np.unique(got[:, W // 2 + 1:, 0])) >= 4                           # fib(0 .. 5) / 8 = 0, 1/8, 1/8, 2/8, 3/8, 5/8
+
+
+def test_compiled_programs_on_a_binned_frame_with_cut_out_batches(oracle, product, monkeypatch):
+    """a program on every batch of a binned lattice AND every third batch textured with holes: the compiled kernel's cut variant
+    (k_raster_jit_cut: rounds in row mode around the cut-out candidates) gives the interpreter's and the oracle's frame, and the frame of
+    the plain compiled kernel (RXR_NO_SPLIT_ROUNDS)"""
+    build = lambda api: scenes.box_grid_scene(api, n=20, width=640, height=360, shader=True, cutout_every=3)   # noqa: E731
+    got, info = three_ways(oracle, product, monkeypatch, build)
+    monkeypatch.setenv("RXR_SHADER_JIT", "1")
+    monkeypatch.setenv("RXR_NO_SPLIT_ROUNDS", "1")
+    plain = scenes.render(build(product)).copy()
+    assert jit_info(product).startswith("compiled:")
+    assert np.array_equal(plain, got)
+    solid = scenes.render(scenes.box_grid_scene(oracle, n=20, width=640, height=360, shader=True))
+    assert (got != solid).any(axis=2).mean() > 0.01, "the holes change nothing: the test tests nothing"

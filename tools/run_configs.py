@@ -63,6 +63,8 @@ def config(api, name):
         cfg.scene.lights([B.Light(B.LIGHT_POINT).with_position((float(rng.uniform(0, 19.2)), 1.2, float(rng.uniform(0, 19.2))))
                           .with_color((1.0, 0.9, 0.7)).with_intensity(1.5).with_start_distance(1.0).with_end_distance(6.0).compile() for _ in range(k)])
         return cfg
+    if name.startswith("C5s_shader_cutout:"):  # ... with the per-batch program on every batch as well (the compiled kernel's cut variant)
+        return scenes.box_grid_scene(api, n=96, width=1920, height=1080, shader=True, cutout_every=int(name.split(":", 1)[1]))
     if name.startswith("C5s_cutout:"):  # the reduced box grid with every k-th batch textured with holes (a fence): cut-out candidates in binned rounds
         return scenes.box_grid_scene(api, n=96, width=1920, height=1080, cutout_every=int(name.split(":", 1)[1]))
     if name == "D2":  # 2D tile map: 60 x 34 textured / translucent rectangles + overlays + lines, render_2d mode
