@@ -2282,11 +2282,22 @@ __device__ __forceinline__ void visit(const RasterParams &P, const TriSetup &S, 
             take = fragment_alpha_is_255_full<X>(P, shade, S.batch, alpha, beta, z, fx, fy);
         } else if (!OPACITY && (S.bflags & DB_ALPHA_TEST)) {
             // the fragment is only written when its encoded alpha is 255 (:1408): sample it now
-            const DevBatch &B = P.batches3d[S.batch];
             const TriShade H = *shade;
             float u, v;
             fragment_uv(H, alpha, beta, gamma, u, v);
-            uint32_t texel = batch_texel<X>(P, B, u, v, 0.0f, 0.0f);  // never a terrain batch: those carry DB_FULL_ALPHA
+            uint32_t texel;
+#if RXR_DESC_IN_TRISHADE
+            // (the candidate is the same for every lane, and so is its record: the descriptor it carries -- make_setup -- leads straight to
+            // the texels; through the batch header and the descriptor table every cut-out candidate of a tile cost two more round trips)
+            if (H.pad[1] & TS_DESC_VALID) {
+                const DevTexDesc d{H.pad[0], H.pad[1] & 0x1FFFu, (H.pad[1] >> 13) & 0x1FFFu, (H.pad[1] >> 28) & 3u};
+                texel = sample_texture(d, texel_base(P, d), u, v, P.sample_mode, (H.pad[1] >> 26) & 3u);
+            } else
+#endif
+            {
+                const DevBatch &B = P.batches3d[S.batch];
+                texel = batch_texel<X>(P, B, u, v, 0.0f, 0.0f);  // never a terrain batch: those carry DB_FULL_ALPHA
+            }
             take = (texel >> 24) == 255u;
         }
     }
