@@ -2512,9 +2512,14 @@ __device__ RXR_ROWS_INLINE uint32_t rows_round(const RasterParams &P, Stage &st,
         if (!(R.bflags & DB_OPACITY_LIST)) {
             const uint32_t x0 = max(R.bx & 0xFFFFu, tile_x0), x1 = min(R.bx >> 16, tile_x0 + RXR_TILE_W);
             const uint32_t y0 = max(R.by & 0xFFFFu, tile_y0px), y1 = min(R.by >> 16, tile_y0px + TH);
-            if (SPLIT && alpha_test) {
+            // (SPLIT with the compaction: a plain cut-out -- its fragments need a texel's alpha and nothing else -- stays a row candidate, marked
+            // in bit 31 of `geo`: the drain samples for the fragments that would win their pixel.  Half of the reduced box grid's batches
+            // fenced: 141 us with every such candidate walked by every pixel)
+            const bool cut_in_rows = SPLIT && COMPACT && (R.bflags & DB_ALPHA_TEST) && !(R.bflags & DB_FULL_ALPHA) && !(P.has_opacity && (R.bflags & DB_HAS_PROFILE));
+            if (SPLIT && alpha_test && !cut_in_rows) {
                 alpha_test = x0 < x1 && y0 < y1;   // (left over for the caller's walk -- if its box meets the tile at all; no row items)
             } else if (x0 < x1 && y0 < y1) {
+                if (cut_in_rows) alpha_test = false;
                 rows = y1 - y0;
                 area = rows * (x1 - x0);
                 // decode data of the pixel items: box origin inside the tile, width, and ceil(8192 / width): for offsets
@@ -2524,11 +2529,13 @@ __device__ RXR_ROWS_INLINE uint32_t rows_round(const RasterParams &P, Stage &st,
                     // (runs per row 1..4, then ceil(8192 / runs) for the same exact short division)
                     const uint32_t segs = (w + 3u) >> 2;
                     items = rows * segs;
-                    geo = (x0 - tile_x0) | ((y0 - tile_y0px) << 4) | (w << 9) | (segs << 14) | (((8192u + segs - 1u) / segs) << 17);
+                    geo = (x0 - tile_x0) | ((y0 - tile_y0px) << 4) | (w << 9) | (segs << 14) | (((8192u + segs - 1u) / segs) << 17) | (cut_in_rows ? 0x80000000u : 0u);
                 } else {
                     geo = (x0 - tile_x0) | ((y0 - tile_y0px) << 4) | (w << 9) | (((8192u + w - 1u) / w) << 14);
                 }
                 static_assert(RXR_TILE_W == 16 && RXR_TILE_H <= 32, "bit fields of `geo`");
+            } else if (cut_in_rows) {
+                alpha_test = false;   // (its box misses the tile: nothing to do anywhere)
             }
         } else if (SPLIT) {
             alpha_test = false;   // (a candidate of the opacity lists: nothing for the opaque pass, neither in rows nor in the walk)
@@ -2635,7 +2642,7 @@ __device__ RXR_ROWS_INLINE uint32_t rows_round(const RasterParams &P, Stage &st,
             // q2 = (ec2, v0x, v0y, v1x)  q3 = (v1y, v2x, v2y, area)  q4 = (iz0, iz1, iz2, batch)  q5 = (PRE acx, PRE acy, PRE r, triangle id)
             static_assert(__builtin_offsetof(TriSetup, v0x) == 36 && __builtin_offsetof(TriSetup, area) == 60 && __builtin_offsetof(TriSetup, iz0) == 64 &&
                           __builtin_offsetof(TriSetup, bx) == 80 && __builtin_offsetof(TriSetup, profile_id) == 92, "the drain's view of a staged record");
-            const float fx = (float)((e >> 8) & 0xFFu) + ((float)tile_x0 + 0.5f), fy = (float)((e >> 16) & 0xFFu) + ((float)tile_y0px + 0.5f);  // (exact sums: the item's own fx, fy)
+            const float fx = (float)((e >> 8) & (SPLIT ? 0x7Fu : 0xFFu)) + ((float)tile_x0 + 0.5f), fy = (float)((e >> 16) & 0xFFu) + ((float)tile_y0px + 0.5f);  // (exact sums: the item's own fx, fy)
             float alpha, beta, z;
             bary_depth<true>(q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, q4.z, fx, fy, alpha, beta, z, q5.x, q5.y, q5.z);
 #if RXR_ROWS_DIAG == 1
@@ -2645,10 +2652,28 @@ __device__ RXR_ROWS_INLINE uint32_t rows_round(const RasterParams &P, Stage &st,
 #endif
             {
                 const unsigned long long key = ((unsigned long long)z_order_bits(z + 0.0f) << 32) | __float_as_uint(q5.w);  // -0 -> +0: they compare equal
-                unsigned long long *const cell = &rl.key[TH == 16 ? (e >> 24) : ((e >> 16) & 0xFFu) * RXR_TILE_W + ((e >> 8) & 0xFFu)];
+                unsigned long long *const cell = &rl.key[TH == 16 ? (e >> 24) : ((e >> 16) & 0xFFu) * RXR_TILE_W + ((e >> 8) & (SPLIT ? 0x7Fu : 0xFFu))];
                 // (cells only ever decrease: a stale value is merely conservative.  A relaxed workgroup-scope atomic load, so that the
                 // read is an LDS instruction)
-                if (key < __hip_atomic_load(cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) atomicMin(cell, key);
+                bool wins = key < __hip_atomic_load(cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if constexpr (SPLIT) {
+                    // a cut-out candidate's fragment is only written when its texel's alpha is 255 (:1408): visit()'s test, for the fragments
+                    // that would take their pixel (the same expressions: fragment_uv of the same barycentrics, the same sampler)
+                    if (wins && (e & 0x8000u)) {
+                        const TriShade H = P.tri_shade[__float_as_uint(q5.w)];
+                        float u, v;
+                        fragment_uv(H, alpha, beta, 1.0f - alpha - beta, u, v);
+                        uint32_t texel;
+                        if (H.pad[1] & TS_DESC_VALID) {
+                            const DevTexDesc d{H.pad[0], H.pad[1] & 0x1FFFu, (H.pad[1] >> 13) & 0x1FFFu, (H.pad[1] >> 28) & 3u};
+                            texel = sample_texture(d, texel_base(P, d), u, v, P.sample_mode, (H.pad[1] >> 26) & 3u);
+                        } else {
+                            texel = batch_texel<0>(P, P.batches3d[__float_as_uint(q4.w)], u, v, 0.0f, 0.0f);
+                        }
+                        wins = (texel >> 24) == 255u;
+                    }
+                }
+                if (wins) atomicMin(cell, key);
             }
         }
     };
@@ -2661,7 +2686,7 @@ __device__ RXR_ROWS_INLINE uint32_t rows_round(const RasterParams &P, Stage &st,
             while (rl.row_start[k + 1u] <= item) ++k;  // candidates without pixels share their successor's start; row_start[n] = n_items > item
             const uint32_t g = rl.raw[k];
             const uint32_t local = item - rl.row_start[k], segs = (g >> 14) & 7u;
-            const uint32_t ry = (local * (g >> 17)) >> 13, sx = local - ry * segs;
+            const uint32_t ry = (local * ((g >> 17) & 0x3FFFu)) >> 13, sx = local - ry * segs;
             const uint32_t lx = (g & 15u) + 4u * sx, ly = ((g >> 4) & 31u) + ry;
             valid = min(((g >> 9) & 31u) - 4u * sx, 4u);
             const uint32_t sl = INDIRECT ? (uint32_t)rl.slot[k] : k;
@@ -2671,7 +2696,7 @@ __device__ RXR_ROWS_INLINE uint32_t rows_round(const RasterParams &P, Stage &st,
             a0 = S.ea[0]; a1 = S.ea[1]; a2 = S.ea[2];
             t0 = S.eb[0] * fy; t1 = S.eb[1] * fy; t2 = S.eb[2] * fy;
             c0 = S.ec[0]; c1 = S.ec[1]; c2 = S.ec[2];
-            entry = sl | (lx << 8) | (ly << 16) | ((ly * RXR_TILE_W + lx) << 24);
+            entry = sl | (lx << 8) | (ly << 16) | ((ly * RXR_TILE_W + lx) << 24) | (SPLIT ? ((g >> 31) << 15) : 0u);   // (bit 15: a cut-out candidate's item)
             static_assert(RXR_STAGE_TRIS <= 256 && RXR_TILE_W == 16 && TH <= 32, "bit fields of a ring entry");
         }
 #if RXR_ROWS_UNROLL_PX
