@@ -63,6 +63,31 @@ def config(api, name):
         cfg.scene.lights([B.Light(B.LIGHT_POINT).with_position((float(rng.uniform(0, 19.2)), 1.2, float(rng.uniform(0, 19.2))))
                           .with_color((1.0, 0.9, 0.7)).with_intensity(1.5).with_start_distance(1.0).with_end_distance(6.0).compile() for _ in range(k)])
         return cfg
+    if name.startswith("many_batches:"):  # the reduced box grid's 9216 boxes as k x k batches of (96 / k)^2 boxes each (k = 96: one box per batch)
+        k = int(name.split(":", 1)[1])
+        cfg = scenes.box_grid_scene(api, n=96, width=1920, height=1080)
+        rng = np.random.default_rng(200)
+        tmpl = api.Batch3D.from_box(0.0, 0.0, 0.0, 0.16, 0.16, 0.16)
+        tv, ti, tuv, _ = tmpl.geometry()
+        ys = rng.random((96, 96)).astype(np.float32) * np.float32(0.4)
+        scene = api.Scene.empty()
+        per = 96 // k
+        for bz in range(k):
+            for bx in range(k):
+                vs, is_, uvs = [], [], []
+                for j in range(per):
+                    for i in range(per):
+                        v = tv.copy()
+                        v[:, 0] += np.float32((bx * per + i) * 0.2)
+                        v[:, 1] += ys[bz * per + j, bx * per + i]
+                        v[:, 2] += np.float32((bz * per + j) * 0.2)
+                        vs.append(v)
+                        is_.append(ti + np.uint32(24 * (j * per + i)))
+                        uvs.append(tuv)
+                b = api.Batch3D.new(np.concatenate(vs), np.concatenate(is_), np.concatenate(uvs))
+                scene.add_d3_static(b.source(B.PixelSource.StaticTileIndex((bz + bx) % 16)).repeat_mode(B.REPEAT_REPEAT_XY).with_computed_normals())
+        cfg.scene = scene
+        return cfg
     if name.startswith("C5s_shader_cutout:"):  # ... with the per-batch program on every batch as well (the compiled kernel's cut variant)
         return scenes.box_grid_scene(api, n=96, width=1920, height=1080, shader=True, cutout_every=int(name.split(":", 1)[1]))
     if name.startswith("C5s_cutout:"):  # the reduced box grid with every k-th batch textured with holes (a fence): cut-out candidates in binned rounds
