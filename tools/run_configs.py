@@ -50,6 +50,21 @@ def config(api, name):
         return scenes.box_grid_scene(api, n=96, width=1920, height=1080, shader=True)
     if name.startswith("near:"):  # the box lattice seen from among its boxes: binned scenes of LARGE triangles (row mode's other end); near:<distance>
         return scenes.box_grid_scene(api, n=48, width=1920, height=1080, distance=float(name.split(":", 1)[1]))
+    if name.startswith("C5s_panes:"):  # ... with k small translucent panes scattered over the lattice in ONE opacity batch (particles, glass)
+        k = int(name.split(":", 1)[1])
+        cfg = scenes.box_grid_scene(api, n=96, width=1920, height=1080)
+        rng = np.random.default_rng(77)
+        tmpl = api.Batch3D.from_box(0.0, 0.0, 0.0, 0.3, 0.3, 0.01)
+        tv, ti, tuv, _ = tmpl.geometry()
+        vs, is_, uvs = [], [], []
+        for j in range(k):
+            v = tv.copy()
+            v[:, 0] += np.float32(rng.uniform(0.0, 19.0)); v[:, 1] += np.float32(rng.uniform(0.5, 1.5)); v[:, 2] += np.float32(rng.uniform(0.0, 19.0))
+            vs.append(v); is_.append(ti + np.uint32(24 * j)); uvs.append(tuv)
+        chunk = cfg.scene.add_chunk()
+        chunk.add_batch3d_opacity(api.Batch3D.new(np.concatenate(vs), np.concatenate(is_), np.concatenate(uvs)).with_computed_normals()
+                                  .source(B.PixelSource.Pixel((90, 160, 250, 120))))
+        return cfg
     if name == "C5s_pane":  # the reduced box grid + ONE small translucent pane in a chunk's opacity list: an opacity pass in a binned frame
         cfg = scenes.box_grid_scene(api, n=96, width=1920, height=1080)
         chunk = cfg.scene.add_chunk()
