@@ -33,6 +33,8 @@ def config(api, name):
         return scenes.map_scene(api, width=3840, height=2160, n_lights=16)
     if name == "C5":
         return scenes.box_grid_scene(api, n=289, width=7680, height=4320)
+    if name == "C5_4k":  # ... and at 3840 x 2160: 31 triangles per 16 x 16 tile on average, hundreds at the horizon
+        return scenes.box_grid_scene(api, n=289, width=3840, height=2160)
     if name == "C5_16k":  # the 1 M-triangle grid at 15360 x 8640 (132.7 Mpixel: beyond k_blockscan's slot budget, a 531 MB frame)
         return scenes.box_grid_scene(api, n=289, width=15360, height=8640)
     if name == "C5s":  # reduced C5 for a full oracle comparison
