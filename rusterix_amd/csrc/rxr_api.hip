@@ -1874,6 +1874,10 @@ int rxr_upload_frame(rxr_ctx *ctx, const rxr_frame *f) {
         const long v = atol(bc);
         if (v > 0 && v <= 4096) ctx->blockscan_cap = (uint32_t)v;
     }
+    // (frames beyond 8K x 8K tiles: fewer slots per bin keep k_blockscan inside its list budget -- their bins are thinner too; a bin that
+    // overflows sends the frame through the general pipeline as ever)
+    if (!getenv("RXR_BLOCKSCAN_CAP"))
+        while (ctx->blockscan_cap > 64u && (size_t)n_bins * ctx->blockscan_cap > (64u << 20)) ctx->blockscan_cap /= 2u;
     ctx->blockscan_off = !(ctx->blockscan_enabled && !ctx->list_floor && n_t3 > RXR_STAGE_TRIS &&
                            (n_groups > RXR_BLOCKSCAN_SCATTER_GROUPS || n_groups * n_blocks <= RXR_BLOCKSCAN_MAX_WORK) &&
                            (size_t)n_bins * ctx->blockscan_cap <= (64u << 20));
